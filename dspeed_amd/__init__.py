@@ -1,0 +1,23 @@
+"""dspeed_amd -- MI355X-native engine for dspeed's waveform-DSP hot path.
+
+Public surface (mirrors the slice of ``dspeed`` that the hot path needs):
+
+* ``dspeed_amd.processors``        -- processor registry, same names as ``dspeed.processors``
+* ``dspeed_amd.build_processing_chain`` / ``ProcessingChain`` -- JSON recipe -> fused device chain
+* ``dspeed_amd.errors``            -- ``DSPFatal`` / ``ProcessingChainError``
+* ``dspeed_amd.device``            -- device arrays, streams, events
+
+The compute path is the HIP library ``libdspeed_hip.so`` (``python -m dspeed_amd.build``); nothing here
+falls back to the CPU.
+"""
+from .errors import DSPError, DSPFatal, ProcessingChainError  # noqa: F401
+
+__version__ = "0.1.0"
+
+
+def __getattr__(name):
+    if name in ("build_processing_chain", "ProcessingChain"):
+        from . import processing_chain
+
+        return getattr(processing_chain, name)
+    raise AttributeError(name)

@@ -1,0 +1,152 @@
+"""ctypes binding of libdspeed_hip.so (include/dspeed_hip.h).
+
+This is the whole Python <-> device boundary: plain pointers and sizes.  The library is REQUIRED:
+there is no CPU fallback anywhere in dspeed_amd -- if the shared object is missing or a HIP call fails,
+the caller gets an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .errors import DSPFatal
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdspeed_hip.so")
+
+# ---- constants of include/dspeed_hip.h
+OK, ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_TOO_LONG = 0, -1, -2, -3, -4
+E_ZERODIV = 17
+F32, F64, I16, U16, I32, U32 = range(6)
+IO_WF_IN, IO_WF_OUT, IO_SCALAR_IN, IO_SCALAR_OUT, IO_TAPS = range(5)
+ARG_CONST, ARG_INPUT, ARG_REG = range(3)
+(OP_LOAD, OP_STORE, OP_STORE_SCALAR, OP_BL_SUBTRACT, OP_POLE_ZERO, OP_DOUBLE_POLE_ZERO, OP_TRAP_FILTER, OP_TRAP_NORM,
+ OP_ASYM_TRAP, OP_PICKOFF, OP_TIME_POINT_THRESH, OP_MIN_MAX, OP_DWT_HAAR, OP_CONVOLVE, OP_COPY, OP_TRAP_PICKOFF, OP_AMAX,
+ OP_SCALAR_AFFINE) = range(1, 19)
+MAX_OPS, MAX_SLOTS, MAX_IO, MAX_SREGS = 48, 8, 24, 32
+
+
+class IoDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("dtype", C.c_int32), ("len", C.c_int32), ("offset", C.c_int32), ("row_stride", C.c_int64)]
+
+
+class ScalarArg(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("index", C.c_int32), ("value", C.c_double)]
+
+
+class Op(C.Structure):
+    _fields_ = [("opcode", C.c_int32), ("dst", C.c_int32), ("src", C.c_int32), ("io", C.c_int32), ("ip", C.c_int32 * 4),
+                ("sp", ScalarArg * 3)]
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m dspeed_amd.build` (hipcc, gfx950). "
+                           "dspeed_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    pi64 = C.POINTER(C.c_int64)
+    sig = {
+        "dsp_device_count": [C.POINTER(C.c_int)],
+        "dsp_set_device": [C.c_int],
+        "dsp_get_device": [C.POINTER(C.c_int)],
+        "dsp_device_info": [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), pi64, C.POINTER(C.c_int)],
+        "dsp_malloc": [C.POINTER(vp), i64],
+        "dsp_free": [vp],
+        "dsp_host_alloc": [C.POINTER(vp), i64],
+        "dsp_host_free": [vp],
+        "dsp_memset": [vp, C.c_int, i64, vp],
+        "dsp_h2d": [vp, vp, i64],
+        "dsp_d2h": [vp, vp, i64],
+        "dsp_h2d_async": [vp, vp, i64, vp],
+        "dsp_d2h_async": [vp, vp, i64, vp],
+        "dsp_stream_create": [C.POINTER(vp)],
+        "dsp_stream_destroy": [vp],
+        "dsp_stream_sync": [vp],
+        "dsp_sync": [],
+        "dsp_event_create": [C.POINTER(vp)],
+        "dsp_event_destroy": [vp],
+        "dsp_event_record": [vp, vp],
+        "dsp_event_sync": [vp],
+        "dsp_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],
+        "dsp_chain_create": [C.POINTER(Op), C.c_int, C.POINTER(IoDesc), C.c_int, C.POINTER(i32), C.c_int, C.c_int, C.c_int,
+                             C.POINTER(vp)],
+        "dsp_chain_execute": [vp, C.POINTER(vp), i64, vp],
+        "dsp_chain_check": [vp, vp, pi64],
+        "dsp_chain_destroy": [vp],
+        "dsp_chain_geometry": [vp, i64, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "dsp_bl_subtract_f32": [vp, C.c_int, i64, i32, i64, vp, f32, vp, i64, vp, pi64],
+        "dsp_pole_zero_f32": [vp, C.c_int, i64, i32, i64, f32, vp, i64, vp, pi64],
+        "dsp_double_pole_zero_f32": [vp, C.c_int, i64, i32, i64, f32, f32, f32, vp, i64, vp, pi64],
+        "dsp_trap_filter_f32": [vp, C.c_int, i64, i32, i64, i32, i32, vp, i64, vp, pi64],
+        "dsp_trap_norm_f32": [vp, C.c_int, i64, i32, i64, i32, i32, vp, i64, vp, pi64],
+        "dsp_asym_trap_filter_f32": [vp, C.c_int, i64, i32, i64, i32, i32, i32, vp, i64, vp, pi64],
+        "dsp_fixed_time_pickoff_f32": [vp, C.c_int, i64, i32, i64, vp, f32, i32, vp, vp, pi64],
+        "dsp_time_point_thresh_f32": [vp, C.c_int, i64, i32, i64, vp, f32, vp, f32, f32, vp, vp, pi64],
+        "dsp_min_max_f32": [vp, C.c_int, i64, i32, i64, vp, vp, vp, vp, vp, pi64],
+        "dsp_dwt_haar_f32": [vp, C.c_int, i64, i32, i64, i32, i32, vp, i32, i64, vp, pi64],
+        "dsp_convolve_wf_f32": [vp, C.c_int, i64, i32, i64, vp, i32, i32, vp, i32, i64, vp, pi64],
+        "dsp_synth_waveforms": [vp, C.c_int, i64, i32, i64, vp, vp, C.c_uint64, i64, f32, f32, f32, f32, f32, f32, f32, vp],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    for name in ("dsp_last_error", "dsp_version"):
+        getattr(L, name).restype = C.c_char_p
+        getattr(L, name).argtypes = []
+    L.dsp_fatal_message.restype = C.c_char_p
+    L.dsp_fatal_message.argtypes = [C.c_int]
+    L.dsp_chain_kernel_name.restype = C.c_char_p
+    L.dsp_chain_kernel_name.argtypes = [vp]
+    _lib = L
+    return L
+
+
+EXPORTS = [
+    "dsp_device_count", "dsp_set_device", "dsp_get_device", "dsp_device_info", "dsp_malloc", "dsp_free", "dsp_host_alloc",
+    "dsp_host_free", "dsp_memset", "dsp_h2d", "dsp_d2h", "dsp_h2d_async", "dsp_d2h_async", "dsp_stream_create", "dsp_stream_destroy",
+    "dsp_stream_sync", "dsp_sync", "dsp_event_create", "dsp_event_destroy", "dsp_event_record", "dsp_event_sync",
+    "dsp_event_elapsed_ms", "dsp_last_error", "dsp_fatal_message", "dsp_version", "dsp_chain_create", "dsp_chain_execute",
+    "dsp_chain_check", "dsp_chain_destroy", "dsp_chain_geometry", "dsp_chain_kernel_name", "dsp_bl_subtract_f32", "dsp_pole_zero_f32",
+    "dsp_double_pole_zero_f32", "dsp_trap_filter_f32", "dsp_trap_norm_f32", "dsp_asym_trap_filter_f32", "dsp_fixed_time_pickoff_f32",
+    "dsp_time_point_thresh_f32", "dsp_min_max_f32", "dsp_dwt_haar_f32", "dsp_convolve_wf_f32", "dsp_synth_waveforms",
+]
+
+
+def last_error() -> str:
+    return lib().dsp_last_error().decode()
+
+
+def fatal_message(code: int) -> str:
+    return lib().dsp_fatal_message(code).decode()
+
+
+def check(rc: int, row: int | None = None, what: str = ""):
+    """Map a status code to the reference's error behaviour: DSP_E_* -> DSPFatal (ZeroDivisionError for the numba
+    division-by-zero case), negative -> RuntimeError / NotImplementedError / ValueError."""
+    if rc == OK:
+        return
+    if rc == E_ZERODIV:
+        raise ZeroDivisionError("division by zero")
+    if rc > 0:
+        msg = last_error() or fatal_message(rc)
+        err = DSPFatal(msg)
+        if row is not None and row >= 0:
+            err.wf_range = range(row, row + 1)
+        if what:
+            err.processor = what
+        raise err
+    msg = f"{what + ': ' if what else ''}{last_error()}"
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc in (ERR_ARG, ERR_TOO_LONG):
+        raise ValueError(msg)
+    raise RuntimeError(msg)

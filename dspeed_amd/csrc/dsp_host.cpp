@@ -1,0 +1,794 @@
+// dsp_host.cpp -- host half of libdspeed_hip.so: the C ABI of include/dspeed_hip.h.
+//
+//   * device/memory/stream helpers (thin wrappers so that a host needs nothing but this library);
+//   * chain translation: validates a dsp_op program, evaluates every constant the reference evaluates once per
+//     call in float64 on the host (exp(-1/tau) through libm exactly as numba/LLVM does, IIR coefficients, lag
+//     splits), lays the waveform slots out in LDS and picks the launch geometry;
+//   * the single-processor entry points (dsp_<name>_f32), which are tiny cached chains.
+//
+// Reference behaviour mirrored here: constant-only DSPFatal conditions are raised at chain creation with the
+// reference's own codes/messages (processors/*.py, cited in include/dspeed_hip.h).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "dsp_program.h"
+
+extern "C" int dsp_internal_launch_vm_f32(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int* err, int blocks,
+                                          int threads, int lds_bytes, hipStream_t stream);
+extern "C" int dsp_internal_set_vm_lds(int lds_bytes);
+extern "C" const char* dsp_internal_vm_kernel_name();
+extern "C" int dsp_internal_launch_synth(void* wf, int out_dtype, int64_t n_wf, int wf_len, int64_t row_stride, float* baseline,
+                                         float* t_pick, uint64_t seed, int64_t first_row, float tau, float sigma, float pick_offset,
+                                         float bl_lo, float bl_hi, float amp_lo, float amp_hi, hipStream_t stream);
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(DSP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int LDS_BYTES_PER_CU = 160 * 1024;
+
+int elem_size(int dtype) {
+    switch (dtype) {
+        case DSP_F32: case DSP_I32: case DSP_U32: return 4;
+        case DSP_F64: return 8;
+        case DSP_I16: case DSP_U16: return 2;
+        default: return 0;
+    }
+}
+
+}  // namespace
+
+struct dsp_chain {
+    DevProgram host{};
+    DevProgram* dev = nullptr;
+    int* dev_err = nullptr;
+    int device = 0;
+    int lds_bytes_per_wave = 0;
+    int waves_per_block = 0;
+    int num_cu = 256;
+    bool dirty_err = false;
+};
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------------ device / memory
+int dsp_device_count(int* count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(DSP_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return DSP_OK;
+}
+int dsp_set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return DSP_OK;
+}
+int dsp_get_device(int* device) {
+    HIP_TRY(hipGetDevice(device));
+    return DSP_OK;
+}
+int dsp_device_info(int device, char* name, int name_cap, int* compute_units, int64_t* hbm_bytes, int* lds_bytes_per_cu) {
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s (%s)", p.name, p.gcnArchName);
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)p.maxSharedMemoryPerMultiProcessor;
+    return DSP_OK;
+}
+int dsp_malloc(void** dev, int64_t bytes) {
+    *dev = nullptr;
+    HIP_TRY(hipMalloc(dev, (size_t)(bytes > 0 ? bytes : 1)));
+    return DSP_OK;
+}
+int dsp_free(void* dev) {
+    if (dev) HIP_TRY(hipFree(dev));
+    return DSP_OK;
+}
+int dsp_host_alloc(void** host, int64_t bytes) {
+    *host = nullptr;
+    HIP_TRY(hipHostMalloc(host, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocDefault));
+    return DSP_OK;
+}
+int dsp_host_free(void* host) {
+    if (host) HIP_TRY(hipHostFree(host));
+    return DSP_OK;
+}
+int dsp_memset(void* dev, int value, int64_t bytes, void* stream) {
+    HIP_TRY(hipMemsetAsync(dev, value, (size_t)bytes, (hipStream_t)stream));
+    return DSP_OK;
+}
+int dsp_h2d(void* dev, const void* host, int64_t bytes) {
+    HIP_TRY(hipMemcpy(dev, host, (size_t)bytes, hipMemcpyHostToDevice));
+    return DSP_OK;
+}
+int dsp_d2h(void* host, const void* dev, int64_t bytes) {
+    HIP_TRY(hipMemcpy(host, dev, (size_t)bytes, hipMemcpyDeviceToHost));
+    return DSP_OK;
+}
+int dsp_h2d_async(void* dev, const void* host, int64_t bytes, void* stream) {
+    HIP_TRY(hipMemcpyAsync(dev, host, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return DSP_OK;
+}
+int dsp_d2h_async(void* host, const void* dev, int64_t bytes, void* stream) {
+    HIP_TRY(hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return DSP_OK;
+}
+int dsp_stream_create(void** stream) {
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void*)s;
+    return DSP_OK;
+}
+int dsp_stream_destroy(void* stream) {
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return DSP_OK;
+}
+int dsp_stream_sync(void* stream) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return DSP_OK;
+}
+int dsp_sync(void) {
+    HIP_TRY(hipDeviceSynchronize());
+    return DSP_OK;
+}
+int dsp_event_create(void** event) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    *event = (void*)e;
+    return DSP_OK;
+}
+int dsp_event_destroy(void* event) {
+    HIP_TRY(hipEventDestroy((hipEvent_t)event));
+    return DSP_OK;
+}
+int dsp_event_record(void* event, void* stream) {
+    HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return DSP_OK;
+}
+int dsp_event_sync(void* event) {
+    HIP_TRY(hipEventSynchronize((hipEvent_t)event));
+    return DSP_OK;
+}
+int dsp_event_elapsed_ms(void* start, void* stop, float* ms) {
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return DSP_OK;
+}
+const char* dsp_last_error(void) { return g_last_error.c_str(); }
+const char* dsp_version(void) { return "dspeed_hip 0.1 (gfx950)"; }
+
+const char* dsp_fatal_message(int code) {
+    switch (code) {
+        case DSP_E_PZ_NAN: return "Pole-zero filter produced nans in output.";
+        case DSP_E_DPZ_SHORT: return "The length of the waveform must be larger than 3 for the filter to work safely";
+        case DSP_E_TRAP_RISE: return "The number of samples in the rise section must be positive";
+        case DSP_E_TRAP_FLAT: return "The number of samples in the flat section must be positive";
+        case DSP_E_TRAP_FALL: return "The number of samples in the fall section must be positive";
+        case DSP_E_TRAP_WIDE: return "The trapezoid width is wider than the waveform";
+        case DSP_E_FTP_INT: return "fixed_time_pickoff requires integer t_in when using mode 'i'";
+        case DSP_E_FTP_MODE: return "Unrecognized interpolation mode";
+        case DSP_E_TPT_START_INT: return "The starting index must be an integer";
+        case DSP_E_TPT_WALK_INT: return "The search direction must be an integer";
+        case DSP_E_TPT_RANGE: return "The starting index is out of range";
+        case DSP_E_CONV_LONG: return "The filter is longer than the input waveform";
+        case DSP_E_CONV_OUTLEN: return "Output waveform has the wrong length for this convolution mode";
+        case DSP_E_CONV_MODE: return "Invalid mode";
+        case DSP_E_DWT_LEVEL: return "The level must be a positive integer";
+        case DSP_E_DWT_OUTLEN: return "Output waveform has the wrong length for this wavelet level";
+        case DSP_E_ZERODIV: return "division by zero";
+        default: return "";
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ chain translation
+static int check_slot(const DevProgram& P, int s) { return s >= 0 && s < P.n_slots; }
+
+static void mat2_mul(const long double* a, const long double* b, long double* o) {
+    long double r[4] = {a[0] * b[0] + a[1] * b[2], a[0] * b[1] + a[1] * b[3], a[2] * b[0] + a[3] * b[2], a[2] * b[1] + a[3] * b[3]};
+    memcpy(o, r, sizeof r);
+}
+
+// lag geometry shared by the three trapezoids (ic/fc layout documented in dsp_vm.hip)
+static int setup_trap(DevOp& d, int kind_opcode, int rise, int flat, int fall, int len, int C) {
+    if (rise < 0) return DSP_E_TRAP_RISE;
+    if (flat < 0) return DSP_E_TRAP_FLAT;
+    int L[3];
+    if (kind_opcode == DSP_OP_ASYM_TRAP) {
+        if (fall < 0) return DSP_E_TRAP_FALL;
+        if ((int64_t)rise + flat + fall > len) return DSP_E_TRAP_WIDE;
+        if (len > 0 && (rise == 0 || (fall == 0 && rise + flat < len))) return DSP_E_ZERODIV;
+        L[0] = rise;
+        L[1] = rise + flat;
+        L[2] = rise + flat + fall;
+    } else {
+        if (2 * (int64_t)rise + flat > len) return DSP_E_TRAP_WIDE;
+        if (kind_opcode == DSP_OP_TRAP_NORM && len > 0 && rise == 0) return DSP_E_ZERODIV;
+        L[0] = rise;
+        L[1] = rise + flat;
+        L[2] = 2 * rise + flat;
+    }
+    for (int k = 0; k < 3; ++k) {
+        d.ic[k] = L[k];
+        d.ic[3 + k] = L[k] / C;
+        d.ic[6 + k] = L[k] % C;
+    }
+    // trap_filter with rise == 0 reads w_out[-1] (the NaN fill) in its first step: the whole output is NaN
+    d.ic[9] = (kind_opcode == DSP_OP_TRAP_FILTER && rise == 0) ? 1 : 0;
+    d.fc[0] = (double)rise;
+    d.fc[1] = (double)fall;
+    return DSP_OK;
+}
+
+int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_io, const int32_t* slot_len, int n_slots,
+                     int n_sregs, int compute_dtype, dsp_chain** out) {
+    if (out) *out = nullptr;
+    if (!ops || !out || n_ops <= 0 || n_ops > DSP_MAX_OPS) return fail(DSP_ERR_ARG, "n_ops=%d out of range (1..%d)", n_ops, DSP_MAX_OPS);
+    if (n_io < 0 || n_io > DSP_MAX_IO) return fail(DSP_ERR_ARG, "n_io=%d out of range", n_io);
+    if (n_slots < 0 || n_slots > DSP_MAX_SLOTS) return fail(DSP_ERR_ARG, "n_slots=%d out of range", n_slots);
+    if (n_sregs < 0 || n_sregs > DSP_MAX_SREGS) return fail(DSP_ERR_ARG, "n_sregs=%d out of range", n_sregs);
+    if (compute_dtype != DSP_F32) return fail(DSP_ERR_UNSUPPORTED, "only the float32 loop is implemented on the device");
+    const int esz = 4;
+
+    std::unique_ptr<dsp_chain> ch(new dsp_chain());
+    DevProgram& P = ch->host;
+    P.n_ops = n_ops;
+    P.n_slots = n_slots;
+    P.n_io = n_io;
+    P.n_sregs = n_sregs;
+
+    // ---- LDS layout: [guard 2*pitch][slot 64*pitch][tail 8] per slot, then the scalar registers
+    int cursor = 0;
+    for (int s = 0; s < n_slots; ++s) {
+        const int len = slot_len[s];
+        if (len <= 0) return fail(DSP_ERR_ARG, "slot %d has length %d", s, len);
+        int C = (len + 63) / 64;
+        C = ((C + 7) / 8) * 8;
+        DevSlot& d = P.slots[s];
+        d.len = len;
+        d.C = C;
+        d.pitch = C + 1;
+        d.invC = 1.0f / (float)C;
+        cursor += 2 * d.pitch;
+        d.off = cursor;
+        cursor += 64 * d.pitch + 8;
+    }
+    P.sreg_off = cursor;
+    cursor += ((n_sregs + 7) / 8) * 8 + 8;
+    cursor = ((cursor + 3) / 4) * 4;
+    P.lds_elems_per_wave = cursor;
+    ch->lds_bytes_per_wave = cursor * esz;
+    if (ch->lds_bytes_per_wave > LDS_BYTES_PER_CU)
+        return fail(DSP_ERR_TOO_LONG, "chain needs %d bytes of LDS per waveform; a CU has %d", ch->lds_bytes_per_wave, LDS_BYTES_PER_CU);
+    int wpb = LDS_BYTES_PER_CU / ch->lds_bytes_per_wave;
+    if (wpb > 4) wpb = 4;
+    ch->waves_per_block = wpb;
+    P.waves_per_block = wpb;
+
+    // ---- I/O bindings
+    for (int k = 0; k < n_io; ++k) {
+        const dsp_io_desc& a = io[k];
+        DevIO& d = P.io[k];
+        const int es = elem_size(a.dtype);
+        if (!es) return fail(DSP_ERR_ARG, "io %d: unknown dtype %d", k, a.dtype);
+        if (a.kind < DSP_IO_WF_IN || a.kind > DSP_IO_TAPS) return fail(DSP_ERR_ARG, "io %d: unknown kind %d", k, a.kind);
+        if (a.len <= 0 || a.offset < 0) return fail(DSP_ERR_ARG, "io %d: bad len/offset", k);
+        if ((a.kind == DSP_IO_WF_IN) && (a.dtype == DSP_I32 || a.dtype == DSP_U32 || a.dtype == DSP_F64))
+            return fail(DSP_ERR_UNSUPPORTED, "io %d: int32/uint32/float64 rows select the reference's float64 loop, which is not on the device yet", k);
+        if ((a.kind == DSP_IO_WF_OUT || a.kind == DSP_IO_SCALAR_OUT || a.kind == DSP_IO_TAPS) && a.dtype != compute_dtype)
+            return fail(DSP_ERR_ARG, "io %d: outputs and taps must have the chain's compute type", k);
+        d.kind = a.kind;
+        d.dtype = a.dtype;
+        d.len = a.len;
+        d.offset = a.offset;
+        d.row_stride = a.row_stride;
+        d.vec_ok = ((a.row_stride * es) % 16 == 0) && ((a.offset * es) % 16 == 0);
+    }
+
+    // ---- ops
+    for (int i = 0; i < n_ops; ++i) {
+        const dsp_op& o = ops[i];
+        DevOp& d = P.ops[i];
+        memset(&d, 0, sizeof d);
+        d.opcode = o.opcode;
+        d.dst = o.dst;
+        d.src = o.src;
+        d.io = o.io;
+        memcpy(d.ip, o.ip, sizeof d.ip);
+        memcpy(d.sp, o.sp, sizeof d.sp);
+        for (int k = 0; k < 3; ++k) {
+            const dsp_scalar_arg& a = o.sp[k];
+            if (a.kind == DSP_ARG_INPUT && (a.index < 0 || a.index >= n_io || io[a.index].kind != DSP_IO_SCALAR_IN))
+                return fail(DSP_ERR_ARG, "op %d: scalar operand %d is not a scalar input binding", i, k);
+            if (a.kind == DSP_ARG_REG && (a.index < 0 || a.index >= n_sregs)) return fail(DSP_ERR_ARG, "op %d: bad scalar register", i);
+            if (a.kind < DSP_ARG_CONST || a.kind > DSP_ARG_REG) return fail(DSP_ERR_ARG, "op %d: bad scalar operand kind", i);
+        }
+        auto need_io = [&](int kind) { return o.io >= 0 && o.io < n_io && io[o.io].kind == kind; };
+        auto cst = [&](int k) { return (double)(float)o.sp[k].value; };  // the float32 loop receives float32 scalars
+        switch (o.opcode) {
+            case DSP_OP_LOAD:
+                if (!check_slot(P, o.dst) || !need_io(DSP_IO_WF_IN)) return fail(DSP_ERR_ARG, "op %d: bad LOAD", i);
+                if (io[o.io].len != slot_len[o.dst]) return fail(DSP_ERR_ARG, "op %d: LOAD length mismatch", i);
+                break;
+            case DSP_OP_STORE:
+                if (!check_slot(P, o.src) || !need_io(DSP_IO_WF_OUT)) return fail(DSP_ERR_ARG, "op %d: bad STORE", i);
+                if (io[o.io].len != slot_len[o.src]) return fail(DSP_ERR_ARG, "op %d: STORE length mismatch", i);
+                break;
+            case DSP_OP_STORE_SCALAR:
+                if (!need_io(DSP_IO_SCALAR_OUT) || o.ip[0] < 0 || o.ip[0] >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad STORE_SCALAR", i);
+                break;
+            case DSP_OP_BL_SUBTRACT:
+                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || slot_len[o.src] != slot_len[o.dst])
+                    return fail(DSP_ERR_ARG, "op %d: bad BL_SUBTRACT", i);
+                break;
+            case DSP_OP_POLE_ZERO: {
+                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || slot_len[o.src] != slot_len[o.dst])
+                    return fail(DSP_ERR_ARG, "op %d: bad POLE_ZERO", i);
+                if (o.sp[0].kind != DSP_ARG_CONST) return fail(DSP_ERR_UNSUPPORTED, "op %d: per-waveform tau is not supported", i);
+                const double tau = cst(0);
+                d.ic[0] = std::isnan(tau) ? 1 : 0;
+                d.fc[0] = std::exp(-1.0 / tau);  // pole_zero.py:60 -- float64 via libm, like numba's lowering
+                break;
+            }
+            case DSP_OP_DOUBLE_POLE_ZERO: {
+                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || slot_len[o.src] != slot_len[o.dst])
+                    return fail(DSP_ERR_ARG, "op %d: bad DOUBLE_POLE_ZERO", i);
+                for (int k = 0; k < 3; ++k)
+                    if (o.sp[k].kind != DSP_ARG_CONST) return fail(DSP_ERR_UNSUPPORTED, "op %d: per-waveform IIR constants are not supported", i);
+                const double tau1 = cst(0), tau2 = cst(1), fr = cst(2);
+                d.ic[0] = (std::isnan(tau1) || std::isnan(tau2) || std::isnan(fr)) ? 1 : 0;
+                if (!d.ic[0] && slot_len[o.src] <= 3) return fail(DSP_E_DPZ_SHORT, "%s", dsp_fatal_message(DSP_E_DPZ_SHORT));
+                if (slot_len[o.src] <= 3) d.ic[0] = 1;
+                const double a = std::exp(-1.0 / tau1), b = std::exp(-1.0 / tau2);  // pole_zero.py:168-174
+                const double den1 = ((fr * b - fr * a) - b) - 1.0;
+                const double den2 = -1.0 * ((fr * b - fr * a) - b);
+                const double num1 = -1.0 * (a + b);
+                const double num2 = a * b;
+                d.fc[0] = num1;
+                d.fc[1] = num2;
+                d.fc[2] = den1;
+                d.fc[3] = den2;
+                // M^(C*2^d), d = 0..5, M = [[-den1, -den2], [1, 0]]
+                long double M[4] = {-(long double)den1, -(long double)den2, 1.0L, 0.0L}, Pw[4] = {1, 0, 0, 1};
+                const int C = P.slots[o.src].C;
+                long double base[4];
+                memcpy(base, M, sizeof base);
+                for (int e = C; e; e >>= 1) {  // Pw = M^C
+                    if (e & 1) mat2_mul(Pw, base, Pw);
+                    mat2_mul(base, base, base);
+                }
+                for (int dd = 0; dd < 6; ++dd) {
+                    for (int k = 0; k < 4; ++k) d.fc[4 + 4 * dd + k] = (double)Pw[k];
+                    mat2_mul(Pw, Pw, Pw);
+                }
+                break;
+            }
+            case DSP_OP_TRAP_FILTER:
+            case DSP_OP_TRAP_NORM:
+            case DSP_OP_ASYM_TRAP: {
+                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || o.src == o.dst || slot_len[o.src] != slot_len[o.dst])
+                    return fail(DSP_ERR_ARG, "op %d: bad trapezoid (source and destination slots must differ)", i);
+                int rc = setup_trap(d, o.opcode, o.ip[0], o.ip[1], o.ip[2], slot_len[o.src], P.slots[o.src].C);
+                if (rc) return fail(rc, "%s", dsp_fatal_message(rc));
+                break;
+            }
+            case DSP_OP_TRAP_PICKOFF: {
+                if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad TRAP_PICKOFF", i);
+                if (o.ip[3] != DSP_OP_TRAP_FILTER && o.ip[3] != DSP_OP_TRAP_NORM && o.ip[3] != DSP_OP_ASYM_TRAP)
+                    return fail(DSP_ERR_ARG, "op %d: TRAP_PICKOFF ip[3] must name a trapezoid opcode", i);
+                if (o.io == 's') return fail(DSP_ERR_UNSUPPORTED, "fixed_time_pickoff mode 's' (natural spline) is not implemented on the device");
+                int rc = setup_trap(d, o.ip[3], o.ip[0], o.ip[1], o.ip[2], slot_len[o.src], P.slots[o.src].C);
+                if (rc) return fail(rc, "%s", dsp_fatal_message(rc));
+                break;
+            }
+            case DSP_OP_PICKOFF:
+                if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad PICKOFF", i);
+                if (o.ip[0] == 's') return fail(DSP_ERR_UNSUPPORTED, "fixed_time_pickoff mode 's' (natural spline) is not implemented on the device");
+                break;
+            case DSP_OP_TIME_POINT_THRESH:
+                if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad TIME_POINT_THRESH", i);
+                break;
+            case DSP_OP_MIN_MAX:
+                if (!check_slot(P, o.src) || o.dst < 0 || o.dst + 3 >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad MIN_MAX", i);
+                break;
+            case DSP_OP_AMAX:
+                if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad AMAX", i);
+                break;
+            case DSP_OP_DWT_HAAR: {
+                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || !check_slot(P, o.ip[2]) || o.dst == o.src || o.dst == o.ip[2])
+                    return fail(DSP_ERR_ARG, "op %d: bad DWT_HAAR slots", i);
+                if (o.ip[0] <= 0) return fail(DSP_E_DWT_LEVEL, "%s", dsp_fatal_message(DSP_E_DWT_LEVEL));
+                if (o.ip[1] != 'a' && o.ip[1] != 'd') return fail(DSP_ERR_ARG, "op %d: DWT coefficient must be 'a' or 'd'", i);
+                int len = slot_len[o.src];
+                if (slot_len[o.ip[2]] < (len + 1) / 2 && o.ip[0] > 1) return fail(DSP_ERR_ARG, "op %d: DWT scratch slot too small", i);
+                for (int l = 0; l < o.ip[0]; ++l) len = (len + 1) / 2;
+                if (len != slot_len[o.dst]) return fail(DSP_E_DWT_OUTLEN, "%s (got %d, expect %d)", dsp_fatal_message(DSP_E_DWT_OUTLEN), slot_len[o.dst], len);
+                break;
+            }
+            case DSP_OP_COPY:
+                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || o.src == o.dst || o.ip[0] < 0 ||
+                    o.ip[0] + slot_len[o.dst] > slot_len[o.src])
+                    return fail(DSP_ERR_ARG, "op %d: bad COPY", i);
+                break;
+            case DSP_OP_CONVOLVE: {
+                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || o.src == o.dst || !need_io(DSP_IO_TAPS))
+                    return fail(DSP_ERR_ARG, "op %d: bad CONVOLVE", i);
+                const int n = slot_len[o.src], m = io[o.io].len, p = slot_len[o.dst], mode = o.ip[0];
+                d.ic[1] = m;
+                d.ic[2] = o.ip[1] ? 1 : 0;  // caller found a NaN among the taps -> output NaN (convolutions.py:45-46)
+                if (m > n) return fail(DSP_E_CONV_LONG, "%s", dsp_fatal_message(DSP_E_CONV_LONG));
+                if (mode == 'f') {
+                    if (p != n + m - 1) return fail(DSP_E_CONV_OUTLEN, "Output waveform has length %d; expect %d", p, n + m - 1);
+                    d.ic[0] = 0;
+                } else if (mode == 'v') {
+                    if (p != n - m + 1) return fail(DSP_E_CONV_OUTLEN, "Output waveform has length %d; expect %d", p, n - m + 1);
+                    d.ic[0] = m - 1;
+                } else if (mode == 's') {
+                    if (p != n) return fail(DSP_E_CONV_OUTLEN, "Output waveform has length %d; expect %d", p, n);
+                    d.ic[0] = (m - 1) / 2;
+                } else {
+                    return fail(DSP_E_CONV_MODE, "%s", dsp_fatal_message(DSP_E_CONV_MODE));
+                }
+                break;
+            }
+            case DSP_OP_SCALAR_AFFINE:
+                if (o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad SCALAR_AFFINE", i);
+                break;
+            default: return fail(DSP_ERR_ARG, "op %d: unknown opcode %d", i, o.opcode);
+        }
+    }
+
+    HIP_TRY(hipGetDevice(&ch->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ch->device));
+    ch->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipMalloc((void**)&ch->dev, sizeof(DevProgram)));
+    HIP_TRY(hipMemcpy(ch->dev, &P, sizeof(DevProgram), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&ch->dev_err, DSP_ERR_WORDS * sizeof(int)));
+    HIP_TRY(hipMemset(ch->dev_err, 0, DSP_ERR_WORDS * sizeof(int)));
+    const int block_lds = ch->lds_bytes_per_wave * ch->waves_per_block;
+    if (block_lds > 64 * 1024) {
+        hipError_t e = (hipError_t)dsp_internal_set_vm_lds(block_lds);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", block_lds, hipGetErrorString(e));
+    }
+    *out = ch.release();
+    return DSP_OK;
+}
+
+static int chain_blocks(const dsp_chain* ch, int64_t n_wf) {
+    const int block_lds = ch->lds_bytes_per_wave * ch->waves_per_block;
+    int per_cu = LDS_BYTES_PER_CU / block_lds;
+    const int wave_cap = 32 / ch->waves_per_block;  // 32 wavefronts per CU
+    if (per_cu > wave_cap) per_cu = wave_cap;
+    if (per_cu < 1) per_cu = 1;
+    int64_t want = (n_wf + ch->waves_per_block - 1) / ch->waves_per_block;
+    int64_t cap = (int64_t)ch->num_cu * per_cu;
+    int64_t b = want < cap ? want : cap;
+    return (int)(b > 0 ? b : 1);
+}
+
+int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* stream) {
+    if (!ch || !io_ptrs) return fail(DSP_ERR_ARG, "null chain or io_ptrs");
+    if (n_wf <= 0) return DSP_OK;
+    IoPtrs ptrs{};
+    for (int k = 0; k < ch->host.n_io; ++k) {
+        if (!io_ptrs[k]) return fail(DSP_ERR_ARG, "io binding %d is NULL", k);
+        ptrs.p[k] = io_ptrs[k];
+    }
+    const int blocks = chain_blocks(ch, n_wf);
+    const int threads = 64 * ch->waves_per_block;
+    const int lds = ch->lds_bytes_per_wave * ch->waves_per_block;
+    hipError_t e = (hipError_t)dsp_internal_launch_vm_f32(ch->dev, &ptrs, n_wf, ch->dev_err, blocks, threads, lds, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DSP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+    return DSP_OK;
+}
+
+int dsp_chain_check(dsp_chain* ch, void* stream, int64_t* row) {
+    if (!ch) return fail(DSP_ERR_ARG, "null chain");
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    int host_err[DSP_ERR_WORDS] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(host_err, ch->dev_err, sizeof host_err, hipMemcpyDeviceToHost));
+    if (host_err[0] != 0) {
+        if (row) *row = ((int64_t)(uint32_t)host_err[2] << 32) | (uint32_t)host_err[1];
+        HIP_TRY(hipMemset(ch->dev_err, 0, sizeof host_err));
+        g_last_error = dsp_fatal_message(host_err[0]);
+        return host_err[0];
+    }
+    return DSP_OK;
+}
+
+int dsp_chain_destroy(dsp_chain* ch) {
+    if (!ch) return DSP_OK;
+    if (ch->dev) hipFree(ch->dev);
+    if (ch->dev_err) hipFree(ch->dev_err);
+    delete ch;
+    return DSP_OK;
+}
+
+int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int* waves_per_block, int* blocks) {
+    if (!ch) return fail(DSP_ERR_ARG, "null chain");
+    if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->lds_bytes_per_wave;
+    if (waves_per_block) *waves_per_block = ch->waves_per_block;
+    if (blocks) *blocks = chain_blocks(ch, n_wf);
+    return DSP_OK;
+}
+
+const char* dsp_chain_kernel_name(dsp_chain* ch) {
+    (void)ch;
+    return dsp_internal_vm_kernel_name();
+}
+
+// ------------------------------------------------------------------------------------------------ single processors
+namespace {
+
+struct MiniKey {
+    std::vector<int64_t> v;
+    bool operator<(const MiniKey& o) const { return v < o.v; }
+};
+std::map<MiniKey, dsp_chain*> g_cache;
+std::mutex g_cache_mu;
+
+int64_t fbits(float f) {
+    int32_t i;
+    memcpy(&i, &f, 4);
+    return i;
+}
+
+struct Mini {
+    std::vector<dsp_op> ops;
+    std::vector<dsp_io_desc> io;
+    std::vector<void*> ptrs;
+    std::vector<int32_t> slots;
+    int n_sregs = 0;
+    MiniKey key;
+
+    int add_io(int kind, int dtype, int len, int64_t stride, const void* p) {
+        dsp_io_desc d{kind, dtype, len, 0, stride};
+        io.push_back(d);
+        ptrs.push_back(const_cast<void*>(p));
+        key.v.insert(key.v.end(), {kind, dtype, len, stride});
+        return (int)io.size() - 1;
+    }
+    int add_slot(int len) {
+        key.v.push_back(len);
+        slots.push_back(len);
+        return (int)slots.size() - 1;
+    }
+    dsp_op& add_op(int opcode, int dst, int src, int io_idx) {
+        dsp_op o;
+        memset(&o, 0, sizeof o);
+        o.opcode = opcode;
+        o.dst = dst;
+        o.src = src;
+        o.io = io_idx;
+        ops.push_back(o);
+        key.v.insert(key.v.end(), {opcode, dst, src, io_idx});
+        return ops.back();
+    }
+    // scalar gufunc argument: device column if given, else broadcast constant
+    dsp_scalar_arg scalar(const float* dev, float value) {
+        dsp_scalar_arg a{DSP_ARG_CONST, 0, (double)value};
+        if (dev) {
+            a.kind = DSP_ARG_INPUT;
+            a.index = add_io(DSP_IO_SCALAR_IN, DSP_F32, 1, 1, dev);
+        } else {
+            key.v.push_back(fbits(value));
+        }
+        return a;
+    }
+    int run(int64_t n_wf, void* stream, int64_t* err_row) {
+        for (auto& o : ops) {
+            for (int k = 0; k < 4; ++k) key.v.push_back(o.ip[k]);
+            key.v.push_back(o.io);
+        }
+        dsp_chain* ch = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            int dev = 0;
+            hipGetDevice(&dev);
+            key.v.push_back(dev);
+            auto it = g_cache.find(key);
+            if (it != g_cache.end()) ch = it->second;
+        }
+        if (!ch) {
+            int rc = dsp_chain_create(ops.data(), (int)ops.size(), io.data(), (int)io.size(), slots.data(), (int)slots.size(), n_sregs,
+                                      DSP_F32, &ch);
+            if (rc) return rc;
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            if (g_cache.size() > 256) {
+                for (auto& kv : g_cache) dsp_chain_destroy(kv.second);
+                g_cache.clear();
+            }
+            g_cache[key] = ch;
+        }
+        int rc = dsp_chain_execute(ch, ptrs.data(), n_wf, stream);
+        if (rc) return rc;
+        return dsp_chain_check(ch, stream, err_row);
+    }
+};
+
+// waveform -> waveform processors
+int wf2wf(int opcode, const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float* out, int32_t out_len,
+          int64_t out_stride, const int32_t* ip, int n_ip, const dsp_scalar_arg* sp, int n_sp, Mini& m, void* stream, int64_t* err_row) {
+    if (n_wf <= 0) return DSP_OK;
+    const int s_in = m.add_slot(wf_len), s_out = m.add_slot(out_len);
+    const int io_in = m.add_io(DSP_IO_WF_IN, in_dtype, wf_len, in_stride, in);
+    m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
+    dsp_op& o = m.add_op(opcode, s_out, s_in, 0);
+    for (int k = 0; k < n_ip; ++k) o.ip[k] = ip[k];
+    for (int k = 0; k < n_sp; ++k) o.sp[k] = sp[k];
+    const int io_out = m.add_io(DSP_IO_WF_OUT, DSP_F32, out_len, out_stride, out);
+    m.add_op(DSP_OP_STORE, 0, s_out, io_out);
+    return m.run(n_wf, stream, err_row);
+}
+
+}  // namespace
+
+int dsp_bl_subtract_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* baseline_dev,
+                        float baseline, float* out, int64_t out_stride, void* stream, int64_t* err_row) {
+    Mini m;
+    dsp_scalar_arg sp[1] = {m.scalar(baseline_dev, baseline)};
+    return wf2wf(DSP_OP_BL_SUBTRACT, in, in_dtype, n_wf, wf_len, in_stride, out, wf_len, out_stride, nullptr, 0, sp, 1, m, stream, err_row);
+}
+
+int dsp_pole_zero_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float tau, float* out,
+                      int64_t out_stride, void* stream, int64_t* err_row) {
+    Mini m;
+    dsp_scalar_arg sp[1] = {m.scalar(nullptr, tau)};
+    return wf2wf(DSP_OP_POLE_ZERO, in, in_dtype, n_wf, wf_len, in_stride, out, wf_len, out_stride, nullptr, 0, sp, 1, m, stream, err_row);
+}
+
+int dsp_double_pole_zero_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float tau1, float tau2,
+                             float frac, float* out, int64_t out_stride, void* stream, int64_t* err_row) {
+    Mini m;
+    dsp_scalar_arg sp[3] = {m.scalar(nullptr, tau1), m.scalar(nullptr, tau2), m.scalar(nullptr, frac)};
+    return wf2wf(DSP_OP_DOUBLE_POLE_ZERO, in, in_dtype, n_wf, wf_len, in_stride, out, wf_len, out_stride, nullptr, 0, sp, 3, m, stream,
+                 err_row);
+}
+
+int dsp_trap_filter_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,
+                        float* out, int64_t out_stride, void* stream, int64_t* err_row) {
+    Mini m;
+    int32_t ip[2] = {rise, flat};
+    return wf2wf(DSP_OP_TRAP_FILTER, in, in_dtype, n_wf, wf_len, in_stride, out, wf_len, out_stride, ip, 2, nullptr, 0, m, stream, err_row);
+}
+
+int dsp_trap_norm_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,
+                      float* out, int64_t out_stride, void* stream, int64_t* err_row) {
+    Mini m;
+    int32_t ip[2] = {rise, flat};
+    return wf2wf(DSP_OP_TRAP_NORM, in, in_dtype, n_wf, wf_len, in_stride, out, wf_len, out_stride, ip, 2, nullptr, 0, m, stream, err_row);
+}
+
+int dsp_asym_trap_filter_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise,
+                             int32_t flat, int32_t fall, float* out, int64_t out_stride, void* stream, int64_t* err_row) {
+    Mini m;
+    int32_t ip[3] = {rise, flat, fall};
+    return wf2wf(DSP_OP_ASYM_TRAP, in, in_dtype, n_wf, wf_len, in_stride, out, wf_len, out_stride, ip, 3, nullptr, 0, m, stream, err_row);
+}
+
+int dsp_dwt_haar_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t level, int32_t coeff_char,
+                     float* out, int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row) {
+    Mini m;
+    int32_t ip[3] = {level, coeff_char, 0};  // scratch = the input slot itself (dead after the transform)
+    return wf2wf(DSP_OP_DWT_HAAR, in, in_dtype, n_wf, wf_len, in_stride, out, out_len, out_stride, ip, 3, nullptr, 0, m, stream, err_row);
+}
+
+int dsp_convolve_wf_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* kernel_dev,
+                        int32_t kernel_len, int32_t mode_char, float* out, int32_t out_len, int64_t out_stride, void* stream,
+                        int64_t* err_row) {
+    if (n_wf <= 0) return DSP_OK;
+    if (kernel_len <= 0) return fail(DSP_ERR_ARG, "empty kernel");
+    // NaN among the taps -> NaN output (convolutions.py:45-46): look at them once on the host
+    std::vector<float> taps((size_t)kernel_len);
+    HIP_TRY(hipMemcpy(taps.data(), kernel_dev, sizeof(float) * (size_t)kernel_len, hipMemcpyDeviceToHost));
+    int has_nan = 0;
+    for (float t : taps) has_nan |= std::isnan(t) ? 1 : 0;
+    Mini m;
+    const int s_in = m.add_slot(wf_len), s_out = m.add_slot(out_len > 0 ? out_len : 1);
+    const int io_in = m.add_io(DSP_IO_WF_IN, in_dtype, wf_len, in_stride, in);
+    const int io_k = m.add_io(DSP_IO_TAPS, DSP_F32, kernel_len, 0, kernel_dev);
+    m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
+    dsp_op& o = m.add_op(DSP_OP_CONVOLVE, s_out, s_in, io_k);
+    o.ip[0] = mode_char;
+    o.ip[1] = has_nan;
+    const int io_out = m.add_io(DSP_IO_WF_OUT, DSP_F32, out_len > 0 ? out_len : 1, out_stride, out);
+    m.add_op(DSP_OP_STORE, 0, s_out, io_out);
+    return m.run(n_wf, stream, err_row);
+}
+
+int dsp_fixed_time_pickoff_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* t_in_dev,
+                               float t_in, int32_t mode_char, float* out, void* stream, int64_t* err_row) {
+    if (n_wf <= 0) return DSP_OK;
+    Mini m;
+    m.n_sregs = 1;
+    const int s_in = m.add_slot(wf_len);
+    const int io_in = m.add_io(DSP_IO_WF_IN, in_dtype, wf_len, in_stride, in);
+    m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
+    dsp_scalar_arg t = m.scalar(t_in_dev, t_in);
+    dsp_op& o = m.add_op(DSP_OP_PICKOFF, 0, s_in, 0);
+    o.ip[0] = mode_char;
+    o.sp[0] = t;
+    const int io_out = m.add_io(DSP_IO_SCALAR_OUT, DSP_F32, 1, 1, out);
+    dsp_op& st = m.add_op(DSP_OP_STORE_SCALAR, 0, 0, io_out);
+    st.ip[0] = 0;
+    return m.run(n_wf, stream, err_row);
+}
+
+int dsp_time_point_thresh_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
+                              const float* threshold_dev, float threshold, const float* t_start_dev, float t_start,
+                              float walk_forward, float* out, void* stream, int64_t* err_row) {
+    if (n_wf <= 0) return DSP_OK;
+    Mini m;
+    m.n_sregs = 1;
+    const int s_in = m.add_slot(wf_len);
+    const int io_in = m.add_io(DSP_IO_WF_IN, in_dtype, wf_len, in_stride, in);
+    m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
+    dsp_scalar_arg a = m.scalar(threshold_dev, threshold), b = m.scalar(t_start_dev, t_start), c = m.scalar(nullptr, walk_forward);
+    dsp_op& o = m.add_op(DSP_OP_TIME_POINT_THRESH, 0, s_in, 0);
+    o.sp[0] = a;
+    o.sp[1] = b;
+    o.sp[2] = c;
+    const int io_out = m.add_io(DSP_IO_SCALAR_OUT, DSP_F32, 1, 1, out);
+    dsp_op& st = m.add_op(DSP_OP_STORE_SCALAR, 0, 0, io_out);
+    st.ip[0] = 0;
+    return m.run(n_wf, stream, err_row);
+}
+
+int dsp_min_max_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float* t_min, float* t_max,
+                    float* a_min, float* a_max, void* stream, int64_t* err_row) {
+    if (n_wf <= 0) return DSP_OK;
+    Mini m;
+    m.n_sregs = 4;
+    const int s_in = m.add_slot(wf_len);
+    const int io_in = m.add_io(DSP_IO_WF_IN, in_dtype, wf_len, in_stride, in);
+    m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
+    m.add_op(DSP_OP_MIN_MAX, 0, s_in, 0);
+    float* outs[4] = {t_min, t_max, a_min, a_max};
+    for (int k = 0; k < 4; ++k) {
+        const int io_out = m.add_io(DSP_IO_SCALAR_OUT, DSP_F32, 1, 1, outs[k]);
+        dsp_op& st = m.add_op(DSP_OP_STORE_SCALAR, 0, 0, io_out);
+        st.ip[0] = k;
+    }
+    return m.run(n_wf, stream, err_row);
+}
+
+int dsp_synth_waveforms(void* wf, int out_dtype, int64_t n_wf, int32_t wf_len, int64_t row_stride, float* baseline, float* t_pick,
+                        uint64_t seed, int64_t first_row, float tau, float sigma, float pick_offset, float bl_lo, float bl_hi,
+                        float amp_lo, float amp_hi, void* stream) {
+    if (out_dtype != DSP_F32 && out_dtype != DSP_I16) return fail(DSP_ERR_ARG, "synth output must be float32 or int16");
+    if (n_wf <= 0) return DSP_OK;
+    hipError_t e = (hipError_t)dsp_internal_launch_synth(wf, out_dtype, n_wf, wf_len, row_stride, baseline, t_pick, seed, first_row, tau,
+                                                         sigma, pick_offset, bl_lo, bl_hi, amp_lo, amp_hi, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DSP_ERR_HIP, "synth launch failed: %s", hipGetErrorString(e));
+    return DSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// dsp_program.h -- device-side program representation shared by the host translator (dsp_host.cpp)
+// and the waveform VM kernel (dsp_vm.hip).  Internal: the public contract is include/dspeed_hip.h.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/dspeed_hip.h"
+
+#define DSP_WAVE 64
+#define DSP_FC 40 /* host-precomputed float64 constants per op */
+#define DSP_IC 12 /* host-precomputed integer constants per op */
+
+// One waveform variable living in LDS.  Lane j of the wavefront owns samples [j*C, (j+1)*C) ("chunk");
+// chunk j starts at element off + j*pitch with pitch = C+1 (odd) so that "every lane reads offset t of
+// its chunk" hits 64 different banks.  Samples >= len up to 64*C are kept finite (zero-filled at load).
+struct DevSlot {
+    int32_t off;   // element offset inside the wavefront's LDS region
+    int32_t len;   // logical number of samples
+    int32_t C;     // samples per lane, multiple of 8
+    int32_t pitch; // C + 1
+    float invC;    // 1/C for index -> (lane, offset) splits
+    int32_t pad_;
+};
+
+struct DevIO {
+    int32_t kind, dtype, len, offset;
+    int64_t row_stride;
+    int32_t vec_ok; // row base, stride and offset keep 16-byte alignment -> wide loads/stores
+    int32_t pad_;
+};
+
+struct DevOp {
+    int32_t opcode, dst, src, io;
+    int32_t ip[4];
+    dsp_scalar_arg sp[3];
+    int32_t ic[DSP_IC];
+    double fc[DSP_FC];
+};
+
+struct DevProgram {
+    int32_t n_ops, n_slots, n_io, n_sregs;
+    int32_t lds_elems_per_wave; // waveform slots + scalar registers, in elements of the compute type
+    int32_t sreg_off;           // element offset of the scalar register file
+    int32_t waves_per_block;
+    int32_t pad_;
+    DevSlot slots[DSP_MAX_SLOTS];
+    DevIO io[DSP_MAX_IO];
+    DevOp ops[DSP_MAX_OPS];
+};
+
+struct IoPtrs {
+    void* p[DSP_MAX_IO];
+};
+
+// device error word layout: err[0] = DSP_E_* code (0 = none), err[1..2] = row (lo, hi)
+#define DSP_ERR_WORDS 4

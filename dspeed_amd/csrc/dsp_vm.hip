@@ -1,0 +1,1016 @@
+// dsp_vm.hip -- the waveform VM: one wavefront per waveform, all intermediates in LDS.
+//
+// Replaces the reference's ProcessingChain inner loop (processing_chain.py:665-673, 1144-1163) and the
+// numba gufunc bodies it calls (processors/*.py, cited per op below) for one batch of rows.
+//
+// Execution model (gfx950 / CDNA4, wave64):
+//   * a workgroup is `waves_per_block` independent wavefronts; wavefront w processes rows
+//     w, w + total_waves, ... ; there is no inter-wave communication, hence no s_barrier anywhere;
+//   * a waveform variable ("slot") lives in LDS; lane j owns the contiguous chunk [j*C, (j+1)*C) of it,
+//     stored at pitch C+1 so that 64 lanes touching the same offset of their chunks hit 64 banks;
+//   * recursions (pole-zero, trapezoids, IIR) are evaluated chunk-serially per lane with the carry
+//     between chunks supplied by a 6-step DPP wavefront scan (row_shr 1/2/4/8, row_bcast 15/31);
+//   * the kernel is memory/LDS bound: no MFMA anywhere.
+//
+// Arithmetic contract: every op reproduces the numba typing of the reference body:
+// float32 (op) float32 stays float32; anything numba promotes is float64 here and is rounded to
+// float32 exactly where the reference stores into a float32 array.  Compiled with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "dsp_program.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// wavefront primitives
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// Orders this wavefront's LDS traffic for the compiler; the hardware executes one wave's LDS
+// instructions in issue order, so no instruction is needed beyond the waitcnt the fence implies.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp0(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp0(float v) {
+    return __int_as_float(dpp0<CTRL, ROW_MASK>(__float_as_int(v)));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp0(double v) {
+    int lo = dpp0<CTRL, ROW_MASK>(__double2loint(v));
+    int hi = dpp0<CTRL, ROW_MASK>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138;
+
+// inclusive + over the 64 lanes (lanes without a source add the DPP "old" value 0)
+__device__ __forceinline__ double wave_scan_add(double v) {
+    v += dpp0<DPP_ROW_SHR1>(v);
+    v += dpp0<DPP_ROW_SHR2>(v);
+    v += dpp0<DPP_ROW_SHR4>(v);
+    v += dpp0<DPP_ROW_SHR8>(v);
+    v += dpp0<DPP_ROW_BCAST15, 0xa>(v);
+    v += dpp0<DPP_ROW_BCAST31, 0xc>(v);
+    return v;
+}
+// value of the previous lane, 0 for lane 0
+template <typename V>
+__device__ __forceinline__ V wave_prev(V v) {
+    return dpp0<DPP_WAVE_SHR1>(v);
+}
+__device__ __forceinline__ double wave_exscan_add(double v) { return wave_prev(wave_scan_add(v)); }
+
+__device__ __forceinline__ float readlane(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ int readlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ double readlane(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// value held `sh` lanes below (uniform sh >= 0); lanes without a source get 0
+__device__ __forceinline__ double wave_shift_up(double v, int sh) {
+    int src = lane_id() - sh;
+    int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
+    int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+    return src >= 0 ? __hiloint2double(hi, lo) : 0.0;
+}
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ bool wave_any(bool p) { return __any(p) != 0; }
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ------------------------------------------------------------------------------------------------
+// per-wave context
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct Ctx {
+    T* lds;                  // this wavefront's LDS region
+    const DevProgram* prog;  // device copy of the program
+    const IoPtrs* ptrs;      // I/O device pointers of this launch
+    int64_t row;             // waveform being processed
+    int* err;                // device error word
+    uint32_t nan_mask;       // bit s set: slot s is "all NaN" (the reference's NaN-propagation state)
+
+    __device__ __forceinline__ T* chunk(const DevSlot& s) const { return lds + s.off + lane_id() * s.pitch; }
+    __device__ __forceinline__ T* sregs() const { return lds + prog->sreg_off; }
+    __device__ __forceinline__ bool slot_nan(int s) const { return (nan_mask >> s) & 1u; }
+    __device__ __forceinline__ void set_nan(int s, bool v) {
+        nan_mask = v ? (nan_mask | (1u << s)) : (nan_mask & ~(1u << s));
+    }
+    __device__ void fatal(int code) const {
+        if (lane_id() == 0 && atomicCAS(&err[0], 0, code) == 0) {
+            err[1] = (int)(row & 0xffffffffll);
+            err[2] = (int)(row >> 32);
+        }
+    }
+    // scalar operand: constant, per-waveform input column, or scalar register
+    __device__ T scalar(const dsp_scalar_arg& a) const {
+        if (a.kind == DSP_ARG_CONST) return (T)a.value;
+        if (a.kind == DSP_ARG_REG) return sregs()[a.index];
+        const DevIO& io = prog->io[a.index];
+        const int64_t at = (int64_t)io.offset + row * io.row_stride;
+        const void* p = ptrs->p[a.index];
+        if (io.dtype == DSP_F32) return (T)((const float*)p)[at];
+        if (io.dtype == DSP_F64) return (T)((const double*)p)[at];
+        if (io.dtype == DSP_I32) return (T)((const int32_t*)p)[at];
+        if (io.dtype == DSP_I16) return (T)((const int16_t*)p)[at];
+        if (io.dtype == DSP_U16) return (T)((const uint16_t*)p)[at];
+        return (T)((const uint32_t*)p)[at];
+    }
+};
+
+// LDS element index of sample e of a slot (e / C via a float reciprocal: exact for e < 2^20, C % 8 == 0)
+__device__ __forceinline__ int padded_index(const DevSlot& s, int e) {
+    int q = (int)(((float)e + 0.5f) * s.invC);
+    return s.off + e + q;
+}
+
+template <typename T>
+__device__ __forceinline__ T quiet_nan() {
+    return (T)__builtin_nanf("");
+}
+
+// ------------------------------------------------------------------------------------------------
+// LOAD / STORE: coalesced 16-byte global accesses <-> chunked LDS layout
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename InT>
+__device__ bool load_slot(Ctx<T>& cx, const DevSlot& s, const InT* __restrict__ g, int len, bool vec_ok) {
+    constexpr int V = 16 / (int)sizeof(InT);
+    typedef InT vec_t __attribute__((ext_vector_type(V)));
+    const int total = 64 * s.C;
+    bool nan = false;
+    if (vec_ok) {
+        constexpr int B = 4;  // loads in flight per lane before the LDS writes
+        for (int e0 = lane_id() * V; e0 < total; e0 += 64 * V * B) {
+            vec_t v[B];
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const int e = e0 + b * 64 * V;
+                if (e + V <= len) {
+                    v[b] = *reinterpret_cast<const vec_t*>(g + e);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < V; ++m) v[b][m] = (e + m < len) ? g[e + m] : (InT)0;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const int e = e0 + b * 64 * V;
+                if (e < total) {
+                    const int a = padded_index(s, e);
+#pragma unroll
+                    for (int m = 0; m < V; ++m) {
+                        T x = (T)v[b][m];
+                        nan |= (x != x);
+                        cx.lds[a + m] = x;
+                    }
+                }
+            }
+        }
+    } else {
+        for (int e = lane_id(); e < total; e += 64) {
+            T x = (e < len) ? (T)g[e] : (T)0;
+            nan |= (x != x);
+            cx.lds[padded_index(s, e)] = x;
+        }
+    }
+    return nan;
+}
+
+template <typename T>
+__device__ void op_load(Ctx<T>& cx, const DevOp& op) {
+    const DevSlot& s = cx.prog->slots[op.dst];
+    const DevIO& io = cx.prog->io[op.io];
+    const char* base = (const char*)cx.ptrs->p[op.io];
+    const int64_t at = cx.row * io.row_stride + io.offset;
+    const bool vec_ok = io.vec_ok && ((reinterpret_cast<uintptr_t>(base) & 15u) == 0);
+    bool nan;
+    switch (io.dtype) {
+        case DSP_F32: nan = load_slot<T, float>(cx, s, (const float*)base + at, io.len, vec_ok); break;
+        case DSP_I16: nan = load_slot<T, int16_t>(cx, s, (const int16_t*)base + at, io.len, vec_ok); break;
+        case DSP_U16: nan = load_slot<T, uint16_t>(cx, s, (const uint16_t*)base + at, io.len, vec_ok); break;
+        case DSP_I32: nan = load_slot<T, int32_t>(cx, s, (const int32_t*)base + at, io.len, vec_ok); break;
+        case DSP_U32: nan = load_slot<T, uint32_t>(cx, s, (const uint32_t*)base + at, io.len, vec_ok); break;
+        default: nan = load_slot<T, double>(cx, s, (const double*)base + at, io.len, vec_ok); break;
+    }
+    cx.set_nan(op.dst, wave_any(nan));
+    wave_sync();
+}
+
+template <typename T>
+__device__ void op_store(Ctx<T>& cx, const DevOp& op) {
+    const DevSlot& s = cx.prog->slots[op.src];
+    const DevIO& io = cx.prog->io[op.io];
+    T* g = (T*)cx.ptrs->p[op.io] + cx.row * io.row_stride + io.offset;
+    const int len = io.len;
+    const bool nan = cx.slot_nan(op.src);
+    constexpr int V = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    if (io.vec_ok && ((reinterpret_cast<uintptr_t>(cx.ptrs->p[op.io]) & 15u) == 0)) {
+        for (int e = lane_id() * V; e < len; e += 64 * V) {
+            const int a = padded_index(s, e);
+            vec_t v;
+#pragma unroll
+            for (int m = 0; m < V; ++m) v[m] = nan ? quiet_nan<T>() : cx.lds[a + m];
+            if (e + V <= len) {
+                *reinterpret_cast<vec_t*>(g + e) = v;
+            } else {
+                for (int m = 0; m < V && e + m < len; ++m) g[e + m] = v[m];
+            }
+        }
+    } else {
+        for (int e = lane_id(); e < len; e += 64) g[e] = nan ? quiet_nan<T>() : cx.lds[padded_index(s, e)];
+    }
+}
+
+template <typename T>
+__device__ void op_store_scalar(Ctx<T>& cx, const DevOp& op) {
+    const DevIO& io = cx.prog->io[op.io];
+    if (lane_id() == 0) ((T*)cx.ptrs->p[op.io])[cx.row * io.row_stride + io.offset] = cx.sregs()[op.ip[0]];
+}
+
+// ------------------------------------------------------------------------------------------------
+// bl_subtract  (processors/bl_subtract.py:11-46):  w_out = w_in - a_baseline, both T
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ void op_bl_subtract(Ctx<T>& cx, const DevOp& op) {
+    const DevSlot& ss = cx.prog->slots[op.src];
+    const DevSlot& sd = cx.prog->slots[op.dst];
+    const T b = cx.scalar(op.sp[0]);
+    if (cx.slot_nan(op.src) || b != b) {
+        cx.set_nan(op.dst, true);
+        return;
+    }
+    const T* ps = cx.chunk(ss);
+    T* pd = cx.chunk(sd);
+    bool nan = false;
+#pragma unroll 8
+    for (int t = 0; t < ss.C; ++t) {
+        T v = ps[t] - b;
+        nan |= (v != v);
+        pd[t] = v;
+    }
+    cx.set_nan(op.dst, wave_any(nan));
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// pole_zero  (processors/pole_zero.py:24-77)
+//   y[0] = x[0];  acc_i = (acc_{i-1} + x[i]) - x[i-1]*c  in float64, y[i] = (T)acc_i,  c = exp(-1/tau) (float64, host libm).
+// Parallel form: acc at the end of sample k is  S(k) - c*S(k-1)  with S = inclusive prefix sum of x, so the carry into
+// lane j's chunk is  E_j - c*(E_j - x[jC-1])  with E_j the exclusive scan of the per-chunk sums; inside the chunk the
+// recurrence runs with the reference's operation order.  fc[0] = c, ic[0] = tau is NaN.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ void op_pole_zero(Ctx<T>& cx, const DevOp& op) {
+    const DevSlot& ss = cx.prog->slots[op.src];
+    const DevSlot& sd = cx.prog->slots[op.dst];
+    if (cx.slot_nan(op.src) || op.ic[0]) {
+        cx.set_nan(op.dst, true);
+        return;
+    }
+    const double c = op.fc[0];
+    const T* ps = cx.chunk(ss);
+    T* pd = cx.chunk(sd);
+    const int C = ss.C;
+    double X = 0.0;
+#pragma unroll 8
+    for (int t = 0; t < C; ++t) X += (double)ps[t];
+    const double E = wave_exscan_add(X);
+    const T xlast = ps[C - 1];
+    const double xprev = (double)wave_prev(xlast);
+    double acc = E - c * (E - xprev);
+    double xp = xprev;
+    bool nan = false;
+#pragma unroll 8
+    for (int t = 0; t < C; ++t) {
+        const double x = (double)ps[t];
+        acc = (acc + x) - xp * c;
+        const T y = (T)acc;
+        nan |= (y != y);
+        pd[t] = y;
+        xp = x;
+    }
+    if (wave_any(nan)) {  // pole_zero.py:76-77: NaN out of non-NaN input (inf - inf)
+        cx.fatal(DSP_E_PZ_NAN);
+        cx.set_nan(op.dst, true);
+    } else {
+        cx.set_nan(op.dst, false);
+    }
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// double_pole_zero  (processors/pole_zero.py:82-198): second-order IIR, float64 state
+//   y[n] = x[n] + n1 x[n-1] + n2 x[n-2] - d1 y[n-1] - d2 y[n-2],   y[0] = x[0], y[1] = x[1]
+// State s = (y[n-1], y[n-2]) advances as s' = M s + (v, 0), M = [[-d1, -d2], [1, 0]].  Each lane first runs its chunk from a
+// zero state (lane 0 from the true initial state) to get the chunk's forced response r_j; the carry into chunk j is
+// sum_{k<j} M^{C(j-1-k)} r_k, a Hillis-Steele scan with the uniform matrices M^{C*2^d} (host, float64).
+// fc: 0 n1, 1 n2, 2 d1, 3 d2, 4.. six 2x2 matrices M^{C}, M^{2C}, ... M^{32C} (row major); ic[0] = parameter NaN.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ void op_double_pole_zero(Ctx<T>& cx, const DevOp& op) {
+    const DevSlot& ss = cx.prog->slots[op.src];
+    const DevSlot& sd = cx.prog->slots[op.dst];
+    if (cx.slot_nan(op.src) || op.ic[0]) {
+        cx.set_nan(op.dst, true);
+        return;
+    }
+    const double n1 = op.fc[0], n2 = op.fc[1], d1 = op.fc[2], d2 = op.fc[3];
+    const T* ps = cx.chunk(ss);
+    T* pd = cx.chunk(sd);
+    const int C = ss.C, lane = lane_id();
+    // the two samples preceding this chunk
+    const double xm1_in = (double)wave_prev(ps[C - 1]);
+    const double xm2_in = (double)wave_prev(ps[C - 2]);
+    // pass 1: forced response (lane 0: true response from y[0], y[1])
+    double y1 = 0.0, y0 = 0.0, xm1 = xm1_in, xm2 = xm2_in;
+    int t_begin = 0;
+    if (lane == 0) {
+        y0 = (double)ps[0];
+        y1 = (double)ps[1];
+        xm2 = y0;
+        xm1 = y1;
+        t_begin = 2;
+    }
+#pragma unroll 4
+    for (int t = t_begin; t < C; ++t) {
+        const double x = (double)ps[t];
+        const double y2 = (((x + n1 * xm1) + n2 * xm2) - d1 * y1) - d2 * y0;
+        y0 = y1;
+        y1 = y2;
+        xm2 = xm1;
+        xm1 = x;
+    }
+    // scan of the affine maps with a common linear part
+    double r1 = y1, r0 = y0;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+        const double* M = &op.fc[4 + 4 * d];
+        const double p1 = wave_shift_up(r1, 1 << d), p0 = wave_shift_up(r0, 1 << d);
+        r1 += M[0] * p1 + M[1] * p0;
+        r0 += M[2] * p1 + M[3] * p0;
+    }
+    // carry in = state at the end of the previous chunk
+    y1 = wave_prev(r1);
+    y0 = wave_prev(r0);
+    xm1 = xm1_in;
+    xm2 = xm2_in;
+    bool nan = false;
+    if (lane == 0) {
+        const T a = ps[0], b = ps[1];
+        y0 = (double)a;
+        y1 = (double)b;
+        xm2 = y0;
+        xm1 = y1;
+        pd[0] = a;
+        pd[1] = b;
+    }
+#pragma unroll 4
+    for (int t = t_begin; t < C; ++t) {
+        const double x = (double)ps[t];
+        const double y2 = (((x + n1 * xm1) + n2 * xm2) - d1 * y1) - d2 * y0;
+        const T y = (T)y2;
+        nan |= (y != y);
+        pd[t] = y;
+        y0 = y1;
+        y1 = y2;
+        xm2 = xm1;
+        xm1 = x;
+    }
+    cx.set_nan(op.dst, wave_any(nan));
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// trapezoidal filters  (processors/trap_filters.py: trap_filter :12-76, trap_norm :79-149, asym_trap_filter :152-227)
+//
+// The reference accumulates y[i] = y[i-1] (+) increments with the feedback going through the float32 output array, i.e. it
+// rounds to float32 after every operation (trap_filter) or after every sample (trap_norm/asym).  That rounding noise is
+// ~1e-6 of the flat-top value, so a mathematically exact scan does NOT reproduce the reference to 1e-6.  Instead every lane
+// replays the reference's operation sequence over its chunk starting from a speculative carry g_j (the exact value of the
+// filter at the chunk boundary, from float64 prefix sums); because float32 addition commutes with a shift by a multiple of
+// the current ulp, the true carries follow from the per-chunk increments h_j - g_j by one more exact scan, and the replayed
+// values are corrected by the (ulp-multiple) offset.  Residual deviations come only from binade crossings / ties.
+//
+// lags:  FILTER/NORM  L1 = rise, L2 = rise+flat, L3 = 2 rise+flat        signs + - - +
+//        ASYM         L1 = rise, L2 = rise+flat, L3 = rise+flat+fall
+// ic: 0..2 lags, 3..5 q_k = L_k / C, 6..8 rho_k = L_k % C;  fc: 0 rise, 1 fall
+// ------------------------------------------------------------------------------------------------
+enum { TRAP_FILTER = 0, TRAP_NORM = 1, TRAP_ASYM = 2 };
+
+template <typename T, int KIND>
+__device__ __forceinline__ T trap_step(T y, T a, T b1, T b2, T b3, double rr, double ll) {
+    if (KIND == TRAP_FILTER) {
+        return (((y + a) - b1) - b2) + b3;
+    } else if (KIND == TRAP_NORM) {
+        const T e = ((a - b1) - b2) + b3;
+        return (T)((double)y + (double)e / rr);
+    } else {
+        const T e1 = a - b1, e2 = b2 - b3;
+        return (T)(((double)y + (double)e1 / rr) - (double)e2 / ll);
+    }
+}
+
+constexpr int TRAP_NCAP = 4;
+
+// Runs the trap emulation over slot `ss`.  If STORE, writes the filtered waveform into slot `sd` (must differ from ss).
+// cap_idx[c] (uniform, -1 = unused): sample indices whose filtered value is wanted; returned in cap_val[c] (uniform).
+template <typename T, int KIND, bool STORE>
+__device__ void trap_core(Ctx<T>& cx, const DevOp& op, const DevSlot& ss, const DevSlot& sd, const int* cap_idx, T* cap_val) {
+    const int C = ss.C, lane = lane_id();
+    const T* ps = cx.chunk(ss);
+    const double rr = op.fc[0], ll = op.fc[1];
+    int q[3], rho[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        q[k] = op.ic[3 + k];
+        rho[k] = op.ic[6 + k];
+    }
+    // ---- pass A: float64 prefix sums of the input, captured at the three offsets the lagged boundaries fall on
+    double run = 0.0, cap[3] = {0.0, 0.0, 0.0};
+    {
+        int t = 0;
+        while (t < C) {
+            int nb = C;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int o = (C - rho[k]) % C;
+                if (o > t && o < nb) nb = o;
+            }
+#pragma unroll 8
+            for (int u = t; u < nb; ++u) run += (double)ps[u];
+            t = nb;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (t == (C - rho[k]) % C) cap[k] = run;
+        }
+    }
+    const double E = wave_exscan_add(run);
+    double G = E;  // sum of all samples before this chunk
+    double A[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int o = (C - rho[k]) % C;
+        const double ak = E + (o == 0 ? 0.0 : cap[k]);       // prefix up to (chunk, offset o)
+        A[k] = wave_shift_up(ak, q[k] + (rho[k] > 0 ? 1 : 0));  // the chunk that index jC - L_k falls into
+    }
+    if (KIND == TRAP_FILTER)
+        G = ((E - A[0]) - A[1]) + A[2];
+    else if (KIND == TRAP_NORM)
+        G = (((E - A[0]) - A[1]) + A[2]) / rr;
+    else
+        G = (E - A[0]) / rr - (A[1] - A[2]) / ll;
+    const T g = (lane == 0) ? (T)-0.0 : (T)G;
+
+    // ---- pass B: replay the reference's rounding sequence from the speculative carry
+    // lagged sample i - L_k lives in chunk (lane - q_k - 1) at offset C - rho_k + t, one element further once t >= rho_k
+    // (the chunk pad).  Lanes whose lagged chunk index is negative read the zero guard below the slot.
+    const T* lag[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int jj = lane - q[k] - 1;
+        // jj >= 0: always inside the slot; jj == -1: offsets t < rho_k fall into the guard chunk right below the slot;
+        // jj < -1: every lagged sample of this lane is before sample 0 -> park the pointer at the bottom of the guard
+        lag[k] = (jj >= -1) ? cx.lds + ss.off + jj * ss.pitch + (C - rho[k]) : cx.lds + ss.off - 2 * ss.pitch;
+    }
+    int cap_lane[TRAP_NCAP], cap_off[TRAP_NCAP];
+    T capv[TRAP_NCAP];
+#pragma unroll
+    for (int c = 0; c < TRAP_NCAP; ++c) {
+        const int ci = cap_idx[c];
+        const int cl = ci >= 0 ? (int)(((float)ci + 0.5f) * ss.invC) : -1;
+        cap_lane[c] = cl;
+        cap_off[c] = ci >= 0 ? ci - cl * C : -1;
+        capv[c] = (T)0;
+    }
+    T* pd = STORE ? cx.chunk(sd) : nullptr;
+    T y = g;
+    {
+        int t = 0;
+        while (t < C) {
+            int nb = C;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (rho[k] > t && rho[k] < nb) nb = rho[k];
+#pragma unroll
+            for (int c = 0; c < TRAP_NCAP; ++c)
+                if (cap_off[c] + 1 > t && cap_off[c] + 1 < nb) nb = cap_off[c] + 1;
+            const T* l0 = lag[0] + (t >= rho[0] ? 1 : 0);
+            const T* l1 = lag[1] + (t >= rho[1] ? 1 : 0);
+            const T* l2 = lag[2] + (t >= rho[2] ? 1 : 0);
+#pragma unroll 4
+            for (int u = t; u < nb; ++u) {
+                y = trap_step<T, KIND>(y, ps[u], l0[u], l1[u], l2[u], rr, ll);
+                if (STORE) pd[u] = y;
+            }
+            t = nb;
+#pragma unroll
+            for (int c = 0; c < TRAP_NCAP; ++c)
+                if (t == cap_off[c] + 1) capv[c] = y;
+        }
+    }
+    // ---- true carries: exact scan of the per-chunk increments
+    const double D = (double)y - (double)g;
+    const double tstart = wave_exscan_add(D);
+    const double delta = tstart - (double)g;
+    if (STORE) {
+        if (delta != 0.0) {
+#pragma unroll 8
+            for (int t = 0; t < C; ++t) pd[t] = (T)((double)pd[t] + delta);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < TRAP_NCAP; ++c) {
+        const T v = (T)((double)capv[c] + delta);
+        cap_val[c] = cap_lane[c] >= 0 ? readlane(v, cap_lane[c]) : (T)0;
+    }
+}
+
+template <typename T>
+__device__ void op_trap(Ctx<T>& cx, const DevOp& op) {
+    const DevSlot& ss = cx.prog->slots[op.src];
+    const DevSlot& sd = cx.prog->slots[op.dst];
+    // ic[9]: static "output is all NaN" (rise == 0: the reference reads w_out[-1] = NaN, trap_filters.py:65-66)
+    if (cx.slot_nan(op.src) || op.ic[9]) {
+        cx.set_nan(op.dst, true);
+        return;
+    }
+    const int none[TRAP_NCAP] = {-1, -1, -1, -1};
+    T dummy[TRAP_NCAP];
+    if (op.opcode == DSP_OP_TRAP_FILTER)
+        trap_core<T, TRAP_FILTER, true>(cx, op, ss, sd, none, dummy);
+    else if (op.opcode == DSP_OP_TRAP_NORM)
+        trap_core<T, TRAP_NORM, true>(cx, op, ss, sd, none, dummy);
+    else
+        trap_core<T, TRAP_ASYM, true>(cx, op, ss, sd, none, dummy);
+    cx.set_nan(op.dst, false);
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fixed_time_pickoff  (processors/fixed_time_pickoff.py:12-125), modes i n f c l h (float64 interpolation weights)
+// w4 = samples at i0-1, i0, i0+1, i0+2 (only the in-range ones are used)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ T pickoff_eval(Ctx<T>& cx, T t_in, int mode, int n, const T* w4) {
+    const int i0 = (int)t_in;
+    if ((T)i0 == t_in) return w4[1];
+    const double t0 = (double)t_in - (double)i0;
+    const double t1 = 1.0 - t0;
+    switch (mode) {
+        case 'n': return (t0 < 0.5) ? w4[1] : w4[2];
+        case 'f': return w4[1];
+        case 'c': return w4[2];
+        case 'l': return (T)(t1 * (double)w4[1] + t0 * (double)w4[2]);
+        case 'h': {
+            const double m0 = (i0 == 0) ? (double)(T)(w4[2] - w4[1]) : (double)(T)(w4[2] - w4[0]) / 2.0;
+            const double m1 = (i0 == n - 2) ? (double)(T)(w4[2] - w4[1]) : (double)(T)(w4[3] - w4[1]) / 2.0;
+            const double t1_2 = t1 * t1, t1_3 = t1 * t1_2, t0_2 = t0 * t0, t0_3 = t0 * t0_2;
+            return (T)(((((-2.0 * t1_3 + 3.0 * t1_2) * (double)w4[1] + (-2.0 * t0_3 + 3.0 * t0_2) * (double)w4[2]) - (t1_3 - t1_2) * m0)) +
+                       (t0_3 - t0_2) * m1);
+        }
+        case 'i': cx.fatal(DSP_E_FTP_INT); return quiet_nan<T>();
+        default: cx.fatal(DSP_E_FTP_MODE); return quiet_nan<T>();
+    }
+}
+
+// in-range test of fixed_time_pickoff.py:68-74; returns false when the output must be NaN
+template <typename T>
+__device__ __forceinline__ bool pickoff_in_range(T t_in, int n) {
+    return !(t_in != t_in) && !(t_in < (T)0) && !(t_in > (T)(n - 1));
+}
+
+template <typename T>
+__device__ void op_pickoff(Ctx<T>& cx, const DevOp& op) {
+    const DevSlot& ss = cx.prog->slots[op.src];
+    const T t_in = cx.scalar(op.sp[0]);
+    T out = quiet_nan<T>();
+    if (!cx.slot_nan(op.src) && pickoff_in_range(t_in, ss.len)) {
+        const int i0 = (int)t_in;
+        T w4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int e = i0 - 1 + k;
+            e = e < 0 ? 0 : (e > ss.len - 1 ? ss.len - 1 : e);
+            w4[k] = cx.lds[padded_index(ss, e)];
+        }
+        out = pickoff_eval(cx, t_in, op.ip[0], ss.len, w4);
+    }
+    if (lane_id() == 0) cx.sregs()[op.dst] = out;
+    wave_sync();
+}
+
+// TRAP_PICKOFF: trap filter whose only consumer is a fixed_time_pickoff -- the filtered waveform never exists.
+template <typename T>
+__device__ void op_trap_pickoff(Ctx<T>& cx, const DevOp& op) {
+    const DevSlot& ss = cx.prog->slots[op.src];
+    const T t_in = cx.scalar(op.sp[0]);
+    T out = quiet_nan<T>();
+    if (!cx.slot_nan(op.src) && !op.ic[9] && pickoff_in_range(t_in, ss.len)) {
+        const int i0 = (int)t_in;
+        int idx[TRAP_NCAP];
+        const bool wide = (op.io == 'h');
+#pragma unroll
+        for (int k = 0; k < TRAP_NCAP; ++k) {
+            const int e = i0 - 1 + k;
+            const bool need = (k == 1) || (k == 2) || wide;
+            idx[k] = (need && e >= 0 && e < ss.len) ? e : -1;
+        }
+        T w4[TRAP_NCAP];
+        if (op.ip[3] == DSP_OP_TRAP_FILTER)
+            trap_core<T, TRAP_FILTER, false>(cx, op, ss, ss, idx, w4);
+        else if (op.ip[3] == DSP_OP_TRAP_NORM)
+            trap_core<T, TRAP_NORM, false>(cx, op, ss, ss, idx, w4);
+        else
+            trap_core<T, TRAP_ASYM, false>(cx, op, ss, ss, idx, w4);
+        out = pickoff_eval(cx, t_in, op.io, ss.len, w4);
+    }
+    if (lane_id() == 0) cx.sregs()[op.dst] = out;
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// time_point_thresh  (processors/time_point_thresh.py:12-92): comparisons only -> bit exact
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ void op_time_point_thresh(Ctx<T>& cx, const DevOp& op) {
+    const DevSlot& ss = cx.prog->slots[op.src];
+    const T thr = cx.scalar(op.sp[0]), ts_f = cx.scalar(op.sp[1]), walk_f = cx.scalar(op.sp[2]);
+    T out = quiet_nan<T>();
+    const int n = ss.len, C = ss.C, lane = lane_id();
+    if (!(cx.slot_nan(op.src) || thr != thr || ts_f != ts_f || walk_f != walk_f)) {
+        if (floor((double)ts_f) != (double)ts_f) {
+            cx.fatal(DSP_E_TPT_START_INT);
+        } else if (floor((double)walk_f) != (double)walk_f) {
+            cx.fatal(DSP_E_TPT_WALK_INT);
+        } else if ((long long)ts_f < 0 || (long long)ts_f >= n) {
+            cx.fatal(DSP_E_TPT_RANGE);
+        } else {
+            const int ts = (int)ts_f;
+            const T* ps = cx.chunk(ss);
+            const int i0 = lane * C;
+            if ((long long)walk_f == 1) {
+                // smallest i in [ts, n-2] with (w[i] <= thr < w[i+1]) or (w[i] >= thr > w[i+1])
+                int best = 0x7fffffff;
+                T cur = ps[0];
+                for (int t = 0; t < C; ++t) {
+                    const T nxt = (t < C - 1) ? ps[t + 1] : ps[C + 1];  // first sample of the next lane's chunk
+                    const int i = i0 + t;
+                    const bool hit = ((cur <= thr && thr < nxt) || (cur >= thr && thr > nxt)) && i >= ts && i < n - 1;
+                    if (hit && best == 0x7fffffff) best = i;
+                    cur = nxt;
+                }
+                best = wave_min(best);
+                if (best != 0x7fffffff) out = (T)best;
+            } else {
+                // largest i in [1, ts] with (w[i-1] < thr <= w[i]) or (w[i-1] > thr >= w[i])
+                int best = -1;
+                T prv = (lane > 0) ? ps[-2] : (T)0;  // last sample of the previous lane's chunk (pad is at ps[-1])
+                for (int t = 0; t < C; ++t) {
+                    const T cur = ps[t];
+                    const int i = i0 + t;
+                    const bool hit = ((prv < thr && thr <= cur) || (prv > thr && thr >= cur)) && i >= 1 && i <= ts;
+                    if (hit) best = i;
+                    prv = cur;
+                }
+                best = wave_max(best);
+                if (best >= 0) out = (T)best;
+            }
+        }
+    }
+    if (lane == 0) cx.sregs()[op.dst] = out;
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// min_max  (processors/min_max.py:11-82): first occurrence of the extremes (strict comparisons)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ void op_min_max(Ctx<T>& cx, const DevOp& op, bool amax_only) {
+    const DevSlot& ss = cx.prog->slots[op.src];
+    const int n = ss.len, C = ss.C, lane = lane_id();
+    T o_tmin = quiet_nan<T>(), o_tmax = o_tmin, o_amin = o_tmin, o_amax = o_tmin;
+    if (!cx.slot_nan(op.src)) {
+        const T* ps = cx.chunk(ss);
+        const int i0 = lane * C;
+        // lanes entirely beyond n start from sample 0 (broadcast) so they never win
+        const T first = cx.lds[ss.off];
+        T vmin = (i0 < n) ? ps[0] : first, vmax = vmin;
+        int imin = (i0 < n) ? i0 : 0, imax = imin;
+        for (int t = 1; t < C; ++t) {
+            const T v = ps[t];
+            const int i = i0 + t;
+            if (i < n) {
+                if (v < vmin) {
+                    vmin = v;
+                    imin = i;
+                }
+                if (v > vmax) {
+                    vmax = v;
+                    imax = i;
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const T ovmin = __shfl_xor(vmin, m), ovmax = __shfl_xor(vmax, m);
+            const int oimin = __shfl_xor(imin, m), oimax = __shfl_xor(imax, m);
+            if (ovmin < vmin || (ovmin == vmin && oimin < imin)) {
+                vmin = ovmin;
+                imin = oimin;
+            }
+            if (ovmax > vmax || (ovmax == vmax && oimax < imax)) {
+                vmax = ovmax;
+                imax = oimax;
+            }
+        }
+        // value = the sample at the winning index (keeps the sign of a zero like w_in[min_index])
+        o_amin = cx.lds[padded_index(ss, imin)];
+        o_amax = cx.lds[padded_index(ss, imax)];
+        o_tmin = (T)imin;
+        o_tmax = (T)imax;
+    }
+    if (lane == 0) {
+        T* r = cx.sregs();
+        if (amax_only) {
+            r[op.dst] = o_amax;
+        } else {
+            r[op.dst + 0] = o_tmin;
+            r[op.dst + 1] = o_tmax;
+            r[op.dst + 2] = o_amin;
+            r[op.dst + 3] = o_amax;
+        }
+    }
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// discrete_wavelet_transform, Haar  (processors/dwt.py:13-81 -> pywt.downcoef, 'symmetric' extension)
+//   level by level: out[k] = fl(fl(f0*x[2k+1]) + fl(f1*x[2k])), f = (c, c) for 'a', (-c, c) for the last level of 'd'.
+// Runs in place on the scratch slot ip[2] (a copy of src, or src itself when it is dead afterwards).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ void op_dwt_haar(Ctx<T>& cx, const DevOp& op) {
+    const DevSlot& ss = cx.prog->slots[op.src];
+    const DevSlot& st = cx.prog->slots[op.ip[2]];
+    const DevSlot& sd = cx.prog->slots[op.dst];
+    if (cx.slot_nan(op.src)) {
+        cx.set_nan(op.dst, true);
+        return;
+    }
+    const int level = op.ip[0], part = op.ip[1], lane = lane_id();
+    const T c = (T)0.7071067811865476;
+    int len = ss.len;
+    for (int l = 0; l < level; ++l) {
+        const DevSlot& in = (l == 0) ? ss : st;
+        const bool last = (l == level - 1);
+        const DevSlot& out = last ? sd : st;
+        const int half = (len + 1) >> 1;
+        const T f0 = (last && part == 'd') ? -c : c;
+        for (int k0 = 0; k0 < half; k0 += 64) {
+            const int k = k0 + lane;
+            T lo = (T)0, hi = (T)0;
+            if (k < half) {
+                lo = cx.lds[padded_index(in, 2 * k)];
+                hi = cx.lds[padded_index(in, (2 * k + 1 < len) ? 2 * k + 1 : len - 1)];
+            }
+            wave_sync();  // all reads of this round precede its writes (in-place halving)
+            if (k < half) cx.lds[padded_index(out, k)] = (T)(f0 * hi) + (T)(c * lo);
+        }
+        wave_sync();
+        len = half;
+    }
+    // keep the pad of dst finite
+    for (int e = sd.len + lane; e < 64 * sd.C; e += 64) cx.lds[padded_index(sd, e)] = (T)0;
+    cx.set_nan(op.dst, false);
+    wave_sync();
+}
+
+// dst[k] = src[k + ip[0]]
+template <typename T>
+__device__ void op_copy(Ctx<T>& cx, const DevOp& op) {
+    const DevSlot& ss = cx.prog->slots[op.src];
+    const DevSlot& sd = cx.prog->slots[op.dst];
+    if (cx.slot_nan(op.src)) {
+        cx.set_nan(op.dst, true);
+        return;
+    }
+    const int total = 64 * sd.C, lane = lane_id();
+    for (int e = lane; e < total; e += 64) {
+        const int se = e + op.ip[0];
+        cx.lds[padded_index(sd, e)] = (e < sd.len && se < ss.len) ? cx.lds[padded_index(ss, se)] : (T)0;
+    }
+    cx.set_nan(op.dst, false);
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// convolve_wf / fft_convolve_wf  (processors/convolutions.py:14-72, :75-119): direct-form FIR
+//   out[o] = sum_k w[o + start - k] * kern[k]   (np.convolve flips the kernel);  taps are wave-uniform -> scalar loads;
+//   each lane produces R consecutive outputs from a sliding register window, so one LDS read feeds R FMAs.
+// Accumulation: float32 FMA over blocks of 64 taps, block sums added into a float64 total (keeps the error well inside the
+// 1e-6-of-peak bar; NumPy's own float32 summation order is library-internal).
+// ic[0] = start offset in the 'full' convolution, ic[1] = kernel length, ic[2] = taps contain NaN
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ void op_convolve(Ctx<T>& cx, const DevOp& op) {
+    const DevSlot& ss = cx.prog->slots[op.src];
+    const DevSlot& sd = cx.prog->slots[op.dst];
+    if (cx.slot_nan(op.src) || op.ic[2]) {
+        cx.set_nan(op.dst, true);
+        return;
+    }
+    constexpr int R = 5;
+    const T* __restrict__ kern = (const T*)cx.ptrs->p[op.io];
+    const int n = ss.len, m = op.ic[1], start = op.ic[0], p = sd.len, lane = lane_id();
+    for (int o0 = 0; o0 < p; o0 += 64 * R) {
+        const int ob = o0 + lane * R;  // first output of this lane
+        double tot[R];
+        T acc[R], win[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            tot[r] = 0.0;
+            acc[r] = (T)0;
+        }
+        // tap k pairs with input index (ob + r + start - k); window holds inputs for r = 0..R-1 at the current k
+        auto in_at = [&](int i) -> T { return (i >= 0 && i < n) ? cx.lds[padded_index(ss, i)] : (T)0; };
+#pragma unroll
+        for (int r = 0; r < R; ++r) win[r] = in_at(ob + r + start);
+        for (int k = 0; k < m; ++k) {
+            const T kv = kern[k];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = __builtin_fmaf((float)win[r], (float)kv, (float)acc[r]);
+            // slide: next k needs inputs one index lower
+#pragma unroll
+            for (int r = R - 1; r > 0; --r) win[r] = win[r - 1];
+            win[0] = in_at(ob + start - (k + 1));
+            if ((k & 63) == 63) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    tot[r] += (double)acc[r];
+                    acc[r] = (T)0;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int o = ob + r;
+            if (o < p) cx.lds[padded_index(sd, o)] = (T)(tot[r] + (double)acc[r]);
+        }
+    }
+    for (int e = p + lane; e < 64 * sd.C; e += 64) cx.lds[padded_index(sd, e)] = (T)0;
+    cx.set_nan(op.dst, false);
+    wave_sync();
+}
+
+template <typename T>
+__device__ void op_scalar_affine(Ctx<T>& cx, const DevOp& op) {
+    const T a = cx.scalar(op.sp[0]), b = cx.scalar(op.sp[1]), c = cx.scalar(op.sp[2]);
+    if (lane_id() == 0) cx.sregs()[op.dst] = a * b + c;
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// the interpreter
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) dsp_vm_kernel(const DevProgram* __restrict__ prog, IoPtrs ptrs, int64_t n_wf, int* err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int wave = (int)(threadIdx.x >> 6);
+    const int wpb = (int)(blockDim.x >> 6);
+    T* lds = reinterpret_cast<T*>(smem_raw) + (size_t)wave * prog->lds_elems_per_wave;
+    // zero the whole region once: guards below each slot must read as 0 forever, pads start finite
+    for (int e = lane_id(); e < prog->lds_elems_per_wave; e += 64) lds[e] = (T)0;
+    wave_sync();
+
+    Ctx<T> cx;
+    cx.lds = lds;
+    cx.prog = prog;
+    cx.ptrs = &ptrs;
+    cx.err = err;
+    const int64_t total_waves = (int64_t)gridDim.x * wpb;
+    const int n_ops = prog->n_ops;
+    for (int64_t row = (int64_t)blockIdx.x * wpb + wave; row < n_wf; row += total_waves) {
+        cx.row = row;
+        cx.nan_mask = 0;
+        for (int i = 0; i < n_ops; ++i) {
+            const DevOp& op = prog->ops[i];
+            switch (op.opcode) {
+                case DSP_OP_LOAD: op_load(cx, op); break;
+                case DSP_OP_STORE: op_store(cx, op); break;
+                case DSP_OP_STORE_SCALAR: op_store_scalar(cx, op); break;
+                case DSP_OP_BL_SUBTRACT: op_bl_subtract(cx, op); break;
+                case DSP_OP_POLE_ZERO: op_pole_zero(cx, op); break;
+                case DSP_OP_DOUBLE_POLE_ZERO: op_double_pole_zero(cx, op); break;
+                case DSP_OP_TRAP_FILTER:
+                case DSP_OP_TRAP_NORM:
+                case DSP_OP_ASYM_TRAP: op_trap(cx, op); break;
+                case DSP_OP_PICKOFF: op_pickoff(cx, op); break;
+                case DSP_OP_TRAP_PICKOFF: op_trap_pickoff(cx, op); break;
+                case DSP_OP_TIME_POINT_THRESH: op_time_point_thresh(cx, op); break;
+                case DSP_OP_MIN_MAX: op_min_max(cx, op, false); break;
+                case DSP_OP_AMAX: op_min_max(cx, op, true); break;
+                case DSP_OP_DWT_HAAR: op_dwt_haar(cx, op); break;
+                case DSP_OP_COPY: op_copy(cx, op); break;
+                case DSP_OP_CONVOLVE: op_convolve(cx, op); break;
+                case DSP_OP_SCALAR_AFFINE: op_scalar_affine(cx, op); break;
+                default: break;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic batch generator (bench.py): counter-based, so any row can be regenerated
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+
+template <typename OutT>
+__global__ void __launch_bounds__(256) dsp_synth_kernel(OutT* wf, int64_t n_wf, int wf_len, int64_t row_stride, float* baseline,
+                                                        float* t_pick, uint32_t seed_lo, uint32_t seed_hi, int64_t first_row,
+                                                        float inv_tau, float sigma, float pick_offset, float bl_lo, float bl_hi,
+                                                        float amp_lo, float amp_hi) {
+    for (int64_t r = blockIdx.x; r < n_wf; r += gridDim.x) {
+        const uint64_t gr = (uint64_t)(first_row + r);
+        const uint32_t k0 = mix32((uint32_t)gr ^ seed_lo), k1 = mix32((uint32_t)(gr >> 32) ^ seed_hi ^ k0);
+        const float B = bl_lo + (bl_hi - bl_lo) * u01(mix32(k1 ^ 0x1234567u));
+        const float A = amp_lo + (amp_hi - amp_lo) * u01(mix32(k1 ^ 0x89abcdeu));
+        const float t0 = floorf((0.45f + 0.10f * u01(mix32(k1 ^ 0x5555aaau))) * (float)wf_len);
+        if (threadIdx.x == 0) {
+            if (baseline) baseline[r] = B;
+            if (t_pick) t_pick[r] = t0 + pick_offset;
+        }
+        for (int i = threadIdx.x; i < wf_len; i += blockDim.x) {
+            // sum of four uniforms: variance 4/12, rescaled to unit variance
+            uint32_t h = mix32(k1 + 0x9e3779b9u * (uint32_t)(i + 1));
+            const float n = ((u01(h) + u01(mix32(h ^ 0xa5a5a5a5u)) + u01(mix32(h + 0x3c6ef372u)) + u01(mix32(h ^ 0x1b873593u))) - 2.0f) *
+                            1.7320508f;
+            const float d = (float)i - t0;
+            float v = B + sigma * n;
+            if (d >= 0.0f) v += A * __expf(-d * inv_tau);
+            if (sizeof(OutT) == 2)
+                wf[r * row_stride + i] = (OutT)__float2int_rn(v);
+            else
+                wf[r * row_stride + i] = (OutT)v;
+        }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launchers (called from dsp_host.cpp)
+// ------------------------------------------------------------------------------------------------
+extern "C" int dsp_internal_launch_vm_f32(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int* err, int blocks,
+                                          int threads, int lds_bytes, hipStream_t stream) {
+    hipLaunchKernelGGL(dsp_vm_kernel<float>, dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dsp_internal_set_vm_lds(int lds_bytes) {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dsp_vm_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    lds_bytes);
+}
+
+extern "C" const char* dsp_internal_vm_kernel_name() { return "dsp_vm_kernel<float>"; }
+
+extern "C" int dsp_internal_launch_synth(void* wf, int out_dtype, int64_t n_wf, int wf_len, int64_t row_stride, float* baseline,
+                                         float* t_pick, uint64_t seed, int64_t first_row, float tau, float sigma, float pick_offset,
+                                         float bl_lo, float bl_hi, float amp_lo, float amp_hi, hipStream_t stream) {
+    const int blocks = (int)(n_wf < 8192 ? (n_wf > 0 ? n_wf : 1) : 8192);
+    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    if (out_dtype == DSP_I16)
+        hipLaunchKernelGGL(dsp_synth_kernel<int16_t>, dim3(blocks), dim3(256), 0, stream, (int16_t*)wf, n_wf, wf_len, row_stride,
+                           baseline, t_pick, lo, hi, first_row, 1.0f / tau, sigma, pick_offset, bl_lo, bl_hi, amp_lo, amp_hi);
+    else
+        hipLaunchKernelGGL(dsp_synth_kernel<float>, dim3(blocks), dim3(256), 0, stream, (float*)wf, n_wf, wf_len, row_stride, baseline,
+                           t_pick, lo, hi, first_row, 1.0f / tau, sigma, pick_offset, bl_lo, bl_hi, amp_lo, amp_hi);
+    return (int)hipGetLastError();
+}

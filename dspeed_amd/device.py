@@ -1,0 +1,191 @@
+"""Device memory and streams on top of the C ABI -- the counterpart of the reference's pre-allocated
+``ProcChainVar`` buffers (processing_chain.py:259-269), but resident in HBM.
+
+``DeviceArray`` is deliberately tiny: shape, dtype, pointer, explicit copies.  Anything that exposes
+``data_ptr()`` (e.g. a torch tensor on the same device) can be wrapped with ``DeviceArray.from_ptr``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_DTYPES = {np.dtype(np.float32): _lib.F32, np.dtype(np.float64): _lib.F64, np.dtype(np.int16): _lib.I16,
+           np.dtype(np.uint16): _lib.U16, np.dtype(np.int32): _lib.I32, np.dtype(np.uint32): _lib.U32}
+
+
+def dtype_code(dt) -> int:
+    try:
+        return _DTYPES[np.dtype(dt)]
+    except KeyError:
+        raise TypeError(f"dtype {dt} is not supported by the device path") from None
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _lib.lib().dsp_device_count(C.byref(n))
+    return n.value
+
+
+def set_device(i: int) -> None:
+    _lib.check(_lib.lib().dsp_set_device(i), what="set_device")
+
+
+def device_info(i: int = 0) -> dict:
+    name = C.create_string_buffer(256)
+    cus, hbm, lds = C.c_int(), C.c_int64(), C.c_int()
+    _lib.check(_lib.lib().dsp_device_info(i, name, 256, C.byref(cus), C.byref(hbm), C.byref(lds)), what="device_info")
+    return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value, "lds_bytes_per_cu": lds.value}
+
+
+def sync() -> None:
+    _lib.check(_lib.lib().dsp_sync(), what="sync")
+
+
+class Stream:
+    """A HIP stream (``hipStreamNonBlocking``); ``Stream.ptr`` is what the C ABI takes."""
+
+    def __init__(self):
+        p = C.c_void_p()
+        _lib.check(_lib.lib().dsp_stream_create(C.byref(p)), what="stream_create")
+        self.ptr = p
+
+    def sync(self):
+        _lib.check(_lib.lib().dsp_stream_sync(self.ptr), what="stream_sync")
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.lib().dsp_stream_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        p = C.c_void_p()
+        _lib.check(_lib.lib().dsp_event_create(C.byref(p)), what="event_create")
+        self.ptr = p
+
+    def record(self, stream: Stream | None = None):
+        _lib.check(_lib.lib().dsp_event_record(self.ptr, stream.ptr if stream else None), what="event_record")
+
+    def sync(self):
+        _lib.check(_lib.lib().dsp_event_sync(self.ptr), what="event_sync")
+
+    def elapsed_ms(self, later: "Event") -> float:
+        ms = C.c_float()
+        _lib.check(_lib.lib().dsp_event_elapsed_ms(self.ptr, later.ptr, C.byref(ms)), what="event_elapsed")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.lib().dsp_event_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class PinnedArray:
+    """Page-locked host staging buffer viewed as a NumPy array (for H2D/D2H that overlaps kernels)."""
+
+    def __init__(self, shape, dtype):
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.dtype = np.dtype(dtype)
+        nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        _lib.check(_lib.lib().dsp_host_alloc(C.byref(p), nbytes), what="host_alloc")
+        self.ptr = p
+        buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.array = None
+                _lib.lib().dsp_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class DeviceArray:
+    """C-contiguous array in device memory."""
+
+    def __init__(self, shape, dtype, ptr=None, owner=True):
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self._owner = owner and ptr is None
+        if ptr is None:
+            p = C.c_void_p()
+            _lib.check(_lib.lib().dsp_malloc(C.byref(p), self.nbytes), what="malloc")
+            ptr = p.value
+        self.ptr = int(ptr) if ptr else 0
+
+    # -- construction
+    @classmethod
+    def from_numpy(cls, a) -> "DeviceArray":
+        a = np.ascontiguousarray(a)
+        d = cls(a.shape, a.dtype)
+        d.copy_from(a)
+        return d
+
+    @classmethod
+    def from_ptr(cls, ptr: int, shape, dtype) -> "DeviceArray":
+        return cls(shape, dtype, ptr=ptr, owner=False)
+
+    @classmethod
+    def zeros(cls, shape, dtype) -> "DeviceArray":
+        d = cls(shape, dtype)
+        _lib.check(_lib.lib().dsp_memset(d.ptr, 0, d.nbytes, None), what="memset")
+        return d
+
+    # -- copies
+    def copy_from(self, a, stream: Stream | None = None):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.nbytes == self.nbytes, f"size mismatch {a.shape} vs {self.shape}"
+        if stream is None:
+            _lib.check(_lib.lib().dsp_h2d(self.ptr, a.ctypes.data, self.nbytes), what="h2d")
+        else:
+            _lib.check(_lib.lib().dsp_h2d_async(self.ptr, a.ctypes.data, self.nbytes, stream.ptr), what="h2d_async")
+
+    def to_numpy(self, out=None, stream: Stream | None = None):
+        if out is None:
+            out = np.empty(self.shape, dtype=self.dtype)
+        assert out.flags.c_contiguous and out.nbytes == self.nbytes
+        if stream is None:
+            _lib.check(_lib.lib().dsp_d2h(out.ctypes.data, self.ptr, self.nbytes), what="d2h")
+        else:
+            _lib.check(_lib.lib().dsp_d2h_async(out.ctypes.data, self.ptr, self.nbytes, stream.ptr), what="d2h_async")
+        return out
+
+    def view_rows(self, start: int, stop: int) -> "DeviceArray":
+        """Rows [start, stop) of a 2-D (or 1-D) array, sharing memory."""
+        row_bytes = self.nbytes // self.shape[0] if self.shape[0] else 0
+        return DeviceArray((stop - start, *self.shape[1:]), self.dtype, ptr=self.ptr + start * row_bytes, owner=False)
+
+    def __len__(self):
+        return self.shape[0]
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def __repr__(self):
+        return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, ptr=0x{self.ptr:x})"
+
+    def free(self):
+        if self._owner and self.ptr:
+            _lib.lib().dsp_free(self.ptr)
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,225 @@
+/* dspeed_hip.h -- C ABI of the MI355X-native waveform DSP engine (libdspeed_hip.so).
+ *
+ * This is the drop-in boundary for dspeed's hot path:
+ *   - the numba @guvectorize processors of the Ge energy chain
+ *     (reference src/dspeed/processors/{bl_subtract,pole_zero,trap_filters,fixed_time_pickoff,
+ *      time_point_thresh,min_max,dwt,convolutions}.py), and
+ *   - the ProcessingChain inner loop that calls them block by block
+ *     (reference src/dspeed/processing_chain.py:665-673 execute(), :1144-1163 _execute_procs(),
+ *      :1778-1781 ProcessorManager.execute()).
+ * The reference has no FFI of its own (it is pure Python over numba); the binding a maintainer adds is
+ * the ctypes stub shown in INTEGRATION.md, which is what dspeed_amd/_lib.py implements.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all `const void* dev` / `void* dev` pointers are DEVICE pointers
+ *     unless the name says host;  waveforms are C-contiguous rows: row r starts at base + r*row_stride
+ *     (in elements), exactly the (n_wf, wf_len) block layout of ProcChainVar buffers
+ *     (processing_chain.py:259-269);
+ *   - every function returns 0 (DSP_OK) or a negative DSP_ERR_* for API/runtime failures; positive
+ *     DSP_E_* codes are the reference's DSPFatal conditions (config errors detected on the host at
+ *     chain creation, data-dependent ones reported by dsp_chain_check);  nothing throws;
+ *   - per-waveform failure is NaN output, never an error (docs/source/manuals/build_dsp.rst:152-175);
+ *   - a chain handle is bound to the device current at creation and is not thread-safe; independent
+ *     handles may be used from different threads/devices; the only global state is the thread-local
+ *     string behind dsp_last_error().
+ */
+#ifndef DSPEED_HIP_H
+#define DSPEED_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes --------------------------------------------------------------------------- */
+#define DSP_OK 0
+#define DSP_ERR_HIP (-1)         /* a HIP runtime call failed (see dsp_last_error) */
+#define DSP_ERR_ARG (-2)         /* malformed program / bad argument */
+#define DSP_ERR_UNSUPPORTED (-3) /* valid in the reference but not implemented on the device path */
+#define DSP_ERR_TOO_LONG (-4)    /* waveform does not fit the per-wavefront LDS budget */
+
+/* DSPFatal conditions of the reference processors (message texts: dsp_fatal_message) */
+#define DSP_E_PZ_NAN 1         /* pole_zero.py:76-77   data dependent */
+#define DSP_E_DPZ_SHORT 2      /* pole_zero.py:163-166 */
+#define DSP_E_TRAP_RISE 3      /* trap_filters.py:53-54 */
+#define DSP_E_TRAP_FLAT 4      /* trap_filters.py:56-57 */
+#define DSP_E_TRAP_FALL 5      /* trap_filters.py:205-206 */
+#define DSP_E_TRAP_WIDE 6      /* trap_filters.py:59-60 */
+#define DSP_E_FTP_INT 7        /* fixed_time_pickoff.py:84-85   data dependent */
+#define DSP_E_FTP_MODE 8       /* fixed_time_pickoff.py:124-125 data dependent (only raised for non-integer t_in) */
+#define DSP_E_TPT_START_INT 9  /* time_point_thresh.py:67-68    data dependent */
+#define DSP_E_TPT_WALK_INT 10  /* time_point_thresh.py:70-71 */
+#define DSP_E_TPT_RANGE 11     /* time_point_thresh.py:73-74    data dependent */
+#define DSP_E_CONV_LONG 12     /* convolutions.py:48-49 */
+#define DSP_E_CONV_OUTLEN 13   /* convolutions.py:52-67 */
+#define DSP_E_CONV_MODE 14     /* convolutions.py:69-70 */
+#define DSP_E_DWT_LEVEL 15     /* dwt.py:67-68 */
+#define DSP_E_DWT_OUTLEN 16    /* shape mismatch in dwt.py:81 */
+#define DSP_E_ZERODIV 17       /* numba error_model='python': division by a zero rise/fall */
+
+/* ---- element types -------------------------------------------------------------------------- */
+#define DSP_F32 0
+#define DSP_F64 1
+#define DSP_I16 2
+#define DSP_U16 3
+#define DSP_I32 4
+#define DSP_U32 5
+
+/* ---- device, memory, streams (thin, so a host needs nothing but this library) --------------------- */
+int dsp_device_count(int* count);
+int dsp_set_device(int device);
+int dsp_get_device(int* device);
+int dsp_device_info(int device, char* name, int name_cap, int* compute_units, int64_t* hbm_bytes, int* lds_bytes_per_cu);
+int dsp_malloc(void** dev, int64_t bytes);
+int dsp_free(void* dev);
+int dsp_host_alloc(void** host, int64_t bytes); /* pinned, for async staging */
+int dsp_host_free(void* host);
+int dsp_memset(void* dev, int value, int64_t bytes, void* stream);
+int dsp_h2d(void* dev, const void* host, int64_t bytes);                      /* synchronous */
+int dsp_d2h(void* host, const void* dev, int64_t bytes);                      /* synchronous */
+int dsp_h2d_async(void* dev, const void* host, int64_t bytes, void* stream);  /* host must be pinned to overlap */
+int dsp_d2h_async(void* host, const void* dev, int64_t bytes, void* stream);
+int dsp_stream_create(void** stream);
+int dsp_stream_destroy(void* stream);
+int dsp_stream_sync(void* stream); /* NULL = default stream */
+int dsp_sync(void);                /* whole device */
+int dsp_event_create(void** event);
+int dsp_event_destroy(void* event);
+int dsp_event_record(void* event, void* stream);
+int dsp_event_sync(void* event);
+int dsp_event_elapsed_ms(void* start, void* stop, float* ms);
+const char* dsp_last_error(void);             /* thread-local text of the last failure */
+const char* dsp_fatal_message(int dsp_e_code); /* the reference's DSPFatal message for a DSP_E_* code */
+const char* dsp_version(void);
+
+/* ---- fused chains: the ProcessingChain inner loop on the device ------------------------------------
+ * A chain is a small program run by one wavefront per waveform with every intermediate waveform
+ * resident in LDS.  It replaces, for one batch of n_wf rows, the reference's
+ *     for block in range(0, n, 16): read inputs; for proc in procs: proc.execute(); write outputs
+ * (processing_chain.py:665-673, 1144-1163).  The host (dspeed_amd.processing_chain) translates a
+ * dspeed JSON recipe into this program.
+ */
+#define DSP_MAX_OPS 48
+#define DSP_MAX_SLOTS 8
+#define DSP_MAX_IO 24
+#define DSP_MAX_SREGS 32
+
+/* I/O binding kinds */
+#define DSP_IO_WF_IN 0      /* waveform input  (n_wf rows of `len` samples starting at `offset` within each row) */
+#define DSP_IO_WF_OUT 1     /* waveform output */
+#define DSP_IO_SCALAR_IN 2  /* one value per waveform */
+#define DSP_IO_SCALAR_OUT 3 /* one value per waveform */
+#define DSP_IO_TAPS 4       /* one constant vector shared by all waveforms (FIR kernel), len elements */
+
+typedef struct dsp_io_desc {
+    int32_t kind;       /* DSP_IO_* */
+    int32_t dtype;      /* DSP_F32 ... ; outputs are always the chain's compute type */
+    int32_t len;        /* samples per row used by the chain (1 for scalars) */
+    int32_t offset;     /* first sample within the row: a constant slice wf[offset:offset+len] costs nothing */
+    int64_t row_stride; /* elements between consecutive rows (>= offset+len; 1 for scalars; 0 = same value for all rows) */
+} dsp_io_desc;
+
+/* scalar operand of an op */
+#define DSP_ARG_CONST 0 /* value */
+#define DSP_ARG_INPUT 1 /* index = I/O binding of kind DSP_IO_SCALAR_IN */
+#define DSP_ARG_REG 2   /* index = scalar register written by an earlier op */
+typedef struct dsp_scalar_arg {
+    int32_t kind;
+    int32_t index;
+    double value;
+} dsp_scalar_arg;
+
+/* opcodes; (reference processor, file:line) */
+#define DSP_OP_LOAD 1          /* dst <- io (waveform input; int16/uint16 rows are widened like NumPy's ufunc casting, processing_chain.py:1565-1572) */
+#define DSP_OP_STORE 2         /* io <- src */
+#define DSP_OP_STORE_SCALAR 3  /* io <- sreg[ip[0]] */
+#define DSP_OP_BL_SUBTRACT 4   /* bl_subtract.py:11-46      dst <- src - sp[0] */
+#define DSP_OP_POLE_ZERO 5     /* pole_zero.py:24-77        sp[0] = tau (const) */
+#define DSP_OP_DOUBLE_POLE_ZERO 6 /* pole_zero.py:82-198    sp[0..2] = tau1, tau2, frac (const) */
+#define DSP_OP_TRAP_FILTER 7   /* trap_filters.py:12-76     ip[0..1] = rise, flat */
+#define DSP_OP_TRAP_NORM 8     /* trap_filters.py:79-149 */
+#define DSP_OP_ASYM_TRAP 9     /* trap_filters.py:152-227   ip[0..2] = rise, flat, fall */
+#define DSP_OP_PICKOFF 10      /* fixed_time_pickoff.py:12-125  sreg[dst] <- src at sp[0]; ip[0] = mode char */
+#define DSP_OP_TIME_POINT_THRESH 11 /* time_point_thresh.py:12-92  sreg[dst] <- src; sp[0..2] = threshold, t_start, walk_forward */
+#define DSP_OP_MIN_MAX 12      /* min_max.py:11-82          sreg[dst..dst+3] <- t_min, t_max, a_min, a_max */
+#define DSP_OP_DWT_HAAR 13     /* dwt.py:13-81              dst <- src; ip[0] = level, ip[1] = 'a'|'d', ip[2] = scratch slot */
+#define DSP_OP_CONVOLVE 14     /* convolutions.py:14-72,75-119  dst <- src (*) io taps; ip[0] = mode char f|v|s */
+#define DSP_OP_COPY 15         /* dst[k] <- src[k + ip[0]]  (constant slice of an intermediate, processing_chain.py:1024-1071) */
+#define DSP_OP_TRAP_PICKOFF 16 /* fusion of TRAP_FILTER|TRAP_NORM|ASYM_TRAP (ip[3] = which opcode) with PICKOFF: the trap output is
+                                  never materialised; sreg[dst] <- trap(src) at sp[0]; ip[0..2] = rise, flat, fall; mode in `io` */
+#define DSP_OP_AMAX 17         /* numpy.amax along the sample axis (icpc-dsp-config.json:123-143): sreg[dst] <- max(src), NaN if any NaN */
+#define DSP_OP_SCALAR_AFFINE 18 /* sreg[dst] <- sp[0] * sp[1] + sp[2]  (host-folded expressions such as tp_0 + 10*us) */
+
+typedef struct dsp_op {
+    int32_t opcode;
+    int32_t dst; /* waveform slot, or first scalar register written */
+    int32_t src; /* waveform slot read */
+    int32_t io;  /* I/O binding index (LOAD/STORE/STORE_SCALAR/CONVOLVE) or mode char (TRAP_PICKOFF) */
+    int32_t ip[4];
+    dsp_scalar_arg sp[3];
+} dsp_op;
+
+typedef struct dsp_chain dsp_chain; /* opaque */
+
+/* compute_dtype: DSP_F32 (the loop int16/uint16/float32 inputs select) -- DSP_F64 is reserved.
+ * slot_len[s] = number of samples held by waveform slot s (static per chain, like ProcChainVar shapes).
+ * Validates the program and every constant-only DSPFatal condition; on failure returns the code and *out = NULL. */
+int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_io, const int32_t* slot_len, int n_slots,
+                     int n_sregs, int compute_dtype, dsp_chain** out);
+/* Enqueue one pass over n_wf rows on `stream` (asynchronous).  io_ptrs[k] = device pointer for binding k. */
+int dsp_chain_execute(dsp_chain* chain, void* const* io_ptrs, int64_t n_wf, void* stream);
+/* Wait for the chain's stream work and return 0 or the first data-dependent DSPFatal (code > 0) with the
+ * offending row in *row (the reference raises it with wf_range, processing_chain.py:1154-1159). */
+int dsp_chain_check(dsp_chain* chain, void* stream, int64_t* row);
+int dsp_chain_destroy(dsp_chain* chain);
+/* launch geometry chosen for the chain (for DESIGN.md / profiling): bytes of LDS per wavefront, wavefronts per
+ * workgroup, workgroups for a batch of n_wf rows */
+int dsp_chain_geometry(dsp_chain* chain, int64_t n_wf, int* lds_bytes_per_wave, int* waves_per_block, int* blocks);
+/* name of the device kernel the chain launches (what rocprofv3 --kernel-trace lists) */
+const char* dsp_chain_kernel_name(dsp_chain* chain);
+
+/* ---- single processors: the gufunc entry points -----------------------------------------------------
+ * One call = one reference gufunc call on an (n_wf, wf_len) block: `in`/`out` device pointers, rows
+ * `*_stride` elements apart.  Scalar gufunc arguments "()" come as (pointer, value): if the pointer is
+ * non-NULL it is a device array with one value per waveform, otherwise `value` is broadcast.
+ * The call is synchronous with respect to errors: it returns DSP_OK or the DSP_E_* code (first offending
+ * row in *err_row when not NULL).  `<ty>`: f32 takes float32 rows; i16/u16 take (u)int16 rows and run the
+ * float32 loop (outputs float32), as the reference's type matching does.
+ */
+int dsp_bl_subtract_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* baseline_dev,
+                        float baseline, float* out, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_pole_zero_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float tau, float* out,
+                      int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_double_pole_zero_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float tau1, float tau2,
+                             float frac, float* out, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_trap_filter_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,
+                        float* out, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_trap_norm_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,
+                      float* out, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_asym_trap_filter_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise,
+                             int32_t flat, int32_t fall, float* out, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_fixed_time_pickoff_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* t_in_dev,
+                               float t_in, int32_t mode_char, float* out, void* stream, int64_t* err_row);
+int dsp_time_point_thresh_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
+                              const float* threshold_dev, float threshold, const float* t_start_dev, float t_start,
+                              float walk_forward, float* out, void* stream, int64_t* err_row);
+int dsp_min_max_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float* t_min, float* t_max,
+                    float* a_min, float* a_max, void* stream, int64_t* err_row);
+int dsp_dwt_haar_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t level, int32_t coeff_char,
+                     float* out, int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_convolve_wf_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* kernel_dev,
+                        int32_t kernel_len, int32_t mode_char, float* out, int32_t out_len, int64_t out_stride, void* stream,
+                        int64_t* err_row);
+
+/* ---- synthetic batches generated on the device (bench.py) ---------------------------------
+ * wf[r][i] = B_r + A_r*exp(-(i-t0_r)/tau)*[i>=t0_r] + sigma*n(r,i), counter-based hash noise;  also writes the
+ * per-waveform baseline B_r and the pick-off time t0_r + pick_offset (samples).  out_dtype DSP_F32 or DSP_I16. */
+int dsp_synth_waveforms(void* wf, int out_dtype, int64_t n_wf, int32_t wf_len, int64_t row_stride, float* baseline, float* t_pick,
+                        uint64_t seed, int64_t first_row, float tau, float sigma, float pick_offset, float bl_lo, float bl_hi,
+                        float amp_lo, float amp_hi, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSPEED_HIP_H */

@@ -1,0 +1,87 @@
+"""GPU parity of the fused chains (one launch, intermediates in LDS) against the golden chain fixtures and the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from golden_util import assert_rel_to_peak, cases
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+
+
+def _run_energy(wf, bl, tp, tau, rise, flat, mode="l"):
+    from dspeed_amd.chain import Chain, energy_chain_program
+    from dspeed_amd.device import DeviceArray
+
+    n_wf, wf_len = wf.shape
+    ch = Chain(energy_chain_program(wf_len, tau, rise, flat, mode, wf_dtype=wf.dtype), "energy")
+    bufs = {"waveform": DeviceArray.from_numpy(wf), "baseline": DeviceArray.from_numpy(bl), "t_pick": DeviceArray.from_numpy(tp),
+            "trapEftp": DeviceArray((n_wf,), np.float32)}
+    ch.execute(bufs, n_wf)
+    ch.check()
+    return bufs["trapEftp"].to_numpy()
+
+
+def test_energy_chain_golden():
+    c2 = cases("chains")[1]
+    p = c2.params
+    got = _run_energy(c2["waveform"], c2["baseline"], c2["t_pick"], p["tau"], p["rise"], p["flat"], p["mode"])
+    want = c2["trapEftp"]
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    rel = np.abs(got[ok] - want[ok]) / np.abs(want[ok])
+    print("fused energy chain vs golden: max rel", rel.max())
+    assert rel.max() <= TOL
+
+
+@pytest.mark.parametrize("wf_len,rise,flat", [(4096, 625, 188), (1024, 64, 16), (8192, 1250, 376), (6092, 500, 100)])
+def test_energy_chain_vs_oracle(wf_len, rise, flat):
+    rng = np.random.default_rng(wf_len + rise)
+    n_wf = 300
+    i = np.arange(wf_len, dtype=np.float64)[None, :]
+    B = rng.uniform(9000, 11000, (n_wf, 1))
+    A = rng.uniform(500, 15000, (n_wf, 1))
+    t0 = np.floor(rng.uniform(0.45, 0.55, (n_wf, 1)) * wf_len)
+    wf = (B + A * np.exp(-(i - t0) / 1716.28) * (i >= t0) + 5.0 * rng.standard_normal((n_wf, wf_len))).astype(np.float32)
+    bl = B[:, 0].astype(np.float32)
+    tp = (t0[:, 0] + rise + 0.8 * flat).astype(np.float32)
+    wf[11, 17] = np.nan
+    tp[12] = np.float32(np.floor(tp[12]))
+    tp[13] = np.float32(wf_len + 3)
+    for mode in "lnh":
+        got = _run_energy(wf, bl, tp, 1716.28, rise, flat, mode)
+        want, rc = oracle.chain_energy(wf, bl, tp, 1716.28, rise, flat, mode)
+        assert rc == 0
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        ok = ~np.isnan(want)
+        rel = np.abs(got[ok] - want[ok]) / np.abs(want[ok])
+        print(f"len={wf_len} mode={mode}: max rel {rel.max():.2e}, median {np.median(rel):.2e}, bit-exact {np.mean(got[ok] == want[ok]):.2f}")
+        assert rel.max() <= TOL
+
+
+def test_energy_chain_matches_unfused_processors():
+    """fused chain == the same processors called one by one on the device (the ProcessingChain way)"""
+    from dspeed_amd import processors as P
+
+    rng = np.random.default_rng(99)
+    n_wf, wf_len = 64, 4096
+    wf = (10000 + 3000 * (np.arange(wf_len)[None, :] > 2000) + 5 * rng.standard_normal((n_wf, wf_len))).astype(np.float32)
+    bl = np.full(n_wf, 10000, dtype=np.float32)
+    tp = np.full(n_wf, 2000 + 625 + 150.4, dtype=np.float32)
+    fused = _run_energy(wf, bl, tp, 1716.28, 625, 188)
+    step = P.fixed_time_pickoff(P.trap_filter(P.pole_zero(P.bl_subtract(wf, bl), 1716.28), 625, 188), tp, ord("l"))
+    assert np.array_equal(fused, step)
+
+
+def test_data_dependent_fatal_reports_row():
+    from dspeed_amd.errors import DSPFatal
+
+    wf = np.ones((10, 256), dtype=np.float32)
+    bl = np.zeros(10, dtype=np.float32)
+    tp = np.full(10, 100.0, dtype=np.float32)
+    tp[6] = 100.5
+    with pytest.raises(DSPFatal) as ei:
+        _run_energy(wf, bl, tp, 100.0, 16, 8, "i")
+    assert ei.value.wf_range == range(6, 7)
+    assert "integer t_in" in str(ei.value)

@@ -1,0 +1,255 @@
+"""GPU parity tests: every hot-path processor, called through the gufunc protocol objects of
+``dspeed_amd.processors`` (-> ctypes -> C ABI -> HIP kernels), against
+
+* the committed golden fixtures (outputs of the reference's own kernel bodies, tests/golden), and
+* the CPU oracle on seeded random inputs at sizes it finishes in seconds.
+
+Bars (BASELINE.json north_star): bit-exact for index/threshold results and for every kernel whose device
+evaluation order equals the reference's (bl_subtract, pickoff, thresholds, min/max, DWT); 1e-6 relative to the
+waveform's peak for float32 filter outputs (pole-zero and trapezoid families, FIR).
+"""
+import numpy as np
+import pytest
+
+import oracle
+from golden_util import assert_rel_to_peak, cases, zerodiv
+
+pytestmark = pytest.mark.gpu
+
+FILTER_TOL = 1e-6  # relative to max |reference output| of the waveform (north_star: "within 1e-6 relative")
+
+
+@pytest.fixture(scope="module")
+def P():
+    from dspeed_amd import processors
+
+    return processors
+
+
+@pytest.fixture(scope="module")
+def DSPFatal():
+    from dspeed_amd.errors import DSPFatal
+
+    return DSPFatal
+
+
+def _f32(cs):
+    return [c for c in cs if c.tag == "f32"]
+
+
+def _eq(got, want, what):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, f"{what}: shape {got.shape} vs {want.shape}"
+    assert np.array_equal(got, want, equal_nan=True), f"{what}: not bit-identical (max diff {np.nanmax(np.abs(got - want))})"
+
+
+def _expect(c, DSPFatal, fn):
+    if c.fatal:
+        with pytest.raises(DSPFatal):
+            fn()
+        return None
+    return fn()
+
+
+# ------------------------------------------------------------------------------------------------ golden fixtures
+@pytest.mark.parametrize("c", _f32(cases("bl_subtract")), ids=lambda c: c.name)
+def test_bl_subtract_golden(c, P, DSPFatal):
+    out = _expect(c, DSPFatal, lambda: P.bl_subtract(c["w_in"], c["baseline"]))
+    _eq(out, c["w_out"], c.name)
+
+
+@pytest.mark.parametrize("c", _f32(cases("pole_zero")), ids=lambda c: c.name)
+def test_pole_zero_golden(c, P, DSPFatal):
+    out = _expect(c, DSPFatal, lambda: P.pole_zero(c["w_in"], c.params["tau"]))
+    if out is not None:
+        assert out.dtype == np.float32
+        assert_rel_to_peak(out, c["w_out"], FILTER_TOL, c.name)
+
+
+@pytest.mark.parametrize("c", _f32(cases("double_pole_zero")), ids=lambda c: c.name)
+def test_double_pole_zero_golden(c, P, DSPFatal):
+    p = c.params
+    out = _expect(c, DSPFatal, lambda: P.double_pole_zero(c["w_in"], p["tau1"], p["tau2"], p["frac"]))
+    if out is not None:
+        assert_rel_to_peak(out, c["w_out"], FILTER_TOL, c.name)
+
+
+@pytest.mark.parametrize("c", _f32(cases("trap_filters")), ids=lambda c: c.name)
+def test_traps_golden(c, P, DSPFatal):
+    p = c.params
+    args = [p["rise"], p["flat"]] + ([p["fall"]] if c.kernel == "asym_trap_filter" else [])
+    fn = getattr(P, c.kernel)
+    if zerodiv(c) and not c.fatal:
+        with pytest.raises(ZeroDivisionError):  # numba error_model='python'
+            fn(c["w_in"], *args)
+        return
+    out = _expect(c, DSPFatal, lambda: fn(c["w_in"], *args))
+    if out is not None:
+        assert_rel_to_peak(out, c["w_out"], FILTER_TOL, c.name)
+
+
+@pytest.mark.parametrize("c", [c for c in _f32(cases("fixed_time_pickoff")) if c.params["mode"] != "s"], ids=lambda c: c.name)
+def test_fixed_time_pickoff_golden(c, P, DSPFatal):
+    out = _expect(c, DSPFatal, lambda: P.fixed_time_pickoff(c["w_in"], c.params["t_in"], ord(c.params["mode"])))
+    if out is not None:
+        _eq(out, c["a_out"], c.name)
+
+
+def test_fixed_time_pickoff_spline_not_silently_wrong(P):
+    with pytest.raises(NotImplementedError):
+        P.fixed_time_pickoff(np.arange(20, dtype=np.float32), 3.5, ord("s"))
+
+
+@pytest.mark.parametrize("c", _f32(cases("time_point_thresh")), ids=lambda c: c.name)
+def test_time_point_thresh_golden(c, P, DSPFatal):
+    p = c.params
+    out = _expect(c, DSPFatal, lambda: P.time_point_thresh(c["w_in"], p["a_threshold"], p["t_start"], p["walk_forward"]))
+    if out is not None:
+        _eq(out, c["t_out"], c.name)
+
+
+@pytest.mark.parametrize("c", _f32(cases("min_max")), ids=lambda c: c.name)
+def test_min_max_golden(c, P):
+    out = P.min_max(c["w_in"])
+    _eq(np.array(out, dtype=np.float32), c["out"], c.name)
+
+
+@pytest.mark.parametrize("c", _f32(cases("dwt")), ids=lambda c: c.name)
+def test_dwt_golden(c, P):
+    want = c["w_out"]
+    out = np.empty_like(want)
+    P.discrete_wavelet_transform(c["w_in"], c.params["level"], ord(c.params["wave_type"]), ord(c.params["coeff"]), out)
+    _eq(out, want, c.name)
+
+
+@pytest.mark.parametrize("c", _f32(cases("convolutions")), ids=lambda c: c.name)
+def test_convolve_golden(c, P, DSPFatal):
+    w, k, want = c["w_in"], c["kernel"], c["w_out"]
+    stop = c.params.get("slice_stop")
+    if stop:
+        w = np.ascontiguousarray(w[:, :stop])
+    fn = P.convolve_wf if c.kernel == "convolve_wf" else P.fft_convolve_wf
+    out = np.empty_like(want)
+    res = _expect(c, DSPFatal, lambda: fn(w, k, ord(c.params["mode"]), out))
+    if res is not None:
+        assert_rel_to_peak(out, want, FILTER_TOL, c.name)
+
+
+# ------------------------------------------------------------------------------------------------ oracle on seeded inputs
+def _synth(rng, n_wf, wf_len, dtype=np.float32, tau=1716.28):
+    i = np.arange(wf_len, dtype=np.float64)[None, :]
+    B = rng.uniform(9000, 11000, (n_wf, 1))
+    A = rng.uniform(500, 15000, (n_wf, 1))
+    t0 = np.floor(rng.uniform(0.45, 0.55, (n_wf, 1)) * wf_len)
+    x = B + A * np.exp(-(i - t0) / tau) * (i >= t0) + 5.0 * rng.standard_normal((n_wf, wf_len))
+    return x.astype(dtype), B[:, 0].astype(np.float32), t0[:, 0]
+
+
+@pytest.mark.parametrize("wf_len", [1024, 4096, 6092, 8192, 100, 37])
+def test_filters_vs_oracle(wf_len, P):
+    rng = np.random.default_rng(wf_len)
+    n_wf = 40
+    w, bl, _ = _synth(rng, n_wf, wf_len)
+    w[3, wf_len // 2] = np.nan
+    xb = P.bl_subtract(w, bl)
+    _eq(xb, oracle.bl_subtract(w, bl)[0], "bl_subtract")
+    pz = P.pole_zero(xb, 1716.28)
+    pz_ref = oracle.pole_zero(xb, 1716.28)[0]
+    assert_rel_to_peak(pz, pz_ref, FILTER_TOL, "pole_zero")
+    dpz = P.double_pole_zero(xb, 1716.28, 62.5, 0.02)
+    assert_rel_to_peak(dpz, oracle.double_pole_zero(xb, 1716.28, 62.5, 0.02)[0], FILTER_TOL, "double_pole_zero")
+    r, f = max(1, wf_len * 625 // 4096), wf_len * 188 // 4096
+    for name, args in (("trap_filter", (r, f)), ("trap_norm", (r, f)), ("asym_trap_filter", (max(1, r // 80), f // 40, max(1, r // 5)))):
+        got = getattr(P, name)(pz_ref, *args)
+        want = getattr(oracle, name)(pz_ref, *args)[0]
+        worst = assert_rel_to_peak(got, want, FILTER_TOL, f"{name}{args} len {wf_len}")
+        assert np.isnan(got[3]).all()
+        print(f"{name} len={wf_len}: max |diff|/peak = {worst:.2e}")
+
+
+@pytest.mark.parametrize("wf_len", [64, 1000, 4096, 8192])
+def test_reductions_vs_oracle(wf_len, P):
+    """index / threshold results must be bit-exact on identical inputs"""
+    rng = np.random.default_rng(7 + wf_len)
+    n_wf = 50
+    w, bl, _ = _synth(rng, n_wf, wf_len)
+    x = oracle.asym_trap_filter(oracle.pole_zero(oracle.bl_subtract(w, bl)[0], 1716.28)[0], 8, 4, min(125, wf_len // 4))[0]
+    x[5, 7] = np.nan
+    got = P.min_max(x)
+    want = oracle.min_max(x)[:4]
+    for g, wv, nm in zip(got, want, ("t_min", "t_max", "a_min", "a_max")):
+        _eq(g, wv, nm)
+    tmax = np.nan_to_num(want[1], nan=0.0).astype(np.float32)
+    thr = (0.1 * np.nan_to_num(want[3])).astype(np.float32)
+    for walk, start in ((0, tmax), (1, np.zeros(n_wf, dtype=np.float32))):
+        got = P.time_point_thresh(x, thr, start, walk)
+        _eq(got, oracle.time_point_thresh(x, thr, start, walk)[0], f"tpt walk={walk}")
+    t_in = rng.uniform(-2, wf_len + 1, n_wf).astype(np.float32)
+    t_in[::7] = np.floor(t_in[::7])
+    for mode in "nfclh":
+        got = P.fixed_time_pickoff(x, t_in, ord(mode))
+        _eq(got, oracle.fixed_time_pickoff(x, t_in, mode)[0], f"pickoff {mode}")
+
+
+def test_int16_input_runs_float32_loop(P):
+    """uint16/int16 waveforms select the float32 loop (reference processing_chain.py:1565-1572)"""
+    rng = np.random.default_rng(3)
+    w, _, _ = _synth(rng, 8, 2048)
+    for dt in (np.int16, np.uint16):
+        wi = np.rint(w).astype(dt)
+        got = P.double_pole_zero(wi, 1716.28, 62.5, 0.02)
+        assert got.dtype == np.float32
+        assert_rel_to_peak(got, oracle.double_pole_zero(wi.astype(np.float32), 1716.28, 62.5, 0.02)[0], FILTER_TOL, str(dt))
+
+
+def test_dwt_vs_oracle(P):
+    rng = np.random.default_rng(11)
+    for n, level in ((8192, 5), (4096, 3), (1000, 4), (6092, 2), (64, 6)):
+        w = (rng.standard_normal((6, n)) * 100).astype(np.float32)
+        m = n
+        for _ in range(level):
+            m = (m + 1) // 2
+        for part in "ad":
+            out = np.empty((6, m), dtype=np.float32)
+            P.discrete_wavelet_transform(w, level, ord("h"), ord(part), out)
+            _eq(out, oracle.dwt_haar(w, level, part, m)[0], f"dwt n={n} level={level} {part}")
+
+
+def test_device_arrays_stay_on_device(P):
+    from dspeed_amd.device import DeviceArray
+
+    rng = np.random.default_rng(5)
+    w, bl, _ = _synth(rng, 16, 4096)
+    d_w, d_bl = DeviceArray.from_numpy(w), DeviceArray.from_numpy(bl)
+    d_out = DeviceArray((16, 4096), np.float32)
+    res = P.bl_subtract(d_w, d_bl, d_out)
+    assert res is d_out
+    _eq(d_out.to_numpy(), oracle.bl_subtract(w, bl)[0], "device path")
+
+
+def test_reference_style_calls(P, DSPFatal):
+    """The reference's own processor tests, float32 flavour (tests/processors/test_pole_zero.py:14-48,
+    test_time_point_thresh.py:82-115, test_fixed_time_pickoff.py:50-59)."""
+    tau, amp = 30000, 17500
+    ts = np.arange(0, 8192, dtype=np.float64)
+    pulse = np.zeros(len(ts) + 20, dtype=np.float32)
+    pulse[20:] = amp * np.exp(-ts / tau)
+    expected = np.concatenate([np.zeros(20), np.full(len(ts), amp)])
+    res = P.pole_zero(pulse, tau)
+    assert res.dtype == np.float32 and np.allclose(res, expected, rtol=1e-6)
+    saw = np.concatenate([np.arange(-1, 5, 1), np.arange(-1, 5, 1)]).astype(np.float32)
+    assert P.time_point_thresh(saw, 1, 11, 0) == 8.0
+    assert P.time_point_thresh(saw, 3, 0, 1) == 4.0
+    with pytest.raises(DSPFatal):
+        P.time_point_thresh(saw, 1, 10.5, 0)
+    with pytest.raises(DSPFatal):
+        P.time_point_thresh(saw, 1, 12, 0)
+    ramp = np.arange(20, dtype=np.float32)
+    for ch, sol in zip("nfclh", [4, 3, 4, 3.5, 3.5]):
+        assert P.fixed_time_pickoff(ramp, 3.5, ord(ch)) == sol
+    with pytest.raises(DSPFatal):
+        P.fixed_time_pickoff(np.ones(20, dtype=np.float32), 1.5, ord("i"))
+    with pytest.raises(DSPFatal):
+        P.fixed_time_pickoff(np.ones(20, dtype=np.float32), 1.5, ord(" "))
+    with pytest.raises(DSPFatal):
+        P.double_pole_zero(np.ones(2, dtype=np.float32), 1000, 30000, 0.98)
