@@ -157,9 +157,17 @@ class Staging:
         return d.ptr, host
 
     def finish(self):
-        for d, host in self.copy_back:
-            tmp = d.to_numpy()
-            host[...] = tmp.reshape(host.shape).astype(host.dtype, copy=False)
+        """Copy outputs back to the caller's arrays, then release the staging buffers (idempotent)."""
+        pending, self.copy_back = self.copy_back, []
+        try:
+            for d, host in pending:
+                tmp = d.to_numpy()
+                host[...] = tmp.reshape(host.shape).astype(host.dtype, copy=False)
+        finally:
+            self.release()
+
+    def release(self):
+        self.copy_back = []
         for d in self.keep:
             d.free()
         self.keep.clear()

@@ -70,7 +70,7 @@ def _wf2wf(name, n_scalars=0, n_ints=0, scalar_cols=()):
             st.finish()
             return res
         finally:
-            st.finish()
+            st.release()
 
     return impl
 
@@ -122,7 +122,7 @@ def _fixed_time_pickoff(g, *args):
         st.finish()
         return res[()] if isinstance(res, np.ndarray) and res.ndim == 0 else res
     finally:
-        st.finish()
+        st.release()
 
 
 def _time_point_thresh(g, *args):
@@ -140,7 +140,7 @@ def _time_point_thresh(g, *args):
         st.finish()
         return res[()] if isinstance(res, np.ndarray) and res.ndim == 0 else res
     finally:
-        st.finish()
+        st.release()
 
 
 def _min_max(g, *args):
@@ -155,7 +155,7 @@ def _min_max(g, *args):
         st.finish()
         return tuple(r[()] if isinstance(r, np.ndarray) and r.ndim == 0 else r for _, r in pr)
     finally:
-        st.finish()
+        st.release()
 
 
 fixed_time_pickoff = HipGUFunc("fixed_time_pickoff", "(n),(),()->()", ["ffb->f", "ddb->d"], _fixed_time_pickoff,
@@ -184,7 +184,7 @@ def _dwt(g, *args):
         st.finish()
         return res
     finally:
-        st.finish()
+        st.release()
 
 
 def _convolve(g, *args):
@@ -210,7 +210,7 @@ def _convolve(g, *args):
         st.finish()
         return res
     finally:
-        st.finish()
+        st.release()
 
 
 discrete_wavelet_transform = HipGUFunc("discrete_wavelet_transform", "(n),(),(),(),(m)", ["fibbf", "dlbbd"], _dwt,
