@@ -109,6 +109,10 @@ class Chain:
         _lib.check(_lib.lib().dsp_chain_geometry(self._h, int(n_wf), C.byref(a), C.byref(b), C.byref(c)))
         return {"lds_bytes_per_wave": a.value, "waves_per_block": b.value, "blocks": c.value}
 
+    def set_fused(self, enable: bool) -> bool:
+        """Use (True, default) or bypass (False) the specialised energy-chain kernel; returns whether it is in use."""
+        return bool(_lib.lib().dsp_chain_set_fused(self._h, 1 if enable else 0))
+
     @property
     def kernel_name(self) -> str:
         return _lib.lib().dsp_chain_kernel_name(self._h).decode()

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -29,6 +30,37 @@ extern "C" const char* dsp_internal_vm_kernel_name();
 extern "C" int dsp_internal_launch_synth(void* wf, int out_dtype, int64_t n_wf, int wf_len, int64_t row_stride, float* baseline,
                                          float* t_pick, uint64_t seed, int64_t first_row, float tau, float sigma, float pick_offset,
                                          float bl_lo, float bl_hi, float amp_lo, float amp_hi, hipStream_t stream);
+
+// mirror of the struct in dsp_energy.hip
+struct EnergyArgs {
+    const void* wf;
+    int64_t wf_stride;
+    int32_t wf_offset;
+    int32_t len;
+    const float* bl;
+    int64_t bl_stride;
+    float bl_const;
+    int32_t has_bl;
+    const float* tp;
+    int64_t tp_stride;
+    float tp_const;
+    int32_t mode;
+    float* out;
+    int64_t out_stride;
+    double c;
+    double rr, ll;
+    int32_t tau_nan;
+    int32_t all_nan;
+    int32_t C, pitch;
+    float invC;
+    int32_t q[3], rho[3];
+    int32_t lds_elems_per_wave;
+    int32_t slot_off;
+};
+extern "C" int dsp_internal_launch_energy(const EnergyArgs* A, int trap_opcode, int npf, int64_t n_wf, int* err, int blocks,
+                                          int threads, int lds_bytes, hipStream_t stream);
+extern "C" int dsp_internal_set_energy_lds(int trap_opcode, int npf, int lds_bytes);
+extern "C" const char* dsp_internal_energy_kernel_name();
 
 namespace {
 
@@ -71,7 +103,11 @@ struct dsp_chain {
     int lds_bytes_per_wave = 0;
     int waves_per_block = 0;
     int num_cu = 256;
-    bool dirty_err = false;
+    // specialised energy-chain kernel (dsp_energy.hip), selected when the program has exactly that shape
+    bool fused_ok = false, fused_on = true;
+    EnergyArgs fused{};
+    int fused_trap = 0, fused_npf = 0;
+    int io_wf = -1, io_bl = -1, io_tp = -1, io_out = -1;
 };
 
 extern "C" {
@@ -270,7 +306,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         const int len = slot_len[s];
         if (len <= 0) return fail(DSP_ERR_ARG, "slot %d has length %d", s, len);
         int C = (len + 63) / 64;
-        C = ((C + 7) / 8) * 8;
+        C = ((C + 15) / 16) * 16;
         DevSlot& d = P.slots[s];
         d.len = len;
         d.C = C;
@@ -465,6 +501,67 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         }
     }
 
+    // ---- does the program have the shape LOAD [-> BL_SUBTRACT] -> POLE_ZERO -> TRAP_PICKOFF -> STORE_SCALAR on one slot?
+    {
+        int i = 0;
+        const dsp_op* ld = (n_ops > i && ops[i].opcode == DSP_OP_LOAD) ? &ops[i++] : nullptr;
+        const dsp_op* bs = (ld && n_ops > i && ops[i].opcode == DSP_OP_BL_SUBTRACT) ? &ops[i++] : nullptr;
+        const dsp_op* pz = (ld && n_ops > i && ops[i].opcode == DSP_OP_POLE_ZERO) ? &ops[i++] : nullptr;
+        const dsp_op* tp = (pz && n_ops > i && ops[i].opcode == DSP_OP_TRAP_PICKOFF) ? &ops[i++] : nullptr;
+        const dsp_op* st = (tp && n_ops > i && ops[i].opcode == DSP_OP_STORE_SCALAR) ? &ops[i++] : nullptr;
+        const bool shape = st && i == n_ops && n_slots == 1 && io[ld->io].dtype == DSP_F32 && P.io[ld->io].vec_ok &&
+                           (!bs || (bs->dst == 0 && bs->src == 0 && bs->sp[0].kind != DSP_ARG_REG)) && pz->dst == 0 && pz->src == 0 &&
+                           tp->src == 0 && tp->sp[0].kind != DSP_ARG_REG && st->ip[0] == tp->dst && P.slots[0].C <= 64;
+        auto f32_col = [&](const dsp_scalar_arg& a) { return a.kind != DSP_ARG_INPUT || io[a.index].dtype == DSP_F32; };
+        if (shape && (!bs || f32_col(bs->sp[0])) && f32_col(tp->sp[0])) {
+            EnergyArgs& F = ch->fused;
+            const DevOp& dpz = P.ops[pz - ops];
+            const DevOp& dtp = P.ops[tp - ops];
+            F.wf_stride = io[ld->io].row_stride;
+            F.wf_offset = io[ld->io].offset;
+            F.len = slot_len[0];
+            F.has_bl = bs ? 1 : 0;
+            if (bs) {
+                if (bs->sp[0].kind == DSP_ARG_INPUT) {
+                    ch->io_bl = bs->sp[0].index;
+                    F.bl_stride = io[ch->io_bl].row_stride;
+                } else {
+                    F.bl_const = (float)bs->sp[0].value;
+                }
+            }
+            if (tp->sp[0].kind == DSP_ARG_INPUT) {
+                ch->io_tp = tp->sp[0].index;
+                F.tp_stride = io[ch->io_tp].row_stride;
+            } else {
+                F.tp_const = (float)tp->sp[0].value;
+            }
+            F.mode = tp->io;
+            F.out_stride = io[st->io].row_stride;
+            F.c = dpz.fc[0];
+            F.tau_nan = dpz.ic[0];
+            F.rr = dtp.fc[0];
+            F.ll = dtp.fc[1];
+            F.all_nan = dtp.ic[9];
+            F.C = P.slots[0].C;
+            F.pitch = P.slots[0].pitch;
+            F.invC = P.slots[0].invC;
+            for (int k = 0; k < 3; ++k) {
+                F.q[k] = dtp.ic[3 + k];
+                F.rho[k] = dtp.ic[6 + k];
+            }
+            F.lds_elems_per_wave = P.lds_elems_per_wave;
+            F.slot_off = P.slots[0].off;
+            ch->io_wf = ld->io;
+            ch->io_out = st->io;
+            ch->fused_trap = tp->ip[3];
+            const int need = F.C / 4;
+            ch->fused_npf = need <= 4 ? 4 : (need <= 8 ? 8 : 16);
+            ch->fused_ok = true;
+            const char* env = getenv("DSPEED_HIP_NO_FUSED");
+            ch->fused_on = !(env && env[0] == '1');
+        }
+    }
+
     HIP_TRY(hipGetDevice(&ch->device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ch->device));
@@ -477,6 +574,10 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     if (block_lds > 64 * 1024) {
         hipError_t e = (hipError_t)dsp_internal_set_vm_lds(block_lds);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", block_lds, hipGetErrorString(e));
+        if (ch->fused_ok) {
+            e = (hipError_t)dsp_internal_set_energy_lds(ch->fused_trap, ch->fused_npf, block_lds);
+            if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(energy kernel, %d): %s", block_lds, hipGetErrorString(e));
+        }
     }
     *out = ch.release();
     return DSP_OK;
@@ -505,6 +606,17 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
     const int blocks = chain_blocks(ch, n_wf);
     const int threads = 64 * ch->waves_per_block;
     const int lds = ch->lds_bytes_per_wave * ch->waves_per_block;
+    if (ch->fused_ok && ch->fused_on && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
+        EnergyArgs F = ch->fused;
+        F.wf = io_ptrs[ch->io_wf];
+        F.bl = ch->io_bl >= 0 ? (const float*)io_ptrs[ch->io_bl] : nullptr;
+        F.tp = ch->io_tp >= 0 ? (const float*)io_ptrs[ch->io_tp] : nullptr;
+        F.out = (float*)io_ptrs[ch->io_out];
+        hipError_t e = (hipError_t)dsp_internal_launch_energy(&F, ch->fused_trap, ch->fused_npf, n_wf, ch->dev_err, blocks, threads, lds,
+                                                              (hipStream_t)stream);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy kernel launch failed: %s", hipGetErrorString(e));
+        return DSP_OK;
+    }
     hipError_t e = (hipError_t)dsp_internal_launch_vm_f32(ch->dev, &ptrs, n_wf, ch->dev_err, blocks, threads, lds, (hipStream_t)stream);
     if (e != hipSuccess) return fail(DSP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return DSP_OK;
@@ -526,8 +638,8 @@ int dsp_chain_check(dsp_chain* ch, void* stream, int64_t* row) {
 
 int dsp_chain_destroy(dsp_chain* ch) {
     if (!ch) return DSP_OK;
-    if (ch->dev) hipFree(ch->dev);
-    if (ch->dev_err) hipFree(ch->dev_err);
+    if (ch->dev) (void)hipFree(ch->dev);
+    if (ch->dev_err) (void)hipFree(ch->dev_err);
     delete ch;
     return DSP_OK;
 }
@@ -541,8 +653,13 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
 }
 
 const char* dsp_chain_kernel_name(dsp_chain* ch) {
-    (void)ch;
-    return dsp_internal_vm_kernel_name();
+    return (ch && ch->fused_ok && ch->fused_on) ? dsp_internal_energy_kernel_name() : dsp_internal_vm_kernel_name();
+}
+
+int dsp_chain_set_fused(dsp_chain* ch, int enable) {
+    if (!ch) return fail(DSP_ERR_ARG, "null chain");
+    ch->fused_on = enable != 0;
+    return (ch->fused_ok && ch->fused_on) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ single processors
@@ -612,7 +729,7 @@ struct Mini {
         {
             std::lock_guard<std::mutex> lk(g_cache_mu);
             int dev = 0;
-            hipGetDevice(&dev);
+            (void)hipGetDevice(&dev);
             key.v.push_back(dev);
             auto it = g_cache.find(key);
             if (it != g_cache.end()) ch = it->second;

@@ -18,84 +18,9 @@
 #include <hip/hip_runtime.h>
 
 #include "dsp_program.h"
+#include "dsp_wave.h"
 
 namespace {
-
-// ------------------------------------------------------------------------------------------------
-// wavefront primitives
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
-
-// Orders this wavefront's LDS traffic for the compiler; the hardware executes one wave's LDS
-// instructions in issue order, so no instruction is needed beyond the waitcnt the fence implies.
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ int dpp0(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
-}
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float dpp0(float v) {
-    return __int_as_float(dpp0<CTRL, ROW_MASK>(__float_as_int(v)));
-}
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ double dpp0(double v) {
-    int lo = dpp0<CTRL, ROW_MASK>(__double2loint(v));
-    int hi = dpp0<CTRL, ROW_MASK>(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-
-constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
-constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138;
-
-// inclusive + over the 64 lanes (lanes without a source add the DPP "old" value 0)
-__device__ __forceinline__ double wave_scan_add(double v) {
-    v += dpp0<DPP_ROW_SHR1>(v);
-    v += dpp0<DPP_ROW_SHR2>(v);
-    v += dpp0<DPP_ROW_SHR4>(v);
-    v += dpp0<DPP_ROW_SHR8>(v);
-    v += dpp0<DPP_ROW_BCAST15, 0xa>(v);
-    v += dpp0<DPP_ROW_BCAST31, 0xc>(v);
-    return v;
-}
-// value of the previous lane, 0 for lane 0
-template <typename V>
-__device__ __forceinline__ V wave_prev(V v) {
-    return dpp0<DPP_WAVE_SHR1>(v);
-}
-__device__ __forceinline__ double wave_exscan_add(double v) { return wave_prev(wave_scan_add(v)); }
-
-__device__ __forceinline__ float readlane(float v, int l) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-__device__ __forceinline__ int readlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ __forceinline__ double readlane(double v, int l) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-// value held `sh` lanes below (uniform sh >= 0); lanes without a source get 0
-__device__ __forceinline__ double wave_shift_up(double v, int sh) {
-    int src = lane_id() - sh;
-    int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
-    int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
-    return src >= 0 ? __hiloint2double(hi, lo) : 0.0;
-}
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m));
-    return v;
-}
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m));
-    return v;
-}
-__device__ __forceinline__ bool wave_any(bool p) { return __any(p) != 0; }
-
-__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ------------------------------------------------------------------------------------------------
 // per-wave context
@@ -136,17 +61,6 @@ struct Ctx {
         return (T)((const uint32_t*)p)[at];
     }
 };
-
-// LDS element index of sample e of a slot (e / C via a float reciprocal: exact for e < 2^20, C % 8 == 0)
-__device__ __forceinline__ int padded_index(const DevSlot& s, int e) {
-    int q = (int)(((float)e + 0.5f) * s.invC);
-    return s.off + e + q;
-}
-
-template <typename T>
-__device__ __forceinline__ T quiet_nan() {
-    return (T)__builtin_nanf("");
-}
 
 // ------------------------------------------------------------------------------------------------
 // LOAD / STORE: coalesced 16-byte global accesses <-> chunked LDS layout
@@ -415,21 +329,6 @@ __device__ void op_double_pole_zero(Ctx<T>& cx, const DevOp& op) {
 //        ASYM         L1 = rise, L2 = rise+flat, L3 = rise+flat+fall
 // ic: 0..2 lags, 3..5 q_k = L_k / C, 6..8 rho_k = L_k % C;  fc: 0 rise, 1 fall
 // ------------------------------------------------------------------------------------------------
-enum { TRAP_FILTER = 0, TRAP_NORM = 1, TRAP_ASYM = 2 };
-
-template <typename T, int KIND>
-__device__ __forceinline__ T trap_step(T y, T a, T b1, T b2, T b3, double rr, double ll) {
-    if (KIND == TRAP_FILTER) {
-        return (((y + a) - b1) - b2) + b3;
-    } else if (KIND == TRAP_NORM) {
-        const T e = ((a - b1) - b2) + b3;
-        return (T)((double)y + (double)e / rr);
-    } else {
-        const T e1 = a - b1, e2 = b2 - b3;
-        return (T)(((double)y + (double)e1 / rr) - (double)e2 / ll);
-    }
-}
-
 constexpr int TRAP_NCAP = 4;
 
 // Runs the trap emulation over slot `ss`.  If STORE, writes the filtered waveform into slot `sd` (must differ from ss).
@@ -571,35 +470,6 @@ __device__ void op_trap(Ctx<T>& cx, const DevOp& op) {
 // w4 = samples at i0-1, i0, i0+1, i0+2 (only the in-range ones are used)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ T pickoff_eval(Ctx<T>& cx, T t_in, int mode, int n, const T* w4) {
-    const int i0 = (int)t_in;
-    if ((T)i0 == t_in) return w4[1];
-    const double t0 = (double)t_in - (double)i0;
-    const double t1 = 1.0 - t0;
-    switch (mode) {
-        case 'n': return (t0 < 0.5) ? w4[1] : w4[2];
-        case 'f': return w4[1];
-        case 'c': return w4[2];
-        case 'l': return (T)(t1 * (double)w4[1] + t0 * (double)w4[2]);
-        case 'h': {
-            const double m0 = (i0 == 0) ? (double)(T)(w4[2] - w4[1]) : (double)(T)(w4[2] - w4[0]) / 2.0;
-            const double m1 = (i0 == n - 2) ? (double)(T)(w4[2] - w4[1]) : (double)(T)(w4[3] - w4[1]) / 2.0;
-            const double t1_2 = t1 * t1, t1_3 = t1 * t1_2, t0_2 = t0 * t0, t0_3 = t0 * t0_2;
-            return (T)(((((-2.0 * t1_3 + 3.0 * t1_2) * (double)w4[1] + (-2.0 * t0_3 + 3.0 * t0_2) * (double)w4[2]) - (t1_3 - t1_2) * m0)) +
-                       (t0_3 - t0_2) * m1);
-        }
-        case 'i': cx.fatal(DSP_E_FTP_INT); return quiet_nan<T>();
-        default: cx.fatal(DSP_E_FTP_MODE); return quiet_nan<T>();
-    }
-}
-
-// in-range test of fixed_time_pickoff.py:68-74; returns false when the output must be NaN
-template <typename T>
-__device__ __forceinline__ bool pickoff_in_range(T t_in, int n) {
-    return !(t_in != t_in) && !(t_in < (T)0) && !(t_in > (T)(n - 1));
-}
-
-template <typename T>
 __device__ void op_pickoff(Ctx<T>& cx, const DevOp& op) {
     const DevSlot& ss = cx.prog->slots[op.src];
     const T t_in = cx.scalar(op.sp[0]);
@@ -613,7 +483,9 @@ __device__ void op_pickoff(Ctx<T>& cx, const DevOp& op) {
             e = e < 0 ? 0 : (e > ss.len - 1 ? ss.len - 1 : e);
             w4[k] = cx.lds[padded_index(ss, e)];
         }
-        out = pickoff_eval(cx, t_in, op.ip[0], ss.len, w4);
+        int fc = 0;
+        out = pickoff_eval(t_in, op.ip[0], ss.len, w4, fc);
+        if (fc) cx.fatal(fc);
     }
     if (lane_id() == 0) cx.sregs()[op.dst] = out;
     wave_sync();
@@ -642,7 +514,9 @@ __device__ void op_trap_pickoff(Ctx<T>& cx, const DevOp& op) {
             trap_core<T, TRAP_NORM, false>(cx, op, ss, ss, idx, w4);
         else
             trap_core<T, TRAP_ASYM, false>(cx, op, ss, ss, idx, w4);
-        out = pickoff_eval(cx, t_in, op.io, ss.len, w4);
+        int fc = 0;
+        out = pickoff_eval(t_in, op.io, ss.len, w4, fc);
+        if (fc) cx.fatal(fc);
     }
     if (lane_id() == 0) cx.sregs()[op.dst] = out;
     wave_sync();

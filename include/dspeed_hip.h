@@ -178,6 +178,10 @@ int dsp_chain_destroy(dsp_chain* chain);
 int dsp_chain_geometry(dsp_chain* chain, int64_t n_wf, int* lds_bytes_per_wave, int* waves_per_block, int* blocks);
 /* name of the device kernel the chain launches (what rocprofv3 --kernel-trace lists) */
 const char* dsp_chain_kernel_name(dsp_chain* chain);
+/* A chain of the shape LOAD [-> BL_SUBTRACT] -> POLE_ZERO -> TRAP_PICKOFF -> STORE_SCALAR (the Ge energy chain) runs on a
+ * specialised kernel with identical arithmetic (dsp_energy.hip).  enable = 0 forces the generic interpreter (parity tests);
+ * returns 1 if the specialised kernel will be used, 0 if not.  Environment DSPEED_HIP_NO_FUSED=1 sets the default to off. */
+int dsp_chain_set_fused(dsp_chain* chain, int enable);
 
 /* ---- single processors: the gufunc entry points -----------------------------------------------------
  * One call = one reference gufunc call on an (n_wf, wf_len) block: `in`/`out` device pointers, rows

@@ -10,12 +10,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-6
 
 
-def _run_energy(wf, bl, tp, tau, rise, flat, mode="l"):
+def _run_energy(wf, bl, tp, tau, rise, flat, mode="l", fused=True, trap="trap_filter"):
+    """fused=True: the specialised energy kernel (dsp_energy.hip) when the shape allows; False: the generic waveform VM."""
     from dspeed_amd.chain import Chain, energy_chain_program
     from dspeed_amd.device import DeviceArray
 
     n_wf, wf_len = wf.shape
-    ch = Chain(energy_chain_program(wf_len, tau, rise, flat, mode, wf_dtype=wf.dtype), "energy")
+    ch = Chain(energy_chain_program(wf_len, tau, rise, flat, mode, wf_dtype=wf.dtype, trap=trap), "energy")
+    ch.set_fused(fused)
     bufs = {"waveform": DeviceArray.from_numpy(wf), "baseline": DeviceArray.from_numpy(bl), "t_pick": DeviceArray.from_numpy(tp),
             "trapEftp": DeviceArray((n_wf,), np.float32)}
     ch.execute(bufs, n_wf)
@@ -23,10 +25,11 @@ def _run_energy(wf, bl, tp, tau, rise, flat, mode="l"):
     return bufs["trapEftp"].to_numpy()
 
 
-def test_energy_chain_golden():
+@pytest.mark.parametrize("fused", [True, False])
+def test_energy_chain_golden(fused):
     c2 = cases("chains")[1]
     p = c2.params
-    got = _run_energy(c2["waveform"], c2["baseline"], c2["t_pick"], p["tau"], p["rise"], p["flat"], p["mode"])
+    got = _run_energy(c2["waveform"], c2["baseline"], c2["t_pick"], p["tau"], p["rise"], p["flat"], p["mode"], fused=fused)
     want = c2["trapEftp"]
     assert np.array_equal(np.isnan(got), np.isnan(want))
     ok = ~np.isnan(want)
@@ -35,8 +38,10 @@ def test_energy_chain_golden():
     assert rel.max() <= TOL
 
 
-@pytest.mark.parametrize("wf_len,rise,flat", [(4096, 625, 188), (1024, 64, 16), (8192, 1250, 376), (6092, 500, 100)])
-def test_energy_chain_vs_oracle(wf_len, rise, flat):
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("wf_len,rise,flat", [(4096, 625, 188), (1024, 64, 16), (8192, 1250, 376), (6092, 500, 100), (2048, 300, 7),
+                                              (3000, 128, 0), (200, 10, 3)])
+def test_energy_chain_vs_oracle(wf_len, rise, flat, fused):
     rng = np.random.default_rng(wf_len + rise)
     n_wf = 300
     i = np.arange(wf_len, dtype=np.float64)[None, :]
@@ -50,7 +55,7 @@ def test_energy_chain_vs_oracle(wf_len, rise, flat):
     tp[12] = np.float32(np.floor(tp[12]))
     tp[13] = np.float32(wf_len + 3)
     for mode in "lnh":
-        got = _run_energy(wf, bl, tp, 1716.28, rise, flat, mode)
+        got = _run_energy(wf, bl, tp, 1716.28, rise, flat, mode, fused=fused)
         want, rc = oracle.chain_energy(wf, bl, tp, 1716.28, rise, flat, mode)
         assert rc == 0
         assert np.array_equal(np.isnan(got), np.isnan(want))
@@ -69,9 +74,12 @@ def test_energy_chain_matches_unfused_processors():
     wf = (10000 + 3000 * (np.arange(wf_len)[None, :] > 2000) + 5 * rng.standard_normal((n_wf, wf_len))).astype(np.float32)
     bl = np.full(n_wf, 10000, dtype=np.float32)
     tp = np.full(n_wf, 2000 + 625 + 150.4, dtype=np.float32)
-    fused = _run_energy(wf, bl, tp, 1716.28, 625, 188)
     step = P.fixed_time_pickoff(P.trap_filter(P.pole_zero(P.bl_subtract(wf, bl), 1716.28), 625, 188), tp, ord("l"))
-    assert np.array_equal(fused, step)
+    for fused in (True, False):
+        assert np.array_equal(_run_energy(wf, bl, tp, 1716.28, 625, 188, fused=fused), step)
+    step = P.fixed_time_pickoff(P.trap_norm(P.pole_zero(P.bl_subtract(wf, bl), 1716.28), 625, 188), tp, ord("h"))
+    for fused in (True, False):
+        assert np.array_equal(_run_energy(wf, bl, tp, 1716.28, 625, 188, mode="h", fused=fused, trap="trap_norm"), step)
 
 
 def test_data_dependent_fatal_reports_row():
@@ -81,7 +89,8 @@ def test_data_dependent_fatal_reports_row():
     bl = np.zeros(10, dtype=np.float32)
     tp = np.full(10, 100.0, dtype=np.float32)
     tp[6] = 100.5
-    with pytest.raises(DSPFatal) as ei:
-        _run_energy(wf, bl, tp, 100.0, 16, 8, "i")
-    assert ei.value.wf_range == range(6, 7)
-    assert "integer t_in" in str(ei.value)
+    for fused in (True, False):
+        with pytest.raises(DSPFatal) as ei:
+            _run_energy(wf, bl, tp, 100.0, 16, 8, "i", fused=fused)
+        assert ei.value.wf_range == range(6, 7)
+        assert "integer t_in" in str(ei.value)
