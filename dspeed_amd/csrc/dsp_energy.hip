@@ -27,7 +27,7 @@ struct EnergyArgs {
     const float* bl;       // per-waveform baseline column, or nullptr
     int64_t bl_stride;
     float bl_const;
-    int32_t has_bl;        // 0: the chain has no bl_subtract
+    int32_t has_bl;        // 0: the chain has no bl_subtract (bl_const is then 0: x - 0 == x exactly)
     const float* tp;       // per-waveform pick-off time column, or nullptr
     int64_t tp_stride;
     float tp_const;
@@ -60,15 +60,15 @@ template <int NPF, int KIND>
 __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_t n_wf, int* err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = lane_id();
-    const int wave = (int)(threadIdx.x >> 6), wpb = (int)(blockDim.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);  // provably wave-uniform
     float* lds = reinterpret_cast<float*>(smem_raw) + (size_t)wave * A.lds_elems_per_wave;
     for (int e = lane; e < A.lds_elems_per_wave; e += 64) lds[e] = 0.0f;
     wave_sync();
 
-    const int C = A.C, pitch = A.pitch, len = A.len;
+    // the host selects this kernel only for len == 256 * NPF: every lane owns exactly C = 4 * NPF samples, no tail
+    constexpr int C = 4 * NPF, pitch = C + 1, len = 256 * NPF;
     float* slot = lds + A.slot_off;
     float* mine = slot + lane * pitch;
-    const int total = 64 * C;
 
     // lagged-read bases (identical for every row): see trap_core in dsp_vm.hip
     const float* lagp[3];
@@ -76,12 +76,6 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
     for (int k = 0; k < 3; ++k) {
         const int jj = lane - A.q[k] - 1;
         lagp[k] = (jj >= -1) ? slot + jj * pitch + (C - A.rho[k]) : slot - 2 * pitch;
-    }
-    int cap_o[3], shift[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        cap_o[k] = (C - A.rho[k]) % C;  // chunk offset at which the prefix needed by lag k is complete
-        shift[k] = A.q[k] + (A.rho[k] > 0 ? 1 : 0);
     }
 
     const int64_t stride_rows = (int64_t)gridDim.x * wpb;
@@ -93,86 +87,89 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
     auto prefetch = [&](int64_t r) {
         const float* g = (const float*)A.wf + r * A.wf_stride + A.wf_offset;
 #pragma unroll
-        for (int b = 0; b < NPF; ++b) {
-            const int e = (b * 64 + lane) * 4;
-            if (e + 4 <= len) {
-                pf[b] = *reinterpret_cast<const f4*>(g + e);
-            } else {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) pf[b][m] = (e + m < len) ? g[e + m] : 0.0f;
-            }
-        }
-        pf_bl = A.bl ? A.bl[r * A.bl_stride] : A.bl_const;
+        for (int b = 0; b < NPF; ++b) pf[b] = reinterpret_cast<const f4*>(g)[b * 64 + lane];
+        pf_bl = A.bl ? A.bl[r * A.bl_stride] : A.bl_const;  // 0 when the chain has no bl_subtract: x - 0 == x exactly
         pf_tp = A.tp ? A.tp[r * A.tp_stride] : A.tp_const;
+    };
+    auto report = [&](int code, int64_t r) {
+        if (lane == 0 && atomicCAS(&err[0], 0, code) == 0) {
+            err[1] = (int)(r & 0xffffffffll);
+            err[2] = (int)(r >> 32);
+        }
     };
     if (row < n_wf) prefetch(row);
 
     for (; row < n_wf; row += stride_rows) {
-        // ---- stage the prefetched waveform into LDS (chunked layout), look for NaN on the way
-        bool nanp = false;
+        // ---- stage the prefetched waveform into LDS (chunked layout)
 #pragma unroll
         for (int b = 0; b < NPF; ++b) {
             const int e = (b * 64 + lane) * 4;
-            if (e < total) {
-                const int a = e + (int)(((float)e + 0.5f) * A.invC);
+            float* d = slot + e + e / C;  // sample e -> element e + e / C (chunk pad)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const float x = pf[b][m];
-                    nanp |= (x != x);
-                    slot[a + m] = x;
-                }
-            }
+            for (int m = 0; m < 4; ++m) d[m] = pf[b][m];
         }
-        const float bl = pf_bl, t_in = pf_tp;
+        // per-waveform scalars are wave-uniform: say so, or every use downstream becomes per-lane (exec-masked) code
+        const float bl = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pf_bl)));
+        const float t_in = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pf_tp)));
         const int64_t next = row + stride_rows;
-        if (next < n_wf) prefetch(next);  // in flight while this waveform is filtered
+        __builtin_amdgcn_sched_barrier(0);  // the staging stores must issue before the registers are reloaded
+        if (next < n_wf) prefetch(next);    // in flight while this waveform is filtered
+        __builtin_amdgcn_sched_barrier(0);
         wave_sync();
 
         float result = quiet_nan<float>();
-        const bool in_nan = wave_any(nanp) || (A.has_bl && bl != bl) || A.tau_nan;
-        if (!in_nan) {
-            // ---- pass 1: per-chunk float64 sum of x = w - baseline
-            double X = 0.0;
-            {
-                float va[G], vb[G];
-                load_group(va, mine);
-                for (int t = 0; t < C; t += 2 * G) {
-                    load_group(vb, mine + t + G);
+        // ---- pass 1: per-chunk float64 sum of x = w - baseline; a NaN anywhere (or a NaN baseline) poisons the sum
+        double X = 0.0;
+        {
+            float va[G], vb[G];
+            load_group(va, mine);
+#pragma unroll 1
+            for (int t = 0; t < C; t += 2 * G) {
+                load_group(vb, mine + t + G);
 #pragma unroll
-                    for (int u = 0; u < G; ++u) X += (double)(A.has_bl ? va[u] - bl : va[u]);
-                    if (t + 2 * G < C) load_group(va, mine + t + 2 * G);
+                for (int u = 0; u < G; ++u) X += (double)(va[u] - bl);
+                if (t + 2 * G < C) load_group(va, mine + t + 2 * G);
 #pragma unroll
-                    for (int u = 0; u < G; ++u) X += (double)(A.has_bl ? vb[u] - bl : vb[u]);
-                }
+                for (int u = 0; u < G; ++u) X += (double)(vb[u] - bl);
             }
+        }
+        bool in_nan = A.tau_nan != 0;
+        if (wave_any(!(fabs(X) <= 1.7976931348623157e308))) {
+            // NaN or infinite sum: look for real NaNs (an infinite input is not NaN for the reference, pole_zero.py:55-58)
+            bool n = false;
+            for (int t = 0; t < C; ++t) {
+                const float x = mine[t] - bl;
+                n |= (x != x);
+            }
+            in_nan |= wave_any(n);
+        }
+        if (!in_nan) {
             const double E = wave_exscan_add(X);
-            const float last_raw = mine[C - 1];
-            const float xlast = A.has_bl ? last_raw - bl : last_raw;
+            const float xlast = mine[C - 1] - bl;
             const double xprev0 = (double)wave_prev(xlast);
-            // ---- pass 2: pole-zero recurrence (reference operation order), output in place, float64 prefix of the output
+            // ---- pass 2: pole-zero recurrence in the reference's operation order, output in place; float32 running sum of
+            // the output feeds the speculative carries of the trapezoid
             const double c = A.c;
-            double acc = E - c * (E - xprev0), xp = xprev0, run = 0.0;
-            double cap[3] = {0.0, 0.0, 0.0};
-            bool nano = false;
+            double acc = E - c * (E - xprev0), xp = xprev0;
+            float run = 0.0f, cap[3] = {0.0f, 0.0f, 0.0f};
             {
                 float va[G], vb[G];
                 load_group(va, mine);
                 auto body = [&](float (&v)[G], int t) {
-                    double rs[G];
+                    float rs[G];
 #pragma unroll
                     for (int u = 0; u < G; ++u) {
-                        const double x = (double)(A.has_bl ? v[u] - bl : v[u]);
+                        const double x = (double)(v[u] - bl);
                         acc = (acc + x) - xp * c;
                         const float y = (float)acc;
-                        nano |= (y != y);
                         mine[t + u] = y;
                         xp = x;
-                        run += (double)y;
+                        run += y;
                         rs[u] = run;
                     }
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const int d = cap_o[k] - t;  // capture after d samples of this group (1..G)
+                        const int d = ((C - A.rho[k]) % C) - t;  // prefix needed by lag k completes after d samples of this group
                         if (d >= 1 && d <= G) {
 #pragma unroll
                             for (int u = 0; u < G; ++u)
@@ -180,6 +177,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
                         }
                     }
                 };
+#pragma unroll 1
                 for (int t = 0; t < C; t += 2 * G) {
                     load_group(vb, mine + t + G);
                     body(va, t);
@@ -187,18 +185,27 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
                     body(vb, t + G);
                 }
             }
-            if (wave_any(nano)) {
-                if (lane == 0 && atomicCAS(&err[0], 0, DSP_E_PZ_NAN) == 0) {
-                    err[1] = (int)(row & 0xffffffffll);
-                    err[2] = (int)(row >> 32);
+            wave_sync();
+            bool pz_nan = false;
+            if (wave_any(!(fabsf(run) <= 3.4028234663852886e38f))) {
+                bool n = false;
+                for (int t = 0; t < C; ++t) {
+                    const float y = mine[t];
+                    n |= (y != y);
                 }
+                pz_nan = wave_any(n);
+            }
+            if (pz_nan) {
+                report(DSP_E_PZ_NAN, row);  // pole_zero.py:76-77
             } else if (!A.all_nan && pickoff_in_range(t_in, len)) {
-                wave_sync();
-                // ---- speculative carries: exact filter value at every chunk boundary from the float64 prefixes
-                const double Ep = wave_exscan_add(run);
+                // ---- speculative carries: filter value at every chunk boundary from the prefix sums
+                const double Ep = wave_exscan_add((double)run);
                 double Ak[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) Ak[k] = wave_shift_up(Ep + (cap_o[k] == 0 ? 0.0 : cap[k]), shift[k]);
+                for (int k = 0; k < 3; ++k) {
+                    const bool whole = (A.rho[k] == 0);
+                    Ak[k] = wave_shift_up(Ep + (whole ? 0.0 : (double)cap[k]), A.q[k] + (whole ? 0 : 1));
+                }
                 double Gd;
                 if (KIND == TRAP_FILTER)
                     Gd = ((Ep - Ak[0]) - Ak[1]) + Ak[2];
@@ -217,7 +224,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
                 for (int k = 0; k < 4; ++k) {
                     const int e = i0 - 1 + k;
                     const bool need = ((k == 1) || (k == 2) || wide) && e >= 0 && e < len;
-                    const int l = need ? (int)(((float)e + 0.5f) * A.invC) : -1;
+                    const int l = need ? e / C : -1;
                     cl[k] = l;
                     co[k] = need ? e - l * C : -1000;
                     capv[k] = 0.0f;
@@ -260,6 +267,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
                         }
                     };
                     fetch(a0, a1, a2, a3, 0);
+#pragma unroll 1
                     for (int t = 0; t < C; t += 2 * G3) {
                         fetch(b0, b1, b2, b3, t + G3);
                         body(a0, a1, a2, a3, t);
@@ -278,10 +286,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
                 }
                 int fc = 0;
                 result = pickoff_eval(t_in, A.mode, len, w4, fc);
-                if (fc && lane == 0 && atomicCAS(&err[0], 0, fc) == 0) {
-                    err[1] = (int)(row & 0xffffffffll);
-                    err[2] = (int)(row >> 32);
-                }
+                if (fc) report(fc, row);
             }
         }
         if (lane == 0) A.out[row * A.out_stride] = result;

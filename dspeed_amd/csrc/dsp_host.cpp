@@ -511,7 +511,8 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         const dsp_op* st = (tp && n_ops > i && ops[i].opcode == DSP_OP_STORE_SCALAR) ? &ops[i++] : nullptr;
         const bool shape = st && i == n_ops && n_slots == 1 && io[ld->io].dtype == DSP_F32 && P.io[ld->io].vec_ok &&
                            (!bs || (bs->dst == 0 && bs->src == 0 && bs->sp[0].kind != DSP_ARG_REG)) && pz->dst == 0 && pz->src == 0 &&
-                           tp->src == 0 && tp->sp[0].kind != DSP_ARG_REG && st->ip[0] == tp->dst && P.slots[0].C <= 64;
+                           tp->src == 0 && tp->sp[0].kind != DSP_ARG_REG && st->ip[0] == tp->dst &&
+                           (slot_len[0] == 1024 || slot_len[0] == 2048 || slot_len[0] == 4096);  // len == 256 * npf, npf in {4, 8, 16}
         auto f32_col = [&](const dsp_scalar_arg& a) { return a.kind != DSP_ARG_INPUT || io[a.index].dtype == DSP_F32; };
         if (shape && (!bs || f32_col(bs->sp[0])) && f32_col(tp->sp[0])) {
             EnergyArgs& F = ch->fused;
@@ -554,8 +555,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             ch->io_wf = ld->io;
             ch->io_out = st->io;
             ch->fused_trap = tp->ip[3];
-            const int need = F.C / 4;
-            ch->fused_npf = need <= 4 ? 4 : (need <= 8 ? 8 : 16);
+            ch->fused_npf = slot_len[0] / 256;
             ch->fused_ok = true;
             const char* env = getenv("DSPEED_HIP_NO_FUSED");
             ch->fused_on = !(env && env[0] == '1');

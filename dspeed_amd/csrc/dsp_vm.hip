@@ -47,7 +47,14 @@ struct Ctx {
         }
     }
     // scalar operand: constant, per-waveform input column, or scalar register
-    __device__ T scalar(const dsp_scalar_arg& a) const {
+    __device__ T scalar(const dsp_scalar_arg& a) const { return make_uniform(scalar_raw(a)); }
+    static __device__ __forceinline__ float make_uniform(float v) {
+        return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+    }
+    static __device__ __forceinline__ double make_uniform(double v) {
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    }
+    __device__ T scalar_raw(const dsp_scalar_arg& a) const {
         if (a.kind == DSP_ARG_CONST) return (T)a.value;
         if (a.kind == DSP_ARG_REG) return sregs()[a.index];
         const DevIO& io = prog->io[a.index];
@@ -344,8 +351,9 @@ __device__ void trap_core(Ctx<T>& cx, const DevOp& op, const DevSlot& ss, const 
         q[k] = op.ic[3 + k];
         rho[k] = op.ic[6 + k];
     }
-    // ---- pass A: float64 prefix sums of the input, captured at the three offsets the lagged boundaries fall on
-    double run = 0.0, cap[3] = {0.0, 0.0, 0.0};
+    // ---- pass A: running sum of the input in T (it only feeds the speculative carries, which need not be exact),
+    // captured at the three offsets the lagged chunk boundaries fall on
+    T run = (T)0, cap[3] = {(T)0, (T)0, (T)0};
     {
         int t = 0;
         while (t < C) {
@@ -356,20 +364,20 @@ __device__ void trap_core(Ctx<T>& cx, const DevOp& op, const DevSlot& ss, const 
                 if (o > t && o < nb) nb = o;
             }
 #pragma unroll 8
-            for (int u = t; u < nb; ++u) run += (double)ps[u];
+            for (int u = t; u < nb; ++u) run += ps[u];
             t = nb;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
                 if (t == (C - rho[k]) % C) cap[k] = run;
         }
     }
-    const double E = wave_exscan_add(run);
+    const double E = wave_exscan_add((double)run);
     double G = E;  // sum of all samples before this chunk
     double A[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int o = (C - rho[k]) % C;
-        const double ak = E + (o == 0 ? 0.0 : cap[k]);       // prefix up to (chunk, offset o)
+        const double ak = E + (o == 0 ? 0.0 : (double)cap[k]);  // prefix up to (chunk, offset o)
         A[k] = wave_shift_up(ak, q[k] + (rho[k] > 0 ? 1 : 0));  // the chunk that index jC - L_k falls into
     }
     if (KIND == TRAP_FILTER)
@@ -769,7 +777,7 @@ __device__ void op_scalar_affine(Ctx<T>& cx, const DevOp& op) {
 template <typename T>
 __global__ void __launch_bounds__(256) dsp_vm_kernel(const DevProgram* __restrict__ prog, IoPtrs ptrs, int64_t n_wf, int* err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int wave = (int)(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably wave-uniform -> rows, pointers in SGPRs
     const int wpb = (int)(blockDim.x >> 6);
     T* lds = reinterpret_cast<T*>(smem_raw) + (size_t)wave * prog->lds_elems_per_wave;
     // zero the whole region once: guards below each slot must read as 0 forever, pads start finite
