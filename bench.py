@@ -51,11 +51,16 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="rows per rank (default: 1 000 000 at N=1, 1 250 000 at N>1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the single-thread CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (profiling runs)")
+    ap.add_argument("--wf-len", type=int, default=0, help="experiment only: other waveform length (trap geometry scaled)")
     return ap.parse_args()
 
 
 def main():
     args = parse()
+    global WF_LEN, RISE, FLAT, BYTES_PER_WF
+    if args.wf_len:
+        WF_LEN, RISE, FLAT = args.wf_len, 625 * args.wf_len // 4096, 188 * args.wf_len // 4096
+        BYTES_PER_WF = WF_LEN * 4 + 12
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

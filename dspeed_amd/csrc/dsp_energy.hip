@@ -43,12 +43,13 @@ struct EnergyArgs {
     int32_t q[3], rho[3];  // lag = q*C + rho
     int32_t lds_elems_per_wave;
     int32_t slot_off;      // element offset of the slot inside the wave's region (2*pitch guard below it)
+    int32_t ablate;        // timing experiments only (DSPEED_HIP_ABLATE): bit 0/1/2 = skip pass 1/2/3; results are then wrong
 };
 
 namespace {
 
 constexpr int G = 8;   // samples per software-pipeline group in the pole-zero passes
-constexpr int G3 = 4;  // ... in the trapezoid replay (4 streams are live there)
+constexpr int G3 = 8;  // ... in the trapezoid replay (4 streams x 2 buffers live there: 64 VGPRs, fine at 2 waves/SIMD)
 
 template <int N>
 __device__ __forceinline__ void load_group(float (&v)[N], const float* p) {
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
         float result = quiet_nan<float>();
         // ---- pass 1: per-chunk float64 sum of x = w - baseline; a NaN anywhere (or a NaN baseline) poisons the sum
         double X = 0.0;
-        {
+        if (!(A.ablate & 1)) {
             float va[G], vb[G];
             load_group(va, mine);
 #pragma unroll 1
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
             const double c = A.c;
             double acc = E - c * (E - xprev0), xp = xprev0;
             float run = 0.0f, cap[3] = {0.0f, 0.0f, 0.0f};
-            {
+            if (!(A.ablate & 2)) {
                 float va[G], vb[G];
                 load_group(va, mine);
                 auto body = [&](float (&v)[G], int t) {
@@ -197,7 +198,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
             }
             if (pz_nan) {
                 report(DSP_E_PZ_NAN, row);  // pole_zero.py:76-77
-            } else if (!A.all_nan && pickoff_in_range(t_in, len)) {
+            } else if (!A.all_nan && !(A.ablate & 4) && pickoff_in_range(t_in, len)) {
                 // ---- speculative carries: filter value at every chunk boundary from the prefix sums
                 const double Ep = wave_exscan_add((double)run);
                 double Ak[3];
@@ -229,6 +230,11 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
                     co[k] = need ? e - l * C : -1000;
                     capv[k] = 0.0f;
                 }
+                // groups of the replay loop that contain a wanted sample (uniform bit mask)
+                unsigned capmask = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (co[k] >= 0) capmask |= 1u << (co[k] / G3);
                 // ---- pass 3: replay the reference's float32 rounding sequence over the chunk
                 float y = g;
                 {
@@ -256,10 +262,10 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
                             y = trap_step<float, KIND>(y, o[u], l0[u], l1[u], l2[u], A.rr, A.ll);
                             ys[u] = y;
                         }
+                        if ((capmask >> (t / G3)) & 1u) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int d = co[k] - t;
-                            if (d >= 0 && d < G3) {
+                            for (int k = 0; k < 4; ++k) {
+                                const int d = co[k] - t;
 #pragma unroll
                                 for (int u = 0; u < G3; ++u)
                                     if (d == u) capv[k] = ys[u];

@@ -56,6 +56,7 @@ struct EnergyArgs {
     int32_t q[3], rho[3];
     int32_t lds_elems_per_wave;
     int32_t slot_off;
+    int32_t ablate;
 };
 extern "C" int dsp_internal_launch_energy(const EnergyArgs* A, int trap_opcode, int npf, int64_t n_wf, int* err, int blocks,
                                           int threads, int lds_bytes, hipStream_t stream);
@@ -325,6 +326,10 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         return fail(DSP_ERR_TOO_LONG, "chain needs %d bytes of LDS per waveform; a CU has %d", ch->lds_bytes_per_wave, LDS_BYTES_PER_CU);
     int wpb = LDS_BYTES_PER_CU / ch->lds_bytes_per_wave;
     if (wpb > 4) wpb = 4;
+    if (const char* env = getenv("DSPEED_HIP_WPB")) {  // tuning knob: wavefronts per workgroup (1..4)
+        const int v = atoi(env);
+        if (v >= 1 && v <= wpb) wpb = v;
+    }
     ch->waves_per_block = wpb;
     P.waves_per_block = wpb;
 
@@ -552,6 +557,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             }
             F.lds_elems_per_wave = P.lds_elems_per_wave;
             F.slot_off = P.slots[0].off;
+            if (const char* ab = getenv("DSPEED_HIP_ABLATE")) F.ablate = atoi(ab);  // timing experiments only
             ch->io_wf = ld->io;
             ch->io_out = st->io;
             ch->fused_trap = tp->ip[3];
