@@ -1,0 +1,143 @@
+"""CPU tests of the recipe -> device-program translation (no GPU needed: the device chain is created lazily)."""
+import numpy as np
+import pytest
+
+import recipes
+from dspeed_amd import _lib
+from dspeed_amd.errors import ProcessingChainError
+from dspeed_amd.processing_chain import Quantity, WaveformInput, build_processing_chain, shard_rows
+
+
+def _ops(chain):
+    return [o[0] for o in chain.program.ops]
+
+
+def _tb(n=8, wf_len=4096, dtype=np.float32, **extra):
+    tb = {"waveform": np.zeros((n, wf_len), dtype=dtype), "baseline": np.zeros(n, dtype=np.float32), "t_pick": np.zeros(n, dtype=np.float32)}
+    tb.update(extra)
+    return tb
+
+
+def test_c2_translates_to_the_fused_energy_shape():
+    chain, mask, tb_out = build_processing_chain(recipes.C2, _tb())
+    assert _ops(chain) == [_lib.OP_LOAD, _lib.OP_BL_SUBTRACT, _lib.OP_POLE_ZERO, _lib.OP_TRAP_PICKOFF, _lib.OP_STORE_SCALAR]
+    assert chain.program.slots == [4096] and chain.program.n_sregs == 1
+    assert sorted(mask) == ["baseline", "t_pick", "waveform"]
+    assert tb_out["trapEftp"].shape == (8,) and tb_out["trapEftp"].dtype == np.float32
+    # the pole-zero constant came from the 'defaults' entry, rise/flat as integers
+    pz = chain.program.ops[2]
+    assert pz[5][0].value == pytest.approx(1716.28)
+    tp = chain.program.ops[3]
+    assert tp[4][:2] == (625, 188) and tp[4][3] == _lib.OP_TRAP_FILTER and tp[3] == ord("l")
+
+
+def test_db_dict_overrides_defaults():
+    chain, _, _ = build_processing_chain(recipes.C2, _tb(), db_dict={"pz": {"tau": "1000.5"}})
+    assert chain.program.ops[2][5][0].value == pytest.approx(1000.5)
+
+
+def test_time_quantities_become_samples():
+    tb = _tb()
+    tb["waveform"] = WaveformInput(tb["waveform"], dt=16.0)
+    chain, _, tb_out = build_processing_chain(recipes.C2_UNITS, tb)
+    ops = chain.program.ops
+    # wf_trap is an output here, so the trapezoid is materialised (no TRAP_PICKOFF fusion)
+    assert [o[0] for o in ops] == [_lib.OP_LOAD, _lib.OP_BL_SUBTRACT, _lib.OP_POLE_ZERO, _lib.OP_TRAP_FILTER, _lib.OP_PICKOFF,
+                                   _lib.OP_STORE_SCALAR, _lib.OP_STORE]
+    assert ops[2][5][0].value == pytest.approx(27460.5 / 16.0)
+    assert ops[3][4][:2] == (625, 188)  # 10 us and 3.008 us at 16 ns, rounded like the reference (processing_chain.py:1747-1770)
+    assert tb_out["wf_trap"].shape == (8, 4096)
+    with pytest.raises(ProcessingChainError):
+        build_processing_chain(recipes.C2_UNITS, _tb())  # plain ndarray input: no sampling period to convert with
+
+
+def test_c1_keeps_two_slots_for_the_trapezoid():
+    chain, mask, tb_out = build_processing_chain(recipes.C1, {"waveform": np.zeros((4, 1024), dtype=np.float32)})
+    assert _ops(chain) == [_lib.OP_LOAD, _lib.OP_POLE_ZERO, _lib.OP_TRAP_FILTER, _lib.OP_STORE]
+    assert chain.program.slots == [1024, 1024]
+    assert mask == ["waveform"] and tb_out["wf_trap"].shape == (4, 1024)
+
+
+def test_c3_folds_kernels_and_slices_the_input():
+    tb = _tb(wf_len=8192)
+    chain, mask, tb_out = build_processing_chain(recipes.C3, tb)
+    ops = _ops(chain)
+    assert ops.count(_lib.OP_CONVOLVE) == 2 and ops.count(_lib.OP_AMAX) == 2 and ops.count(_lib.OP_COPY) == 1
+    taps = [io for io in chain.program.io if io[1] == _lib.IO_TAPS]
+    assert len(taps) == 2 and all(io[3] == 5792 for io in taps)
+    assert set(tb_out) == {"cuspEmax", "zacEmax"}
+    # the folded kernels equal the golden cusp/zac fixtures
+    from golden_util import cases
+
+    gold = {c.kernel: c["kernel"] for c in cases("energy_kernels", tag="f32") if c.name.endswith("geo1")}
+    assert np.array_equal(chain._consts["taps:cusp_kernel"], gold["cusp_filter"])
+    assert np.array_equal(chain._consts["taps:zac_kernel"], gold["zac_filter"])
+
+
+def test_c5_int16_chain():
+    tb = {"waveform": np.zeros((4, 8192), dtype=np.int16), "thr": np.zeros(4, dtype=np.float32)}
+    chain, mask, tb_out = build_processing_chain(recipes.C5, tb)
+    ops = _ops(chain)
+    assert ops[:3] == [_lib.OP_LOAD, _lib.OP_DOUBLE_POLE_ZERO, _lib.OP_ASYM_TRAP]
+    assert _lib.OP_MIN_MAX in ops and _lib.OP_TIME_POINT_THRESH in ops and _lib.OP_DWT_HAAR in ops
+    assert chain.program.io[0][2] == _lib.I16
+    assert tb_out["dwt_haar"].shape == (4, 256) and tb_out["tp_0"].shape == (4,)
+    # time_point_thresh starts from the register min_max wrote (tp_max), threshold from the input column
+    tpt = chain.program.ops[ops.index(_lib.OP_TIME_POINT_THRESH)]
+    assert tpt[5][0].kind == _lib.ARG_INPUT and tpt[5][1].kind == _lib.ARG_REG
+
+
+def test_dependency_order_is_resolved_from_outputs_and_cycles_raise():
+    shuffled = {"outputs": ["trapEftp"], "processors": dict(reversed(list(recipes.C2["processors"].items())))}
+    chain, _, _ = build_processing_chain(shuffled, _tb())
+    assert _ops(chain) == [_lib.OP_LOAD, _lib.OP_BL_SUBTRACT, _lib.OP_POLE_ZERO, _lib.OP_TRAP_PICKOFF, _lib.OP_STORE_SCALAR]
+    cyc = {"outputs": ["a"], "processors": {"a": "dspeed.processors.pole_zero(b, 10, a)", "b": "dspeed.processors.pole_zero(a, 10, b)"}}
+    with pytest.raises(ProcessingChainError, match="Circular"):
+        build_processing_chain(cyc, _tb())
+
+
+def test_unknown_things_fail_loudly():
+    bad = {"outputs": ["x"], "processors": {"x": "dspeed.processors.wiener_filter(waveform, x)"}}
+    with pytest.raises(NotImplementedError):
+        build_processing_chain(bad, _tb())
+    missing = {"outputs": ["x"], "processors": {"x": "dspeed.processors.pole_zero(nothere, 10, x)"}}
+    with pytest.raises(ProcessingChainError):
+        build_processing_chain(missing, _tb())
+    nodb = {"outputs": ["x"], "processors": {"x": "dspeed.processors.pole_zero(waveform, db.nope, x)"}}
+    with pytest.raises(ProcessingChainError, match="database"):
+        build_processing_chain(nodb, _tb())
+
+
+def test_per_event_time_expression():
+    r = {"outputs": ["e"], "processors": {
+        "wf_pz": "dspeed.processors.pole_zero(waveform, 100, wf_pz)",
+        "wf_t": "dspeed.processors.trap_norm(wf_pz, 10*us, 3*us, wf_t)",
+        "e": "dspeed.processors.fixed_time_pickoff(wf_t, t_pick + 10*us, 'h', e)"}}
+    tb = _tb()
+    tb["waveform"] = WaveformInput(tb["waveform"], dt=16.0)
+    chain, _, _ = build_processing_chain(r, tb)
+    ops = chain.program.ops
+    aff = [o for o in ops if o[0] == _lib.OP_SCALAR_AFFINE][0]
+    assert aff[5][2].value == pytest.approx(625.0)
+    fused = [o for o in ops if o[0] == _lib.OP_TRAP_PICKOFF][0]
+    assert fused[4][3] == _lib.OP_TRAP_NORM and fused[3] == ord("h") and fused[5][0].kind == _lib.ARG_REG
+
+
+def test_quantity_arithmetic():
+    from dspeed_amd.processing_chain import _Builder
+
+    b = _Builder({"w": WaveformInput(np.zeros((2, 8192), dtype=np.float32), dt=16.0)}, {})
+    assert b.eval_arg("round((128*ns+2*us)/w.period)") == 133
+    assert b.eval_arg("len(w)-(33.6*us/w.period)-(4.8*us/w.period)") == pytest.approx(8192 - 2100 - 300)
+    assert isinstance(b.eval_arg("10*us"), Quantity) and float(b.eval_arg("10*us")) == 10000.0
+    assert b.eval_arg("'l'") == ("char", "l")
+
+
+def test_shard_rows_partitions_the_event_axis():
+    for n in (0, 1, 7, 1000, 10_000_000):
+        for g in (1, 2, 3, 8):
+            parts = [shard_rows(n, g, r) for r in range(g)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(g - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
