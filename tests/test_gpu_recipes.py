@@ -46,9 +46,15 @@ def test_c2_recipe_golden_and_units_form():
     assert np.max(np.abs(out["trapEftp"][ok] - want[ok]) / np.abs(want[ok])) <= TOL
     assert chain._chain.kernel_name == "dsp_energy_kernel"  # the recipe took the specialised path
     tb["waveform"] = WaveformInput(c2["waveform"], dt=16.0)
+    # the LEGEND-style form: tau = 27460.5 ns / 16 ns (not exactly the 1716.28 of the fixture), rise/flat from time quantities;
+    # wf_trap is an output there, so this runs on the generic VM with a materialised trapezoid
     _, out2 = _run(recipes.C2_UNITS, tb)
-    assert np.array_equal(out2["trapEftp"], out["trapEftp"], equal_nan=True)  # same numbers through the generic VM + time units
-    assert_rel_to_peak(out2["wf_trap"][:2], c2["wf_trap"], TOL, "wf_trap")
+    want2, rc = oracle.chain_energy(c2["waveform"], c2["baseline"], c2["t_pick"], 27460.5 / 16.0, 625, 188, "l")
+    assert rc == 0 and np.array_equal(np.isnan(out2["trapEftp"]), np.isnan(want2))
+    assert np.max(np.abs(out2["trapEftp"][ok] - want2[ok]) / np.abs(want2[ok])) <= TOL
+    xb = oracle.bl_subtract(c2["waveform"], c2["baseline"])[0]
+    tr = oracle.trap_filter(oracle.pole_zero(xb, 27460.5 / 16.0)[0], 625, 188)[0]
+    assert_rel_to_peak(out2["wf_trap"], tr, TOL, "wf_trap")
 
 
 def test_c5_recipe_golden():
