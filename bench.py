@@ -166,13 +166,25 @@ def main():
         t = time.perf_counter()
         oracle.chain_energy(wf_c, bl_c, tp_c, TAU, RISE, FLAT, "l", block_width=16, n_threads=1)
         dt1 = time.perf_counter() - t
-        cores = oracle.max_threads()
+        # the GPU box exposes every host CPU, but one GPU's share is 16: use no more threads than that
+        cores = max(1, min(oracle.max_threads(), len(os.sched_getaffinity(0)), 16))
         t = time.perf_counter()
         oracle.chain_energy(wf_c, bl_c, tp_c, TAU, RISE, FLAT, "l", block_width=16, n_threads=cores)
         dtn = time.perf_counter() - t
         cpu = {"value": n_cpu / dt1, "unit": "waveforms/s", "cores": 1, "kind": "port",
                "sample": f"first {n_cpu} rows of the same synthetic batch, 16-row blocks, one processor call per block (dspeed defaults), {dt1:.1f} s",
                "all_cores": {"value": n_cpu / dtn, "cores": cores, "seconds": round(dtn, 2)}}
+
+    # HBM traffic per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled as the gfx950 guide prescribes),
+    # recorded under profiles/ by tools/profile_bench.sh; null if no recorded measurement matches this workload
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            t = json.load(f)
+        if t.get("rows") == rows and t.get("wf_len") == WF_LEN and t.get("kernel") == chain.kernel_name:
+            traffic, traffic_src = t["hbm_bytes_per_launch"], t.get("source")
+    except (OSError, ValueError, KeyError):
+        pass
 
     info = device_info(local_rank % ndev)
     line = {
@@ -194,7 +206,8 @@ def main():
                    "kernel": chain.kernel_name, "lds_bytes_per_wave": geo["lds_bytes_per_wave"], "waves_per_block": geo["waves_per_block"],
                    "blocks": geo["blocks"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "bytes_per_waveform": BYTES_PER_WF, "kernel_ms_avg": 1e3 * avg_kernel_s,
+                     "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": rows * BYTES_PER_WF,
+                     "bytes_per_waveform": BYTES_PER_WF, "kernel_ms_avg": 1e3 * avg_kernel_s,
                      "kernel_ms_min": float(np.min(kernel_ms))},
         "cpu_baseline": cpu,
         "parity_max_rel_vs_oracle": parity,

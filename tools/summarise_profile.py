@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/prof_<tag>/ (rocprofv3 csv output of tools/profile_bench.sh) into the tracked files
+profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json, profiles/<tag>_pmc_traffic.json and profiles/<tag>_summary.md."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+
+stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
+if stats:
+    shutil.copy(stats[0], f"profiles/{tag}_kernel_stats.csv")
+bench = json.load(open(f"{src}/bench_default.json"))
+kernel = bench["config"]["kernel"]
+rows, wf_len = bench["config"]["rows_per_gpu"], bench["config"]["wf_len"]
+
+pmc = {}
+for d in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
+    for f in glob.glob(f"{src}/{d}/*/*_counter_collection.csv"):
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            pmc[k] = sum(v) / len(v)
+json.dump({"kernel": kernel, "rows": rows, "wf_len": wf_len, "per_launch": pmc}, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
+
+summary = [f"# {tag}: `python bench.py` on MI355X ({bench['config']['device'].strip()})", "",
+           f"* value: **{bench['value'] / 1e6:.1f} M waveforms/s**, {bench['ms_per_step']:.3f} ms per step ({rows} x {wf_len} float32 rows)",
+           f"* roofline: {bench['roofline']['achieved']:.0f} GB/s algorithmic of {bench['roofline']['peak']:.0f} GB/s = "
+           f"**{100 * bench['roofline']['frac']:.1f} %**; kernel `{kernel}` avg {bench['roofline']['kernel_ms_avg']:.3f} ms (HIP events)",
+           f"* parity guard inside the bench: max |GPU - oracle| / |oracle| = {bench['parity_max_rel_vs_oracle']:.2e} over 4096 rows"]
+if bench.get("cpu_baseline"):
+    c = bench["cpu_baseline"]
+    summary.append(f"* cpu_baseline (oracle, dspeed-style 16-row blocks): {c['value']:.0f} wf/s on 1 core; "
+                   f"{c['all_cores']['value']:.0f} wf/s on {c['all_cores']['cores']} cores")
+if stats:
+    for r in csv.DictReader(open(stats[0])):
+        if kernel in r["Name"]:
+            summary.append(f"* rocprofv3 --kernel-trace --stats: {r['Calls']} calls, average {float(r['AverageNs']) / 1e6:.3f} ms "
+                           f"(min {float(r['MinNs']) / 1e6:.3f}, max {float(r['MaxNs']) / 1e6:.3f})")
+if "FETCH_SIZE" in pmc:
+    fetch = pmc["FETCH_SIZE"] * 1024 * 2  # KiB -> B, x2: gfx950 tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM)
+    write = pmc.get("WRITE_SIZE", 0.0) * 1024
+    alg = rows * (wf_len * 4 + 12)
+    summary.append(f"* HBM traffic per launch (PMC, separate passes): FETCH_SIZE x2 = {fetch / 1e9:.3f} GB, WRITE_SIZE = {write / 1e6:.2f} MB; "
+                   f"algorithmic {alg / 1e9:.3f} GB -> traffic / algorithmic = {(fetch + write) / alg:.3f}")
+    json.dump({"kernel": kernel, "rows": rows, "wf_len": wf_len, "hbm_bytes_per_launch": fetch + write,
+               "source": f"profiles/{tag}_pmc.json: FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (rocprofv3 --pmc, separate passes)"},
+              open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+n = 1e6 * rows / 1e6
+per = lambda k: pmc.get(k, float("nan")) / rows  # noqa: E731
+summary += ["", "Per waveform (= per wavefront-iteration), SQ counters in quad-cycles:", "",
+            "| VALU insts | SALU insts | LDS insts | wave cycles | active VALU | active LDS | wait any | LDS bank-conflict cycles | LDS active cycles |",
+            "|---|---|---|---|---|---|---|---|---|",
+            "| " + " | ".join(f"{per(k):.0f}" for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU",
+                                                        "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")) + " |"]
+open(f"profiles/{tag}_summary.md", "w").write("\n".join(summary) + "\n")
+shutil.copy(f"{src}/bench_default.json", f"profiles/{tag}_bench.json")
+print("\n".join(summary))
