@@ -12,7 +12,7 @@ import os
 from .errors import DSPFatal
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdspeed_hip.so")
+LIB_PATH = os.environ.get("DSPEED_HIP_LIB") or os.path.join(_HERE, "libdspeed_hip.so")  # override: A/B kernel builds
 
 # ---- constants of include/dspeed_hip.h
 OK, ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_TOO_LONG = 0, -1, -2, -3, -4

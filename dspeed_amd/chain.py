@@ -109,9 +109,10 @@ class Chain:
         _lib.check(_lib.lib().dsp_chain_geometry(self._h, int(n_wf), C.byref(a), C.byref(b), C.byref(c)))
         return {"lds_bytes_per_wave": a.value, "waves_per_block": b.value, "blocks": c.value}
 
-    def set_fused(self, enable: bool) -> bool:
-        """Use (True, default) or bypass (False) the specialised energy-chain kernel; returns whether it is in use."""
-        return bool(_lib.lib().dsp_chain_set_fused(self._h, 1 if enable else 0))
+    def set_fused(self, enable) -> bool:
+        """False/0: generic waveform VM; True/1: default specialised energy kernel (one chain per lane); 3: 2 sub-chains per lane on a
+        pad-free LDS image; 5: 4 sub-chains per lane.  Returns whether a specialised kernel is in use."""
+        return bool(_lib.lib().dsp_chain_set_fused(self._h, int(enable)))
 
     @property
     def kernel_name(self) -> str:

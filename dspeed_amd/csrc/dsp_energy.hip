@@ -51,6 +51,21 @@ namespace {
 constexpr int G = 8;   // samples per software-pipeline group in the pole-zero passes
 constexpr int G3 = 8;  // ... in the trapezoid replay (4 streams x 2 buffers live there: 64 VGPRs, fine at 2 waves/SIMD)
 
+// diagnostic cycle stamps (DSPEED_HIP_ABLATE bit 3): where a wavefront spends its time, summed per phase into err[4 + 2*phase]
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define PHASE(i)                                   \
+    if (stamps) {                                  \
+        const unsigned long long now_ = stamp();   \
+        tsum[i] += now_ - tlast;                   \
+        tlast = now_;                              \
+    }
+
 template <int N>
 __device__ __forceinline__ void load_group(float (&v)[N], const float* p) {
 #pragma unroll
@@ -99,6 +114,8 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
         }
     };
     if (row < n_wf) prefetch(row);
+    const bool stamps = (A.ablate & 8) != 0;
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = stamps ? stamp() : 0;
 
     for (; row < n_wf; row += stride_rows) {
         // ---- stage the prefetched waveform into LDS (chunked layout)
@@ -117,6 +134,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
         if (next < n_wf) prefetch(next);    // in flight while this waveform is filtered
         __builtin_amdgcn_sched_barrier(0);
         wave_sync();
+        PHASE(0)
 
         float result = quiet_nan<float>();
         // ---- pass 1: per-chunk float64 sum of x = w - baseline; a NaN anywhere (or a NaN baseline) poisons the sum
@@ -144,6 +162,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
             }
             in_nan |= wave_any(n);
         }
+        PHASE(1)
         if (!in_nan) {
             const double E = wave_exscan_add(X);
             const float xlast = mine[C - 1] - bl;
@@ -187,6 +206,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
                 }
             }
             wave_sync();
+            PHASE(2)
             bool pz_nan = false;
             if (wave_any(!(fabsf(run) <= 3.4028234663852886e38f))) {
                 bool n = false;
@@ -235,6 +255,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (co[k] >= 0) capmask |= 1u << (co[k] / G3);
+                PHASE(3)
                 // ---- pass 3: replay the reference's float32 rounding sequence over the chunk
                 float y = g;
                 {
@@ -281,6 +302,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
                         body(b0, b1, b2, b3, t + G3);
                     }
                 }
+                PHASE(4)
                 // ---- true carries from the per-chunk increments (exact scan), then the pick-off
                 const double D = (double)y - (double)g;
                 const double delta = wave_exscan_add(D) - (double)g;
@@ -297,7 +319,344 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
         }
         if (lane == 0) A.out[row * A.out_stride] = result;
         wave_sync();
+        PHASE(5)
     }
+    if (stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(err + 4) + i, tsum[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ILP variant: S independent sub-chains per lane, linear (pad-free) LDS layout.
+//
+// The one-chunk-per-lane kernel above is latency bound: each lane walks one dependent chain (2 float64 operations per
+// sample in the pole-zero pass, 4 float32 additions per sample in the trapezoid replay) and only two wavefronts share a
+// SIMD.  Here every lane owns C = 4*NPF + 1 samples (an ODD count, so the lane stride is odd and the waveform can sit in
+// LDS exactly as it sits in memory: no chunk pads, lagged streams are plain contiguous reads, staging is one 16-byte
+// store per load) and walks them as S interleaved sub-chains of CS = (C-1)/S samples (the last one also takes sample
+// C-1).  Each sub-chain has its own pole-zero carry (from the float64 prefix sums of pass 1) and its own speculative
+// trapezoid carry, so S dependent chains are in flight per lane.  Same arithmetic per sample as everywhere else.
+//
+// Host-provided plan (EnergyPlan): for every (lag k, sub-chain s) where the prefix value the carry needs lives:
+// `shift` lanes below, after `r` samples of that lane's chunk, i.e. in sub-chain cs after `local` samples of it.
+// ------------------------------------------------------------------------------------------------
+struct EnergyPlan {
+    int32_t shift[3][4];  // lane distance
+    int32_t cs[3][4];     // sub-chain that holds the capture point
+    int32_t local[3][4];  // capture after `local` samples of that sub-chain (0: nothing of it)
+};
+
+template <int NPF, int KIND, int S>
+__global__ void __launch_bounds__(256, 2) dsp_energy_ilp_kernel(EnergyArgs A, EnergyPlan PL, int64_t n_wf, int* err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int C = 4 * NPF + 1, len = 256 * NPF, CS = (C - 1) / S, GQ = 4;
+    static_assert(CS % GQ == 0, "sub-chain length must be a multiple of the group size");
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
+    float* lds = reinterpret_cast<float*>(smem_raw) + (size_t)wave * A.lds_elems_per_wave;
+    for (int e = lane; e < A.lds_elems_per_wave; e += 64) lds[e] = 0.0f;
+    wave_sync();
+    float* slot = lds + A.slot_off;  // sample i of the waveform lives at slot[i]; zeros below (guard) and above len
+    float* mine = slot + lane * C;
+
+    // lagged streams: sample (lane*C + t - L_k) = lagp[k][t]; lanes whose whole range is before sample 0 read the zero guard
+    const float* lagp[3];
+    int L[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        L[k] = A.q[k];  // for this kernel the host passes the lags themselves in q[]
+        const int pos0 = lane * C - L[k];
+        lagp[k] = (pos0 >= -C) ? slot + pos0 : slot - (2 * C + 8);
+    }
+
+    const int64_t stride_rows = (int64_t)gridDim.x * wpb;
+    int64_t row = (int64_t)blockIdx.x * wpb + wave;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 pf[NPF];
+    float pf_bl = 0.0f, pf_tp = 0.0f;
+    auto prefetch = [&](int64_t r) {
+        const float* g = (const float*)A.wf + r * A.wf_stride + A.wf_offset;
+#pragma unroll
+        for (int b = 0; b < NPF; ++b) pf[b] = reinterpret_cast<const f4*>(g)[b * 64 + lane];
+        pf_bl = A.bl ? A.bl[r * A.bl_stride] : A.bl_const;
+        pf_tp = A.tp ? A.tp[r * A.tp_stride] : A.tp_const;
+    };
+    auto report = [&](int code, int64_t r) {
+        if (lane == 0 && atomicCAS(&err[0], 0, code) == 0) {
+            err[1] = (int)(r & 0xffffffffll);
+            err[2] = (int)(r >> 32);
+        }
+    };
+    if (row < n_wf) prefetch(row);
+    const bool stamps = (A.ablate & 8) != 0;
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = stamps ? stamp() : 0;
+
+    for (; row < n_wf; row += stride_rows) {
+        // ---- stage: the waveform goes to LDS as it is (16-byte stores)
+#pragma unroll
+        for (int b = 0; b < NPF; ++b) *reinterpret_cast<f4*>(slot + (b * 64 + lane) * 4) = pf[b];
+        slot[len + lane] = pf_bl;  // the 64 virtual samples above len hold the baseline: x = w - baseline = 0 exactly (re-set per row)
+        const float bl = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pf_bl)));
+        const float t_in = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pf_tp)));
+        const int64_t next = row + stride_rows;
+        __builtin_amdgcn_sched_barrier(0);
+        if (next < n_wf) prefetch(next);
+        __builtin_amdgcn_sched_barrier(0);
+        wave_sync();
+        PHASE(0)
+
+        float result = quiet_nan<float>();
+        // ---- pass 1: float64 sums of x = w - baseline per sub-chain
+        double X[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) X[s] = 0.0;
+#pragma unroll 1
+        for (int t = 0; t < CS; t += GQ) {
+            float v[S][GQ];
+#pragma unroll
+            for (int s = 0; s < S; ++s) load_group(v[s], mine + s * CS + t);
+#pragma unroll
+            for (int u = 0; u < GQ; ++u)
+#pragma unroll
+                for (int s = 0; s < S; ++s) X[s] += (double)(v[s][u] - bl);
+        }
+        X[S - 1] += (double)(mine[C - 1] - bl);
+        double Xtot = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) Xtot += X[s];
+        bool in_nan = A.tau_nan != 0;
+        if (wave_any(!(fabs(Xtot) <= 1.7976931348623157e308))) {
+            bool n = false;
+            for (int t = 0; t < C; ++t) {
+                const float x = mine[t] - bl;
+                n |= (x != x);
+            }
+            in_nan |= wave_any(n);
+        }
+        PHASE(1)
+        if (!in_nan) {
+            const double E0 = wave_exscan_add(Xtot);
+            // ---- pass 2: S interleaved pole-zero chains, output in place, float32 running sums for the trapezoid carries
+            const double c = A.c;
+            double acc[S], xp[S];
+            float run[S], capr[3][S];
+            int capg[3][S], capsel[3][S];  // group of pass 2 that completes the capture, and which (sub-chain, sample) of it
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const int lc = PL.local[k][s];
+                    capg[k][s] = lc > 0 ? (lc - 1) / GQ : -1;
+                    capsel[k][s] = PL.cs[k][s] * GQ + (lc > 0 ? (lc - 1) % GQ : 0);
+                }
+            {
+                double Es = E0;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const int at = lane * C + s * CS;  // first sample of the sub-chain
+                    const float xprev = (at > 0) ? mine[s * CS - 1] - bl : 0.0f;
+                    xp[s] = (double)xprev;
+                    acc[s] = Es - c * (Es - xp[s]);
+                    Es += X[s];
+                    run[s] = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) capr[k][s] = 0.0f;
+                }
+            }
+            auto pz_step = [&](int s, float raw) -> float {
+                const double x = (double)(raw - bl);
+                acc[s] = (acc[s] + x) - xp[s] * c;
+                const float y = (float)acc[s];
+                xp[s] = x;
+                run[s] += y;
+                return y;
+            };
+#pragma unroll 1
+            for (int t = 0; t < CS; t += GQ) {
+                float v[S][GQ], rs[S][GQ];
+#pragma unroll
+                for (int s = 0; s < S; ++s) load_group(v[s], mine + s * CS + t);
+#pragma unroll
+                for (int u = 0; u < GQ; ++u)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const float y = pz_step(s, v[s][u]);
+                        mine[s * CS + t + u] = y;
+                        rs[s][u] = run[s];
+                    }
+                // prefix captures that fall into this group (positions fixed by the lag geometry)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        if (capg[k][s] * GQ == t) {
+#pragma unroll
+                            for (int s2 = 0; s2 < S; ++s2)
+#pragma unroll
+                                for (int u = 0; u < GQ; ++u)
+                                    if (capsel[k][s] == s2 * GQ + u) capr[k][s] = rs[s2][u];
+                        }
+                    }
+            }
+            {
+                const float y = pz_step(S - 1, mine[C - 1]);
+                mine[C - 1] = y;
+            }
+            wave_sync();
+            PHASE(2)
+            float runtot = 0.0f, runbefore[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                runbefore[s] = runtot;
+                runtot += run[s];
+            }
+            bool pz_nan = false;
+            if (wave_any(!(fabsf(runtot) <= 3.4028234663852886e38f))) {
+                bool n = false;
+                for (int t = 0; t < C; ++t) {
+                    const float y = mine[t];
+                    n |= (y != y);
+                }
+                pz_nan = wave_any(n);
+            }
+            if (pz_nan) {
+                report(DSP_E_PZ_NAN, row);
+            } else if (!A.all_nan && !(A.ablate & 4) && pickoff_in_range(t_in, len)) {
+                // ---- speculative carry of every sub-chain
+                const double Ep = wave_exscan_add((double)runtot);
+                float g[S], y[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    double Ak[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        // prefix up to the capture point in the lane `shift` below: sub-chains before cs in full, cs partially
+                        float part = capr[k][s];
+#pragma unroll
+                        for (int s2 = 0; s2 < S; ++s2)
+                            if (PL.cs[k][s] > s2) part += run[s2];
+                        Ak[k] = wave_shift_up(Ep + (double)part, PL.shift[k][s]);
+                    }
+                    const double own = Ep + (double)runbefore[s];
+                    double Gd;
+                    if (KIND == TRAP_FILTER)
+                        Gd = ((own - Ak[0]) - Ak[1]) + Ak[2];
+                    else if (KIND == TRAP_NORM)
+                        Gd = (((own - Ak[0]) - Ak[1]) + Ak[2]) / A.rr;
+                    else
+                        Gd = (own - Ak[0]) / A.rr - (Ak[1] - Ak[2]) / A.ll;
+                    g[s] = (lane == 0 && s == 0) ? -0.0f : (float)Gd;
+                    y[s] = g[s];
+                }
+                // ---- wanted samples (uniform): i0-1 .. i0+2
+                const int i0 = (int)t_in;
+                const bool wide = (A.mode == 'h');
+                int cl[4], cch[4], cloc[4];  // owning lane, sub-chain, sample within the sub-chain (CS = its tail step)
+                float capv[4];
+                unsigned capmask = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = i0 - 1 + k;
+                    const bool need = ((k == 1) || (k == 2) || wide) && e >= 0 && e < len;
+                    const int l = need ? e / C : -1;
+                    const int off = need ? e - l * C : 0;
+                    int ch = off / CS;
+                    if (ch > S - 1) ch = S - 1;
+                    cl[k] = l;
+                    cch[k] = ch;
+                    cloc[k] = need ? off - ch * CS : -1000;
+                    capv[k] = 0.0f;
+                    if (need && cloc[k] < CS) capmask |= 1u << (cloc[k] / GQ);
+                }
+                PHASE(3)
+                // ---- pass 3: S interleaved replays of the reference's float32 rounding sequence
+#pragma unroll 1
+                for (int t = 0; t < CS; t += GQ) {
+                    float o[S][GQ], l0[S][GQ], l1[S][GQ], l2[S][GQ], ys[S][GQ];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        load_group(o[s], mine + s * CS + t);
+                        load_group(l0[s], lagp[0] + s * CS + t);
+                        if (A.ablate & 16) {  // timing experiment: half the lagged LDS traffic
+#pragma unroll
+                            for (int u = 0; u < GQ; ++u) l1[s][u] = l2[s][u] = 0.0f;
+                        } else {
+                            load_group(l1[s], lagp[1] + s * CS + t);
+                            load_group(l2[s], lagp[2] + s * CS + t);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < GQ; ++u)
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            y[s] = trap_step<float, KIND>(y[s], o[s][u], l0[s][u], l1[s][u], l2[s][u], A.rr, A.ll);
+                            ys[s][u] = y[s];
+                        }
+                    if ((capmask >> (t / GQ)) & 1u) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int d = cloc[k] - t;
+#pragma unroll
+                            for (int s = 0; s < S; ++s)
+#pragma unroll
+                                for (int u = 0; u < GQ; ++u)
+                                    if (cch[k] == s && d == u) capv[k] = ys[s][u];
+                        }
+                    }
+                }
+                {
+                    const int tt = C - 1;  // the odd sample continues the last sub-chain
+                    y[S - 1] = trap_step<float, KIND>(y[S - 1], mine[tt], lagp[0][tt], lagp[1][tt], lagp[2][tt], A.rr, A.ll);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (cloc[k] == CS && cch[k] == S - 1) capv[k] = y[S - 1];
+                }
+                PHASE(4)
+                // ---- true carries: exact scan of the increments, per lane then across lanes
+                double D[S], Dtot = 0.0, Dbefore[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    D[s] = (double)y[s] - (double)g[s];
+                    Dbefore[s] = Dtot;
+                    Dtot += D[s];
+                }
+                const double T0 = wave_exscan_add(Dtot);
+                float w4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    double delta = 0.0;
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+                        if (cch[k] == s) delta = (T0 + Dbefore[s]) - (double)g[s];
+                    const float v = (float)((double)capv[k] + delta);
+                    w4[k] = cl[k] >= 0 ? readlane(v, cl[k]) : 0.0f;
+                }
+                int fc = 0;
+                result = pickoff_eval(t_in, A.mode, len, w4, fc);
+                if (fc) report(fc, row);
+            }
+        }
+        if (lane == 0) A.out[row * A.out_stride] = result;
+        wave_sync();
+        PHASE(5)
+    }
+    if (stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(err + 4) + i, tsum[i]);
+    }
+}
+
+template <int KIND, int S>
+int launch_ilp_kind(const EnergyArgs& A, const EnergyPlan& PL, int npf, int64_t n_wf, int* err, int blocks, int threads, int lds_bytes,
+                    hipStream_t st) {
+    switch (npf) {
+        case 4: hipLaunchKernelGGL((dsp_energy_ilp_kernel<4, KIND, S>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 8: hipLaunchKernelGGL((dsp_energy_ilp_kernel<8, KIND, S>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 16: hipLaunchKernelGGL((dsp_energy_ilp_kernel<16, KIND, S>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+    return (int)hipGetLastError();
 }
 
 template <int KIND>
@@ -335,4 +694,17 @@ extern "C" int dsp_internal_set_energy_lds(int trap_opcode, int npf, int lds_byt
     return (int)hipErrorInvalidValue;
 }
 
+// S sub-chains per lane (2 or 4); q[] of A carries the three lags; plan from the host
+extern "C" int dsp_internal_launch_energy_ilp(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int64_t n_wf,
+                                              int* err, int blocks, int threads, int lds_bytes, hipStream_t stream) {
+#define GO_(KIND)                                                                                                  \
+    return S == 4 ? launch_ilp_kind<KIND, 4>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream)          \
+                  : launch_ilp_kind<KIND, 2>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
+    if (trap_opcode == DSP_OP_TRAP_FILTER) { GO_(TRAP_FILTER) }
+    if (trap_opcode == DSP_OP_TRAP_NORM) { GO_(TRAP_NORM) }
+    GO_(TRAP_ASYM)
+#undef GO_
+}
+
 extern "C" const char* dsp_internal_energy_kernel_name() { return "dsp_energy_kernel"; }
+extern "C" const char* dsp_internal_energy_ilp_kernel_name() { return "dsp_energy_ilp_kernel"; }

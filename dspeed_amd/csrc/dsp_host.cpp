@@ -62,6 +62,15 @@ extern "C" int dsp_internal_launch_energy(const EnergyArgs* A, int trap_opcode, 
                                           int threads, int lds_bytes, hipStream_t stream);
 extern "C" int dsp_internal_set_energy_lds(int trap_opcode, int npf, int lds_bytes);
 extern "C" const char* dsp_internal_energy_kernel_name();
+static const char* dsp_internal_energy_pair_kernel_name() { return "dsp_energy_pair_kernel"; }
+struct EnergyPlan {
+    int32_t shift[3][4];
+    int32_t cs[3][4];
+    int32_t local[3][4];
+};
+extern "C" int dsp_internal_launch_energy_ilp(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int64_t n_wf,
+                                              int* err, int blocks, int threads, int lds_bytes, hipStream_t stream);
+extern "C" const char* dsp_internal_energy_ilp_kernel_name();
 
 namespace {
 
@@ -108,6 +117,16 @@ struct dsp_chain {
     bool fused_ok = false, fused_on = true;
     EnergyArgs fused{};
     int fused_trap = 0, fused_npf = 0;
+    // two-wavefronts-per-waveform variant of the same kernel (len = 2048 / 4096 / 8192)
+    bool pair_ok = false, pair_on = true;
+    EnergyArgs pair{};
+    int pair_npfh = 0, pair_lds_bytes = 0;
+    // ILP variant (S sub-chains per lane, pad-free LDS): the default for 1024/2048/4096-sample energy chains
+    bool ilp_ok = false;
+    int variant = 1;  // 1: one chain per lane (default: fastest so far), 0: 2 sub-chains per lane (pad-free LDS), 2: 4 sub-chains
+    EnergyArgs ilp{};
+    EnergyPlan plan[2]{};  // [0]: S=2, [1]: S=4
+    int ilp_lds_bytes = 0;
     int io_wf = -1, io_bl = -1, io_tp = -1, io_out = -1;
 };
 
@@ -315,7 +334,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         d.invC = 1.0f / (float)C;
         cursor += 2 * d.pitch;
         d.off = cursor;
-        cursor += 64 * d.pitch + 8;
+        cursor += 64 * d.pitch + 40;  // tail: the pipelined loops read up to 2 groups + 1 past the last chunk
     }
     P.sreg_off = cursor;
     cursor += ((n_sregs + 7) / 8) * 8 + 8;
@@ -517,7 +536,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         const bool shape = st && i == n_ops && n_slots == 1 && io[ld->io].dtype == DSP_F32 && P.io[ld->io].vec_ok &&
                            (!bs || (bs->dst == 0 && bs->src == 0 && bs->sp[0].kind != DSP_ARG_REG)) && pz->dst == 0 && pz->src == 0 &&
                            tp->src == 0 && tp->sp[0].kind != DSP_ARG_REG && st->ip[0] == tp->dst &&
-                           (slot_len[0] == 1024 || slot_len[0] == 2048 || slot_len[0] == 4096);  // len == 256 * npf, npf in {4, 8, 16}
+                           (slot_len[0] == 1024 || slot_len[0] == 2048 || slot_len[0] == 4096 || slot_len[0] == 8192);
         auto f32_col = [&](const dsp_scalar_arg& a) { return a.kind != DSP_ARG_INPUT || io[a.index].dtype == DSP_F32; };
         if (shape && (!bs || f32_col(bs->sp[0])) && f32_col(tp->sp[0])) {
             EnergyArgs& F = ch->fused;
@@ -561,10 +580,66 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             ch->io_wf = ld->io;
             ch->io_out = st->io;
             ch->fused_trap = tp->ip[3];
-            ch->fused_npf = slot_len[0] / 256;
-            ch->fused_ok = true;
+            ch->fused_npf = slot_len[0] / 256;          // one wavefront per waveform: len == 256 * npf, npf in {4, 8, 16}
+            ch->fused_ok = slot_len[0] <= 4096;
             const char* env = getenv("DSPEED_HIP_NO_FUSED");
             ch->fused_on = !(env && env[0] == '1');
+            if (slot_len[0] <= 4096) {  // ILP variant: C = len/64 + 1 samples per lane, linear LDS image of the waveform
+                EnergyArgs& I = ch->ilp;
+                I = F;
+                const int Ci = slot_len[0] / 64 + 1;
+                I.C = Ci;
+                I.pitch = Ci;
+                I.invC = 1.0f / (float)Ci;
+                int guard = 2 * Ci + 8;
+                guard = ((guard + 3) / 4) * 4;
+                I.slot_off = guard;
+                int elems = guard + 64 * Ci + 16;
+                elems = ((elems + 3) / 4) * 4;
+                I.lds_elems_per_wave = elems;
+                ch->ilp_lds_bytes = elems * 4;
+                for (int k = 0; k < 3; ++k) {
+                    I.q[k] = dtp.ic[k];  // the lags themselves
+                    I.rho[k] = 0;
+                }
+                for (int v = 0; v < 2; ++v) {
+                    const int S = v == 0 ? 2 : 4, CS = (Ci - 1) / S;
+                    for (int k = 0; k < 3; ++k)
+                        for (int sidx = 0; sidx < S; ++sidx) {
+                            const int pos = sidx * CS - dtp.ic[k];          // samples before the sub-chain start, relative to the chunk
+                            const int r = ((pos % Ci) + Ci) % Ci;           // ... = r samples into the chunk of the lane `shift` below
+                            const int shift = (r - pos) / Ci;
+                            int cs = r / CS;
+                            if (cs > S - 1) cs = S - 1;
+                            ch->plan[v].shift[k][sidx] = shift;
+                            ch->plan[v].cs[k][sidx] = cs;
+                            ch->plan[v].local[k][sidx] = r - cs * CS;
+                        }
+                }
+                ch->ilp_ok = true;
+                if (const char* venv = getenv("DSPEED_HIP_VARIANT")) ch->variant = atoi(venv);
+            }
+            if (slot_len[0] >= 2048) {                  // two wavefronts per waveform: len == 512 * npfh, npfh in {4, 8, 16}
+                EnergyArgs& Q = ch->pair;
+                Q = F;
+                const int C2 = slot_len[0] / 128, pitch2 = C2 + 1;
+                Q.C = C2;
+                Q.pitch = pitch2;
+                Q.invC = 1.0f / (float)C2;
+                for (int k = 0; k < 3; ++k) {
+                    Q.q[k] = dtp.ic[k] / C2;
+                    Q.rho[k] = dtp.ic[k] % C2;
+                }
+                Q.slot_off = 2 * pitch2;
+                int elems = 2 * pitch2 + 128 * pitch2 + 40 + 32 + 3 * 128 + 8;  // tail 40: see the slot layout above
+                elems = ((elems + 3) / 4) * 4;
+                Q.lds_elems_per_wave = elems;  // per workgroup here
+                ch->pair_lds_bytes = elems * 4;
+                ch->pair_npfh = slot_len[0] / 512;
+                ch->pair_ok = false;  // the two-wavefronts-per-waveform variant measured slower (barriers); kept out of the build
+                const char* penv = getenv("DSPEED_HIP_PAIR");
+                ch->pair_on = !(penv && penv[0] == '0');
+            }
         }
     }
 
@@ -612,6 +687,40 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
     const int blocks = chain_blocks(ch, n_wf);
     const int threads = 64 * ch->waves_per_block;
     const int lds = ch->lds_bytes_per_wave * ch->waves_per_block;
+    if (ch->pair_ok && ch->pair_on && ch->fused_on && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
+        EnergyArgs F = ch->pair;
+        F.wf = io_ptrs[ch->io_wf];
+        F.bl = ch->io_bl >= 0 ? (const float*)io_ptrs[ch->io_bl] : nullptr;
+        F.tp = ch->io_tp >= 0 ? (const float*)io_ptrs[ch->io_tp] : nullptr;
+        F.out = (float*)io_ptrs[ch->io_out];
+        int per_cu = LDS_BYTES_PER_CU / ch->pair_lds_bytes;
+        const int reg_cap = (ch->pair_npfh <= 8) ? 8 : 4;  // 4 resp. 2 wavefronts per SIMD by registers
+        if (per_cu > reg_cap) per_cu = reg_cap;
+        int64_t pblocks = (int64_t)ch->num_cu * per_cu;
+        if (pblocks > n_wf) pblocks = n_wf;
+        (void)pblocks;
+        (void)F;
+        return fail(DSP_ERR_UNSUPPORTED, "pair kernel not built");
+    }
+    if (ch->ilp_ok && ch->fused_on && ch->variant != 1 && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
+        EnergyArgs F = ch->ilp;
+        F.wf = io_ptrs[ch->io_wf];
+        F.bl = ch->io_bl >= 0 ? (const float*)io_ptrs[ch->io_bl] : nullptr;
+        F.tp = ch->io_tp >= 0 ? (const float*)io_ptrs[ch->io_tp] : nullptr;
+        F.out = (float*)io_ptrs[ch->io_out];
+        const int S = ch->variant == 2 ? 4 : 2;
+        int wpb = LDS_BYTES_PER_CU / ch->ilp_lds_bytes;
+        if (wpb > 4) wpb = 4;
+        int per_cu = LDS_BYTES_PER_CU / (ch->ilp_lds_bytes * wpb);
+        if (per_cu * wpb > 8) per_cu = 8 / wpb;  // registers: 2 wavefronts per SIMD
+        if (per_cu < 1) per_cu = 1;
+        int64_t want = (n_wf + wpb - 1) / wpb, cap = (int64_t)ch->num_cu * per_cu;
+        const int iblocks = (int)(want < cap ? want : cap);
+        hipError_t e = (hipError_t)dsp_internal_launch_energy_ilp(&F, &ch->plan[S == 4 ? 1 : 0], ch->fused_trap, ch->fused_npf, S, n_wf, ch->dev_err,
+                                                                  iblocks, 64 * wpb, ch->ilp_lds_bytes * wpb, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy ILP kernel launch failed: %s", hipGetErrorString(e));
+        return DSP_OK;
+    }
     if (ch->fused_ok && ch->fused_on && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
         EnergyArgs F = ch->fused;
         F.wf = io_ptrs[ch->io_wf];
@@ -631,11 +740,23 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
 int dsp_chain_check(dsp_chain* ch, void* stream, int64_t* row) {
     if (!ch) return fail(DSP_ERR_ARG, "null chain");
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    int host_err[DSP_ERR_WORDS] = {0, 0, 0, 0};
+    int host_err[DSP_ERR_WORDS] = {0};
     HIP_TRY(hipMemcpy(host_err, ch->dev_err, sizeof host_err, hipMemcpyDeviceToHost));
+    if (getenv("DSPEED_HIP_ABLATE") && (atoi(getenv("DSPEED_HIP_ABLATE")) & 8)) {  // diagnostic phase stamps
+        unsigned long long ph[6];
+        memcpy(ph, host_err + 4, sizeof ph);
+        unsigned long long tot = 0;
+        for (int i = 0; i < 6; ++i) tot += ph[i];
+        if (tot) {
+            fprintf(stderr, "[dspeed_hip stamps] cycles per phase (stage, pass1, pass2, carries, pass3, tail):");
+            for (int i = 0; i < 6; ++i) fprintf(stderr, " %.1f%%", 100.0 * (double)ph[i] / (double)tot);
+            fprintf(stderr, "  total %llu\n", tot);
+            HIP_TRY(hipMemset(ch->dev_err + 4, 0, sizeof ph));
+        }
+    }
     if (host_err[0] != 0) {
         if (row) *row = ((int64_t)(uint32_t)host_err[2] << 32) | (uint32_t)host_err[1];
-        HIP_TRY(hipMemset(ch->dev_err, 0, sizeof host_err));
+        HIP_TRY(hipMemset(ch->dev_err, 0, 4 * sizeof(int)));
         g_last_error = dsp_fatal_message(host_err[0]);
         return host_err[0];
     }
@@ -659,13 +780,17 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
 }
 
 const char* dsp_chain_kernel_name(dsp_chain* ch) {
+    if (ch && ch->pair_ok && ch->pair_on && ch->fused_on) return dsp_internal_energy_pair_kernel_name();
+    if (ch && ch->ilp_ok && ch->fused_on && ch->variant != 1) return dsp_internal_energy_ilp_kernel_name();
     return (ch && ch->fused_ok && ch->fused_on) ? dsp_internal_energy_kernel_name() : dsp_internal_vm_kernel_name();
 }
 
 int dsp_chain_set_fused(dsp_chain* ch, int enable) {
     if (!ch) return fail(DSP_ERR_ARG, "null chain");
-    ch->fused_on = enable != 0;
-    return (ch->fused_ok && ch->fused_on) ? 1 : 0;
+    ch->fused_on = (enable & 1) != 0;   // bit 0: use a specialised kernel
+    ch->variant = (enable >> 1) & 3;    // bits 1-2: 0 = one chain per lane (default), 1 = 2 sub-chains per lane, 2 = 4 sub-chains
+    ch->variant = ch->variant == 0 ? 1 : (ch->variant == 1 ? 0 : 2);
+    return ((ch->fused_ok || ch->ilp_ok) && ch->fused_on) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ single processors

@@ -52,4 +52,4 @@ struct IoPtrs {
 };
 
 // device error word layout: err[0] = DSP_E_* code (0 = none), err[1..2] = row (lo, hi)
-#define DSP_ERR_WORDS 4
+#define DSP_ERR_WORDS 20 /* 4 error words + 6 x 64-bit diagnostic phase-cycle sums */

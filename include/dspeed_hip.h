@@ -179,8 +179,10 @@ int dsp_chain_geometry(dsp_chain* chain, int64_t n_wf, int* lds_bytes_per_wave, 
 /* name of the device kernel the chain launches (what rocprofv3 --kernel-trace lists) */
 const char* dsp_chain_kernel_name(dsp_chain* chain);
 /* A chain of the shape LOAD [-> BL_SUBTRACT] -> POLE_ZERO -> TRAP_PICKOFF -> STORE_SCALAR (the Ge energy chain) runs on a
- * specialised kernel with identical arithmetic (dsp_energy.hip).  enable = 0 forces the generic interpreter (parity tests);
- * returns 1 if the specialised kernel will be used, 0 if not.  Environment DSPEED_HIP_NO_FUSED=1 sets the default to off. */
+ * specialised kernel with the same per-sample arithmetic (dsp_energy.hip).  enable = 0 forces the generic interpreter (parity
+ * tests); 1 = default specialised kernel (one chain per lane); 3 = 2 interleaved sub-chains per lane on a pad-free LDS image;
+ * 5 = 4 sub-chains per lane.  Returns 1 if a specialised kernel will be used.  Environment DSPEED_HIP_NO_FUSED=1 sets the default
+ * to the interpreter; DSPEED_HIP_VARIANT={1,0,2} picks the kernel variant (tuning). */
 int dsp_chain_set_fused(dsp_chain* chain, int enable);
 
 /* ---- single processors: the gufunc entry points -----------------------------------------------------

@@ -44,7 +44,7 @@ def test_c2_recipe_golden_and_units_form():
     assert np.array_equal(np.isnan(out["trapEftp"]), np.isnan(want))
     ok = ~np.isnan(want)
     assert np.max(np.abs(out["trapEftp"][ok] - want[ok]) / np.abs(want[ok])) <= TOL
-    assert chain._chain.kernel_name == "dsp_energy_kernel"  # the recipe took the specialised path
+    assert chain._chain.kernel_name.startswith("dsp_energy")  # the recipe took the specialised path
     tb["waveform"] = WaveformInput(c2["waveform"], dt=16.0)
     # the LEGEND-style form: tau = 27460.5 ns / 16 ns (not exactly the 1716.28 of the fixture), rise/flat from time quantities;
     # wf_trap is an output there, so this runs on the generic VM with a materialised trapezoid
