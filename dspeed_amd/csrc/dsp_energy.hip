@@ -659,6 +659,371 @@ int launch_ilp_kind(const EnergyArgs& A, const EnergyPlan& PL, int npf, int64_t 
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// "v3": pad-free LDS image with an EVEN lane stride C = 4*NPF + 2 = 2*odd, every chunk access 64 bits wide.
+//
+// What the measurements above say: the pole-zero passes run near the float64 issue rate whatever the structure, the
+// trapezoid replay is latency bound (helped by 2 interleaved sub-chains), and the LDS pipe is the most loaded unit
+// (55 % busy, mostly 32-bit accesses at 128 B/clk).  So: one chain per lane for passes 1 and 2, two sub-chains for the
+// replay, and all chunk traffic as ds_read_b64 / ds_write_b64 (256 B/clk reads).  With a stride of 2*odd dwords the 32 lanes of
+// a half-wave cover all 64 banks with their 8-byte accesses; lagged streams are contiguous (no pads); a stream whose lag is
+// odd starts on an odd dword, so it is fetched from the aligned dword below and consumed one register later -- the 8
+// combinations of the three lag parities are 8 static variants of the add chain behind one uniform switch.
+// Lane j owns samples [jC, jC + C); sub-chain 0 = offsets [0, 32*NPF/8...), see CS; the last two samples continue
+// sub-chain 1.  Virtual samples above len hold the baseline (x = 0 exactly).
+// Plan from the host: for (lag k, sub-chain s) the prefix the speculative carry needs = lane `shift` below, after `r` samples.
+// ------------------------------------------------------------------------------------------------
+struct EnergyPlan3 {
+    int32_t shift[3][2];
+    int32_t r[3][2];
+};
+
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+template <int KIND, int P0, int P1, int P2>
+__device__ __forceinline__ void replay4(float (&y)[2], float (&ys)[2][4], const f2v (&own)[2][2], const f2v (&r0)[2][3], const f2v (&r1)[2][3],
+                                        const f2v (&r2)[2][3], double rr, double ll) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float a = own[s][u >> 1][u & 1];
+            const float b1 = r0[s][(u + P0) >> 1][(u + P0) & 1];
+            const float b2 = r1[s][(u + P1) >> 1][(u + P1) & 1];
+            const float b3 = r2[s][(u + P2) >> 1][(u + P2) & 1];
+            y[s] = trap_step<float, KIND>(y[s], a, b1, b2, b3, rr, ll);
+            ys[s][u] = y[s];
+        }
+}
+
+template <int NPF, int KIND>
+__global__ void __launch_bounds__(256, 2) dsp_energy_v3_kernel(EnergyArgs A, EnergyPlan3 PL, int64_t n_wf, int* err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int C = 4 * NPF + 2, len = 256 * NPF, CS = (C - 2) / 2, G8 = 8;
+    static_assert(CS % 4 == 0 && (C - 2) % G8 == 0, "chunk geometry");
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
+    float* lds = reinterpret_cast<float*>(smem_raw) + (size_t)wave * A.lds_elems_per_wave;
+    for (int e = lane; e < A.lds_elems_per_wave; e += 64) lds[e] = 0.0f;
+    wave_sync();
+    float* slot = lds + A.slot_off;
+    float* mine = slot + lane * C;
+
+    // lagged streams, fetched from the even dword at or below their start (par = lag & 1)
+    const float* lagb[3];
+    int par[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int Lk = A.q[k];
+        par[k] = Lk & 1;
+        const int pos0 = lane * C - Lk - par[k];  // even
+        lagb[k] = (pos0 >= -(C + 2)) ? slot + pos0 : slot - (2 * C + 16);
+    }
+    const int parmask = par[0] | (par[1] << 1) | (par[2] << 2);
+
+    const int64_t stride_rows = (int64_t)gridDim.x * wpb;
+    int64_t row = (int64_t)blockIdx.x * wpb + wave;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 pf[NPF];
+    float pf_bl = 0.0f, pf_tp = 0.0f;
+    auto prefetch = [&](int64_t r) {
+        const float* g = (const float*)A.wf + r * A.wf_stride + A.wf_offset;
+#pragma unroll
+        for (int b = 0; b < NPF; ++b) pf[b] = reinterpret_cast<const f4*>(g)[b * 64 + lane];
+        pf_bl = A.bl ? A.bl[r * A.bl_stride] : A.bl_const;
+        pf_tp = A.tp ? A.tp[r * A.tp_stride] : A.tp_const;
+    };
+    auto report = [&](int code, int64_t r) {
+        if (lane == 0 && atomicCAS(&err[0], 0, code) == 0) {
+            err[1] = (int)(r & 0xffffffffll);
+            err[2] = (int)(r >> 32);
+        }
+    };
+    if (row < n_wf) prefetch(row);
+    const bool stamps = (A.ablate & 8) != 0;
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = stamps ? stamp() : 0;
+
+    // capture points of pass 2 (static): prefix after r samples, r in [0, C)
+    int cap_r[7];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        cap_r[2 * k] = PL.r[k][0];
+        cap_r[2 * k + 1] = PL.r[k][1];
+    }
+    cap_r[6] = CS;  // start of sub-chain 1
+
+    for (; row < n_wf; row += stride_rows) {
+        // ---- stage: linear image, 16-byte stores; virtual samples above len = baseline
+#pragma unroll
+        for (int b = 0; b < NPF; ++b) *reinterpret_cast<f4*>(slot + (b * 64 + lane) * 4) = pf[b];
+        {
+            const int nv = 64 * C - len;  // 128 for every supported length
+            for (int e = lane; e < nv; e += 64) slot[len + e] = pf_bl;
+        }
+        const float bl = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pf_bl)));
+        const float t_in = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pf_tp)));
+        const int64_t next = row + stride_rows;
+        __builtin_amdgcn_sched_barrier(0);
+        if (next < n_wf) prefetch(next);
+        __builtin_amdgcn_sched_barrier(0);
+        wave_sync();
+        PHASE(0)
+
+        float result = quiet_nan<float>();
+        // ---- pass 1: float64 sum of x = w - baseline over the chunk
+        double X = 0.0;
+        {
+            // software pipelined: the next group's loads are issued before the current group's arithmetic; the loads past the last
+            // group read the (always present) slot tail and are ignored
+            f2v va[4], vb[4];
+            auto ld = [&](f2v (&v)[4], int t) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) v[m] = *reinterpret_cast<const f2v*>(mine + t + 2 * m);
+            };
+            auto sum = [&](const f2v (&v)[4]) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    X += (double)(v[m][0] - bl);
+                    X += (double)(v[m][1] - bl);
+                }
+            };
+            ld(va, 0);
+#pragma unroll 1
+            for (int t = 0; t < C - 2; t += 2 * G8) {
+                ld(vb, t + G8);
+                sum(va);
+                ld(va, t + 2 * G8);
+                sum(vb);
+            }
+            // va now holds offsets C-2 .. C+5: its first pair is the chunk's tail pair
+            X += (double)(va[0][0] - bl);
+            X += (double)(va[0][1] - bl);
+        }
+        bool in_nan = A.tau_nan != 0;
+        if (wave_any(!(fabs(X) <= 1.7976931348623157e308))) {
+            bool n = false;
+            for (int t = 0; t < C; ++t) {
+                const float x = mine[t] - bl;
+                n |= (x != x);
+            }
+            in_nan |= wave_any(n);
+        }
+        PHASE(1)
+        if (!in_nan) {
+            const double E = wave_exscan_add(X);
+            // ---- pass 2: pole-zero recurrence, in place; float32 running sum of the output, captured at the plan's offsets
+            const double c = A.c;
+            const float xprev = (lane > 0) ? mine[-1] - bl : 0.0f;
+            double xp = (double)xprev, acc = E - c * (E - xp);
+            float run = 0.0f, capv2[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) capv2[i] = 0.0f;
+            auto pz1 = [&](float raw) -> float {
+                const double x = (double)(raw - bl);
+                acc = (acc + x) - xp * c;
+                const float y = (float)acc;
+                xp = x;
+                run += y;
+                return y;
+            };
+            {
+                f2v va[4], vb[4];
+                auto ld = [&](f2v (&v)[4], int t) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) v[m] = *reinterpret_cast<const f2v*>(mine + t + 2 * m);
+                };
+                auto body = [&](const f2v (&v)[4], int t) {
+                    f2v w[4];
+                    float rs[G8];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        w[m][0] = pz1(v[m][0]);
+                        rs[2 * m] = run;
+                        w[m][1] = pz1(v[m][1]);
+                        rs[2 * m + 1] = run;
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) *reinterpret_cast<f2v*>(mine + t + 2 * m) = w[m];
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) {
+                        const int d = cap_r[i] - t;  // capture after d samples of this group (1..8)
+                        if (d >= 1 && d <= G8) {
+#pragma unroll
+                            for (int u = 0; u < G8; ++u)
+                                if (d == u + 1) capv2[i] = rs[u];
+                        }
+                    }
+                };
+                ld(va, 0);
+#pragma unroll 1
+                for (int t = 0; t < C - 2; t += 2 * G8) {
+                    ld(vb, t + G8);
+                    body(va, t);
+                    ld(va, t + 2 * G8);
+                    body(vb, t + G8);
+                }
+                // tail pair (offsets C-2, C-1) = first pair of va
+                f2v w;
+                w[0] = pz1(va[0][0]);
+                const float run_mid = run;
+                w[1] = pz1(va[0][1]);
+                *reinterpret_cast<f2v*>(mine + C - 2) = w;
+#pragma unroll
+                for (int i = 0; i < 7; ++i)
+                    if (cap_r[i] == C - 1) capv2[i] = run_mid;
+            }
+            wave_sync();
+            PHASE(2)
+            bool pz_nan = false;
+            if (wave_any(!(fabsf(run) <= 3.4028234663852886e38f))) {
+                bool n = false;
+                for (int t = 0; t < C; ++t) {
+                    const float y = mine[t];
+                    n |= (y != y);
+                }
+                pz_nan = wave_any(n);
+            }
+            if (pz_nan) {
+                report(DSP_E_PZ_NAN, row);
+            } else if (!A.all_nan && !(A.ablate & 4) && pickoff_in_range(t_in, len)) {
+                // ---- speculative carries of the two sub-chains
+                const double Ep = wave_exscan_add((double)run);
+                float g[2], y[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    double Ak[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) Ak[k] = wave_shift_up(Ep + (double)capv2[2 * k + s], PL.shift[k][s]);
+                    const double own = Ep + (s ? (double)capv2[6] : 0.0);
+                    double Gd;
+                    if (KIND == TRAP_FILTER)
+                        Gd = ((own - Ak[0]) - Ak[1]) + Ak[2];
+                    else if (KIND == TRAP_NORM)
+                        Gd = (((own - Ak[0]) - Ak[1]) + Ak[2]) / A.rr;
+                    else
+                        Gd = (own - Ak[0]) / A.rr - (Ak[1] - Ak[2]) / A.ll;
+                    g[s] = (lane == 0 && s == 0) ? -0.0f : (float)Gd;
+                    y[s] = g[s];
+                }
+                // ---- wanted samples (uniform)
+                const int i0 = (int)t_in;
+                const bool wide = (A.mode == 'h');
+                int cl[4], cch[4], cloc[4];  // owning lane, sub-chain, sample within the sub-chain (>= CS: its two tail steps)
+                float capv[4];
+                unsigned capmask = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = i0 - 1 + k;
+                    const bool need = ((k == 1) || (k == 2) || wide) && e >= 0 && e < len;
+                    const int l = need ? e / C : -1;
+                    const int off = need ? e - l * C : 0;
+                    const int ch = off >= CS ? 1 : 0;
+                    cl[k] = l;
+                    cch[k] = ch;
+                    cloc[k] = need ? off - ch * CS : -1000;
+                    capv[k] = 0.0f;
+                    if (need && cloc[k] < CS) capmask |= 1u << (cloc[k] >> 2);
+                }
+                PHASE(3)
+                // ---- pass 3: two interleaved replays, groups of 4 samples per sub-chain, all loads 64-bit
+                {
+                    struct Grp {
+                        f2v own[2][2], r0[2][3], r1[2][3], r2[2][3];
+                    };
+                    Grp ga, gb;
+                    auto ld = [&](Grp& q, int t) {
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const int off = s * CS + t;
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) q.own[s][m] = *reinterpret_cast<const f2v*>(mine + off + 2 * m);
+#pragma unroll
+                            for (int m = 0; m < 3; ++m) {
+                                q.r0[s][m] = *reinterpret_cast<const f2v*>(lagb[0] + off + 2 * m);
+                                q.r1[s][m] = *reinterpret_cast<const f2v*>(lagb[1] + off + 2 * m);
+                                q.r2[s][m] = *reinterpret_cast<const f2v*>(lagb[2] + off + 2 * m);
+                            }
+                        }
+                    };
+                    auto body = [&](const Grp& q, int t) {
+                        float ys[2][4];
+                        switch (parmask) {
+                            case 0: replay4<KIND, 0, 0, 0>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
+                            case 1: replay4<KIND, 1, 0, 0>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
+                            case 2: replay4<KIND, 0, 1, 0>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
+                            case 3: replay4<KIND, 1, 1, 0>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
+                            case 4: replay4<KIND, 0, 0, 1>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
+                            case 5: replay4<KIND, 1, 0, 1>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
+                            case 6: replay4<KIND, 0, 1, 1>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
+                            default: replay4<KIND, 1, 1, 1>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
+                        }
+                        if ((capmask >> (t >> 2)) & 1u) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const int d = cloc[k] - t;
+#pragma unroll
+                                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u)
+                                        if (cch[k] == s && d == u) capv[k] = ys[s][u];
+                            }
+                        }
+                    };
+                    ld(ga, 0);
+#pragma unroll 1
+                    for (int t = 0; t < CS; t += 8) {
+                        ld(gb, t + 4);
+                        body(ga, t);
+                        ld(ga, t + 8);  // past the last group: reads the next sub-chain / slot tail, ignored
+                        body(gb, t + 4);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {  // the two tail samples continue sub-chain 1
+                    const int tt = 2 * CS + e;
+                    y[1] = trap_step<float, KIND>(y[1], mine[tt], lagb[0][tt + par[0]], lagb[1][tt + par[1]], lagb[2][tt + par[2]], A.rr, A.ll);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (cch[k] == 1 && cloc[k] == CS + e) capv[k] = y[1];
+                }
+                PHASE(4)
+                // ---- true carries: exact scan of the increments
+                const double D0 = (double)y[0] - (double)g[0], D1 = (double)y[1] - (double)g[1];
+                const double T0 = wave_exscan_add(D0 + D1);
+                float w4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double delta = cch[k] ? (T0 + D0) - (double)g[1] : T0 - (double)g[0];
+                    const float v = (float)((double)capv[k] + delta);
+                    w4[k] = cl[k] >= 0 ? readlane(v, cl[k]) : 0.0f;
+                }
+                int fc = 0;
+                result = pickoff_eval(t_in, A.mode, len, w4, fc);
+                if (fc) report(fc, row);
+            }
+        }
+        if (lane == 0) A.out[row * A.out_stride] = result;
+        wave_sync();
+        PHASE(5)
+    }
+    if (stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(err + 4) + i, tsum[i]);
+    }
+}
+
+template <int KIND>
+int launch_v3_kind(const EnergyArgs& A, const EnergyPlan3& PL, int npf, int64_t n_wf, int* err, int blocks, int threads, int lds_bytes,
+                   hipStream_t st) {
+    switch (npf) {
+        case 4: hipLaunchKernelGGL((dsp_energy_v3_kernel<4, KIND>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 8: hipLaunchKernelGGL((dsp_energy_v3_kernel<8, KIND>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 16: hipLaunchKernelGGL((dsp_energy_v3_kernel<16, KIND>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+    return (int)hipGetLastError();
+}
+
 template <int KIND>
 int launch_kind(const EnergyArgs& A, int npf, int64_t n_wf, int* err, int blocks, int threads, int lds_bytes, hipStream_t s) {
     switch (npf) {
@@ -705,6 +1070,14 @@ extern "C" int dsp_internal_launch_energy_ilp(const EnergyArgs* A, const EnergyP
     GO_(TRAP_ASYM)
 #undef GO_
 }
+
+extern "C" int dsp_internal_launch_energy_v3(const EnergyArgs* A, const EnergyPlan3* PL, int trap_opcode, int npf, int64_t n_wf, int* err,
+                                             int blocks, int threads, int lds_bytes, hipStream_t stream) {
+    if (trap_opcode == DSP_OP_TRAP_FILTER) return launch_v3_kind<TRAP_FILTER>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
+    if (trap_opcode == DSP_OP_TRAP_NORM) return launch_v3_kind<TRAP_NORM>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
+    return launch_v3_kind<TRAP_ASYM>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
+}
+extern "C" const char* dsp_internal_energy_v3_kernel_name() { return "dsp_energy_v3_kernel"; }
 
 extern "C" const char* dsp_internal_energy_kernel_name() { return "dsp_energy_kernel"; }
 extern "C" const char* dsp_internal_energy_ilp_kernel_name() { return "dsp_energy_ilp_kernel"; }

@@ -71,6 +71,13 @@ struct EnergyPlan {
 extern "C" int dsp_internal_launch_energy_ilp(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int64_t n_wf,
                                               int* err, int blocks, int threads, int lds_bytes, hipStream_t stream);
 extern "C" const char* dsp_internal_energy_ilp_kernel_name();
+struct EnergyPlan3 {
+    int32_t shift[3][2];
+    int32_t r[3][2];
+};
+extern "C" int dsp_internal_launch_energy_v3(const EnergyArgs* A, const EnergyPlan3* PL, int trap_opcode, int npf, int64_t n_wf, int* err,
+                                             int blocks, int threads, int lds_bytes, hipStream_t stream);
+extern "C" const char* dsp_internal_energy_v3_kernel_name();
 
 namespace {
 
@@ -127,6 +134,10 @@ struct dsp_chain {
     EnergyArgs ilp{};
     EnergyPlan plan[2]{};  // [0]: S=2, [1]: S=4
     int ilp_lds_bytes = 0;
+    // v3: even lane stride, 64-bit LDS accesses, two sub-chains in the replay only (variant 3)
+    EnergyArgs v3{};
+    EnergyPlan3 plan3{};
+    int v3_lds_bytes = 0;
     int io_wf = -1, io_bl = -1, io_tp = -1, io_out = -1;
 };
 
@@ -616,6 +627,29 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                             ch->plan[v].local[k][sidx] = r - cs * CS;
                         }
                 }
+                {
+                    EnergyArgs& V = ch->v3;
+                    V = F;
+                    const int Cv = slot_len[0] / 64 + 2, CSv = (Cv - 2) / 2;
+                    V.C = Cv;
+                    V.pitch = Cv;
+                    const int guard3 = 2 * Cv + 16;  // multiple of 4 for Cv = 18, 34, 66
+                    V.slot_off = guard3;
+                    int el = guard3 + 64 * Cv + 16;
+                    el = ((el + 3) / 4) * 4;
+                    V.lds_elems_per_wave = el;
+                    ch->v3_lds_bytes = el * 4;
+                    for (int k = 0; k < 3; ++k) {
+                        V.q[k] = dtp.ic[k];
+                        V.rho[k] = 0;
+                        for (int sidx = 0; sidx < 2; ++sidx) {
+                            const int pos = sidx * CSv - dtp.ic[k];
+                            const int r = ((pos % Cv) + Cv) % Cv;
+                            ch->plan3.r[k][sidx] = r;
+                            ch->plan3.shift[k][sidx] = (r - pos) / Cv;
+                        }
+                    }
+                }
                 ch->ilp_ok = true;
                 if (const char* venv = getenv("DSPEED_HIP_VARIANT")) ch->variant = atoi(venv);
             }
@@ -702,6 +736,24 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         (void)F;
         return fail(DSP_ERR_UNSUPPORTED, "pair kernel not built");
     }
+    if (ch->ilp_ok && ch->fused_on && ch->variant == 3 && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
+        EnergyArgs F = ch->v3;
+        F.wf = io_ptrs[ch->io_wf];
+        F.bl = ch->io_bl >= 0 ? (const float*)io_ptrs[ch->io_bl] : nullptr;
+        F.tp = ch->io_tp >= 0 ? (const float*)io_ptrs[ch->io_tp] : nullptr;
+        F.out = (float*)io_ptrs[ch->io_out];
+        int wpb = LDS_BYTES_PER_CU / ch->v3_lds_bytes;
+        if (wpb > 4) wpb = 4;
+        int per_cu = LDS_BYTES_PER_CU / (ch->v3_lds_bytes * wpb);
+        if (per_cu * wpb > 8) per_cu = 8 / wpb;
+        if (per_cu < 1) per_cu = 1;
+        int64_t want = (n_wf + wpb - 1) / wpb, cap = (int64_t)ch->num_cu * per_cu;
+        const int vblocks = (int)(want < cap ? want : cap);
+        hipError_t e = (hipError_t)dsp_internal_launch_energy_v3(&F, &ch->plan3, ch->fused_trap, ch->fused_npf, n_wf, ch->dev_err, vblocks,
+                                                                 64 * wpb, ch->v3_lds_bytes * wpb, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy v3 kernel launch failed: %s", hipGetErrorString(e));
+        return DSP_OK;
+    }
     if (ch->ilp_ok && ch->fused_on && ch->variant != 1 && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
         EnergyArgs F = ch->ilp;
         F.wf = io_ptrs[ch->io_wf];
@@ -781,6 +833,7 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
 
 const char* dsp_chain_kernel_name(dsp_chain* ch) {
     if (ch && ch->pair_ok && ch->pair_on && ch->fused_on) return dsp_internal_energy_pair_kernel_name();
+    if (ch && ch->ilp_ok && ch->fused_on && ch->variant == 3) return dsp_internal_energy_v3_kernel_name();
     if (ch && ch->ilp_ok && ch->fused_on && ch->variant != 1) return dsp_internal_energy_ilp_kernel_name();
     return (ch && ch->fused_ok && ch->fused_on) ? dsp_internal_energy_kernel_name() : dsp_internal_vm_kernel_name();
 }
@@ -789,7 +842,7 @@ int dsp_chain_set_fused(dsp_chain* ch, int enable) {
     if (!ch) return fail(DSP_ERR_ARG, "null chain");
     ch->fused_on = (enable & 1) != 0;   // bit 0: use a specialised kernel
     ch->variant = (enable >> 1) & 3;    // bits 1-2: 0 = one chain per lane (default), 1 = 2 sub-chains per lane, 2 = 4 sub-chains
-    ch->variant = ch->variant == 0 ? 1 : (ch->variant == 1 ? 0 : 2);
+    ch->variant = ch->variant == 0 ? 1 : (ch->variant == 1 ? 0 : ch->variant);  // 2 -> 4 sub-chains, 3 -> v3
     return ((ch->fused_ok || ch->ilp_ok) && ch->fused_on) ? 1 : 0;
 }
 
