@@ -66,9 +66,10 @@ class Program:
 class Chain:
     """A compiled chain bound to the current device."""
 
-    def __init__(self, program: Program, name: str = "chain"):
+    def __init__(self, program: Program, name: str = "chain", compute_dtype=np.float32):
         self.program = program
         self.name = name
+        self.compute_dtype = np.dtype(compute_dtype)
         L = _lib.lib()
         n_ops, n_io = len(program.ops), len(program.io)
         ops = (_lib.Op * max(n_ops, 1))()
@@ -85,7 +86,7 @@ class Chain:
             d.kind, d.dtype, d.len, d.offset, d.row_stride = kind, code, length, offset, stride
         slots = (C.c_int32 * max(len(program.slots), 1))(*program.slots)
         handle = C.c_void_p()
-        rc = L.dsp_chain_create(ops, n_ops, ios, n_io, slots, len(program.slots), program.n_sregs, _lib.F32, C.byref(handle))
+        rc = L.dsp_chain_create(ops, n_ops, ios, n_io, slots, len(program.slots), program.n_sregs, dtype_code(self.compute_dtype), C.byref(handle))
         _lib.check(rc, what=name)
         self._h = handle
         self.io_names = [io[0] for io in program.io]

@@ -25,6 +25,8 @@
 
 extern "C" int dsp_internal_launch_vm_f32(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int* err, int blocks,
                                           int threads, int lds_bytes, hipStream_t stream);
+extern "C" int dsp_internal_launch_vm_f64(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int* err, int blocks,
+                                          int threads, int lds_bytes, hipStream_t stream);
 extern "C" int dsp_internal_set_vm_lds(int lds_bytes);
 extern "C" const char* dsp_internal_vm_kernel_name();
 extern "C" int dsp_internal_launch_synth(void* wf, int out_dtype, int64_t n_wf, int wf_len, int64_t row_stride, float* baseline,
@@ -120,6 +122,7 @@ struct dsp_chain {
     int lds_bytes_per_wave = 0;
     int waves_per_block = 0;
     int num_cu = 256;
+    bool f64 = false;  // the float64 gufunc loop (LDS elements are 8 bytes)
     // specialised energy-chain kernel (dsp_energy.hip), selected when the program has exactly that shape
     bool fused_ok = false, fused_on = true;
     EnergyArgs fused{};
@@ -321,8 +324,9 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     if (n_io < 0 || n_io > DSP_MAX_IO) return fail(DSP_ERR_ARG, "n_io=%d out of range", n_io);
     if (n_slots < 0 || n_slots > DSP_MAX_SLOTS) return fail(DSP_ERR_ARG, "n_slots=%d out of range", n_slots);
     if (n_sregs < 0 || n_sregs > DSP_MAX_SREGS) return fail(DSP_ERR_ARG, "n_sregs=%d out of range", n_sregs);
-    if (compute_dtype != DSP_F32) return fail(DSP_ERR_UNSUPPORTED, "only the float32 loop is implemented on the device");
-    const int esz = 4;
+    if (compute_dtype != DSP_F32 && compute_dtype != DSP_F64) return fail(DSP_ERR_ARG, "compute_dtype must be DSP_F32 or DSP_F64");
+    const int esz = compute_dtype == DSP_F64 ? 8 : 4;
+    const bool f64 = compute_dtype == DSP_F64;
 
     std::unique_ptr<dsp_chain> ch(new dsp_chain());
     DevProgram& P = ch->host;
@@ -330,6 +334,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     P.n_slots = n_slots;
     P.n_io = n_io;
     P.n_sregs = n_sregs;
+    ch->f64 = f64;
 
     // ---- LDS layout: [guard 2*pitch][slot 64*pitch][tail 8] per slot, then the scalar registers
     int cursor = 0;
@@ -371,8 +376,9 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         if (!es) return fail(DSP_ERR_ARG, "io %d: unknown dtype %d", k, a.dtype);
         if (a.kind < DSP_IO_WF_IN || a.kind > DSP_IO_TAPS) return fail(DSP_ERR_ARG, "io %d: unknown kind %d", k, a.kind);
         if (a.len <= 0 || a.offset < 0) return fail(DSP_ERR_ARG, "io %d: bad len/offset", k);
-        if ((a.kind == DSP_IO_WF_IN) && (a.dtype == DSP_I32 || a.dtype == DSP_U32 || a.dtype == DSP_F64))
-            return fail(DSP_ERR_UNSUPPORTED, "io %d: int32/uint32/float64 rows select the reference's float64 loop, which is not on the device yet", k);
+        // which rows may feed which loop: NumPy's can_cast rule as ProcessorManager applies it (processing_chain.py:1565-1572)
+        if (a.kind == DSP_IO_WF_IN && !f64 && (a.dtype == DSP_I32 || a.dtype == DSP_U32 || a.dtype == DSP_F64))
+            return fail(DSP_ERR_ARG, "io %d: int32/uint32/float64 rows select the float64 loop (compute_dtype DSP_F64)", k);
         if ((a.kind == DSP_IO_WF_OUT || a.kind == DSP_IO_SCALAR_OUT || a.kind == DSP_IO_TAPS) && a.dtype != compute_dtype)
             return fail(DSP_ERR_ARG, "io %d: outputs and taps must have the chain's compute type", k);
         d.kind = a.kind;
@@ -402,7 +408,8 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             if (a.kind < DSP_ARG_CONST || a.kind > DSP_ARG_REG) return fail(DSP_ERR_ARG, "op %d: bad scalar operand kind", i);
         }
         auto need_io = [&](int kind) { return o.io >= 0 && o.io < n_io && io[o.io].kind == kind; };
-        auto cst = [&](int k) { return (double)(float)o.sp[k].value; };  // the float32 loop receives float32 scalars
+        // the float32 loop receives float32 scalars, the float64 loop float64 ones
+        auto cst = [&](int k) { return f64 ? o.sp[k].value : (double)(float)o.sp[k].value; };
         switch (o.opcode) {
             case DSP_OP_LOAD:
                 if (!check_slot(P, o.dst) || !need_io(DSP_IO_WF_IN)) return fail(DSP_ERR_ARG, "op %d: bad LOAD", i);
@@ -544,7 +551,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         const dsp_op* pz = (ld && n_ops > i && ops[i].opcode == DSP_OP_POLE_ZERO) ? &ops[i++] : nullptr;
         const dsp_op* tp = (pz && n_ops > i && ops[i].opcode == DSP_OP_TRAP_PICKOFF) ? &ops[i++] : nullptr;
         const dsp_op* st = (tp && n_ops > i && ops[i].opcode == DSP_OP_STORE_SCALAR) ? &ops[i++] : nullptr;
-        const bool shape = st && i == n_ops && n_slots == 1 && io[ld->io].dtype == DSP_F32 && P.io[ld->io].vec_ok &&
+        const bool shape = !f64 && st && i == n_ops && n_slots == 1 && io[ld->io].dtype == DSP_F32 && P.io[ld->io].vec_ok &&
                            (!bs || (bs->dst == 0 && bs->src == 0 && bs->sp[0].kind != DSP_ARG_REG)) && pz->dst == 0 && pz->src == 0 &&
                            tp->src == 0 && tp->sp[0].kind != DSP_ARG_REG && st->ip[0] == tp->dst &&
                            (slot_len[0] == 1024 || slot_len[0] == 2048 || slot_len[0] == 4096 || slot_len[0] == 8192);
@@ -784,7 +791,8 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy kernel launch failed: %s", hipGetErrorString(e));
         return DSP_OK;
     }
-    hipError_t e = (hipError_t)dsp_internal_launch_vm_f32(ch->dev, &ptrs, n_wf, ch->dev_err, blocks, threads, lds, (hipStream_t)stream);
+    hipError_t e = ch->f64 ? (hipError_t)dsp_internal_launch_vm_f64(ch->dev, &ptrs, n_wf, ch->dev_err, blocks, threads, lds, (hipStream_t)stream)
+                           : (hipError_t)dsp_internal_launch_vm_f32(ch->dev, &ptrs, n_wf, ch->dev_err, blocks, threads, lds, (hipStream_t)stream);
     if (e != hipSuccess) return fail(DSP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return DSP_OK;
 }
@@ -847,6 +855,8 @@ int dsp_chain_set_fused(dsp_chain* ch, int enable) {
 }
 
 // ------------------------------------------------------------------------------------------------ single processors
+// One implementation per processor, generic in the loop type TY (DSP_F32 / DSP_F64); the exported dsp_<name>_f32 / _f64
+// functions below only fix the scalar C types.
 namespace {
 
 struct MiniKey {
@@ -856,19 +866,22 @@ struct MiniKey {
 std::map<MiniKey, dsp_chain*> g_cache;
 std::mutex g_cache_mu;
 
-int64_t fbits(float f) {
-    int32_t i;
-    memcpy(&i, &f, 4);
+int64_t dbits(double f) {
+    int64_t i;
+    memcpy(&i, &f, 8);
     return i;
 }
 
 struct Mini {
+    int ty;  // DSP_F32 or DSP_F64: the gufunc loop
     std::vector<dsp_op> ops;
     std::vector<dsp_io_desc> io;
     std::vector<void*> ptrs;
     std::vector<int32_t> slots;
     int n_sregs = 0;
     MiniKey key;
+
+    explicit Mini(int ty_) : ty(ty_) { key.v.push_back(ty_); }
 
     int add_io(int kind, int dtype, int len, int64_t stride, const void* p) {
         dsp_io_desc d{kind, dtype, len, 0, stride};
@@ -893,14 +906,14 @@ struct Mini {
         key.v.insert(key.v.end(), {opcode, dst, src, io_idx});
         return ops.back();
     }
-    // scalar gufunc argument: device column if given, else broadcast constant
-    dsp_scalar_arg scalar(const float* dev, float value) {
-        dsp_scalar_arg a{DSP_ARG_CONST, 0, (double)value};
+    // scalar gufunc argument: device column (of the loop type) if given, else broadcast constant
+    dsp_scalar_arg scalar(const void* dev, double value) {
+        dsp_scalar_arg a{DSP_ARG_CONST, 0, value};
         if (dev) {
             a.kind = DSP_ARG_INPUT;
-            a.index = add_io(DSP_IO_SCALAR_IN, DSP_F32, 1, 1, dev);
+            a.index = add_io(DSP_IO_SCALAR_IN, ty, 1, 1, dev);
         } else {
-            key.v.push_back(fbits(value));
+            key.v.push_back(dbits(value));
         }
         return a;
     }
@@ -919,8 +932,8 @@ struct Mini {
             if (it != g_cache.end()) ch = it->second;
         }
         if (!ch) {
-            int rc = dsp_chain_create(ops.data(), (int)ops.size(), io.data(), (int)io.size(), slots.data(), (int)slots.size(), n_sregs,
-                                      DSP_F32, &ch);
+            int rc = dsp_chain_create(ops.data(), (int)ops.size(), io.data(), (int)io.size(), slots.data(), (int)slots.size(), n_sregs, ty,
+                                      &ch);
             if (rc) return rc;
             std::lock_guard<std::mutex> lk(g_cache_mu);
             if (g_cache.size() > 256) {
@@ -935,151 +948,183 @@ struct Mini {
     }
 };
 
+struct WfIn {
+    const void* ptr;
+    int dtype;
+    int64_t n_wf;
+    int32_t len;
+    int64_t stride;
+};
+
 // waveform -> waveform processors
-int wf2wf(int opcode, const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float* out, int32_t out_len,
-          int64_t out_stride, const int32_t* ip, int n_ip, const dsp_scalar_arg* sp, int n_sp, Mini& m, void* stream, int64_t* err_row) {
-    if (n_wf <= 0) return DSP_OK;
-    const int s_in = m.add_slot(wf_len), s_out = m.add_slot(out_len);
-    const int io_in = m.add_io(DSP_IO_WF_IN, in_dtype, wf_len, in_stride, in);
+int wf2wf(int ty, int opcode, const WfIn& in, void* out, int32_t out_len, int64_t out_stride, const int32_t* ip, int n_ip,
+          const double* consts, int n_c, const void* col0, void* stream, int64_t* err_row) {
+    if (in.n_wf <= 0) return DSP_OK;
+    Mini m(ty);
+    const int s_in = m.add_slot(in.len), s_out = m.add_slot(out_len);
+    const int io_in = m.add_io(DSP_IO_WF_IN, in.dtype, in.len, in.stride, in.ptr);
     m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
+    dsp_scalar_arg sp[3];
+    memset(sp, 0, sizeof sp);
+    for (int k = 0; k < n_c; ++k) sp[k] = m.scalar(k == 0 ? col0 : nullptr, consts[k]);
     dsp_op& o = m.add_op(opcode, s_out, s_in, 0);
     for (int k = 0; k < n_ip; ++k) o.ip[k] = ip[k];
-    for (int k = 0; k < n_sp; ++k) o.sp[k] = sp[k];
-    const int io_out = m.add_io(DSP_IO_WF_OUT, DSP_F32, out_len, out_stride, out);
+    for (int k = 0; k < n_c; ++k) o.sp[k] = sp[k];
+    const int io_out = m.add_io(DSP_IO_WF_OUT, ty, out_len, out_stride, out);
     m.add_op(DSP_OP_STORE, 0, s_out, io_out);
-    return m.run(n_wf, stream, err_row);
+    return m.run(in.n_wf, stream, err_row);
 }
 
-}  // namespace
-
-int dsp_bl_subtract_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* baseline_dev,
-                        float baseline, float* out, int64_t out_stride, void* stream, int64_t* err_row) {
-    Mini m;
-    dsp_scalar_arg sp[1] = {m.scalar(baseline_dev, baseline)};
-    return wf2wf(DSP_OP_BL_SUBTRACT, in, in_dtype, n_wf, wf_len, in_stride, out, wf_len, out_stride, nullptr, 0, sp, 1, m, stream, err_row);
+int g_bl_subtract(int ty, const WfIn& in, const void* bl_dev, double bl, void* out, int64_t out_stride, void* st, int64_t* er) {
+    const double c[1] = {bl};
+    return wf2wf(ty, DSP_OP_BL_SUBTRACT, in, out, in.len, out_stride, nullptr, 0, c, 1, bl_dev, st, er);
 }
-
-int dsp_pole_zero_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float tau, float* out,
-                      int64_t out_stride, void* stream, int64_t* err_row) {
-    Mini m;
-    dsp_scalar_arg sp[1] = {m.scalar(nullptr, tau)};
-    return wf2wf(DSP_OP_POLE_ZERO, in, in_dtype, n_wf, wf_len, in_stride, out, wf_len, out_stride, nullptr, 0, sp, 1, m, stream, err_row);
+int g_pole_zero(int ty, const WfIn& in, double tau, void* out, int64_t out_stride, void* st, int64_t* er) {
+    const double c[1] = {tau};
+    return wf2wf(ty, DSP_OP_POLE_ZERO, in, out, in.len, out_stride, nullptr, 0, c, 1, nullptr, st, er);
 }
-
-int dsp_double_pole_zero_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float tau1, float tau2,
-                             float frac, float* out, int64_t out_stride, void* stream, int64_t* err_row) {
-    Mini m;
-    dsp_scalar_arg sp[3] = {m.scalar(nullptr, tau1), m.scalar(nullptr, tau2), m.scalar(nullptr, frac)};
-    return wf2wf(DSP_OP_DOUBLE_POLE_ZERO, in, in_dtype, n_wf, wf_len, in_stride, out, wf_len, out_stride, nullptr, 0, sp, 3, m, stream,
-                 err_row);
+int g_double_pole_zero(int ty, const WfIn& in, double tau1, double tau2, double frac, void* out, int64_t out_stride, void* st, int64_t* er) {
+    const double c[3] = {tau1, tau2, frac};
+    return wf2wf(ty, DSP_OP_DOUBLE_POLE_ZERO, in, out, in.len, out_stride, nullptr, 0, c, 3, nullptr, st, er);
 }
-
-int dsp_trap_filter_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,
-                        float* out, int64_t out_stride, void* stream, int64_t* err_row) {
-    Mini m;
-    int32_t ip[2] = {rise, flat};
-    return wf2wf(DSP_OP_TRAP_FILTER, in, in_dtype, n_wf, wf_len, in_stride, out, wf_len, out_stride, ip, 2, nullptr, 0, m, stream, err_row);
+int g_trap(int ty, int opcode, const WfIn& in, int32_t rise, int32_t flat, int32_t fall, void* out, int64_t out_stride, void* st, int64_t* er) {
+    const int32_t ip[3] = {rise, flat, fall};
+    return wf2wf(ty, opcode, in, out, in.len, out_stride, ip, 3, nullptr, 0, nullptr, st, er);
 }
-
-int dsp_trap_norm_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,
-                      float* out, int64_t out_stride, void* stream, int64_t* err_row) {
-    Mini m;
-    int32_t ip[2] = {rise, flat};
-    return wf2wf(DSP_OP_TRAP_NORM, in, in_dtype, n_wf, wf_len, in_stride, out, wf_len, out_stride, ip, 2, nullptr, 0, m, stream, err_row);
+int g_dwt(int ty, const WfIn& in, int32_t level, int32_t coeff, void* out, int32_t out_len, int64_t out_stride, void* st, int64_t* er) {
+    const int32_t ip[3] = {level, coeff, 0};  // scratch = the input slot itself (dead after the transform)
+    return wf2wf(ty, DSP_OP_DWT_HAAR, in, out, out_len, out_stride, ip, 3, nullptr, 0, nullptr, st, er);
 }
-
-int dsp_asym_trap_filter_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise,
-                             int32_t flat, int32_t fall, float* out, int64_t out_stride, void* stream, int64_t* err_row) {
-    Mini m;
-    int32_t ip[3] = {rise, flat, fall};
-    return wf2wf(DSP_OP_ASYM_TRAP, in, in_dtype, n_wf, wf_len, in_stride, out, wf_len, out_stride, ip, 3, nullptr, 0, m, stream, err_row);
-}
-
-int dsp_dwt_haar_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t level, int32_t coeff_char,
-                     float* out, int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row) {
-    Mini m;
-    int32_t ip[3] = {level, coeff_char, 0};  // scratch = the input slot itself (dead after the transform)
-    return wf2wf(DSP_OP_DWT_HAAR, in, in_dtype, n_wf, wf_len, in_stride, out, out_len, out_stride, ip, 3, nullptr, 0, m, stream, err_row);
-}
-
-int dsp_convolve_wf_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* kernel_dev,
-                        int32_t kernel_len, int32_t mode_char, float* out, int32_t out_len, int64_t out_stride, void* stream,
-                        int64_t* err_row) {
-    if (n_wf <= 0) return DSP_OK;
+int g_convolve(int ty, const WfIn& in, const void* kernel_dev, int32_t kernel_len, int32_t mode, void* out, int32_t out_len, int64_t out_stride,
+               void* st, int64_t* er) {
+    if (in.n_wf <= 0) return DSP_OK;
     if (kernel_len <= 0) return fail(DSP_ERR_ARG, "empty kernel");
     // NaN among the taps -> NaN output (convolutions.py:45-46): look at them once on the host
-    std::vector<float> taps((size_t)kernel_len);
-    HIP_TRY(hipMemcpy(taps.data(), kernel_dev, sizeof(float) * (size_t)kernel_len, hipMemcpyDeviceToHost));
+    const size_t esz = ty == DSP_F64 ? 8 : 4;
+    std::vector<unsigned char> taps(esz * (size_t)kernel_len);
+    HIP_TRY(hipMemcpy(taps.data(), kernel_dev, taps.size(), hipMemcpyDeviceToHost));
     int has_nan = 0;
-    for (float t : taps) has_nan |= std::isnan(t) ? 1 : 0;
-    Mini m;
-    const int s_in = m.add_slot(wf_len), s_out = m.add_slot(out_len > 0 ? out_len : 1);
-    const int io_in = m.add_io(DSP_IO_WF_IN, in_dtype, wf_len, in_stride, in);
-    const int io_k = m.add_io(DSP_IO_TAPS, DSP_F32, kernel_len, 0, kernel_dev);
+    for (int k = 0; k < kernel_len; ++k)
+        has_nan |= (ty == DSP_F64 ? std::isnan(((const double*)taps.data())[k]) : std::isnan(((const float*)taps.data())[k])) ? 1 : 0;
+    Mini m(ty);
+    const int s_in = m.add_slot(in.len), s_out = m.add_slot(out_len > 0 ? out_len : 1);
+    const int io_in = m.add_io(DSP_IO_WF_IN, in.dtype, in.len, in.stride, in.ptr);
+    const int io_k = m.add_io(DSP_IO_TAPS, ty, kernel_len, 0, kernel_dev);
     m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
     dsp_op& o = m.add_op(DSP_OP_CONVOLVE, s_out, s_in, io_k);
-    o.ip[0] = mode_char;
+    o.ip[0] = mode;
     o.ip[1] = has_nan;
-    const int io_out = m.add_io(DSP_IO_WF_OUT, DSP_F32, out_len > 0 ? out_len : 1, out_stride, out);
+    const int io_out = m.add_io(DSP_IO_WF_OUT, ty, out_len > 0 ? out_len : 1, out_stride, out);
     m.add_op(DSP_OP_STORE, 0, s_out, io_out);
-    return m.run(n_wf, stream, err_row);
+    return m.run(in.n_wf, st, er);
 }
-
-int dsp_fixed_time_pickoff_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* t_in_dev,
-                               float t_in, int32_t mode_char, float* out, void* stream, int64_t* err_row) {
-    if (n_wf <= 0) return DSP_OK;
-    Mini m;
+int g_pickoff(int ty, const WfIn& in, const void* t_dev, double t_in, int32_t mode, void* out, void* st, int64_t* er) {
+    if (in.n_wf <= 0) return DSP_OK;
+    Mini m(ty);
     m.n_sregs = 1;
-    const int s_in = m.add_slot(wf_len);
-    const int io_in = m.add_io(DSP_IO_WF_IN, in_dtype, wf_len, in_stride, in);
+    const int s_in = m.add_slot(in.len);
+    const int io_in = m.add_io(DSP_IO_WF_IN, in.dtype, in.len, in.stride, in.ptr);
     m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
-    dsp_scalar_arg t = m.scalar(t_in_dev, t_in);
+    dsp_scalar_arg t = m.scalar(t_dev, t_in);
     dsp_op& o = m.add_op(DSP_OP_PICKOFF, 0, s_in, 0);
-    o.ip[0] = mode_char;
+    o.ip[0] = mode;
     o.sp[0] = t;
-    const int io_out = m.add_io(DSP_IO_SCALAR_OUT, DSP_F32, 1, 1, out);
-    dsp_op& st = m.add_op(DSP_OP_STORE_SCALAR, 0, 0, io_out);
-    st.ip[0] = 0;
-    return m.run(n_wf, stream, err_row);
+    const int io_out = m.add_io(DSP_IO_SCALAR_OUT, ty, 1, 1, out);
+    dsp_op& sto = m.add_op(DSP_OP_STORE_SCALAR, 0, 0, io_out);
+    sto.ip[0] = 0;
+    return m.run(in.n_wf, st, er);
 }
-
-int dsp_time_point_thresh_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
-                              const float* threshold_dev, float threshold, const float* t_start_dev, float t_start,
-                              float walk_forward, float* out, void* stream, int64_t* err_row) {
-    if (n_wf <= 0) return DSP_OK;
-    Mini m;
+int g_tpt(int ty, const WfIn& in, const void* thr_dev, double thr, const void* ts_dev, double ts, double walk, void* out, void* st, int64_t* er) {
+    if (in.n_wf <= 0) return DSP_OK;
+    Mini m(ty);
     m.n_sregs = 1;
-    const int s_in = m.add_slot(wf_len);
-    const int io_in = m.add_io(DSP_IO_WF_IN, in_dtype, wf_len, in_stride, in);
+    const int s_in = m.add_slot(in.len);
+    const int io_in = m.add_io(DSP_IO_WF_IN, in.dtype, in.len, in.stride, in.ptr);
     m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
-    dsp_scalar_arg a = m.scalar(threshold_dev, threshold), b = m.scalar(t_start_dev, t_start), c = m.scalar(nullptr, walk_forward);
+    dsp_scalar_arg a = m.scalar(thr_dev, thr), b = m.scalar(ts_dev, ts), c = m.scalar(nullptr, walk);
     dsp_op& o = m.add_op(DSP_OP_TIME_POINT_THRESH, 0, s_in, 0);
     o.sp[0] = a;
     o.sp[1] = b;
     o.sp[2] = c;
-    const int io_out = m.add_io(DSP_IO_SCALAR_OUT, DSP_F32, 1, 1, out);
-    dsp_op& st = m.add_op(DSP_OP_STORE_SCALAR, 0, 0, io_out);
-    st.ip[0] = 0;
-    return m.run(n_wf, stream, err_row);
+    const int io_out = m.add_io(DSP_IO_SCALAR_OUT, ty, 1, 1, out);
+    dsp_op& sto = m.add_op(DSP_OP_STORE_SCALAR, 0, 0, io_out);
+    sto.ip[0] = 0;
+    return m.run(in.n_wf, st, er);
 }
-
-int dsp_min_max_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float* t_min, float* t_max,
-                    float* a_min, float* a_max, void* stream, int64_t* err_row) {
-    if (n_wf <= 0) return DSP_OK;
-    Mini m;
+int g_min_max(int ty, const WfIn& in, void* t_min, void* t_max, void* a_min, void* a_max, void* st, int64_t* er) {
+    if (in.n_wf <= 0) return DSP_OK;
+    Mini m(ty);
     m.n_sregs = 4;
-    const int s_in = m.add_slot(wf_len);
-    const int io_in = m.add_io(DSP_IO_WF_IN, in_dtype, wf_len, in_stride, in);
+    const int s_in = m.add_slot(in.len);
+    const int io_in = m.add_io(DSP_IO_WF_IN, in.dtype, in.len, in.stride, in.ptr);
     m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
     m.add_op(DSP_OP_MIN_MAX, 0, s_in, 0);
-    float* outs[4] = {t_min, t_max, a_min, a_max};
+    void* outs[4] = {t_min, t_max, a_min, a_max};
     for (int k = 0; k < 4; ++k) {
-        const int io_out = m.add_io(DSP_IO_SCALAR_OUT, DSP_F32, 1, 1, outs[k]);
-        dsp_op& st = m.add_op(DSP_OP_STORE_SCALAR, 0, 0, io_out);
-        st.ip[0] = k;
+        const int io_out = m.add_io(DSP_IO_SCALAR_OUT, ty, 1, 1, outs[k]);
+        dsp_op& sto = m.add_op(DSP_OP_STORE_SCALAR, 0, 0, io_out);
+        sto.ip[0] = k;
     }
-    return m.run(n_wf, stream, err_row);
+    return m.run(in.n_wf, st, er);
 }
+
+}  // namespace
+
+#define DSP_GUFUNCS(SFX, TY, FT)                                                                                                              \
+    int dsp_bl_subtract_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const FT* baseline_dev,          \
+                              FT baseline, FT* out, int64_t out_stride, void* stream, int64_t* err_row) {                                     \
+        return g_bl_subtract(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, baseline_dev, (double)baseline, out, out_stride, stream,        \
+                             err_row);                                                                                                        \
+    }                                                                                                                                         \
+    int dsp_pole_zero_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, FT tau, FT* out,                   \
+                            int64_t out_stride, void* stream, int64_t* err_row) {                                                             \
+        return g_pole_zero(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, (double)tau, out, out_stride, stream, err_row);                   \
+    }                                                                                                                                         \
+    int dsp_double_pole_zero_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, FT tau1, FT tau2, FT frac,  \
+                                   FT* out, int64_t out_stride, void* stream, int64_t* err_row) {                                             \
+        return g_double_pole_zero(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, (double)tau1, (double)tau2, (double)frac, out, out_stride, \
+                                  stream, err_row);                                                                                           \
+    }                                                                                                                                         \
+    int dsp_trap_filter_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,      \
+                              FT* out, int64_t out_stride, void* stream, int64_t* err_row) {                                                  \
+        return g_trap(TY, DSP_OP_TRAP_FILTER, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, rise, flat, 0, out, out_stride, stream, err_row);  \
+    }                                                                                                                                         \
+    int dsp_trap_norm_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,        \
+                            FT* out, int64_t out_stride, void* stream, int64_t* err_row) {                                                    \
+        return g_trap(TY, DSP_OP_TRAP_NORM, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, rise, flat, 0, out, out_stride, stream, err_row);    \
+    }                                                                                                                                         \
+    int dsp_asym_trap_filter_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat, \
+                                   int32_t fall, FT* out, int64_t out_stride, void* stream, int64_t* err_row) {                               \
+        return g_trap(TY, DSP_OP_ASYM_TRAP, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, rise, flat, fall, out, out_stride, stream, err_row); \
+    }                                                                                                                                         \
+    int dsp_fixed_time_pickoff_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const FT* t_in_dev,       \
+                                     FT t_in, int32_t mode_char, FT* out, void* stream, int64_t* err_row) {                                   \
+        return g_pickoff(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, t_in_dev, (double)t_in, mode_char, out, stream, err_row);           \
+    }                                                                                                                                         \
+    int dsp_time_point_thresh_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const FT* threshold_dev,   \
+                                    FT threshold, const FT* t_start_dev, FT t_start, FT walk_forward, FT* out, void* stream,                  \
+                                    int64_t* err_row) {                                                                                       \
+        return g_tpt(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, threshold_dev, (double)threshold, t_start_dev, (double)t_start,         \
+                     (double)walk_forward, out, stream, err_row);                                                                             \
+    }                                                                                                                                         \
+    int dsp_min_max_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, FT* t_min, FT* t_max, FT* a_min,     \
+                          FT* a_max, void* stream, int64_t* err_row) {                                                                        \
+        return g_min_max(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, t_min, t_max, a_min, a_max, stream, err_row);                       \
+    }                                                                                                                                         \
+    int dsp_dwt_haar_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t level, int32_t coeff_char,  \
+                           FT* out, int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row) {                                    \
+        return g_dwt(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, level, coeff_char, out, out_len, out_stride, stream, err_row);          \
+    }                                                                                                                                         \
+    int dsp_convolve_wf_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const FT* kernel_dev,            \
+                              int32_t kernel_len, int32_t mode_char, FT* out, int32_t out_len, int64_t out_stride, void* stream,              \
+                              int64_t* err_row) {                                                                                             \
+        return g_convolve(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, kernel_dev, kernel_len, mode_char, out, out_len, out_stride,       \
+                          stream, err_row);                                                                                                   \
+    }
+
+DSP_GUFUNCS(f32, DSP_F32, float)
+DSP_GUFUNCS(f64, DSP_F64, double)
+#undef DSP_GUFUNCS
 
 int dsp_synth_waveforms(void* wf, int out_dtype, int64_t n_wf, int32_t wf_len, int64_t row_stride, float* baseline, float* t_pick,
                         uint64_t seed, int64_t first_row, float tau, float sigma, float pick_offset, float bl_lo, float bl_hi,

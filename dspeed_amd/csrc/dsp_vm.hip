@@ -713,6 +713,9 @@ __device__ void op_copy(Ctx<T>& cx, const DevOp& op) {
 // 1e-6-of-peak bar; NumPy's own float32 summation order is library-internal).
 // ic[0] = start offset in the 'full' convolution, ic[1] = kernel length, ic[2] = taps contain NaN
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 template <typename T>
 __device__ void op_convolve(Ctx<T>& cx, const DevOp& op) {
     const DevSlot& ss = cx.prog->slots[op.src];
@@ -740,7 +743,7 @@ __device__ void op_convolve(Ctx<T>& cx, const DevOp& op) {
         for (int k = 0; k < m; ++k) {
             const T kv = kern[k];
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = __builtin_fmaf((float)win[r], (float)kv, (float)acc[r]);
+            for (int r = 0; r < R; ++r) acc[r] = fma_t(win[r], kv, acc[r]);
             // slide: next k needs inputs one index lower
 #pragma unroll
             for (int r = R - 1; r > 0; --r) win[r] = win[r - 1];
@@ -876,8 +879,17 @@ extern "C" int dsp_internal_launch_vm_f32(const DevProgram* dev_prog, const IoPt
     return (int)hipGetLastError();
 }
 
+extern "C" int dsp_internal_launch_vm_f64(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int* err, int blocks,
+                                          int threads, int lds_bytes, hipStream_t stream) {
+    hipLaunchKernelGGL(dsp_vm_kernel<double>, dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
+    return (int)hipGetLastError();
+}
+
 extern "C" int dsp_internal_set_vm_lds(int lds_bytes) {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dsp_vm_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dsp_vm_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      lds_bytes);
+    if (rc) return rc;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dsp_vm_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     lds_bytes);
 }
 

@@ -95,8 +95,10 @@ class ProcessingChain:
     """Runs a translated recipe over a buffer of rows.  ``execute(start, stop)`` has the meaning of the reference's
     (processing_chain.py:665-673); ``__call__(tb_in, tb_out)`` relinks I/O like :675-716."""
 
-    def __init__(self, program: Program, inputs: dict, outputs: dict, consts: dict, buffer_len: int, proc_strings: list[str]):
+    def __init__(self, program: Program, inputs: dict, outputs: dict, consts: dict, buffer_len: int, proc_strings: list[str],
+                 loop_dtype=np.float32):
         self._program = program
+        self.loop_dtype = np.dtype(loop_dtype)  # float32 or float64 gufunc loop of the whole chain
         self._in_vars = inputs      # binding name -> Var (source column)
         self._out_vars = outputs    # binding name -> (Var, length or None)
         self._consts = consts       # binding name -> ndarray (taps)
@@ -127,7 +129,7 @@ class ProcessingChain:
 
     def _ensure(self):
         if self._chain is None:
-            self._chain = Chain(self._program, "processing_chain")
+            self._chain = Chain(self._program, "processing_chain", self.loop_dtype)
             self._stream = Stream()
             for name, arr in self._consts.items():
                 self._dev[name] = DeviceArray.from_numpy(arr)
@@ -154,7 +156,7 @@ class ProcessingChain:
             if isinstance(col, DeviceArray):
                 bufs[name] = col.view_rows(start, stop)
             else:
-                d = DeviceArray((n,) if length is None else (n, length), np.float32)
+                d = DeviceArray((n,) if length is None else (n, length), self.loop_dtype)
                 bufs[name] = d
                 staged_out.append((d, col))
         t1 = time.perf_counter()
@@ -610,8 +612,21 @@ def _fold_generator(b: _Builder, function, args, new_vars):
 # ----------------------------------------------------------------------------------------------------------------
 # program generation
 # ----------------------------------------------------------------------------------------------------------------
+def _loop_dtype(b: _Builder):
+    """float32 loop unless an input selects the float64 one (first castable signature wins, reference :1565-1572, 1654-1664):
+    float64 / int32 / uint32 waveforms or float64 scalar columns cannot be cast to float32."""
+    for v in b.vars.values():
+        if v.is_input and v.dtype is not None:
+            if v.kind == "wf" and v.dtype in (np.dtype(np.float64), np.dtype(np.int32), np.dtype(np.uint32)):
+                return np.dtype(np.float64)
+            if v.kind == "scalar" and v.dtype == np.dtype(np.float64):
+                return np.dtype(np.float64)
+    return np.dtype(np.float32)
+
+
 def _compile(b: _Builder, out_pars, n_rows, proc_strings):
     p = Program()
+    ft = _loop_dtype(b)
     in_bind, out_bind, consts = {}, {}, {}
     steps = b.steps
 
@@ -855,8 +870,8 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             if not (isinstance(taps, Var) and taps.kind == "taps"):
                 raise NotImplementedError(f"{fn}: the kernel must be a constant computed in the recipe (cusp_filter / zac_filter)")
             if taps.io is None:
-                taps.io = p.add_io(f"taps:{taps.name}", _lib.IO_TAPS, np.float32, taps.length, 0, 0)
-                consts[f"taps:{taps.name}"] = taps.const
+                taps.io = p.add_io(f"taps:{taps.name}", _lib.IO_TAPS, ft, taps.length, 0, 0)
+                consts[f"taps:{taps.name}"] = taps.const.astype(ft)
             dst = out_wf(args[3], None, src)
             if dst.length is None:
                 raise ProcessingChainError(f"{fn}: declare the output as name(length, 'f')")
@@ -880,24 +895,24 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
         if v.kind == "wf":
             if v.slot is None:
                 raise ProcessingChainError(f"output waveform '{o}' was never computed")
-            io = p.add_io(f"out:{o}", _lib.IO_WF_OUT, np.float32, v.length)
+            io = p.add_io(f"out:{o}", _lib.IO_WF_OUT, ft, v.length)
             p.add_op(_lib.OP_STORE, src=v.slot, io=io)
             out_bind[f"out:{o}"] = (v, v.length)
-            tb_out[o] = np.empty((n_rows, v.length), dtype=np.float32)
+            tb_out[o] = np.empty((n_rows, v.length), dtype=ft)
         else:
             if v.sreg is None:
                 if v.is_input:
                     tb_out[o] = _column(b.tb_in, v.source)
                     continue
                 raise ProcessingChainError(f"output '{o}' was never computed")
-            io = p.add_io(f"out:{o}", _lib.IO_SCALAR_OUT, np.float32)
+            io = p.add_io(f"out:{o}", _lib.IO_SCALAR_OUT, ft)
             p.add_op(_lib.OP_STORE_SCALAR, io=io, ip=(v.sreg,))
             out_bind[f"out:{o}"] = (v, None)
-            tb_out[o] = np.empty(n_rows, dtype=np.float32)
+            tb_out[o] = np.empty(n_rows, dtype=ft)
     p.slots = slot_len
     if len(p.ops) > _lib.MAX_OPS or len(p.slots) > _lib.MAX_SLOTS or len(p.io) > _lib.MAX_IO or p.n_sregs > _lib.MAX_SREGS:
         raise NotImplementedError("recipe is too large for one device chain (ops/slots/bindings limit)")
-    chain = ProcessingChain(p, in_bind, out_bind, consts, n_rows, proc_strings)
+    chain = ProcessingChain(p, in_bind, out_bind, consts, n_rows, proc_strings, ft)
     return chain, tb_out
 
 

@@ -162,7 +162,7 @@ typedef struct dsp_op {
 
 typedef struct dsp_chain dsp_chain; /* opaque */
 
-/* compute_dtype: DSP_F32 (the loop int16/uint16/float32 inputs select) -- DSP_F64 is reserved.
+/* compute_dtype: DSP_F32 (the loop int16/uint16/float32 inputs select) or DSP_F64 (float64/int32/uint32 inputs).
  * slot_len[s] = number of samples held by waveform slot s (static per chain, like ProcChainVar shapes).
  * Validates the program and every constant-only DSPFatal condition; on failure returns the code and *out = NULL. */
 int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_io, const int32_t* slot_len, int n_slots,
@@ -190,8 +190,9 @@ int dsp_chain_set_fused(dsp_chain* chain, int enable);
  * `*_stride` elements apart.  Scalar gufunc arguments "()" come as (pointer, value): if the pointer is
  * non-NULL it is a device array with one value per waveform, otherwise `value` is broadcast.
  * The call is synchronous with respect to errors: it returns DSP_OK or the DSP_E_* code (first offending
- * row in *err_row when not NULL).  `<ty>`: f32 takes float32 rows; i16/u16 take (u)int16 rows and run the
- * float32 loop (outputs float32), as the reference's type matching does.
+ * row in *err_row when not NULL).  `<ty>` names the gufunc loop: `_f32` takes float32, int16 or uint16 rows (in_dtype) and
+ * produces float32; `_f64` takes float64, int32 or uint32 rows and produces float64 -- the reference's type matching
+ * (first signature every argument can be cast to, processing_chain.py:1565-1572, 1654-1664).
  */
 int dsp_bl_subtract_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* baseline_dev,
                         float baseline, float* out, int64_t out_stride, void* stream, int64_t* err_row);
@@ -216,6 +217,32 @@ int dsp_dwt_haar_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len,
                      float* out, int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_convolve_wf_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* kernel_dev,
                         int32_t kernel_len, int32_t mode_char, float* out, int32_t out_len, int64_t out_stride, void* stream,
+                        int64_t* err_row);
+
+/* the float64 loops: float64 (and int32 / uint32) rows, float64 scalars and outputs -- same argument order */
+int dsp_bl_subtract_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const double* baseline_dev,
+                        double baseline, double* out, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_pole_zero_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, double tau, double* out,
+                      int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_double_pole_zero_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, double tau1, double tau2,
+                             double frac, double* out, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_trap_filter_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,
+                        double* out, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_trap_norm_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,
+                      double* out, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_asym_trap_filter_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise,
+                             int32_t flat, int32_t fall, double* out, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_fixed_time_pickoff_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const double* t_in_dev,
+                               double t_in, int32_t mode_char, double* out, void* stream, int64_t* err_row);
+int dsp_time_point_thresh_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
+                              const double* threshold_dev, double threshold, const double* t_start_dev, double t_start,
+                              double walk_forward, double* out, void* stream, int64_t* err_row);
+int dsp_min_max_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, double* t_min, double* t_max,
+                    double* a_min, double* a_max, void* stream, int64_t* err_row);
+int dsp_dwt_haar_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t level, int32_t coeff_char,
+                     double* out, int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_convolve_wf_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const double* kernel_dev,
+                        int32_t kernel_len, int32_t mode_char, double* out, int32_t out_len, int64_t out_stride, void* stream,
                         int64_t* err_row);
 
 /* ---- synthetic batches generated on the device (bench.py) ---------------------------------

@@ -143,3 +143,18 @@ def test_fatal_from_recipe_carries_processor_context():
     chain, _, _ = build_processing_chain(bad, {"waveform": np.zeros((4, 4096), dtype=np.float32)})
     with pytest.raises(DSPFatal, match="wider than the waveform"):
         chain.execute()
+
+
+def test_float64_inputs_run_the_float64_chain():
+    """A float64 waveform column selects the float64 loops for the whole recipe; outputs come back as float64."""
+    rng = np.random.default_rng(8)
+    x, bl, t0 = _synth(rng, 40, 4096)
+    tp = (t0 + 625 + 150.4)
+    chain, out = _run(recipes.C2_UNITS, {"waveform": __import__("dspeed_amd.processing_chain", fromlist=["WaveformInput"]).WaveformInput(x, dt=16.0),
+                                         "baseline": bl.astype(np.float64), "t_pick": tp})
+    assert out["trapEftp"].dtype == np.float64 and out["wf_trap"].dtype == np.float64
+    xb = oracle.bl_subtract(x, bl.astype(np.float64))[0]
+    tr = oracle.trap_filter(oracle.pole_zero(xb, 27460.5 / 16.0)[0], 625, 188)[0]
+    assert_rel_to_peak(out["wf_trap"], tr, 1e-12, "wf_trap f64")
+    e = oracle.fixed_time_pickoff(tr, tp, "l")[0]
+    assert np.max(np.abs(out["trapEftp"] - e) / np.abs(e)) <= 1e-12
