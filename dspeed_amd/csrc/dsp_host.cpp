@@ -64,7 +64,6 @@ extern "C" int dsp_internal_launch_energy(const EnergyArgs* A, int trap_opcode, 
                                           int threads, int lds_bytes, hipStream_t stream);
 extern "C" int dsp_internal_set_energy_lds(int trap_opcode, int npf, int lds_bytes);
 extern "C" const char* dsp_internal_energy_kernel_name();
-static const char* dsp_internal_energy_pair_kernel_name() { return "dsp_energy_pair_kernel"; }
 struct EnergyPlan {
     int32_t shift[3][4];
     int32_t cs[3][4];
@@ -80,6 +79,9 @@ struct EnergyPlan3 {
 extern "C" int dsp_internal_launch_energy_v3(const EnergyArgs* A, const EnergyPlan3* PL, int trap_opcode, int npf, int64_t n_wf, int* err,
                                              int blocks, int threads, int lds_bytes, hipStream_t stream);
 extern "C" const char* dsp_internal_energy_v3_kernel_name();
+extern "C" int dsp_internal_launch_energy_sl(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int64_t n_wf,
+                                             int* err, int blocks, int threads, int lds_bytes, hipStream_t stream);
+extern "C" const char* dsp_internal_energy_sl_kernel_name();
 
 namespace {
 
@@ -127,15 +129,11 @@ struct dsp_chain {
     bool fused_ok = false, fused_on = true;
     EnergyArgs fused{};
     int fused_trap = 0, fused_npf = 0;
-    // two-wavefronts-per-waveform variant of the same kernel (len = 2048 / 4096 / 8192)
-    bool pair_ok = false, pair_on = true;
-    EnergyArgs pair{};
-    int pair_npfh = 0, pair_lds_bytes = 0;
     // ILP variant (S sub-chains per lane, pad-free LDS): the default for 1024/2048/4096-sample energy chains
     bool ilp_ok = false;
     int variant = 1;  // 1: one chain per lane (default: fastest so far), 0: 2 sub-chains per lane (pad-free LDS), 2: 4 sub-chains
     EnergyArgs ilp{};
-    EnergyPlan plan[2]{};  // [0]: S=2, [1]: S=4
+    EnergyPlan plan[3]{};  // [0]: S=2, [1]: S=4, [2]: S=1
     int ilp_lds_bytes = 0;
     // v3: even lane stride, 64-bit LDS accesses, two sub-chains in the replay only (variant 3)
     EnergyArgs v3{};
@@ -612,7 +610,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 int guard = 2 * Ci + 8;
                 guard = ((guard + 3) / 4) * 4;
                 I.slot_off = guard;
-                int elems = guard + 64 * Ci + 16;
+                int elems = guard + 64 * Ci + 16 + 64 * 9 + 8;  // slot, tail, per-lane side array of the straight-line variant
                 elems = ((elems + 3) / 4) * 4;
                 I.lds_elems_per_wave = elems;
                 ch->ilp_lds_bytes = elems * 4;
@@ -620,8 +618,8 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                     I.q[k] = dtp.ic[k];  // the lags themselves
                     I.rho[k] = 0;
                 }
-                for (int v = 0; v < 2; ++v) {
-                    const int S = v == 0 ? 2 : 4, CS = (Ci - 1) / S;
+                for (int v = 0; v < 3; ++v) {
+                    const int S = v == 0 ? 2 : (v == 1 ? 4 : 1), CS = (Ci - 1) / S;
                     for (int k = 0; k < 3; ++k)
                         for (int sidx = 0; sidx < S; ++sidx) {
                             const int pos = sidx * CS - dtp.ic[k];          // samples before the sub-chain start, relative to the chunk
@@ -659,27 +657,6 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 }
                 ch->ilp_ok = true;
                 if (const char* venv = getenv("DSPEED_HIP_VARIANT")) ch->variant = atoi(venv);
-            }
-            if (slot_len[0] >= 2048) {                  // two wavefronts per waveform: len == 512 * npfh, npfh in {4, 8, 16}
-                EnergyArgs& Q = ch->pair;
-                Q = F;
-                const int C2 = slot_len[0] / 128, pitch2 = C2 + 1;
-                Q.C = C2;
-                Q.pitch = pitch2;
-                Q.invC = 1.0f / (float)C2;
-                for (int k = 0; k < 3; ++k) {
-                    Q.q[k] = dtp.ic[k] / C2;
-                    Q.rho[k] = dtp.ic[k] % C2;
-                }
-                Q.slot_off = 2 * pitch2;
-                int elems = 2 * pitch2 + 128 * pitch2 + 40 + 32 + 3 * 128 + 8;  // tail 40: see the slot layout above
-                elems = ((elems + 3) / 4) * 4;
-                Q.lds_elems_per_wave = elems;  // per workgroup here
-                ch->pair_lds_bytes = elems * 4;
-                ch->pair_npfh = slot_len[0] / 512;
-                ch->pair_ok = false;  // the two-wavefronts-per-waveform variant measured slower (barriers); kept out of the build
-                const char* penv = getenv("DSPEED_HIP_PAIR");
-                ch->pair_on = !(penv && penv[0] == '0');
             }
         }
     }
@@ -728,21 +705,6 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
     const int blocks = chain_blocks(ch, n_wf);
     const int threads = 64 * ch->waves_per_block;
     const int lds = ch->lds_bytes_per_wave * ch->waves_per_block;
-    if (ch->pair_ok && ch->pair_on && ch->fused_on && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
-        EnergyArgs F = ch->pair;
-        F.wf = io_ptrs[ch->io_wf];
-        F.bl = ch->io_bl >= 0 ? (const float*)io_ptrs[ch->io_bl] : nullptr;
-        F.tp = ch->io_tp >= 0 ? (const float*)io_ptrs[ch->io_tp] : nullptr;
-        F.out = (float*)io_ptrs[ch->io_out];
-        int per_cu = LDS_BYTES_PER_CU / ch->pair_lds_bytes;
-        const int reg_cap = (ch->pair_npfh <= 8) ? 8 : 4;  // 4 resp. 2 wavefronts per SIMD by registers
-        if (per_cu > reg_cap) per_cu = reg_cap;
-        int64_t pblocks = (int64_t)ch->num_cu * per_cu;
-        if (pblocks > n_wf) pblocks = n_wf;
-        (void)pblocks;
-        (void)F;
-        return fail(DSP_ERR_UNSUPPORTED, "pair kernel not built");
-    }
     if (ch->ilp_ok && ch->fused_on && ch->variant == 3 && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
         EnergyArgs F = ch->v3;
         F.wf = io_ptrs[ch->io_wf];
@@ -759,6 +721,26 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         hipError_t e = (hipError_t)dsp_internal_launch_energy_v3(&F, &ch->plan3, ch->fused_trap, ch->fused_npf, n_wf, ch->dev_err, vblocks,
                                                                  64 * wpb, ch->v3_lds_bytes * wpb, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy v3 kernel launch failed: %s", hipGetErrorString(e));
+        return DSP_OK;
+    }
+    if (ch->ilp_ok && ch->fused_on && (ch->variant == 4 || ch->variant == 5) && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
+        // straight-line variant: variant 4 = one replay chain per lane, 5 = two
+        EnergyArgs F = ch->ilp;
+        F.wf = io_ptrs[ch->io_wf];
+        F.bl = ch->io_bl >= 0 ? (const float*)io_ptrs[ch->io_bl] : nullptr;
+        F.tp = ch->io_tp >= 0 ? (const float*)io_ptrs[ch->io_tp] : nullptr;
+        F.out = (float*)io_ptrs[ch->io_out];
+        const int S = ch->variant == 5 ? 2 : 1;
+        int wpb = LDS_BYTES_PER_CU / ch->ilp_lds_bytes;
+        if (wpb > 4) wpb = 4;
+        int per_cu = LDS_BYTES_PER_CU / (ch->ilp_lds_bytes * wpb);
+        if (per_cu * wpb > 8) per_cu = 8 / wpb;
+        if (per_cu < 1) per_cu = 1;
+        int64_t want = (n_wf + wpb - 1) / wpb, cap = (int64_t)ch->num_cu * per_cu;
+        const int iblocks = (int)(want < cap ? want : cap);
+        hipError_t e = (hipError_t)dsp_internal_launch_energy_sl(&F, &ch->plan[S == 2 ? 0 : 2], ch->fused_trap, ch->fused_npf, S, n_wf,
+                                                                 ch->dev_err, iblocks, 64 * wpb, ch->ilp_lds_bytes * wpb, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy straight-line kernel launch failed: %s", hipGetErrorString(e));
         return DSP_OK;
     }
     if (ch->ilp_ok && ch->fused_on && ch->variant != 1 && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
@@ -840,8 +822,8 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
 }
 
 const char* dsp_chain_kernel_name(dsp_chain* ch) {
-    if (ch && ch->pair_ok && ch->pair_on && ch->fused_on) return dsp_internal_energy_pair_kernel_name();
     if (ch && ch->ilp_ok && ch->fused_on && ch->variant == 3) return dsp_internal_energy_v3_kernel_name();
+    if (ch && ch->ilp_ok && ch->fused_on && (ch->variant == 4 || ch->variant == 5)) return dsp_internal_energy_sl_kernel_name();
     if (ch && ch->ilp_ok && ch->fused_on && ch->variant != 1) return dsp_internal_energy_ilp_kernel_name();
     return (ch && ch->fused_ok && ch->fused_on) ? dsp_internal_energy_kernel_name() : dsp_internal_vm_kernel_name();
 }
@@ -849,8 +831,8 @@ const char* dsp_chain_kernel_name(dsp_chain* ch) {
 int dsp_chain_set_fused(dsp_chain* ch, int enable) {
     if (!ch) return fail(DSP_ERR_ARG, "null chain");
     ch->fused_on = (enable & 1) != 0;   // bit 0: use a specialised kernel
-    ch->variant = (enable >> 1) & 3;    // bits 1-2: 0 = one chain per lane (default), 1 = 2 sub-chains per lane, 2 = 4 sub-chains
-    ch->variant = ch->variant == 0 ? 1 : (ch->variant == 1 ? 0 : ch->variant);  // 2 -> 4 sub-chains, 3 -> v3
+    ch->variant = (enable >> 1) & 7;    // bits 1-3: kernel variant: 0 = default, 1 = ILP S=2, 2 = ILP S=4, 3 = v3, 4/5 = straight line S=1/2
+    ch->variant = ch->variant == 0 ? 1 : (ch->variant == 1 ? 0 : ch->variant);
     return ((ch->fused_ok || ch->ilp_ok) && ch->fused_on) ? 1 : 0;
 }
 

@@ -30,26 +30,6 @@ def _parse_signature(sig: str):
     return dims(sig), []
 
 
-class _Arg:
-    """One gufunc argument normalised for the C ABI."""
-
-    def __init__(self, value, core_ndim, is_output=False):
-        self.is_device = isinstance(value, DeviceArray)
-        self.core_ndim = core_ndim
-        self.orig = value
-        if self.is_device:
-            self.shape, self.dtype = value.shape, value.dtype
-        else:
-            value = np.asarray(value)
-            self.shape, self.dtype = value.shape, value.dtype
-        self.value = value
-        self.is_output = is_output
-
-    @property
-    def loop_shape(self):
-        return self.shape[: len(self.shape) - self.core_ndim]
-
-
 class HipGUFunc:
     def __init__(self, name: str, signature: str, types: list[str], impl, doc: str = ""):
         self.__name__ = name

@@ -25,7 +25,7 @@ def _run_energy(wf, bl, tp, tau, rise, flat, mode="l", fused=True, trap="trap_fi
     return bufs["trapEftp"].to_numpy()
 
 
-@pytest.mark.parametrize("fused", [1, 3, 5, 7, 0])
+@pytest.mark.parametrize("fused", [1, 3, 5, 7, 9, 11, 0])
 def test_energy_chain_golden(fused):
     c2 = cases("chains")[1]
     p = c2.params
@@ -38,7 +38,7 @@ def test_energy_chain_golden(fused):
     assert rel.max() <= TOL
 
 
-@pytest.mark.parametrize("fused", [1, 3, 5, 7, 0])
+@pytest.mark.parametrize("fused", [1, 3, 5, 7, 9, 11, 0])
 @pytest.mark.parametrize("wf_len,rise,flat", [(4096, 625, 188), (1024, 64, 16), (8192, 1250, 376), (6092, 500, 100), (2048, 300, 7),
                                               (3000, 128, 0), (200, 10, 3)])
 def test_energy_chain_vs_oracle(wf_len, rise, flat, fused):
@@ -79,12 +79,12 @@ def test_energy_chain_matches_unfused_processors():
     step = P.fixed_time_pickoff(P.trap_filter(P.pole_zero(P.bl_subtract(wf, bl), 1716.28), 625, 188), tp, ord("l"))
     for fused in (1, 0):
         assert np.array_equal(_run_energy(wf, bl, tp, 1716.28, 625, 188, fused=fused), step)
-    for fused in (3, 5, 7):
+    for fused in (3, 5, 7, 9, 11):
         assert np.max(np.abs(_run_energy(wf, bl, tp, 1716.28, 625, 188, fused=fused) - step) / np.abs(step)) <= TOL
     step = P.fixed_time_pickoff(P.trap_norm(P.pole_zero(P.bl_subtract(wf, bl), 1716.28), 625, 188), tp, ord("h"))
     for fused in (1, 0):
         assert np.array_equal(_run_energy(wf, bl, tp, 1716.28, 625, 188, mode="h", fused=fused, trap="trap_norm"), step)
-    for fused in (3, 5, 7):
+    for fused in (3, 5, 7, 9, 11):
         assert np.max(np.abs(_run_energy(wf, bl, tp, 1716.28, 625, 188, mode="h", fused=fused, trap="trap_norm") - step) / np.abs(step)) <= TOL
 
 
@@ -95,7 +95,7 @@ def test_data_dependent_fatal_reports_row():
     bl = np.zeros(10, dtype=np.float32)
     tp = np.full(10, 100.0, dtype=np.float32)
     tp[6] = 100.5
-    for fused in (1, 3, 5, 7, 0):
+    for fused in (1, 3, 5, 7, 9, 11, 0):
         with pytest.raises(DSPFatal) as ei:
             _run_energy(wf, bl, tp, 100.0, 16, 8, "i", fused=fused)
         assert ei.value.wf_range == range(6, 7)
