@@ -1268,6 +1268,264 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_sl_kernel(EnergyArgs A, Ene
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// "rr" (register resident): the straight-line kernel with the lane's own chunk held in registers across all three passes
+// (one LDS read per sample instead of three), bl_subtract folded into the staging stores, and the lagged streams of the
+// replay loaded one group ahead of their use so every wait is a counted one.
+// ------------------------------------------------------------------------------------------------
+template <int NPF, int KIND>
+__global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, EnergyPlan PL, int64_t n_wf, int* err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int S = 1, C = 4 * NPF + 1, len = 256 * NPF, NG = (C - 1) / 8, CS = C - 1, NGS = NG;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
+    float* lds = reinterpret_cast<float*>(smem_raw) + (size_t)wave * A.lds_elems_per_wave;
+    for (int e = lane; e < A.lds_elems_per_wave; e += 64) lds[e] = 0.0f;
+    wave_sync();
+    float* slot = lds + A.slot_off;
+    float* mine = slot + lane * C;
+    // per-lane side array (pitch 9, odd): group-end prefix sums of pass 2, later the group-start states of the replay.  Kept in
+    // LDS so that "the value of group gi" with a run-time gi is an address, not a register select chain
+    constexpr int AUXP = 9;
+    static_assert(NG + 1 <= AUXP && S * NGS + 1 <= AUXP, "side array too small");
+    float* aux = slot + 64 * C + 16 + lane * AUXP;
+    const float* lagp[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int pos0 = lane * C - A.q[k];  // q[] carries the lags
+        lagp[k] = (pos0 >= -C) ? slot + pos0 : slot - (2 * C + 8);
+    }
+
+    const int64_t stride_rows = (int64_t)gridDim.x * wpb;
+    int64_t row = (int64_t)blockIdx.x * wpb + wave;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 pf[NPF];
+    float pf_bl = 0.0f, pf_tp = 0.0f;
+    auto prefetch = [&](int64_t r) {
+        const float* g = (const float*)A.wf + r * A.wf_stride + A.wf_offset;
+#pragma unroll
+        for (int b = 0; b < NPF; ++b) pf[b] = reinterpret_cast<const f4*>(g)[b * 64 + lane];
+        pf_bl = A.bl ? A.bl[r * A.bl_stride] : A.bl_const;
+        pf_tp = A.tp ? A.tp[r * A.tp_stride] : A.tp_const;
+    };
+    auto report = [&](int code, int64_t r) {
+        if (lane == 0 && atomicCAS(&err[0], 0, code) == 0) {
+            err[1] = (int)(r & 0xffffffffll);
+            err[2] = (int)(r >> 32);
+        }
+    };
+    // prefix after r samples of this lane's chunk, from the group-end sums of pass 2 and at most 7 re-read outputs
+    auto prefix_at = [&](int r) -> float {
+        const int gi = (r > 0 ? r - 1 : 0) >> 3;  // group that contains sample r-1
+        const float base = gi > 0 ? aux[gi - 1] : 0.0f;
+        const int n = r - 8 * gi;  // 0..8 samples of group gi (gi == NG: the odd sample)
+        float part = 0.0f;
+        __builtin_amdgcn_sched_barrier(0);
+        const float* p = mine + 8 * gi;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float v = p[u];  // (reads at most 7 past the chunk: inside the slot tail)
+            part += (u < n) ? v : 0.0f;
+        }
+        return base + part;
+    };
+    if (row < n_wf) prefetch(row);
+    const bool stamps = (A.ablate & 8) != 0;
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = stamps ? stamp() : 0;
+
+    for (; row < n_wf; row += stride_rows) {
+#pragma unroll
+        for (int b = 0; b < NPF; ++b) *reinterpret_cast<f4*>(slot + (b * 64 + lane) * 4) = pf[b] - pf_bl;  // bl_subtract while staging
+        slot[len + lane] = 0.0f;  // virtual samples above len
+        const float t_in = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pf_tp)));
+        const int64_t next = row + stride_rows;
+        __builtin_amdgcn_sched_barrier(0);
+        if (next < n_wf) prefetch(next);
+        __builtin_amdgcn_sched_barrier(0);
+        wave_sync();
+        PHASE(0)
+
+        float result = quiet_nan<float>();
+        // ---- the lane's chunk lives in registers from here to the end of the replay: x, then (in place) the pole-zero output
+        float xr[C];
+#pragma unroll
+        for (int t = 0; t < C; ++t) xr[t] = mine[t];
+        const float xprev = (lane > 0) ? mine[-1] : 0.0f;
+        // ---- pass 1: float64 sum of x over the chunk
+        double X = 0.0;
+#pragma unroll
+        for (int t = 0; t < C; ++t) {
+            if ((t & 7) == 0) __builtin_amdgcn_sched_barrier(0);  // (keeps the float64 conversions from being hoisted: registers)
+            X += (double)xr[t];
+        }
+        bool in_nan = A.tau_nan != 0;
+        if (wave_any(!(fabs(X) <= 1.7976931348623157e308))) {
+            bool n = false;
+#pragma unroll
+            for (int t = 0; t < C; ++t) n |= (xr[t] != xr[t]);
+            in_nan |= wave_any(n);
+        }
+        PHASE(1)
+        // the float64 images of the samples are cheaper to recompute in pass 2 than to keep (130 registers): hide the reuse
+#pragma unroll
+        for (int t = 0; t < C; ++t) asm volatile("" : "+v"(xr[t]));
+        if (!in_nan) {
+            const double E = wave_exscan_add(X);
+            // ---- pass 2 (straight line): pole-zero recurrence in the reference's operation order, in place
+            const double c = A.c;
+            double xp = (double)xprev, acc = E - c * (E - xp);
+            float run = 0.0f;
+#pragma unroll
+            for (int t = 0; t < C; ++t) {
+                if ((t & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+                const double x = (double)xr[t];
+                acc = (acc + x) - xp * c;
+                const float y = (float)acc;
+                xr[t] = y;
+                mine[t] = y;  // other lanes read it with a lag
+                xp = x;
+                run += y;
+                if ((t & 7) == 7) aux[t >> 3] = run;
+            }
+            wave_sync();
+            PHASE(2)
+            bool pz_nan = false;
+            if (wave_any(!(fabsf(run) <= 3.4028234663852886e38f))) {
+                bool n = false;
+#pragma unroll
+                for (int t = 0; t < C; ++t) n |= (xr[t] != xr[t]);
+                pz_nan = wave_any(n);
+            }
+            if (pz_nan) {
+                report(DSP_E_PZ_NAN, row);
+            } else if (!A.all_nan && !(A.ablate & 4) && pickoff_in_range(t_in, len)) {
+                // ---- speculative carries
+                const double Ep = wave_exscan_add((double)run);
+                float g[S], y[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    double Ak[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        int r = PL.cs[k][s] * CS + PL.local[k][s];  // samples of the source lane's chunk before the capture point
+                        // opaque to the optimiser: otherwise every mask derived from the (row-invariant) plan is hoisted out of the
+                        // row loop and the kernel drowns in spilled SGPR pairs
+                        asm volatile("" : "+s"(r));
+                        Ak[k] = wave_shift_up(Ep + (double)prefix_at(r), PL.shift[k][s]);
+                    }
+                    const double own = Ep + (s ? (double)aux[s * NGS - 1] : 0.0);
+                    double Gd;
+                    if (KIND == TRAP_FILTER)
+                        Gd = ((own - Ak[0]) - Ak[1]) + Ak[2];
+                    else if (KIND == TRAP_NORM)
+                        Gd = (((own - Ak[0]) - Ak[1]) + Ak[2]) / A.rr;
+                    else
+                        Gd = (own - Ak[0]) / A.rr - (Ak[1] - Ak[2]) / A.ll;
+                    g[s] = (lane == 0 && s == 0) ? -0.0f : (float)Gd;
+                    y[s] = g[s];
+                }
+                PHASE(3)
+                // ---- pass 3: replay; own samples from registers, the three lagged streams software-pipelined one 8-sample group ahead
+                wave_sync();  // the prefix sums in aux are consumed; aux now receives the replay state at every group start
+                constexpr int GL = 4, NL = (C - 1) / GL;  // samples per pipeline stage of the lagged streams (registers: 2 x 3 x GL)
+                float lb[2][GL][3], lodd[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int u = 0; u < GL; ++u)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) lb[0][u][k] = lagp[k][u];
+#pragma unroll
+                for (int gl = 0; gl < NL; ++gl) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (gl + 1 < NL) {
+#pragma unroll
+                        for (int u = 0; u < GL; ++u)
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) lb[(gl + 1) & 1][u][k] = lagp[k][(gl + 1) * GL + u];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) lodd[k] = lagp[k][C - 1];
+                    }
+                    if ((gl * GL) % 8 == 0) aux[(gl * GL) / 8] = y[0];
+                    __builtin_amdgcn_sched_barrier(0);  // the reads just issued are younger than the stage consumed next: a counted wait
+#pragma unroll
+                    for (int u = 0; u < GL; ++u)
+                        y[0] = trap_step<float, KIND>(y[0], xr[gl * GL + u], lb[gl & 1][u][0], lb[gl & 1][u][1], lb[gl & 1][u][2], A.rr, A.ll);
+                }
+                aux[NG] = y[0];  // state before the odd sample
+                y[0] = trap_step<float, KIND>(y[0], xr[C - 1], lodd[0], lodd[1], lodd[2], A.rr, A.ll);
+                PHASE(4)
+                // ---- true carries: exact scan of the increments
+                double D[S], Dbefore[S], Dtot = 0.0;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    D[s] = (double)y[s] - (double)g[s];
+                    Dbefore[s] = Dtot;
+                    Dtot += D[s];
+                }
+                const double T0 = wave_exscan_add(Dtot);
+                // ---- wanted samples: re-run the one 8-sample group that contains each of them from its saved start state
+                const int i0 = (int)t_in;
+                const bool wide = (A.mode == 'h');
+                float w4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = i0 - 1 + k;
+                    const bool need = ((k == 1) || (k == 2) || wide) && e >= 0 && e < len;
+                    w4[k] = 0.0f;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (need) {  // uniform
+                        const int l = e / C, off = e - l * C;
+                        int ch = off / CS;
+                        if (ch > S - 1) ch = S - 1;
+                        const int loc = off - ch * CS;  // 0..CS (CS: the odd sample, chain S-1 only)
+                        const int gi = loc >> 3, u0 = loc & 7;
+                        float ys = aux[ch * NGS + gi], gsel = 0.0f;  // (chain S-1, group NGS) -> aux[S*NGS]
+                        double dsel = 0.0;
+#pragma unroll
+                        for (int s = 0; s < S; ++s)
+                            if (ch == s) {
+                                gsel = g[s];
+                                dsel = Dbefore[s];
+                            }
+                        const int base = ch * CS + gi * 8;
+                        float yk = ys;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int tt = base + u;  // (beyond the chunk for the odd sample's group: reads stay in the slot tail, unused)
+                            ys = trap_step<float, KIND>(ys, mine[tt], lagp[0][tt], lagp[1][tt], lagp[2][tt], A.rr, A.ll);
+                            if (u == u0) yk = ys;
+                        }
+                        const double delta = (T0 + dsel) - (double)gsel;
+                        w4[k] = readlane((float)((double)yk + delta), l);
+                    }
+                }
+                int fc = 0;
+                result = pickoff_eval(t_in, A.mode, len, w4, fc);
+                if (fc) report(fc, row);
+            }
+        }
+        if (lane == 0) A.out[row * A.out_stride] = result;
+        wave_sync();
+        PHASE(5)
+    }
+    if (stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(err + 4) + i, tsum[i]);
+    }
+}
+
+template <int KIND>
+int launch_rr_kind(const EnergyArgs& A, const EnergyPlan& PL, int npf, int64_t n_wf, int* err, int blocks, int threads, int lds_bytes,
+                   hipStream_t st) {
+    switch (npf) {
+        case 4: hipLaunchKernelGGL((dsp_energy_rr_kernel<4, KIND>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 8: hipLaunchKernelGGL((dsp_energy_rr_kernel<8, KIND>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 16: hipLaunchKernelGGL((dsp_energy_rr_kernel<16, KIND>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+    return (int)hipGetLastError();
+}
+
 template <int KIND, int S>
 int launch_sl_kind(const EnergyArgs& A, const EnergyPlan& PL, int npf, int64_t n_wf, int* err, int blocks, int threads, int lds_bytes,
                    hipStream_t st) {
@@ -1347,6 +1605,14 @@ extern "C" int dsp_internal_launch_energy_sl(const EnergyArgs* A, const EnergyPl
 #undef GO_
 }
 extern "C" const char* dsp_internal_energy_sl_kernel_name() { return "dsp_energy_sl_kernel"; }
+
+extern "C" int dsp_internal_launch_energy_rr(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int64_t n_wf, int* err,
+                                             int blocks, int threads, int lds_bytes, hipStream_t stream) {
+    if (trap_opcode == DSP_OP_TRAP_FILTER) return launch_rr_kind<TRAP_FILTER>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
+    if (trap_opcode == DSP_OP_TRAP_NORM) return launch_rr_kind<TRAP_NORM>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
+    return launch_rr_kind<TRAP_ASYM>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
+}
+extern "C" const char* dsp_internal_energy_rr_kernel_name() { return "dsp_energy_rr_kernel"; }
 
 extern "C" const char* dsp_internal_energy_kernel_name() { return "dsp_energy_kernel"; }
 extern "C" const char* dsp_internal_energy_ilp_kernel_name() { return "dsp_energy_ilp_kernel"; }

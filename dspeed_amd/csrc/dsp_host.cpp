@@ -82,6 +82,9 @@ extern "C" const char* dsp_internal_energy_v3_kernel_name();
 extern "C" int dsp_internal_launch_energy_sl(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int64_t n_wf,
                                              int* err, int blocks, int threads, int lds_bytes, hipStream_t stream);
 extern "C" const char* dsp_internal_energy_sl_kernel_name();
+extern "C" int dsp_internal_launch_energy_rr(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int64_t n_wf, int* err,
+                                             int blocks, int threads, int lds_bytes, hipStream_t stream);
+extern "C" const char* dsp_internal_energy_rr_kernel_name();
 
 namespace {
 
@@ -723,8 +726,8 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy v3 kernel launch failed: %s", hipGetErrorString(e));
         return DSP_OK;
     }
-    if (ch->ilp_ok && ch->fused_on && (ch->variant == 4 || ch->variant == 5) && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
-        // straight-line variant: variant 4 = one replay chain per lane, 5 = two
+    if (ch->ilp_ok && ch->fused_on && (ch->variant == 4 || ch->variant == 5 || ch->variant == 6) && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
+        // straight-line variants: 4 = one replay chain per lane, 5 = two, 6 = register-resident chunk
         EnergyArgs F = ch->ilp;
         F.wf = io_ptrs[ch->io_wf];
         F.bl = ch->io_bl >= 0 ? (const float*)io_ptrs[ch->io_bl] : nullptr;
@@ -738,8 +741,11 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         if (per_cu < 1) per_cu = 1;
         int64_t want = (n_wf + wpb - 1) / wpb, cap = (int64_t)ch->num_cu * per_cu;
         const int iblocks = (int)(want < cap ? want : cap);
-        hipError_t e = (hipError_t)dsp_internal_launch_energy_sl(&F, &ch->plan[S == 2 ? 0 : 2], ch->fused_trap, ch->fused_npf, S, n_wf,
-                                                                 ch->dev_err, iblocks, 64 * wpb, ch->ilp_lds_bytes * wpb, (hipStream_t)stream);
+        hipError_t e = ch->variant == 6
+                           ? (hipError_t)dsp_internal_launch_energy_rr(&F, &ch->plan[2], ch->fused_trap, ch->fused_npf, n_wf, ch->dev_err, iblocks,
+                                                                       64 * wpb, ch->ilp_lds_bytes * wpb, (hipStream_t)stream)
+                           : (hipError_t)dsp_internal_launch_energy_sl(&F, &ch->plan[S == 2 ? 0 : 2], ch->fused_trap, ch->fused_npf, S, n_wf,
+                                                                       ch->dev_err, iblocks, 64 * wpb, ch->ilp_lds_bytes * wpb, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy straight-line kernel launch failed: %s", hipGetErrorString(e));
         return DSP_OK;
     }
@@ -823,6 +829,7 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
 
 const char* dsp_chain_kernel_name(dsp_chain* ch) {
     if (ch && ch->ilp_ok && ch->fused_on && ch->variant == 3) return dsp_internal_energy_v3_kernel_name();
+    if (ch && ch->ilp_ok && ch->fused_on && ch->variant == 6) return dsp_internal_energy_rr_kernel_name();
     if (ch && ch->ilp_ok && ch->fused_on && (ch->variant == 4 || ch->variant == 5)) return dsp_internal_energy_sl_kernel_name();
     if (ch && ch->ilp_ok && ch->fused_on && ch->variant != 1) return dsp_internal_energy_ilp_kernel_name();
     return (ch && ch->fused_ok && ch->fused_on) ? dsp_internal_energy_kernel_name() : dsp_internal_vm_kernel_name();

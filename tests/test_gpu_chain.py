@@ -25,7 +25,7 @@ def _run_energy(wf, bl, tp, tau, rise, flat, mode="l", fused=True, trap="trap_fi
     return bufs["trapEftp"].to_numpy()
 
 
-@pytest.mark.parametrize("fused", [1, 3, 5, 7, 9, 11, 0])
+@pytest.mark.parametrize("fused", [1, 3, 5, 7, 9, 11, 13, 0])
 def test_energy_chain_golden(fused):
     c2 = cases("chains")[1]
     p = c2.params
@@ -38,7 +38,7 @@ def test_energy_chain_golden(fused):
     assert rel.max() <= TOL
 
 
-@pytest.mark.parametrize("fused", [1, 3, 5, 7, 9, 11, 0])
+@pytest.mark.parametrize("fused", [1, 3, 5, 7, 9, 11, 13, 0])
 @pytest.mark.parametrize("wf_len,rise,flat", [(4096, 625, 188), (1024, 64, 16), (8192, 1250, 376), (6092, 500, 100), (2048, 300, 7),
                                               (3000, 128, 0), (200, 10, 3)])
 def test_energy_chain_vs_oracle(wf_len, rise, flat, fused):
