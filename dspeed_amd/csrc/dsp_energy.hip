@@ -1305,8 +1305,11 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
         const float* g = (const float*)A.wf + r * A.wf_stride + A.wf_offset;
 #pragma unroll
         for (int b = 0; b < NPF; ++b) pf[b] = reinterpret_cast<const f4*>(g)[b * 64 + lane];
-        pf_bl = A.bl ? A.bl[r * A.bl_stride] : A.bl_const;
-        pf_tp = A.tp ? A.tp[r * A.tp_stride] : A.tp_const;
+        // (address space 1 spelled out: a pointer that went through a null test is otherwise loaded with flat_load, whose
+        // out-of-order return forces every LDS wait that follows it down to lgkmcnt(0))
+        typedef const __attribute__((address_space(1))) float* gptr;
+        pf_bl = A.bl ? ((gptr)A.bl)[r * A.bl_stride] : A.bl_const;
+        pf_tp = A.tp ? ((gptr)A.tp)[r * A.tp_stride] : A.tp_const;
     };
     auto report = [&](int code, int64_t r) {
         if (lane == 0 && atomicCAS(&err[0], 0, code) == 0) {
@@ -1405,13 +1408,28 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     double Ak[3];
+                    float pbase[3], pv[3][8];
+                    int pn[3];
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         int r = PL.cs[k][s] * CS + PL.local[k][s];  // samples of the source lane's chunk before the capture point
                         // opaque to the optimiser: otherwise every mask derived from the (row-invariant) plan is hoisted out of the
                         // row loop and the kernel drowns in spilled SGPR pairs
                         asm volatile("" : "+s"(r));
-                        Ak[k] = wave_shift_up(Ep + (double)prefix_at(r), PL.shift[k][s]);
+                        const int gi = (r > 0 ? r - 1 : 0) >> 3;  // group that contains sample r-1
+                        pn[k] = r - 8 * gi;                        // 0..8 samples of group gi (gi == NG: the odd sample)
+                        const float b = aux[gi > 0 ? gi - 1 : 0];
+                        pbase[k] = gi > 0 ? b : 0.0f;
+                        const float* p = mine + 8 * gi;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) pv[k][u] = p[u];  // (reads at most 7 past the chunk: inside the slot tail)
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        float part = 0.0f;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) part += (u < pn[k]) ? pv[k][u] : 0.0f;
+                        Ak[k] = wave_shift_up(Ep + (double)(pbase[k] + part), PL.shift[k][s]);
                     }
                     const double own = Ep + (s ? (double)aux[s * NGS - 1] : 0.0);
                     double Gd;
@@ -1427,6 +1445,22 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
                 PHASE(3)
                 // ---- pass 3: replay; own samples from registers, the three lagged streams software-pipelined one 8-sample group ahead
                 wave_sync();  // the prefix sums in aux are consumed; aux now receives the replay state at every group start
+                // the two samples every pick-off mode needs (floor and ceil of the time point) are caught on the fly: stage numbers
+                const int i0 = (int)t_in;
+                int capst[2], capoff[2], caplane[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int e = i0 + k;
+                    const bool ok = e >= 0 && e < len;
+                    caplane[k] = ok ? e / C : 0;
+                    capoff[k] = ok ? e - caplane[k] * C : 0;
+                    capst[k] = ok ? capoff[k] >> 4 : -1;  // 16-sample block of the chunk; block (C-1)/16 (never reached) = the odd sample
+                }
+                // one test per 16 samples (a not-taken branch still costs tens of cycles): bit q set = block q holds a wanted sample
+                int capmask = (capst[0] >= 0 ? 1 << capst[0] : 0) | (capst[1] >= 0 ? 1 << capst[1] : 0);
+                asm volatile("" : "+s"(capmask));  // one live scalar, not a recomputation at each test
+                float* capbuf = slot + 64 * C + 16 + 64 * AUXP;  // 2 x 16 floats per wavefront, written by the lane that owns the sample
+                float ys16[16];
                 constexpr int GL = 4, NL = (C - 1) / GL;  // samples per pipeline stage of the lagged streams (registers: 2 x 3 x GL)
                 float lb[2][GL][3], lodd[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -1448,8 +1482,18 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
                     if ((gl * GL) % 8 == 0) aux[(gl * GL) / 8] = y[0];
                     __builtin_amdgcn_sched_barrier(0);  // the reads just issued are younger than the stage consumed next: a counted wait
 #pragma unroll
-                    for (int u = 0; u < GL; ++u)
+                    for (int u = 0; u < GL; ++u) {
                         y[0] = trap_step<float, KIND>(y[0], xr[gl * GL + u], lb[gl & 1][u][0], lb[gl & 1][u][1], lb[gl & 1][u][2], A.rr, A.ll);
+                        ys16[(gl & 3) * GL + u] = y[0];
+                    }
+                    if ((gl & 3) == 3 && (capmask & (1 << (gl >> 2)))) {  // uniform, taken at most twice per waveform
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+                            if (capst[k] == (gl >> 2) && lane == caplane[k]) {
+#pragma unroll
+                                for (int u = 0; u < 16; ++u) capbuf[k * 16 + u] = ys16[u];
+                            }
+                    }
                 }
                 aux[NG] = y[0];  // state before the odd sample
                 y[0] = trap_step<float, KIND>(y[0], xr[C - 1], lodd[0], lodd[1], lodd[2], A.rr, A.ll);
@@ -1464,13 +1508,21 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
                 }
                 const double T0 = wave_exscan_add(Dtot);
                 // ---- wanted samples: re-run the one 8-sample group that contains each of them from its saved start state
-                const int i0 = (int)t_in;
                 const bool wide = (A.mode == 'h');
                 float w4[4];
+                {
+                    const double delta = T0 - (double)g[0];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < 2; ++k) {
+                        float v = capbuf[k * 16 + (capoff[k] & 15)];  // (stale when the sample is the odd one or out of range: not used then)
+                        v = capoff[k] == C - 1 ? y[0] : v;
+                        w4[1 + k] = capst[k] >= 0 ? readlane((float)((double)v + delta), caplane[k]) : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k += 3) {  // the outer two samples of the 4-point mode: re-run their 8-sample group
                     const int e = i0 - 1 + k;
-                    const bool need = ((k == 1) || (k == 2) || wide) && e >= 0 && e < len;
+                    const bool need = wide && e >= 0 && e < len;
                     w4[k] = 0.0f;
                     __builtin_amdgcn_sched_barrier(0);
                     if (need) {  // uniform

@@ -613,7 +613,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 int guard = 2 * Ci + 8;
                 guard = ((guard + 3) / 4) * 4;
                 I.slot_off = guard;
-                int elems = guard + 64 * Ci + 16 + 64 * 9 + 8;  // slot, tail, per-lane side array of the straight-line variant
+                int elems = guard + 64 * Ci + 16 + 64 * 9 + 32;  // slot, tail, per-lane side array and capture buffer of the straight-line variants
                 elems = ((elems + 3) / 4) * 4;
                 I.lds_elems_per_wave = elems;
                 ch->ilp_lds_bytes = elems * 4;
