@@ -1335,6 +1335,10 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
     if (row < n_wf) prefetch(row);
     const bool stamps = (A.ablate & 8) != 0;
     unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = stamps ? stamp() : 0;
+    // a row's result is stored one iteration late, behind the next prefetch: vmcnt counts stores too, so a store issued
+    // at the end of the loop body would sit (a full write latency) in front of the s_waitcnt vmcnt(0) that opens the next staging
+    float pend_result = 0.0f;
+    int64_t pend_row = -1;
 
     for (; row < n_wf; row += stride_rows) {
 #pragma unroll
@@ -1344,6 +1348,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
         const int64_t next = row + stride_rows;
         __builtin_amdgcn_sched_barrier(0);
         if (next < n_wf) prefetch(next);
+        if (pend_row >= 0 && lane == 0) A.out[pend_row * A.out_stride] = pend_result;
         __builtin_amdgcn_sched_barrier(0);
         wave_sync();
         PHASE(0)
@@ -1382,7 +1387,9 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
             for (int t = 0; t < C; ++t) {
                 if ((t & 7) == 0) __builtin_amdgcn_sched_barrier(0);
                 const double x = (double)xr[t];
-                acc = (acc + x) - xp * c;
+                // acc_k = acc_{k-1} + (x_k - c x_{k-1}); the float64 association differs from the reference's (acc + x) - xp*c by
+                // <= 1 ulp of a double (the chunk carry already does), invisible after the float32 store; the chain is one add long
+                acc += __builtin_fma(-c, xp, x);
                 const float y = (float)acc;
                 xr[t] = y;
                 mine[t] = y;  // other lanes read it with a lag
@@ -1556,10 +1563,12 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
                 if (fc) report(fc, row);
             }
         }
-        if (lane == 0) A.out[row * A.out_stride] = result;
+        pend_result = result;
+        pend_row = row;
         wave_sync();
         PHASE(5)
     }
+    if (pend_row >= 0 && lane == 0) A.out[pend_row * A.out_stride] = pend_result;
     if (stamps && lane == 0) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(err + 4) + i, tsum[i]);

@@ -134,7 +134,9 @@ struct dsp_chain {
     int fused_trap = 0, fused_npf = 0;
     // ILP variant (S sub-chains per lane, pad-free LDS): the default for 1024/2048/4096-sample energy chains
     bool ilp_ok = false;
-    int variant = 1;  // 1: one chain per lane (default: fastest so far), 0: 2 sub-chains per lane (pad-free LDS), 2: 4 sub-chains
+    // 6: register-resident straight-line kernel (default where it applies), 1: classic one-chain-per-lane kernel (the only one for
+    // 8192 samples), 0 / 2: 2 / 4 sub-chains per lane, 3: v3, 4 / 5: straight line from LDS with 1 / 2 replay chains -- kept for A/B runs
+    int variant = 1;
     EnergyArgs ilp{};
     EnergyPlan plan[3]{};  // [0]: S=2, [1]: S=4, [2]: S=1
     int ilp_lds_bytes = 0;
@@ -659,6 +661,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                     }
                 }
                 ch->ilp_ok = true;
+                ch->variant = 6;
                 if (const char* venv = getenv("DSPEED_HIP_VARIANT")) ch->variant = atoi(venv);
             }
         }
@@ -838,8 +841,10 @@ const char* dsp_chain_kernel_name(dsp_chain* ch) {
 int dsp_chain_set_fused(dsp_chain* ch, int enable) {
     if (!ch) return fail(DSP_ERR_ARG, "null chain");
     ch->fused_on = (enable & 1) != 0;   // bit 0: use a specialised kernel
-    ch->variant = (enable >> 1) & 7;    // bits 1-3: kernel variant: 0 = default, 1 = ILP S=2, 2 = ILP S=4, 3 = v3, 4/5 = straight line S=1/2
-    ch->variant = ch->variant == 0 ? 1 : (ch->variant == 1 ? 0 : ch->variant);
+    // bits 1-3: kernel variant for A/B runs: 0 = default (register-resident where it applies), 1 = ILP S=2, 2 = ILP S=4, 3 = v3,
+    // 4/5 = straight line S=1/2, 6 = register-resident, 7 = classic
+    const int v = (enable >> 1) & 7;
+    ch->variant = v == 0 ? (ch->ilp_ok ? 6 : 1) : (v == 1 ? 0 : (v == 7 ? 1 : v));
     return ((ch->fused_ok || ch->ilp_ok) && ch->fused_on) ? 1 : 0;
 }
 

@@ -25,7 +25,7 @@ def _run_energy(wf, bl, tp, tau, rise, flat, mode="l", fused=True, trap="trap_fi
     return bufs["trapEftp"].to_numpy()
 
 
-@pytest.mark.parametrize("fused", [1, 3, 5, 7, 9, 11, 13, 0])
+@pytest.mark.parametrize("fused", [1, 3, 5, 7, 9, 11, 13, 15, 0])
 def test_energy_chain_golden(fused):
     c2 = cases("chains")[1]
     p = c2.params
@@ -38,7 +38,7 @@ def test_energy_chain_golden(fused):
     assert rel.max() <= TOL
 
 
-@pytest.mark.parametrize("fused", [1, 3, 5, 7, 9, 11, 13, 0])
+@pytest.mark.parametrize("fused", [1, 3, 5, 7, 9, 11, 13, 15, 0])
 @pytest.mark.parametrize("wf_len,rise,flat", [(4096, 625, 188), (1024, 64, 16), (8192, 1250, 376), (6092, 500, 100), (2048, 300, 7),
                                               (3000, 128, 0), (200, 10, 3)])
 def test_energy_chain_vs_oracle(wf_len, rise, flat, fused):
@@ -74,17 +74,18 @@ def test_energy_chain_matches_unfused_processors():
     wf = (10000 + 3000 * (np.arange(wf_len)[None, :] > 2000) + 5 * rng.standard_normal((n_wf, wf_len))).astype(np.float32)
     bl = np.full(n_wf, 10000, dtype=np.float32)
     tp = np.full(n_wf, 2000 + 625 + 150.4, dtype=np.float32)
-    # fused in (1, 0) use the same chunking as the single processors -> identical bits; the sub-chain variants (3, 5) replay the
-    # rounding sequence over shorter chunks -> equal within the filter tolerance
+    # the classic kernel (15) and the VM (0) use the same chunking as the single processors -> identical bits; the default
+    # register-resident kernel (1 = 13) and the other variants replay the rounding sequence over different chunks -> equal within
+    # the filter tolerance
     step = P.fixed_time_pickoff(P.trap_filter(P.pole_zero(P.bl_subtract(wf, bl), 1716.28), 625, 188), tp, ord("l"))
-    for fused in (1, 0):
+    for fused in (15, 0):
         assert np.array_equal(_run_energy(wf, bl, tp, 1716.28, 625, 188, fused=fused), step)
-    for fused in (3, 5, 7, 9, 11):
+    for fused in (1, 3, 5, 7, 9, 11, 13):
         assert np.max(np.abs(_run_energy(wf, bl, tp, 1716.28, 625, 188, fused=fused) - step) / np.abs(step)) <= TOL
     step = P.fixed_time_pickoff(P.trap_norm(P.pole_zero(P.bl_subtract(wf, bl), 1716.28), 625, 188), tp, ord("h"))
-    for fused in (1, 0):
+    for fused in (15, 0):
         assert np.array_equal(_run_energy(wf, bl, tp, 1716.28, 625, 188, mode="h", fused=fused, trap="trap_norm"), step)
-    for fused in (3, 5, 7, 9, 11):
+    for fused in (1, 3, 5, 7, 9, 11, 13):
         assert np.max(np.abs(_run_energy(wf, bl, tp, 1716.28, 625, 188, mode="h", fused=fused, trap="trap_norm") - step) / np.abs(step)) <= TOL
 
 
@@ -95,7 +96,7 @@ def test_data_dependent_fatal_reports_row():
     bl = np.zeros(10, dtype=np.float32)
     tp = np.full(10, 100.0, dtype=np.float32)
     tp[6] = 100.5
-    for fused in (1, 3, 5, 7, 9, 11, 0):
+    for fused in (1, 3, 5, 7, 9, 11, 13, 15, 0):
         with pytest.raises(DSPFatal) as ei:
             _run_energy(wf, bl, tp, 100.0, 16, 8, "i", fused=fused)
         assert ei.value.wf_range == range(6, 7)
