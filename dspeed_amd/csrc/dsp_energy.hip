@@ -2,18 +2,19 @@
 //
 //     waveform --bl_subtract--> --pole_zero--> --trap_filter|trap_norm|asym_trap--> fixed_time_pickoff --> 1 float
 //
-// Same arithmetic as the generic waveform VM (dsp_vm.hip) -- the host selects this kernel when a chain has exactly
-// this shape -- but organised for the HBM roofline:
-//   * the next waveform's 16 KB are already in flight (16-byte global loads into registers) while the current one
-//     is being filtered, so HBM latency is hidden behind the arithmetic of the same wavefront;
-//   * bl_subtract is folded into the pole-zero passes, the float64 prefix sums the trapezoid needs are produced by
-//     the pole-zero pass itself, and the trapezoid output is never stored (only the picked-off samples are kept):
-//     per waveform the LDS sees 2 writes and 6 reads per sample instead of 4 and 9;
-//   * every chunk loop is software-pipelined in groups of 8 samples (the next group's LDS reads are issued before
-//     the current group's dependent arithmetic).
-// One wavefront per waveform, lane j owns samples [jC, (j+1)C), LDS pitch C+1, zero guard of 2 pitches below the slot
-// (layout identical to a VM slot).  Reference bodies: processors/bl_subtract.py:11-46, pole_zero.py:24-77,
-// trap_filters.py:12-227, fixed_time_pickoff.py:12-125.
+// Same arithmetic as the generic waveform VM (dsp_vm.hip) -- the host selects these kernels when a chain has exactly this
+// shape.  One wavefront per waveform, lane j owns a chunk of consecutive samples, the next waveform's 16 KB are already in
+// flight (16-byte global loads into registers) while the current one is filtered, and the trapezoid output is never stored
+// (only the picked-off samples are kept).  Two kernels:
+//   * dsp_energy_rr_kernel ("register resident", the default for 1024/2048/4096 samples): pad-free LDS image (sample i at
+//     element i, C = len/64 + 1 samples per lane: an odd lane stride, so every "offset t of my chunk" access is
+//     conflict-free), every pass over the chunk fully unrolled (immediate LDS offsets, counted waits), the lane's own chunk
+//     in VGPRs from the staging to the end of the replay.  Per sample the LDS sees 2 writes (staging, pole-zero output) and
+//     4 reads (own chunk once, three lagged trapezoid streams).
+//   * dsp_energy_kernel ("classic"): the VM's slot layout (C = len/64, pitch C + 1, zero guard of 2 pitches below the slot),
+//     chunk loops software-pipelined in groups of 8 samples.  Bit-identical to the VM; kept as the cross-check of the
+//     default kernel and for A/B measurements (set_fused(15)).
+// Reference bodies: processors/bl_subtract.py:11-46, pole_zero.py:24-77, trap_filters.py:12-227, fixed_time_pickoff.py:12-125.
 #include <hip/hip_runtime.h>
 
 #include "dsp_program.h"
@@ -328,18 +329,9 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
 }
 
 // ------------------------------------------------------------------------------------------------
-// ILP variant: S independent sub-chains per lane, linear (pad-free) LDS layout.
-//
-// The one-chunk-per-lane kernel above is latency bound: each lane walks one dependent chain (2 float64 operations per
-// sample in the pole-zero pass, 4 float32 additions per sample in the trapezoid replay) and only two wavefronts share a
-// SIMD.  Here every lane owns C = 4*NPF + 1 samples (an ODD count, so the lane stride is odd and the waveform can sit in
-// LDS exactly as it sits in memory: no chunk pads, lagged streams are plain contiguous reads, staging is one 16-byte
-// store per load) and walks them as S interleaved sub-chains of CS = (C-1)/S samples (the last one also takes sample
-// C-1).  Each sub-chain has its own pole-zero carry (from the float64 prefix sums of pass 1) and its own speculative
-// trapezoid carry, so S dependent chains are in flight per lane.  Same arithmetic per sample as everywhere else.
-//
-// Host-provided plan (EnergyPlan): for every (lag k, sub-chain s) where the prefix value the carry needs lives:
-// `shift` lanes below, after `r` samples of that lane's chunk, i.e. in sub-chain cs after `local` samples of it.
+// Capture plan of the pad-free layout (C = len/64 + 1 samples per lane, sample i at LDS element i): for lag k and replay
+// sub-chain s the speculative carry needs the prefix sum `local` samples into sub-chain `cs` of the lane `shift` below.
+// Row-invariant, built by the host (dsp_host.cpp).
 // ------------------------------------------------------------------------------------------------
 struct EnergyPlan {
     int32_t shift[3][4];  // lane distance
@@ -347,936 +339,30 @@ struct EnergyPlan {
     int32_t local[3][4];  // capture after `local` samples of that sub-chain (0: nothing of it)
 };
 
-template <int NPF, int KIND, int S>
-__global__ void __launch_bounds__(256, 2) dsp_energy_ilp_kernel(EnergyArgs A, EnergyPlan PL, int64_t n_wf, int* err) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int C = 4 * NPF + 1, len = 256 * NPF, CS = (C - 1) / S, GQ = 4;
-    static_assert(CS % GQ == 0, "sub-chain length must be a multiple of the group size");
-    const int lane = lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
-    float* lds = reinterpret_cast<float*>(smem_raw) + (size_t)wave * A.lds_elems_per_wave;
-    for (int e = lane; e < A.lds_elems_per_wave; e += 64) lds[e] = 0.0f;
-    wave_sync();
-    float* slot = lds + A.slot_off;  // sample i of the waveform lives at slot[i]; zeros below (guard) and above len
-    float* mine = slot + lane * C;
-
-    // lagged streams: sample (lane*C + t - L_k) = lagp[k][t]; lanes whose whole range is before sample 0 read the zero guard
-    const float* lagp[3];
-    int L[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        L[k] = A.q[k];  // for this kernel the host passes the lags themselves in q[]
-        const int pos0 = lane * C - L[k];
-        lagp[k] = (pos0 >= -C) ? slot + pos0 : slot - (2 * C + 8);
-    }
-
-    const int64_t stride_rows = (int64_t)gridDim.x * wpb;
-    int64_t row = (int64_t)blockIdx.x * wpb + wave;
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    f4 pf[NPF];
-    float pf_bl = 0.0f, pf_tp = 0.0f;
-    auto prefetch = [&](int64_t r) {
-        const float* g = (const float*)A.wf + r * A.wf_stride + A.wf_offset;
-#pragma unroll
-        for (int b = 0; b < NPF; ++b) pf[b] = reinterpret_cast<const f4*>(g)[b * 64 + lane];
-        pf_bl = A.bl ? A.bl[r * A.bl_stride] : A.bl_const;
-        pf_tp = A.tp ? A.tp[r * A.tp_stride] : A.tp_const;
-    };
-    auto report = [&](int code, int64_t r) {
-        if (lane == 0 && atomicCAS(&err[0], 0, code) == 0) {
-            err[1] = (int)(r & 0xffffffffll);
-            err[2] = (int)(r >> 32);
-        }
-    };
-    if (row < n_wf) prefetch(row);
-    const bool stamps = (A.ablate & 8) != 0;
-    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = stamps ? stamp() : 0;
-
-    for (; row < n_wf; row += stride_rows) {
-        // ---- stage: the waveform goes to LDS as it is (16-byte stores)
-#pragma unroll
-        for (int b = 0; b < NPF; ++b) *reinterpret_cast<f4*>(slot + (b * 64 + lane) * 4) = pf[b];
-        slot[len + lane] = pf_bl;  // the 64 virtual samples above len hold the baseline: x = w - baseline = 0 exactly (re-set per row)
-        const float bl = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pf_bl)));
-        const float t_in = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pf_tp)));
-        const int64_t next = row + stride_rows;
-        __builtin_amdgcn_sched_barrier(0);
-        if (next < n_wf) prefetch(next);
-        __builtin_amdgcn_sched_barrier(0);
-        wave_sync();
-        PHASE(0)
-
-        float result = quiet_nan<float>();
-        // ---- pass 1: float64 sums of x = w - baseline per sub-chain
-        double X[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) X[s] = 0.0;
-#pragma unroll 1
-        for (int t = 0; t < CS; t += GQ) {
-            float v[S][GQ];
-#pragma unroll
-            for (int s = 0; s < S; ++s) load_group(v[s], mine + s * CS + t);
-#pragma unroll
-            for (int u = 0; u < GQ; ++u)
-#pragma unroll
-                for (int s = 0; s < S; ++s) X[s] += (double)(v[s][u] - bl);
-        }
-        X[S - 1] += (double)(mine[C - 1] - bl);
-        double Xtot = 0.0;
-#pragma unroll
-        for (int s = 0; s < S; ++s) Xtot += X[s];
-        bool in_nan = A.tau_nan != 0;
-        if (wave_any(!(fabs(Xtot) <= 1.7976931348623157e308))) {
-            bool n = false;
-            for (int t = 0; t < C; ++t) {
-                const float x = mine[t] - bl;
-                n |= (x != x);
-            }
-            in_nan |= wave_any(n);
-        }
-        PHASE(1)
-        if (!in_nan) {
-            const double E0 = wave_exscan_add(Xtot);
-            // ---- pass 2: S interleaved pole-zero chains, output in place, float32 running sums for the trapezoid carries
-            const double c = A.c;
-            double acc[S], xp[S];
-            float run[S], capr[3][S];
-            int capg[3][S], capsel[3][S];  // group of pass 2 that completes the capture, and which (sub-chain, sample) of it
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const int lc = PL.local[k][s];
-                    capg[k][s] = lc > 0 ? (lc - 1) / GQ : -1;
-                    capsel[k][s] = PL.cs[k][s] * GQ + (lc > 0 ? (lc - 1) % GQ : 0);
-                }
-            {
-                double Es = E0;
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const int at = lane * C + s * CS;  // first sample of the sub-chain
-                    const float xprev = (at > 0) ? mine[s * CS - 1] - bl : 0.0f;
-                    xp[s] = (double)xprev;
-                    acc[s] = Es - c * (Es - xp[s]);
-                    Es += X[s];
-                    run[s] = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) capr[k][s] = 0.0f;
-                }
-            }
-            auto pz_step = [&](int s, float raw) -> float {
-                const double x = (double)(raw - bl);
-                acc[s] = (acc[s] + x) - xp[s] * c;
-                const float y = (float)acc[s];
-                xp[s] = x;
-                run[s] += y;
-                return y;
-            };
-#pragma unroll 1
-            for (int t = 0; t < CS; t += GQ) {
-                float v[S][GQ], rs[S][GQ];
-#pragma unroll
-                for (int s = 0; s < S; ++s) load_group(v[s], mine + s * CS + t);
-#pragma unroll
-                for (int u = 0; u < GQ; ++u)
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        const float y = pz_step(s, v[s][u]);
-                        mine[s * CS + t + u] = y;
-                        rs[s][u] = run[s];
-                    }
-                // prefix captures that fall into this group (positions fixed by the lag geometry)
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        if (capg[k][s] * GQ == t) {
-#pragma unroll
-                            for (int s2 = 0; s2 < S; ++s2)
-#pragma unroll
-                                for (int u = 0; u < GQ; ++u)
-                                    if (capsel[k][s] == s2 * GQ + u) capr[k][s] = rs[s2][u];
-                        }
-                    }
-            }
-            {
-                const float y = pz_step(S - 1, mine[C - 1]);
-                mine[C - 1] = y;
-            }
-            wave_sync();
-            PHASE(2)
-            float runtot = 0.0f, runbefore[S];
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                runbefore[s] = runtot;
-                runtot += run[s];
-            }
-            bool pz_nan = false;
-            if (wave_any(!(fabsf(runtot) <= 3.4028234663852886e38f))) {
-                bool n = false;
-                for (int t = 0; t < C; ++t) {
-                    const float y = mine[t];
-                    n |= (y != y);
-                }
-                pz_nan = wave_any(n);
-            }
-            if (pz_nan) {
-                report(DSP_E_PZ_NAN, row);
-            } else if (!A.all_nan && !(A.ablate & 4) && pickoff_in_range(t_in, len)) {
-                // ---- speculative carry of every sub-chain
-                const double Ep = wave_exscan_add((double)runtot);
-                float g[S], y[S];
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    double Ak[3];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        // prefix up to the capture point in the lane `shift` below: sub-chains before cs in full, cs partially
-                        float part = capr[k][s];
-#pragma unroll
-                        for (int s2 = 0; s2 < S; ++s2)
-                            if (PL.cs[k][s] > s2) part += run[s2];
-                        Ak[k] = wave_shift_up(Ep + (double)part, PL.shift[k][s]);
-                    }
-                    const double own = Ep + (double)runbefore[s];
-                    double Gd;
-                    if (KIND == TRAP_FILTER)
-                        Gd = ((own - Ak[0]) - Ak[1]) + Ak[2];
-                    else if (KIND == TRAP_NORM)
-                        Gd = (((own - Ak[0]) - Ak[1]) + Ak[2]) / A.rr;
-                    else
-                        Gd = (own - Ak[0]) / A.rr - (Ak[1] - Ak[2]) / A.ll;
-                    g[s] = (lane == 0 && s == 0) ? -0.0f : (float)Gd;
-                    y[s] = g[s];
-                }
-                // ---- wanted samples (uniform): i0-1 .. i0+2
-                const int i0 = (int)t_in;
-                const bool wide = (A.mode == 'h');
-                int cl[4], cch[4], cloc[4];  // owning lane, sub-chain, sample within the sub-chain (CS = its tail step)
-                float capv[4];
-                unsigned capmask = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int e = i0 - 1 + k;
-                    const bool need = ((k == 1) || (k == 2) || wide) && e >= 0 && e < len;
-                    const int l = need ? e / C : -1;
-                    const int off = need ? e - l * C : 0;
-                    int ch = off / CS;
-                    if (ch > S - 1) ch = S - 1;
-                    cl[k] = l;
-                    cch[k] = ch;
-                    cloc[k] = need ? off - ch * CS : -1000;
-                    capv[k] = 0.0f;
-                    if (need && cloc[k] < CS) capmask |= 1u << (cloc[k] / GQ);
-                }
-                PHASE(3)
-                // ---- pass 3: S interleaved replays of the reference's float32 rounding sequence
-#pragma unroll 1
-                for (int t = 0; t < CS; t += GQ) {
-                    float o[S][GQ], l0[S][GQ], l1[S][GQ], l2[S][GQ], ys[S][GQ];
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        load_group(o[s], mine + s * CS + t);
-                        load_group(l0[s], lagp[0] + s * CS + t);
-                        if (A.ablate & 16) {  // timing experiment: half the lagged LDS traffic
-#pragma unroll
-                            for (int u = 0; u < GQ; ++u) l1[s][u] = l2[s][u] = 0.0f;
-                        } else {
-                            load_group(l1[s], lagp[1] + s * CS + t);
-                            load_group(l2[s], lagp[2] + s * CS + t);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < GQ; ++u)
-#pragma unroll
-                        for (int s = 0; s < S; ++s) {
-                            y[s] = trap_step<float, KIND>(y[s], o[s][u], l0[s][u], l1[s][u], l2[s][u], A.rr, A.ll);
-                            ys[s][u] = y[s];
-                        }
-                    if ((capmask >> (t / GQ)) & 1u) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int d = cloc[k] - t;
-#pragma unroll
-                            for (int s = 0; s < S; ++s)
-#pragma unroll
-                                for (int u = 0; u < GQ; ++u)
-                                    if (cch[k] == s && d == u) capv[k] = ys[s][u];
-                        }
-                    }
-                }
-                {
-                    const int tt = C - 1;  // the odd sample continues the last sub-chain
-                    y[S - 1] = trap_step<float, KIND>(y[S - 1], mine[tt], lagp[0][tt], lagp[1][tt], lagp[2][tt], A.rr, A.ll);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (cloc[k] == CS && cch[k] == S - 1) capv[k] = y[S - 1];
-                }
-                PHASE(4)
-                // ---- true carries: exact scan of the increments, per lane then across lanes
-                double D[S], Dtot = 0.0, Dbefore[S];
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    D[s] = (double)y[s] - (double)g[s];
-                    Dbefore[s] = Dtot;
-                    Dtot += D[s];
-                }
-                const double T0 = wave_exscan_add(Dtot);
-                float w4[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    double delta = 0.0;
-#pragma unroll
-                    for (int s = 0; s < S; ++s)
-                        if (cch[k] == s) delta = (T0 + Dbefore[s]) - (double)g[s];
-                    const float v = (float)((double)capv[k] + delta);
-                    w4[k] = cl[k] >= 0 ? readlane(v, cl[k]) : 0.0f;
-                }
-                int fc = 0;
-                result = pickoff_eval(t_in, A.mode, len, w4, fc);
-                if (fc) report(fc, row);
-            }
-        }
-        if (lane == 0) A.out[row * A.out_stride] = result;
-        wave_sync();
-        PHASE(5)
-    }
-    if (stamps && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(err + 4) + i, tsum[i]);
-    }
-}
-
-template <int KIND, int S>
-int launch_ilp_kind(const EnergyArgs& A, const EnergyPlan& PL, int npf, int64_t n_wf, int* err, int blocks, int threads, int lds_bytes,
-                    hipStream_t st) {
-    switch (npf) {
-        case 4: hipLaunchKernelGGL((dsp_energy_ilp_kernel<4, KIND, S>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
-        case 8: hipLaunchKernelGGL((dsp_energy_ilp_kernel<8, KIND, S>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
-        case 16: hipLaunchKernelGGL((dsp_energy_ilp_kernel<16, KIND, S>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
-        default: return (int)hipErrorInvalidValue;
-    }
-    return (int)hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------------------------
-// "v3": pad-free LDS image with an EVEN lane stride C = 4*NPF + 2 = 2*odd, every chunk access 64 bits wide.
+// "rr" (register resident) kernel.
 //
-// What the measurements above say: the pole-zero passes run near the float64 issue rate whatever the structure, the
-// trapezoid replay is latency bound (helped by 2 interleaved sub-chains), and the LDS pipe is the most loaded unit
-// (55 % busy, mostly 32-bit accesses at 128 B/clk).  So: one chain per lane for passes 1 and 2, two sub-chains for the
-// replay, and all chunk traffic as ds_read_b64 / ds_write_b64 (256 B/clk reads).  With a stride of 2*odd dwords the 32 lanes of
-// a half-wave cover all 64 banks with their 8-byte accesses; lagged streams are contiguous (no pads); a stream whose lag is
-// odd starts on an odd dword, so it is fetched from the aligned dword below and consumed one register later -- the 8
-// combinations of the three lag parities are 8 static variants of the add chain behind one uniform switch.
-// Lane j owns samples [jC, jC + C); sub-chain 0 = offsets [0, 32*NPF/8...), see CS; the last two samples continue
-// sub-chain 1.  Virtual samples above len hold the baseline (x = 0 exactly).
-// Plan from the host: for (lag k, sub-chain s) the prefix the speculative carry needs = lane `shift` below, after `r` samples.
-// ------------------------------------------------------------------------------------------------
-struct EnergyPlan3 {
-    int32_t shift[3][2];
-    int32_t r[3][2];
-};
-
-typedef float f2v __attribute__((ext_vector_type(2)));
-
-template <int KIND, int P0, int P1, int P2>
-__device__ __forceinline__ void replay4(float (&y)[2], float (&ys)[2][4], const f2v (&own)[2][2], const f2v (&r0)[2][3], const f2v (&r1)[2][3],
-                                        const f2v (&r2)[2][3], double rr, double ll) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const float a = own[s][u >> 1][u & 1];
-            const float b1 = r0[s][(u + P0) >> 1][(u + P0) & 1];
-            const float b2 = r1[s][(u + P1) >> 1][(u + P1) & 1];
-            const float b3 = r2[s][(u + P2) >> 1][(u + P2) & 1];
-            y[s] = trap_step<float, KIND>(y[s], a, b1, b2, b3, rr, ll);
-            ys[s][u] = y[s];
-        }
-}
-
-template <int NPF, int KIND>
-__global__ void __launch_bounds__(256, 2) dsp_energy_v3_kernel(EnergyArgs A, EnergyPlan3 PL, int64_t n_wf, int* err) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int C = 4 * NPF + 2, len = 256 * NPF, CS = (C - 2) / 2, G8 = 8;
-    static_assert(CS % 4 == 0 && (C - 2) % G8 == 0, "chunk geometry");
-    const int lane = lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
-    float* lds = reinterpret_cast<float*>(smem_raw) + (size_t)wave * A.lds_elems_per_wave;
-    for (int e = lane; e < A.lds_elems_per_wave; e += 64) lds[e] = 0.0f;
-    wave_sync();
-    float* slot = lds + A.slot_off;
-    float* mine = slot + lane * C;
-
-    // lagged streams, fetched from the even dword at or below their start (par = lag & 1)
-    const float* lagb[3];
-    int par[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int Lk = A.q[k];
-        par[k] = Lk & 1;
-        const int pos0 = lane * C - Lk - par[k];  // even
-        lagb[k] = (pos0 >= -(C + 2)) ? slot + pos0 : slot - (2 * C + 16);
-    }
-    const int parmask = par[0] | (par[1] << 1) | (par[2] << 2);
-
-    const int64_t stride_rows = (int64_t)gridDim.x * wpb;
-    int64_t row = (int64_t)blockIdx.x * wpb + wave;
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    f4 pf[NPF];
-    float pf_bl = 0.0f, pf_tp = 0.0f;
-    auto prefetch = [&](int64_t r) {
-        const float* g = (const float*)A.wf + r * A.wf_stride + A.wf_offset;
-#pragma unroll
-        for (int b = 0; b < NPF; ++b) pf[b] = reinterpret_cast<const f4*>(g)[b * 64 + lane];
-        pf_bl = A.bl ? A.bl[r * A.bl_stride] : A.bl_const;
-        pf_tp = A.tp ? A.tp[r * A.tp_stride] : A.tp_const;
-    };
-    auto report = [&](int code, int64_t r) {
-        if (lane == 0 && atomicCAS(&err[0], 0, code) == 0) {
-            err[1] = (int)(r & 0xffffffffll);
-            err[2] = (int)(r >> 32);
-        }
-    };
-    if (row < n_wf) prefetch(row);
-    const bool stamps = (A.ablate & 8) != 0;
-    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = stamps ? stamp() : 0;
-
-    // capture points of pass 2 (static): prefix after r samples, r in [0, C)
-    int cap_r[7];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        cap_r[2 * k] = PL.r[k][0];
-        cap_r[2 * k + 1] = PL.r[k][1];
-    }
-    cap_r[6] = CS;  // start of sub-chain 1
-    unsigned cap_groups = 0;  // groups of pass 2 in which some capture completes (one test per group instead of seven)
-#pragma unroll
-    for (int i = 0; i < 7; ++i)
-        if (cap_r[i] >= 1 && cap_r[i] <= C - 2) cap_groups |= 1u << ((cap_r[i] - 1) / G8);
-
-    for (; row < n_wf; row += stride_rows) {
-        // ---- stage: linear image, 16-byte stores; virtual samples above len = baseline
-#pragma unroll
-        for (int b = 0; b < NPF; ++b) *reinterpret_cast<f4*>(slot + (b * 64 + lane) * 4) = pf[b];
-        {
-            const int nv = 64 * C - len;  // 128 for every supported length
-            for (int e = lane; e < nv; e += 64) slot[len + e] = pf_bl;
-        }
-        const float bl = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pf_bl)));
-        const float t_in = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pf_tp)));
-        const int64_t next = row + stride_rows;
-        __builtin_amdgcn_sched_barrier(0);
-        if (next < n_wf) prefetch(next);
-        __builtin_amdgcn_sched_barrier(0);
-        wave_sync();
-        PHASE(0)
-
-        float result = quiet_nan<float>();
-        // ---- pass 1: float64 sum of x = w - baseline over the chunk
-        double X = 0.0;
-        {
-            // software pipelined: the next group's loads are issued before the current group's arithmetic; the loads past the last
-            // group read the (always present) slot tail and are ignored
-            f2v va[4], vb[4];
-            auto ld = [&](f2v (&v)[4], int t) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) v[m] = *reinterpret_cast<const f2v*>(mine + t + 2 * m);
-            };
-            auto sum = [&](const f2v (&v)[4]) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    X += (double)(v[m][0] - bl);
-                    X += (double)(v[m][1] - bl);
-                }
-            };
-            ld(va, 0);
-#pragma unroll 1
-            for (int t = 0; t < C - 2; t += 2 * G8) {
-                ld(vb, t + G8);
-                sum(va);
-                ld(va, t + 2 * G8);
-                sum(vb);
-            }
-            // va now holds offsets C-2 .. C+5: its first pair is the chunk's tail pair
-            X += (double)(va[0][0] - bl);
-            X += (double)(va[0][1] - bl);
-        }
-        bool in_nan = A.tau_nan != 0;
-        if (wave_any(!(fabs(X) <= 1.7976931348623157e308))) {
-            bool n = false;
-            for (int t = 0; t < C; ++t) {
-                const float x = mine[t] - bl;
-                n |= (x != x);
-            }
-            in_nan |= wave_any(n);
-        }
-        PHASE(1)
-        if (!in_nan) {
-            const double E = wave_exscan_add(X);
-            // ---- pass 2: pole-zero recurrence, in place; float32 running sum of the output, captured at the plan's offsets
-            const double c = A.c;
-            const float xprev = (lane > 0) ? mine[-1] - bl : 0.0f;
-            double xp = (double)xprev, acc = E - c * (E - xp);
-            float run = 0.0f, capv2[7];
-#pragma unroll
-            for (int i = 0; i < 7; ++i) capv2[i] = 0.0f;
-            auto pz1 = [&](float raw) -> float {
-                const double x = (double)(raw - bl);
-                acc = (acc + x) - xp * c;
-                const float y = (float)acc;
-                xp = x;
-                run += y;
-                return y;
-            };
-            {
-                f2v va[4], vb[4];
-                auto ld = [&](f2v (&v)[4], int t) {
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) v[m] = *reinterpret_cast<const f2v*>(mine + t + 2 * m);
-                };
-                auto body = [&](const f2v (&v)[4], int t) {
-                    f2v w[4];
-                    float rs[G8];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        w[m][0] = pz1(v[m][0]);
-                        rs[2 * m] = run;
-                        w[m][1] = pz1(v[m][1]);
-                        rs[2 * m + 1] = run;
-                    }
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) *reinterpret_cast<f2v*>(mine + t + 2 * m) = w[m];
-                    if ((cap_groups >> (t / G8)) & 1u) {
-#pragma unroll
-                        for (int i = 0; i < 7; ++i) {
-                            const int d = cap_r[i] - t;  // capture after d samples of this group (1..8)
-#pragma unroll
-                            for (int u = 0; u < G8; ++u)
-                                if (d == u + 1) capv2[i] = rs[u];
-                        }
-                    }
-                };
-                ld(va, 0);
-#pragma unroll 1
-                for (int t = 0; t < C - 2; t += 2 * G8) {
-                    ld(vb, t + G8);
-                    body(va, t);
-                    ld(va, t + 2 * G8);
-                    body(vb, t + G8);
-                }
-                // tail pair (offsets C-2, C-1) = first pair of va
-                f2v w;
-                w[0] = pz1(va[0][0]);
-                const float run_mid = run;
-                w[1] = pz1(va[0][1]);
-                *reinterpret_cast<f2v*>(mine + C - 2) = w;
-#pragma unroll
-                for (int i = 0; i < 7; ++i)
-                    if (cap_r[i] == C - 1) capv2[i] = run_mid;
-            }
-            wave_sync();
-            PHASE(2)
-            bool pz_nan = false;
-            if (wave_any(!(fabsf(run) <= 3.4028234663852886e38f))) {
-                bool n = false;
-                for (int t = 0; t < C; ++t) {
-                    const float y = mine[t];
-                    n |= (y != y);
-                }
-                pz_nan = wave_any(n);
-            }
-            if (pz_nan) {
-                report(DSP_E_PZ_NAN, row);
-            } else if (!A.all_nan && !(A.ablate & 4) && pickoff_in_range(t_in, len)) {
-                // ---- speculative carries of the two sub-chains
-                const double Ep = wave_exscan_add((double)run);
-                float g[2], y[2];
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    double Ak[3];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) Ak[k] = wave_shift_up(Ep + (double)capv2[2 * k + s], PL.shift[k][s]);
-                    const double own = Ep + (s ? (double)capv2[6] : 0.0);
-                    double Gd;
-                    if (KIND == TRAP_FILTER)
-                        Gd = ((own - Ak[0]) - Ak[1]) + Ak[2];
-                    else if (KIND == TRAP_NORM)
-                        Gd = (((own - Ak[0]) - Ak[1]) + Ak[2]) / A.rr;
-                    else
-                        Gd = (own - Ak[0]) / A.rr - (Ak[1] - Ak[2]) / A.ll;
-                    g[s] = (lane == 0 && s == 0) ? -0.0f : (float)Gd;
-                    y[s] = g[s];
-                }
-                // ---- wanted samples (uniform)
-                const int i0 = (int)t_in;
-                const bool wide = (A.mode == 'h');
-                int cl[4], cch[4], cloc[4];  // owning lane, sub-chain, sample within the sub-chain (>= CS: its two tail steps)
-                float capv[4];
-                unsigned capmask = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int e = i0 - 1 + k;
-                    const bool need = ((k == 1) || (k == 2) || wide) && e >= 0 && e < len;
-                    const int l = need ? e / C : -1;
-                    const int off = need ? e - l * C : 0;
-                    const int ch = off >= CS ? 1 : 0;
-                    cl[k] = l;
-                    cch[k] = ch;
-                    cloc[k] = need ? off - ch * CS : -1000;
-                    capv[k] = 0.0f;
-                    if (need && cloc[k] < CS) capmask |= 1u << (cloc[k] >> 2);
-                }
-                PHASE(3)
-                // ---- pass 3: two interleaved replays, groups of 4 samples per sub-chain, all loads 64-bit
-                {
-                    struct Grp {
-                        f2v own[2][2], r0[2][3], r1[2][3], r2[2][3];
-                    };
-                    Grp ga, gb;
-                    auto ld = [&](Grp& q, int t) {
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            const int off = s * CS + t;
-#pragma unroll
-                            for (int m = 0; m < 2; ++m) q.own[s][m] = *reinterpret_cast<const f2v*>(mine + off + 2 * m);
-#pragma unroll
-                            for (int m = 0; m < 3; ++m) {
-                                q.r0[s][m] = *reinterpret_cast<const f2v*>(lagb[0] + off + 2 * m);
-                                q.r1[s][m] = *reinterpret_cast<const f2v*>(lagb[1] + off + 2 * m);
-                                q.r2[s][m] = *reinterpret_cast<const f2v*>(lagb[2] + off + 2 * m);
-                            }
-                        }
-                    };
-                    auto body = [&](const Grp& q, int t) {
-                        float ys[2][4];
-                        switch (parmask) {
-                            case 0: replay4<KIND, 0, 0, 0>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
-                            case 1: replay4<KIND, 1, 0, 0>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
-                            case 2: replay4<KIND, 0, 1, 0>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
-                            case 3: replay4<KIND, 1, 1, 0>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
-                            case 4: replay4<KIND, 0, 0, 1>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
-                            case 5: replay4<KIND, 1, 0, 1>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
-                            case 6: replay4<KIND, 0, 1, 1>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
-                            default: replay4<KIND, 1, 1, 1>(y, ys, q.own, q.r0, q.r1, q.r2, A.rr, A.ll); break;
-                        }
-                        if ((capmask >> (t >> 2)) & 1u) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const int d = cloc[k] - t;
-#pragma unroll
-                                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                                    for (int u = 0; u < 4; ++u)
-                                        if (cch[k] == s && d == u) capv[k] = ys[s][u];
-                            }
-                        }
-                    };
-                    ld(ga, 0);
-#pragma unroll 1
-                    for (int t = 0; t < CS; t += 8) {
-                        ld(gb, t + 4);
-                        body(ga, t);
-                        ld(ga, t + 8);  // past the last group: reads the next sub-chain / slot tail, ignored
-                        body(gb, t + 4);
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {  // the two tail samples continue sub-chain 1
-                    const int tt = 2 * CS + e;
-                    y[1] = trap_step<float, KIND>(y[1], mine[tt], lagb[0][tt + par[0]], lagb[1][tt + par[1]], lagb[2][tt + par[2]], A.rr, A.ll);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (cch[k] == 1 && cloc[k] == CS + e) capv[k] = y[1];
-                }
-                PHASE(4)
-                // ---- true carries: exact scan of the increments
-                const double D0 = (double)y[0] - (double)g[0], D1 = (double)y[1] - (double)g[1];
-                const double T0 = wave_exscan_add(D0 + D1);
-                float w4[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const double delta = cch[k] ? (T0 + D0) - (double)g[1] : T0 - (double)g[0];
-                    const float v = (float)((double)capv[k] + delta);
-                    w4[k] = cl[k] >= 0 ? readlane(v, cl[k]) : 0.0f;
-                }
-                int fc = 0;
-                result = pickoff_eval(t_in, A.mode, len, w4, fc);
-                if (fc) report(fc, row);
-            }
-        }
-        if (lane == 0) A.out[row * A.out_stride] = result;
-        wave_sync();
-        PHASE(5)
-    }
-    if (stamps && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(err + 4) + i, tsum[i]);
-    }
-}
-
-template <int KIND>
-int launch_v3_kind(const EnergyArgs& A, const EnergyPlan3& PL, int npf, int64_t n_wf, int* err, int blocks, int threads, int lds_bytes,
-                   hipStream_t st) {
-    switch (npf) {
-        case 4: hipLaunchKernelGGL((dsp_energy_v3_kernel<4, KIND>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
-        case 8: hipLaunchKernelGGL((dsp_energy_v3_kernel<8, KIND>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
-        case 16: hipLaunchKernelGGL((dsp_energy_v3_kernel<16, KIND>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
-        default: return (int)hipErrorInvalidValue;
-    }
-    return (int)hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------
-// "sl" (straight line): the pad-free odd-stride layout of the ILP variant, with every chunk pass FULLY UNROLLED.
-//
-// Lesson of the variants above: with uniform branches inside the chunk loops (pad crossings, capture tests, guarded
-// prefetches) hipcc falls back to s_waitcnt lgkmcnt(0) and serialises LDS latency with the arithmetic.  Here each pass
-// over the C = 4*NPF + 1 samples of a lane is one basic block -- immediate LDS offsets, no branches -- so the compiler can
-// hoist the loads and count its waits.  What used to be tested inside the loops is recomputed afterwards from values the
-// block leaves in registers: the float32 running sum at every 8-sample group end (prefix captures = group end + at most 7
-// re-read samples) and the replay state at every group start (a wanted sample = re-run of one 8-sample group).
-// S sub-chains (1 or 2) in the trapezoid replay only; the pole-zero passes are float64-issue bound either way.
+// What the measurements on MI355X said (profiles/r01_summary.md has the counters): a wavefront of this chain is bound by its
+// own instruction stream -- about one instruction per 4 cycles, an LDS access several times that -- and at 17-20 KB of LDS
+// per waveform only 2 wavefronts fit a SIMD, so nothing hides a stall.  Hence:
+//   * every pass over the C samples of a lane is straight-line code (no loop counters, no address arithmetic, no uniform
+//     branches inside: with those hipcc falls back to s_waitcnt lgkmcnt(0) and serialises LDS latency with the arithmetic);
+//   * the chunk is read from LDS once and stays in VGPRs through pass 1 (float64 sum), pass 2 (pole-zero, in place) and
+//     pass 3 (trapezoid replay); only the three lagged streams of the replay come from LDS, loaded PD stages ahead;
+//   * bl_subtract happens in the staging stores; the result of row r is stored behind the prefetch of row r + 2 (vmcnt
+//     counts stores: a store at the end of the loop body would sit in front of the next staging's s_waitcnt vmcnt(0));
+//   * what must be picked out at a run-time position is never tested per sample: the float32 prefix sum at each 8-sample
+//     group end and the replay state at each group start go to a 9-entry per-lane LDS side array (a run-time group number is
+//     then an address); the two trapezoid samples every pick-off mode needs are copied out of a 16-sample register window
+//     by one uniform branch per 16 samples (a not-taken branch costs tens of cycles; 32 of them cost more than they saved).
+// S = sub-chains of the replay per lane: 2 halves the dependent-add chain but doubles the carry captures; measured slower.
 // ------------------------------------------------------------------------------------------------
 template <int NPF, int KIND, int S>
-__global__ void __launch_bounds__(256, 2) dsp_energy_sl_kernel(EnergyArgs A, EnergyPlan PL, int64_t n_wf, int* err) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int C = 4 * NPF + 1, len = 256 * NPF, NG = (C - 1) / 8, CS = (C - 1) / S, NGS = CS / 8;
-    static_assert((C - 1) % (8 * S) == 0, "sub-chain length must be a whole number of 8-sample groups");
-    const int lane = lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
-    float* lds = reinterpret_cast<float*>(smem_raw) + (size_t)wave * A.lds_elems_per_wave;
-    for (int e = lane; e < A.lds_elems_per_wave; e += 64) lds[e] = 0.0f;
-    wave_sync();
-    float* slot = lds + A.slot_off;
-    float* mine = slot + lane * C;
-    // per-lane side array (pitch 9, odd): group-end prefix sums of pass 2, later the group-start states of the replay.  Kept in
-    // LDS so that "the value of group gi" with a run-time gi is an address, not a register select chain
-    constexpr int AUXP = 9;
-    static_assert(NG + 1 <= AUXP && S * NGS + 1 <= AUXP, "side array too small");
-    float* aux = slot + 64 * C + 16 + lane * AUXP;
-    const float* lagp[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int pos0 = lane * C - A.q[k];  // q[] carries the lags
-        lagp[k] = (pos0 >= -C) ? slot + pos0 : slot - (2 * C + 8);
-    }
-
-    const int64_t stride_rows = (int64_t)gridDim.x * wpb;
-    int64_t row = (int64_t)blockIdx.x * wpb + wave;
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    f4 pf[NPF];
-    float pf_bl = 0.0f, pf_tp = 0.0f;
-    auto prefetch = [&](int64_t r) {
-        const float* g = (const float*)A.wf + r * A.wf_stride + A.wf_offset;
-#pragma unroll
-        for (int b = 0; b < NPF; ++b) pf[b] = reinterpret_cast<const f4*>(g)[b * 64 + lane];
-        pf_bl = A.bl ? A.bl[r * A.bl_stride] : A.bl_const;
-        pf_tp = A.tp ? A.tp[r * A.tp_stride] : A.tp_const;
-    };
-    auto report = [&](int code, int64_t r) {
-        if (lane == 0 && atomicCAS(&err[0], 0, code) == 0) {
-            err[1] = (int)(r & 0xffffffffll);
-            err[2] = (int)(r >> 32);
-        }
-    };
-    // prefix after r samples of this lane's chunk, from the group-end sums of pass 2 and at most 7 re-read outputs
-    auto prefix_at = [&](int r) -> float {
-        const int gi = (r > 0 ? r - 1 : 0) >> 3;  // group that contains sample r-1
-        const float base = gi > 0 ? aux[gi - 1] : 0.0f;
-        const int n = r - 8 * gi;  // 0..8 samples of group gi (gi == NG: the odd sample)
-        float part = 0.0f;
-        __builtin_amdgcn_sched_barrier(0);
-        const float* p = mine + 8 * gi;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float v = p[u];  // (reads at most 7 past the chunk: inside the slot tail)
-            part += (u < n) ? v : 0.0f;
-        }
-        return base + part;
-    };
-    if (row < n_wf) prefetch(row);
-    const bool stamps = (A.ablate & 8) != 0;
-    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = stamps ? stamp() : 0;
-
-    for (; row < n_wf; row += stride_rows) {
-#pragma unroll
-        for (int b = 0; b < NPF; ++b) *reinterpret_cast<f4*>(slot + (b * 64 + lane) * 4) = pf[b];
-        slot[len + lane] = pf_bl;  // virtual samples above len hold the baseline: x = 0 exactly
-        const float bl = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pf_bl)));
-        const float t_in = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pf_tp)));
-        const int64_t next = row + stride_rows;
-        __builtin_amdgcn_sched_barrier(0);
-        if (next < n_wf) prefetch(next);
-        __builtin_amdgcn_sched_barrier(0);
-        wave_sync();
-        PHASE(0)
-
-        float result = quiet_nan<float>();
-        // ---- pass 1 (straight line): float64 sum of x = w - baseline over the chunk
-        double X = 0.0;
-#pragma unroll
-        for (int t = 0; t < C; ++t) {
-            if ((t & 15) == 0) __builtin_amdgcn_sched_barrier(0);  // bound the load hoisting (registers) to 16 samples
-            X += (double)(mine[t] - bl);
-        }
-        bool in_nan = A.tau_nan != 0;
-        if (wave_any(!(fabs(X) <= 1.7976931348623157e308))) {
-            bool n = false;
-            for (int t = 0; t < C; ++t) {
-                const float x = mine[t] - bl;
-                n |= (x != x);
-            }
-            in_nan |= wave_any(n);
-        }
-        wave_sync();  // (also keeps the compiler from carrying the 65 loaded samples of pass 1 in registers into pass 2)
-        PHASE(1)
-        if (!in_nan) {
-            const double E = wave_exscan_add(X);
-            // ---- pass 2 (straight line): pole-zero recurrence in the reference's operation order, in place
-            const double c = A.c;
-            const float xprev = (lane > 0) ? mine[-1] - bl : 0.0f;
-            double xp = (double)xprev, acc = E - c * (E - xp);
-            float run = 0.0f;
-#pragma unroll
-            for (int t = 0; t < C; ++t) {
-                if ((t & 15) == 0) __builtin_amdgcn_sched_barrier(0);
-                const double x = (double)(mine[t] - bl);
-                acc = (acc + x) - xp * c;
-                const float y = (float)acc;
-                mine[t] = y;
-                xp = x;
-                run += y;
-                if ((t & 7) == 7) aux[t >> 3] = run;
-            }
-            wave_sync();
-            PHASE(2)
-            bool pz_nan = false;
-            if (wave_any(!(fabsf(run) <= 3.4028234663852886e38f))) {
-                bool n = false;
-                for (int t = 0; t < C; ++t) {
-                    const float y = mine[t];
-                    n |= (y != y);
-                }
-                pz_nan = wave_any(n);
-            }
-            if (pz_nan) {
-                report(DSP_E_PZ_NAN, row);
-            } else if (!A.all_nan && !(A.ablate & 4) && pickoff_in_range(t_in, len)) {
-                // ---- speculative carries
-                const double Ep = wave_exscan_add((double)run);
-                float g[S], y[S];
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    double Ak[3];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        int r = PL.cs[k][s] * CS + PL.local[k][s];  // samples of the source lane's chunk before the capture point
-                        // opaque to the optimiser: otherwise every mask derived from the (row-invariant) plan is hoisted out of the
-                        // row loop and the kernel drowns in spilled SGPR pairs
-                        asm volatile("" : "+s"(r));
-                        Ak[k] = wave_shift_up(Ep + (double)prefix_at(r), PL.shift[k][s]);
-                    }
-                    const double own = Ep + (s ? (double)aux[s * NGS - 1] : 0.0);
-                    double Gd;
-                    if (KIND == TRAP_FILTER)
-                        Gd = ((own - Ak[0]) - Ak[1]) + Ak[2];
-                    else if (KIND == TRAP_NORM)
-                        Gd = (((own - Ak[0]) - Ak[1]) + Ak[2]) / A.rr;
-                    else
-                        Gd = (own - Ak[0]) / A.rr - (Ak[1] - Ak[2]) / A.ll;
-                    g[s] = (lane == 0 && s == 0) ? -0.0f : (float)Gd;
-                    y[s] = g[s];
-                }
-                PHASE(3)
-                // ---- pass 3 (straight line): S interleaved replays; the state at every group start stays in registers
-                wave_sync();  // the prefix sums in aux are consumed; aux now receives the replay state at every group start
-#pragma unroll
-                for (int gi = 0; gi < NGS; ++gi) {
-                    __builtin_amdgcn_sched_barrier(0);  // one 8-sample group (4 x S streams) of loads in flight at a time
-#pragma unroll
-                    for (int s = 0; s < S; ++s) aux[s * NGS + gi] = y[s];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-#pragma unroll
-                        for (int s = 0; s < S; ++s) {
-                            const int tt = s * CS + gi * 8 + u;
-                            y[s] = trap_step<float, KIND>(y[s], mine[tt], lagp[0][tt], lagp[1][tt], lagp[2][tt], A.rr, A.ll);
-                        }
-                }
-                aux[S * NGS] = y[S - 1];  // state before the odd sample (group NGS of the last chain)
-                y[S - 1] = trap_step<float, KIND>(y[S - 1], mine[C - 1], lagp[0][C - 1], lagp[1][C - 1], lagp[2][C - 1], A.rr, A.ll);
-                PHASE(4)
-                // ---- true carries: exact scan of the increments
-                double D[S], Dbefore[S], Dtot = 0.0;
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    D[s] = (double)y[s] - (double)g[s];
-                    Dbefore[s] = Dtot;
-                    Dtot += D[s];
-                }
-                const double T0 = wave_exscan_add(Dtot);
-                // ---- wanted samples: re-run the one 8-sample group that contains each of them from its saved start state
-                const int i0 = (int)t_in;
-                const bool wide = (A.mode == 'h');
-                float w4[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int e = i0 - 1 + k;
-                    const bool need = ((k == 1) || (k == 2) || wide) && e >= 0 && e < len;
-                    w4[k] = 0.0f;
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (need) {  // uniform
-                        const int l = e / C, off = e - l * C;
-                        int ch = off / CS;
-                        if (ch > S - 1) ch = S - 1;
-                        const int loc = off - ch * CS;  // 0..CS (CS: the odd sample, chain S-1 only)
-                        const int gi = loc >> 3, u0 = loc & 7;
-                        float ys = aux[ch * NGS + gi], gsel = 0.0f;  // (chain S-1, group NGS) -> aux[S*NGS]
-                        double dsel = 0.0;
-#pragma unroll
-                        for (int s = 0; s < S; ++s)
-                            if (ch == s) {
-                                gsel = g[s];
-                                dsel = Dbefore[s];
-                            }
-                        const int base = ch * CS + gi * 8;
-                        float yk = ys;
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int tt = base + u;  // (beyond the chunk for the odd sample's group: reads stay in the slot tail, unused)
-                            ys = trap_step<float, KIND>(ys, mine[tt], lagp[0][tt], lagp[1][tt], lagp[2][tt], A.rr, A.ll);
-                            if (u == u0) yk = ys;
-                        }
-                        const double delta = (T0 + dsel) - (double)gsel;
-                        w4[k] = readlane((float)((double)yk + delta), l);
-                    }
-                }
-                int fc = 0;
-                result = pickoff_eval(t_in, A.mode, len, w4, fc);
-                if (fc) report(fc, row);
-            }
-        }
-        if (lane == 0) A.out[row * A.out_stride] = result;
-        wave_sync();
-        PHASE(5)
-    }
-    if (stamps && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(err + 4) + i, tsum[i]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// "rr" (register resident): the straight-line kernel with the lane's own chunk held in registers across all three passes
-// (one LDS read per sample instead of three), bl_subtract folded into the staging stores, and the lagged streams of the
-// replay loaded one group ahead of their use so every wait is a counted one.
-// ------------------------------------------------------------------------------------------------
-template <int NPF, int KIND>
 __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, EnergyPlan PL, int64_t n_wf, int* err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    constexpr int S = 1, C = 4 * NPF + 1, len = 256 * NPF, NG = (C - 1) / 8, CS = C - 1, NGS = NG;
+    constexpr int C = 4 * NPF + 1, len = 256 * NPF, NG = (C - 1) / 8, CS = (C - 1) / S, NGS = CS / 8;
+    constexpr int BS = CS >= 16 ? 16 : CS;  // samples per capture block
+    static_assert((C - 1) % (8 * S) == 0, "sub-chain length must be a whole number of 8-sample groups");
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
     float* lds = reinterpret_cast<float*>(smem_raw) + (size_t)wave * A.lds_elems_per_wave;
@@ -1316,21 +402,6 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
             err[1] = (int)(r & 0xffffffffll);
             err[2] = (int)(r >> 32);
         }
-    };
-    // prefix after r samples of this lane's chunk, from the group-end sums of pass 2 and at most 7 re-read outputs
-    auto prefix_at = [&](int r) -> float {
-        const int gi = (r > 0 ? r - 1 : 0) >> 3;  // group that contains sample r-1
-        const float base = gi > 0 ? aux[gi - 1] : 0.0f;
-        const int n = r - 8 * gi;  // 0..8 samples of group gi (gi == NG: the odd sample)
-        float part = 0.0f;
-        __builtin_amdgcn_sched_barrier(0);
-        const float* p = mine + 8 * gi;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float v = p[u];  // (reads at most 7 past the chunk: inside the slot tail)
-            part += (u < n) ? v : 0.0f;
-        }
-        return base + part;
     };
     if (row < n_wf) prefetch(row);
     const bool stamps = (A.ablate & 8) != 0;
@@ -1461,49 +532,68 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
                     const bool ok = e >= 0 && e < len;
                     caplane[k] = ok ? e / C : 0;
                     capoff[k] = ok ? e - caplane[k] * C : 0;
-                    capst[k] = ok ? capoff[k] >> 4 : -1;  // 16-sample block of the chunk; block (C-1)/16 (never reached) = the odd sample
+                    capst[k] = ok ? capoff[k] / BS : -1;  // capture block of the chunk; block (C-1)/BS (never reached) = the odd sample
                 }
-                // one test per 16 samples (a not-taken branch still costs tens of cycles): bit q set = block q holds a wanted sample
+                // one test per BS samples (a not-taken branch still costs tens of cycles): bit q set = block q holds a wanted sample
                 int capmask = (capst[0] >= 0 ? 1 << capst[0] : 0) | (capst[1] >= 0 ? 1 << capst[1] : 0);
                 asm volatile("" : "+s"(capmask));  // one live scalar, not a recomputation at each test
                 float* capbuf = slot + 64 * C + 16 + 64 * AUXP;  // 2 x 16 floats per wavefront, written by the lane that owns the sample
-                float ys16[16];
-                constexpr int GL = 4, NL = (C - 1) / GL;  // samples per pipeline stage of the lagged streams (registers: 2 x 3 x GL)
-                float lb[2][GL][3], lodd[3] = {0.0f, 0.0f, 0.0f};
+                float ysb[S][BS];
+                constexpr int GL = 4, NL = CS / GL;  // samples per pipeline stage of the lagged streams (registers: 2 x S x 3 x GL)
+                constexpr int PD = S == 1 ? 2 : 1;  // stages the lagged loads run ahead of their use (lgkmcnt counts to 15: 6*S reads per stage)
+                float lb[PD + 1][S][GL][3], lodd[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int u = 0; u < GL; ++u)
+                for (int p = 0; p < PD; ++p)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) lb[0][u][k] = lagp[k][u];
-#pragma unroll
-                for (int gl = 0; gl < NL; ++gl) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (gl + 1 < NL) {
+                    for (int s = 0; s < S; ++s)
 #pragma unroll
                         for (int u = 0; u < GL; ++u)
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) lb[(gl + 1) & 1][u][k] = lagp[k][(gl + 1) * GL + u];
-                    } else {
+                            for (int k = 0; k < 3; ++k) lb[p][s][u][k] = lagp[k][s * CS + p * GL + u];
+#pragma unroll
+                for (int gl = 0; gl < NL; ++gl) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (gl + PD < NL) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s)
+#pragma unroll
+                            for (int u = 0; u < GL; ++u)
+#pragma unroll
+                                for (int k = 0; k < 3; ++k) lb[(gl + PD) % (PD + 1)][s][u][k] = lagp[k][s * CS + (gl + PD) * GL + u];
+                    } else if (gl + PD == NL) {
 #pragma unroll
                         for (int k = 0; k < 3; ++k) lodd[k] = lagp[k][C - 1];
                     }
-                    if ((gl * GL) % 8 == 0) aux[(gl * GL) / 8] = y[0];
+                    if ((gl * GL) % 8 == 0) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) aux[s * NGS + (gl * GL) / 8] = y[s];
+                    }
                     __builtin_amdgcn_sched_barrier(0);  // the reads just issued are younger than the stage consumed next: a counted wait
 #pragma unroll
-                    for (int u = 0; u < GL; ++u) {
-                        y[0] = trap_step<float, KIND>(y[0], xr[gl * GL + u], lb[gl & 1][u][0], lb[gl & 1][u][1], lb[gl & 1][u][2], A.rr, A.ll);
-                        ys16[(gl & 3) * GL + u] = y[0];
-                    }
-                    if ((gl & 3) == 3 && (capmask & (1 << (gl >> 2)))) {  // uniform, taken at most twice per waveform
+                    for (int u = 0; u < GL; ++u)
 #pragma unroll
-                        for (int k = 0; k < 2; ++k)
-                            if (capst[k] == (gl >> 2) && lane == caplane[k]) {
+                        for (int s = 0; s < S; ++s) {
+                            y[s] = trap_step<float, KIND>(y[s], xr[s * CS + gl * GL + u], lb[gl % (PD + 1)][s][u][0], lb[gl % (PD + 1)][s][u][1],
+                                                          lb[gl % (PD + 1)][s][u][2], A.rr, A.ll);
+                            ysb[s][(gl * GL + u) % BS] = y[s];
+                        }
+                    if (((gl + 1) * GL) % BS == 0) {
 #pragma unroll
-                                for (int u = 0; u < 16; ++u) capbuf[k * 16 + u] = ys16[u];
+                        for (int s = 0; s < S; ++s) {
+                            const int q = s * (CS / BS) + (gl * GL) / BS;
+                            if (capmask & (1 << q)) {  // uniform, taken at most twice per waveform
+#pragma unroll
+                                for (int k = 0; k < 2; ++k)
+                                    if (capst[k] == q && lane == caplane[k]) {
+#pragma unroll
+                                        for (int u = 0; u < BS; ++u) capbuf[k * 16 + u] = ysb[s][u];
+                                    }
                             }
+                        }
                     }
                 }
-                aux[NG] = y[0];  // state before the odd sample
-                y[0] = trap_step<float, KIND>(y[0], xr[C - 1], lodd[0], lodd[1], lodd[2], A.rr, A.ll);
+                aux[S * NGS] = y[S - 1];  // state before the odd sample (it extends the last chain)
+                y[S - 1] = trap_step<float, KIND>(y[S - 1], xr[C - 1], lodd[0], lodd[1], lodd[2], A.rr, A.ll);
                 PHASE(4)
                 // ---- true carries: exact scan of the increments
                 double D[S], Dbefore[S], Dtot = 0.0;
@@ -1517,14 +607,15 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
                 // ---- wanted samples: re-run the one 8-sample group that contains each of them from its saved start state
                 const bool wide = (A.mode == 'h');
                 float w4[4];
-                {
-                    const double delta = T0 - (double)g[0];
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        float v = capbuf[k * 16 + (capoff[k] & 15)];  // (stale when the sample is the odd one or out of range: not used then)
-                        v = capoff[k] == C - 1 ? y[0] : v;
-                        w4[1 + k] = capst[k] >= 0 ? readlane((float)((double)v + delta), caplane[k]) : 0.0f;
-                    }
+                for (int k = 0; k < 2; ++k) {
+                    float v = capbuf[k * 16 + (capoff[k] % BS)];  // (stale when the sample is the odd one or out of range: not used then)
+                    v = capoff[k] == C - 1 ? y[S - 1] : v;
+                    double delta = T0 - (double)g[0];
+#pragma unroll
+                    for (int s = 1; s < S; ++s)
+                        if (capoff[k] >= s * CS) delta = (T0 + Dbefore[s]) - (double)g[s];
+                    w4[1 + k] = capst[k] >= 0 ? readlane((float)((double)v + delta), caplane[k]) : 0.0f;
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k += 3) {  // the outer two samples of the 4-point mode: re-run their 8-sample group
@@ -1575,25 +666,13 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
     }
 }
 
-template <int KIND>
+template <int KIND, int S>
 int launch_rr_kind(const EnergyArgs& A, const EnergyPlan& PL, int npf, int64_t n_wf, int* err, int blocks, int threads, int lds_bytes,
                    hipStream_t st) {
     switch (npf) {
-        case 4: hipLaunchKernelGGL((dsp_energy_rr_kernel<4, KIND>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
-        case 8: hipLaunchKernelGGL((dsp_energy_rr_kernel<8, KIND>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
-        case 16: hipLaunchKernelGGL((dsp_energy_rr_kernel<16, KIND>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
-        default: return (int)hipErrorInvalidValue;
-    }
-    return (int)hipGetLastError();
-}
-
-template <int KIND, int S>
-int launch_sl_kind(const EnergyArgs& A, const EnergyPlan& PL, int npf, int64_t n_wf, int* err, int blocks, int threads, int lds_bytes,
-                   hipStream_t st) {
-    switch (npf) {
-        case 4: hipLaunchKernelGGL((dsp_energy_sl_kernel<4, KIND, S>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
-        case 8: hipLaunchKernelGGL((dsp_energy_sl_kernel<8, KIND, S>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
-        case 16: hipLaunchKernelGGL((dsp_energy_sl_kernel<16, KIND, S>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 4: hipLaunchKernelGGL((dsp_energy_rr_kernel<4, KIND, S>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 8: hipLaunchKernelGGL((dsp_energy_rr_kernel<8, KIND, S>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 16: hipLaunchKernelGGL((dsp_energy_rr_kernel<16, KIND, S>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
         default: return (int)hipErrorInvalidValue;
     }
     return (int)hipGetLastError();
@@ -1634,46 +713,17 @@ extern "C" int dsp_internal_set_energy_lds(int trap_opcode, int npf, int lds_byt
     return (int)hipErrorInvalidValue;
 }
 
-// S sub-chains per lane (2 or 4); q[] of A carries the three lags; plan from the host
-extern "C" int dsp_internal_launch_energy_ilp(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int64_t n_wf,
-                                              int* err, int blocks, int threads, int lds_bytes, hipStream_t stream) {
-#define GO_(KIND)                                                                                                  \
-    return S == 4 ? launch_ilp_kind<KIND, 4>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream)          \
-                  : launch_ilp_kind<KIND, 2>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
-    if (trap_opcode == DSP_OP_TRAP_FILTER) { GO_(TRAP_FILTER) }
-    if (trap_opcode == DSP_OP_TRAP_NORM) { GO_(TRAP_NORM) }
-    GO_(TRAP_ASYM)
-#undef GO_
-}
-
-extern "C" int dsp_internal_launch_energy_v3(const EnergyArgs* A, const EnergyPlan3* PL, int trap_opcode, int npf, int64_t n_wf, int* err,
-                                             int blocks, int threads, int lds_bytes, hipStream_t stream) {
-    if (trap_opcode == DSP_OP_TRAP_FILTER) return launch_v3_kind<TRAP_FILTER>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
-    if (trap_opcode == DSP_OP_TRAP_NORM) return launch_v3_kind<TRAP_NORM>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
-    return launch_v3_kind<TRAP_ASYM>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
-}
-extern "C" const char* dsp_internal_energy_v3_kernel_name() { return "dsp_energy_v3_kernel"; }
-
-// straight-line variant; S = sub-chains of the trapezoid replay (1 or 2); plan[S == 2 ? 0 : unused]
-extern "C" int dsp_internal_launch_energy_sl(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int64_t n_wf,
+// register-resident kernel; S = sub-chains of the trapezoid replay (1: default, 2: measured slower, kept for A/B); plan[S - 1]
+extern "C" int dsp_internal_launch_energy_rr(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int64_t n_wf,
                                              int* err, int blocks, int threads, int lds_bytes, hipStream_t stream) {
 #define GO_(KIND)                                                                                                 \
-    return S == 2 ? launch_sl_kind<KIND, 2>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream)          \
-                  : launch_sl_kind<KIND, 1>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
+    return S == 2 ? launch_rr_kind<KIND, 2>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream)          \
+                  : launch_rr_kind<KIND, 1>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
     if (trap_opcode == DSP_OP_TRAP_FILTER) { GO_(TRAP_FILTER) }
     if (trap_opcode == DSP_OP_TRAP_NORM) { GO_(TRAP_NORM) }
     GO_(TRAP_ASYM)
 #undef GO_
-}
-extern "C" const char* dsp_internal_energy_sl_kernel_name() { return "dsp_energy_sl_kernel"; }
-
-extern "C" int dsp_internal_launch_energy_rr(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int64_t n_wf, int* err,
-                                             int blocks, int threads, int lds_bytes, hipStream_t stream) {
-    if (trap_opcode == DSP_OP_TRAP_FILTER) return launch_rr_kind<TRAP_FILTER>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
-    if (trap_opcode == DSP_OP_TRAP_NORM) return launch_rr_kind<TRAP_NORM>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
-    return launch_rr_kind<TRAP_ASYM>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
 }
 extern "C" const char* dsp_internal_energy_rr_kernel_name() { return "dsp_energy_rr_kernel"; }
 
 extern "C" const char* dsp_internal_energy_kernel_name() { return "dsp_energy_kernel"; }
-extern "C" const char* dsp_internal_energy_ilp_kernel_name() { return "dsp_energy_ilp_kernel"; }

@@ -69,21 +69,8 @@ struct EnergyPlan {
     int32_t cs[3][4];
     int32_t local[3][4];
 };
-extern "C" int dsp_internal_launch_energy_ilp(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int64_t n_wf,
-                                              int* err, int blocks, int threads, int lds_bytes, hipStream_t stream);
-extern "C" const char* dsp_internal_energy_ilp_kernel_name();
-struct EnergyPlan3 {
-    int32_t shift[3][2];
-    int32_t r[3][2];
-};
-extern "C" int dsp_internal_launch_energy_v3(const EnergyArgs* A, const EnergyPlan3* PL, int trap_opcode, int npf, int64_t n_wf, int* err,
-                                             int blocks, int threads, int lds_bytes, hipStream_t stream);
-extern "C" const char* dsp_internal_energy_v3_kernel_name();
-extern "C" int dsp_internal_launch_energy_sl(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int64_t n_wf,
+extern "C" int dsp_internal_launch_energy_rr(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int64_t n_wf,
                                              int* err, int blocks, int threads, int lds_bytes, hipStream_t stream);
-extern "C" const char* dsp_internal_energy_sl_kernel_name();
-extern "C" int dsp_internal_launch_energy_rr(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int64_t n_wf, int* err,
-                                             int blocks, int threads, int lds_bytes, hipStream_t stream);
 extern "C" const char* dsp_internal_energy_rr_kernel_name();
 
 namespace {
@@ -132,18 +119,14 @@ struct dsp_chain {
     bool fused_ok = false, fused_on = true;
     EnergyArgs fused{};
     int fused_trap = 0, fused_npf = 0;
-    // ILP variant (S sub-chains per lane, pad-free LDS): the default for 1024/2048/4096-sample energy chains
-    bool ilp_ok = false;
-    // 6: register-resident straight-line kernel (default where it applies), 1: classic one-chain-per-lane kernel (the only one for
-    // 8192 samples), 0 / 2: 2 / 4 sub-chains per lane, 3: v3, 4 / 5: straight line from LDS with 1 / 2 replay chains -- kept for A/B runs
+    // register-resident kernel (pad-free LDS image): the default for 1024/2048/4096-sample energy chains
+    bool rr_ok = false;
+    // 6: register-resident kernel (default where it applies), 8: the same with two replay sub-chains per lane (A/B only),
+    // 1: classic kernel (VM layout, bit-identical to the VM)
     int variant = 1;
-    EnergyArgs ilp{};
-    EnergyPlan plan[3]{};  // [0]: S=2, [1]: S=4, [2]: S=1
-    int ilp_lds_bytes = 0;
-    // v3: even lane stride, 64-bit LDS accesses, two sub-chains in the replay only (variant 3)
-    EnergyArgs v3{};
-    EnergyPlan3 plan3{};
-    int v3_lds_bytes = 0;
+    EnergyArgs rr{};
+    EnergyPlan plan[2]{};  // [S - 1]
+    int rr_lds_bytes = 0;
     int io_wf = -1, io_bl = -1, io_tp = -1, io_out = -1;
 };
 
@@ -605,26 +588,26 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             ch->fused_ok = slot_len[0] <= 4096;
             const char* env = getenv("DSPEED_HIP_NO_FUSED");
             ch->fused_on = !(env && env[0] == '1');
-            if (slot_len[0] <= 4096) {  // ILP variant: C = len/64 + 1 samples per lane, linear LDS image of the waveform
-                EnergyArgs& I = ch->ilp;
+            if (slot_len[0] <= 4096) {  // register-resident kernel: C = len/64 + 1 samples per lane, linear LDS image of the waveform
+                EnergyArgs& I = ch->rr;
                 I = F;
                 const int Ci = slot_len[0] / 64 + 1;
                 I.C = Ci;
                 I.pitch = Ci;
                 I.invC = 1.0f / (float)Ci;
-                int guard = 2 * Ci + 8;
+                int guard = 2 * Ci + 8;  // zeros below the image: lagged reads before sample 0
                 guard = ((guard + 3) / 4) * 4;
                 I.slot_off = guard;
-                int elems = guard + 64 * Ci + 16 + 64 * 9 + 32;  // slot, tail, per-lane side array and capture buffer of the straight-line variants
+                int elems = guard + 64 * Ci + 16 + 64 * 9 + 32;  // image, tail, per-lane side array (9 per lane), capture buffer (2 x 16)
                 elems = ((elems + 3) / 4) * 4;
                 I.lds_elems_per_wave = elems;
-                ch->ilp_lds_bytes = elems * 4;
+                ch->rr_lds_bytes = elems * 4;
                 for (int k = 0; k < 3; ++k) {
                     I.q[k] = dtp.ic[k];  // the lags themselves
                     I.rho[k] = 0;
                 }
-                for (int v = 0; v < 3; ++v) {
-                    const int S = v == 0 ? 2 : (v == 1 ? 4 : 1), CS = (Ci - 1) / S;
+                for (int S = 1; S <= 2; ++S) {
+                    const int CS = (Ci - 1) / S;
                     for (int k = 0; k < 3; ++k)
                         for (int sidx = 0; sidx < S; ++sidx) {
                             const int pos = sidx * CS - dtp.ic[k];          // samples before the sub-chain start, relative to the chunk
@@ -632,37 +615,15 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                             const int shift = (r - pos) / Ci;
                             int cs = r / CS;
                             if (cs > S - 1) cs = S - 1;
-                            ch->plan[v].shift[k][sidx] = shift;
-                            ch->plan[v].cs[k][sidx] = cs;
-                            ch->plan[v].local[k][sidx] = r - cs * CS;
+                            ch->plan[S - 1].shift[k][sidx] = shift;
+                            ch->plan[S - 1].cs[k][sidx] = cs;
+                            ch->plan[S - 1].local[k][sidx] = r - cs * CS;
                         }
                 }
-                {
-                    EnergyArgs& V = ch->v3;
-                    V = F;
-                    const int Cv = slot_len[0] / 64 + 2, CSv = (Cv - 2) / 2;
-                    V.C = Cv;
-                    V.pitch = Cv;
-                    const int guard3 = 2 * Cv + 16;  // multiple of 4 for Cv = 18, 34, 66
-                    V.slot_off = guard3;
-                    int el = guard3 + 64 * Cv + 16;
-                    el = ((el + 3) / 4) * 4;
-                    V.lds_elems_per_wave = el;
-                    ch->v3_lds_bytes = el * 4;
-                    for (int k = 0; k < 3; ++k) {
-                        V.q[k] = dtp.ic[k];
-                        V.rho[k] = 0;
-                        for (int sidx = 0; sidx < 2; ++sidx) {
-                            const int pos = sidx * CSv - dtp.ic[k];
-                            const int r = ((pos % Cv) + Cv) % Cv;
-                            ch->plan3.r[k][sidx] = r;
-                            ch->plan3.shift[k][sidx] = (r - pos) / Cv;
-                        }
-                    }
-                }
-                ch->ilp_ok = true;
+                ch->rr_ok = true;
                 ch->variant = 6;
-                if (const char* venv = getenv("DSPEED_HIP_VARIANT")) ch->variant = atoi(venv);
+                if (const char* venv = getenv("DSPEED_HIP_VARIANT")) ch->variant = atoi(venv);  // A/B runs: 1, 6, 8
+                if (ch->variant != 1 && ch->variant != 8) ch->variant = 6;
             }
         }
     }
@@ -700,6 +661,19 @@ static int chain_blocks(const dsp_chain* ch, int64_t n_wf) {
     return (int)(b > 0 ? b : 1);
 }
 
+// launch geometry of the register-resident kernel: up to 4 wavefronts per block, 2 wavefronts per SIMD (its register budget)
+static void rr_geometry(const dsp_chain* ch, int64_t n_wf, int* wpb_out, int* blocks_out) {
+    int wpb = LDS_BYTES_PER_CU / ch->rr_lds_bytes;
+    if (wpb > 4) wpb = 4;
+    if (wpb < 1) wpb = 1;
+    int per_cu = LDS_BYTES_PER_CU / (ch->rr_lds_bytes * wpb);
+    if (per_cu * wpb > 8) per_cu = 8 / wpb;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t want = (n_wf + wpb - 1) / wpb, cap = (int64_t)ch->num_cu * per_cu;
+    *wpb_out = wpb;
+    *blocks_out = (int)(want < cap ? want : cap);
+}
+
 int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* stream) {
     if (!ch || !io_ptrs) return fail(DSP_ERR_ARG, "null chain or io_ptrs");
     if (n_wf <= 0) return DSP_OK;
@@ -711,64 +685,18 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
     const int blocks = chain_blocks(ch, n_wf);
     const int threads = 64 * ch->waves_per_block;
     const int lds = ch->lds_bytes_per_wave * ch->waves_per_block;
-    if (ch->ilp_ok && ch->fused_on && ch->variant == 3 && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
-        EnergyArgs F = ch->v3;
+    if (ch->rr_ok && ch->fused_on && ch->variant != 1 && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
+        EnergyArgs F = ch->rr;
         F.wf = io_ptrs[ch->io_wf];
         F.bl = ch->io_bl >= 0 ? (const float*)io_ptrs[ch->io_bl] : nullptr;
         F.tp = ch->io_tp >= 0 ? (const float*)io_ptrs[ch->io_tp] : nullptr;
         F.out = (float*)io_ptrs[ch->io_out];
-        int wpb = LDS_BYTES_PER_CU / ch->v3_lds_bytes;
-        if (wpb > 4) wpb = 4;
-        int per_cu = LDS_BYTES_PER_CU / (ch->v3_lds_bytes * wpb);
-        if (per_cu * wpb > 8) per_cu = 8 / wpb;
-        if (per_cu < 1) per_cu = 1;
-        int64_t want = (n_wf + wpb - 1) / wpb, cap = (int64_t)ch->num_cu * per_cu;
-        const int vblocks = (int)(want < cap ? want : cap);
-        hipError_t e = (hipError_t)dsp_internal_launch_energy_v3(&F, &ch->plan3, ch->fused_trap, ch->fused_npf, n_wf, ch->dev_err, vblocks,
-                                                                 64 * wpb, ch->v3_lds_bytes * wpb, (hipStream_t)stream);
-        if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy v3 kernel launch failed: %s", hipGetErrorString(e));
-        return DSP_OK;
-    }
-    if (ch->ilp_ok && ch->fused_on && (ch->variant == 4 || ch->variant == 5 || ch->variant == 6) && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
-        // straight-line variants: 4 = one replay chain per lane, 5 = two, 6 = register-resident chunk
-        EnergyArgs F = ch->ilp;
-        F.wf = io_ptrs[ch->io_wf];
-        F.bl = ch->io_bl >= 0 ? (const float*)io_ptrs[ch->io_bl] : nullptr;
-        F.tp = ch->io_tp >= 0 ? (const float*)io_ptrs[ch->io_tp] : nullptr;
-        F.out = (float*)io_ptrs[ch->io_out];
-        const int S = ch->variant == 5 ? 2 : 1;
-        int wpb = LDS_BYTES_PER_CU / ch->ilp_lds_bytes;
-        if (wpb > 4) wpb = 4;
-        int per_cu = LDS_BYTES_PER_CU / (ch->ilp_lds_bytes * wpb);
-        if (per_cu * wpb > 8) per_cu = 8 / wpb;
-        if (per_cu < 1) per_cu = 1;
-        int64_t want = (n_wf + wpb - 1) / wpb, cap = (int64_t)ch->num_cu * per_cu;
-        const int iblocks = (int)(want < cap ? want : cap);
-        hipError_t e = ch->variant == 6
-                           ? (hipError_t)dsp_internal_launch_energy_rr(&F, &ch->plan[2], ch->fused_trap, ch->fused_npf, n_wf, ch->dev_err, iblocks,
-                                                                       64 * wpb, ch->ilp_lds_bytes * wpb, (hipStream_t)stream)
-                           : (hipError_t)dsp_internal_launch_energy_sl(&F, &ch->plan[S == 2 ? 0 : 2], ch->fused_trap, ch->fused_npf, S, n_wf,
-                                                                       ch->dev_err, iblocks, 64 * wpb, ch->ilp_lds_bytes * wpb, (hipStream_t)stream);
-        if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy straight-line kernel launch failed: %s", hipGetErrorString(e));
-        return DSP_OK;
-    }
-    if (ch->ilp_ok && ch->fused_on && ch->variant != 1 && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
-        EnergyArgs F = ch->ilp;
-        F.wf = io_ptrs[ch->io_wf];
-        F.bl = ch->io_bl >= 0 ? (const float*)io_ptrs[ch->io_bl] : nullptr;
-        F.tp = ch->io_tp >= 0 ? (const float*)io_ptrs[ch->io_tp] : nullptr;
-        F.out = (float*)io_ptrs[ch->io_out];
-        const int S = ch->variant == 2 ? 4 : 2;
-        int wpb = LDS_BYTES_PER_CU / ch->ilp_lds_bytes;
-        if (wpb > 4) wpb = 4;
-        int per_cu = LDS_BYTES_PER_CU / (ch->ilp_lds_bytes * wpb);
-        if (per_cu * wpb > 8) per_cu = 8 / wpb;  // registers: 2 wavefronts per SIMD
-        if (per_cu < 1) per_cu = 1;
-        int64_t want = (n_wf + wpb - 1) / wpb, cap = (int64_t)ch->num_cu * per_cu;
-        const int iblocks = (int)(want < cap ? want : cap);
-        hipError_t e = (hipError_t)dsp_internal_launch_energy_ilp(&F, &ch->plan[S == 4 ? 1 : 0], ch->fused_trap, ch->fused_npf, S, n_wf, ch->dev_err,
-                                                                  iblocks, 64 * wpb, ch->ilp_lds_bytes * wpb, (hipStream_t)stream);
-        if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy ILP kernel launch failed: %s", hipGetErrorString(e));
+        const int S = ch->variant == 8 ? 2 : 1;
+        int rwpb, rblocks;
+        rr_geometry(ch, n_wf, &rwpb, &rblocks);
+        hipError_t e = (hipError_t)dsp_internal_launch_energy_rr(&F, &ch->plan[S - 1], ch->fused_trap, ch->fused_npf, S, n_wf, ch->dev_err,
+                                                                 rblocks, 64 * rwpb, ch->rr_lds_bytes * rwpb, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy kernel launch failed: %s", hipGetErrorString(e));
         return DSP_OK;
     }
     if (ch->fused_ok && ch->fused_on && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
@@ -824,6 +752,14 @@ int dsp_chain_destroy(dsp_chain* ch) {
 
 int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int* waves_per_block, int* blocks) {
     if (!ch) return fail(DSP_ERR_ARG, "null chain");
+    if (ch->rr_ok && ch->fused_on && ch->variant != 1) {
+        int wpb, b;
+        rr_geometry(ch, n_wf, &wpb, &b);
+        if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->rr_lds_bytes;
+        if (waves_per_block) *waves_per_block = wpb;
+        if (blocks) *blocks = b;
+        return DSP_OK;
+    }
     if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->lds_bytes_per_wave;
     if (waves_per_block) *waves_per_block = ch->waves_per_block;
     if (blocks) *blocks = chain_blocks(ch, n_wf);
@@ -831,21 +767,18 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
 }
 
 const char* dsp_chain_kernel_name(dsp_chain* ch) {
-    if (ch && ch->ilp_ok && ch->fused_on && ch->variant == 3) return dsp_internal_energy_v3_kernel_name();
-    if (ch && ch->ilp_ok && ch->fused_on && ch->variant == 6) return dsp_internal_energy_rr_kernel_name();
-    if (ch && ch->ilp_ok && ch->fused_on && (ch->variant == 4 || ch->variant == 5)) return dsp_internal_energy_sl_kernel_name();
-    if (ch && ch->ilp_ok && ch->fused_on && ch->variant != 1) return dsp_internal_energy_ilp_kernel_name();
+    if (ch && ch->rr_ok && ch->fused_on && ch->variant != 1) return dsp_internal_energy_rr_kernel_name();
     return (ch && ch->fused_ok && ch->fused_on) ? dsp_internal_energy_kernel_name() : dsp_internal_vm_kernel_name();
 }
 
 int dsp_chain_set_fused(dsp_chain* ch, int enable) {
     if (!ch) return fail(DSP_ERR_ARG, "null chain");
-    ch->fused_on = (enable & 1) != 0;   // bit 0: use a specialised kernel
-    // bits 1-3: kernel variant for A/B runs: 0 = default (register-resident where it applies), 1 = ILP S=2, 2 = ILP S=4, 3 = v3,
-    // 4/5 = straight line S=1/2, 6 = register-resident, 7 = classic
+    ch->fused_on = (enable & 1) != 0;  // bit 0: use a specialised kernel
+    // bits 1-3 pick one for cross-checks and A/B runs: 0 = default (register-resident where it applies), 6 = register-resident,
+    // 7 = classic (VM layout); anything else = default
     const int v = (enable >> 1) & 7;
-    ch->variant = v == 0 ? (ch->ilp_ok ? 6 : 1) : (v == 1 ? 0 : (v == 7 ? 1 : v));
-    return ((ch->fused_ok || ch->ilp_ok) && ch->fused_on) ? 1 : 0;
+    ch->variant = (v == 7 || !ch->rr_ok) ? 1 : 6;
+    return ((ch->fused_ok || ch->rr_ok) && ch->fused_on) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ single processors

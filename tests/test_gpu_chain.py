@@ -25,7 +25,7 @@ def _run_energy(wf, bl, tp, tau, rise, flat, mode="l", fused=True, trap="trap_fi
     return bufs["trapEftp"].to_numpy()
 
 
-@pytest.mark.parametrize("fused", [1, 3, 5, 7, 9, 11, 13, 15, 0])
+@pytest.mark.parametrize("fused", [1, 13, 15, 0])
 def test_energy_chain_golden(fused):
     c2 = cases("chains")[1]
     p = c2.params
@@ -38,7 +38,7 @@ def test_energy_chain_golden(fused):
     assert rel.max() <= TOL
 
 
-@pytest.mark.parametrize("fused", [1, 3, 5, 7, 9, 11, 13, 15, 0])
+@pytest.mark.parametrize("fused", [1, 13, 15, 0])
 @pytest.mark.parametrize("wf_len,rise,flat", [(4096, 625, 188), (1024, 64, 16), (8192, 1250, 376), (6092, 500, 100), (2048, 300, 7),
                                               (3000, 128, 0), (200, 10, 3)])
 def test_energy_chain_vs_oracle(wf_len, rise, flat, fused):
@@ -52,6 +52,8 @@ def test_energy_chain_vs_oracle(wf_len, rise, flat, fused):
     bl = B[:, 0].astype(np.float32)
     tp = (t0[:, 0] + rise + 0.8 * flat).astype(np.float32)
     wf[11, 17] = np.nan
+    bl[14] = np.nan
+    tp[15] = np.nan
     tp[12] = np.float32(np.floor(tp[12]))
     tp[13] = np.float32(wf_len + 3)
     for mode in "lnh":
@@ -65,6 +67,35 @@ def test_energy_chain_vs_oracle(wf_len, rise, flat, fused):
         assert rel.max() <= TOL
 
 
+@pytest.mark.parametrize("fused", [1, 15])
+@pytest.mark.parametrize("wf_len,rise,flat", [(4096, 300, 50), (2048, 100, 31), (1024, 40, 9)])
+def test_energy_pickoff_position_sweep(wf_len, rise, flat, fused):
+    """the picked-off samples are caught at run-time positions: sweep the time point over lane-chunk boundaries (C = len/64 + 1
+    samples per lane in the default kernel), capture-block boundaries, both ends of the waveform, integer and fractional times"""
+    C = wf_len // 64 + 1
+    pos = sorted(set([0, 1, 2, 3, 14, 15, 16, 17, 31, 32, 33, C - 2, C - 1, C, C + 1, 2 * C - 1, 2 * C, 2 * C + 15, 2 * C + 16, 5 * C + 47,
+                      5 * C + 48, 31 * C + C // 2, 62 * C, 63 * C - 1, 63 * C, wf_len - 3, wf_len - 2, wf_len - 1]))
+    tp = np.array([p + f for p in pos for f in (0.0, 0.3, 0.5, 0.75)], dtype=np.float32)
+    n_wf = tp.size
+    rng = np.random.default_rng(wf_len)
+    i = np.arange(wf_len, dtype=np.float64)[None, :]
+    t0 = np.floor(rng.uniform(0.1, 0.9, (n_wf, 1)) * wf_len)
+    wf = (10000 + 8000 * np.exp(-(i - t0) / 1716.28) * (i >= t0) + 5.0 * rng.standard_normal((n_wf, wf_len))).astype(np.float32)
+    bl = np.full(n_wf, 10000, dtype=np.float32)
+    # the filter-output tolerance is relative to the trapezoid's peak in that waveform (its rounding noise does not shrink where the
+    # output is near zero)
+    trap, rc = oracle.chain_pz_trap(wf - bl[:, None], 1716.28, rise, flat)
+    assert rc == 0
+    peak = np.max(np.abs(trap), axis=1)
+    for mode in "lnhfc":
+        got = _run_energy(wf, bl, tp, 1716.28, rise, flat, mode, fused=fused)
+        want, rc = oracle.chain_energy(wf, bl, tp, 1716.28, rise, flat, mode)
+        assert rc == 0
+        assert np.array_equal(np.isnan(got), np.isnan(want)), mode
+        ok = ~np.isnan(want)
+        assert np.max(np.abs(got[ok] - want[ok]) / peak[ok]) <= TOL, mode
+
+
 def test_energy_chain_matches_unfused_processors():
     """fused chain == the same processors called one by one on the device (the ProcessingChain way)"""
     from dspeed_amd import processors as P
@@ -75,17 +106,16 @@ def test_energy_chain_matches_unfused_processors():
     bl = np.full(n_wf, 10000, dtype=np.float32)
     tp = np.full(n_wf, 2000 + 625 + 150.4, dtype=np.float32)
     # the classic kernel (15) and the VM (0) use the same chunking as the single processors -> identical bits; the default
-    # register-resident kernel (1 = 13) and the other variants replay the rounding sequence over different chunks -> equal within
-    # the filter tolerance
+    # register-resident kernel (1 = 13) replays the rounding sequence over 65-sample chunks -> equal within the filter tolerance
     step = P.fixed_time_pickoff(P.trap_filter(P.pole_zero(P.bl_subtract(wf, bl), 1716.28), 625, 188), tp, ord("l"))
     for fused in (15, 0):
         assert np.array_equal(_run_energy(wf, bl, tp, 1716.28, 625, 188, fused=fused), step)
-    for fused in (1, 3, 5, 7, 9, 11, 13):
+    for fused in (1, 13):
         assert np.max(np.abs(_run_energy(wf, bl, tp, 1716.28, 625, 188, fused=fused) - step) / np.abs(step)) <= TOL
     step = P.fixed_time_pickoff(P.trap_norm(P.pole_zero(P.bl_subtract(wf, bl), 1716.28), 625, 188), tp, ord("h"))
     for fused in (15, 0):
         assert np.array_equal(_run_energy(wf, bl, tp, 1716.28, 625, 188, mode="h", fused=fused, trap="trap_norm"), step)
-    for fused in (1, 3, 5, 7, 9, 11, 13):
+    for fused in (1, 13):
         assert np.max(np.abs(_run_energy(wf, bl, tp, 1716.28, 625, 188, mode="h", fused=fused, trap="trap_norm") - step) / np.abs(step)) <= TOL
 
 
@@ -96,7 +126,7 @@ def test_data_dependent_fatal_reports_row():
     bl = np.zeros(10, dtype=np.float32)
     tp = np.full(10, 100.0, dtype=np.float32)
     tp[6] = 100.5
-    for fused in (1, 3, 5, 7, 9, 11, 13, 15, 0):
+    for fused in (1, 13, 15, 0):
         with pytest.raises(DSPFatal) as ei:
             _run_energy(wf, bl, tp, 100.0, 16, 8, "i", fused=fused)
         assert ei.value.wf_range == range(6, 7)
