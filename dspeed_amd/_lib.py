@@ -95,6 +95,7 @@ def lib():
         "dsp_dwt_haar_f32": [vp, C.c_int, i64, i32, i64, i32, i32, vp, i32, i64, vp, pi64],
         "dsp_convolve_wf_f32": [vp, C.c_int, i64, i32, i64, vp, i32, i32, vp, i32, i64, vp, pi64],
         "dsp_synth_waveforms": [vp, C.c_int, i64, i32, i64, vp, vp, C.c_uint64, i64, f32, f32, f32, f32, f32, f32, f32, vp],
+        "dsp_stream_read": [vp, i64, vp, vp],
     }
     f64 = C.c_double
     for name in list(sig):  # the float64 loops: same argument order, double scalars
@@ -122,7 +123,7 @@ EXPORTS = [
     "dsp_event_elapsed_ms", "dsp_last_error", "dsp_fatal_message", "dsp_version", "dsp_chain_create", "dsp_chain_execute",
     "dsp_chain_check", "dsp_chain_destroy", "dsp_chain_geometry", "dsp_chain_kernel_name", "dsp_chain_set_fused", "dsp_bl_subtract_f32", "dsp_pole_zero_f32",
     "dsp_double_pole_zero_f32", "dsp_trap_filter_f32", "dsp_trap_norm_f32", "dsp_asym_trap_filter_f32", "dsp_fixed_time_pickoff_f32",
-    "dsp_time_point_thresh_f32", "dsp_min_max_f32", "dsp_dwt_haar_f32", "dsp_convolve_wf_f32", "dsp_synth_waveforms",
+    "dsp_time_point_thresh_f32", "dsp_min_max_f32", "dsp_dwt_haar_f32", "dsp_convolve_wf_f32", "dsp_synth_waveforms", "dsp_stream_read",
     "dsp_bl_subtract_f64", "dsp_pole_zero_f64", "dsp_double_pole_zero_f64", "dsp_trap_filter_f64", "dsp_trap_norm_f64",
     "dsp_asym_trap_filter_f64", "dsp_fixed_time_pickoff_f64", "dsp_time_point_thresh_f64", "dsp_min_max_f64", "dsp_dwt_haar_f64",
     "dsp_convolve_wf_f64",

@@ -29,6 +29,7 @@ extern "C" int dsp_internal_launch_vm_f64(const DevProgram* dev_prog, const IoPt
                                           int threads, int lds_bytes, hipStream_t stream);
 extern "C" int dsp_internal_set_vm_lds(int lds_bytes);
 extern "C" const char* dsp_internal_vm_kernel_name();
+extern "C" int dsp_internal_launch_stream_read(const void* src, int64_t bytes, uint32_t* sink, int blocks, hipStream_t stream);
 extern "C" int dsp_internal_launch_synth(void* wf, int out_dtype, int64_t n_wf, int wf_len, int64_t row_stride, float* baseline,
                                          float* t_pick, uint64_t seed, int64_t first_row, float tau, float sigma, float pick_offset,
                                          float bl_lo, float bl_hi, float amp_lo, float amp_hi, hipStream_t stream);
@@ -1052,6 +1053,19 @@ int g_min_max(int ty, const WfIn& in, void* t_min, void* t_max, void* a_min, voi
 DSP_GUFUNCS(f32, DSP_F32, float)
 DSP_GUFUNCS(f64, DSP_F64, double)
 #undef DSP_GUFUNCS
+
+int dsp_stream_read(const void* src, int64_t bytes, void* sink, void* stream) {
+    if (!src || !sink || bytes < 16) return fail(DSP_ERR_ARG, "dsp_stream_read: need a source of at least 16 bytes and a 4-byte sink");
+    if (reinterpret_cast<uintptr_t>(src) & 15u) return fail(DSP_ERR_ARG, "dsp_stream_read: source must be 16-byte aligned");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t e = (hipError_t)dsp_internal_launch_stream_read(src, bytes, (uint32_t*)sink, cus * 8, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DSP_ERR_HIP, "stream-read kernel launch failed: %s", hipGetErrorString(e));
+    return DSP_OK;
+}
 
 int dsp_synth_waveforms(void* wf, int out_dtype, int64_t n_wf, int32_t wf_len, int64_t row_stride, float* baseline, float* t_pick,
                         uint64_t seed, int64_t first_row, float tau, float sigma, float pick_offset, float bl_lo, float bl_hi,

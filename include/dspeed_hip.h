@@ -252,6 +252,11 @@ int dsp_synth_waveforms(void* wf, int out_dtype, int64_t n_wf, int32_t wf_len, i
                         uint64_t seed, int64_t first_row, float tau, float sigma, float pick_offset, float bl_lo, float bl_hi,
                         float amp_lo, float amp_hi, void* stream);
 
+/* ---- measurement helper (bench.py; SURVEY.md 8d "also report against a measured read-only streaming kernel") -----------
+ * Reads `bytes` (multiple of 16) device bytes once with 16-byte loads and discards them; `sink` = any 4 writable device bytes.
+ * Asynchronous on `stream`.  Replaces nothing in the reference. */
+int dsp_stream_read(const void* src, int64_t bytes, void* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
