@@ -468,14 +468,14 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad TRAP_PICKOFF", i);
                 if (o.ip[3] != DSP_OP_TRAP_FILTER && o.ip[3] != DSP_OP_TRAP_NORM && o.ip[3] != DSP_OP_ASYM_TRAP)
                     return fail(DSP_ERR_ARG, "op %d: TRAP_PICKOFF ip[3] must name a trapezoid opcode", i);
-                if (o.io == 's') return fail(DSP_ERR_UNSUPPORTED, "fixed_time_pickoff mode 's' (natural spline) is not implemented on the device");
+                if (o.io == 's')
+                    return fail(DSP_ERR_UNSUPPORTED, "TRAP_PICKOFF cannot take mode 's' (the spline needs the whole filtered waveform): use TRAP_FILTER + PICKOFF");
                 int rc = setup_trap(d, o.ip[3], o.ip[0], o.ip[1], o.ip[2], slot_len[o.src], P.slots[o.src].C);
                 if (rc) return fail(rc, "%s", dsp_fatal_message(rc));
                 break;
             }
             case DSP_OP_PICKOFF:
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad PICKOFF", i);
-                if (o.ip[0] == 's') return fail(DSP_ERR_UNSUPPORTED, "fixed_time_pickoff mode 's' (natural spline) is not implemented on the device");
                 break;
             case DSP_OP_TIME_POINT_THRESH:
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad TIME_POINT_THRESH", i);

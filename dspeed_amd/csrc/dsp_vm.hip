@@ -477,12 +477,56 @@ __device__ void op_trap(Ctx<T>& cx, const DevOp& op) {
 // fixed_time_pickoff  (processors/fixed_time_pickoff.py:12-125), modes i n f c l h (float64 interpolation weights)
 // w4 = samples at i0-1, i0, i0+1, i0+2 (only the in-range ones are used)
 // ------------------------------------------------------------------------------------------------
+// mode 's' (fixed_time_pickoff.py:107-123): natural cubic spline through the whole waveform, evaluated at t_in.  The reference
+// runs the tridiagonal sweep over all samples; its two recurrences (u forward, the second derivatives backward) contract by
+// |w2| -> 2 - sqrt(3) = 0.268 per step, so a perturbation 48 samples away is scaled by 3e-28 -- far below one float64 ulp.
+// Lane l therefore rebuilds u[i0 + l] from a 48-sample warm-up in the reference's operation order (exact from sample 1 when
+// the window reaches it), and the back substitution runs over the 64 lanes' values (the tail beyond them is dropped the same way).
+// The forward coefficient w2[i] = -0.5 / (0.5 w2[i-1] + 2) is data independent and stationary in float64 from i = 15 on.
+template <typename T>
+__device__ T pickoff_spline(Ctx<T>& cx, const DevSlot& ss, T t_in) {
+    const int n = ss.len, lane = lane_id();
+    const int i0 = (int)t_in;  // 0 <= i0 <= n - 2: the caller handles integer t_in
+    const double t0 = (double)t_in - (double)i0, t1 = 1.0 - t0;
+    auto X = [&](int i) -> double { return (double)cx.lds[padded_index(ss, i)]; };
+    constexpr int WARM = 48;
+    constexpr double W2_FIX = -0.2679491924311227;
+    const int j = i0 + lane;
+    double u = 0.0, w = 0.0;
+    if (j >= 1 && j <= n - 2) {
+        int s = j - WARM;
+        if (s < 1) s = 1;
+        if (s - 1 >= 15) {
+            w = W2_FIX;
+        } else {
+            for (int i = 1; i <= s - 1; ++i) w = -0.5 / (0.5 * w + 2.0);
+        }
+        for (int i = s; i <= j; ++i) {
+            const double p = 0.5 * w + 2.0;
+            w = -0.5 / p;
+            const double d = (X(i + 1) - 2.0 * X(i)) + X(i - 1);
+            u = (3.0 * d - 0.5 * u) / p;
+        }
+    }
+    // w2[i] = w2[i] * w2[i+1] + u[i] from the far end down to i0 (w2 = u = 0 outside 1..n-2, as np.zeros leaves them)
+    double W = 0.0, W1 = 0.0;
+    for (int l = 63; l >= 0; --l) {
+        const double wl = readlane(w, l), ul = readlane(u, l);
+        W = wl * W + ul;
+        if (l == 1) W1 = W;
+    }
+    const double t1_3 = t1 * (t1 * t1), t0_3 = t0 * (t0 * t0);
+    return (T)((t1 * X(i0) + t0 * X(i0 + 1)) + ((t1_3 - t1) * W + (t0_3 - t0) * W1) / 6.0);
+}
+
 template <typename T>
 __device__ void op_pickoff(Ctx<T>& cx, const DevOp& op) {
     const DevSlot& ss = cx.prog->slots[op.src];
     const T t_in = cx.scalar(op.sp[0]);
     T out = quiet_nan<T>();
-    if (!cx.slot_nan(op.src) && pickoff_in_range(t_in, ss.len)) {
+    if (op.ip[0] == 's' && !cx.slot_nan(op.src) && pickoff_in_range(t_in, ss.len) && (T)(int)t_in != t_in) {
+        out = pickoff_spline(cx, ss, t_in);
+    } else if (!cx.slot_nan(op.src) && pickoff_in_range(t_in, ss.len)) {
         const int i0 = (int)t_in;
         T w4[4];
 #pragma unroll

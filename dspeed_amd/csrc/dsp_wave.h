@@ -136,6 +136,7 @@ __device__ T pickoff_eval(T t_in, int mode, int n, const T* w4, int& fatal_code)
             return (T)(((((-2.0 * t1_3 + 3.0 * t1_2) * (double)w4[1] + (-2.0 * t0_3 + 3.0 * t0_2) * (double)w4[2]) - (t1_3 - t1_2) * m0)) +
                        (t0_3 - t0_2) * m1);
         }
+        case 's': return w4[1];  // (only reached for integer t_in, handled above: the spline itself is pickoff_spline in dsp_vm.hip)
         case 'i': fatal_code = DSP_E_FTP_INT; return quiet_nan<T>();
         default: fatal_code = DSP_E_FTP_MODE; return quiet_nan<T>();
     }

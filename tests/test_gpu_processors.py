@@ -101,7 +101,7 @@ def test_traps_golden(c, P, DSPFatal):
         assert_rel_to_peak(out, c["w_out"], _tol(c), c.name)
 
 
-@pytest.mark.parametrize("c", [c for c in _f32(cases("fixed_time_pickoff")) if c.params["mode"] != "s"], ids=lambda c: c.name)
+@pytest.mark.parametrize("c", _f32(cases("fixed_time_pickoff")), ids=lambda c: c.name)
 def test_fixed_time_pickoff_golden(c, P, DSPFatal):
     out = _expect(c, DSPFatal, lambda: P.fixed_time_pickoff(c["w_in"], c.params["t_in"], ord(c.params["mode"])))
     if out is not None:
@@ -111,9 +111,18 @@ def test_fixed_time_pickoff_golden(c, P, DSPFatal):
             _eq(out, c["a_out"], c.name)
 
 
-def test_fixed_time_pickoff_spline_not_silently_wrong(P):
-    with pytest.raises(NotImplementedError):
-        P.fixed_time_pickoff(np.arange(20, dtype=np.float32), 3.5, ord("s"))
+def test_fixed_time_pickoff_spline_windowed_equals_full_sweep(P):
+    """mode 's': the device rebuilds the spline's second derivatives from a 48-sample window around t_in; the reference
+    sweeps the whole waveform (fixed_time_pickoff.py:107-123).  Same float32 result at every position, ends included."""
+    rng = np.random.default_rng(5)
+    for wf_len in (20, 64, 100, 1000, 4096):
+        pos = np.unique(np.clip(np.concatenate([np.arange(0, 70), np.arange(wf_len - 70, wf_len - 1), rng.integers(0, wf_len - 1, 60)]),
+                                0, wf_len - 2))
+        t_in = (pos + rng.uniform(0.05, 0.95, pos.size)).astype(np.float32)
+        x = (1000 * np.sin(np.arange(wf_len) / 7.0)[None, :] + 300 * rng.standard_normal((pos.size, wf_len))).astype(np.float32)
+        got = P.fixed_time_pickoff(x, t_in, ord("s"))
+        want = oracle.fixed_time_pickoff(x, t_in, "s")[0]
+        _eq(got, want, f"spline len={wf_len}")
 
 
 @pytest.mark.parametrize("c", _f32(cases("time_point_thresh")), ids=lambda c: c.name)
@@ -202,7 +211,7 @@ def test_reductions_vs_oracle(wf_len, P):
         _eq(got, oracle.time_point_thresh(x, thr, start, walk)[0], f"tpt walk={walk}")
     t_in = rng.uniform(-2, wf_len + 1, n_wf).astype(np.float32)
     t_in[::7] = np.floor(t_in[::7])
-    for mode in "nfclh":
+    for mode in "nfclhs":
         got = P.fixed_time_pickoff(x, t_in, ord(mode))
         _eq(got, oracle.fixed_time_pickoff(x, t_in, mode)[0], f"pickoff {mode}")
 
