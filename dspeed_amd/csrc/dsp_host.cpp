@@ -480,6 +480,9 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             case DSP_OP_TIME_POINT_THRESH:
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad TIME_POINT_THRESH", i);
                 break;
+            case DSP_OP_MEAN_BELOW:
+                if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad MEAN_BELOW", i);
+                break;
             case DSP_OP_MIN_MAX:
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst + 3 >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad MIN_MAX", i);
                 break;
@@ -979,6 +982,21 @@ int g_tpt(int ty, const WfIn& in, const void* thr_dev, double thr, const void* t
     sto.ip[0] = 0;
     return m.run(in.n_wf, st, er);
 }
+int g_mean_below(int ty, const WfIn& in, const void* thr_dev, double thr, void* out, void* st, int64_t* er) {
+    if (in.n_wf <= 0) return DSP_OK;
+    Mini m(ty);
+    m.n_sregs = 1;
+    const int s_in = m.add_slot(in.len);
+    const int io_in = m.add_io(DSP_IO_WF_IN, in.dtype, in.len, in.stride, in.ptr);
+    m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
+    dsp_scalar_arg a = m.scalar(thr_dev, thr);
+    dsp_op& o = m.add_op(DSP_OP_MEAN_BELOW, 0, s_in, 0);
+    o.sp[0] = a;
+    const int io_out = m.add_io(DSP_IO_SCALAR_OUT, ty, 1, 1, out);
+    dsp_op& sto = m.add_op(DSP_OP_STORE_SCALAR, 0, 0, io_out);
+    sto.ip[0] = 0;
+    return m.run(in.n_wf, st, er);
+}
 int g_min_max(int ty, const WfIn& in, void* t_min, void* t_max, void* a_min, void* a_max, void* st, int64_t* er) {
     if (in.n_wf <= 0) return DSP_OK;
     Mini m(ty);
@@ -1034,6 +1052,10 @@ int g_min_max(int ty, const WfIn& in, void* t_min, void* t_max, void* a_min, voi
                                     int64_t* err_row) {                                                                                       \
         return g_tpt(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, threshold_dev, (double)threshold, t_start_dev, (double)t_start,         \
                      (double)walk_forward, out, stream, err_row);                                                                             \
+    }                                                                                                                                         \
+    int dsp_mean_below_threshold_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,                        \
+                                       const FT* threshold_dev, FT threshold, FT* out, void* stream, int64_t* err_row) {                      \
+        return g_mean_below(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, threshold_dev, (double)threshold, out, stream, err_row);         \
     }                                                                                                                                         \
     int dsp_min_max_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, FT* t_min, FT* t_max, FT* a_min,     \
                           FT* a_max, void* stream, int64_t* err_row) {                                                                        \

@@ -575,6 +575,35 @@ __device__ void op_trap_pickoff(Ctx<T>& cx, const DevOp& op) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// mean_below_threshold (processors/arithmetic.py:9-62): float64 total of the samples below the threshold / their count.
+// The reference adds them one by one; here per-lane partial sums and a wavefront scan.  For float32 samples of one
+// waveform's dynamic range the float64 sums are exact, hence order independent; otherwise the last float64 bit may differ.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ void op_mean_below(Ctx<T>& cx, const DevOp& op) {
+    const DevSlot& ss = cx.prog->slots[op.src];
+    const T thr = cx.scalar(op.sp[0]);
+    T out = quiet_nan<T>();
+    if (!cx.slot_nan(op.src) && !(thr != thr)) {
+        const int n = ss.len, C = ss.C, i0 = lane_id() * C;
+        const T* ps = cx.chunk(ss);
+        double total = 0.0, count = 0.0;
+        for (int t = 0; t < C; ++t) {
+            const T v = ps[t];
+            if (i0 + t < n && v < thr) {
+                total += (double)v;
+                count += 1.0;
+            }
+        }
+        total = readlane(wave_scan_add(total), 63);
+        count = readlane(wave_scan_add(count), 63);
+        if (count > 0.0) out = (T)(total / count);
+    }
+    if (lane_id() == 0) cx.sregs()[op.dst] = out;
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
 // time_point_thresh  (processors/time_point_thresh.py:12-92): comparisons only -> bit exact
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -858,6 +887,7 @@ __global__ void __launch_bounds__(256) dsp_vm_kernel(const DevProgram* __restric
                 case DSP_OP_TIME_POINT_THRESH: op_time_point_thresh(cx, op); break;
                 case DSP_OP_MIN_MAX: op_min_max(cx, op, false); break;
                 case DSP_OP_AMAX: op_min_max(cx, op, true); break;
+                case DSP_OP_MEAN_BELOW: op_mean_below(cx, op); break;
                 case DSP_OP_DWT_HAAR: op_dwt_haar(cx, op); break;
                 case DSP_OP_COPY: op_copy(cx, op); break;
                 case DSP_OP_CONVOLVE: op_convolve(cx, op); break;

@@ -86,6 +86,7 @@ _SIGS = {
     "bl_subtract": "wsW", "pole_zero": "wsW", "double_pole_zero": "wsssW", "trap_filter": "wiiW", "trap_norm": "wiiW",
     "asym_trap_filter": "wiiiW", "fixed_time_pickoff": "wscS", "time_point_thresh": "wsssS", "min_max": "wSSSS",
     "discrete_wavelet_transform": "wiccW", "convolve_wf": "wtcW", "fft_convolve_wf": "wtcW", "amax": "wiS",
+    "mean_below_threshold": "wsS",
 }
 _GENERATORS = ("cusp_filter", "zac_filter")
 _MODULES = ("dspeed.processors", "dspeed_amd.processors", "numpy", "np")
@@ -841,6 +842,11 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
                     raise ProcessingChainError("min_max outputs must be variable names")
                 a.kind, a.sreg = "scalar", first + k
             p.add_op(_lib.OP_MIN_MAX, dst=first, src=src.slot)
+            release(src, si)
+        elif fn == "mean_below_threshold":
+            src = ensure_loaded(args[0], si)
+            o = out_scalar(args[2])
+            p.add_op(_lib.OP_MEAN_BELOW, dst=o.sreg, src=src.slot, sp=(scalar_operand(args[1], args, what=what),))
             release(src, si)
         elif fn == "amax":
             src = ensure_loaded(args[0], si)

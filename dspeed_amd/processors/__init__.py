@@ -143,6 +143,22 @@ def _time_point_thresh(g, *args):
         st.release()
 
 
+def _mean_below_threshold(g, *args):
+    ins, outs = _split(g, args)
+    st = Staging()
+    try:
+        ptr, code, n_wf, n, stride, one_d = st.wf_in(ins[0])
+        sfx = loop_suffix(_dtype_of(ins[0]))
+        ft = _F[sfx]
+        tp, tv = st.scalar_in(ins[1], n_wf, ft)
+        optr, res = st.out(outs[0], () if one_d else (n_wf,), ft)
+        run(entry("mean_below_threshold", sfx), g.__name__, ptr, code, n_wf, n, stride, tp, tv, optr)
+        st.finish()
+        return res[()] if isinstance(res, np.ndarray) and res.ndim == 0 else res
+    finally:
+        st.release()
+
+
 def _min_max(g, *args):
     ins, outs = _split(g, args)
     st = Staging()
@@ -162,6 +178,8 @@ fixed_time_pickoff = HipGUFunc("fixed_time_pickoff", "(n),(),()->()", ["ffb->f",
                                "value at a (fractional) sample index, modes i n f c l h (reference processors/fixed_time_pickoff.py:12-125)")
 time_point_thresh = HipGUFunc("time_point_thresh", "(n),(),(),()->()", ["ffff->f", "dddd->d"], _time_point_thresh,
                               "first threshold crossing walking forward/backward (reference processors/time_point_thresh.py:12-92)")
+mean_below_threshold = HipGUFunc("mean_below_threshold", "(n),()->()", ["ff->f", "dd->d"], _mean_below_threshold,
+                                 "mean of the samples below a threshold (reference processors/arithmetic.py:9-62)")
 min_max = HipGUFunc("min_max", "(n)->(),(),(),()", ["f->ffff", "d->dddd"], _min_max,
                     "first-occurrence argmin/argmax and values (reference processors/min_max.py:11-82)")
 
@@ -287,4 +305,4 @@ zac_filter = HipGUFunc("zac_filter", "(),(),(),(n)", ["ffff", "dddd"], _zac_filt
                        "zero-area CUSP kernel generator, host, once (reference processors/energy_kernels.py:76-157)")
 
 __all__ = ["bl_subtract", "pole_zero", "double_pole_zero", "trap_filter", "trap_norm", "asym_trap_filter", "fixed_time_pickoff",
-           "time_point_thresh", "min_max", "discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "cusp_filter", "zac_filter"]
+           "time_point_thresh", "min_max", "mean_below_threshold", "discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "cusp_filter", "zac_filter"]

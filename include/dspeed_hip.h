@@ -149,6 +149,7 @@ typedef struct dsp_scalar_arg {
 #define DSP_OP_TRAP_PICKOFF 16 /* fusion of TRAP_FILTER|TRAP_NORM|ASYM_TRAP (ip[3] = which opcode) with PICKOFF: the trap output is
                                   never materialised; sreg[dst] <- trap(src) at sp[0]; ip[0..2] = rise, flat, fall; mode in `io` */
 #define DSP_OP_AMAX 17         /* numpy.amax along the sample axis (icpc-dsp-config.json:123-143): sreg[dst] <- max(src), NaN if any NaN */
+#define DSP_OP_MEAN_BELOW 19    /* arithmetic.py:9-62 mean_below_threshold: sreg[dst] <- mean of the samples of src below sp[0]; NaN if none */
 #define DSP_OP_SCALAR_AFFINE 18 /* sreg[dst] <- sp[0] * sp[1] + sp[2]  (host-folded expressions such as tp_0 + 10*us) */
 
 typedef struct dsp_op {
@@ -211,6 +212,8 @@ int dsp_fixed_time_pickoff_f32(const void* in, int in_dtype, int64_t n_wf, int32
 int dsp_time_point_thresh_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
                               const float* threshold_dev, float threshold, const float* t_start_dev, float t_start,
                               float walk_forward, float* out, void* stream, int64_t* err_row);
+int dsp_mean_below_threshold_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* threshold_dev,
+                                 float threshold, float* out, void* stream, int64_t* err_row);
 int dsp_min_max_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float* t_min, float* t_max,
                     float* a_min, float* a_max, void* stream, int64_t* err_row);
 int dsp_dwt_haar_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t level, int32_t coeff_char,
@@ -237,6 +240,8 @@ int dsp_fixed_time_pickoff_f64(const void* in, int in_dtype, int64_t n_wf, int32
 int dsp_time_point_thresh_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
                               const double* threshold_dev, double threshold, const double* t_start_dev, double t_start,
                               double walk_forward, double* out, void* stream, int64_t* err_row);
+int dsp_mean_below_threshold_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
+                                 const double* threshold_dev, double threshold, double* out, void* stream, int64_t* err_row);
 int dsp_min_max_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, double* t_min, double* t_max,
                     double* a_min, double* a_max, void* stream, int64_t* err_row);
 int dsp_dwt_haar_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t level, int32_t coeff_char,

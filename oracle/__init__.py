@@ -153,6 +153,14 @@ def min_max(w):
     return (*o, rc)
 
 
+def mean_below_threshold(w, threshold):
+    w = _rows(w)
+    thr, st = _vec(threshold, w.shape[0], w.dtype)
+    out = np.empty(w.shape[0], dtype=w.dtype)
+    rc = _call("mean_below_threshold", w.dtype, _p(w), C.c_long(w.shape[0]), C.c_int(w.shape[1]), _p(thr), C.c_int(st), _p(out))
+    return out, rc
+
+
 def convolve_wf(w, kernel, mode, out_len, in_len=None):
     """``in_len``: use only the first in_len samples of each row (the reference's ``wf[:in_len]`` slice view)."""
     w = _rows(w)

@@ -52,6 +52,7 @@ enum {
     int orc_time_point_thresh_##S(const T* in, long n_wf, int len, const T* thr, int thr_stride, const T* t_start,            \
                                   int t_start_stride, T walk_forward, T* out, long* err_row);                                 \
     int orc_min_max_##S(const T* in, long n_wf, int len, T* t_min, T* t_max, T* a_min, T* a_max, long* err_row);              \
+    int orc_mean_below_threshold_##S(const T* in, long n_wf, int len, const T* thr, int thr_stride, T* out, long* err_row);   \
     int orc_convolve_##S(const T* in, long n_wf, int len, long in_row_stride, const T* kern, int m, int mode, T* out, int p,  \
                          long* err_row);                                                                                      \
     int orc_dwt_haar_##S(const T* in, long n_wf, int len, int level, int part, T* out, int p, long* err_row);

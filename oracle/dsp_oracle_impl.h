@@ -253,6 +253,23 @@ static int FN(row_min_max)(const T* w_in, int n, T* t_min, T* t_max, T* a_min, T
     return 0;
 }
 
+/* arithmetic.py:9-62 mean_below_threshold: `total = 0.0` is float64 and stays float64 (float64 += T), `count` int64,
+ * result = total / count (float64 / int64 -> float64) rounded by the store; NaN if nothing is below the threshold. */
+static int FN(row_mean_below_threshold)(const T* w_in, int n, T threshold, T* result) {
+    *result = (T)NAN;
+    if (FN(row_has_nan)(w_in, n) || isnan(threshold)) return 0;
+    double total = 0.0;
+    long count = 0;
+    for (int i = 0; i < n; ++i)
+        if (w_in[i] < threshold) {
+            total += (double)w_in[i];
+            ++count;
+        }
+    if (count == 0) return 0;
+    *result = (T)(total / (double)count);
+    return 0;
+}
+
 /* convolutions.py:14-72 (and :75-119 for the FFT variant, which computes the same sums by another route).
  * np.convolve's float32 summation order is NumPy-internal and not part of the reference, so the
  * oracle accumulates each output in double and rounds once; parity vs the goldens is 1e-6 of max|out|. */
@@ -364,6 +381,9 @@ int FN(orc_time_point_thresh)(const T* in, long n_wf, int len, const T* thr, int
 }
 int FN(orc_min_max)(const T* in, long n_wf, int len, T* t_min, T* t_max, T* a_min, T* a_max, long* err_row) {
     ROWLOOP(FN(row_min_max)(in + r * len, len, t_min + r, t_max + r, a_min + r, a_max + r))
+}
+int FN(orc_mean_below_threshold)(const T* in, long n_wf, int len, const T* thr, int thr_stride, T* out, long* err_row) {
+    ROWLOOP(FN(row_mean_below_threshold)(in + r * len, len, PV(thr, r), out + r))
 }
 int FN(orc_convolve)(const T* in, long n_wf, int len, long in_row_stride, const T* kern, int m, int mode, T* out, int p, long* err_row) {
     ROWLOOP(FN(row_convolve)(in + r * in_row_stride, len, kern, m, mode, out + r * (long)p, p))

@@ -26,6 +26,7 @@ feed each body:
 
 Usage:  python oracle/gen_golden.py            (writes tests/golden/*.npz)
         /opt/conda/bin/python3.9 oracle/gen_golden.py --dwt   (PyWavelets 1.1.1 lives there)
+        python oracle/gen_golden.py --arithmetic   (only tests/golden/arithmetic.npz)
 """
 from __future__ import annotations
 
@@ -192,6 +193,15 @@ def call_min_max(w):
     o = [np.empty(1, dtype=w.dtype) for _ in range(4)]
     fatal = run_body(m.min_max, w, *o)
     return np.array([x[0] for x in o], dtype=w.dtype), fatal
+
+
+def call_mean_below(w, thr):
+    """float32 loop: numba keeps `total` (0.0) in float64 and adds float32 samples to it; plain NumPy-2 would demote the
+    Python float to float32.  Feeding the float32 samples as float64 copies reproduces numba (comparison unchanged)."""
+    m = _ref("arithmetic")
+    out = np.empty(1, dtype=w.dtype)
+    fatal = run_body(m.mean_below_threshold, w.astype(np.float64), np.float64(w.dtype.type(thr)), out)
+    return out[0], fatal
 
 
 def call_kernel_gen(name, sigma, flat, decay, length, dt):
@@ -437,6 +447,28 @@ def gen_tpt(rng):
     b.save()
 
 
+def gen_arithmetic():
+    """own seed: added after the other books, which must not change"""
+    rng = np.random.default_rng(0xA717)
+    b = Book("arithmetic")
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        cases = [(np.array([1, 2, 3, 4, 5.0], dtype=dt), 4.0), (np.array([10, 20, 30, 40, 50.0], dtype=dt), 10.0),
+                 (np.array([1, 2, 3, 4, 5.0], dtype=dt), 100.0), (np.array([1, 2, np.nan, 4, 5.0], dtype=dt), 4.0),
+                 (np.array([1, 2, 3, 4, 5.0], dtype=dt), np.nan), (np.array([7.5], dtype=dt), 8.0),
+                 (np.array([-np.inf, 1.0, 2.0], dtype=dt), 1.5), (np.array([0.0, -0.0, 1e-30], dtype=dt), 1e-20)]
+        for n in (63, 64, 65, 1000, 4096, 8192):
+            w = synth_waveforms(rng, 1, n, dtype=dt)[0][0]
+            cases.append((w, float(np.median(w))))
+            cases.append((w, float(w.min())))
+            cases.append((w, float(w.max()) + 1.0))
+        wide = (rng.standard_normal(3000) * 10.0 ** rng.uniform(-6, 6, 3000)).astype(dt)
+        cases.append((wide, 0.0))
+        for k, (w, thr) in enumerate(cases):
+            out, fatal = call_mean_below(w, thr)
+            b.add(f"{tag}_case{k}", "mean_below_threshold", tag, {"w_in": w, "result": out}, {"threshold": float(dt(thr))}, fatal)
+    b.save()
+
+
 def gen_fir(rng):
     b = Book("energy_kernels")
     for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
@@ -561,6 +593,9 @@ def main():
         gen_dwt()
         return
     _install_stubs()
+    if "--arithmetic" in sys.argv:
+        gen_arithmetic()
+        return
     rng = np.random.default_rng(0xD5BEED)
     gen_elementwise(rng)
     gen_pole_zero(rng)
@@ -569,6 +604,7 @@ def main():
     gen_tpt(rng)
     gen_fir(rng)
     gen_chains(rng)
+    gen_arithmetic()
 
 
 if __name__ == "__main__":

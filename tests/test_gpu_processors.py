@@ -125,6 +125,30 @@ def test_fixed_time_pickoff_spline_windowed_equals_full_sweep(P):
         _eq(got, want, f"spline len={wf_len}")
 
 
+@pytest.mark.parametrize("c", cases("arithmetic"), ids=lambda c: c.name)
+def test_mean_below_threshold_golden(c, P, DSPFatal):
+    out = _expect(c, DSPFatal, lambda: P.mean_below_threshold(c["w_in"], c.params["threshold"]))
+    if c.tag == "f64":  # float64 partial sums in another order than the reference's sequential one: last bits
+        assert np.isclose(out, c["result"], rtol=1e-13, atol=0, equal_nan=True), c.name
+    else:
+        _eq(out, c["result"], c.name)
+
+
+def test_mean_below_threshold_vs_oracle_and_reference_answers(P):
+    """reference tests/processors/test_arithmetic.py:8-40, then seeded rows with per-waveform thresholds"""
+    w = np.array([1.0, 2.0, 3.0, 4.0, 5.0])
+    assert P.mean_below_threshold(w, 4.0) == 2.0 and P.mean_below_threshold(w, 100.0) == 3.0
+    assert np.isnan(P.mean_below_threshold(np.array([10.0, 20.0, 30.0, 40.0, 50.0]), 10.0))
+    assert np.isnan(P.mean_below_threshold(np.array([1.0, 2.0, np.nan, 4.0, 5.0]), 4.0))
+    rng = np.random.default_rng(3)
+    x = (10000 + 50 * rng.standard_normal((200, 2781))).astype(np.float32)
+    thr = (10000 + 50 * rng.standard_normal(200)).astype(np.float32)
+    thr[5] = np.nan
+    thr[6] = 0.0
+    x[7, 100] = np.nan
+    _eq(P.mean_below_threshold(x, thr), oracle.mean_below_threshold(x, thr)[0], "mean_below_threshold")
+
+
 @pytest.mark.parametrize("c", _f32(cases("time_point_thresh")), ids=lambda c: c.name)
 def test_time_point_thresh_golden(c, P, DSPFatal):
     p = c.params

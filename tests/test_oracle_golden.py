@@ -204,6 +204,22 @@ def test_golden_min_max(c):
     _eq(np.array([x[0] for x in o]), c["out"], c.name)
 
 
+@pytest.mark.parametrize("c", cases("arithmetic"), ids=lambda c: c.name)
+def test_golden_mean_below_threshold(c):
+    out, rc = oracle.mean_below_threshold(c["w_in"], c.params["threshold"])
+    _check_fatal(c, rc)
+    _eq(out[0], c["result"], c.name)
+
+
+def test_reference_known_answers_mean_below_threshold():
+    """reference tests/processors/test_arithmetic.py:8-40"""
+    w = np.array([1.0, 2.0, 3.0, 4.0, 5.0])
+    assert oracle.mean_below_threshold(w, 4.0)[0][0] == 2.0
+    assert oracle.mean_below_threshold(w, 100.0)[0][0] == 3.0
+    assert np.isnan(oracle.mean_below_threshold(np.array([10.0, 20.0, 30.0, 40.0, 50.0]), 10.0)[0][0])
+    assert np.isnan(oracle.mean_below_threshold(np.array([1.0, 2.0, np.nan, 4.0, 5.0]), 4.0)[0][0])
+
+
 @pytest.mark.parametrize("c", cases("convolutions"), ids=lambda c: c.name)
 def test_golden_convolve(c):
     w, k, want = c["w_in"], c["kernel"], c["w_out"]
