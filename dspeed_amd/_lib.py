@@ -74,6 +74,9 @@ def lib():
         "dsp_event_create": [C.POINTER(vp)],
         "dsp_event_destroy": [vp],
         "dsp_event_record": [vp, vp],
+        "dsp_stream_wait_event": [vp, vp],
+        "dsp_host_register": [vp, i64],
+        "dsp_host_unregister": [vp],
         "dsp_event_sync": [vp],
         "dsp_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],
         "dsp_chain_create": [C.POINTER(Op), C.c_int, C.POINTER(IoDesc), C.c_int, C.POINTER(i32), C.c_int, C.c_int, C.c_int,
@@ -118,7 +121,7 @@ def lib():
 
 
 EXPORTS = [
-    "dsp_device_count", "dsp_set_device", "dsp_get_device", "dsp_device_info", "dsp_malloc", "dsp_free", "dsp_host_alloc",
+    "dsp_device_count", "dsp_set_device", "dsp_get_device", "dsp_device_info", "dsp_malloc", "dsp_free", "dsp_host_alloc", "dsp_host_register", "dsp_host_unregister", "dsp_stream_wait_event",
     "dsp_host_free", "dsp_memset", "dsp_h2d", "dsp_d2h", "dsp_h2d_async", "dsp_d2h_async", "dsp_stream_create", "dsp_stream_destroy",
     "dsp_stream_sync", "dsp_sync", "dsp_event_create", "dsp_event_destroy", "dsp_event_record", "dsp_event_sync",
     "dsp_event_elapsed_ms", "dsp_last_error", "dsp_fatal_message", "dsp_version", "dsp_chain_create", "dsp_chain_execute",

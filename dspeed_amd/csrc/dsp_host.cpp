@@ -91,7 +91,10 @@ int fail(int code, const char* fmt, ...) {
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess) return fail(DSP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) {                                                                    \
+            (void)hipGetLastError(); /* reported here: do not leave it for an unrelated later launch check */ \
+            return fail(DSP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));               \
+        }                                                                                          \
     } while (0)
 
 constexpr int LDS_BYTES_PER_CU = 160 * 1024;
@@ -229,6 +232,28 @@ int dsp_event_destroy(void* event) {
 }
 int dsp_event_record(void* event, void* stream) {
     HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return DSP_OK;
+}
+int dsp_stream_wait_event(void* stream, void* event) {
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return DSP_OK;
+}
+int dsp_host_register(void* host, int64_t bytes) {
+    if (!host || bytes <= 0) return fail(DSP_ERR_ARG, "dsp_host_register: null pointer or empty range");
+    hipError_t e = hipHostRegister(host, (size_t)bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // a refusal (range already registered, read-only mapping) must not poison the next launch check
+        return fail(DSP_ERR_HIP, "hipHostRegister: %s", hipGetErrorString(e));
+    }
+    return DSP_OK;
+}
+int dsp_host_unregister(void* host) {
+    if (!host) return DSP_OK;
+    hipError_t e = hipHostUnregister(host);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(DSP_ERR_HIP, "hipHostUnregister: %s", hipGetErrorString(e));
+    }
     return DSP_OK;
 }
 int dsp_event_sync(void* event) {
@@ -686,6 +711,7 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         if (!io_ptrs[k]) return fail(DSP_ERR_ARG, "io binding %d is NULL", k);
         ptrs.p[k] = io_ptrs[k];
     }
+    (void)hipGetLastError();  // launch checks below report this launch, not a stale error of an unrelated earlier call
     const int blocks = chain_blocks(ch, n_wf);
     const int threads = 64 * ch->waves_per_block;
     const int lds = ch->lds_bytes_per_wave * ch->waves_per_block;

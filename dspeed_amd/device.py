@@ -55,6 +55,10 @@ class Stream:
     def sync(self):
         _lib.check(_lib.lib().dsp_stream_sync(self.ptr), what="stream_sync")
 
+    def wait_event(self, event: "Event"):
+        """work queued on this stream from now on starts after ``event``"""
+        _lib.check(_lib.lib().dsp_stream_wait_event(self.ptr, event.ptr), what="stream_wait_event")
+
     def __del__(self):
         try:
             if self.ptr:
@@ -109,6 +113,32 @@ class PinnedArray:
                 self.array = None
                 _lib.lib().dsp_host_free(self.ptr)
                 self.ptr = None
+        except Exception:
+            pass
+
+
+class HostPin:
+    """Page-locks a caller-owned C-contiguous NumPy array in place for as long as this object lives, so that ``h2d_async`` /
+    ``d2h_async`` on it overlap kernels without a staging copy.  The reference's ``build_dsp`` fills the same input buffer for
+    every file chunk (build_dsp.py:399-432), so a linked buffer is pinned once and reused."""
+
+    def __init__(self, array: np.ndarray):
+        if not (isinstance(array, np.ndarray) and array.flags.c_contiguous and array.nbytes > 0):
+            raise ValueError("HostPin needs a non-empty C-contiguous NumPy array")
+        self.array = array
+        self.ptr = array.ctypes.data
+        self.nbytes = array.nbytes
+        _lib.check(_lib.lib().dsp_host_register(self.ptr, self.nbytes), what="host_register")
+        self._registered = True
+
+    def close(self):
+        if getattr(self, "_registered", False):
+            self._registered = False
+            _lib.lib().dsp_host_unregister(self.ptr)
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

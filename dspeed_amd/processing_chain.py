@@ -32,7 +32,7 @@ import numpy as np
 
 from . import _lib
 from .chain import Chain, Program, Scalar
-from .device import DeviceArray, Stream
+from .device import DeviceArray, Event, HostPin, Stream
 from .errors import DSPFatal, ProcessingChainError
 
 _UNITS_NS = {"ns": 1.0, "us": 1e3, "ms": 1e6, "s": 1e9}
@@ -109,6 +109,8 @@ class ProcessingChain:
         self._dev = {}
         self._tb_in = None
         self._tb_out = None
+        self._pins = {}           # (address, bytes) -> HostPin of a linked host column (None: registration refused)
+        self._copy_stream = None  # H2D of the next piece runs here while the compute stream works on the current one
         self._timing = {"h2d": 0.0, "kernel": 0.0, "d2h": 0.0}
         self.proc_strings = proc_strings
 
@@ -125,6 +127,11 @@ class ProcessingChain:
 
     # -- I/O
     def link(self, tb_in, tb_out):
+        if tb_in is not self._tb_in or tb_out is not self._tb_out:
+            for pin in self._pins.values():
+                if pin is not None:
+                    pin.close()
+            self._pins = {}
         self._tb_in, self._tb_out = tb_in, tb_out
         self._buffer_len = len(_column(tb_in, next(iter(self._in_vars.values())).source)) if self._in_vars else self._buffer_len
 
@@ -135,6 +142,22 @@ class ProcessingChain:
             for name, arr in self._consts.items():
                 self._dev[name] = DeviceArray.from_numpy(arr)
 
+    #: bytes of host-resident I/O per pipelined piece: tens of MB keep PCIe transfers efficient, two pieces are in flight
+    pipeline_bytes = 64 << 20
+
+    def _pinned(self, arr: np.ndarray) -> bool:
+        """Page-lock a linked host column in place, once (the reference's build_dsp refills the same buffers for every file
+        chunk).  Registration can be refused (read-only or already registered memory): copies then run unpinned, only slower."""
+        if arr.nbytes < (1 << 20):  # small columns: the copy is latency, not bandwidth; and they share pages with their neighbours
+            return False
+        key = (arr.ctypes.data, arr.nbytes)
+        if key not in self._pins:
+            try:
+                self._pins[key] = HostPin(arr)
+            except Exception:
+                self._pins[key] = None
+        return self._pins[key] is not None
+
     def execute(self, start: int = 0, stop: int | None = None) -> None:
         if stop is None:
             stop = self._buffer_len
@@ -142,39 +165,94 @@ class ProcessingChain:
         if n <= 0:
             return
         self._ensure()
-        bufs = dict(self._dev)
-        staged_out = []
-        t0 = time.perf_counter()
+        lib = _lib.lib()
+        # ---- sort the linked columns: device-resident ones are used in place, host ones are streamed through piece buffers
+        dev_in, host_in, dev_out, host_out = {}, {}, {}, {}
         for name, var in self._in_vars.items():
             col = _column(self._tb_in, var.source)
             if isinstance(col, DeviceArray):
-                bufs[name] = col.view_rows(start, stop)
+                dev_in[name] = col
             else:
-                a = np.ascontiguousarray(col[start:stop])
-                bufs[name] = DeviceArray.from_numpy(a)
+                a = np.asarray(col)
+                if not a.flags.c_contiguous:
+                    a = np.ascontiguousarray(a)
+                else:
+                    self._pinned(a)
+                host_in[name] = a
         for name, (var, length) in self._out_vars.items():
             col = self._tb_out[var.name]
             if isinstance(col, DeviceArray):
-                bufs[name] = col.view_rows(start, stop)
+                dev_out[name] = col
             else:
-                d = DeviceArray((n,) if length is None else (n, length), self.loop_dtype)
+                direct = isinstance(col, np.ndarray) and col.flags.c_contiguous and col.dtype == self.loop_dtype
+                if direct:
+                    self._pinned(col)
+                host_out[name] = (col, length, direct)
+        row_bytes = sum(a.nbytes // max(len(a), 1) for a in host_in.values())
+        row_bytes += sum(self.loop_dtype.itemsize * (1 if length is None else length) for _, length, _ in host_out.values())
+        piece = n if row_bytes == 0 else int(max(1, min(n, self.pipeline_bytes // row_bytes)))
+        n_slots = 2 if piece < n else 1
+        slots = []
+        for _ in range(n_slots):
+            sl = {name: DeviceArray((piece, *a.shape[1:]), a.dtype) for name, a in host_in.items()}
+            sl.update({name: DeviceArray((piece,) if length is None else (piece, length), self.loop_dtype)
+                       for name, (_, length, _) in host_out.items()})
+            slots.append(sl)
+        if self._copy_stream is None:
+            self._copy_stream = Stream()
+        ev_in = [Event() for _ in range(n_slots)]
+        s_in, s_c = self._copy_stream, self._stream
+
+        def finish(a, b, temps):
+            """piece [a, b): wait for its kernel and copies, report its DSPFatal with absolute rows, deliver converted outputs"""
+            t = time.perf_counter()
+            try:
+                self._chain.check(s_c, row_offset=a)
+            except DSPFatal as e:  # the reference annotates and re-raises (processing_chain.py:1154-1159)
+                if e.wf_range is None:
+                    e.wf_range = range(a, b)
+                raise
+            self._timing["kernel"] += time.perf_counter() - t
+            t = time.perf_counter()
+            for col, tmp in temps:
+                col[a:b] = tmp.astype(col.dtype, copy=False)
+            self._timing["d2h"] += time.perf_counter() - t
+
+        # ---- pieces: H2D(k) on the copy stream overlaps kernel(k-1) and D2H(k-1) on the compute stream
+        pending = None
+        for k, a in enumerate(range(start, stop, piece)):
+            b = min(stop, a + piece)
+            m, sl = b - a, slots[k % n_slots]
+            t = time.perf_counter()
+            bufs = dict(self._dev)
+            for name, arr in host_in.items():  # (slot k % 2 is free: piece k-2 was finished in iteration k-1)
+                d = sl[name].view_rows(0, m)
+                src = arr[a:b]
+                _lib.check(lib.dsp_h2d_async(d.ptr, src.ctypes.data, src.nbytes, s_in.ptr), what="h2d_async")
                 bufs[name] = d
-                staged_out.append((d, col))
-        t1 = time.perf_counter()
-        self._chain.execute(bufs, n, self._stream)
-        try:
-            self._chain.check(self._stream, row_offset=start)
-        except DSPFatal as e:  # the reference annotates and re-raises (processing_chain.py:1154-1159)
-            if e.wf_range is None:
-                e.wf_range = range(start, stop)
-            raise
-        t2 = time.perf_counter()
-        for d, col in staged_out:
-            col[start:stop] = d.to_numpy().astype(col.dtype, copy=False)
-        t3 = time.perf_counter()
-        self._timing["h2d"] += t1 - t0
-        self._timing["kernel"] += t2 - t1
-        self._timing["d2h"] += t3 - t2
+            ev_in[k % n_slots].record(s_in)
+            for name, col in dev_in.items():
+                bufs[name] = col.view_rows(a, b)
+            for name, col in dev_out.items():
+                bufs[name] = col.view_rows(a, b)
+            self._timing["h2d"] += time.perf_counter() - t
+            if pending is not None:
+                finish(*pending)
+            s_c.wait_event(ev_in[k % n_slots])
+            temps = []
+            for name in host_out:
+                bufs[name] = sl[name].view_rows(0, m)
+            self._chain.execute(bufs, m, s_c)
+            for name, (col, length, direct) in host_out.items():
+                d = bufs[name]
+                if direct:
+                    dst = col[a:b]
+                else:
+                    dst = np.empty(d.shape, dtype=self.loop_dtype)
+                    temps.append((col, dst))
+                _lib.check(lib.dsp_d2h_async(dst.ctypes.data, d.ptr, d.nbytes, s_c.ptr), what="d2h_async")
+            pending = (a, b, temps)
+        finish(*pending)
 
     def __call__(self, tb_in, tb_out, begin: int = 0, end: int | None = None):
         self.link(tb_in, tb_out)

@@ -75,6 +75,8 @@ int dsp_malloc(void** dev, int64_t bytes);
 int dsp_free(void* dev);
 int dsp_host_alloc(void** host, int64_t bytes); /* pinned, for async staging */
 int dsp_host_free(void* host);
+int dsp_host_register(void* host, int64_t bytes);   /* page-lock caller-owned memory (e.g. a NumPy buffer) in place: async copies then */
+int dsp_host_unregister(void* host);                /* overlap kernels without a staging memcpy; undo before the memory is freed */
 int dsp_memset(void* dev, int value, int64_t bytes, void* stream);
 int dsp_h2d(void* dev, const void* host, int64_t bytes);                      /* synchronous */
 int dsp_d2h(void* host, const void* dev, int64_t bytes);                      /* synchronous */
@@ -87,6 +89,7 @@ int dsp_sync(void);                /* whole device */
 int dsp_event_create(void** event);
 int dsp_event_destroy(void* event);
 int dsp_event_record(void* event, void* stream);
+int dsp_stream_wait_event(void* stream, void* event); /* work queued on `stream` after this call waits for `event` */
 int dsp_event_sync(void* event);
 int dsp_event_elapsed_ms(void* start, void* stop, float* ms);
 const char* dsp_last_error(void);             /* thread-local text of the last failure */

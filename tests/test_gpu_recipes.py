@@ -135,6 +135,50 @@ def test_chain_executes_in_row_ranges_and_on_device_buffers():
     assert np.array_equal(out_dev["trapEftp"].to_numpy(), full)
 
 
+def test_host_buffers_stream_through_in_overlapped_pieces():
+    """Host-resident columns are processed in pieces (H2D of piece k+1 overlaps kernel and D2H of piece k): same results as one
+    piece, a waveform-valued output included, an output column of another dtype converted, a data-dependent DSPFatal reported
+    with its absolute row."""
+    from dspeed_amd.errors import DSPFatal
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    rng = np.random.default_rng(15)
+    n = 1000
+    x, bl, t0 = _synth(rng, n, 4096)
+    wf = x.astype(np.float32)
+    tp = (t0 + 625 + 150.4).astype(np.float32)
+    want, _ = oracle.chain_energy(wf, bl, tp, 1716.28, 625, 188, "l")
+    tb = {"waveform": wf, "baseline": bl, "t_pick": tp}
+    chain, _, tb_out = build_processing_chain(recipes.C2, tb)
+    chain.execute()
+    one_piece = tb_out["trapEftp"].copy()
+    assert np.max(np.abs(one_piece - want) / np.abs(want)) <= TOL
+    chain.pipeline_bytes = 37 * 4096 * 4  # 37-row pieces: 28 pieces, the last one ragged
+    tb_out["trapEftp"][:] = 0
+    chain.execute()
+    assert np.array_equal(tb_out["trapEftp"], one_piece)
+    out64 = {"trapEftp": np.zeros(n, dtype=np.float64)}  # a column of another dtype is filled through a converted copy
+    chain(tb, out64)
+    assert np.array_equal(out64["trapEftp"], one_piece.astype(np.float64))
+    # waveform-valued output + error row attribution across pieces
+    c1, _, o1 = build_processing_chain(recipes.C1, {"waveform": wf[:, :1024].copy()})
+    c1.execute()
+    ref = o1["wf_trap"].copy()
+    c1.pipeline_bytes = 64 * 1024 * 4 * 2
+    o1["wf_trap"][:] = 0
+    c1.execute()
+    assert np.array_equal(o1["wf_trap"], ref)
+    tpi = np.floor(tp).astype(np.float32)
+    tpi[777] += 0.5
+    ci, _, _ = build_processing_chain({"outputs": ["e"], "processors": {
+        "wf_t": "dspeed.processors.trap_filter(waveform, 100, 10, wf_t)",
+        "e": "dspeed.processors.fixed_time_pickoff(wf_t, t_pick, 'i', e)"}}, {"waveform": wf, "t_pick": tpi})
+    ci.pipeline_bytes = 100 * 4096 * 4
+    with pytest.raises(DSPFatal) as ei:
+        ci.execute()
+    assert ei.value.wf_range == range(777, 778)
+
+
 def test_fatal_from_recipe_carries_processor_context():
     from dspeed_amd.errors import DSPFatal
     from dspeed_amd.processing_chain import build_processing_chain
