@@ -349,6 +349,27 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     ch->f64 = f64;
 
     // ---- LDS layout: [guard 2*pitch][slot 64*pitch][tail 8] per slot, then the scalar registers
+    // FIR inputs are laid out linearly (no chunk pad): a slot qualifies when a CONVOLVE reads it and everything else that touches
+    // it is layout-agnostic (load, store, copy, bl_subtract); the chunk-serial filters keep the padded, conflict-free layout
+    bool linear[DSP_MAX_SLOTS] = {false};
+    for (int s = 0; s < n_slots; ++s) {
+        bool fir_in = false, only_plain = true;
+        for (int i = 0; i < n_ops; ++i) {
+            const dsp_op& o = ops[i];
+            const bool reads = (o.opcode != DSP_OP_LOAD && o.opcode != DSP_OP_STORE_SCALAR && o.opcode != DSP_OP_SCALAR_AFFINE && o.src == s);
+            const bool writes = (o.opcode == DSP_OP_LOAD || o.opcode == DSP_OP_BL_SUBTRACT || o.opcode == DSP_OP_POLE_ZERO ||
+                                 o.opcode == DSP_OP_DOUBLE_POLE_ZERO || o.opcode == DSP_OP_TRAP_FILTER || o.opcode == DSP_OP_TRAP_NORM ||
+                                 o.opcode == DSP_OP_ASYM_TRAP || o.opcode == DSP_OP_DWT_HAAR || o.opcode == DSP_OP_CONVOLVE ||
+                                 o.opcode == DSP_OP_COPY) && o.dst == s;
+            const bool scratch = o.opcode == DSP_OP_DWT_HAAR && o.ip[2] == s;
+            if (!reads && !writes && !scratch) continue;
+            if (o.opcode == DSP_OP_CONVOLVE && reads) fir_in = true;
+            const bool plain = o.opcode == DSP_OP_LOAD || o.opcode == DSP_OP_STORE || o.opcode == DSP_OP_COPY ||
+                               o.opcode == DSP_OP_BL_SUBTRACT || (o.opcode == DSP_OP_CONVOLVE && reads && !writes);
+            if (!plain) only_plain = false;
+        }
+        linear[s] = fir_in && only_plain;
+    }
     int cursor = 0;
     for (int s = 0; s < n_slots; ++s) {
         const int len = slot_len[s];
@@ -358,7 +379,8 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         DevSlot& d = P.slots[s];
         d.len = len;
         d.C = C;
-        d.pitch = C + 1;
+        d.padw = linear[s] ? 0 : 1;
+        d.pitch = C + d.padw;
         d.invC = 1.0f / (float)C;
         cursor += 2 * d.pitch;
         d.off = cursor;

@@ -12,13 +12,15 @@
 // One waveform variable living in LDS.  Lane j of the wavefront owns samples [j*C, (j+1)*C) ("chunk");
 // chunk j starts at element off + j*pitch with pitch = C+1 (odd) so that "every lane reads offset t of
 // its chunk" hits 64 different banks.  Samples >= len up to 64*C are kept finite (zero-filled at load).
+// FIR inputs are laid out without the pad (padw = 0, pitch = C: sample i at element off + i) so that a lane's
+// window of consecutive samples is addressed with immediate offsets.
 struct DevSlot {
     int32_t off;   // element offset inside the wavefront's LDS region
     int32_t len;   // logical number of samples
     int32_t C;     // samples per lane, multiple of 8
     int32_t pitch; // C + 1
     float invC;    // 1/C for index -> (lane, offset) splits
-    int32_t pad_;
+    int32_t padw;  // pitch - C: 1 (chunk pad) or 0 (linear)
 };
 
 struct DevIO {

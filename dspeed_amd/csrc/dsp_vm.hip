@@ -797,42 +797,88 @@ __device__ void op_convolve(Ctx<T>& cx, const DevOp& op) {
         cx.set_nan(op.dst, true);
         return;
     }
-    constexpr int R = 5;
+    constexpr int R = 5;   // consecutive outputs per lane (odd: the lanes' windows start 5 elements apart -> conflict-free reads)
+    constexpr int U = 16;  // taps per block of the fast path
+    constexpr int W = R + U - 1;
     const T* __restrict__ kern = (const T*)cx.ptrs->p[op.io];
     const int n = ss.len, m = op.ic[1], start = op.ic[0], p = sd.len, lane = lane_id();
+    const bool linear = ss.padw == 0;  // the host lays FIR inputs out without chunk pads: a window is R + U - 1 consecutive elements
+    const T* x0 = cx.lds + ss.off;
+    auto in_at = [&](int i) -> T { return (i >= 0 && i < n) ? cx.lds[padded_index(ss, i)] : (T)0; };
     for (int o0 = 0; o0 < p; o0 += 64 * R) {
-        const int ob = o0 + lane * R;  // first output of this lane
+        const int ob_true = o0 + lane * R;  // first output of this lane
+        // lanes past the end redo the last R outputs (discarded): their windows then stay inside the waveform like everyone's
+        const int ob = (ob_true + R > p && p >= R) ? p - R : ob_true;
         double tot[R];
-        T acc[R], win[R];
+        T acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             tot[r] = 0.0;
             acc[r] = (T)0;
         }
-        // tap k pairs with input index (ob + r + start - k); window holds inputs for r = 0..R-1 at the current k
-        auto in_at = [&](int i) -> T { return (i >= 0 && i < n) ? cx.lds[padded_index(ss, i)] : (T)0; };
+        auto flush = [&]() {  // every 64 taps: block sums (T) into the float64 totals
 #pragma unroll
-        for (int r = 0; r < R; ++r) win[r] = in_at(ob + r + start);
-        for (int k = 0; k < m; ++k) {
-            const T kv = kern[k];
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = fma_t(win[r], kv, acc[r]);
-            // slide: next k needs inputs one index lower
-#pragma unroll
-            for (int r = R - 1; r > 0; --r) win[r] = win[r - 1];
-            win[0] = in_at(ob + start - (k + 1));
-            if ((k & 63) == 63) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    tot[r] += (double)acc[r];
-                    acc[r] = (T)0;
-                }
+            for (int r = 0; r < R; ++r) {
+                tot[r] += (double)acc[r];
+                acc[r] = (T)0;
             }
+        };
+        auto slow_taps = [&](int ka, int kb) {  // taps [ka, kb) one by one, bounds checked (edges of the 'full' and 'same' modes)
+            for (int k = ka; k < kb; ++k) {
+                const T kv = kern[k];
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = fma_t(in_at(ob + r + start - k), kv, acc[r]);
+                if ((k & 63) == 63) flush();
+            }
+        };
+        // tap k pairs with input index (ob + r + start - k).  A block of U taps starting at k0 touches inputs
+        // [ob + start - k0 - (U-1), ob + (R-1) + start - k0]: inside the waveform for every lane iff kA <= k0 <= kB
+        int kA = wave_max(ob + (R - 1) + start - (n - 1)), kB = wave_min(ob + start - (U - 1));
+        kA = kA < 0 ? 0 : ((kA + U - 1) / U) * U;
+        if (kB > m - U) kB = m - U;
+        if (!linear || kB < kA) {
+            slow_taps(0, m);
+        } else {
+            slow_taps(0, kA);
+            // ---- fast blocks: R + U - 1 inputs at immediate offsets, U taps (one broadcast 16-byte load each 4), R * U FMAs in tap
+            // order; the next block's loads are issued before this block's arithmetic
+            T w[2][W], h[2][U];
+            auto load_block = [&](int k0, T (&wb)[W], T (&hb)[U]) {
+                const T* base = x0 + (ob + start - k0 - (U - 1));
+#pragma unroll
+                for (int j = 0; j < W; ++j) wb[j] = base[j];
+#pragma unroll
+                for (int u = 0; u < U; ++u) hb[u] = kern[k0 + u];
+            };
+            auto fma_block = [&](const T (&wb)[W], const T (&hb)[U]) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r] = fma_t(wb[U - 1 - u + r], hb[u], acc[r]);
+            };
+            const int nblk = (kB - kA) / U + 1;
+            load_block(kA, w[0], h[0]);
+            int k0 = kA;
+            for (int b = 0; b + 1 < nblk; b += 2) {
+                load_block(k0 + U, w[1], h[1]);
+                fma_block(w[0], h[0]);
+                if (((k0 + U) & 63) == 0) flush();
+                if (b + 2 < nblk) load_block(k0 + 2 * U, w[0], h[0]);
+                fma_block(w[1], h[1]);
+                if (((k0 + 2 * U) & 63) == 0) flush();
+                k0 += 2 * U;
+            }
+            if (nblk & 1) {
+                fma_block(w[0], h[0]);
+                if (((k0 + U) & 63) == 0) flush();
+                k0 += U;
+            }
+            slow_taps(k0, m);
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int o = ob + r;
-            if (o < p) cx.lds[padded_index(sd, o)] = (T)(tot[r] + (double)acc[r]);
+            if (o >= ob_true && o < p) cx.lds[padded_index(sd, o)] = (T)(tot[r] + (double)acc[r]);
         }
     }
     for (int e = p + lane; e < 64 * sd.C; e += 64) cx.lds[padded_index(sd, e)] = (T)0;

@@ -86,7 +86,7 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 // LDS element index of sample e of a slot (e / C via a float reciprocal: exact for e < 2^20, C % 8 == 0)
 __device__ __forceinline__ int padded_index(const DevSlot& s, int e) {
     int q = (int)(((float)e + 0.5f) * s.invC);
-    return s.off + e + q;
+    return s.off + e + q * s.padw;
 }
 
 template <typename T>

@@ -717,6 +717,38 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             return a[1]
         return None
 
+    # --- slice push-down: an element-wise result (bl_subtract) that is read ONLY through one constant slice [lo:hi] -- the
+    # long-FIR recipes do that, icpc-dsp-config.json:160-239 -- is computed on that slice alone: a 6092-sample slot instead of
+    # an 8192-sample one plus a copy.  Same values: the op is per sample.
+    def slices_of(v):
+        found, plain = set(), False
+        for _fn, a2, _k in steps:
+            for x in a2:
+                if isinstance(x, tuple) and x[0] == "slice" and x[1] is v:
+                    found.add((x[2], x[3]))
+                elif x is v or (isinstance(x, tuple) and x[0] == "affine" and x[1] is v):
+                    plain = True
+        return found, plain
+
+    for si, (fn, args, key) in enumerate(steps):
+        if fn != "bl_subtract" or not isinstance(args[0], Var) or not isinstance(args[-1], Var) or args[-1].name in out_pars:
+            continue
+        src_v, dst_v = args[0], args[-1]
+        found, plain = slices_of(dst_v)
+        uses_of_dst = sum(1 for _fn, a2, _k in steps for x in a2 if x is dst_v)  # the producing step itself counts once
+        if len(found) != 1 or uses_of_dst != 1 or not src_v.is_input or src_v.kind != "wf":
+            continue
+        (lo, hi), = found
+        if not (0 <= lo < hi <= (src_v.length or 0)):
+            continue
+        new_args = list(args)
+        new_args[0] = ("slice", src_v, lo, hi)
+        steps[si] = (fn, new_args, key)
+        dst_v.length = hi - lo
+        for sj, (fn2, a2, k2) in enumerate(steps):
+            if sj != si:
+                steps[sj] = (fn2, [dst_v if (isinstance(x, tuple) and x[0] == "slice" and x[1] is dst_v) else x for x in a2], k2)
+
     last_use = {}
     for si, (fn, args, _) in enumerate(steps):
         roles = _SIGS.get(fn, "")

@@ -62,7 +62,10 @@ def test_c3_folds_kernels_and_slices_the_input():
     tb = _tb(wf_len=8192)
     chain, mask, tb_out = build_processing_chain(recipes.C3, tb)
     ops = _ops(chain)
-    assert ops.count(_lib.OP_CONVOLVE) == 2 and ops.count(_lib.OP_AMAX) == 2 and ops.count(_lib.OP_COPY) == 1
+    # slice push-down: wf_blsub is only read as wf_blsub[:6092], so the input is loaded and baseline-subtracted on that slice
+    # alone (a 6092-sample slot, no copy)
+    assert ops.count(_lib.OP_CONVOLVE) == 2 and ops.count(_lib.OP_AMAX) == 2 and ops.count(_lib.OP_COPY) == 0
+    assert chain.program.io[0][3] == 6092
     taps = [io for io in chain.program.io if io[1] == _lib.IO_TAPS]
     assert len(taps) == 2 and all(io[3] == 5792 for io in taps)
     assert set(tb_out) == {"cuspEmax", "zacEmax"}
