@@ -77,6 +77,7 @@ template <int NPF, int KIND>
 __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_t n_wf, int* err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = lane_id();
+    const double inv_rr = 1.0 / A.rr, inv_ll = 1.0 / A.ll;  // trap_norm / asym_trap divide by these counts every sample
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);  // provably wave-uniform
     float* lds = reinterpret_cast<float*>(smem_raw) + (size_t)wave * A.lds_elems_per_wave;
     for (int e = lane; e < A.lds_elems_per_wave; e += 64) lds[e] = 0.0f;
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
                         float ys[G3];
 #pragma unroll
                         for (int u = 0; u < G3; ++u) {
-                            y = trap_step<float, KIND>(y, o[u], l0[u], l1[u], l2[u], A.rr, A.ll);
+                            y = trap_step_r<float, KIND>(y, o[u], l0[u], l1[u], l2[u], A.rr, A.ll, inv_rr, inv_ll);
                             ys[u] = y;
                         }
                         if ((capmask >> (t / G3)) & 1u) {
@@ -364,6 +365,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
     constexpr int BS = CS >= 16 ? 16 : CS;  // samples per capture block
     static_assert((C - 1) % (8 * S) == 0, "sub-chain length must be a whole number of 8-sample groups");
     const int lane = lane_id();
+    const double inv_rr = 1.0 / A.rr, inv_ll = 1.0 / A.ll;  // trap_norm / asym_trap divide by these counts every sample
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), wpb = (int)(blockDim.x >> 6);
     float* lds = reinterpret_cast<float*>(smem_raw) + (size_t)wave * A.lds_elems_per_wave;
     for (int e = lane; e < A.lds_elems_per_wave; e += 64) lds[e] = 0.0f;
@@ -573,8 +575,8 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
                     for (int u = 0; u < GL; ++u)
 #pragma unroll
                         for (int s = 0; s < S; ++s) {
-                            y[s] = trap_step<float, KIND>(y[s], xr[s * CS + gl * GL + u], lb[gl % (PD + 1)][s][u][0], lb[gl % (PD + 1)][s][u][1],
-                                                          lb[gl % (PD + 1)][s][u][2], A.rr, A.ll);
+                            y[s] = trap_step_r<float, KIND>(y[s], xr[s * CS + gl * GL + u], lb[gl % (PD + 1)][s][u][0], lb[gl % (PD + 1)][s][u][1],
+                                                          lb[gl % (PD + 1)][s][u][2], A.rr, A.ll, inv_rr, inv_ll);
                             ysb[s][(gl * GL + u) % BS] = y[s];
                         }
                     if (((gl + 1) * GL) % BS == 0) {
@@ -593,7 +595,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
                     }
                 }
                 aux[S * NGS] = y[S - 1];  // state before the odd sample (it extends the last chain)
-                y[S - 1] = trap_step<float, KIND>(y[S - 1], xr[C - 1], lodd[0], lodd[1], lodd[2], A.rr, A.ll);
+                y[S - 1] = trap_step_r<float, KIND>(y[S - 1], xr[C - 1], lodd[0], lodd[1], lodd[2], A.rr, A.ll, inv_rr, inv_ll);
                 PHASE(4)
                 // ---- true carries: exact scan of the increments
                 double D[S], Dbefore[S], Dtot = 0.0;
@@ -642,7 +644,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const int tt = base + u;  // (beyond the chunk for the odd sample's group: reads stay in the slot tail, unused)
-                            ys = trap_step<float, KIND>(ys, mine[tt], lagp[0][tt], lagp[1][tt], lagp[2][tt], A.rr, A.ll);
+                            ys = trap_step_r<float, KIND>(ys, mine[tt], lagp[0][tt], lagp[1][tt], lagp[2][tt], A.rr, A.ll, inv_rr, inv_ll);
                             if (u == u0) yk = ys;
                         }
                         const double delta = (T0 + dsel) - (double)gsel;

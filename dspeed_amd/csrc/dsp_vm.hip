@@ -345,6 +345,7 @@ __device__ void trap_core(Ctx<T>& cx, const DevOp& op, const DevSlot& ss, const 
     const int C = ss.C, lane = lane_id();
     const T* ps = cx.chunk(ss);
     const double rr = op.fc[0], ll = op.fc[1];
+    const double inv_rr = 1.0 / rr, inv_ll = 1.0 / ll;  // (rise or fall == 0 never gets here: ZeroDivisionError at chain creation)
     int q[3], rho[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -424,9 +425,9 @@ __device__ void trap_core(Ctx<T>& cx, const DevOp& op, const DevSlot& ss, const 
             const T* l0 = lag[0] + (t >= rho[0] ? 1 : 0);
             const T* l1 = lag[1] + (t >= rho[1] ? 1 : 0);
             const T* l2 = lag[2] + (t >= rho[2] ? 1 : 0);
-#pragma unroll 4
+#pragma unroll 8
             for (int u = t; u < nb; ++u) {
-                y = trap_step<T, KIND>(y, ps[u], l0[u], l1[u], l2[u], rr, ll);
+                y = trap_step_r<T, KIND>(y, ps[u], l0[u], l1[u], l2[u], rr, ll, inv_rr, inv_ll);
                 if (STORE) pd[u] = y;
             }
             t = nb;
@@ -588,6 +589,7 @@ __device__ void op_mean_below(Ctx<T>& cx, const DevOp& op) {
         const int n = ss.len, C = ss.C, i0 = lane_id() * C;
         const T* ps = cx.chunk(ss);
         double total = 0.0, count = 0.0;
+#pragma unroll 8
         for (int t = 0; t < C; ++t) {
             const T v = ps[t];
             if (i0 + t < n && v < thr) {
@@ -627,6 +629,7 @@ __device__ void op_time_point_thresh(Ctx<T>& cx, const DevOp& op) {
                 // smallest i in [ts, n-2] with (w[i] <= thr < w[i+1]) or (w[i] >= thr > w[i+1])
                 int best = 0x7fffffff;
                 T cur = ps[0];
+#pragma unroll 8
                 for (int t = 0; t < C; ++t) {
                     const T nxt = (t < C - 1) ? ps[t + 1] : ps[C + 1];  // first sample of the next lane's chunk
                     const int i = i0 + t;
@@ -640,6 +643,7 @@ __device__ void op_time_point_thresh(Ctx<T>& cx, const DevOp& op) {
                 // largest i in [1, ts] with (w[i-1] < thr <= w[i]) or (w[i-1] > thr >= w[i])
                 int best = -1;
                 T prv = (lane > 0) ? ps[-2] : (T)0;  // last sample of the previous lane's chunk (pad is at ps[-1])
+#pragma unroll 8
                 for (int t = 0; t < C; ++t) {
                     const T cur = ps[t];
                     const int i = i0 + t;
@@ -671,6 +675,7 @@ __device__ void op_min_max(Ctx<T>& cx, const DevOp& op, bool amax_only) {
         const T first = cx.lds[ss.off];
         T vmin = (i0 < n) ? ps[0] : first, vmax = vmin;
         int imin = (i0 < n) ? i0 : 0, imax = imin;
+#pragma unroll 8
         for (int t = 1; t < C; ++t) {
             const T v = ps[t];
             const int i = i0 + t;
