@@ -7,7 +7,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p "$OUT"
-BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu"
+BENCH="python3 bench.py --steps 20 --warmup 5 --no-cpu"  # enough launches that first-touch effects do not weigh on the averages
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS \
     --output-format csv -d "$OUT/pmc_sq1" -- $BENCH > /dev/null 2> "$OUT/pmc_sq1.err"
