@@ -12,7 +12,12 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 
-stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
+def newest(pattern):
+    """gpurun merges every run's files into the same directory: keep the most recent one"""
+    return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+
+
+stats = newest(f"{src}/trace/*/*_kernel_stats.csv")
 if stats:
     shutil.copy(stats[0], f"profiles/{tag}_kernel_stats.csv")
 bench = json.load(open(f"{src}/bench_default.json"))
@@ -21,7 +26,7 @@ rows, wf_len = bench["config"]["rows_per_gpu"], bench["config"]["wf_len"]
 
 pmc = {}
 for d in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
-    for f in glob.glob(f"{src}/{d}/*/*_counter_collection.csv"):
+    for f in newest(f"{src}/{d}/*/*_counter_collection.csv"):
         acc = {}
         for r in csv.DictReader(open(f)):
             if kernel in r["Kernel_Name"]:
