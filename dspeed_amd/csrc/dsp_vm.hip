@@ -838,7 +838,7 @@ __device__ void op_convolve(Ctx<T>& cx, const DevOp& op) {
         };
         // tap k pairs with input index (ob + r + start - k).  A block of U taps starting at k0 touches inputs
         // [ob + start - k0 - (U-1), ob + (R-1) + start - k0]: inside the waveform for every lane iff kA <= k0 <= kB
-        int kA = wave_max(ob + (R - 1) + start - (n - 1)), kB = wave_min(ob + start - (U - 1));
+        int kA = uniform(wave_max(ob + (R - 1) + start - (n - 1))), kB = uniform(wave_min(ob + start - (U - 1)));  // (SGPRs: tap addresses stay scalar)
         kA = kA < 0 ? 0 : ((kA + U - 1) / U) * U;
         if (kB > m - U) kB = m - U;
         if (!linear || kB < kA) {
@@ -848,6 +848,8 @@ __device__ void op_convolve(Ctx<T>& cx, const DevOp& op) {
             // ---- fast blocks: R + U - 1 inputs at immediate offsets, U taps (one broadcast 16-byte load each 4), R * U FMAs in tap
             // order; the next block's loads are issued before this block's arithmetic
             T w[2][W], h[2][U];
+            // (taps as scalar loads -- constant address space, SGPR operands -- were measured slower: v_pk_fma_f32 wants its
+            // multiplier pair in VGPRs, so every tap was moved back; the 16-byte vector loads below hit one cache line per wave)
             auto load_block = [&](int k0, T (&wb)[W], T (&hb)[U]) {
                 const T* base = x0 + (ob + start - k0 - (U - 1));
 #pragma unroll
