@@ -363,9 +363,10 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                                  o.opcode == DSP_OP_COPY) && o.dst == s;
             const bool scratch = o.opcode == DSP_OP_DWT_HAAR && o.ip[2] == s;
             if (!reads && !writes && !scratch) continue;
-            if (o.opcode == DSP_OP_CONVOLVE && reads) fir_in = true;
+            if ((o.opcode == DSP_OP_CONVOLVE || o.opcode == DSP_OP_CONVOLVE_AMAX) && reads) fir_in = true;
             const bool plain = o.opcode == DSP_OP_LOAD || o.opcode == DSP_OP_STORE || o.opcode == DSP_OP_COPY ||
-                               o.opcode == DSP_OP_BL_SUBTRACT || (o.opcode == DSP_OP_CONVOLVE && reads && !writes);
+                               o.opcode == DSP_OP_BL_SUBTRACT || (o.opcode == DSP_OP_CONVOLVE && reads && !writes) ||
+                               (o.opcode == DSP_OP_CONVOLVE_AMAX && reads);
             if (!plain) only_plain = false;
         }
         linear[s] = fir_in && only_plain;
@@ -393,11 +394,21 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     ch->lds_bytes_per_wave = cursor * esz;
     if (ch->lds_bytes_per_wave > LDS_BYTES_PER_CU)
         return fail(DSP_ERR_TOO_LONG, "chain needs %d bytes of LDS per waveform; a CU has %d", ch->lds_bytes_per_wave, LDS_BYTES_PER_CU);
-    int wpb = LDS_BYTES_PER_CU / ch->lds_bytes_per_wave;
-    if (wpb > 4) wpb = 4;
+    // wavefronts per workgroup (1..4): the size that fits the most wavefronts into a CU's LDS and register budget (25 KB per
+    // waveform: 3 per group and 2 groups = 6 wavefronts, where 4 per group would leave one group of 4); ties go to the larger group
+    int wpb = 1, best_waves = 0;
+    for (int w = 1; w <= 4; ++w) {
+        int groups = LDS_BYTES_PER_CU / (w * ch->lds_bytes_per_wave);
+        if (groups > 8 / w) groups = 8 / w;  // the kernels are built for 2 wavefronts per SIMD (registers): 8 per CU, whole groups only
+        const int waves = groups * w;
+        if (groups >= 1 && waves >= best_waves) {
+            best_waves = waves;
+            wpb = w;
+        }
+    }
     if (const char* env = getenv("DSPEED_HIP_WPB")) {  // tuning knob: wavefronts per workgroup (1..4)
         const int v = atoi(env);
-        if (v >= 1 && v <= wpb) wpb = v;
+        if (v >= 1 && v <= 4 && v * ch->lds_bytes_per_wave <= LDS_BYTES_PER_CU) wpb = v;
     }
     ch->waves_per_block = wpb;
     P.waves_per_block = wpb;
@@ -552,12 +563,16 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                     o.ip[0] + slot_len[o.dst] > slot_len[o.src])
                     return fail(DSP_ERR_ARG, "op %d: bad COPY", i);
                 break;
-            case DSP_OP_CONVOLVE: {
-                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || o.src == o.dst || !need_io(DSP_IO_TAPS))
-                    return fail(DSP_ERR_ARG, "op %d: bad CONVOLVE", i);
-                const int n = slot_len[o.src], m = io[o.io].len, p = slot_len[o.dst], mode = o.ip[0];
+            case DSP_OP_CONVOLVE:
+            case DSP_OP_CONVOLVE_AMAX: {
+                const bool fusedmax = o.opcode == DSP_OP_CONVOLVE_AMAX;
+                if (!check_slot(P, o.src) || !need_io(DSP_IO_TAPS)) return fail(DSP_ERR_ARG, "op %d: bad CONVOLVE", i);
+                if (fusedmax ? (o.dst < 0 || o.dst >= n_sregs || o.ip[2] <= 0) : (!check_slot(P, o.dst) || o.src == o.dst))
+                    return fail(DSP_ERR_ARG, "op %d: bad CONVOLVE destination", i);
+                const int n = slot_len[o.src], m = io[o.io].len, p = fusedmax ? o.ip[2] : slot_len[o.dst], mode = o.ip[0];
                 d.ic[1] = m;
                 d.ic[2] = o.ip[1] ? 1 : 0;  // caller found a NaN among the taps -> output NaN (convolutions.py:45-46)
+                d.ic[3] = p;
                 if (m > n) return fail(DSP_E_CONV_LONG, "%s", dsp_fatal_message(DSP_E_CONV_LONG));
                 if (mode == 'f') {
                     if (p != n + m - 1) return fail(DSP_E_CONV_OUTLEN, "Output waveform has length %d; expect %d", p, n + m - 1);

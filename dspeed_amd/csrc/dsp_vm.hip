@@ -29,7 +29,10 @@ template <typename T>
 struct Ctx {
     T* lds;                  // this wavefront's LDS region
     const DevProgram* prog;  // device copy of the program
-    const IoPtrs* ptrs;      // I/O device pointers of this launch
+    // I/O device pointers of this launch: read straight from the kernel-argument segment (constant address space, scalar loads with a
+    // run-time index); taking the address of the by-value IoPtrs argument instead makes the compiler copy it to scratch
+    const __attribute__((address_space(4))) uint64_t* kptrs;
+    __device__ __forceinline__ void* io_ptr(int i) const { return reinterpret_cast<void*>(kptrs[i]); }
     int64_t row;             // waveform being processed
     int* err;                // device error word
     uint32_t nan_mask;       // bit s set: slot s is "all NaN" (the reference's NaN-propagation state)
@@ -59,7 +62,7 @@ struct Ctx {
         if (a.kind == DSP_ARG_REG) return sregs()[a.index];
         const DevIO& io = prog->io[a.index];
         const int64_t at = (int64_t)io.offset + row * io.row_stride;
-        const void* p = ptrs->p[a.index];
+        const void* p = io_ptr(a.index);
         if (io.dtype == DSP_F32) return (T)((const float*)p)[at];
         if (io.dtype == DSP_F64) return (T)((const double*)p)[at];
         if (io.dtype == DSP_I32) return (T)((const int32_t*)p)[at];
@@ -120,7 +123,7 @@ template <typename T>
 __device__ void op_load(Ctx<T>& cx, const DevOp& op) {
     const DevSlot& s = cx.prog->slots[op.dst];
     const DevIO& io = cx.prog->io[op.io];
-    const char* base = (const char*)cx.ptrs->p[op.io];
+    const char* base = (const char*)cx.io_ptr(op.io);
     const int64_t at = cx.row * io.row_stride + io.offset;
     const bool vec_ok = io.vec_ok && ((reinterpret_cast<uintptr_t>(base) & 15u) == 0);
     bool nan;
@@ -140,12 +143,12 @@ template <typename T>
 __device__ void op_store(Ctx<T>& cx, const DevOp& op) {
     const DevSlot& s = cx.prog->slots[op.src];
     const DevIO& io = cx.prog->io[op.io];
-    T* g = (T*)cx.ptrs->p[op.io] + cx.row * io.row_stride + io.offset;
+    T* g = (T*)cx.io_ptr(op.io) + cx.row * io.row_stride + io.offset;
     const int len = io.len;
     const bool nan = cx.slot_nan(op.src);
     constexpr int V = 16 / (int)sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(V)));
-    if (io.vec_ok && ((reinterpret_cast<uintptr_t>(cx.ptrs->p[op.io]) & 15u) == 0)) {
+    if (io.vec_ok && ((reinterpret_cast<uintptr_t>(cx.io_ptr(op.io)) & 15u) == 0)) {
         for (int e = lane_id() * V; e < len; e += 64 * V) {
             const int a = padded_index(s, e);
             vec_t v;
@@ -165,7 +168,7 @@ __device__ void op_store(Ctx<T>& cx, const DevOp& op) {
 template <typename T>
 __device__ void op_store_scalar(Ctx<T>& cx, const DevOp& op) {
     const DevIO& io = cx.prog->io[op.io];
-    if (lane_id() == 0) ((T*)cx.ptrs->p[op.io])[cx.row * io.row_stride + io.offset] = cx.sregs()[op.ip[0]];
+    if (lane_id() == 0) ((T*)cx.io_ptr(op.io))[cx.row * io.row_stride + io.offset] = cx.sregs()[op.ip[0]];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -794,19 +797,27 @@ __device__ void op_copy(Ctx<T>& cx, const DevOp& op) {
 __device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// AMAX: fused with numpy.amax over the output (DSP_OP_CONVOLVE_AMAX): nothing is stored, sreg[dst] receives the maximum
 template <typename T>
-__device__ void op_convolve(Ctx<T>& cx, const DevOp& op) {
+__device__ void op_convolve(Ctx<T>& cx, const DevOp& op, const bool AMAX) {  // (one body for both: the tap loop is the big part)
     const DevSlot& ss = cx.prog->slots[op.src];
-    const DevSlot& sd = cx.prog->slots[op.dst];
+    const DevSlot& sd = cx.prog->slots[AMAX ? op.src : op.dst];  // (unused when AMAX)
     if (cx.slot_nan(op.src) || op.ic[2]) {
-        cx.set_nan(op.dst, true);
+        if (AMAX) {
+            if (lane_id() == 0) cx.sregs()[op.dst] = quiet_nan<T>();
+            wave_sync();
+        } else {
+            cx.set_nan(op.dst, true);
+        }
         return;
     }
+    T vmax = -__builtin_huge_val();
+    bool vnan = false;
     constexpr int R = 5;   // consecutive outputs per lane (odd: the lanes' windows start 5 elements apart -> conflict-free reads)
     constexpr int U = 16;  // taps per block of the fast path
     constexpr int W = R + U - 1;
-    const T* __restrict__ kern = (const T*)cx.ptrs->p[op.io];
-    const int n = ss.len, m = op.ic[1], start = op.ic[0], p = sd.len, lane = lane_id();
+    const T* __restrict__ kern = (const T*)cx.io_ptr(op.io);
+    const int n = ss.len, m = op.ic[1], start = op.ic[0], p = op.ic[3], lane = lane_id();
     const bool linear = ss.padw == 0;  // the host lays FIR inputs out without chunk pads: a window is R + U - 1 consecutive elements
     const T* x0 = cx.lds + ss.off;
     auto in_at = [&](int i) -> T { return (i >= 0 && i < n) ? cx.lds[padded_index(ss, i)] : (T)0; };
@@ -885,11 +896,28 @@ __device__ void op_convolve(Ctx<T>& cx, const DevOp& op) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int o = ob + r;
-            if (o >= ob_true && o < p) cx.lds[padded_index(sd, o)] = (T)(tot[r] + (double)acc[r]);
+            if (o >= ob_true && o < p) {
+                const T v = (T)(tot[r] + (double)acc[r]);
+                if (AMAX) {
+                    vnan |= (v != v);
+                    vmax = v > vmax ? v : vmax;
+                } else {
+                    cx.lds[padded_index(sd, o)] = v;
+                }
+            }
         }
     }
-    for (int e = p + lane; e < 64 * sd.C; e += 64) cx.lds[padded_index(sd, e)] = (T)0;
-    cx.set_nan(op.dst, false);
+    if (AMAX) {
+#pragma unroll
+        for (int msk = 1; msk < 64; msk <<= 1) {
+            const T other = __shfl_xor(vmax, msk);
+            vmax = other > vmax ? other : vmax;
+        }
+        if (lane == 0) cx.sregs()[op.dst] = wave_any(vnan) ? quiet_nan<T>() : vmax;  // numpy.amax propagates NaN
+    } else {
+        for (int e = p + lane; e < 64 * sd.C; e += 64) cx.lds[padded_index(sd, e)] = (T)0;
+        cx.set_nan(op.dst, false);
+    }
     wave_sync();
 }
 
@@ -916,7 +944,10 @@ __global__ void __launch_bounds__(256) dsp_vm_kernel(const DevProgram* __restric
     Ctx<T> cx;
     cx.lds = lds;
     cx.prog = prog;
-    cx.ptrs = &ptrs;
+    // kernel arguments: (const DevProgram*, IoPtrs, int64_t, int*) -> the pointer table starts 8 bytes into the segment
+    static_assert(sizeof(const DevProgram*) == 8 && alignof(IoPtrs) == 8, "kernel-argument layout");
+    cx.kptrs = (const __attribute__((address_space(4))) uint64_t*)__builtin_amdgcn_kernarg_segment_ptr() + 1;
+    (void)ptrs;
     cx.err = err;
     const int64_t total_waves = (int64_t)gridDim.x * wpb;
     const int n_ops = prog->n_ops;
@@ -943,7 +974,8 @@ __global__ void __launch_bounds__(256) dsp_vm_kernel(const DevProgram* __restric
                 case DSP_OP_MEAN_BELOW: op_mean_below(cx, op); break;
                 case DSP_OP_DWT_HAAR: op_dwt_haar(cx, op); break;
                 case DSP_OP_COPY: op_copy(cx, op); break;
-                case DSP_OP_CONVOLVE: op_convolve(cx, op); break;
+                case DSP_OP_CONVOLVE:
+                case DSP_OP_CONVOLVE_AMAX: op_convolve<T>(cx, op, op.opcode == DSP_OP_CONVOLVE_AMAX); break;
                 case DSP_OP_SCALAR_AFFINE: op_scalar_affine(cx, op); break;
                 default: break;
             }

@@ -991,8 +991,19 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             dst = out_wf(args[3], None, src)
             if dst.length is None:
                 raise ProcessingChainError(f"{fn}: declare the output as name(length, 'f')")
+            has_nan = int(np.isnan(taps.const).any())
+            # fusion: the filtered waveform's only consumer is one numpy.amax and it is not an output -> it is never stored
+            users = [sj for sj, (f2, a2, _k) in enumerate(steps) if sj != si and any(wf_of(x) is dst for x in a2)]
+            if (len(users) == 1 and steps[users[0]][0] == "amax" and steps[users[0]][1][0] is dst and dst.name not in out_pars
+                    and users[0] > si and users[0] not in skip):
+                o = out_scalar(steps[users[0]][1][2])
+                p.add_op(_lib.OP_CONVOLVE_AMAX, dst=o.sreg, src=src.slot, io=taps.io, ip=(char_of(args[2]), has_nan, int(dst.length)))
+                skip.add(users[0])
+                last_use[src.name] = max(last_use.get(src.name, si), si)
+                release(src, si)
+                continue
             dst.slot = new_slot(dst.length)
-            p.add_op(_lib.OP_CONVOLVE, dst=dst.slot, src=src.slot, io=taps.io, ip=(char_of(args[2]), int(np.isnan(taps.const).any())))
+            p.add_op(_lib.OP_CONVOLVE, dst=dst.slot, src=src.slot, io=taps.io, ip=(char_of(args[2]), has_nan))
             release(src, si)
         else:
             raise NotImplementedError(f"processor '{fn}' is not implemented on the device path")

@@ -153,6 +153,9 @@ typedef struct dsp_scalar_arg {
                                   never materialised; sreg[dst] <- trap(src) at sp[0]; ip[0..2] = rise, flat, fall; mode in `io` */
 #define DSP_OP_AMAX 17         /* numpy.amax along the sample axis (icpc-dsp-config.json:123-143): sreg[dst] <- max(src), NaN if any NaN */
 #define DSP_OP_MEAN_BELOW 19    /* arithmetic.py:9-62 mean_below_threshold: sreg[dst] <- mean of the samples of src below sp[0]; NaN if none */
+#define DSP_OP_CONVOLVE_AMAX 20  /* fusion of CONVOLVE with numpy.amax over its output (icpc-dsp-config.json:160-239 cuspEmax / zacEmax): the
+                                  * filtered waveform is never stored.  sreg[dst] <- max_o (src (*) io taps)[o]; ip[0] = mode, ip[1] = taps
+                                  * hold a NaN, ip[2] = output length the recipe declared */
 #define DSP_OP_SCALAR_AFFINE 18 /* sreg[dst] <- sp[0] * sp[1] + sp[2]  (host-folded expressions such as tp_0 + 10*us) */
 
 typedef struct dsp_op {

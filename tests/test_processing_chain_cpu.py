@@ -64,7 +64,9 @@ def test_c3_folds_kernels_and_slices_the_input():
     ops = _ops(chain)
     # slice push-down: wf_blsub is only read as wf_blsub[:6092], so the input is loaded and baseline-subtracted on that slice
     # alone (a 6092-sample slot, no copy)
-    assert ops.count(_lib.OP_CONVOLVE) == 2 and ops.count(_lib.OP_AMAX) == 2 and ops.count(_lib.OP_COPY) == 0
+    # ... and each FIR output feeds nothing but its numpy.amax, so the pair is one fused op and no filtered waveform is stored
+    assert ops.count(_lib.OP_CONVOLVE_AMAX) == 2 and ops.count(_lib.OP_CONVOLVE) == 0 and ops.count(_lib.OP_AMAX) == 0
+    assert ops.count(_lib.OP_COPY) == 0 and chain.program.slots == [6092]
     assert chain.program.io[0][3] == 6092
     taps = [io for io in chain.program.io if io[1] == _lib.IO_TAPS]
     assert len(taps) == 2 and all(io[3] == 5792 for io in taps)
