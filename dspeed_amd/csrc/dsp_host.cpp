@@ -955,7 +955,10 @@ int wf2wf(int ty, int opcode, const WfIn& in, void* out, int32_t out_len, int64_
           const double* consts, int n_c, const void* col0, void* stream, int64_t* err_row) {
     if (in.n_wf <= 0) return DSP_OK;
     Mini m(ty);
-    const int s_in = m.add_slot(in.len), s_out = m.add_slot(out_len);
+    // the per-sample and scan filters work in place: one LDS slot, so a wavefront holds a waveform twice as long (about 38 k float32
+    // samples instead of 19 k for the filters that need source and destination side by side)
+    const bool in_place = (opcode == DSP_OP_BL_SUBTRACT || opcode == DSP_OP_POLE_ZERO || opcode == DSP_OP_DOUBLE_POLE_ZERO) && out_len == in.len;
+    const int s_in = m.add_slot(in.len), s_out = in_place ? s_in : m.add_slot(out_len);
     const int io_in = m.add_io(DSP_IO_WF_IN, in.dtype, in.len, in.stride, in.ptr);
     m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
     dsp_scalar_arg sp[3];

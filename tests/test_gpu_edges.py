@@ -1,0 +1,80 @@
+"""Edge shapes of the gufunc and chain entry points: empty batches, a single 1-D waveform, ragged lengths (not a multiple of the
+wavefront), the longest waveform one wavefront can hold and the first length it cannot, the shortest waveforms."""
+import numpy as np
+import pytest
+
+import oracle
+from golden_util import assert_rel_to_peak
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    from dspeed_amd import processors
+
+    return processors
+
+
+def test_empty_batch_is_a_no_op(P):
+    w = np.zeros((0, 1024), dtype=np.float32)
+    assert P.trap_filter(w, 10, 5).shape == (0, 1024)
+    assert P.fixed_time_pickoff(w, np.zeros(0, dtype=np.float32), ord("l")).shape == (0,)
+    from dspeed_amd.processing_chain import build_processing_chain
+    import recipes
+
+    chain, _, out = build_processing_chain(recipes.C1, {"waveform": w})
+    chain.execute()
+    assert out["wf_trap"].shape == (0, 1024)
+
+
+def test_one_dimensional_waveform_in_one_dimensional_result_out(P):
+    rng = np.random.default_rng(2)
+    w = (1000 * rng.standard_normal(777)).astype(np.float32)
+    got = P.pole_zero(w, 50.0)
+    assert got.shape == (777,)
+    assert_rel_to_peak(got[None, :], oracle.pole_zero(w[None, :], 50.0)[0], 1e-6, "pz 1-D")
+    tmin, tmax, amin, amax = P.min_max(w)
+    assert (tmin, tmax) == (float(np.argmin(w)), float(np.argmax(w))) and amin == w.min() and amax == w.max()
+
+
+@pytest.mark.parametrize("wf_len", [1, 2, 5, 63, 64, 65, 127, 129, 1000, 4097])
+def test_ragged_lengths(P, wf_len):
+    rng = np.random.default_rng(wf_len)
+    w = (100 * rng.standard_normal((9, wf_len))).astype(np.float32)
+    assert np.array_equal(P.bl_subtract(w, 3.5), oracle.bl_subtract(w, 3.5)[0])
+    mm = P.min_max(w)
+    ref = oracle.min_max(w)
+    for g, r in zip(mm, ref[:4]):
+        assert np.array_equal(g, r)
+    assert_rel_to_peak(P.pole_zero(w, 20.0), oracle.pole_zero(w, 20.0)[0], 1e-6, "pz ragged")
+    if wf_len >= 5:
+        assert_rel_to_peak(P.trap_filter(w, 2, 1), oracle.trap_filter(w, 2, 1)[0], 1e-6, "trap ragged")
+
+
+def test_longest_waveform_and_the_first_that_does_not_fit(P):
+    """one wavefront holds a waveform in LDS (160 KB per CU): 32768 float32 samples fit for the in-place filters and the
+    waveform -> scalar processors (about 19 k for filters that keep source and destination side by side); 65536 do not -> a clear error"""
+    rng = np.random.default_rng(4)
+    w = (100 * rng.standard_normal((3, 32768))).astype(np.float32)
+    assert np.array_equal(P.bl_subtract(w, 1.0), w - np.float32(1.0))
+    t = np.array([0.0, 16000.5, 32767.0], dtype=np.float32)
+    assert np.array_equal(P.fixed_time_pickoff(w, t, ord("l")), oracle.fixed_time_pickoff(w, t, "l")[0])
+    assert_rel_to_peak(P.pole_zero(w, 500.0), oracle.pole_zero(w, 500.0)[0], 1e-6, "pz 32768")
+    w16 = w[:, :16384].copy()
+    assert_rel_to_peak(P.trap_filter(w16, 100, 30), oracle.trap_filter(w16, 100, 30)[0], 1e-6, "trap 16384")
+    with pytest.raises(ValueError, match="LDS"):
+        P.bl_subtract(np.zeros((1, 65536), dtype=np.float32), 1.0)
+    with pytest.raises(ValueError, match="LDS"):
+        P.trap_filter(w, 100, 30)
+
+
+def test_shortest_waveforms_follow_the_reference(P):
+    from dspeed_amd.errors import DSPFatal
+
+    w3 = np.ones((2, 3), dtype=np.float32)
+    with pytest.raises(DSPFatal):  # pole_zero.py:163-166: double_pole_zero needs more than 3 samples
+        P.double_pole_zero(w3, 10.0, 5.0, 0.1)
+    with pytest.raises(DSPFatal):  # trap_filters.py:59-60: 2*rise + flat > len
+        P.trap_filter(w3, 2, 0)
+    assert np.array_equal(P.pole_zero(np.ones((1, 1), dtype=np.float32), 10.0), np.ones((1, 1), dtype=np.float32))
