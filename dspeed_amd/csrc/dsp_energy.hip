@@ -358,7 +358,9 @@ struct EnergyPlan {
 //     by one uniform branch per 16 samples (a not-taken branch costs tens of cycles; 32 of them cost more than they saved).
 // S = sub-chains of the replay per lane: 2 halves the dependent-add chain but doubles the carry captures; measured slower.
 // ------------------------------------------------------------------------------------------------
-template <int NPF, int KIND, int S>
+// IN: waveform element type in HBM: 0 float32, 1 int16, 2 uint16 (digitiser samples; widened to float32 while staging, exactly
+// like the reference's ufunc casting picks the float32 loop for them, processing_chain.py:1565-1572)
+template <int NPF, int KIND, int S, int IN>
 __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, EnergyPlan PL, int64_t n_wf, int* err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int C = 4 * NPF + 1, len = 256 * NPF, NG = (C - 1) / 8, CS = (C - 1) / S, NGS = CS / 8;
@@ -387,12 +389,15 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
     const int64_t stride_rows = (int64_t)gridDim.x * wpb;
     int64_t row = (int64_t)blockIdx.x * wpb + wave;
     typedef float f4 __attribute__((ext_vector_type(4)));
-    f4 pf[NPF];
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    constexpr int NLD = IN == 0 ? NPF : NPF / 2;  // 16-byte loads per lane and waveform: 4 float32 or 8 16-bit samples each
+    static_assert(IN == 0 || NPF % 2 == 0, "16-bit rows: an even number of 4-sample groups per lane");
+    u4 pf[NLD];
     float pf_bl = 0.0f, pf_tp = 0.0f;
     auto prefetch = [&](int64_t r) {
-        const float* g = (const float*)A.wf + r * A.wf_stride + A.wf_offset;
+        const char* g = (const char*)A.wf + (r * A.wf_stride + A.wf_offset) * (IN == 0 ? 4 : 2);
 #pragma unroll
-        for (int b = 0; b < NPF; ++b) pf[b] = reinterpret_cast<const f4*>(g)[b * 64 + lane];
+        for (int b = 0; b < NLD; ++b) pf[b] = reinterpret_cast<const u4*>(g)[b * 64 + lane];
         // (address space 1 spelled out: a pointer that went through a null test is otherwise loaded with flat_load, whose
         // out-of-order return forces every LDS wait that follows it down to lgkmcnt(0))
         typedef const __attribute__((address_space(1))) float* gptr;
@@ -414,8 +419,33 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
     int64_t pend_row = -1;
 
     for (; row < n_wf; row += stride_rows) {
+        // bl_subtract while staging (16-bit samples: unpacked and converted first; a lane's load covers 8 consecutive samples)
 #pragma unroll
-        for (int b = 0; b < NPF; ++b) *reinterpret_cast<f4*>(slot + (b * 64 + lane) * 4) = pf[b] - pf_bl;  // bl_subtract while staging
+        for (int b = 0; b < NLD; ++b) {
+            if (IN == 0) {
+                f4 v;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) v[m] = __uint_as_float(pf[b][m]);
+                *reinterpret_cast<f4*>(slot + (b * 64 + lane) * 4) = v - pf_bl;
+            } else {
+                f4 lo, hi;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const unsigned int wv = pf[b][m];
+                    const float s0 = IN == 1 ? (float)(short)(wv & 0xffffu) : (float)(wv & 0xffffu);
+                    const float s1 = IN == 1 ? (float)(short)(wv >> 16) : (float)(wv >> 16);
+                    if (m < 2) {
+                        lo[2 * m] = s0;
+                        lo[2 * m + 1] = s1;
+                    } else {
+                        hi[2 * (m - 2)] = s0;
+                        hi[2 * (m - 2) + 1] = s1;
+                    }
+                }
+                *reinterpret_cast<f4*>(slot + (b * 64 + lane) * 8) = lo - pf_bl;
+                *reinterpret_cast<f4*>(slot + (b * 64 + lane) * 8 + 4) = hi - pf_bl;
+            }
+        }
         slot[len + lane] = 0.0f;  // virtual samples above len
         const float t_in = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pf_tp)));
         const int64_t next = row + stride_rows;
@@ -668,13 +698,13 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
     }
 }
 
-template <int KIND, int S>
+template <int KIND, int S, int IN>
 int launch_rr_kind(const EnergyArgs& A, const EnergyPlan& PL, int npf, int64_t n_wf, int* err, int blocks, int threads, int lds_bytes,
                    hipStream_t st) {
     switch (npf) {
-        case 4: hipLaunchKernelGGL((dsp_energy_rr_kernel<4, KIND, S>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
-        case 8: hipLaunchKernelGGL((dsp_energy_rr_kernel<8, KIND, S>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
-        case 16: hipLaunchKernelGGL((dsp_energy_rr_kernel<16, KIND, S>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 4: hipLaunchKernelGGL((dsp_energy_rr_kernel<4, KIND, S, IN>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 8: hipLaunchKernelGGL((dsp_energy_rr_kernel<8, KIND, S, IN>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 16: hipLaunchKernelGGL((dsp_energy_rr_kernel<16, KIND, S, IN>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
         default: return (int)hipErrorInvalidValue;
     }
     return (int)hipGetLastError();
@@ -715,12 +745,15 @@ extern "C" int dsp_internal_set_energy_lds(int trap_opcode, int npf, int lds_byt
     return (int)hipErrorInvalidValue;
 }
 
-// register-resident kernel; S = sub-chains of the trapezoid replay (1: default, 2: measured slower, kept for A/B); plan[S - 1]
-extern "C" int dsp_internal_launch_energy_rr(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int64_t n_wf,
-                                             int* err, int blocks, int threads, int lds_bytes, hipStream_t stream) {
-#define GO_(KIND)                                                                                                 \
-    return S == 2 ? launch_rr_kind<KIND, 2>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream)          \
-                  : launch_rr_kind<KIND, 1>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
+// register-resident kernel; S = sub-chains of the trapezoid replay (1: default, 2: measured slower, kept for A/B, float32 rows only);
+// plan[S - 1]; wf_dtype = DSP_F32 / DSP_I16 / DSP_U16 rows
+extern "C" int dsp_internal_launch_energy_rr(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int wf_dtype,
+                                             int64_t n_wf, int* err, int blocks, int threads, int lds_bytes, hipStream_t stream) {
+#define GO_(KIND)                                                                                                          \
+    if (wf_dtype == DSP_I16) return launch_rr_kind<KIND, 1, 1>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream); \
+    if (wf_dtype == DSP_U16) return launch_rr_kind<KIND, 1, 2>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream); \
+    return S == 2 ? launch_rr_kind<KIND, 2, 0>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream)                \
+                  : launch_rr_kind<KIND, 1, 0>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);
     if (trap_opcode == DSP_OP_TRAP_FILTER) { GO_(TRAP_FILTER) }
     if (trap_opcode == DSP_OP_TRAP_NORM) { GO_(TRAP_NORM) }
     GO_(TRAP_ASYM)

@@ -70,8 +70,8 @@ struct EnergyPlan {
     int32_t cs[3][4];
     int32_t local[3][4];
 };
-extern "C" int dsp_internal_launch_energy_rr(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int64_t n_wf,
-                                             int* err, int blocks, int threads, int lds_bytes, hipStream_t stream);
+extern "C" int dsp_internal_launch_energy_rr(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int wf_dtype,
+                                             int64_t n_wf, int* err, int blocks, int threads, int lds_bytes, hipStream_t stream);
 extern "C" const char* dsp_internal_energy_rr_kernel_name();
 
 namespace {
@@ -122,7 +122,7 @@ struct dsp_chain {
     // specialised energy-chain kernel (dsp_energy.hip), selected when the program has exactly that shape
     bool fused_ok = false, fused_on = true;
     EnergyArgs fused{};
-    int fused_trap = 0, fused_npf = 0;
+    int fused_trap = 0, fused_npf = 0, wf_dtype = DSP_F32;
     // register-resident kernel (pad-free LDS image): the default for 1024/2048/4096-sample energy chains
     bool rr_ok = false;
     // 6: register-resident kernel (default where it applies), 8: the same with two replay sub-chains per lane (A/B only),
@@ -603,7 +603,8 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         const dsp_op* pz = (ld && n_ops > i && ops[i].opcode == DSP_OP_POLE_ZERO) ? &ops[i++] : nullptr;
         const dsp_op* tp = (pz && n_ops > i && ops[i].opcode == DSP_OP_TRAP_PICKOFF) ? &ops[i++] : nullptr;
         const dsp_op* st = (tp && n_ops > i && ops[i].opcode == DSP_OP_STORE_SCALAR) ? &ops[i++] : nullptr;
-        const bool shape = !f64 && st && i == n_ops && n_slots == 1 && io[ld->io].dtype == DSP_F32 && P.io[ld->io].vec_ok &&
+        const int wdt = ld ? io[ld->io].dtype : -1;
+        const bool shape = !f64 && st && i == n_ops && n_slots == 1 && (wdt == DSP_F32 || wdt == DSP_I16 || wdt == DSP_U16) && P.io[ld->io].vec_ok &&
                            (!bs || (bs->dst == 0 && bs->src == 0 && bs->sp[0].kind != DSP_ARG_REG)) && pz->dst == 0 && pz->src == 0 &&
                            tp->src == 0 && tp->sp[0].kind != DSP_ARG_REG && st->ip[0] == tp->dst &&
                            (slot_len[0] == 1024 || slot_len[0] == 2048 || slot_len[0] == 4096 || slot_len[0] == 8192);
@@ -651,7 +652,8 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             ch->io_out = st->io;
             ch->fused_trap = tp->ip[3];
             ch->fused_npf = slot_len[0] / 256;          // one wavefront per waveform: len == 256 * npf, npf in {4, 8, 16}
-            ch->fused_ok = slot_len[0] <= 4096;
+            ch->fused_ok = slot_len[0] <= 4096 && wdt == DSP_F32;  // the classic kernel reads float32 rows only
+            ch->wf_dtype = wdt;
             const char* env = getenv("DSPEED_HIP_NO_FUSED");
             ch->fused_on = !(env && env[0] == '1');
             if (slot_len[0] <= 4096) {  // register-resident kernel: C = len/64 + 1 samples per lane, linear LDS image of the waveform
@@ -758,11 +760,11 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         F.bl = ch->io_bl >= 0 ? (const float*)io_ptrs[ch->io_bl] : nullptr;
         F.tp = ch->io_tp >= 0 ? (const float*)io_ptrs[ch->io_tp] : nullptr;
         F.out = (float*)io_ptrs[ch->io_out];
-        const int S = ch->variant == 8 ? 2 : 1;
+        const int S = (ch->variant == 8 && ch->wf_dtype == DSP_F32) ? 2 : 1;
         int rwpb, rblocks;
         rr_geometry(ch, n_wf, &rwpb, &rblocks);
-        hipError_t e = (hipError_t)dsp_internal_launch_energy_rr(&F, &ch->plan[S - 1], ch->fused_trap, ch->fused_npf, S, n_wf, ch->dev_err,
-                                                                 rblocks, 64 * rwpb, ch->rr_lds_bytes * rwpb, (hipStream_t)stream);
+        hipError_t e = (hipError_t)dsp_internal_launch_energy_rr(&F, &ch->plan[S - 1], ch->fused_trap, ch->fused_npf, S, ch->wf_dtype, n_wf,
+                                                                 ch->dev_err, rblocks, 64 * rwpb, ch->rr_lds_bytes * rwpb, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy kernel launch failed: %s", hipGetErrorString(e));
         return DSP_OK;
     }

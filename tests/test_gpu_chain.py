@@ -96,6 +96,42 @@ def test_energy_pickoff_position_sweep(wf_len, rise, flat, fused):
         assert np.max(np.abs(got[ok] - want[ok]) / peak[ok]) <= TOL, mode
 
 
+@pytest.mark.parametrize("dtype", [np.int16, np.uint16])
+@pytest.mark.parametrize("wf_len,rise,flat", [(4096, 625, 188), (2048, 300, 7), (1024, 64, 16)])
+def test_energy_chain_on_digitiser_samples(dtype, wf_len, rise, flat):
+    """16-bit rows (what the digitisers write) take the float32 loop like in the reference (ufunc casting, processing_chain.py:1565-1572):
+    the default kernel widens them while staging.  Same results as the float32 copy of the same samples, the VM and the oracle."""
+    rng = np.random.default_rng(wf_len)
+    n_wf = 257
+    i = np.arange(wf_len, dtype=np.float64)[None, :]
+    off = 0 if dtype == np.int16 else 20000
+    B = rng.uniform(-3000, 3000, (n_wf, 1)) + off
+    A = rng.uniform(500, 15000, (n_wf, 1))
+    t0 = np.floor(rng.uniform(0.45, 0.55, (n_wf, 1)) * wf_len)
+    wf = np.rint(B + A * np.exp(-(i - t0) / 1716.28) * (i >= t0) + 5.0 * rng.standard_normal((n_wf, wf_len))).astype(dtype)
+    if dtype == np.int16:
+        wf[3, 5] = -32768
+        wf[4, 6] = 32767
+    else:
+        wf[3, 5] = 0
+        wf[4, 6] = 65535
+    bl = B[:, 0].astype(np.float32)
+    tp = (t0[:, 0] + rise + 0.8 * flat).astype(np.float32)
+    want, rc = oracle.chain_energy(wf.astype(np.float32), bl, tp, 1716.28, rise, flat, "l")
+    assert rc == 0
+    from dspeed_amd.chain import Chain, energy_chain_program
+
+    ch = Chain(energy_chain_program(wf_len, 1716.28, rise, flat, "l", wf_dtype=dtype), "k")
+    assert ch.kernel_name == "dsp_energy_rr_kernel"  # the specialised kernel takes these rows directly
+    got = _run_energy(wf, bl, tp, 1716.28, rise, flat, "l", fused=1)
+    assert np.max(np.abs(got - want) / np.abs(want)) <= TOL
+    assert np.array_equal(got, _run_energy(wf.astype(np.float32), bl, tp, 1716.28, rise, flat, "l", fused=1))  # widening is exact
+    vm = _run_energy(wf, bl, tp, 1716.28, rise, flat, "l", fused=0)
+    assert np.max(np.abs(vm - want) / np.abs(want)) <= TOL
+    # the classic kernel reads float32 rows only: asking for it on 16-bit rows runs the VM, not something wrong
+    assert np.array_equal(_run_energy(wf, bl, tp, 1716.28, rise, flat, "l", fused=15), vm)
+
+
 def test_energy_chain_matches_unfused_processors():
     """fused chain == the same processors called one by one on the device (the ProcessingChain way)"""
     from dspeed_amd import processors as P
