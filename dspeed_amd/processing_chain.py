@@ -110,6 +110,7 @@ class ProcessingChain:
         self._tb_in = None
         self._tb_out = None
         self._pins = {}           # (address, bytes) -> HostPin of a linked host column (None: registration refused)
+        self._piece_key, self._piece_bufs, self._piece_events = None, [], []  # device buffers host columns are streamed through
         self._copy_stream = None  # H2D of the next piece runs here while the compute stream works on the current one
         self._timing = {"h2d": 0.0, "kernel": 0.0, "d2h": 0.0}
         self.proc_strings = proc_strings
@@ -192,15 +193,22 @@ class ProcessingChain:
         row_bytes += sum(self.loop_dtype.itemsize * (1 if length is None else length) for _, length, _ in host_out.values())
         piece = n if row_bytes == 0 else int(max(1, min(n, self.pipeline_bytes // row_bytes)))
         n_slots = 2 if piece < n else 1
-        slots = []
-        for _ in range(n_slots):
-            sl = {name: DeviceArray((piece, *a.shape[1:]), a.dtype) for name, a in host_in.items()}
-            sl.update({name: DeviceArray((piece,) if length is None else (piece, length), self.loop_dtype)
-                       for name, (_, length, _) in host_out.items()})
-            slots.append(sl)
+        # piece buffers live as long as the chain (the reference pre-allocates its ProcChainVar buffers the same way,
+        # processing_chain.py:259-269): build_dsp calls execute() once per file chunk with the same shapes
+        key = (piece, n_slots, tuple((nm, a.shape[1:], a.dtype.str) for nm, a in host_in.items()),
+               tuple((nm, length) for nm, (_, length, _) in host_out.items()))
+        if self._piece_key != key:
+            self._piece_bufs = []
+            for _ in range(n_slots):
+                sl = {name: DeviceArray((piece, *a.shape[1:]), a.dtype) for name, a in host_in.items()}
+                sl.update({name: DeviceArray((piece,) if length is None else (piece, length), self.loop_dtype)
+                           for name, (_, length, _) in host_out.items()})
+                self._piece_bufs.append(sl)
+            self._piece_events = [Event() for _ in range(n_slots)]
+            self._piece_key = key
+        slots, ev_in = self._piece_bufs, self._piece_events
         if self._copy_stream is None:
             self._copy_stream = Stream()
-        ev_in = [Event() for _ in range(n_slots)]
         s_in, s_c = self._copy_stream, self._stream
 
         def finish(a, b, temps):
