@@ -97,6 +97,18 @@ int fail(int code, const char* fmt, ...) {
         }                                                                                          \
     } while (0)
 
+// Release-type calls (free, destroy, unregister) run from destructors / garbage collection at arbitrary moments of the caller: they
+// report through their return code only and leave dsp_last_error() alone, so the text of an error the caller is about to read is
+// never replaced by an unrelated one.
+#define HIP_RELEASE(expr)                       \
+    do {                                        \
+        hipError_t e_ = (expr);                 \
+        if (e_ != hipSuccess) {                 \
+            (void)hipGetLastError();            \
+            return DSP_ERR_HIP;                 \
+        }                                       \
+    } while (0)
+
 constexpr int LDS_BYTES_PER_CU = 160 * 1024;
 
 int elem_size(int dtype) {
@@ -170,7 +182,7 @@ int dsp_malloc(void** dev, int64_t bytes) {
     return DSP_OK;
 }
 int dsp_free(void* dev) {
-    if (dev) HIP_TRY(hipFree(dev));
+    if (dev) HIP_RELEASE(hipFree(dev));
     return DSP_OK;
 }
 int dsp_host_alloc(void** host, int64_t bytes) {
@@ -179,7 +191,7 @@ int dsp_host_alloc(void** host, int64_t bytes) {
     return DSP_OK;
 }
 int dsp_host_free(void* host) {
-    if (host) HIP_TRY(hipHostFree(host));
+    if (host) HIP_RELEASE(hipHostFree(host));
     return DSP_OK;
 }
 int dsp_memset(void* dev, int value, int64_t bytes, void* stream) {
@@ -209,7 +221,7 @@ int dsp_stream_create(void** stream) {
     return DSP_OK;
 }
 int dsp_stream_destroy(void* stream) {
-    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    HIP_RELEASE(hipStreamDestroy((hipStream_t)stream));
     return DSP_OK;
 }
 int dsp_stream_sync(void* stream) {
@@ -227,7 +239,7 @@ int dsp_event_create(void** event) {
     return DSP_OK;
 }
 int dsp_event_destroy(void* event) {
-    HIP_TRY(hipEventDestroy((hipEvent_t)event));
+    HIP_RELEASE(hipEventDestroy((hipEvent_t)event));
     return DSP_OK;
 }
 int dsp_event_record(void* event, void* stream) {
@@ -249,11 +261,7 @@ int dsp_host_register(void* host, int64_t bytes) {
 }
 int dsp_host_unregister(void* host) {
     if (!host) return DSP_OK;
-    hipError_t e = hipHostUnregister(host);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(DSP_ERR_HIP, "hipHostUnregister: %s", hipGetErrorString(e));
-    }
+    HIP_RELEASE(hipHostUnregister(host));
     return DSP_OK;
 }
 int dsp_event_sync(void* event) {

@@ -117,10 +117,15 @@ class PinnedArray:
             pass
 
 
+_PINNED = {}  # (address, bytes) -> number of HostPin objects holding that registration (hipHostRegister itself does not count)
+
+
 class HostPin:
     """Page-locks a caller-owned C-contiguous NumPy array in place for as long as this object lives, so that ``h2d_async`` /
     ``d2h_async`` on it overlap kernels without a staging copy.  The reference's ``build_dsp`` fills the same input buffer for
-    every file chunk (build_dsp.py:399-432), so a linked buffer is pinned once and reused."""
+    every file chunk (build_dsp.py:399-432), so a linked buffer is pinned once and reused.  Several holders of the same buffer
+    (two chains linked to one table) share one registration: the runtime accepts a second ``hipHostRegister`` of a range but a
+    single unregister then drops it for everybody, so the count is kept here."""
 
     def __init__(self, array: np.ndarray):
         if not (isinstance(array, np.ndarray) and array.flags.c_contiguous and array.nbytes > 0):
@@ -128,13 +133,21 @@ class HostPin:
         self.array = array
         self.ptr = array.ctypes.data
         self.nbytes = array.nbytes
-        _lib.check(_lib.lib().dsp_host_register(self.ptr, self.nbytes), what="host_register")
-        self._registered = True
+        self._key = (self.ptr, self.nbytes)
+        if _PINNED.get(self._key, 0) == 0:
+            _lib.check(_lib.lib().dsp_host_register(self.ptr, self.nbytes), what="host_register")
+        _PINNED[self._key] = _PINNED.get(self._key, 0) + 1
+        self._held = True
 
     def close(self):
-        if getattr(self, "_registered", False):
-            self._registered = False
-            _lib.lib().dsp_host_unregister(self.ptr)
+        if getattr(self, "_held", False):
+            self._held = False
+            left = _PINNED.get(self._key, 1) - 1
+            if left <= 0:
+                _PINNED.pop(self._key, None)
+                _lib.lib().dsp_host_unregister(self.ptr)
+            else:
+                _PINNED[self._key] = left
 
     def __del__(self):
         try:

@@ -135,6 +135,45 @@ def test_chain_executes_in_row_ranges_and_on_device_buffers():
     assert np.array_equal(out_dev["trapEftp"].to_numpy(), full)
 
 
+def test_energy_recipe_variants_take_the_specialised_kernel():
+    """the shapes the specialised kernel accepts besides BASELINE's: constant baseline and pick-off time, no bl_subtract at all,
+    trap_norm and asym_trap_filter as the shaping filter, time quantities; each against the oracle run processor by processor"""
+    rng = np.random.default_rng(21)
+    x, bl, t0 = _synth(rng, 130, 4096, bl=(9999.5, 10000.5))
+    wf = x.astype(np.float32)
+    M = "dspeed.processors"
+
+    def run(procs, tb, out="e"):
+        chain, o = _run({"outputs": [out], "processors": procs}, tb)
+        assert chain._chain.kernel_name == "dsp_energy_rr_kernel", chain._chain.kernel_name
+        return o[out]
+
+    peak = lambda tr: np.max(np.abs(tr), axis=1)  # noqa: E731
+    # constant baseline, constant pick-off time
+    got = run({"b": f"{M}.bl_subtract(waveform, 10000, b)", "p": f"{M}.pole_zero(b, 1716.28, p)", "t": f"{M}.trap_filter(p, 400, 100, t)",
+               "e": f"{M}.fixed_time_pickoff(t, 2900.25, 'l', e)"}, {"waveform": wf})
+    pz = oracle.pole_zero(oracle.bl_subtract(wf, np.float32(10000))[0], 1716.28)[0]
+    tr = oracle.trap_filter(pz, 400, 100)[0]
+    want = oracle.fixed_time_pickoff(tr, np.float32(2900.25), "l")[0]
+    assert np.max(np.abs(got - want) / peak(tr)) <= TOL
+    # no bl_subtract: pole_zero straight on the input
+    got = run({"p": f"{M}.pole_zero(waveform, 1716.28, p)", "t": f"{M}.trap_filter(p, 200, 50, t)",
+               "e": f"{M}.fixed_time_pickoff(t, t_pick, 'n', e)"}, {"waveform": wf, "t_pick": (t0 + 300.7).astype(np.float32)})
+    pz = oracle.pole_zero(wf, 1716.28)[0]
+    tr = oracle.trap_filter(pz, 200, 50)[0]
+    want = oracle.fixed_time_pickoff(tr, (t0 + 300.7).astype(np.float32), "n")[0]
+    assert np.max(np.abs(got - want) / peak(tr)) <= TOL
+    # trap_norm and asym_trap_filter, per-event baseline, Hermite pick-off
+    for name, args, ref in (("trap_norm", "300, 80", lambda p: oracle.trap_norm(p, 300, 80)[0]),
+                            ("asym_trap_filter", "100, 40, 300", lambda p: oracle.asym_trap_filter(p, 100, 40, 300)[0])):
+        got = run({"b": f"{M}.bl_subtract(waveform, baseline, b)", "p": f"{M}.pole_zero(b, 1716.28, p)", "t": f"{M}.{name}(p, {args}, t)",
+                   "e": f"{M}.fixed_time_pickoff(t, t_pick, 'h', e)"}, {"waveform": wf, "baseline": bl, "t_pick": (t0 + 350.3).astype(np.float32)})
+        pz = oracle.pole_zero(oracle.bl_subtract(wf, bl)[0], 1716.28)[0]
+        tr = ref(pz)
+        want = oracle.fixed_time_pickoff(tr, (t0 + 350.3).astype(np.float32), "h")[0]
+        assert np.max(np.abs(got - want) / peak(tr)) <= TOL, name
+
+
 def test_host_buffers_stream_through_in_overlapped_pieces():
     """Host-resident columns are processed in pieces (H2D of piece k+1 overlaps kernel and D2H of piece k): same results as one
     piece, a waveform-valued output included, an output column of another dtype converted, a data-dependent DSPFatal reported
