@@ -111,10 +111,9 @@ class Chain:
         return {"lds_bytes_per_wave": a.value, "waves_per_block": b.value, "blocks": c.value}
 
     def set_fused(self, enable) -> bool:
-        """False/0: generic waveform VM; True/1: the default specialised energy kernel (register-resident straight-line kernel for
-        1024/2048/4096 samples, the classic one otherwise).  Odd values 3..15 pick the other variants kept for A/B measurements
-        (3/5: 2/4 sub-chains per lane, 7: v3, 9/11: straight line from LDS, 13: register-resident, 15: classic).  Returns whether
-        a specialised kernel is in use."""
+        """False/0: the generic waveform VM; True/1: the default specialised energy kernel where the chain has that shape (the
+        register-resident kernel for 1024/2048/4096 samples); 13: the register-resident kernel explicitly; 15: the classic
+        specialised kernel (VM layout, bit-identical to the VM; float32 rows only).  Returns whether a specialised kernel is in use."""
         return bool(_lib.lib().dsp_chain_set_fused(self._h, int(enable)))
 
     @property
