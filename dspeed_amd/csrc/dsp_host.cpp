@@ -294,6 +294,9 @@ const char* dsp_fatal_message(int code) {
         case DSP_E_DWT_LEVEL: return "The level must be a positive integer";
         case DSP_E_DWT_OUTLEN: return "Output waveform has the wrong length for this wavelet level";
         case DSP_E_ZERODIV: return "division by zero";
+        case DSP_E_WINDOW_LONG: return "The windowed waveform must be smaller than the input waveform";
+        case DSP_E_AVGCUR_RANGE: return "length is out of range, must be between 0 and the length of the waveform";
+        case DSP_E_TPO_INT: return "The pick-off index must be an integer";
         default: return "";
     }
 }
@@ -368,7 +371,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             const bool writes = (o.opcode == DSP_OP_LOAD || o.opcode == DSP_OP_BL_SUBTRACT || o.opcode == DSP_OP_POLE_ZERO ||
                                  o.opcode == DSP_OP_DOUBLE_POLE_ZERO || o.opcode == DSP_OP_TRAP_FILTER || o.opcode == DSP_OP_TRAP_NORM ||
                                  o.opcode == DSP_OP_ASYM_TRAP || o.opcode == DSP_OP_DWT_HAAR || o.opcode == DSP_OP_CONVOLVE ||
-                                 o.opcode == DSP_OP_COPY) && o.dst == s;
+                                 o.opcode == DSP_OP_COPY || o.opcode == DSP_OP_WINDOWER || o.opcode == DSP_OP_AVG_CURRENT) && o.dst == s;
             const bool scratch = o.opcode == DSP_OP_DWT_HAAR && o.ip[2] == s;
             if (!reads && !writes && !scratch) continue;
             if ((o.opcode == DSP_OP_CONVOLVE || o.opcode == DSP_OP_CONVOLVE_AMAX) && reads) fir_in = true;
@@ -549,6 +552,32 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             case DSP_OP_MEAN_BELOW:
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad MEAN_BELOW", i);
                 break;
+            case DSP_OP_WINDOWER:
+                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || o.src == o.dst) return fail(DSP_ERR_ARG, "op %d: bad WINDOWER", i);
+                if (slot_len[o.dst] >= slot_len[o.src]) return fail(DSP_E_WINDOW_LONG, "%s", dsp_fatal_message(DSP_E_WINDOW_LONG));
+                break;
+            case DSP_OP_AVG_CURRENT: {
+                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || o.src == o.dst) return fail(DSP_ERR_ARG, "op %d: bad AVG_CURRENT", i);
+                if (o.sp[0].kind != DSP_ARG_CONST) return fail(DSP_ERR_UNSUPPORTED, "avg_current: the window length must be a constant");
+                const double length = f64 ? o.sp[0].value : (double)(float)o.sp[0].value;
+                const int n = slot_len[o.src];
+                if (!(length >= 0) || !(length < (double)n)) return fail(DSP_E_AVGCUR_RANGE, "%s", dsp_fatal_message(DSP_E_AVGCUR_RANGE));
+                const int L = (int)length;
+                if (L <= 0 || slot_len[o.dst] != n - L)
+                    return fail(DSP_ERR_ARG, "avg_current: the output must hold len(w_in) - int(length) = %d samples (it holds %d)", n - L,
+                                slot_len[o.dst]);
+                d.ic[0] = L;
+                d.fc[0] = length;
+                break;
+            }
+            case DSP_OP_TRAP_WINDOW_PICKOFF: {
+                if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad TRAP_WINDOW_PICKOFF", i);
+                const int rise = o.ip[0], flat = o.ip[1];
+                if (rise < 0) return fail(DSP_E_TRAP_RISE, "%s", dsp_fatal_message(DSP_E_TRAP_RISE));
+                if (flat < 0) return fail(DSP_E_TRAP_FLAT, "%s", dsp_fatal_message(DSP_E_TRAP_FLAT));
+                if (2 * (long long)rise + flat > slot_len[o.src]) return fail(DSP_E_TRAP_WIDE, "%s", dsp_fatal_message(DSP_E_TRAP_WIDE));
+                break;
+            }
             case DSP_OP_MIN_MAX:
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst + 3 >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad MIN_MAX", i);
                 break;
@@ -1058,6 +1087,31 @@ int g_tpt(int ty, const WfIn& in, const void* thr_dev, double thr, const void* t
     sto.ip[0] = 0;
     return m.run(in.n_wf, st, er);
 }
+int g_windower(int ty, const WfIn& in, const void* t0_dev, double t0, void* out, int32_t out_len, int64_t out_stride, void* st, int64_t* er) {
+    const double c[1] = {t0};
+    return wf2wf(ty, DSP_OP_WINDOWER, in, out, out_len, out_stride, nullptr, 0, c, 1, t0_dev, st, er);
+}
+int g_avg_current(int ty, const WfIn& in, double length, void* out, int32_t out_len, int64_t out_stride, void* st, int64_t* er) {
+    const double c[1] = {length};
+    return wf2wf(ty, DSP_OP_AVG_CURRENT, in, out, out_len, out_stride, nullptr, 0, c, 1, nullptr, st, er);
+}
+int g_trap_window_pickoff(int ty, const WfIn& in, int32_t rise, int32_t flat, const void* tp_dev, double tp, void* out, void* st, int64_t* er) {
+    if (in.n_wf <= 0) return DSP_OK;
+    Mini m(ty);
+    m.n_sregs = 1;
+    const int s_in = m.add_slot(in.len);
+    const int io_in = m.add_io(DSP_IO_WF_IN, in.dtype, in.len, in.stride, in.ptr);
+    m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
+    dsp_scalar_arg a = m.scalar(tp_dev, tp);
+    dsp_op& o = m.add_op(DSP_OP_TRAP_WINDOW_PICKOFF, 0, s_in, 0);
+    o.ip[0] = rise;
+    o.ip[1] = flat;
+    o.sp[0] = a;
+    const int io_out = m.add_io(DSP_IO_SCALAR_OUT, ty, 1, 1, out);
+    dsp_op& sto = m.add_op(DSP_OP_STORE_SCALAR, 0, 0, io_out);
+    sto.ip[0] = 0;
+    return m.run(in.n_wf, st, er);
+}
 int g_mean_below(int ty, const WfIn& in, const void* thr_dev, double thr, void* out, void* st, int64_t* er) {
     if (in.n_wf <= 0) return DSP_OK;
     Mini m(ty);
@@ -1128,6 +1182,19 @@ int g_min_max(int ty, const WfIn& in, void* t_min, void* t_max, void* a_min, voi
                                     int64_t* err_row) {                                                                                       \
         return g_tpt(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, threshold_dev, (double)threshold, t_start_dev, (double)t_start,         \
                      (double)walk_forward, out, stream, err_row);                                                                             \
+    }                                                                                                                                         \
+    int dsp_windower_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const FT* t0_dev, FT t0, FT* out,   \
+                           int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row) {                                             \
+        return g_windower(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, t0_dev, (double)t0, out, out_len, out_stride, stream, err_row);    \
+    }                                                                                                                                         \
+    int dsp_avg_current_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, FT length, FT* out,              \
+                              int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row) {                                          \
+        return g_avg_current(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, (double)length, out, out_len, out_stride, stream, err_row);     \
+    }                                                                                                                                         \
+    int dsp_trap_pickoff_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,     \
+                               const FT* t_pickoff_dev, FT t_pickoff, FT* out, void* stream, int64_t* err_row) {                              \
+        return g_trap_window_pickoff(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, rise, flat, t_pickoff_dev, (double)t_pickoff, out,      \
+                                     stream, err_row);                                                                                       \
     }                                                                                                                                         \
     int dsp_mean_below_threshold_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,                        \
                                        const FT* threshold_dev, FT threshold, FT* out, void* stream, int64_t* err_row) {                      \

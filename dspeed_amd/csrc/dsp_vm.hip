@@ -20,6 +20,9 @@
 #include "dsp_program.h"
 #include "dsp_wave.h"
 
+// pointers into device memory (the program, I/O buffers) carry their address space in the type, see Ctx
+#define DSP_GLOBAL __attribute__((address_space(1)))
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -27,21 +30,38 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 struct Ctx {
-    T* lds;                  // this wavefront's LDS region
-    const DevProgram* prog;  // device copy of the program
+    // LDS pointers carry their address space in the type: an op that the compiler decides not to inline into the interpreter would
+    // otherwise see a generic pointer and access LDS through flat_load / flat_store (measured: the FIR op 5x slower)
+    typedef __attribute__((address_space(3))) T LT;
+    LT* lds;                 // this wavefront's LDS region
+    const DSP_GLOBAL DevProgram* prog;  // device copy of the program
     // I/O device pointers of this launch: read straight from the kernel-argument segment (constant address space, scalar loads with a
     // run-time index); taking the address of the by-value IoPtrs argument instead makes the compiler copy it to scratch
     const __attribute__((address_space(4))) uint64_t* kptrs;
-    __device__ __forceinline__ void* io_ptr(int i) const { return reinterpret_cast<void*>(kptrs[i]); }
+    // (global address space spelled out for the same reason as LDS above: global_load / global_store, not flat)
+    __device__ __forceinline__ uint64_t io_addr(int i) const { return kptrs[i]; }
+    template <typename U>
+    __device__ __forceinline__ DSP_GLOBAL U* io_ptr(int i) const {
+        return (DSP_GLOBAL U*)kptrs[i];
+    }
     int64_t row;             // waveform being processed
     int* err;                // device error word
-    uint32_t nan_mask;       // bit s set: slot s is "all NaN" (the reference's NaN-propagation state)
+    // bit s set: slot s is "all NaN" (the reference's NaN-propagation state; its content is then not maintained);
+    // bit 16 + s set: slot s holds real content with NaN samples in it (windower output reaching past the input) -- consumers
+    // treat it like all-NaN (np.isnan(w_in).any()), a store writes the content
+    uint32_t nan_mask;
 
-    __device__ __forceinline__ T* chunk(const DevSlot& s) const { return lds + s.off + lane_id() * s.pitch; }
-    __device__ __forceinline__ T* sregs() const { return lds + prog->sreg_off; }
-    __device__ __forceinline__ bool slot_nan(int s) const { return (nan_mask >> s) & 1u; }
+    __device__ __forceinline__ LT* chunk(const DSP_GLOBAL DevSlot& s) const { return lds + s.off + lane_id() * s.pitch; }
+    __device__ __forceinline__ LT* sregs() const { return lds + prog->sreg_off; }
+    __device__ __forceinline__ bool slot_nan(int s) const { return ((nan_mask | (nan_mask >> 16)) >> s) & 1u; }
+    __device__ __forceinline__ bool slot_all_nan(int s) const { return (nan_mask >> s) & 1u; }
     __device__ __forceinline__ void set_nan(int s, bool v) {
-        nan_mask = v ? (nan_mask | (1u << s)) : (nan_mask & ~(1u << s));
+        nan_mask &= ~((1u << s) | (1u << (16 + s)));
+        if (v) nan_mask |= 1u << s;
+    }
+    __device__ __forceinline__ void set_some_nan(int s) {
+        nan_mask &= ~(1u << s);
+        nan_mask |= 1u << (16 + s);
     }
     __device__ void fatal(int code) const {
         if (lane_id() == 0 && atomicCAS(&err[0], 0, code) == 0) {
@@ -50,25 +70,24 @@ struct Ctx {
         }
     }
     // scalar operand: constant, per-waveform input column, or scalar register
-    __device__ T scalar(const dsp_scalar_arg& a) const { return make_uniform(scalar_raw(a)); }
+    __device__ T scalar(const DSP_GLOBAL dsp_scalar_arg& a) const { return make_uniform(scalar_raw(a)); }
     static __device__ __forceinline__ float make_uniform(float v) {
         return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
     }
     static __device__ __forceinline__ double make_uniform(double v) {
         return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
     }
-    __device__ T scalar_raw(const dsp_scalar_arg& a) const {
+    __device__ T scalar_raw(const DSP_GLOBAL dsp_scalar_arg& a) const {
         if (a.kind == DSP_ARG_CONST) return (T)a.value;
         if (a.kind == DSP_ARG_REG) return sregs()[a.index];
-        const DevIO& io = prog->io[a.index];
+        const DSP_GLOBAL DevIO& io = prog->io[a.index];
         const int64_t at = (int64_t)io.offset + row * io.row_stride;
-        const void* p = io_ptr(a.index);
-        if (io.dtype == DSP_F32) return (T)((const float*)p)[at];
-        if (io.dtype == DSP_F64) return (T)((const double*)p)[at];
-        if (io.dtype == DSP_I32) return (T)((const int32_t*)p)[at];
-        if (io.dtype == DSP_I16) return (T)((const int16_t*)p)[at];
-        if (io.dtype == DSP_U16) return (T)((const uint16_t*)p)[at];
-        return (T)((const uint32_t*)p)[at];
+        if (io.dtype == DSP_F32) return (T)io_ptr<const float>(a.index)[at];
+        if (io.dtype == DSP_F64) return (T)io_ptr<const double>(a.index)[at];
+        if (io.dtype == DSP_I32) return (T)io_ptr<const int32_t>(a.index)[at];
+        if (io.dtype == DSP_I16) return (T)io_ptr<const int16_t>(a.index)[at];
+        if (io.dtype == DSP_U16) return (T)io_ptr<const uint16_t>(a.index)[at];
+        return (T)io_ptr<const uint32_t>(a.index)[at];
     }
 };
 
@@ -76,7 +95,7 @@ struct Ctx {
 // LOAD / STORE: coalesced 16-byte global accesses <-> chunked LDS layout
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename InT>
-__device__ bool load_slot(Ctx<T>& cx, const DevSlot& s, const InT* __restrict__ g, int len, bool vec_ok) {
+__device__ bool load_slot(Ctx<T>& cx, const DSP_GLOBAL DevSlot& s, const DSP_GLOBAL InT* __restrict__ g, int len, bool vec_ok) {
     constexpr int V = 16 / (int)sizeof(InT);
     typedef InT vec_t __attribute__((ext_vector_type(V)));
     const int total = 64 * s.C;
@@ -89,7 +108,7 @@ __device__ bool load_slot(Ctx<T>& cx, const DevSlot& s, const InT* __restrict__ 
             for (int b = 0; b < B; ++b) {
                 const int e = e0 + b * 64 * V;
                 if (e + V <= len) {
-                    v[b] = *reinterpret_cast<const vec_t*>(g + e);
+                    v[b] = *(const DSP_GLOBAL vec_t*)(g + e);
                 } else {
 #pragma unroll
                     for (int m = 0; m < V; ++m) v[b][m] = (e + m < len) ? g[e + m] : (InT)0;
@@ -120,42 +139,41 @@ __device__ bool load_slot(Ctx<T>& cx, const DevSlot& s, const InT* __restrict__ 
 }
 
 template <typename T>
-__device__ void op_load(Ctx<T>& cx, const DevOp& op) {
-    const DevSlot& s = cx.prog->slots[op.dst];
-    const DevIO& io = cx.prog->io[op.io];
-    const char* base = (const char*)cx.io_ptr(op.io);
+__device__ void op_load(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& s = cx.prog->slots[op.dst];
+    const DSP_GLOBAL DevIO& io = cx.prog->io[op.io];
     const int64_t at = cx.row * io.row_stride + io.offset;
-    const bool vec_ok = io.vec_ok && ((reinterpret_cast<uintptr_t>(base) & 15u) == 0);
+    const bool vec_ok = io.vec_ok && ((cx.io_addr(op.io) & 15u) == 0);
     bool nan;
     switch (io.dtype) {
-        case DSP_F32: nan = load_slot<T, float>(cx, s, (const float*)base + at, io.len, vec_ok); break;
-        case DSP_I16: nan = load_slot<T, int16_t>(cx, s, (const int16_t*)base + at, io.len, vec_ok); break;
-        case DSP_U16: nan = load_slot<T, uint16_t>(cx, s, (const uint16_t*)base + at, io.len, vec_ok); break;
-        case DSP_I32: nan = load_slot<T, int32_t>(cx, s, (const int32_t*)base + at, io.len, vec_ok); break;
-        case DSP_U32: nan = load_slot<T, uint32_t>(cx, s, (const uint32_t*)base + at, io.len, vec_ok); break;
-        default: nan = load_slot<T, double>(cx, s, (const double*)base + at, io.len, vec_ok); break;
+        case DSP_F32: nan = load_slot<T, float>(cx, s, cx.template io_ptr<const float>(op.io) + at, io.len, vec_ok); break;
+        case DSP_I16: nan = load_slot<T, int16_t>(cx, s, cx.template io_ptr<const int16_t>(op.io) + at, io.len, vec_ok); break;
+        case DSP_U16: nan = load_slot<T, uint16_t>(cx, s, cx.template io_ptr<const uint16_t>(op.io) + at, io.len, vec_ok); break;
+        case DSP_I32: nan = load_slot<T, int32_t>(cx, s, cx.template io_ptr<const int32_t>(op.io) + at, io.len, vec_ok); break;
+        case DSP_U32: nan = load_slot<T, uint32_t>(cx, s, cx.template io_ptr<const uint32_t>(op.io) + at, io.len, vec_ok); break;
+        default: nan = load_slot<T, double>(cx, s, cx.template io_ptr<const double>(op.io) + at, io.len, vec_ok); break;
     }
     cx.set_nan(op.dst, wave_any(nan));
     wave_sync();
 }
 
 template <typename T>
-__device__ void op_store(Ctx<T>& cx, const DevOp& op) {
-    const DevSlot& s = cx.prog->slots[op.src];
-    const DevIO& io = cx.prog->io[op.io];
-    T* g = (T*)cx.io_ptr(op.io) + cx.row * io.row_stride + io.offset;
+__device__ void op_store(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& s = cx.prog->slots[op.src];
+    const DSP_GLOBAL DevIO& io = cx.prog->io[op.io];
+    DSP_GLOBAL T* g = cx.template io_ptr<T>(op.io) + cx.row * io.row_stride + io.offset;
     const int len = io.len;
-    const bool nan = cx.slot_nan(op.src);
+    const bool nan = cx.slot_all_nan(op.src);  // (a slot with some NaN samples is stored as it is)
     constexpr int V = 16 / (int)sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(V)));
-    if (io.vec_ok && ((reinterpret_cast<uintptr_t>(cx.io_ptr(op.io)) & 15u) == 0)) {
+    if (io.vec_ok && ((cx.io_addr(op.io) & 15u) == 0)) {
         for (int e = lane_id() * V; e < len; e += 64 * V) {
             const int a = padded_index(s, e);
             vec_t v;
 #pragma unroll
             for (int m = 0; m < V; ++m) v[m] = nan ? quiet_nan<T>() : cx.lds[a + m];
             if (e + V <= len) {
-                *reinterpret_cast<vec_t*>(g + e) = v;
+                *(DSP_GLOBAL vec_t*)(g + e) = v;
             } else {
                 for (int m = 0; m < V && e + m < len; ++m) g[e + m] = v[m];
             }
@@ -166,25 +184,25 @@ __device__ void op_store(Ctx<T>& cx, const DevOp& op) {
 }
 
 template <typename T>
-__device__ void op_store_scalar(Ctx<T>& cx, const DevOp& op) {
-    const DevIO& io = cx.prog->io[op.io];
-    if (lane_id() == 0) ((T*)cx.io_ptr(op.io))[cx.row * io.row_stride + io.offset] = cx.sregs()[op.ip[0]];
+__device__ void op_store_scalar(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevIO& io = cx.prog->io[op.io];
+    if (lane_id() == 0) cx.template io_ptr<T>(op.io)[cx.row * io.row_stride + io.offset] = cx.sregs()[op.ip[0]];
 }
 
 // ------------------------------------------------------------------------------------------------
 // bl_subtract  (processors/bl_subtract.py:11-46):  w_out = w_in - a_baseline, both T
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_bl_subtract(Ctx<T>& cx, const DevOp& op) {
-    const DevSlot& ss = cx.prog->slots[op.src];
-    const DevSlot& sd = cx.prog->slots[op.dst];
+__device__ void op_bl_subtract(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
     const T b = cx.scalar(op.sp[0]);
     if (cx.slot_nan(op.src) || b != b) {
         cx.set_nan(op.dst, true);
         return;
     }
-    const T* ps = cx.chunk(ss);
-    T* pd = cx.chunk(sd);
+    const auto* ps = cx.chunk(ss);
+    auto* pd = cx.chunk(sd);
     bool nan = false;
 #pragma unroll 8
     for (int t = 0; t < ss.C; ++t) {
@@ -204,16 +222,16 @@ __device__ void op_bl_subtract(Ctx<T>& cx, const DevOp& op) {
 // recurrence runs with the reference's operation order.  fc[0] = c, ic[0] = tau is NaN.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_pole_zero(Ctx<T>& cx, const DevOp& op) {
-    const DevSlot& ss = cx.prog->slots[op.src];
-    const DevSlot& sd = cx.prog->slots[op.dst];
+__device__ void op_pole_zero(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
     if (cx.slot_nan(op.src) || op.ic[0]) {
         cx.set_nan(op.dst, true);
         return;
     }
     const double c = op.fc[0];
-    const T* ps = cx.chunk(ss);
-    T* pd = cx.chunk(sd);
+    const auto* ps = cx.chunk(ss);
+    auto* pd = cx.chunk(sd);
     const int C = ss.C;
     double X = 0.0;
 #pragma unroll 8
@@ -251,16 +269,16 @@ __device__ void op_pole_zero(Ctx<T>& cx, const DevOp& op) {
 // fc: 0 n1, 1 n2, 2 d1, 3 d2, 4.. six 2x2 matrices M^{C}, M^{2C}, ... M^{32C} (row major); ic[0] = parameter NaN.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_double_pole_zero(Ctx<T>& cx, const DevOp& op) {
-    const DevSlot& ss = cx.prog->slots[op.src];
-    const DevSlot& sd = cx.prog->slots[op.dst];
+__device__ void op_double_pole_zero(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
     if (cx.slot_nan(op.src) || op.ic[0]) {
         cx.set_nan(op.dst, true);
         return;
     }
     const double n1 = op.fc[0], n2 = op.fc[1], d1 = op.fc[2], d2 = op.fc[3];
-    const T* ps = cx.chunk(ss);
-    T* pd = cx.chunk(sd);
+    const auto* ps = cx.chunk(ss);
+    auto* pd = cx.chunk(sd);
     const int C = ss.C, lane = lane_id();
     // the two samples preceding this chunk
     const double xm1_in = (double)wave_prev(ps[C - 1]);
@@ -288,7 +306,7 @@ __device__ void op_double_pole_zero(Ctx<T>& cx, const DevOp& op) {
     double r1 = y1, r0 = y0;
 #pragma unroll
     for (int d = 0; d < 6; ++d) {
-        const double* M = &op.fc[4 + 4 * d];
+        const auto* M = &op.fc[4 + 4 * d];
         const double p1 = wave_shift_up(r1, 1 << d), p0 = wave_shift_up(r0, 1 << d);
         r1 += M[0] * p1 + M[1] * p0;
         r0 += M[2] * p1 + M[3] * p0;
@@ -344,9 +362,9 @@ constexpr int TRAP_NCAP = 4;
 // Runs the trap emulation over slot `ss`.  If STORE, writes the filtered waveform into slot `sd` (must differ from ss).
 // cap_idx[c] (uniform, -1 = unused): sample indices whose filtered value is wanted; returned in cap_val[c] (uniform).
 template <typename T, int KIND, bool STORE>
-__device__ void trap_core(Ctx<T>& cx, const DevOp& op, const DevSlot& ss, const DevSlot& sd, const int* cap_idx, T* cap_val) {
+__device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOBAL DevSlot& ss, const DSP_GLOBAL DevSlot& sd, const int* cap_idx, T* cap_val) {
     const int C = ss.C, lane = lane_id();
-    const T* ps = cx.chunk(ss);
+    const auto* ps = cx.chunk(ss);
     const double rr = op.fc[0], ll = op.fc[1];
     const double inv_rr = 1.0 / rr, inv_ll = 1.0 / ll;  // (rise or fall == 0 never gets here: ZeroDivisionError at chain creation)
     int q[3], rho[3];
@@ -395,7 +413,7 @@ __device__ void trap_core(Ctx<T>& cx, const DevOp& op, const DevSlot& ss, const 
     // ---- pass B: replay the reference's rounding sequence from the speculative carry
     // lagged sample i - L_k lives in chunk (lane - q_k - 1) at offset C - rho_k + t, one element further once t >= rho_k
     // (the chunk pad).  Lanes whose lagged chunk index is negative read the zero guard below the slot.
-    const T* lag[3];
+    const typename Ctx<T>::LT* lag[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int jj = lane - q[k] - 1;
@@ -413,7 +431,7 @@ __device__ void trap_core(Ctx<T>& cx, const DevOp& op, const DevSlot& ss, const 
         cap_off[c] = ci >= 0 ? ci - cl * C : -1;
         capv[c] = (T)0;
     }
-    T* pd = STORE ? cx.chunk(sd) : nullptr;
+    typename Ctx<T>::LT* pd = STORE ? cx.chunk(sd) : nullptr;
     T y = g;
     {
         int t = 0;
@@ -425,9 +443,9 @@ __device__ void trap_core(Ctx<T>& cx, const DevOp& op, const DevSlot& ss, const 
 #pragma unroll
             for (int c = 0; c < TRAP_NCAP; ++c)
                 if (cap_off[c] + 1 > t && cap_off[c] + 1 < nb) nb = cap_off[c] + 1;
-            const T* l0 = lag[0] + (t >= rho[0] ? 1 : 0);
-            const T* l1 = lag[1] + (t >= rho[1] ? 1 : 0);
-            const T* l2 = lag[2] + (t >= rho[2] ? 1 : 0);
+            const auto* l0 = lag[0] + (t >= rho[0] ? 1 : 0);
+            const auto* l1 = lag[1] + (t >= rho[1] ? 1 : 0);
+            const auto* l2 = lag[2] + (t >= rho[2] ? 1 : 0);
 #pragma unroll 8
             for (int u = t; u < nb; ++u) {
                 y = trap_step_r<T, KIND>(y, ps[u], l0[u], l1[u], l2[u], rr, ll, inv_rr, inv_ll);
@@ -457,9 +475,9 @@ __device__ void trap_core(Ctx<T>& cx, const DevOp& op, const DevSlot& ss, const 
 }
 
 template <typename T>
-__device__ void op_trap(Ctx<T>& cx, const DevOp& op) {
-    const DevSlot& ss = cx.prog->slots[op.src];
-    const DevSlot& sd = cx.prog->slots[op.dst];
+__device__ void op_trap(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
     // ic[9]: static "output is all NaN" (rise == 0: the reference reads w_out[-1] = NaN, trap_filters.py:65-66)
     if (cx.slot_nan(op.src) || op.ic[9]) {
         cx.set_nan(op.dst, true);
@@ -488,7 +506,7 @@ __device__ void op_trap(Ctx<T>& cx, const DevOp& op) {
 // the window reaches it), and the back substitution runs over the 64 lanes' values (the tail beyond them is dropped the same way).
 // The forward coefficient w2[i] = -0.5 / (0.5 w2[i-1] + 2) is data independent and stationary in float64 from i = 15 on.
 template <typename T>
-__device__ T pickoff_spline(Ctx<T>& cx, const DevSlot& ss, T t_in) {
+__device__ T pickoff_spline(Ctx<T>& cx, const DSP_GLOBAL DevSlot& ss, T t_in) {
     const int n = ss.len, lane = lane_id();
     const int i0 = (int)t_in;  // 0 <= i0 <= n - 2: the caller handles integer t_in
     const double t0 = (double)t_in - (double)i0, t1 = 1.0 - t0;
@@ -524,8 +542,8 @@ __device__ T pickoff_spline(Ctx<T>& cx, const DevSlot& ss, T t_in) {
 }
 
 template <typename T>
-__device__ void op_pickoff(Ctx<T>& cx, const DevOp& op) {
-    const DevSlot& ss = cx.prog->slots[op.src];
+__device__ void op_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const T t_in = cx.scalar(op.sp[0]);
     T out = quiet_nan<T>();
     if (op.ip[0] == 's' && !cx.slot_nan(op.src) && pickoff_in_range(t_in, ss.len) && (T)(int)t_in != t_in) {
@@ -549,8 +567,8 @@ __device__ void op_pickoff(Ctx<T>& cx, const DevOp& op) {
 
 // TRAP_PICKOFF: trap filter whose only consumer is a fixed_time_pickoff -- the filtered waveform never exists.
 template <typename T>
-__device__ void op_trap_pickoff(Ctx<T>& cx, const DevOp& op) {
-    const DevSlot& ss = cx.prog->slots[op.src];
+__device__ void op_trap_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const T t_in = cx.scalar(op.sp[0]);
     T out = quiet_nan<T>();
     if (!cx.slot_nan(op.src) && !op.ic[9] && pickoff_in_range(t_in, ss.len)) {
@@ -579,18 +597,112 @@ __device__ void op_trap_pickoff(Ctx<T>& cx, const DevOp& op) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// windower (processors/windower.py:12-54): w_out[k] = w_in[int(t0) + k], NaN where the window reaches outside the input
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ void op_windower(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+    const T t0 = cx.scalar(op.sp[0]);
+    if (cx.slot_nan(op.src) || t0 != t0) {
+        cx.set_nan(op.dst, true);
+        return;
+    }
+    const int n = ss.len, m = sd.len;
+    // int(t0) truncates toward zero; anything at or beyond the ends gives an all-NaN window either way
+    const int beg = t0 >= (T)n ? n : (t0 <= (T)(-m) ? -m : (int)t0);
+    const bool inside = beg >= 0 && beg + m <= n;
+    for (int e = lane_id(); e < 64 * sd.C; e += 64) {
+        const int si = beg + e;
+        T v = (T)0;
+        if (e < m) v = (si >= 0 && si < n) ? cx.lds[padded_index(ss, si)] : quiet_nan<T>();
+        cx.lds[padded_index(sd, e)] = v;
+    }
+    if (inside)
+        cx.set_nan(op.dst, false);
+    else
+        cx.set_some_nan(op.dst);
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// avg_current (processors/moving_windows.py:206-249): w_out = (w_in[L:] - w_in[:-L]) / length in T; ic[0] = L, fc[0] = length
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ void op_avg_current(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+    if (cx.slot_nan(op.src)) {
+        cx.set_nan(op.dst, true);
+        return;
+    }
+    const int L = op.ic[0], m = sd.len;
+    const T length = (T)op.fc[0];
+    bool nan = false;
+    for (int e = lane_id(); e < 64 * sd.C; e += 64) {
+        T v = (T)0;
+        if (e < m) {
+            v = (T)(cx.lds[padded_index(ss, e + L)] - cx.lds[padded_index(ss, e)]) / length;
+            nan |= (v != v);  // (inf - inf)
+        }
+        cx.lds[padded_index(sd, e)] = v;
+    }
+    if (wave_any(nan))
+        cx.set_some_nan(op.dst);
+    else
+        cx.set_nan(op.dst, false);
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// trap_pickoff (processors/trap_filters.py:230-293): (float64 sum of the `rise` samples ending at the pick-off sample minus the
+// `rise` samples ending rise + flat earlier) / rise.  The reference adds them one by one; here lanes take strided elements and a
+// wavefront scan adds the partial sums (float64 sums of one waveform's float32 samples are exact, so order does not matter).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ void op_trap_window_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    const T tp = cx.scalar(op.sp[0]);
+    const int n = ss.len, rise = op.ip[0], flat = op.ip[1];
+    T out = quiet_nan<T>();
+    if (!cx.slot_nan(op.src) && !(tp != tp)) {
+        if (floor((double)tp) != (double)tp) {
+            cx.fatal(DSP_E_TPO_INT);
+        } else {
+            const double startd = (double)tp + 1.0;
+            if (startd <= (double)n && startd >= (double)(2 * (long long)rise + flat)) {
+                const int start = (int)startd;
+                double s1 = 0.0, s2 = 0.0;
+                for (int k = lane_id(); k < rise; k += 64) {
+                    s1 += (double)cx.lds[padded_index(ss, start - rise + k)];
+                    s2 += (double)cx.lds[padded_index(ss, start - 2 * rise - flat + k)];
+                }
+                s1 = readlane(wave_scan_add(s1), 63);
+                s2 = readlane(wave_scan_add(s2), 63);
+                if (rise == 0)
+                    cx.fatal(DSP_E_ZERODIV);
+                else
+                    out = (T)((s1 - s2) / (double)rise);
+            }
+        }
+    }
+    if (lane_id() == 0) cx.sregs()[op.dst] = out;
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
 // mean_below_threshold (processors/arithmetic.py:9-62): float64 total of the samples below the threshold / their count.
 // The reference adds them one by one; here per-lane partial sums and a wavefront scan.  For float32 samples of one
 // waveform's dynamic range the float64 sums are exact, hence order independent; otherwise the last float64 bit may differ.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_mean_below(Ctx<T>& cx, const DevOp& op) {
-    const DevSlot& ss = cx.prog->slots[op.src];
+__device__ void op_mean_below(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const T thr = cx.scalar(op.sp[0]);
     T out = quiet_nan<T>();
     if (!cx.slot_nan(op.src) && !(thr != thr)) {
         const int n = ss.len, C = ss.C, i0 = lane_id() * C;
-        const T* ps = cx.chunk(ss);
+        const auto* ps = cx.chunk(ss);
         double total = 0.0, count = 0.0;
 #pragma unroll 8
         for (int t = 0; t < C; ++t) {
@@ -612,8 +724,8 @@ __device__ void op_mean_below(Ctx<T>& cx, const DevOp& op) {
 // time_point_thresh  (processors/time_point_thresh.py:12-92): comparisons only -> bit exact
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_time_point_thresh(Ctx<T>& cx, const DevOp& op) {
-    const DevSlot& ss = cx.prog->slots[op.src];
+__device__ void op_time_point_thresh(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const T thr = cx.scalar(op.sp[0]), ts_f = cx.scalar(op.sp[1]), walk_f = cx.scalar(op.sp[2]);
     T out = quiet_nan<T>();
     const int n = ss.len, C = ss.C, lane = lane_id();
@@ -626,7 +738,7 @@ __device__ void op_time_point_thresh(Ctx<T>& cx, const DevOp& op) {
             cx.fatal(DSP_E_TPT_RANGE);
         } else {
             const int ts = (int)ts_f;
-            const T* ps = cx.chunk(ss);
+            const auto* ps = cx.chunk(ss);
             const int i0 = lane * C;
             if ((long long)walk_f == 1) {
                 // smallest i in [ts, n-2] with (w[i] <= thr < w[i+1]) or (w[i] >= thr > w[i+1])
@@ -667,12 +779,12 @@ __device__ void op_time_point_thresh(Ctx<T>& cx, const DevOp& op) {
 // min_max  (processors/min_max.py:11-82): first occurrence of the extremes (strict comparisons)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_min_max(Ctx<T>& cx, const DevOp& op, bool amax_only) {
-    const DevSlot& ss = cx.prog->slots[op.src];
+__device__ void op_min_max(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, bool amax_only) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const int n = ss.len, C = ss.C, lane = lane_id();
     T o_tmin = quiet_nan<T>(), o_tmax = o_tmin, o_amin = o_tmin, o_amax = o_tmin;
     if (!cx.slot_nan(op.src)) {
-        const T* ps = cx.chunk(ss);
+        const auto* ps = cx.chunk(ss);
         const int i0 = lane * C;
         // lanes entirely beyond n start from sample 0 (broadcast) so they never win
         const T first = cx.lds[ss.off];
@@ -713,7 +825,7 @@ __device__ void op_min_max(Ctx<T>& cx, const DevOp& op, bool amax_only) {
         o_tmax = (T)imax;
     }
     if (lane == 0) {
-        T* r = cx.sregs();
+        auto* r = cx.sregs();
         if (amax_only) {
             r[op.dst] = o_amax;
         } else {
@@ -732,10 +844,10 @@ __device__ void op_min_max(Ctx<T>& cx, const DevOp& op, bool amax_only) {
 // Runs in place on the scratch slot ip[2] (a copy of src, or src itself when it is dead afterwards).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_dwt_haar(Ctx<T>& cx, const DevOp& op) {
-    const DevSlot& ss = cx.prog->slots[op.src];
-    const DevSlot& st = cx.prog->slots[op.ip[2]];
-    const DevSlot& sd = cx.prog->slots[op.dst];
+__device__ void op_dwt_haar(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_GLOBAL DevSlot& st = cx.prog->slots[op.ip[2]];
+    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
     if (cx.slot_nan(op.src)) {
         cx.set_nan(op.dst, true);
         return;
@@ -744,9 +856,9 @@ __device__ void op_dwt_haar(Ctx<T>& cx, const DevOp& op) {
     const T c = (T)0.7071067811865476;
     int len = ss.len;
     for (int l = 0; l < level; ++l) {
-        const DevSlot& in = (l == 0) ? ss : st;
+        const DSP_GLOBAL DevSlot& in = (l == 0) ? ss : st;
         const bool last = (l == level - 1);
-        const DevSlot& out = last ? sd : st;
+        const DSP_GLOBAL DevSlot& out = last ? sd : st;
         const int half = (len + 1) >> 1;
         const T f0 = (last && part == 'd') ? -c : c;
         for (int k0 = 0; k0 < half; k0 += 64) {
@@ -770,9 +882,9 @@ __device__ void op_dwt_haar(Ctx<T>& cx, const DevOp& op) {
 
 // dst[k] = src[k + ip[0]]
 template <typename T>
-__device__ void op_copy(Ctx<T>& cx, const DevOp& op) {
-    const DevSlot& ss = cx.prog->slots[op.src];
-    const DevSlot& sd = cx.prog->slots[op.dst];
+__device__ void op_copy(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
     if (cx.slot_nan(op.src)) {
         cx.set_nan(op.dst, true);
         return;
@@ -799,9 +911,9 @@ __device__ __forceinline__ double fma_t(double a, double b, double c) { return _
 
 // AMAX: fused with numpy.amax over the output (DSP_OP_CONVOLVE_AMAX): nothing is stored, sreg[dst] receives the maximum
 template <typename T>
-__device__ void op_convolve(Ctx<T>& cx, const DevOp& op, const bool AMAX) {  // (one body for both: the tap loop is the big part)
-    const DevSlot& ss = cx.prog->slots[op.src];
-    const DevSlot& sd = cx.prog->slots[AMAX ? op.src : op.dst];  // (unused when AMAX)
+__device__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const bool AMAX) {  // (one body for both: the tap loop is the big part)
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[AMAX ? op.src : op.dst];  // (unused when AMAX)
     if (cx.slot_nan(op.src) || op.ic[2]) {
         if (AMAX) {
             if (lane_id() == 0) cx.sregs()[op.dst] = quiet_nan<T>();
@@ -816,10 +928,10 @@ __device__ void op_convolve(Ctx<T>& cx, const DevOp& op, const bool AMAX) {  // 
     constexpr int R = 5;   // consecutive outputs per lane (odd: the lanes' windows start 5 elements apart -> conflict-free reads)
     constexpr int U = 16;  // taps per block of the fast path
     constexpr int W = R + U - 1;
-    const T* __restrict__ kern = (const T*)cx.io_ptr(op.io);
+    const DSP_GLOBAL T* __restrict__ kern = cx.template io_ptr<const T>(op.io);
     const int n = ss.len, m = op.ic[1], start = op.ic[0], p = op.ic[3], lane = lane_id();
     const bool linear = ss.padw == 0;  // the host lays FIR inputs out without chunk pads: a window is R + U - 1 consecutive elements
-    const T* x0 = cx.lds + ss.off;
+    const auto* x0 = cx.lds + ss.off;
     auto in_at = [&](int i) -> T { return (i >= 0 && i < n) ? cx.lds[padded_index(ss, i)] : (T)0; };
     for (int o0 = 0; o0 < p; o0 += 64 * R) {
         const int ob_true = o0 + lane * R;  // first output of this lane
@@ -862,7 +974,7 @@ __device__ void op_convolve(Ctx<T>& cx, const DevOp& op, const bool AMAX) {  // 
             // (taps as scalar loads -- constant address space, SGPR operands -- were measured slower: v_pk_fma_f32 wants its
             // multiplier pair in VGPRs, so every tap was moved back; the 16-byte vector loads below hit one cache line per wave)
             auto load_block = [&](int k0, T (&wb)[W], T (&hb)[U]) {
-                const T* base = x0 + (ob + start - k0 - (U - 1));
+                const auto* base = x0 + (ob + start - k0 - (U - 1));
 #pragma unroll
                 for (int j = 0; j < W; ++j) wb[j] = base[j];
 #pragma unroll
@@ -922,7 +1034,7 @@ __device__ void op_convolve(Ctx<T>& cx, const DevOp& op, const bool AMAX) {  // 
 }
 
 template <typename T>
-__device__ void op_scalar_affine(Ctx<T>& cx, const DevOp& op) {
+__device__ void op_scalar_affine(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const T a = cx.scalar(op.sp[0]), b = cx.scalar(op.sp[1]), c = cx.scalar(op.sp[2]);
     if (lane_id() == 0) cx.sregs()[op.dst] = a * b + c;
     wave_sync();
@@ -936,14 +1048,14 @@ __global__ void __launch_bounds__(256) dsp_vm_kernel(const DevProgram* __restric
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably wave-uniform -> rows, pointers in SGPRs
     const int wpb = (int)(blockDim.x >> 6);
-    T* lds = reinterpret_cast<T*>(smem_raw) + (size_t)wave * prog->lds_elems_per_wave;
+    auto* lds = (typename Ctx<T>::LT*)smem_raw + (size_t)wave * prog->lds_elems_per_wave;  // (C cast: generic -> LDS address space)
     // zero the whole region once: guards below each slot must read as 0 forever, pads start finite
     for (int e = lane_id(); e < prog->lds_elems_per_wave; e += 64) lds[e] = (T)0;
     wave_sync();
 
     Ctx<T> cx;
     cx.lds = lds;
-    cx.prog = prog;
+    cx.prog = (const DSP_GLOBAL DevProgram*)prog;
     // kernel arguments: (const DevProgram*, IoPtrs, int64_t, int*) -> the pointer table starts 8 bytes into the segment
     static_assert(sizeof(const DevProgram*) == 8 && alignof(IoPtrs) == 8, "kernel-argument layout");
     cx.kptrs = (const __attribute__((address_space(4))) uint64_t*)__builtin_amdgcn_kernarg_segment_ptr() + 1;
@@ -955,7 +1067,7 @@ __global__ void __launch_bounds__(256) dsp_vm_kernel(const DevProgram* __restric
         cx.row = row;
         cx.nan_mask = 0;
         for (int i = 0; i < n_ops; ++i) {
-            const DevOp& op = prog->ops[i];
+            const DSP_GLOBAL DevOp& op = cx.prog->ops[i];
             switch (op.opcode) {
                 case DSP_OP_LOAD: op_load(cx, op); break;
                 case DSP_OP_STORE: op_store(cx, op); break;
@@ -972,6 +1084,9 @@ __global__ void __launch_bounds__(256) dsp_vm_kernel(const DevProgram* __restric
                 case DSP_OP_MIN_MAX: op_min_max(cx, op, false); break;
                 case DSP_OP_AMAX: op_min_max(cx, op, true); break;
                 case DSP_OP_MEAN_BELOW: op_mean_below(cx, op); break;
+                case DSP_OP_WINDOWER: op_windower(cx, op); break;
+                case DSP_OP_AVG_CURRENT: op_avg_current(cx, op); break;
+                case DSP_OP_TRAP_WINDOW_PICKOFF: op_trap_window_pickoff(cx, op); break;
                 case DSP_OP_DWT_HAAR: op_dwt_haar(cx, op); break;
                 case DSP_OP_COPY: op_copy(cx, op); break;
                 case DSP_OP_CONVOLVE:

@@ -84,7 +84,8 @@ __device__ __forceinline__ bool wave_any(bool p) { return __any(p) != 0; }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // LDS element index of sample e of a slot (e / C via a float reciprocal: exact for e < 2^20, C % 8 == 0)
-__device__ __forceinline__ int padded_index(const DevSlot& s, int e) {
+template <typename SlotRef>  // (DevSlot in any address space)
+__device__ __forceinline__ int padded_index(const SlotRef& s, int e) {
     int q = (int)(((float)e + 0.5f) * s.invC);
     return s.off + e + q * s.padw;
 }

@@ -86,7 +86,7 @@ _SIGS = {
     "bl_subtract": "wsW", "pole_zero": "wsW", "double_pole_zero": "wsssW", "trap_filter": "wiiW", "trap_norm": "wiiW",
     "asym_trap_filter": "wiiiW", "fixed_time_pickoff": "wscS", "time_point_thresh": "wsssS", "min_max": "wSSSS",
     "discrete_wavelet_transform": "wiccW", "convolve_wf": "wtcW", "fft_convolve_wf": "wtcW", "amax": "wiS",
-    "mean_below_threshold": "wsS",
+    "mean_below_threshold": "wsS", "windower": "wsW", "avg_current": "wsW", "trap_pickoff": "wiisS",
 }
 _GENERATORS = ("cusp_filter", "zac_filter")
 _MODULES = ("dspeed.processors", "dspeed_amd.processors", "numpy", "np")
@@ -663,7 +663,7 @@ def _add_step(b: _Builder, key, node, new_vars, proc_strings):
         if r == "W" and isinstance(a, Var):
             if a.kind is None:
                 a.kind = "wf"
-            if a.length is None and function not in ("discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf"):
+            if a.length is None and function not in ("discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "windower", "avg_current"):
                 a.length = src_len
             if a.period is None:
                 a.period = src_period
@@ -960,6 +960,21 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
                     raise ProcessingChainError("min_max outputs must be variable names")
                 a.kind, a.sreg = "scalar", first + k
             p.add_op(_lib.OP_MIN_MAX, dst=first, src=src.slot)
+            release(src, si)
+        elif fn in ("windower", "avg_current"):
+            src = ensure_loaded(args[0], si)
+            dst = out_wf(args[2], None, src)
+            if dst.length is None:
+                raise ProcessingChainError(f"{fn}: declare the output as name(length, 'f')")
+            dst.slot = new_slot(dst.length)
+            p.add_op(_lib.OP_WINDOWER if fn == "windower" else _lib.OP_AVG_CURRENT, dst=dst.slot, src=src.slot,
+                     sp=(scalar_operand(args[1], args, what=what),))
+            release(src, si)
+        elif fn == "trap_pickoff":
+            src = ensure_loaded(args[0], si)
+            ints = [scalar_operand(a, args, integer=True, what=what) for a in args[1:3]]
+            o = out_scalar(args[4])
+            p.add_op(_lib.OP_TRAP_WINDOW_PICKOFF, dst=o.sreg, src=src.slot, ip=tuple(ints), sp=(scalar_operand(args[3], args, what=what),))
             release(src, si)
         elif fn == "mean_below_threshold":
             src = ensure_loaded(args[0], si)

@@ -205,6 +205,60 @@ def _dwt(g, *args):
         st.release()
 
 
+def _windower(g, *args):
+    if len(args) != 3:
+        raise TypeError("windower(w_in, t0_in, w_out): w_out must be passed (its length is the window size)")
+    w_in, t0_in, w_out = args
+    st = Staging()
+    try:
+        ptr, code, n_wf, n, stride, one_d = st.wf_in(w_in)
+        sfx = loop_suffix(_dtype_of(w_in))
+        ft = _F[sfx]
+        tp, tv = st.scalar_in(t0_in, n_wf, ft)
+        m = w_out.shape[-1]
+        optr, res = st.out(w_out, (m,) if one_d else (n_wf, m), ft)
+        run(entry("windower", sfx), g.__name__, ptr, code, n_wf, n, stride, tp, tv, optr, m, m)
+        st.finish()
+        return res
+    finally:
+        st.release()
+
+
+def _avg_current(g, *args):
+    if len(args) != 3:
+        raise TypeError("avg_current(w_in, length, w_out): w_out must be passed (len(w_in) - int(length) samples)")
+    w_in, length, w_out = args
+    st = Staging()
+    try:
+        ptr, code, n_wf, n, stride, one_d = st.wf_in(w_in)
+        sfx = loop_suffix(_dtype_of(w_in))
+        ft = _F[sfx]
+        m = w_out.shape[-1]
+        optr, res = st.out(w_out, (m,) if one_d else (n_wf, m), ft)
+        run(entry("avg_current", sfx), g.__name__, ptr, code, n_wf, n, stride, float(np.asarray(length).reshape(-1)[0]), optr, m, m)
+        st.finish()
+        return res
+    finally:
+        st.release()
+
+
+def _trap_pickoff(g, *args):
+    ins, outs = _split(g, args)
+    st = Staging()
+    try:
+        ptr, code, n_wf, n, stride, one_d = st.wf_in(ins[0])
+        sfx = loop_suffix(_dtype_of(ins[0]))
+        ft = _F[sfx]
+        tp, tv = st.scalar_in(ins[3], n_wf, ft)
+        optr, res = st.out(outs[0], () if one_d else (n_wf,), ft)
+        run(entry("trap_pickoff", sfx), g.__name__, ptr, code, n_wf, n, stride, _as_int(ins[1], g.__name__), _as_int(ins[2], g.__name__),
+            tp, tv, optr)
+        st.finish()
+        return res[()] if isinstance(res, np.ndarray) and res.ndim == 0 else res
+    finally:
+        st.release()
+
+
 def _convolve(g, *args):
     if len(args) != 4:
         raise TypeError(f"{g.__name__}(w_in, kernel, mode_in, w_out): w_out must be passed (its length selects the output size)")
@@ -299,10 +353,16 @@ def _zac_filter(g, sigma, flat, decay, kernel):
     return kernel
 
 
+windower = HipGUFunc("windower", "(n),(),(m)", ["fff", "ddd"], _windower,
+                     "window of len(w_out) samples starting at int(t0_in), NaN outside the input (reference processors/windower.py:12-54)")
+avg_current = HipGUFunc("avg_current", "(n),(),(m)", ["fff", "ddd"], _avg_current,
+                        "(w_in[L:] - w_in[:-L]) / length (reference processors/moving_windows.py:206-249)")
+trap_pickoff = HipGUFunc("trap_pickoff", "(n),(),(),()->()", ["fiif->f", "diid->d"], _trap_pickoff,
+                         "normalised difference of two rise-long window sums at an integer pick-off sample (reference processors/trap_filters.py:230-293)")
 cusp_filter = HipGUFunc("cusp_filter", "(),(),(),(n)", ["ffff", "dddd"], _cusp_filter,
                         "CUSP kernel generator, evaluated once on the host at chain build (reference processors/energy_kernels.py:12-73)")
 zac_filter = HipGUFunc("zac_filter", "(),(),(),(n)", ["ffff", "dddd"], _zac_filter,
                        "zero-area CUSP kernel generator, host, once (reference processors/energy_kernels.py:76-157)")
 
 __all__ = ["bl_subtract", "pole_zero", "double_pole_zero", "trap_filter", "trap_norm", "asym_trap_filter", "fixed_time_pickoff",
-           "time_point_thresh", "min_max", "mean_below_threshold", "discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "cusp_filter", "zac_filter"]
+           "time_point_thresh", "min_max", "mean_below_threshold", "windower", "avg_current", "trap_pickoff", "discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "cusp_filter", "zac_filter"]

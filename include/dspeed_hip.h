@@ -57,6 +57,9 @@ extern "C" {
 #define DSP_E_DWT_LEVEL 15     /* dwt.py:67-68 */
 #define DSP_E_DWT_OUTLEN 16    /* shape mismatch in dwt.py:81 */
 #define DSP_E_ZERODIV 17       /* numba error_model='python': division by a zero rise/fall */
+#define DSP_E_WINDOW_LONG 18   /* windower.py:36-37 */
+#define DSP_E_AVGCUR_RANGE 19  /* moving_windows.py:243-246 */
+#define DSP_E_TPO_INT 20       /* trap_filters.py:270-271       data dependent */
 
 /* ---- element types -------------------------------------------------------------------------- */
 #define DSP_F32 0
@@ -156,6 +159,10 @@ typedef struct dsp_scalar_arg {
 #define DSP_OP_CONVOLVE_AMAX 20  /* fusion of CONVOLVE with numpy.amax over its output (icpc-dsp-config.json:160-239 cuspEmax / zacEmax): the
                                   * filtered waveform is never stored.  sreg[dst] <- max_o (src (*) io taps)[o]; ip[0] = mode, ip[1] = taps
                                   * hold a NaN, ip[2] = output length the recipe declared */
+#define DSP_OP_WINDOWER 21      /* windower.py:12-54         dst[k] <- src[int(sp[0]) + k], NaN where that falls outside src */
+#define DSP_OP_AVG_CURRENT 22   /* moving_windows.py:206-249 dst[k] <- (src[k + L] - src[k]) / sp[0], L = int(sp[0]) (constant) */
+#define DSP_OP_TRAP_WINDOW_PICKOFF 23 /* trap_filters.py:230-293 trap_pickoff: sreg[dst] <- (sum of the rise samples ending at sp[0]
+                                  * minus the rise samples ending rise+flat earlier) / rise; ip[0..1] = rise, flat */
 #define DSP_OP_SCALAR_AFFINE 18 /* sreg[dst] <- sp[0] * sp[1] + sp[2]  (host-folded expressions such as tp_0 + 10*us) */
 
 typedef struct dsp_op {
@@ -218,6 +225,12 @@ int dsp_fixed_time_pickoff_f32(const void* in, int in_dtype, int64_t n_wf, int32
 int dsp_time_point_thresh_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
                               const float* threshold_dev, float threshold, const float* t_start_dev, float t_start,
                               float walk_forward, float* out, void* stream, int64_t* err_row);
+int dsp_windower_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* t0_dev, float t0,
+                     float* out, int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_avg_current_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float length, float* out,
+                        int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_trap_pickoff_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,
+                         const float* t_pickoff_dev, float t_pickoff, float* out, void* stream, int64_t* err_row);
 int dsp_mean_below_threshold_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* threshold_dev,
                                  float threshold, float* out, void* stream, int64_t* err_row);
 int dsp_min_max_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float* t_min, float* t_max,
@@ -246,6 +259,12 @@ int dsp_fixed_time_pickoff_f64(const void* in, int in_dtype, int64_t n_wf, int32
 int dsp_time_point_thresh_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
                               const double* threshold_dev, double threshold, const double* t_start_dev, double t_start,
                               double walk_forward, double* out, void* stream, int64_t* err_row);
+int dsp_windower_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const double* t0_dev, double t0,
+                     double* out, int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_avg_current_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, double length, double* out,
+                        int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_trap_pickoff_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,
+                         const double* t_pickoff_dev, double t_pickoff, double* out, void* stream, int64_t* err_row);
 int dsp_mean_below_threshold_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
                                  const double* threshold_dev, double threshold, double* out, void* stream, int64_t* err_row);
 int dsp_min_max_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, double* t_min, double* t_max,

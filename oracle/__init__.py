@@ -153,6 +153,32 @@ def min_max(w):
     return (*o, rc)
 
 
+def windower(w, t0, out_len):
+    w = _rows(w)
+    t, st = _vec(t0, w.shape[0], w.dtype)
+    out = np.empty((w.shape[0], int(out_len)), dtype=w.dtype)
+    rc = _call("windower", w.dtype, _p(w), C.c_long(w.shape[0]), C.c_int(w.shape[1]), _p(t), C.c_int(st), _p(out), C.c_int(int(out_len)))
+    return out, rc
+
+
+def avg_current(w, length, out_len=None):
+    w = _rows(w)
+    _, ct = _sfx(w.dtype)
+    m = w.shape[1] - int(length) if out_len is None else int(out_len)
+    out = np.empty((w.shape[0], max(m, 0)), dtype=w.dtype)
+    rc = _call("avg_current", w.dtype, _p(w), C.c_long(w.shape[0]), C.c_int(w.shape[1]), ct(float(length)), _p(out), C.c_int(m))
+    return out, rc
+
+
+def trap_pickoff(w, rise, flat, t_pickoff):
+    w = _rows(w)
+    t, st = _vec(t_pickoff, w.shape[0], w.dtype)
+    out = np.empty(w.shape[0], dtype=w.dtype)
+    rc = _call("trap_pickoff", w.dtype, _p(w), C.c_long(w.shape[0]), C.c_int(w.shape[1]), C.c_int(int(rise)), C.c_int(int(flat)), _p(t),
+               C.c_int(st), _p(out))
+    return out, rc
+
+
 def mean_below_threshold(w, threshold):
     w = _rows(w)
     thr, st = _vec(threshold, w.shape[0], w.dtype)

@@ -37,7 +37,10 @@ enum {
     ORC_E_CONV_MODE = 14,    /* convolutions.py:69-70 */
     ORC_E_DWT_LEVEL = 15,    /* dwt.py:67-68 */
     ORC_E_DWT_OUTLEN = 16,   /* numpy broadcast error in dwt.py:81 */
-    ORC_E_ZERODIV = 17       /* numba error_model='python': x / 0 raises ZeroDivisionError */
+    ORC_E_ZERODIV = 17,      /* numba error_model='python': x / 0 raises ZeroDivisionError */
+    ORC_E_WINDOW_LONG = 18,  /* windower.py:36-37 */
+    ORC_E_AVGCUR_RANGE = 19, /* moving_windows.py:243-246 */
+    ORC_E_TPO_INT = 20       /* trap_filters.py:270-271 */
 };
 
 #define ORC_DECL(T, S)                                                                                                         \
@@ -52,6 +55,10 @@ enum {
     int orc_time_point_thresh_##S(const T* in, long n_wf, int len, const T* thr, int thr_stride, const T* t_start,            \
                                   int t_start_stride, T walk_forward, T* out, long* err_row);                                 \
     int orc_min_max_##S(const T* in, long n_wf, int len, T* t_min, T* t_max, T* a_min, T* a_max, long* err_row);              \
+    int orc_windower_##S(const T* in, long n_wf, int len, const T* t0, int t0_stride, T* out, int m, long* err_row);          \
+    int orc_avg_current_##S(const T* in, long n_wf, int len, T length, T* out, int m, long* err_row);                         \
+    int orc_trap_pickoff_##S(const T* in, long n_wf, int len, int rise, int flat, const T* tp, int tp_stride, T* out,         \
+                             long* err_row);                                                                                  \
     int orc_mean_below_threshold_##S(const T* in, long n_wf, int len, const T* thr, int thr_stride, T* out, long* err_row);   \
     int orc_convolve_##S(const T* in, long n_wf, int len, long in_row_stride, const T* kern, int m, int mode, T* out, int p,  \
                          long* err_row);                                                                                      \

@@ -253,6 +253,55 @@ static int FN(row_min_max)(const T* w_in, int n, T* t_min, T* t_max, T* a_min, T
     return 0;
 }
 
+/* windower.py:12-54: a window of len(w_out) samples starting at int(t0_in) (truncation toward zero); what falls outside the input is NaN */
+static int FN(row_windower)(const T* w_in, int n, T t0_in, T* w_out, int m) {
+    FN(fill_nan)(w_out, m);
+    if (FN(row_has_nan)(w_in, n) || isnan(t0_in)) return 0;
+    if (m >= n) return ORC_E_WINDOW_LONG;
+    long beg = (long)t0_in;
+    if (beg > n) beg = n;
+    long end = beg + m;
+    if (end < 0) end = 0;
+    if (beg < 0) {
+        for (long k = 0; k < end; ++k) w_out[m - end + k] = w_in[k];
+    } else if (end < n) {
+        for (long k = 0; k < m; ++k) w_out[k] = w_in[beg + k];
+    } else {
+        for (long k = 0; k < n - beg; ++k) w_out[k] = w_in[beg + k];
+    }
+    return 0;
+}
+
+/* moving_windows.py:206-249 avg_current: w_out = (w_in[L:] - w_in[:-L]) / length, all in T (array / T scalar) */
+static int FN(row_avg_current)(const T* w_in, int n, T length, T* w_out, int m) {
+    FN(fill_nan)(w_out, m);
+    if (FN(row_has_nan)(w_in, n)) return 0;
+    if (!(length >= 0) || !(length < (T)n)) return ORC_E_AVGCUR_RANGE;
+    const int L = (int)length;
+    if (L <= 0 || m != n - L) return ORC_E_AVGCUR_RANGE; /* L == 0: NumPy cannot broadcast w_in[0:] - w_in[:-0] */
+    for (int k = 0; k < m; ++k) w_out[k] = (T)(w_in[k + L] - w_in[k]) / length;
+    return 0;
+}
+
+/* trap_filters.py:230-293 trap_pickoff: float64 sums of the two rise-long windows ending at / rise+flat before the pick-off sample,
+ * (i_1 - i_2) / rise (float64 / int32 -> float64), rounded by the store */
+static int FN(row_trap_pickoff)(const T* w_in, int n, int rise, int flat, T t_pickoff, T* a_out) {
+    *a_out = (T)NAN;
+    if (FN(row_has_nan)(w_in, n) || isnan(t_pickoff)) return 0;
+    if (floor((double)t_pickoff) != (double)t_pickoff) return ORC_E_TPO_INT;
+    if (rise < 0) return ORC_E_TRAP_RISE;
+    if (flat < 0) return ORC_E_TRAP_FLAT;
+    if (2 * (long)rise + flat > n) return ORC_E_TRAP_WIDE;
+    const long start = (long)((double)t_pickoff + 1.0);
+    if (!(n >= start && start >= 2 * (long)rise + flat)) return 0;
+    double i1 = 0.0, i2 = 0.0;
+    for (long i = start - rise; i < start; ++i) i1 += (double)w_in[i];
+    for (long i = start - 2 * (long)rise - flat; i < start - rise - flat; ++i) i2 += (double)w_in[i];
+    if (rise == 0) return ORC_E_ZERODIV;
+    *a_out = (T)((i1 - i2) / (double)rise);
+    return 0;
+}
+
 /* arithmetic.py:9-62 mean_below_threshold: `total = 0.0` is float64 and stays float64 (float64 += T), `count` int64,
  * result = total / count (float64 / int64 -> float64) rounded by the store; NaN if nothing is below the threshold. */
 static int FN(row_mean_below_threshold)(const T* w_in, int n, T threshold, T* result) {
@@ -381,6 +430,15 @@ int FN(orc_time_point_thresh)(const T* in, long n_wf, int len, const T* thr, int
 }
 int FN(orc_min_max)(const T* in, long n_wf, int len, T* t_min, T* t_max, T* a_min, T* a_max, long* err_row) {
     ROWLOOP(FN(row_min_max)(in + r * len, len, t_min + r, t_max + r, a_min + r, a_max + r))
+}
+int FN(orc_windower)(const T* in, long n_wf, int len, const T* t0, int t0_stride, T* out, int m, long* err_row) {
+    ROWLOOP(FN(row_windower)(in + r * len, len, PV(t0, r), out + r * (long)m, m))
+}
+int FN(orc_avg_current)(const T* in, long n_wf, int len, T length, T* out, int m, long* err_row) {
+    ROWLOOP(FN(row_avg_current)(in + r * len, len, length, out + r * (long)m, m))
+}
+int FN(orc_trap_pickoff)(const T* in, long n_wf, int len, int rise, int flat, const T* tp, int tp_stride, T* out, long* err_row) {
+    ROWLOOP(FN(row_trap_pickoff)(in + r * len, len, rise, flat, PV(tp, r), out + r))
 }
 int FN(orc_mean_below_threshold)(const T* in, long n_wf, int len, const T* thr, int thr_stride, T* out, long* err_row) {
     ROWLOOP(FN(row_mean_below_threshold)(in + r * len, len, PV(thr, r), out + r))

@@ -27,6 +27,7 @@ feed each body:
 Usage:  python oracle/gen_golden.py            (writes tests/golden/*.npz)
         /opt/conda/bin/python3.9 oracle/gen_golden.py --dwt   (PyWavelets 1.1.1 lives there)
         python oracle/gen_golden.py --arithmetic   (only tests/golden/arithmetic.npz)
+        python oracle/gen_golden.py --windows      (only tests/golden/windows.npz)
 """
 from __future__ import annotations
 
@@ -447,6 +448,42 @@ def gen_tpt(rng):
     b.save()
 
 
+def gen_windows():
+    """windower, avg_current, trap_pickoff (SURVEY 8f #2); own seed, own book"""
+    rng = np.random.default_rng(0x51DE)
+    b = Book("windows")
+    mw, mv, mt = _ref("windower"), _ref("moving_windows"), _ref("trap_filters")
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        w = synth_waveforms(rng, 1, 1000, dtype=dt)[0][0]
+        wn = w.copy()
+        wn[500] = np.nan
+        k = 0
+        for src, t0, m in [(w, 0, 100), (w, 250, 300), (w, 250.9, 300), (w, 900, 300), (w, 999, 10), (w, 1000, 10), (w, 5000, 10), (w, -1, 50),
+                           (w, -49, 50), (w, -50, 50), (w, -500.5, 50), (w, -0.5, 999), (w, np.nan, 50), (wn, 10, 50), (w, 0, 1000), (w, 0, 1200)]:
+            out = np.empty(m, dtype=dt)
+            fatal = run_body(mw.windower, src, dt(t0), out)
+            b.add(f"{tag}_win{k}", "windower", tag, {"w_in": src, "w_out": out}, {"t0_in": float(dt(t0))}, fatal)
+            k += 1
+        k = 0
+        for src, length in [(w, 1), (w, 2), (w, 7), (w, 500), (w, 999), (wn, 3), (w, 1000), (w, -1), (w, 2.0)]:
+            L = int(length)
+            m = max(len(src) - L, 1) if 0 < L < len(src) else 10
+            out = np.empty(m, dtype=dt)
+            fatal = run_body(mv.avg_current, src, dt(length), out)
+            b.add(f"{tag}_cur{k}", "avg_current", tag, {"w_in": src, "w_out": out}, {"length": float(dt(length))}, fatal)
+            k += 1
+        k = 0
+        # numba: i_1 / i_2 start as 0.0 (float64) and add T samples -> float64 sums; feed float64 copies for the float32 loop
+        for src, rise, flat, tpo in [(w, 10, 5, 600), (w, 100, 0, 999), (w, 100, 30, 229), (w, 100, 30, 228), (w, 1, 0, 1), (w, 1, 0, 0),
+                                    (w, 400, 200, 999), (w, 400, 201, 999), (w, -1, 5, 600), (w, 5, -1, 600), (w, 10, 5, 600.5), (wn, 10, 5, 600),
+                                    (w, 10, 5, np.nan), (w, 10, 5, 1000), (w, 10, 5, 5000), (w, 10, 5, -3)]:
+            out = np.empty(1, dtype=dt)
+            fatal = run_body(mt.trap_pickoff, src.astype(np.float64), np.int32(rise), np.int32(flat), np.float64(dt(tpo)), out)
+            b.add(f"{tag}_tpo{k}", "trap_pickoff", tag, {"w_in": src, "a_out": out[0]}, {"rise": rise, "flat": flat, "t_pickoff": float(dt(tpo))}, fatal)
+            k += 1
+    b.save()
+
+
 def gen_arithmetic():
     """own seed: added after the other books, which must not change"""
     rng = np.random.default_rng(0xA717)
@@ -596,6 +633,9 @@ def main():
     if "--arithmetic" in sys.argv:
         gen_arithmetic()
         return
+    if "--windows" in sys.argv:
+        gen_windows()
+        return
     rng = np.random.default_rng(0xD5BEED)
     gen_elementwise(rng)
     gen_pole_zero(rng)
@@ -605,6 +645,7 @@ def main():
     gen_fir(rng)
     gen_chains(rng)
     gen_arithmetic()
+    gen_windows()
 
 
 if __name__ == "__main__":

@@ -125,6 +125,49 @@ def test_fixed_time_pickoff_spline_windowed_equals_full_sweep(P):
         _eq(got, want, f"spline len={wf_len}")
 
 
+@pytest.mark.parametrize("c", cases("windows"), ids=lambda c: c.name)
+def test_windows_golden(c, P, DSPFatal):
+    """windower, avg_current, trap_pickoff against the fixtures made from the reference bodies"""
+    p = c.params
+    if c.kernel == "windower":
+        out = _expect(c, DSPFatal, lambda: P.windower(c["w_in"], p["t0_in"], np.empty_like(c["w_out"])))
+        want = c["w_out"]
+    elif c.kernel == "avg_current":
+        if c.fatal or not (0 < int(p["length"]) < c["w_in"].shape[-1]):
+            with pytest.raises((DSPFatal, ValueError)):
+                P.avg_current(c["w_in"], p["length"], np.empty_like(c["w_out"]))
+            return
+        out = P.avg_current(c["w_in"], p["length"], np.empty_like(c["w_out"]))
+        want = c["w_out"]
+    else:
+        out = _expect(c, DSPFatal, lambda: P.trap_pickoff(c["w_in"], p["rise"], p["flat"], p["t_pickoff"]))
+        want = c["a_out"]
+    if out is not None:
+        if c.kernel == "trap_pickoff" and c.tag == "f64":  # float64 partial sums in another order; the result is a difference of sums
+            assert np.isclose(out, want, rtol=0, atol=1e-12 * np.nanmax(np.abs(c["w_in"])), equal_nan=True), c.name
+        else:
+            _eq(out, want, c.name)
+
+
+def test_windows_vs_oracle_per_event(P):
+    """per-event window starts and pick-off samples over many rows, both loops"""
+    rng = np.random.default_rng(12)
+    for dt in (np.float32, np.float64):
+        x = (10000 + 300 * rng.standard_normal((300, 2000))).astype(dt)
+        x[7, 33] = np.nan
+        t0 = rng.uniform(-700, 2300, 300).astype(dt)
+        t0[::9] = np.floor(t0[::9])
+        t0[5] = np.nan
+        _eq(P.windower(x, t0, np.empty((300, 600), dtype=dt)), oracle.windower(x, t0, 600)[0], "windower")
+        _eq(P.avg_current(x, 3, np.empty((300, 1997), dtype=dt)), oracle.avg_current(x, 3)[0], "avg_current")
+        tp = np.floor(rng.uniform(-5, 2100, 300)).astype(dt)
+        got, want = P.trap_pickoff(x, 40, 12, tp), oracle.trap_pickoff(x, 40, 12, tp)[0]
+        if dt == np.float32:
+            _eq(got, want, "trap_pickoff")
+        else:
+            assert np.allclose(got, want, rtol=0, atol=1e-12 * np.nanmax(np.abs(x)), equal_nan=True)
+
+
 @pytest.mark.parametrize("c", cases("arithmetic"), ids=lambda c: c.name)
 def test_mean_below_threshold_golden(c, P, DSPFatal):
     out = _expect(c, DSPFatal, lambda: P.mean_below_threshold(c["w_in"], c.params["threshold"]))

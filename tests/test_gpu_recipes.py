@@ -174,6 +174,37 @@ def test_energy_recipe_variants_take_the_specialised_kernel():
         assert np.max(np.abs(got - want) / peak(tr)) <= TOL, name
 
 
+def test_current_branch_recipe_pieces():
+    """windower -> avg_current -> min_max (the first steps of the A/E branch, icpc-dsp-config.json:294-346) and trap_pickoff in one
+    recipe; a window that reaches past the input makes NaN samples there, and every consumer of it NaN, as in the reference"""
+    rng = np.random.default_rng(31)
+    x, bl, t0 = _synth(rng, 90, 4096)
+    wf = x.astype(np.float32)
+    start = (t0 - 1000).astype(np.float32)
+    start[3] = 4000.0  # window runs off the end
+    M = "dspeed.processors"
+    rec = {"outputs": ["wf_win", "a_max", "t_amax", "ct"], "processors": {
+        "wf_pz": f"{M}.pole_zero(waveform, 1716.28, wf_pz)",
+        "wf_win": f"{M}.windower(wf_pz, w_start, wf_win(2000, 'f'))",
+        "curr": f"{M}.avg_current(wf_win, 5, curr(1995, 'f'))",
+        "t_amin, t_amax, a_min, a_max": {"function": "min_max", "module": M, "args": ["curr", "t_amin", "t_amax", "a_min", "a_max"]},
+        "ct": f"{M}.trap_pickoff(wf_pz, 94, 0, t_ct, ct)"}}
+    tct = np.floor(t0 + 200).astype(np.float32)
+    _, out = _run(rec, {"waveform": wf, "w_start": start, "t_ct": tct})
+    pz = oracle.pole_zero(wf, 1716.28)[0]
+    win = oracle.windower(pz, start, 2000)[0]
+    assert np.array_equal(np.isnan(out["wf_win"]), np.isnan(win)) and np.isnan(win[3]).any() and not np.isnan(win[3]).all()
+    assert_rel_to_peak(np.nan_to_num(out["wf_win"]), np.nan_to_num(win), TOL, "wf_win")
+    cur = oracle.avg_current(np.nan_to_num(win), 5)[0]
+    tmin, tmax, amin, amax, _ = oracle.min_max(cur)
+    ok = np.ones(90, dtype=bool)
+    ok[3] = False
+    assert np.isnan(out["a_max"][3]) and np.isnan(out["t_amax"][3])
+    assert np.max(np.abs(out["a_max"][ok] - amax[ok]) / np.abs(amax[ok])) <= 1e-5
+    ct = oracle.trap_pickoff(pz, 94, 0, tct)[0]
+    assert np.max(np.abs(out["ct"] - ct) / np.max(np.abs(pz), axis=1)) <= TOL
+
+
 def test_host_buffers_stream_through_in_overlapped_pieces():
     """Host-resident columns are processed in pieces (H2D of piece k+1 overlaps kernel and D2H of piece k): same results as one
     piece, a waveform-valued output included, an output column of another dtype converted, a data-dependent DSPFatal reported

@@ -204,6 +204,22 @@ def test_golden_min_max(c):
     _eq(np.array([x[0] for x in o]), c["out"], c.name)
 
 
+@pytest.mark.parametrize("c", cases("windows"), ids=lambda c: c.name)
+def test_golden_windows(c):
+    p = c.params
+    if c.kernel == "windower":
+        out, rc = oracle.windower(c["w_in"], p["t0_in"], c["w_out"].shape[-1])
+        want = c["w_out"]
+    elif c.kernel == "avg_current":
+        out, rc = oracle.avg_current(c["w_in"], p["length"], c["w_out"].shape[-1])
+        want = c["w_out"]
+    else:
+        out, rc = oracle.trap_pickoff(c["w_in"], p["rise"], p["flat"], p["t_pickoff"])
+        want = c["a_out"]
+    _check_fatal(c, rc)
+    _eq(out[0], want, c.name)
+
+
 @pytest.mark.parametrize("c", cases("arithmetic"), ids=lambda c: c.name)
 def test_golden_mean_below_threshold(c):
     out, rc = oracle.mean_below_threshold(c["w_in"], c.params["threshold"])
