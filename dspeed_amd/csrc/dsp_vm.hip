@@ -139,7 +139,7 @@ __device__ bool load_slot(Ctx<T>& cx, const DSP_GLOBAL DevSlot& s, const DSP_GLO
 }
 
 template <typename T>
-__device__ void op_load(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_load(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& s = cx.prog->slots[op.dst];
     const DSP_GLOBAL DevIO& io = cx.prog->io[op.io];
     const int64_t at = cx.row * io.row_stride + io.offset;
@@ -158,7 +158,7 @@ __device__ void op_load(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
 }
 
 template <typename T>
-__device__ void op_store(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_store(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& s = cx.prog->slots[op.src];
     const DSP_GLOBAL DevIO& io = cx.prog->io[op.io];
     DSP_GLOBAL T* g = cx.template io_ptr<T>(op.io) + cx.row * io.row_stride + io.offset;
@@ -184,7 +184,7 @@ __device__ void op_store(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
 }
 
 template <typename T>
-__device__ void op_store_scalar(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_store_scalar(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevIO& io = cx.prog->io[op.io];
     if (lane_id() == 0) cx.template io_ptr<T>(op.io)[cx.row * io.row_stride + io.offset] = cx.sregs()[op.ip[0]];
 }
@@ -193,7 +193,7 @@ __device__ void op_store_scalar(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
 // bl_subtract  (processors/bl_subtract.py:11-46):  w_out = w_in - a_baseline, both T
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_bl_subtract(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_bl_subtract(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
     const T b = cx.scalar(op.sp[0]);
@@ -222,7 +222,7 @@ __device__ void op_bl_subtract(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
 // recurrence runs with the reference's operation order.  fc[0] = c, ic[0] = tau is NaN.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_pole_zero(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_pole_zero(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
     if (cx.slot_nan(op.src) || op.ic[0]) {
@@ -269,7 +269,7 @@ __device__ void op_pole_zero(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
 // fc: 0 n1, 1 n2, 2 d1, 3 d2, 4.. six 2x2 matrices M^{C}, M^{2C}, ... M^{32C} (row major); ic[0] = parameter NaN.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_double_pole_zero(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_double_pole_zero(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
     if (cx.slot_nan(op.src) || op.ic[0]) {
@@ -475,7 +475,7 @@ __device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOB
 }
 
 template <typename T>
-__device__ void op_trap(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_trap(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
     // ic[9]: static "output is all NaN" (rise == 0: the reference reads w_out[-1] = NaN, trap_filters.py:65-66)
@@ -542,7 +542,7 @@ __device__ T pickoff_spline(Ctx<T>& cx, const DSP_GLOBAL DevSlot& ss, T t_in) {
 }
 
 template <typename T>
-__device__ void op_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const T t_in = cx.scalar(op.sp[0]);
     T out = quiet_nan<T>();
@@ -567,7 +567,7 @@ __device__ void op_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
 
 // TRAP_PICKOFF: trap filter whose only consumer is a fixed_time_pickoff -- the filtered waveform never exists.
 template <typename T>
-__device__ void op_trap_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_trap_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const T t_in = cx.scalar(op.sp[0]);
     T out = quiet_nan<T>();
@@ -600,7 +600,7 @@ __device__ void op_trap_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
 // windower (processors/windower.py:12-54): w_out[k] = w_in[int(t0) + k], NaN where the window reaches outside the input
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_windower(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_windower(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
     const T t0 = cx.scalar(op.sp[0]);
@@ -629,7 +629,7 @@ __device__ void op_windower(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
 // avg_current (processors/moving_windows.py:206-249): w_out = (w_in[L:] - w_in[:-L]) / length in T; ic[0] = L, fc[0] = length
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_avg_current(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_avg_current(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
     if (cx.slot_nan(op.src)) {
@@ -660,7 +660,7 @@ __device__ void op_avg_current(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
 // wavefront scan adds the partial sums (float64 sums of one waveform's float32 samples are exact, so order does not matter).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_trap_window_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_trap_window_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const T tp = cx.scalar(op.sp[0]);
     const int n = ss.len, rise = op.ip[0], flat = op.ip[1];
@@ -696,7 +696,7 @@ __device__ void op_trap_window_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
 // waveform's dynamic range the float64 sums are exact, hence order independent; otherwise the last float64 bit may differ.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_mean_below(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_mean_below(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const T thr = cx.scalar(op.sp[0]);
     T out = quiet_nan<T>();
@@ -724,7 +724,7 @@ __device__ void op_mean_below(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
 // time_point_thresh  (processors/time_point_thresh.py:12-92): comparisons only -> bit exact
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_time_point_thresh(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_time_point_thresh(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const T thr = cx.scalar(op.sp[0]), ts_f = cx.scalar(op.sp[1]), walk_f = cx.scalar(op.sp[2]);
     T out = quiet_nan<T>();
@@ -779,7 +779,7 @@ __device__ void op_time_point_thresh(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
 // min_max  (processors/min_max.py:11-82): first occurrence of the extremes (strict comparisons)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_min_max(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, bool amax_only) {
+__device__ __forceinline__ void op_min_max(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, bool amax_only) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const int n = ss.len, C = ss.C, lane = lane_id();
     T o_tmin = quiet_nan<T>(), o_tmax = o_tmin, o_amin = o_tmin, o_amax = o_tmin;
@@ -844,7 +844,7 @@ __device__ void op_min_max(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, bool amax_onl
 // Runs in place on the scratch slot ip[2] (a copy of src, or src itself when it is dead afterwards).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ void op_dwt_haar(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_dwt_haar(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const DSP_GLOBAL DevSlot& st = cx.prog->slots[op.ip[2]];
     const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
@@ -861,15 +861,27 @@ __device__ void op_dwt_haar(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
         const DSP_GLOBAL DevSlot& out = last ? sd : st;
         const int half = (len + 1) >> 1;
         const T f0 = (last && part == 'd') ? -c : c;
-        for (int k0 = 0; k0 < half; k0 += 64) {
-            const int k = k0 + lane;
-            T lo = (T)0, hi = (T)0;
-            if (k < half) {
-                lo = cx.lds[padded_index(in, 2 * k)];
-                hi = cx.lds[padded_index(in, (2 * k + 1 < len) ? 2 * k + 1 : len - 1)];
+        // NB rounds of 64 outputs at a time: their 2 * NB * 64 inputs are all read before any of their outputs is written (the
+        // outputs of rounds r .. r+NB-1 land below sample 64 (r + NB), the unread inputs start at 128 (r + NB): in-place halving is
+        // safe), so the LDS latency is paid once per batch instead of once per round
+        constexpr int NB = 8;
+        for (int k0 = 0; k0 < half; k0 += 64 * NB) {
+            T lo[NB], hi[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int k = k0 + b * 64 + lane;
+                lo[b] = hi[b] = (T)0;
+                if (k < half) {
+                    lo[b] = cx.lds[padded_index(in, 2 * k)];
+                    hi[b] = cx.lds[padded_index(in, (2 * k + 1 < len) ? 2 * k + 1 : len - 1)];
+                }
             }
-            wave_sync();  // all reads of this round precede its writes (in-place halving)
-            if (k < half) cx.lds[padded_index(out, k)] = (T)(f0 * hi) + (T)(c * lo);
+            wave_sync();  // all reads of this batch precede its writes
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int k = k0 + b * 64 + lane;
+                if (k < half) cx.lds[padded_index(out, k)] = (T)(f0 * hi[b]) + (T)(c * lo[b]);
+            }
         }
         wave_sync();
         len = half;
@@ -882,7 +894,7 @@ __device__ void op_dwt_haar(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
 
 // dst[k] = src[k + ip[0]]
 template <typename T>
-__device__ void op_copy(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_copy(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
     if (cx.slot_nan(op.src)) {
@@ -911,7 +923,7 @@ __device__ __forceinline__ double fma_t(double a, double b, double c) { return _
 
 // AMAX: fused with numpy.amax over the output (DSP_OP_CONVOLVE_AMAX): nothing is stored, sreg[dst] receives the maximum
 template <typename T>
-__device__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const bool AMAX) {  // (one body for both: the tap loop is the big part)
+__device__ __forceinline__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const bool AMAX) {  // (one body for both: the tap loop is the big part)
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const DSP_GLOBAL DevSlot& sd = cx.prog->slots[AMAX ? op.src : op.dst];  // (unused when AMAX)
     if (cx.slot_nan(op.src) || op.ic[2]) {
@@ -1034,7 +1046,7 @@ __device__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const bool A
 }
 
 template <typename T>
-__device__ void op_scalar_affine(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_scalar_affine(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const T a = cx.scalar(op.sp[0]), b = cx.scalar(op.sp[1]), c = cx.scalar(op.sp[2]);
     if (lane_id() == 0) cx.sregs()[op.dst] = a * b + c;
     wave_sync();
