@@ -463,12 +463,15 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
         for (int t = 0; t < C; ++t) xr[t] = mine[t];
         const float xprev = (lane > 0) ? mine[-1] : 0.0f;
         // ---- pass 1: float64 sum of x over the chunk
-        double X = 0.0;
+        // (four partial sums: the float64 sum of 65 float32 samples is exact for one waveform's dynamic range, so the order is free,
+        // and one chain of dependent float64 adds would cost their full latency 65 times)
+        double Xp[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int t = 0; t < C; ++t) {
             if ((t & 7) == 0) __builtin_amdgcn_sched_barrier(0);  // (keeps the float64 conversions from being hoisted: registers)
-            X += (double)xr[t];
+            Xp[t & 3] += (double)xr[t];
         }
+        const double X = (Xp[0] + Xp[1]) + (Xp[2] + Xp[3]);
         bool in_nan = A.tau_nan != 0;
         if (wave_any(!(fabs(X) <= 1.7976931348623157e308))) {
             bool n = false;
