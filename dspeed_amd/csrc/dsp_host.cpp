@@ -24,9 +24,9 @@
 #include "dsp_program.h"
 
 extern "C" int dsp_internal_launch_vm_f32(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int* err, int blocks,
-                                          int threads, int lds_bytes, hipStream_t stream);
+                                          int threads, int lds_bytes, int with_fir, hipStream_t stream);
 extern "C" int dsp_internal_launch_vm_f64(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int* err, int blocks,
-                                          int threads, int lds_bytes, hipStream_t stream);
+                                          int threads, int lds_bytes, int with_fir, hipStream_t stream);
 extern "C" int dsp_internal_set_vm_lds(int lds_bytes);
 extern "C" const char* dsp_internal_vm_kernel_name();
 extern "C" int dsp_internal_launch_stream_read(const void* src, int64_t bytes, uint32_t* sink, int blocks, hipStream_t stream);
@@ -128,7 +128,9 @@ struct dsp_chain {
     int* dev_err = nullptr;
     int device = 0;
     int lds_bytes_per_wave = 0;
-    int waves_per_block = 0;
+    int waves_per_block = 0;   // generic VM launch
+    int classic_wpb = 0;       // classic energy kernel launch (built for 2 wavefronts per SIMD)
+    bool has_fir = false;      // the program holds a CONVOLVE: the VM build with the FIR op (2 wavefronts per SIMD instead of 4)
     int num_cu = 256;
     bool f64 = false;  // the float64 gufunc loop (LDS elements are 8 bytes)
     // specialised energy-chain kernel (dsp_energy.hip), selected when the program has exactly that shape
@@ -406,21 +408,24 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     if (ch->lds_bytes_per_wave > LDS_BYTES_PER_CU)
         return fail(DSP_ERR_TOO_LONG, "chain needs %d bytes of LDS per waveform; a CU has %d", ch->lds_bytes_per_wave, LDS_BYTES_PER_CU);
     // wavefronts per workgroup (1..4): the size that fits the most wavefronts into a CU's LDS and register budget (25 KB per
-    // waveform: 3 per group and 2 groups = 6 wavefronts, where 4 per group would leave one group of 4); ties go to the larger group
-    int wpb = 1, best_waves = 0;
-    for (int w = 1; w <= 4; ++w) {
-        int groups = LDS_BYTES_PER_CU / (w * ch->lds_bytes_per_wave);
-        if (groups > 8 / w) groups = 8 / w;  // the kernels are built for 2 wavefronts per SIMD (registers): 8 per CU, whole groups only
-        const int waves = groups * w;
-        if (groups >= 1 && waves >= best_waves) {
-            best_waves = waves;
-            wpb = w;
+    // waveform: 3 per group and 2 groups = 6 wavefronts, where 4 per group would leave one group of 4); ties go to the larger group.
+    // Register budget: the VM without the FIR op and 4 wavefronts per SIMD = 16 per CU, everything else 2 per SIMD = 8 per CU.
+    for (int i = 0; i < n_ops; ++i) ch->has_fir |= (ops[i].opcode == DSP_OP_CONVOLVE || ops[i].opcode == DSP_OP_CONVOLVE_AMAX);
+    auto pick_wpb = [&](int cap_waves) {
+        int best_w = 1, best_waves = 0;
+        for (int w = 1; w <= 4; ++w) {
+            int groups = LDS_BYTES_PER_CU / (w * ch->lds_bytes_per_wave);
+            if (groups > cap_waves / w) groups = cap_waves / w;  // whole groups only
+            const int waves = groups * w;
+            if (groups >= 1 && waves >= best_waves) {
+                best_waves = waves;
+                best_w = w;
+            }
         }
-    }
-    if (const char* env = getenv("DSPEED_HIP_WPB")) {  // tuning knob: wavefronts per workgroup (1..4)
-        const int v = atoi(env);
-        if (v >= 1 && v <= 4 && v * ch->lds_bytes_per_wave <= LDS_BYTES_PER_CU) wpb = v;
-    }
+        return best_w;
+    };
+    int wpb = pick_wpb(ch->has_fir ? 8 : 16);
+    ch->classic_wpb = pick_wpb(8);
     ch->waves_per_block = wpb;
     P.waves_per_block = wpb;
 
@@ -745,26 +750,27 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     if (block_lds > 64 * 1024) {
         hipError_t e = (hipError_t)dsp_internal_set_vm_lds(block_lds);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", block_lds, hipGetErrorString(e));
-        if (ch->fused_ok) {
-            e = (hipError_t)dsp_internal_set_energy_lds(ch->fused_trap, ch->fused_npf, block_lds);
-            if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(energy kernel, %d): %s", block_lds, hipGetErrorString(e));
-        }
+    }
+    const int classic_lds = ch->lds_bytes_per_wave * ch->classic_wpb;
+    if (ch->fused_ok && classic_lds > 64 * 1024) {
+        hipError_t e = (hipError_t)dsp_internal_set_energy_lds(ch->fused_trap, ch->fused_npf, classic_lds);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(energy kernel, %d): %s", classic_lds, hipGetErrorString(e));
     }
     *out = ch.release();
     return DSP_OK;
 }
 
-static int chain_blocks(const dsp_chain* ch, int64_t n_wf) {
-    const int block_lds = ch->lds_bytes_per_wave * ch->waves_per_block;
+static int chain_blocks(const dsp_chain* ch, int64_t n_wf, int wpb, int cap_waves) {
+    const int block_lds = ch->lds_bytes_per_wave * wpb;
     int per_cu = LDS_BYTES_PER_CU / block_lds;
-    const int wave_cap = 32 / ch->waves_per_block;  // 32 wavefronts per CU
-    if (per_cu > wave_cap) per_cu = wave_cap;
+    if (per_cu > cap_waves / wpb) per_cu = cap_waves / wpb;
     if (per_cu < 1) per_cu = 1;
-    int64_t want = (n_wf + ch->waves_per_block - 1) / ch->waves_per_block;
+    int64_t want = (n_wf + wpb - 1) / wpb;
     int64_t cap = (int64_t)ch->num_cu * per_cu;
     int64_t b = want < cap ? want : cap;
     return (int)(b > 0 ? b : 1);
 }
+static int vm_blocks(const dsp_chain* ch, int64_t n_wf) { return chain_blocks(ch, n_wf, ch->waves_per_block, ch->has_fir ? 8 : 16); }
 
 // launch geometry of the register-resident kernel: up to 4 wavefronts per block, 2 wavefronts per SIMD (its register budget)
 static void rr_geometry(const dsp_chain* ch, int64_t n_wf, int* wpb_out, int* blocks_out) {
@@ -788,7 +794,7 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         ptrs.p[k] = io_ptrs[k];
     }
     (void)hipGetLastError();  // launch checks below report this launch, not a stale error of an unrelated earlier call
-    const int blocks = chain_blocks(ch, n_wf);
+    const int blocks = vm_blocks(ch, n_wf);
     const int threads = 64 * ch->waves_per_block;
     const int lds = ch->lds_bytes_per_wave * ch->waves_per_block;
     if (ch->rr_ok && ch->fused_on && ch->variant != 1 && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
@@ -811,13 +817,16 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         F.bl = ch->io_bl >= 0 ? (const float*)io_ptrs[ch->io_bl] : nullptr;
         F.tp = ch->io_tp >= 0 ? (const float*)io_ptrs[ch->io_tp] : nullptr;
         F.out = (float*)io_ptrs[ch->io_out];
-        hipError_t e = (hipError_t)dsp_internal_launch_energy(&F, ch->fused_trap, ch->fused_npf, n_wf, ch->dev_err, blocks, threads, lds,
-                                                              (hipStream_t)stream);
+        const int cw = ch->classic_wpb;
+        hipError_t e = (hipError_t)dsp_internal_launch_energy(&F, ch->fused_trap, ch->fused_npf, n_wf, ch->dev_err, chain_blocks(ch, n_wf, cw, 8),
+                                                              64 * cw, ch->lds_bytes_per_wave * cw, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy kernel launch failed: %s", hipGetErrorString(e));
         return DSP_OK;
     }
-    hipError_t e = ch->f64 ? (hipError_t)dsp_internal_launch_vm_f64(ch->dev, &ptrs, n_wf, ch->dev_err, blocks, threads, lds, (hipStream_t)stream)
-                           : (hipError_t)dsp_internal_launch_vm_f32(ch->dev, &ptrs, n_wf, ch->dev_err, blocks, threads, lds, (hipStream_t)stream);
+    hipError_t e = ch->f64 ? (hipError_t)dsp_internal_launch_vm_f64(ch->dev, &ptrs, n_wf, ch->dev_err, blocks, threads, lds, ch->has_fir,
+                                                                    (hipStream_t)stream)
+                           : (hipError_t)dsp_internal_launch_vm_f32(ch->dev, &ptrs, n_wf, ch->dev_err, blocks, threads, lds, ch->has_fir,
+                                                                    (hipStream_t)stream);
     if (e != hipSuccess) return fail(DSP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return DSP_OK;
 }
@@ -868,7 +877,7 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
     }
     if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->lds_bytes_per_wave;
     if (waves_per_block) *waves_per_block = ch->waves_per_block;
-    if (blocks) *blocks = chain_blocks(ch, n_wf);
+    if (blocks) *blocks = vm_blocks(ch, n_wf);
     return DSP_OK;
 }
 

@@ -1055,8 +1055,10 @@ __device__ __forceinline__ void op_scalar_affine(Ctx<T>& cx, const DSP_GLOBAL De
 // ------------------------------------------------------------------------------------------------
 // the interpreter
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256) dsp_vm_kernel(const DevProgram* __restrict__ prog, IoPtrs ptrs, int64_t n_wf, int* err) {
+// FIR: the interpreter with the long-FIR op compiled in.  That op's register needs (183 VGPRs with it, 113 without) would cap every
+// chain at 2 wavefronts per SIMD, so programs without a CONVOLVE run the lean build: 4 wavefronts per SIMD where LDS allows.
+template <typename T, bool FIR>
+__global__ void __launch_bounds__(256, FIR ? 2 : 4) dsp_vm_kernel(const DevProgram* __restrict__ prog, IoPtrs ptrs, int64_t n_wf, int* err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably wave-uniform -> rows, pointers in SGPRs
     const int wpb = (int)(blockDim.x >> 6);
@@ -1102,7 +1104,9 @@ __global__ void __launch_bounds__(256) dsp_vm_kernel(const DevProgram* __restric
                 case DSP_OP_DWT_HAAR: op_dwt_haar(cx, op); break;
                 case DSP_OP_COPY: op_copy(cx, op); break;
                 case DSP_OP_CONVOLVE:
-                case DSP_OP_CONVOLVE_AMAX: op_convolve<T>(cx, op, op.opcode == DSP_OP_CONVOLVE_AMAX); break;
+                case DSP_OP_CONVOLVE_AMAX:
+                    if constexpr (FIR) op_convolve<T>(cx, op, op.opcode == DSP_OP_CONVOLVE_AMAX);
+                    break;
                 case DSP_OP_SCALAR_AFFINE: op_scalar_affine(cx, op); break;
                 default: break;
             }
@@ -1178,23 +1182,31 @@ __global__ void __launch_bounds__(256) dsp_stream_read_kernel(const uint4* src, 
 // launchers (called from dsp_host.cpp)
 // ------------------------------------------------------------------------------------------------
 extern "C" int dsp_internal_launch_vm_f32(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int* err, int blocks,
-                                          int threads, int lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL(dsp_vm_kernel<float>, dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
+                                          int threads, int lds_bytes, int with_fir, hipStream_t stream) {
+    if (with_fir)
+        hipLaunchKernelGGL((dsp_vm_kernel<float, true>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
+    else
+        hipLaunchKernelGGL((dsp_vm_kernel<float, false>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
     return (int)hipGetLastError();
 }
 
 extern "C" int dsp_internal_launch_vm_f64(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int* err, int blocks,
-                                          int threads, int lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL(dsp_vm_kernel<double>, dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
+                                          int threads, int lds_bytes, int with_fir, hipStream_t stream) {
+    if (with_fir)
+        hipLaunchKernelGGL((dsp_vm_kernel<double, true>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
+    else
+        hipLaunchKernelGGL((dsp_vm_kernel<double, false>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
     return (int)hipGetLastError();
 }
 
 extern "C" int dsp_internal_set_vm_lds(int lds_bytes) {
-    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dsp_vm_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      lds_bytes);
-    if (rc) return rc;
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dsp_vm_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    lds_bytes);
+    const void* k[4] = {reinterpret_cast<const void*>(&dsp_vm_kernel<float, true>), reinterpret_cast<const void*>(&dsp_vm_kernel<float, false>),
+                        reinterpret_cast<const void*>(&dsp_vm_kernel<double, true>), reinterpret_cast<const void*>(&dsp_vm_kernel<double, false>)};
+    for (int i = 0; i < 4; ++i) {
+        const int rc = (int)hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (rc != 0) return rc;
+    }
+    return 0;
 }
 
 extern "C" const char* dsp_internal_vm_kernel_name() { return "dsp_vm_kernel<float>"; }
