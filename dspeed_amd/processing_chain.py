@@ -88,7 +88,7 @@ _SIGS = {
     "discrete_wavelet_transform": "wiccW", "convolve_wf": "wtcW", "fft_convolve_wf": "wtcW", "amax": "wiS",
     "mean_below_threshold": "wsS", "windower": "wsW", "avg_current": "wsW", "trap_pickoff": "wiisS",
 }
-_GENERATORS = ("cusp_filter", "zac_filter")
+_GENERATORS = ("cusp_filter", "zac_filter", "t0_filter", "moving_slope")
 _MODULES = ("dspeed.processors", "dspeed_amd.processors", "numpy", "np")
 
 
@@ -675,7 +675,8 @@ def _add_step(b: _Builder, key, node, new_vars, proc_strings):
 
 
 def _fold_generator(b: _Builder, function, args, new_vars):
-    """cusp_filter / zac_filter with constant arguments run once, here, on the host (reference :2797-2813)."""
+    """Kernel generators (cusp_filter, zac_filter, t0_filter, moving_slope) with constant arguments run once, here, on the host
+    (reference :2797-2813)."""
     from . import processors as P
 
     *scal, out = args

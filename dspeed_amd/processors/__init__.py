@@ -359,10 +359,41 @@ avg_current = HipGUFunc("avg_current", "(n),(),(m)", ["fff", "ddd"], _avg_curren
                         "(w_in[L:] - w_in[:-L]) / length (reference processors/moving_windows.py:206-249)")
 trap_pickoff = HipGUFunc("trap_pickoff", "(n),(),(),()->()", ["fiif->f", "diid->d"], _trap_pickoff,
                          "normalised difference of two rise-long window sums at an integer pick-off sample (reference processors/trap_filters.py:230-293)")
+def _t0_filter(g, rise, fall, kernel):
+    """kernels.py:12-66: linearly weighted rise (weights 2(r - i) / (r (r + 1))), then -1/fall; object mode -> Python floats"""
+    rise, fall = _scalar_for(kernel, rise), _scalar_for(kernel, fall)
+    if rise < 0:
+        raise DSPFatal("The length of the rise section must be positive")
+    if fall < 0:
+        raise DSPFatal("The length of the fall section must be positive")
+    if len(kernel) != rise + fall:
+        raise DSPFatal("The length of the output kernel must equal rise+fall")
+    for i in range(int(rise)):
+        kernel[i] = 2 * (int(rise) - i) / (rise * (rise + 1))
+    for i in range(int(rise), len(kernel)):
+        kernel[i] = -1 / fall
+    return kernel
+
+
+def _moving_slope(g, kernel):
+    """kernels.py:69-98: least-squares slope weights over len(kernel) samples, reversed for use as a convolution kernel"""
+    n = len(kernel)
+    sum_x = n * (n + 1) / 2
+    sum_x2 = n * (n + 1) * (2 * n + 1) / 6
+    kernel[:] = (np.arange(1, n + 1, 1) * n) - (np.ones(n) * sum_x)
+    kernel[:] /= n * sum_x2 - sum_x * sum_x
+    kernel[:] = kernel[::-1]
+    return kernel
+
+
+t0_filter = HipGUFunc("t0_filter", "(),(),(n)", ["fff", "ddd"], _t0_filter,
+                      "t0 kernel generator (asymmetric trapezoid weights), host, once (reference processors/kernels.py:12-66)")
+moving_slope = HipGUFunc("moving_slope", "(n)", ["f", "d"], _moving_slope,
+                         "moving-slope kernel generator, host, once (reference processors/kernels.py:69-98)")
 cusp_filter = HipGUFunc("cusp_filter", "(),(),(),(n)", ["ffff", "dddd"], _cusp_filter,
                         "CUSP kernel generator, evaluated once on the host at chain build (reference processors/energy_kernels.py:12-73)")
 zac_filter = HipGUFunc("zac_filter", "(),(),(),(n)", ["ffff", "dddd"], _zac_filter,
                        "zero-area CUSP kernel generator, host, once (reference processors/energy_kernels.py:76-157)")
 
 __all__ = ["bl_subtract", "pole_zero", "double_pole_zero", "trap_filter", "trap_norm", "asym_trap_filter", "fixed_time_pickoff",
-           "time_point_thresh", "min_max", "mean_below_threshold", "windower", "avg_current", "trap_pickoff", "discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "cusp_filter", "zac_filter"]
+           "time_point_thresh", "min_max", "mean_below_threshold", "windower", "avg_current", "trap_pickoff", "discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "cusp_filter", "zac_filter", "t0_filter", "moving_slope"]

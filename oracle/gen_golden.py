@@ -484,6 +484,29 @@ def gen_windows():
     b.save()
 
 
+def gen_kernels():
+    """t0_filter, moving_slope (object-mode generators, kernels.py): float32 scalars arrive as Python floats"""
+    b = Book("kernels")
+    m = _ref("kernels")
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        for k, (rise, fall) in enumerate([(8, 125), (1, 1), (0, 5), (5, 0), (3.0, 7.0), (-1, 5), (4, -2), (8, 100)]):
+            n = int(rise + fall) if (rise >= 0 and fall >= 0) else 6
+            if k == 7:
+                n = 50  # wrong length -> DSPFatal
+            out = np.zeros(max(n, 1), dtype=dt)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                try:
+                    fatal = run_body(m.t0_filter, float(dt(rise)), float(dt(fall)), out)
+                except ZeroDivisionError:
+                    continue  # (fall == 0: Python raises; not a DSPFatal)
+            b.add(f"{tag}_t0{k}", "t0_filter", tag, {"kernel": out}, {"rise": float(rise), "fall": float(fall)}, fatal)
+        for k, n in enumerate([2, 3, 12, 133]):
+            out = np.zeros(n, dtype=dt)
+            fatal = run_body(m.moving_slope, out)
+            b.add(f"{tag}_slope{k}", "moving_slope", tag, {"kernel": out}, {"length": n}, fatal)
+    b.save()
+
+
 def gen_arithmetic():
     """own seed: added after the other books, which must not change"""
     rng = np.random.default_rng(0xA717)
@@ -636,6 +659,9 @@ def main():
     if "--windows" in sys.argv:
         gen_windows()
         return
+    if "--kernels" in sys.argv:
+        gen_kernels()
+        return
     rng = np.random.default_rng(0xD5BEED)
     gen_elementwise(rng)
     gen_pole_zero(rng)
@@ -646,6 +672,7 @@ def main():
     gen_chains(rng)
     gen_arithmetic()
     gen_windows()
+    gen_kernels()
 
 
 if __name__ == "__main__":
