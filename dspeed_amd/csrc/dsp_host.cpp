@@ -777,6 +777,10 @@ static void rr_geometry(const dsp_chain* ch, int64_t n_wf, int* wpb_out, int* bl
     int wpb = LDS_BYTES_PER_CU / ch->rr_lds_bytes;
     if (wpb > 4) wpb = 4;
     if (wpb < 1) wpb = 1;
+    if (const char* env = getenv("DSPEED_HIP_WPB")) {  // tuning knob: wavefronts per workgroup
+        const int v = atoi(env);
+        if (v >= 1 && v <= wpb) wpb = v;
+    }
     int per_cu = LDS_BYTES_PER_CU / (ch->rr_lds_bytes * wpb);
     if (per_cu * wpb > 8) per_cu = 8 / wpb;
     if (per_cu < 1) per_cu = 1;

@@ -132,6 +132,35 @@ def test_energy_chain_on_digitiser_samples(dtype, wf_len, rise, flat):
     assert np.array_equal(_run_energy(wf, bl, tp, 1716.28, rise, flat, "l", fused=15), vm)
 
 
+@pytest.mark.parametrize("row_stride,offset_rows", [(4096, 0), (4100, 0), (4097, 0), (4104, 3)])
+def test_energy_chain_on_strided_and_offset_rows(row_stride, offset_rows):
+    """rows inside a wider allocation (row_stride > wf_len) and a buffer that starts mid-allocation: 16-byte aligned rows take the
+    specialised kernel, anything else the VM's element-wise loads; same energies either way"""
+    from dspeed_amd.chain import Chain, energy_chain_program
+    from dspeed_amd.device import DeviceArray
+
+    rng = np.random.default_rng(row_stride)
+    n_wf, wf_len = 70, 4096
+    i = np.arange(wf_len, dtype=np.float64)[None, :]
+    t0 = np.floor(rng.uniform(0.45, 0.55, (n_wf, 1)) * wf_len)
+    wf = (10000 + 7000 * np.exp(-(i - t0) / 1716.28) * (i >= t0) + 5.0 * rng.standard_normal((n_wf, wf_len))).astype(np.float32)
+    bl = np.full(n_wf, 10000, dtype=np.float32)
+    tp = (t0[:, 0] + 625 + 150.4).astype(np.float32)
+    want, _ = oracle.chain_energy(wf, bl, tp, 1716.28, 625, 188, "l")
+    big = np.full((n_wf + offset_rows, row_stride), np.nan, dtype=np.float32)  # NaN everywhere the chain must not look
+    big[offset_rows:, :wf_len] = wf
+    dev = DeviceArray.from_numpy(big)
+    view = dev.view_rows(offset_rows, offset_rows + n_wf)
+    ch = Chain(energy_chain_program(wf_len, 1716.28, 625, 188, "l", row_stride=row_stride), "strided")
+    out = DeviceArray((n_wf,), np.float32)
+    ch.execute({"waveform": view, "baseline": DeviceArray.from_numpy(bl), "t_pick": DeviceArray.from_numpy(tp), "trapEftp": out}, n_wf)
+    ch.check()
+    got = out.to_numpy()
+    assert np.max(np.abs(got - want) / np.abs(want)) <= TOL
+    aligned = row_stride % 4 == 0
+    assert ch.kernel_name == ("dsp_energy_rr_kernel" if aligned else "dsp_vm_kernel<float>")
+
+
 def test_energy_chain_matches_unfused_processors():
     """fused chain == the same processors called one by one on the device (the ProcessingChain way)"""
     from dspeed_amd import processors as P
