@@ -22,7 +22,7 @@ IO_WF_IN, IO_WF_OUT, IO_SCALAR_IN, IO_SCALAR_OUT, IO_TAPS = range(5)
 ARG_CONST, ARG_INPUT, ARG_REG = range(3)
 (OP_LOAD, OP_STORE, OP_STORE_SCALAR, OP_BL_SUBTRACT, OP_POLE_ZERO, OP_DOUBLE_POLE_ZERO, OP_TRAP_FILTER, OP_TRAP_NORM,
  OP_ASYM_TRAP, OP_PICKOFF, OP_TIME_POINT_THRESH, OP_MIN_MAX, OP_DWT_HAAR, OP_CONVOLVE, OP_COPY, OP_TRAP_PICKOFF, OP_AMAX,
- OP_SCALAR_AFFINE, OP_MEAN_BELOW, OP_CONVOLVE_AMAX, OP_WINDOWER, OP_AVG_CURRENT, OP_TRAP_WINDOW_PICKOFF) = range(1, 24)
+ OP_SCALAR_AFFINE, OP_MEAN_BELOW, OP_CONVOLVE_AMAX, OP_WINDOWER, OP_AVG_CURRENT, OP_TRAP_WINDOW_PICKOFF, OP_TRAP_REDUCE) = range(1, 25)
 MAX_OPS, MAX_SLOTS, MAX_IO, MAX_SREGS = 48, 8, 24, 32
 
 

@@ -548,6 +548,15 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 if (rc) return fail(rc, "%s", dsp_fatal_message(rc));
                 break;
             }
+            case DSP_OP_TRAP_REDUCE: {
+                if (!check_slot(P, o.src) || (o.dst < 0 && o.io < 0) || (o.dst >= 0 && o.dst + 3 >= n_sregs) || o.io >= n_sregs)
+                    return fail(DSP_ERR_ARG, "op %d: bad TRAP_REDUCE", i);
+                if (o.ip[3] != DSP_OP_TRAP_FILTER && o.ip[3] != DSP_OP_TRAP_NORM && o.ip[3] != DSP_OP_ASYM_TRAP)
+                    return fail(DSP_ERR_ARG, "op %d: TRAP_REDUCE ip[3] must name a trapezoid opcode", i);
+                int rc = setup_trap(d, o.ip[3], o.ip[0], o.ip[1], o.ip[2], slot_len[o.src], P.slots[o.src].C);
+                if (rc) return fail(rc, "%s", dsp_fatal_message(rc));
+                break;
+            }
             case DSP_OP_PICKOFF:
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad PICKOFF", i);
                 break;

@@ -361,7 +361,10 @@ constexpr int TRAP_NCAP = 4;
 
 // Runs the trap emulation over slot `ss`.  If STORE, writes the filtered waveform into slot `sd` (must differ from ss).
 // cap_idx[c] (uniform, -1 = unused): sample indices whose filtered value is wanted; returned in cap_val[c] (uniform).
-template <typename T, int KIND, bool STORE>
+// RED (with STORE false): the filtered waveform only feeds reductions -- min_max and / or time_point_thresh -- and is never stored
+// (DSP_OP_TRAP_REDUCE): extremes are tracked during the replay (the correction by delta_j is monotone, so the extreme of the
+// corrected values is the corrected extreme), the threshold walk is a second replay comparing consecutive corrected samples.
+template <typename T, int KIND, bool STORE, bool RED = false>
 __device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOBAL DevSlot& ss, const DSP_GLOBAL DevSlot& sd, const int* cap_idx, T* cap_val) {
     const int C = ss.C, lane = lane_id();
     const auto* ps = cx.chunk(ss);
@@ -433,6 +436,9 @@ __device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOB
     }
     typename Ctx<T>::LT* pd = STORE ? cx.chunk(sd) : nullptr;
     T y = g;
+    const int n_valid = ss.len, i_first = lane * C;
+    T vmin = __builtin_huge_val(), vmax = -__builtin_huge_val();
+    int imin = 0x7fffffff, imax = 0x7fffffff;
     {
         int t = 0;
         while (t < C) {
@@ -450,6 +456,19 @@ __device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOB
             for (int u = t; u < nb; ++u) {
                 y = trap_step_r<T, KIND>(y, ps[u], l0[u], l1[u], l2[u], rr, ll, inv_rr, inv_ll);
                 if (STORE) pd[u] = y;
+                if (RED) {
+                    const int idx = i_first + u;
+                    if (idx < n_valid) {
+                        if (y < vmin) {
+                            vmin = y;
+                            imin = idx;
+                        }
+                        if (y > vmax) {
+                            vmax = y;
+                            imax = idx;
+                        }
+                    }
+                }
             }
             t = nb;
 #pragma unroll
@@ -472,6 +491,114 @@ __device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOB
         const T v = (T)((double)capv[c] + delta);
         cap_val[c] = cap_lane[c] >= 0 ? readlane(v, cap_lane[c]) : (T)0;
     }
+    if constexpr (RED) {
+        // ---- min_max (min_max.py:11-82) over the corrected values: lowest index wins ties
+        T cmin = imin != 0x7fffffff ? (T)((double)vmin + delta) : vmin, cmax = imax != 0x7fffffff ? (T)((double)vmax + delta) : vmax;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const T omin = __shfl_xor(cmin, m), omax = __shfl_xor(cmax, m);
+            const int oimin = __shfl_xor(imin, m), oimax = __shfl_xor(imax, m);
+            if (omin < cmin || (omin == cmin && oimin < imin)) {
+                cmin = omin;
+                imin = oimin;
+            }
+            if (omax > cmax || (omax == cmax && oimax < imax)) {
+                cmax = omax;
+                imax = oimax;
+            }
+        }
+        if (op.dst >= 0 && lane == 0) {
+            auto* r = cx.sregs();
+            r[op.dst] = (T)imin;
+            r[op.dst + 1] = (T)imax;
+            r[op.dst + 2] = cmin;
+            r[op.dst + 3] = cmax;
+        }
+        wave_sync();
+        // ---- time_point_thresh (time_point_thresh.py:12-92) on the corrected values: second replay, consecutive samples compared
+        if (op.io >= 0) {
+            const T thr = cx.scalar(op.sp[0]), ts_f = cx.scalar(op.sp[1]), walk_f = cx.scalar(op.sp[2]);  // (t_start may be the t_max just written)
+            T out = quiet_nan<T>();
+            if (!(thr != thr || ts_f != ts_f || walk_f != walk_f)) {
+                if (floor((double)ts_f) != (double)ts_f) {
+                    cx.fatal(DSP_E_TPT_START_INT);
+                } else if (floor((double)walk_f) != (double)walk_f) {
+                    cx.fatal(DSP_E_TPT_WALK_INT);
+                } else if ((long long)ts_f < 0 || (long long)ts_f >= n_valid) {
+                    cx.fatal(DSP_E_TPT_RANGE);
+                } else {
+                    const int ts = (int)ts_f;
+                    const bool forward = (long long)walk_f == 1;
+                    T prv = wave_prev((T)((double)y + delta));  // last corrected sample of the previous lane's chunk
+                    int best = forward ? 0x7fffffff : -1;
+                    T yy = g;
+                    int t = 0;
+                    while (t < C) {
+                        int nb = C;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            if (rho[k] > t && rho[k] < nb) nb = rho[k];
+                        const auto* l0 = lag[0] + (t >= rho[0] ? 1 : 0);
+                        const auto* l1 = lag[1] + (t >= rho[1] ? 1 : 0);
+                        const auto* l2 = lag[2] + (t >= rho[2] ? 1 : 0);
+#pragma unroll 8
+                        for (int u = t; u < nb; ++u) {
+                            yy = trap_step_r<T, KIND>(yy, ps[u], l0[u], l1[u], l2[u], rr, ll, inv_rr, inv_ll);
+                            const T cur = (T)((double)yy + delta);
+                            const int idx = i_first + u;
+                            if (idx < n_valid) {
+                                if (forward) {  // smallest i = idx - 1 in [ts, n-2] with (w[i] <= thr < w[i+1]) or (w[i] >= thr > w[i+1])
+                                    const bool hit = ((prv <= thr && thr < cur) || (prv >= thr && thr > cur)) && idx - 1 >= ts && idx >= 1;
+                                    if (hit && best == 0x7fffffff) best = idx - 1;
+                                } else {        // largest i = idx in [1, ts] with (w[i-1] < thr <= w[i]) or (w[i-1] > thr >= w[i])
+                                    const bool hit = ((prv < thr && thr <= cur) || (prv > thr && thr >= cur)) && idx >= 1 && idx <= ts;
+                                    if (hit) best = idx;
+                                }
+                            }
+                            prv = cur;
+                        }
+                        t = nb;
+                    }
+                    if (forward) {
+                        best = wave_min(best);
+                        if (best != 0x7fffffff) out = (T)best;
+                    } else {
+                        best = wave_max(best);
+                        if (best >= 0) out = (T)best;
+                    }
+                }
+            }
+            if (lane == 0) cx.sregs()[op.io] = out;
+            wave_sync();
+        }
+    }
+}
+
+// TRAP_REDUCE: trap filter whose only consumers are min_max and / or time_point_thresh -- the filtered waveform never exists
+// (no second 8192-sample slot: the LEGEND t0 chain asym_trap_filter -> min_max -> time_point_thresh fits twice as many wavefronts).
+// dst = first of the four min_max registers (t_min, t_max, a_min, a_max) or -1; io = time_point_thresh register or -1;
+// sp[0..2] = threshold, t_start, walk_forward; ip[0..2] = rise, flat, fall; ip[3] = trapezoid opcode
+template <typename T>
+__device__ __forceinline__ void op_trap_reduce(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    if (cx.slot_nan(op.src) || op.ic[9]) {
+        if (lane_id() == 0) {
+            auto* r = cx.sregs();
+            if (op.dst >= 0)
+                for (int k = 0; k < 4; ++k) r[op.dst + k] = quiet_nan<T>();
+            if (op.io >= 0) r[op.io] = quiet_nan<T>();
+        }
+        wave_sync();
+        return;
+    }
+    const int none[TRAP_NCAP] = {-1, -1, -1, -1};
+    T dummy[TRAP_NCAP];
+    if (op.ip[3] == DSP_OP_TRAP_FILTER)
+        trap_core<T, TRAP_FILTER, false, true>(cx, op, ss, ss, none, dummy);
+    else if (op.ip[3] == DSP_OP_TRAP_NORM)
+        trap_core<T, TRAP_NORM, false, true>(cx, op, ss, ss, none, dummy);
+    else
+        trap_core<T, TRAP_ASYM, false, true>(cx, op, ss, ss, none, dummy);
 }
 
 template <typename T>
@@ -1094,6 +1221,7 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 4) dsp_vm_kernel(const DevProgr
                 case DSP_OP_ASYM_TRAP: op_trap(cx, op); break;
                 case DSP_OP_PICKOFF: op_pickoff(cx, op); break;
                 case DSP_OP_TRAP_PICKOFF: op_trap_pickoff(cx, op); break;
+                case DSP_OP_TRAP_REDUCE: op_trap_reduce(cx, op); break;
                 case DSP_OP_TIME_POINT_THRESH: op_time_point_thresh(cx, op); break;
                 case DSP_OP_MIN_MAX: op_min_max(cx, op, false); break;
                 case DSP_OP_AMAX: op_min_max(cx, op, true); break;

@@ -903,6 +903,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
 
     trap_ops = {"trap_filter": _lib.OP_TRAP_FILTER, "trap_norm": _lib.OP_TRAP_NORM, "asym_trap_filter": _lib.OP_ASYM_TRAP}
     skip = set()
+    pending_reduce = {}  # trapezoid output name -> what its fused min_max / time_point_thresh op needs
     for si, (fn, args, key) in enumerate(steps):
         if si in skip:
             continue
@@ -939,9 +940,36 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
                 skip.add(si + 1)
                 release(src, si + 1)
                 continue
+            # fusion: the trapezoid only feeds one min_max and / or one time_point_thresh (the t0 chain of the LEGEND recipes:
+            # asym_trap_filter -> min_max -> time_point_thresh) and is not an output -> it is never stored.  The fused op is emitted
+            # where the last of the two stands, so their scalar operands (a threshold computed in between) are ready
+            users = [sj for sj, (f2, a2, _k) in enumerate(steps) if sj > si and sj not in skip and any(wf_of(x) is dst for x in a2)]
+            kinds = [steps[sj][0] for sj in users]
+            plain = all(steps[sj][1][0] is dst for sj in users)  # (not through a slice)
+            if (users and plain and dst.name not in out_pars and sorted(kinds) in (["min_max"], ["time_point_thresh"], ["min_max", "time_point_thresh"])
+                    and not any(isinstance(x, tuple) and x[0] == "slice" and x[1] is dst for _f, a2, _k in steps for x in a2)):
+                pending_reduce[dst.name] = {"src": src, "ints": ints, "kind": trap_ops[fn], "emit_at": max(users), "mm_first": -1}
+                last_use[src.name] = max(last_use.get(src.name, si), max(users))
+                continue
             dst.slot = new_slot(src.length)
             p.add_op(trap_ops[fn], dst=dst.slot, src=src.slot, ip=ints)
             release(src, si)
+        elif fn in ("min_max", "time_point_thresh") and isinstance(args[0], Var) and args[0].name in pending_reduce:
+            pr = pending_reduce[args[0].name]
+            if fn == "min_max":
+                pr["mm_first"] = p.add_sregs(4)
+                for k, a in enumerate(args[1:5]):
+                    if not isinstance(a, Var):
+                        raise ProcessingChainError("min_max outputs must be variable names")
+                    a.kind, a.sreg = "scalar", pr["mm_first"] + k
+            else:
+                pr["tpt"] = (tuple(scalar_operand(a, args, what=what) for a in args[1:4]), out_scalar(args[4]))
+            if si == pr["emit_at"]:
+                sp, o = pr.get("tpt", ((), None))
+                p.add_op(_lib.OP_TRAP_REDUCE, dst=pr["mm_first"], src=pr["src"].slot, io=(o.sreg if o is not None else -1),
+                         ip=(*pr["ints"], pr["kind"]), sp=sp)
+                release(pr["src"], si)
+                del pending_reduce[args[0].name]
         elif fn == "fixed_time_pickoff":
             src = ensure_loaded(args[0], si)
             o = out_scalar(args[3])

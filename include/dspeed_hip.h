@@ -163,6 +163,9 @@ typedef struct dsp_scalar_arg {
 #define DSP_OP_AVG_CURRENT 22   /* moving_windows.py:206-249 dst[k] <- (src[k + L] - src[k]) / sp[0], L = int(sp[0]) (constant) */
 #define DSP_OP_TRAP_WINDOW_PICKOFF 23 /* trap_filters.py:230-293 trap_pickoff: sreg[dst] <- (sum of the rise samples ending at sp[0]
                                   * minus the rise samples ending rise+flat earlier) / rise; ip[0..1] = rise, flat */
+#define DSP_OP_TRAP_REDUCE 24    /* fusion of TRAP_FILTER|TRAP_NORM|ASYM_TRAP (ip[3]) with the min_max and / or time_point_thresh that are its only
+                                  * consumers: the filtered waveform is never stored.  dst = first of 4 registers t_min,t_max,a_min,a_max
+                                  * (or -1), io = time_point_thresh register (or -1), sp[0..2] = threshold, t_start, walk_forward */
 #define DSP_OP_SCALAR_AFFINE 18 /* sreg[dst] <- sp[0] * sp[1] + sp[2]  (host-folded expressions such as tp_0 + 10*us) */
 
 typedef struct dsp_op {

@@ -174,6 +174,60 @@ def test_energy_recipe_variants_take_the_specialised_kernel():
         assert np.max(np.abs(got - want) / peak(tr)) <= TOL, name
 
 
+@pytest.mark.parametrize("trap,targs", [("asym_trap_filter", "8, 4, 125"), ("trap_filter", "100, 30"), ("trap_norm", "64, 16")])
+def test_trapezoid_fused_with_its_reductions_equals_the_unfused_ops(trap, targs):
+    """a trapezoid that only feeds min_max / time_point_thresh is never stored (TRAP_REDUCE): same numbers as the three ops run one
+    after the other -- forward and backward walks, per-event thresholds, start from t_max / t_min / a column, NaN rows, DSPFatal"""
+    from dspeed_amd.errors import DSPFatal
+
+    rng = np.random.default_rng(77)
+    x, bl, t0 = _synth(rng, 150, 4096, bl=(-50, 50))
+    wf = x.astype(np.float32)
+    wf[9, 100] = np.nan
+    thr = rng.uniform(5, 400, 150).astype(np.float32)
+    thr[11] = np.nan
+    start = np.floor(rng.uniform(0, 4095, 150)).astype(np.float32)
+    M = "dspeed.processors"
+    mm = {"function": "min_max", "module": M, "args": ["wf_t", "t_min", "t_max", "a_min", "a_max"]}
+
+    def recipe(outs, tpt_args):
+        procs = {"wf_pz": f"{M}.pole_zero(waveform, 1716.28, wf_pz)", "wf_t": f"{M}.{trap}(wf_pz, {targs}, wf_t)",
+                 "t_min, t_max, a_min, a_max": mm}
+        for name, a in tpt_args.items():
+            procs[name] = f"{M}.time_point_thresh(wf_t, {a}, {name})"
+        return {"outputs": outs, "processors": procs}
+
+    tb = {"waveform": wf, "thr": thr, "start": start}
+    tpts = {"tp_b": "thr, t_max, 0", "tp_f": "thr, start, 1"}
+    for use in ({"tp_b": tpts["tp_b"]}, {"tp_f": tpts["tp_f"]}, {}):
+        names = ["t_min", "t_max", "a_min", "a_max", *use]
+        fused_chain, fused = _run(recipe(names, use), tb)
+        plain_chain, plain = _run(recipe(names + ["wf_t"], use), tb)
+        from dspeed_amd import _lib
+
+        f_ops = [o[0] for o in fused_chain.program.ops]
+        assert _lib.OP_TRAP_REDUCE in f_ops and _lib.OP_MIN_MAX not in f_ops
+        assert _lib.OP_TRAP_REDUCE not in [o[0] for o in plain_chain.program.ops]
+        for nm in names:
+            assert np.array_equal(fused[nm], plain[nm], equal_nan=True), (trap, nm)
+        assert np.isnan(fused["a_max"][9]) and (not use or np.isnan(fused[next(iter(use))][11]))
+    # time_point_thresh alone (no min_max), and its data-dependent DSPFatal with the absolute row
+    only = {"outputs": ["tp"], "processors": {"wf_t": f"{M}.{trap}(waveform, {targs}, wf_t)", "tp": f"{M}.time_point_thresh(wf_t, thr, start, 0, tp)"}}
+    c1, o1 = _run(only, tb)
+    assert [o[0] for o in c1.program.ops].count(_lib.OP_TRAP_REDUCE) == 1
+    only2 = {"outputs": ["tp", "wf_t"], "processors": dict(only["processors"])}
+    _, o2 = _run(only2, tb)
+    assert np.array_equal(o1["tp"], o2["tp"], equal_nan=True)
+    bad = start.copy()
+    bad[40] = 17.5
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    cb, _, _ = build_processing_chain(only, {"waveform": wf, "thr": thr, "start": bad})
+    with pytest.raises(DSPFatal, match="starting index must be an integer") as ei:
+        cb.execute()
+    assert ei.value.wf_range == range(40, 41)
+
+
 def test_current_branch_recipe_pieces():
     """windower -> avg_current -> min_max (the first steps of the A/E branch, icpc-dsp-config.json:294-346) and trap_pickoff in one
     recipe; a window that reaches past the input makes NaN samples there, and every consumer of it NaN, as in the reference"""

@@ -83,13 +83,24 @@ def test_c5_int16_chain():
     tb = {"waveform": np.zeros((4, 8192), dtype=np.int16), "thr": np.zeros(4, dtype=np.float32)}
     chain, mask, tb_out = build_processing_chain(recipes.C5, tb)
     ops = _ops(chain)
-    assert ops[:3] == [_lib.OP_LOAD, _lib.OP_DOUBLE_POLE_ZERO, _lib.OP_ASYM_TRAP]
-    assert _lib.OP_MIN_MAX in ops and _lib.OP_TIME_POINT_THRESH in ops and _lib.OP_DWT_HAAR in ops
+    # asym_trap_filter only feeds min_max and time_point_thresh: one fused op, no second 8192-sample slot
+    assert ops[:3] == [_lib.OP_LOAD, _lib.OP_DOUBLE_POLE_ZERO, _lib.OP_TRAP_REDUCE]
+    assert _lib.OP_MIN_MAX not in ops and _lib.OP_TIME_POINT_THRESH not in ops and _lib.OP_ASYM_TRAP not in ops and _lib.OP_DWT_HAAR in ops
+    assert chain.program.slots == [8192, 256]
     assert chain.program.io[0][2] == _lib.I16
     assert tb_out["dwt_haar"].shape == (4, 256) and tb_out["tp_0"].shape == (4,)
-    # time_point_thresh starts from the register min_max wrote (tp_max), threshold from the input column
-    tpt = chain.program.ops[ops.index(_lib.OP_TIME_POINT_THRESH)]
-    assert tpt[5][0].kind == _lib.ARG_INPUT and tpt[5][1].kind == _lib.ARG_REG
+    # time_point_thresh starts from the register the min_max part writes (tp_max), threshold from the input column
+    red = chain.program.ops[2]
+    assert red[4] == (8, 4, 125, _lib.OP_ASYM_TRAP) and red[1] == 0 and red[3] >= 4
+    assert red[5][0].kind == _lib.ARG_INPUT and red[5][1].kind == _lib.ARG_REG and red[5][1].index == 1
+
+
+def test_trapezoid_that_is_an_output_or_has_other_readers_is_not_fused_away():
+    keep = dict(recipes.C5)
+    keep["outputs"] = ["tp_0", "wf_atrap"]
+    chain, _, _ = build_processing_chain(keep, {"waveform": np.zeros((4, 8192), dtype=np.int16), "thr": np.zeros(4, dtype=np.float32)})
+    ops = _ops(chain)
+    assert _lib.OP_ASYM_TRAP in ops and _lib.OP_TRAP_REDUCE not in ops and _lib.OP_MIN_MAX in ops and _lib.OP_TIME_POINT_THRESH in ops
 
 
 def test_dependency_order_is_resolved_from_outputs_and_cycles_raise():
