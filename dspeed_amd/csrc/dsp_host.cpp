@@ -299,6 +299,11 @@ const char* dsp_fatal_message(int code) {
         case DSP_E_WINDOW_LONG: return "The windowed waveform must be smaller than the input waveform";
         case DSP_E_AVGCUR_RANGE: return "length is out of range, must be between 0 and the length of the waveform";
         case DSP_E_TPO_INT: return "The pick-off index must be an integer";
+        case DSP_E_UPSAMPLE: return "Upsample must be greater than 0";
+        case DSP_E_MW_LEN_INT: return "The length of the moving window must be an integer";
+        case DSP_E_MW_NUM_INT: return "The number of moving windows must be an integer";
+        case DSP_E_MW_LEN_RANGE: return "The length of the moving window is out of range";
+        case DSP_E_MW_NUM_NEG: return "The number of moving windows much be positive";
         default: return "";
     }
 }
@@ -373,8 +378,9 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             const bool writes = (o.opcode == DSP_OP_LOAD || o.opcode == DSP_OP_BL_SUBTRACT || o.opcode == DSP_OP_POLE_ZERO ||
                                  o.opcode == DSP_OP_DOUBLE_POLE_ZERO || o.opcode == DSP_OP_TRAP_FILTER || o.opcode == DSP_OP_TRAP_NORM ||
                                  o.opcode == DSP_OP_ASYM_TRAP || o.opcode == DSP_OP_DWT_HAAR || o.opcode == DSP_OP_CONVOLVE ||
-                                 o.opcode == DSP_OP_COPY || o.opcode == DSP_OP_WINDOWER || o.opcode == DSP_OP_AVG_CURRENT) && o.dst == s;
-            const bool scratch = o.opcode == DSP_OP_DWT_HAAR && o.ip[2] == s;
+                                 o.opcode == DSP_OP_COPY || o.opcode == DSP_OP_WINDOWER || o.opcode == DSP_OP_AVG_CURRENT || o.opcode == DSP_OP_UPSAMPLER ||
+                                 o.opcode == DSP_OP_MOVING_WINDOW_MULTI) && o.dst == s;
+            const bool scratch = (o.opcode == DSP_OP_DWT_HAAR || o.opcode == DSP_OP_MOVING_WINDOW_MULTI) && o.ip[2] == s;
             if (!reads && !writes && !scratch) continue;
             if ((o.opcode == DSP_OP_CONVOLVE || o.opcode == DSP_OP_CONVOLVE_AMAX) && reads) fir_in = true;
             const bool plain = o.opcode == DSP_OP_LOAD || o.opcode == DSP_OP_STORE || o.opcode == DSP_OP_COPY ||
@@ -581,6 +587,34 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                     return fail(DSP_ERR_ARG, "avg_current: the output must hold len(w_in) - int(length) = %d samples (it holds %d)", n - L,
                                 slot_len[o.dst]);
                 d.ic[0] = L;
+                d.fc[0] = length;
+                break;
+            }
+            case DSP_OP_UPSAMPLER: {
+                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || o.src == o.dst) return fail(DSP_ERR_ARG, "op %d: bad UPSAMPLER", i);
+                if (o.sp[0].kind != DSP_ARG_CONST) return fail(DSP_ERR_UNSUPPORTED, "upsampler: the factor must be a constant");
+                const double up = f64 ? o.sp[0].value : (double)(float)o.sp[0].value;
+                if (!(up > 0)) return fail(DSP_E_UPSAMPLE, "%s", dsp_fatal_message(DSP_E_UPSAMPLE));
+                d.fc[0] = up;
+                d.fc[1] = floor(up / 2.0);
+                d.ic[0] = (int)up;
+                break;
+            }
+            case DSP_OP_MOVING_WINDOW_MULTI: {
+                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || o.src == o.dst || slot_len[o.src] != slot_len[o.dst])
+                    return fail(DSP_ERR_ARG, "op %d: bad MOVING_WINDOW_MULTI", i);
+                if (o.sp[0].kind != DSP_ARG_CONST) return fail(DSP_ERR_UNSUPPORTED, "moving_window_multi: the window length must be a constant");
+                const double length = f64 ? o.sp[0].value : (double)(float)o.sp[0].value;
+                const int num = o.ip[1], n = slot_len[o.src];
+                if (floor(length) != length) return fail(DSP_E_MW_LEN_INT, "%s", dsp_fatal_message(DSP_E_MW_LEN_INT));
+                if ((long long)length < 0 || (long long)length >= n) return fail(DSP_E_MW_LEN_RANGE, "%s", dsp_fatal_message(DSP_E_MW_LEN_RANGE));
+                if (num < 0) return fail(DSP_E_MW_NUM_NEG, "%s", dsp_fatal_message(DSP_E_MW_NUM_NEG));
+                if (num > 0 && (long long)length == 0) return fail(DSP_E_ZERODIV, "%s", dsp_fatal_message(DSP_E_ZERODIV));
+                if (num > 1 && (!check_slot(P, o.ip[2]) || o.ip[2] == o.src || o.ip[2] == o.dst || slot_len[o.ip[2]] != n))
+                    return fail(DSP_ERR_ARG, "op %d: MOVING_WINDOW_MULTI with several windows needs a scratch slot of the same length (ip[2])", i);
+                d.ic[0] = (int)length;
+                d.ic[1] = num;
+                d.ic[2] = o.ip[0];
                 d.fc[0] = length;
                 break;
             }
@@ -1134,6 +1168,28 @@ int g_trap_window_pickoff(int ty, const WfIn& in, int32_t rise, int32_t flat, co
     sto.ip[0] = 0;
     return m.run(in.n_wf, st, er);
 }
+int g_upsampler(int ty, const WfIn& in, double up, void* out, int32_t out_len, int64_t out_stride, void* st, int64_t* er) {
+    const double c[1] = {up};
+    return wf2wf(ty, DSP_OP_UPSAMPLER, in, out, out_len, out_stride, nullptr, 0, c, 1, nullptr, st, er);
+}
+int g_moving_window_multi(int ty, const WfIn& in, double length, double num_mw, int32_t mw_type, void* out, int64_t out_stride, void* st,
+                          int64_t* er) {
+    if (in.n_wf <= 0) return DSP_OK;
+    if (floor(num_mw) != num_mw) return fail(DSP_E_MW_NUM_INT, "%s", dsp_fatal_message(DSP_E_MW_NUM_INT));
+    Mini m(ty);
+    const int s_in = m.add_slot(in.len), s_out = m.add_slot(in.len);
+    const int s_tmp = num_mw > 1 ? m.add_slot(in.len) : 0;
+    const int io_in = m.add_io(DSP_IO_WF_IN, in.dtype, in.len, in.stride, in.ptr);
+    m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
+    dsp_op& o = m.add_op(DSP_OP_MOVING_WINDOW_MULTI, s_out, s_in, 0);
+    o.ip[0] = mw_type;
+    o.ip[1] = (int32_t)num_mw;
+    o.ip[2] = s_tmp;
+    o.sp[0] = m.scalar(nullptr, length);
+    const int io_out = m.add_io(DSP_IO_WF_OUT, ty, in.len, out_stride, out);
+    m.add_op(DSP_OP_STORE, 0, s_out, io_out);
+    return m.run(in.n_wf, st, er);
+}
 int g_mean_below(int ty, const WfIn& in, const void* thr_dev, double thr, void* out, void* st, int64_t* er) {
     if (in.n_wf <= 0) return DSP_OK;
     Mini m(ty);
@@ -1217,6 +1273,15 @@ int g_min_max(int ty, const WfIn& in, void* t_min, void* t_max, void* a_min, voi
                                const FT* t_pickoff_dev, FT t_pickoff, FT* out, void* stream, int64_t* err_row) {                              \
         return g_trap_window_pickoff(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, rise, flat, t_pickoff_dev, (double)t_pickoff, out,      \
                                      stream, err_row);                                                                                       \
+    }                                                                                                                                         \
+    int dsp_upsampler_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, FT upsample, FT* out,              \
+                            int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row) {                                            \
+        return g_upsampler(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, (double)upsample, out, out_len, out_stride, stream, err_row);     \
+    }                                                                                                                                         \
+    int dsp_moving_window_multi_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, FT length, FT num_mw,    \
+                                      int32_t mw_type, FT* out, int64_t out_stride, void* stream, int64_t* err_row) {                         \
+        return g_moving_window_multi(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, (double)length, (double)num_mw, mw_type, out,          \
+                                     out_stride, stream, err_row);                                                                           \
     }                                                                                                                                         \
     int dsp_mean_below_threshold_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,                        \
                                        const FT* threshold_dev, FT threshold, FT* out, void* stream, int64_t* err_row) {                      \

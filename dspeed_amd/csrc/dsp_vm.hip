@@ -818,6 +818,121 @@ __device__ __forceinline__ void op_trap_window_pickoff(Ctx<T>& cx, const DSP_GLO
 }
 
 // ------------------------------------------------------------------------------------------------
+// upsampler (processors/upsampler.py:13-56): input sample t lands on the int(upsample) outputs starting at
+// int(t * upsample - floor(upsample / 2)); computed per output by inverting that map (ranges of consecutive t do not overlap: their
+// starts are at least int(upsample) apart).  fc[0] = upsample, fc[1] = floor(upsample / 2), ic[0] = int(upsample)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void op_upsampler(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+    if (cx.slot_nan(op.src)) {
+        cx.set_nan(op.dst, true);
+        return;
+    }
+    const int n = ss.len, m = sd.len, cnt = op.ic[0];
+    const double up = op.fc[0], half = op.fc[1];
+    bool nan = false;
+    for (int j = lane_id(); j < 64 * sd.C; j += 64) {
+        T v = (T)0;
+        if (j < m) {
+            v = quiet_nan<T>();
+            const long long tc = (long long)floor(((double)j + half) / up);
+#pragma unroll
+            for (int d = 1; d >= -1; --d) {  // the last input sample that reaches output j wins, as in the reference's loop order
+                const long long t = tc + d;
+                const long long s0 = (long long)((double)t * up - half);  // (truncation toward zero, like int())
+                if (v != v && t >= 0 && t < n && s0 <= j && j < s0 + cnt) v = cx.lds[padded_index(ss, (int)t)];
+            }
+            nan |= (v != v);
+        }
+        cx.lds[padded_index(sd, j)] = v;
+    }
+    if (wave_any(nan))
+        cx.set_some_nan(op.dst);
+    else
+        cx.set_nan(op.dst, false);
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// moving_window_multi (processors/moving_windows.py:117-204): num_mw moving averages, alternately from the left and from the right.
+// One pass:  y[0] = x[0],  y[v] = y[v-1] + (x[v] - (v < L ? x[0] : x[v-L])) / length,  every operation rounded to T and the sum fed
+// back through the output array -- the same structure as trap_filter, so the same rounding replay: lane j runs the reference
+// recurrence over its chunk from a speculative start (the exact running sum of the increments before the chunk, rounded), the
+// true starts are the exact scan of the per-chunk increments, outputs are shifted by the difference.  A pass from the right is the
+// same on the mirrored index.  ic[0] = L, ic[1] = num_mw, ic[2] = mw_type, fc[0] = length
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void mw_pass(Ctx<T>& cx, const DSP_GLOBAL DevSlot& in, const DSP_GLOBAL DevSlot& out, int L, T length, bool right) {
+    const int n = in.len, C = in.C, lane = lane_id(), v0 = lane * C;
+    auto X = [&](int v) -> T { return cx.lds[padded_index(in, right ? n - 1 - v : v)]; };
+    const T x0 = X(0);
+    auto inc = [&](int v) -> T {  // what the reference adds to y[v-1]
+        if (v == 0) return x0;
+        const T b = v < L ? x0 : X(v - L);
+        return (T)(X(v) - b) / length;
+    };
+    // pass A: exact (float64) sum of this chunk's increments -> speculative start
+    double S = 0.0;
+    for (int t = 0; t < C; ++t) {
+        const int v = v0 + t;
+        if (v < n) S += (double)inc(v);
+    }
+    const double E = wave_exscan_add(S);
+    const T g = (lane == 0) ? (T)-0.0 : (T)E;
+    // pass B: the reference recurrence from g
+    T y = g;
+    for (int t = 0; t < C; ++t) {
+        const int v = v0 + t;
+        if (v < n) {
+            y = y + inc(v);
+            cx.lds[padded_index(out, right ? n - 1 - v : v)] = y;
+        }
+    }
+    // true starts: exact scan of the per-chunk increments (y before sample 0 is 0)
+    const double D = (double)y - (double)g;
+    const double delta = wave_exscan_add(D) - (double)g;
+    wave_sync();
+    if (delta != 0.0) {
+        for (int t = 0; t < C; ++t) {
+            const int v = v0 + t;
+            if (v < n) {
+                const int a = padded_index(out, right ? n - 1 - v : v);
+                cx.lds[a] = (T)((double)cx.lds[a] + delta);
+            }
+        }
+    }
+    wave_sync();
+}
+
+template <typename T>
+__device__ __forceinline__ void op_moving_window_multi(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+    const DSP_GLOBAL DevSlot& sq = cx.prog->slots[op.ip[2]];
+    const int L = op.ic[0], num = op.ic[1], type = op.ic[2];
+    if (cx.slot_nan(op.src) || num == 0) {  // (no window at all leaves the output as it was initialised: NaN)
+        cx.set_nan(op.dst, true);
+        return;
+    }
+    for (int e = lane_id(); e < 64 * sd.C; e += 64) {  // pads of both targets stay finite
+        cx.lds[padded_index(sd, e)] = (T)0;
+        if (num > 1) cx.lds[padded_index(sq, e)] = (T)0;
+    }
+    wave_sync();
+    const T length = (T)op.fc[0];
+    for (int p = 0; p < num; ++p) {
+        const bool right = ((p % 2 == 1) && type == 0) || type == 2;
+        const bool to_dst = ((num - 1 - p) % 2) == 0;  // the last pass lands in dst
+        const DSP_GLOBAL DevSlot& in = p == 0 ? ss : (to_dst ? sq : sd);
+        mw_pass(cx, in, to_dst ? sd : sq, L, length, right);
+    }
+    cx.set_nan(op.dst, false);
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
 // mean_below_threshold (processors/arithmetic.py:9-62): float64 total of the samples below the threshold / their count.
 // The reference adds them one by one; here per-lane partial sums and a wavefront scan.  For float32 samples of one
 // waveform's dynamic range the float64 sums are exact, hence order independent; otherwise the last float64 bit may differ.
@@ -1222,6 +1337,8 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 4) dsp_vm_kernel(const DevProgr
                 case DSP_OP_PICKOFF: op_pickoff(cx, op); break;
                 case DSP_OP_TRAP_PICKOFF: op_trap_pickoff(cx, op); break;
                 case DSP_OP_TRAP_REDUCE: op_trap_reduce(cx, op); break;
+                case DSP_OP_UPSAMPLER: op_upsampler(cx, op); break;
+                case DSP_OP_MOVING_WINDOW_MULTI: op_moving_window_multi(cx, op); break;
                 case DSP_OP_TIME_POINT_THRESH: op_time_point_thresh(cx, op); break;
                 case DSP_OP_MIN_MAX: op_min_max(cx, op, false); break;
                 case DSP_OP_AMAX: op_min_max(cx, op, true); break;

@@ -87,6 +87,7 @@ _SIGS = {
     "asym_trap_filter": "wiiiW", "fixed_time_pickoff": "wscS", "time_point_thresh": "wsssS", "min_max": "wSSSS",
     "discrete_wavelet_transform": "wiccW", "convolve_wf": "wtcW", "fft_convolve_wf": "wtcW", "amax": "wiS",
     "mean_below_threshold": "wsS", "windower": "wsW", "avg_current": "wsW", "trap_pickoff": "wiisS",
+    "upsampler": "wsW", "moving_window_multi": "wsiiW", "add": "ssS",
 }
 _GENERATORS = ("cusp_filter", "zac_filter", "t0_filter", "moving_slope")
 _MODULES = ("dspeed.processors", "dspeed_amd.processors", "numpy", "np")
@@ -505,6 +506,16 @@ class _Builder:
                 return ("affine", a, 1.0, b if isinstance(op, ast.Add) else -b)
             if isinstance(b, Var) and b.kind == "scalar" and isinstance(a, (int, float)) and isinstance(op, ast.Add):
                 return ("affine", b, 1.0, a)
+            # per-event scalar (*|/) constant: a multiplication; a division only where multiplying by the reciprocal is the same
+            # operation bit for bit (powers of two: tp_aoe_max / 16 in icpc-dsp-config.json:344)
+            if isinstance(a, Var) and a.kind == "scalar" and isinstance(b, (int, float)) and isinstance(op, ast.Mult):
+                return ("affine", a, float(b), 0.0)
+            if isinstance(b, Var) and b.kind == "scalar" and isinstance(a, (int, float)) and isinstance(op, ast.Mult):
+                return ("affine", b, float(a), 0.0)
+            if isinstance(a, Var) and a.kind == "scalar" and isinstance(b, (int, float)) and isinstance(op, ast.Div) and b != 0:
+                m, e = np.frexp(abs(float(b)))
+                if m == 0.5:
+                    return ("affine", a, 1.0 / float(b), 0.0)
             raise NotImplementedError("expressions on waveforms / between per-event variables are not supported on the device")
         qa, qb = isinstance(a, Quantity), isinstance(b, Quantity)
         fa, fb = float(a), float(b)
@@ -640,7 +651,7 @@ def _add_step(b: _Builder, key, node, new_vars, proc_strings):
         return
     if module not in _MODULES:
         raise NotImplementedError(f"module '{module}' is not available on the device path (processor {module}.{function})")
-    if module in ("numpy", "np") and function != "amax":
+    if module in ("numpy", "np") and function not in ("amax", "add"):
         raise NotImplementedError(f"numpy.{function} is not available on the device path")
     args = [b.eval_arg(a, new_vars) for a in node["args"]]
     if function in _GENERATORS:
@@ -663,7 +674,7 @@ def _add_step(b: _Builder, key, node, new_vars, proc_strings):
         if r == "W" and isinstance(a, Var):
             if a.kind is None:
                 a.kind = "wf"
-            if a.length is None and function not in ("discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "windower", "avg_current"):
+            if a.length is None and function not in ("discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "windower", "avg_current", "upsampler"):
                 a.length = src_len
             if a.period is None:
                 a.period = src_period
@@ -999,6 +1010,29 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             p.add_op(_lib.OP_WINDOWER if fn == "windower" else _lib.OP_AVG_CURRENT, dst=dst.slot, src=src.slot,
                      sp=(scalar_operand(args[1], args, what=what),))
             release(src, si)
+        elif fn == "upsampler":
+            src = ensure_loaded(args[0], si)
+            dst = out_wf(args[2], None, src)
+            if dst.length is None:
+                raise ProcessingChainError("upsampler: declare the output as name(length, 'f')")
+            dst.slot = new_slot(dst.length)
+            p.add_op(_lib.OP_UPSAMPLER, dst=dst.slot, src=src.slot, sp=(scalar_operand(args[1], args, what=what),))
+            release(src, si)
+        elif fn == "moving_window_multi":
+            src = ensure_loaded(args[0], si)
+            num = scalar_operand(args[2], args, integer=True, what=what)
+            typ = scalar_operand(args[3], args, integer=True, what=what)
+            dst = out_wf(args[4], src.length, src)
+            dst.slot = new_slot(src.length)
+            tmp = new_slot(src.length) if num > 1 else dst.slot  # ping-pong target of the passes before the last
+            p.add_op(_lib.OP_MOVING_WINDOW_MULTI, dst=dst.slot, src=src.slot, ip=(typ, num, tmp), sp=(scalar_operand(args[1], args, what=what),))
+            if num > 1 and tmp not in free_slots:
+                free_slots.append(tmp)
+            release(src, si)
+        elif fn == "add":  # numpy.add on per-event scalars (icpc-dsp-config.json:341-346): a * 1 + b, exact
+            o = out_scalar(args[2])
+            p.add_op(_lib.OP_SCALAR_AFFINE, dst=o.sreg, sp=(scalar_operand(args[0], args, what=what), Scalar.const(1.0),
+                                                            scalar_operand(args[1], args, what=what)))
         elif fn == "trap_pickoff":
             src = ensure_loaded(args[0], si)
             ints = [scalar_operand(a, args, integer=True, what=what) for a in args[1:3]]

@@ -242,6 +242,40 @@ def _avg_current(g, *args):
         st.release()
 
 
+def _upsampler(g, *args):
+    if len(args) != 3:
+        raise TypeError("upsampler(w_in, upsample, w_out): w_out must be passed (its length is the output size)")
+    w_in, upsample, w_out = args
+    st = Staging()
+    try:
+        ptr, code, n_wf, n, stride, one_d = st.wf_in(w_in)
+        sfx = loop_suffix(_dtype_of(w_in))
+        ft = _F[sfx]
+        m = w_out.shape[-1]
+        optr, res = st.out(w_out, (m,) if one_d else (n_wf, m), ft)
+        run(entry("upsampler", sfx), g.__name__, ptr, code, n_wf, n, stride, float(np.asarray(upsample).reshape(-1)[0]), optr, m, m)
+        st.finish()
+        return res
+    finally:
+        st.release()
+
+
+def _moving_window_multi(g, *args):
+    ins, outs = _split(g, args)
+    st = Staging()
+    try:
+        ptr, code, n_wf, n, stride, one_d = st.wf_in(ins[0])
+        sfx = loop_suffix(_dtype_of(ins[0]))
+        ft = _F[sfx]
+        optr, res = st.out(outs[0], (n,) if one_d else (n_wf, n), ft)
+        run(entry("moving_window_multi", sfx), g.__name__, ptr, code, n_wf, n, stride, float(np.asarray(ins[1]).reshape(-1)[0]),
+            float(np.asarray(ins[2]).reshape(-1)[0]), _as_int(ins[3], g.__name__), optr, n)
+        st.finish()
+        return res
+    finally:
+        st.release()
+
+
 def _trap_pickoff(g, *args):
     ins, outs = _split(g, args)
     st = Staging()
@@ -357,6 +391,10 @@ windower = HipGUFunc("windower", "(n),(),(m)", ["fff", "ddd"], _windower,
                      "window of len(w_out) samples starting at int(t0_in), NaN outside the input (reference processors/windower.py:12-54)")
 avg_current = HipGUFunc("avg_current", "(n),(),(m)", ["fff", "ddd"], _avg_current,
                         "(w_in[L:] - w_in[:-L]) / length (reference processors/moving_windows.py:206-249)")
+upsampler = HipGUFunc("upsampler", "(n),(),(m)", ["fff", "ddd"], _upsampler,
+                      "every sample repeated int(upsample) times (reference processors/upsampler.py:13-56)")
+moving_window_multi = HipGUFunc("moving_window_multi", "(n),(),(),()->(n)", ["fffi->f", "dddi->d"], _moving_window_multi,
+                                "moving averages applied alternately from the left and the right (reference processors/moving_windows.py:117-204)")
 trap_pickoff = HipGUFunc("trap_pickoff", "(n),(),(),()->()", ["fiif->f", "diid->d"], _trap_pickoff,
                          "normalised difference of two rise-long window sums at an integer pick-off sample (reference processors/trap_filters.py:230-293)")
 def _t0_filter(g, rise, fall, kernel):
@@ -396,4 +434,4 @@ zac_filter = HipGUFunc("zac_filter", "(),(),(),(n)", ["ffff", "dddd"], _zac_filt
                        "zero-area CUSP kernel generator, host, once (reference processors/energy_kernels.py:76-157)")
 
 __all__ = ["bl_subtract", "pole_zero", "double_pole_zero", "trap_filter", "trap_norm", "asym_trap_filter", "fixed_time_pickoff",
-           "time_point_thresh", "min_max", "mean_below_threshold", "windower", "avg_current", "trap_pickoff", "discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "cusp_filter", "zac_filter", "t0_filter", "moving_slope"]
+           "time_point_thresh", "min_max", "mean_below_threshold", "windower", "avg_current", "upsampler", "moving_window_multi", "trap_pickoff", "discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "cusp_filter", "zac_filter", "t0_filter", "moving_slope"]

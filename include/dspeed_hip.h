@@ -60,6 +60,11 @@ extern "C" {
 #define DSP_E_WINDOW_LONG 18   /* windower.py:36-37 */
 #define DSP_E_AVGCUR_RANGE 19  /* moving_windows.py:243-246 */
 #define DSP_E_TPO_INT 20       /* trap_filters.py:270-271       data dependent */
+#define DSP_E_UPSAMPLE 21      /* upsampler.py:47-48 */
+#define DSP_E_MW_LEN_INT 22    /* moving_windows.py:167-168 */
+#define DSP_E_MW_NUM_INT 23    /* moving_windows.py:170-171 */
+#define DSP_E_MW_LEN_RANGE 24  /* moving_windows.py:173-174 */
+#define DSP_E_MW_NUM_NEG 25    /* moving_windows.py:176-177 */
 
 /* ---- element types -------------------------------------------------------------------------- */
 #define DSP_F32 0
@@ -166,6 +171,9 @@ typedef struct dsp_scalar_arg {
 #define DSP_OP_TRAP_REDUCE 24    /* fusion of TRAP_FILTER|TRAP_NORM|ASYM_TRAP (ip[3]) with the min_max and / or time_point_thresh that are its only
                                   * consumers: the filtered waveform is never stored.  dst = first of 4 registers t_min,t_max,a_min,a_max
                                   * (or -1), io = time_point_thresh register (or -1), sp[0..2] = threshold, t_start, walk_forward */
+#define DSP_OP_UPSAMPLER 25      /* upsampler.py:13-56        dst <- every sample of src repeated int(sp[0]) times (constant factor), NaN where nothing lands */
+#define DSP_OP_MOVING_WINDOW_MULTI 26 /* moving_windows.py:117-204  dst <- ip[1] moving averages of src, length sp[0] (constant), ip[0] = mw_type,
+                                  * ip[2] = scratch slot (needed for two or more windows) */
 #define DSP_OP_SCALAR_AFFINE 18 /* sreg[dst] <- sp[0] * sp[1] + sp[2]  (host-folded expressions such as tp_0 + 10*us) */
 
 typedef struct dsp_op {
@@ -234,6 +242,10 @@ int dsp_avg_current_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_l
                         int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_trap_pickoff_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,
                          const float* t_pickoff_dev, float t_pickoff, float* out, void* stream, int64_t* err_row);
+int dsp_upsampler_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float upsample, float* out,
+                      int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_moving_window_multi_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float length, float num_mw,
+                                int32_t mw_type, float* out, int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_mean_below_threshold_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* threshold_dev,
                                  float threshold, float* out, void* stream, int64_t* err_row);
 int dsp_min_max_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float* t_min, float* t_max,
@@ -268,6 +280,10 @@ int dsp_avg_current_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_l
                         int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_trap_pickoff_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,
                          const double* t_pickoff_dev, double t_pickoff, double* out, void* stream, int64_t* err_row);
+int dsp_upsampler_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, double upsample, double* out,
+                      int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_moving_window_multi_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, double length, double num_mw,
+                                int32_t mw_type, double* out, int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_mean_below_threshold_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
                                  const double* threshold_dev, double threshold, double* out, void* stream, int64_t* err_row);
 int dsp_min_max_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, double* t_min, double* t_max,

@@ -179,6 +179,23 @@ def trap_pickoff(w, rise, flat, t_pickoff):
     return out, rc
 
 
+def upsampler(w, upsample, out_len):
+    w = _rows(w)
+    _, ct = _sfx(w.dtype)
+    out = np.empty((w.shape[0], int(out_len)), dtype=w.dtype)
+    rc = _call("upsampler", w.dtype, _p(w), C.c_long(w.shape[0]), C.c_int(w.shape[1]), ct(float(upsample)), _p(out), C.c_int(int(out_len)))
+    return out, rc
+
+
+def moving_window_multi(w, length, num_mw, mw_type):
+    w = _rows(w)
+    _, ct = _sfx(w.dtype)
+    out = np.empty_like(w)
+    rc = _call("moving_window_multi", w.dtype, _p(w), C.c_long(w.shape[0]), C.c_int(w.shape[1]), ct(float(length)), ct(float(num_mw)),
+               C.c_int(int(mw_type)), _p(out))
+    return out, rc
+
+
 def mean_below_threshold(w, threshold):
     w = _rows(w)
     thr, st = _vec(threshold, w.shape[0], w.dtype)

@@ -40,7 +40,12 @@ enum {
     ORC_E_ZERODIV = 17,      /* numba error_model='python': x / 0 raises ZeroDivisionError */
     ORC_E_WINDOW_LONG = 18,  /* windower.py:36-37 */
     ORC_E_AVGCUR_RANGE = 19, /* moving_windows.py:243-246 */
-    ORC_E_TPO_INT = 20       /* trap_filters.py:270-271 */
+    ORC_E_TPO_INT = 20,      /* trap_filters.py:270-271 */
+    ORC_E_UPSAMPLE = 21,     /* upsampler.py:47-48 */
+    ORC_E_MW_LEN_INT = 22,   /* moving_windows.py:167-168 */
+    ORC_E_MW_NUM_INT = 23,   /* moving_windows.py:170-171 */
+    ORC_E_MW_LEN_RANGE = 24, /* moving_windows.py:173-174 */
+    ORC_E_MW_NUM_NEG = 25    /* moving_windows.py:176-177 */
 };
 
 #define ORC_DECL(T, S)                                                                                                         \
@@ -59,6 +64,8 @@ enum {
     int orc_avg_current_##S(const T* in, long n_wf, int len, T length, T* out, int m, long* err_row);                         \
     int orc_trap_pickoff_##S(const T* in, long n_wf, int len, int rise, int flat, const T* tp, int tp_stride, T* out,         \
                              long* err_row);                                                                                  \
+    int orc_upsampler_##S(const T* in, long n_wf, int len, T upsample, T* out, int m, long* err_row);                         \
+    int orc_moving_window_multi_##S(const T* in, long n_wf, int len, T length, T num_mw, int mw_type, T* out, long* err_row); \
     int orc_mean_below_threshold_##S(const T* in, long n_wf, int len, const T* thr, int thr_stride, T* out, long* err_row);   \
     int orc_convolve_##S(const T* in, long n_wf, int len, long in_row_stride, const T* kern, int m, int mode, T* out, int p,  \
                          long* err_row);                                                                                      \

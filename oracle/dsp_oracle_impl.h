@@ -302,6 +302,52 @@ static int FN(row_trap_pickoff)(const T* w_in, int n, int rise, int flat, T t_pi
     return 0;
 }
 
+/* upsampler.py:13-56: every input sample is written to int(upsample) consecutive outputs starting at
+ * int(t_in * upsample - floor(upsample / 2)) (int64 * T -> float64; int() truncates toward zero); untouched outputs stay NaN */
+static int FN(row_upsampler)(const T* w_in, int n, T upsample, T* w_out, int m) {
+    FN(fill_nan)(w_out, m);
+    if (FN(row_has_nan)(w_in, n)) return 0;
+    if (!(upsample > 0)) return ORC_E_UPSAMPLE;
+    const double half = floor((double)upsample / 2.0);
+    const long cnt = (long)upsample;
+    for (long t = 0; t < n; ++t) {
+        long t_out = (long)((double)t * (double)upsample - half);
+        for (long k = 0; k < cnt; ++k, ++t_out)
+            if (t_out >= 0 && t_out < m) w_out[t_out] = w_in[t];
+    }
+    return 0;
+}
+
+/* moving_windows.py:117-204 moving_window_multi: num_mw moving averages of `length` samples, alternately from the left and from the
+ * right (mw_type 0), only left (1) or only right (2).  All in T: w_out[i] = w_out[i-1] + (w_buf[i] - w_buf[i-L]) / length with one
+ * rounding per operation and feedback through the output array; the first L samples subtract w_buf[0] instead. */
+static int FN(row_moving_window_multi)(const T* w_in, int n, T length, T num_mw, int mw_type, T* w_out) {
+    FN(fill_nan)(w_out, n);
+    if (FN(row_has_nan)(w_in, n)) return 0;
+    if (floor((double)length) != (double)length) return ORC_E_MW_LEN_INT;
+    if (floor((double)num_mw) != (double)num_mw) return ORC_E_MW_NUM_INT;
+    const long L = (long)length;
+    if (L < 0 || L >= n) return ORC_E_MW_LEN_RANGE;
+    if ((long)num_mw < 0) return ORC_E_MW_NUM_NEG;
+    if ((long)num_mw > 0 && L == 0) return ORC_E_ZERODIV; /* numba error_model='python': (x - x) / 0.0 raises (L >= 1 below) */
+    T* buf = (T*)malloc(sizeof(T) * (size_t)n);
+    memcpy(buf, w_in, sizeof(T) * (size_t)n);
+    for (long p = 0; p < (long)num_mw; ++p) {
+        if (((p % 2 == 1) && mw_type == 0) || mw_type == 2) {
+            w_out[n - 1] = buf[n - 1];
+            for (long i = 1; i < L; ++i) w_out[n - 1 - i] = w_out[n - i] + (T)(buf[n - 1 - i] - w_out[n - 1]) / length;
+            for (long i = L; i < n; ++i) w_out[n - 1 - i] = w_out[n - i] + (T)(buf[n - 1 - i] - buf[n - 1 - i + L]) / length;
+        } else {
+            w_out[0] = buf[0];
+            for (long i = 1; i < L; ++i) w_out[i] = w_out[i - 1] + (T)(buf[i] - buf[0]) / length;
+            for (long i = L; i < n; ++i) w_out[i] = w_out[i - 1] + (T)(buf[i] - buf[i - L]) / length;
+        }
+        memcpy(buf, w_out, sizeof(T) * (size_t)n);
+    }
+    free(buf);
+    return 0;
+}
+
 /* arithmetic.py:9-62 mean_below_threshold: `total = 0.0` is float64 and stays float64 (float64 += T), `count` int64,
  * result = total / count (float64 / int64 -> float64) rounded by the store; NaN if nothing is below the threshold. */
 static int FN(row_mean_below_threshold)(const T* w_in, int n, T threshold, T* result) {
@@ -439,6 +485,12 @@ int FN(orc_avg_current)(const T* in, long n_wf, int len, T length, T* out, int m
 }
 int FN(orc_trap_pickoff)(const T* in, long n_wf, int len, int rise, int flat, const T* tp, int tp_stride, T* out, long* err_row) {
     ROWLOOP(FN(row_trap_pickoff)(in + r * len, len, rise, flat, PV(tp, r), out + r))
+}
+int FN(orc_upsampler)(const T* in, long n_wf, int len, T upsample, T* out, int m, long* err_row) {
+    ROWLOOP(FN(row_upsampler)(in + r * len, len, upsample, out + r * (long)m, m))
+}
+int FN(orc_moving_window_multi)(const T* in, long n_wf, int len, T length, T num_mw, int mw_type, T* out, long* err_row) {
+    ROWLOOP(FN(row_moving_window_multi)(in + r * len, len, length, num_mw, mw_type, out + r * len))
 }
 int FN(orc_mean_below_threshold)(const T* in, long n_wf, int len, const T* thr, int thr_stride, T* out, long* err_row) {
     ROWLOOP(FN(row_mean_below_threshold)(in + r * len, len, PV(thr, r), out + r))

@@ -484,6 +484,36 @@ def gen_windows():
     b.save()
 
 
+def gen_current():
+    """upsampler, moving_window_multi (the A/E branch, icpc-dsp-config.json:323-334)"""
+    rng = np.random.default_rng(0xC0FFEE)
+    b = Book("current")
+    mu, mv = _ref("upsampler"), _ref("moving_windows")
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        w = (100 * rng.standard_normal(300) + 50 * np.sin(np.arange(300) / 9.0)).astype(dt)
+        wn = w.copy()
+        wn[17] = np.nan
+        k = 0
+        # numba: t_in * upsample is int64 * T -> float64, upsample / 2 is T / int -> float64: feed the T value as a float64 scalar
+        for src, up, m in [(w, 16, 4800), (w, 16, 4784), (w, 16, 5000), (w, 1, 300), (w, 2, 600), (w, 3, 900), (w, 2.5, 750), (w, 0.5, 150),
+                           (w, 16, 100), (wn, 4, 1200), (w, 0, 10), (w, -2, 10)]:
+            out = np.empty(m, dtype=dt)
+            fatal = run_body(mu.upsampler, src, np.float64(dt(up)), out)
+            b.add(f"{tag}_up{k}", "upsampler", tag, {"w_in": src, "w_out": out}, {"upsample": float(dt(up))}, fatal)
+            k += 1
+        k = 0
+        wl = (100 * rng.standard_normal(4800) + 3000 * np.exp(-((np.arange(4800) - 2400) / 300.0) ** 2)).astype(dt)
+        for src, L, num, typ in [(w, 5, 1, 1), (w, 5, 1, 2), (w, 5, 2, 0), (w, 5, 3, 0), (w, 1, 3, 0), (w, 2, 4, 0), (w, 299, 1, 1), (wl, 48, 3, 0),
+                                 (wl, 48, 3, 1), (wl, 48, 3, 2), (wl, 100, 5, 0), (w, 5, 0, 0), (wn, 5, 3, 0), (w, 5.5, 3, 0), (w, 5, 2.5, 0),
+                                 (w, 300, 3, 0), (w, -1, 3, 0), (w, 5, -1, 0)]:
+            out = np.empty(len(src), dtype=dt)
+            with np.errstate(all="ignore"):
+                fatal = run_body(mv.moving_window_multi, src, dt(L), dt(num), np.int32(typ), out)
+            b.add(f"{tag}_mw{k}", "moving_window_multi", tag, {"w_in": src, "w_out": out}, {"length": float(L), "num_mw": float(num), "mw_type": typ}, fatal)
+            k += 1
+    b.save()
+
+
 def gen_kernels():
     """t0_filter, moving_slope (object-mode generators, kernels.py): float32 scalars arrive as Python floats"""
     b = Book("kernels")
@@ -662,6 +692,9 @@ def main():
     if "--kernels" in sys.argv:
         gen_kernels()
         return
+    if "--current" in sys.argv:
+        gen_current()
+        return
     rng = np.random.default_rng(0xD5BEED)
     gen_elementwise(rng)
     gen_pole_zero(rng)
@@ -673,6 +706,7 @@ def main():
     gen_arithmetic()
     gen_windows()
     gen_kernels()
+    gen_current()
 
 
 if __name__ == "__main__":

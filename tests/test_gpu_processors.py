@@ -149,6 +149,30 @@ def test_windows_golden(c, P, DSPFatal):
             _eq(out, want, c.name)
 
 
+@pytest.mark.parametrize("c", cases("current"), ids=lambda c: c.name)
+def test_current_branch_golden(c, P, DSPFatal):
+    """upsampler and moving_window_multi against fixtures made from the reference bodies"""
+    p = c.params
+    if c.kernel == "upsampler":
+        out = _expect(c, DSPFatal, lambda: P.upsampler(c["w_in"], p["upsample"], np.empty_like(c["w_out"])))
+        if out is not None:
+            _eq(out, c["w_out"], c.name)
+    else:
+        out = _expect(c, DSPFatal, lambda: P.moving_window_multi(c["w_in"], p["length"], p["num_mw"], p["mw_type"]))
+        if out is not None:  # float32 feedback through the output: rounding replay, like trap_filter
+            assert_rel_to_peak(out, c["w_out"], _tol(c), c.name)
+
+
+def test_moving_window_multi_vs_oracle(P):
+    rng = np.random.default_rng(44)
+    x = (50 * rng.standard_normal((120, 4784)) + 2000 * np.exp(-((np.arange(4784)[None, :] - rng.uniform(1500, 3500, (120, 1))) / 200.0) ** 2)).astype(np.float32)
+    x[5, 7] = np.nan
+    for L, num, typ in ((48, 3, 0), (48, 1, 2), (7, 2, 1), (1, 4, 0), (300, 2, 0)):
+        got, want = P.moving_window_multi(x, L, num, typ), oracle.moving_window_multi(x, L, num, typ)[0]
+        assert_rel_to_peak(got, want, FILTER_TOL, f"mwm {L} {num} {typ}")
+    _eq(P.upsampler(x[:, :299], 16, np.empty((120, 4784), dtype=np.float32)), oracle.upsampler(x[:, :299], 16, 4784)[0], "upsampler")
+
+
 def test_windows_vs_oracle_per_event(P):
     """per-event window starts and pick-off samples over many rows, both loops"""
     rng = np.random.default_rng(12)

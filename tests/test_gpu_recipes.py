@@ -228,6 +228,33 @@ def test_trapezoid_fused_with_its_reductions_equals_the_unfused_ops(trap, targs)
     assert ei.value.wf_range == range(40, 41)
 
 
+def test_current_branch_of_the_icpc_recipe():
+    """the A/E branch as the production recipe writes it (icpc-dsp-config.json:306-346): windower -> avg_current -> upsampler ->
+    moving_window_multi -> min_max -> numpy.add, one device program, against the oracle run processor by processor"""
+    rng = np.random.default_rng(61)
+    x, bl, t0 = _synth(rng, 80, 4096)
+    wf = x.astype(np.float32)
+    est = (t0 - 100).astype(np.float32)
+    M = "dspeed.processors"
+    rec = {"outputs": ["A_max", "tp_aoe_samp"], "processors": {
+        "wf_pz": f"{M}.pole_zero(waveform, 1716.28, wf_pz)",
+        "wf_le": f"{M}.windower(wf_pz, tp_0_est, wf_le(301, 'f'))",
+        "curr": f"{M}.avg_current(wf_le, 1, curr(300, 'f'))",
+        "curr_up": f"{M}.upsampler(curr, 16, curr_up(4784, 'f'))",
+        "curr_av": f"{M}.moving_window_multi(curr_up, 48, 3, 0, curr_av)",
+        "aoe_t_min, tp_aoe_max, A_min, A_max": {"function": "min_max", "module": M, "args": ["curr_av", "aoe_t_min", "tp_aoe_max", "A_min", "A_max"]},
+        "tp_aoe_samp": {"function": "add", "module": "numpy", "args": ["tp_0_est", "tp_aoe_max/16", "tp_aoe_samp"]}}}
+    _, out = _run(rec, {"waveform": wf, "tp_0_est": est})
+    pz = oracle.pole_zero(wf, 1716.28)[0]
+    le = oracle.windower(pz, est, 301)[0]
+    cur = oracle.avg_current(le, 1)[0]
+    up = oracle.upsampler(cur, 16, 4784)[0]
+    av = oracle.moving_window_multi(up, 48, 3, 0)[0]
+    tmin, tmax, amin, amax, _ = oracle.min_max(av)
+    assert np.max(np.abs(out["A_max"] - amax) / np.abs(amax)) <= 1e-5
+    assert np.all(np.abs(out["tp_aoe_samp"] - (est + tmax / 16)) <= 1.0)
+
+
 def test_current_branch_recipe_pieces():
     """windower -> avg_current -> min_max (the first steps of the A/E branch, icpc-dsp-config.json:294-346) and trap_pickoff in one
     recipe; a window that reaches past the input makes NaN samples there, and every consumer of it NaN, as in the reference"""

@@ -220,6 +220,17 @@ def test_golden_windows(c):
     _eq(out[0], want, c.name)
 
 
+@pytest.mark.parametrize("c", cases("current"), ids=lambda c: c.name)
+def test_golden_current_branch(c):
+    p = c.params
+    if c.kernel == "upsampler":
+        out, rc = oracle.upsampler(c["w_in"], p["upsample"], c["w_out"].shape[-1])
+    else:
+        out, rc = oracle.moving_window_multi(c["w_in"], p["length"], p["num_mw"], p["mw_type"])
+    _check_fatal(c, rc)
+    _eq(out[0], c["w_out"], c.name)
+
+
 @pytest.mark.parametrize("c", cases("arithmetic"), ids=lambda c: c.name)
 def test_golden_mean_below_threshold(c):
     out, rc = oracle.mean_below_threshold(c["w_in"], c.params["threshold"])
