@@ -629,6 +629,10 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             case DSP_OP_MIN_MAX:
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst + 3 >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad MIN_MAX", i);
                 break;
+            case DSP_OP_LINEAR_SLOPE_FIT:
+                if (!check_slot(P, o.src) || o.dst < 0 || o.dst + 3 >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad LINEAR_SLOPE_FIT", i);
+                if (slot_len[o.src] < 2) return fail(DSP_E_ZERODIV, "%s", dsp_fatal_message(DSP_E_ZERODIV));  // the line fit's denominator
+                break;
             case DSP_OP_AMAX:
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad AMAX", i);
                 break;
@@ -1190,6 +1194,22 @@ int g_moving_window_multi(int ty, const WfIn& in, double length, double num_mw, 
     m.add_op(DSP_OP_STORE, 0, s_out, io_out);
     return m.run(in.n_wf, st, er);
 }
+int g_linear_slope_fit(int ty, const WfIn& in, void* mean, void* stdev, void* slope, void* intercept, void* st, int64_t* er) {
+    if (in.n_wf <= 0) return DSP_OK;
+    Mini m(ty);
+    m.n_sregs = 4;
+    const int s_in = m.add_slot(in.len);
+    const int io_in = m.add_io(DSP_IO_WF_IN, in.dtype, in.len, in.stride, in.ptr);
+    m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
+    m.add_op(DSP_OP_LINEAR_SLOPE_FIT, 0, s_in, 0);
+    void* outs[4] = {mean, stdev, slope, intercept};
+    for (int k = 0; k < 4; ++k) {
+        const int io_out = m.add_io(DSP_IO_SCALAR_OUT, ty, 1, 1, outs[k]);
+        dsp_op& sto = m.add_op(DSP_OP_STORE_SCALAR, 0, 0, io_out);
+        sto.ip[0] = k;
+    }
+    return m.run(in.n_wf, st, er);
+}
 int g_mean_below(int ty, const WfIn& in, const void* thr_dev, double thr, void* out, void* st, int64_t* er) {
     if (in.n_wf <= 0) return DSP_OK;
     Mini m(ty);
@@ -1282,6 +1302,10 @@ int g_min_max(int ty, const WfIn& in, void* t_min, void* t_max, void* a_min, voi
                                       int32_t mw_type, FT* out, int64_t out_stride, void* stream, int64_t* err_row) {                         \
         return g_moving_window_multi(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, (double)length, (double)num_mw, mw_type, out,          \
                                      out_stride, stream, err_row);                                                                           \
+    }                                                                                                                                         \
+    int dsp_linear_slope_fit_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, FT* mean, FT* stdev,       \
+                                   FT* slope, FT* intercept, void* stream, int64_t* err_row) {                                                \
+        return g_linear_slope_fit(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, mean, stdev, slope, intercept, stream, err_row);           \
     }                                                                                                                                         \
     int dsp_mean_below_threshold_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,                        \
                                        const FT* threshold_dev, FT threshold, FT* out, void* stream, int64_t* err_row) {                      \

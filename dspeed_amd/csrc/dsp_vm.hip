@@ -933,6 +933,69 @@ __device__ __forceinline__ void op_moving_window_multi(Ctx<T>& cx, const DSP_GLO
 }
 
 // ------------------------------------------------------------------------------------------------
+// linear_slope_fit (processors/linear_slope_fit.py:11-91): Welford mean / variance and a least-squares line.
+// The mean and the variance feed back through float32 (T) accumulators that round after every sample, and the update
+// mean += (x - mean) / (i + 1) does not commute with a shift of its state (it contracts it), so unlike the trapezoids there is no
+// parallel replay: the recurrence is run sample by sample, by every lane redundantly (the LDS reads are broadcasts).  That makes
+// this the slowest op of the VM by far (a float64 division per sample on a dependent chain); a lane-per-waveform kernel is the
+// right shape for it.  The regression sums are float64 and order-free: lanes take their chunks, one wavefront scan.
+// Typing as numba resolves it (PARITY UNPINNED, see oracle/dsp_oracle_impl.h): temp, the products and the accumulators in T,
+// temp / (i + 1) and stdev / (n - 1) in float64 rounded back to T.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void op_linear_slope_fit(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    const int n = ss.len, C = ss.C, lane = lane_id();
+    T o_mean = quiet_nan<T>(), o_std = o_mean, o_slope = o_mean, o_icpt = o_mean;
+    if (!cx.slot_nan(op.src)) {
+        // regression sums
+        const auto* ps = cx.chunk(ss);
+        double sy = 0.0, sxy = 0.0;
+#pragma unroll 8
+        for (int t = 0; t < C; ++t) {
+            const int i = lane * C + t;
+            if (i < n) {
+                const double x = (double)ps[t];
+                sy += x;
+                sxy += x * (double)i;
+            }
+        }
+        sy = readlane(wave_scan_add(sy), 63);
+        sxy = readlane(wave_scan_add(sxy), 63);
+        // Welford, sequential
+        T m = (T)0, s = (T)0;
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            T x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = cx.lds[padded_index(ss, i0 + u < n ? i0 + u : n - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u < n) {
+                    const T temp = x[u] - m;
+                    m = (T)((double)m + (double)temp / (double)(i0 + u + 1));
+                    s = s + temp * (x[u] - m);
+                }
+            }
+        }
+        s = (T)((double)s / (double)(n - 1));
+        s = (T)sqrt((double)s);
+        const long long nn = n, sum_x = nn * (nn - 1) / 2, sum_x2 = (nn - 1) * nn * (2 * nn - 1) / 6;
+        o_mean = m;
+        o_std = s;
+        o_slope = (T)(((double)nn * sxy - (double)sum_x * sy) / (double)(nn * sum_x2 - sum_x * sum_x));
+        o_icpt = (T)((sy - (double)sum_x * (double)o_slope) / (double)nn);
+    }
+    if (lane == 0) {
+        auto* r = cx.sregs();
+        r[op.dst] = o_mean;
+        r[op.dst + 1] = o_std;
+        r[op.dst + 2] = o_slope;
+        r[op.dst + 3] = o_icpt;
+    }
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
 // mean_below_threshold (processors/arithmetic.py:9-62): float64 total of the samples below the threshold / their count.
 // The reference adds them one by one; here per-lane partial sums and a wavefront scan.  For float32 samples of one
 // waveform's dynamic range the float64 sums are exact, hence order independent; otherwise the last float64 bit may differ.
@@ -1338,6 +1401,7 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 4) dsp_vm_kernel(const DevProgr
                 case DSP_OP_TRAP_PICKOFF: op_trap_pickoff(cx, op); break;
                 case DSP_OP_TRAP_REDUCE: op_trap_reduce(cx, op); break;
                 case DSP_OP_UPSAMPLER: op_upsampler(cx, op); break;
+                case DSP_OP_LINEAR_SLOPE_FIT: op_linear_slope_fit(cx, op); break;
                 case DSP_OP_MOVING_WINDOW_MULTI: op_moving_window_multi(cx, op); break;
                 case DSP_OP_TIME_POINT_THRESH: op_time_point_thresh(cx, op); break;
                 case DSP_OP_MIN_MAX: op_min_max(cx, op, false); break;

@@ -87,7 +87,7 @@ _SIGS = {
     "asym_trap_filter": "wiiiW", "fixed_time_pickoff": "wscS", "time_point_thresh": "wsssS", "min_max": "wSSSS",
     "discrete_wavelet_transform": "wiccW", "convolve_wf": "wtcW", "fft_convolve_wf": "wtcW", "amax": "wiS",
     "mean_below_threshold": "wsS", "windower": "wsW", "avg_current": "wsW", "trap_pickoff": "wiisS",
-    "upsampler": "wsW", "moving_window_multi": "wsiiW", "add": "ssS",
+    "upsampler": "wsW", "moving_window_multi": "wsiiW", "add": "ssS", "linear_slope_fit": "wSSSS",
 }
 _GENERATORS = ("cusp_filter", "zac_filter", "t0_filter", "moving_slope")
 _MODULES = ("dspeed.processors", "dspeed_amd.processors", "numpy", "np")
@@ -1043,6 +1043,15 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             src = ensure_loaded(args[0], si)
             o = out_scalar(args[2])
             p.add_op(_lib.OP_MEAN_BELOW, dst=o.sreg, src=src.slot, sp=(scalar_operand(args[1], args, what=what),))
+            release(src, si)
+        elif fn == "linear_slope_fit":
+            src = ensure_loaded(args[0], si)
+            first = p.add_sregs(4)
+            for k, a in enumerate(args[1:5]):
+                if not isinstance(a, Var):
+                    raise ProcessingChainError("linear_slope_fit outputs must be variable names")
+                a.kind, a.sreg = "scalar", first + k
+            p.add_op(_lib.OP_LINEAR_SLOPE_FIT, dst=first, src=src.slot)
             release(src, si)
         elif fn == "amax":
             src = ensure_loaded(args[0], si)

@@ -174,6 +174,8 @@ typedef struct dsp_scalar_arg {
 #define DSP_OP_UPSAMPLER 25      /* upsampler.py:13-56        dst <- every sample of src repeated int(sp[0]) times (constant factor), NaN where nothing lands */
 #define DSP_OP_MOVING_WINDOW_MULTI 26 /* moving_windows.py:117-204  dst <- ip[1] moving averages of src, length sp[0] (constant), ip[0] = mw_type,
                                   * ip[2] = scratch slot (needed for two or more windows) */
+#define DSP_OP_LINEAR_SLOPE_FIT 27 /* linear_slope_fit.py:11-91  sreg[dst..dst+3] <- mean, stdev (Welford, in the reference's rounding
+                                  * sequence), slope, intercept of src */
 #define DSP_OP_SCALAR_AFFINE 18 /* sreg[dst] <- sp[0] * sp[1] + sp[2]  (host-folded expressions such as tp_0 + 10*us) */
 
 typedef struct dsp_op {
@@ -246,6 +248,8 @@ int dsp_upsampler_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len
                       int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_moving_window_multi_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float length, float num_mw,
                                 int32_t mw_type, float* out, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_linear_slope_fit_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float* mean, float* stdev,
+                             float* slope, float* intercept, void* stream, int64_t* err_row);
 int dsp_mean_below_threshold_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* threshold_dev,
                                  float threshold, float* out, void* stream, int64_t* err_row);
 int dsp_min_max_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float* t_min, float* t_max,
@@ -284,6 +288,8 @@ int dsp_upsampler_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len
                       int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_moving_window_multi_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, double length, double num_mw,
                                 int32_t mw_type, double* out, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_linear_slope_fit_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, double* mean, double* stdev,
+                             double* slope, double* intercept, void* stream, int64_t* err_row);
 int dsp_mean_below_threshold_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
                                  const double* threshold_dev, double threshold, double* out, void* stream, int64_t* err_row);
 int dsp_min_max_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, double* t_min, double* t_max,

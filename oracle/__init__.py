@@ -196,6 +196,14 @@ def moving_window_multi(w, length, num_mw, mw_type):
     return out, rc
 
 
+def linear_slope_fit(w):
+    """PARITY UNPINNED (see dsp_oracle_impl.h): numba's typing of this body is restated from its rules, not executed"""
+    w = _rows(w)
+    o = [np.empty(w.shape[0], dtype=w.dtype) for _ in range(4)]
+    rc = _call("linear_slope_fit", w.dtype, _p(w), C.c_long(w.shape[0]), C.c_int(w.shape[1]), *[_p(x) for x in o])
+    return (*o, rc)
+
+
 def mean_below_threshold(w, threshold):
     w = _rows(w)
     thr, st = _vec(threshold, w.shape[0], w.dtype)

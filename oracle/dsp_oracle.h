@@ -66,6 +66,7 @@ enum {
                              long* err_row);                                                                                  \
     int orc_upsampler_##S(const T* in, long n_wf, int len, T upsample, T* out, int m, long* err_row);                         \
     int orc_moving_window_multi_##S(const T* in, long n_wf, int len, T length, T num_mw, int mw_type, T* out, long* err_row); \
+    int orc_linear_slope_fit_##S(const T* in, long n_wf, int len, T* mean, T* stdev, T* slope, T* intercept, long* err_row);  \
     int orc_mean_below_threshold_##S(const T* in, long n_wf, int len, const T* thr, int thr_stride, T* out, long* err_row);   \
     int orc_convolve_##S(const T* in, long n_wf, int len, long in_row_stride, const T* kern, int m, int mode, T* out, int p,  \
                          long* err_row);                                                                                      \

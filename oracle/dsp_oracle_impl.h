@@ -348,6 +348,36 @@ static int FN(row_moving_window_multi)(const T* w_in, int n, T length, T num_mw,
     return 0;
 }
 
+/* linear_slope_fit.py:11-91.  PARITY UNPINNED: the reference has no test for it and its nopython typing cannot be executed here
+ * (numba is not importable); this follows numba's documented rules as analysed in DESIGN.md: `mean`/`stdev` are 1-element T arrays
+ * used as accumulators, `temp = w_in[i] - mean` is a T array expression, `temp / (i + 1)` is array(T) / int64 -> float64 and the
+ * in-place add casts back to T; `stdev += temp * (w_in[i] - mean)` is all T; sum_xy, sum_y unify to float64, sum_x, sum_x2 stay
+ * int64; `stdev /= isum - 1` divides in float64 and casts back, np.sqrt works in T. */
+static int FN(row_linear_slope_fit)(const T* w_in, int n, T* mean, T* stdev, T* slope, T* intercept) {
+    *mean = *stdev = *slope = *intercept = (T)NAN;
+    if (FN(row_has_nan)(w_in, n)) return 0;
+    if (n < 2) return ORC_E_ZERODIV; /* the regression denominator isum*sum_x2 - sum_x**2 is the int64 0: ZeroDivisionError */
+    T m = (T)0, s = (T)0;
+    double sum_xy = 0.0, sum_y = 0.0;
+    long long sum_x = 0, sum_x2 = 0;
+    for (long long i = 0; i < n; ++i) {
+        const T temp = (T)(w_in[i] - m);
+        m = (T)((double)m + (double)temp / (double)(i + 1));
+        s = (T)(s + (T)(temp * (T)(w_in[i] - m)));
+        sum_x += i;
+        sum_x2 += i * i;
+        sum_xy += (double)w_in[i] * (double)i;
+        sum_y += (double)w_in[i];
+    }
+    s = (T)((double)s / (double)(n - 1));
+    s = (T)sqrt((double)s); /* (correctly rounded either way: sqrtf(x) == (float)sqrt((double)x)) */
+    *mean = m;
+    *stdev = s;
+    *slope = (T)(((double)n * sum_xy - (double)sum_x * sum_y) / (double)((long long)n * sum_x2 - sum_x * sum_x));
+    *intercept = (T)((sum_y - (double)sum_x * (double)*slope) / (double)n);
+    return 0;
+}
+
 /* arithmetic.py:9-62 mean_below_threshold: `total = 0.0` is float64 and stays float64 (float64 += T), `count` int64,
  * result = total / count (float64 / int64 -> float64) rounded by the store; NaN if nothing is below the threshold. */
 static int FN(row_mean_below_threshold)(const T* w_in, int n, T threshold, T* result) {
@@ -491,6 +521,9 @@ int FN(orc_upsampler)(const T* in, long n_wf, int len, T upsample, T* out, int m
 }
 int FN(orc_moving_window_multi)(const T* in, long n_wf, int len, T length, T num_mw, int mw_type, T* out, long* err_row) {
     ROWLOOP(FN(row_moving_window_multi)(in + r * len, len, length, num_mw, mw_type, out + r * len))
+}
+int FN(orc_linear_slope_fit)(const T* in, long n_wf, int len, T* mean, T* stdev, T* slope, T* intercept, long* err_row) {
+    ROWLOOP(FN(row_linear_slope_fit)(in + r * len, len, mean + r, stdev + r, slope + r, intercept + r))
 }
 int FN(orc_mean_below_threshold)(const T* in, long n_wf, int len, const T* thr, int thr_stride, T* out, long* err_row) {
     ROWLOOP(FN(row_mean_below_threshold)(in + r * len, len, PV(thr, r), out + r))

@@ -514,6 +514,55 @@ def gen_current():
     b.save()
 
 
+def gen_linear_slope_fit():
+    """PARITY UNPINNED.  linear_slope_fit's nopython typing (in-place array expressions mixing float32 arrays with int64 scalars)
+    cannot be reproduced by running the reference body under NumPy 2 -- `temp / (i + 1)` is float32 there, float64 in numba -- so
+    these fixtures come from an explicit emulation of numba's rules (the same rules the C oracle restates), and the result of the
+    plain NumPy-2 execution of the reference body is stored beside them (`numpy2_*`) to show the size of the difference."""
+    rng = np.random.default_rng(0x5107E)
+    b = Book("linear_slope_fit")
+    ref = _ref("linear_slope_fit")
+
+    def emulate(w):
+        T = w.dtype.type
+        m, s = T(0), T(0)
+        sxy, sy, sx, sx2 = np.float64(0), np.float64(0), 0, 0
+        n = len(w)
+        for i in range(n):
+            temp = T(w[i] - m)
+            m = T(np.float64(m) + np.float64(temp) / np.float64(i + 1))
+            s = T(s + T(temp * T(w[i] - m)))
+            sx += i
+            sx2 += i * i
+            sxy += np.float64(w[i]) * np.float64(i)
+            sy += np.float64(w[i])
+        with np.errstate(all="ignore"):
+            s = np.sqrt(T(np.float64(s) / np.float64(n - 1)))
+            slope = T((np.float64(n) * sxy - np.float64(sx) * sy) / np.float64(n * sx2 - sx * sx))
+            icpt = T((sy - np.float64(sx) * np.float64(slope)) / np.float64(n))
+        return np.array([m, s, slope, icpt], dtype=w.dtype)
+
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        cases = [np.array([1, 2, 3, 4, 5.0], dtype=dt), np.array([7.0, 7.0], dtype=dt), np.arange(100, dtype=dt) * 3 - 20]
+        for n in (750, 1650, 6692):
+            cases.append(synth_waveforms(rng, 1, n, dtype=dt)[0][0])
+        cases.append((10000 + 5 * rng.standard_normal(750) + 0.02 * np.arange(750)).astype(dt))
+        wn = cases[3].copy()
+        wn[5] = np.nan
+        cases.append(wn)
+        for k, w in enumerate(cases):
+            if np.isnan(w).any():
+                out = np.full(4, np.nan, dtype=dt)
+            else:
+                out = emulate(w)
+            o = [np.empty(1, dtype=dt) for _ in range(4)]
+            with np.errstate(all="ignore"):
+                run_body(ref.linear_slope_fit, w, *o)
+            b.add(f"{tag}_lsf{k}", "linear_slope_fit", tag, {"w_in": w, "out": out, "numpy2_out": np.array([x[0] for x in o], dtype=dt)}, {},
+                  False, note="out = mean, stdev, slope, intercept under numba typing (emulated); numpy2_out = the body run under NumPy 2")
+    b.save()
+
+
 def gen_kernels():
     """t0_filter, moving_slope (object-mode generators, kernels.py): float32 scalars arrive as Python floats"""
     b = Book("kernels")
@@ -695,6 +744,9 @@ def main():
     if "--current" in sys.argv:
         gen_current()
         return
+    if "--lsf" in sys.argv:
+        gen_linear_slope_fit()
+        return
     rng = np.random.default_rng(0xD5BEED)
     gen_elementwise(rng)
     gen_pole_zero(rng)
@@ -707,6 +759,7 @@ def main():
     gen_windows()
     gen_kernels()
     gen_current()
+    gen_linear_slope_fit()
 
 
 if __name__ == "__main__":

@@ -149,6 +149,33 @@ def test_windows_golden(c, P, DSPFatal):
             _eq(out, want, c.name)
 
 
+@pytest.mark.parametrize("c", cases("linear_slope_fit"), ids=lambda c: c.name)
+def test_linear_slope_fit_golden(c, P):
+    """(fixtures restate numba's typing, see oracle/gen_golden.py: parity with the reference is unpinned for this processor)
+    mean and standard deviation run the same sequence of IEEE operations as the oracle: identical bits; slope and intercept come from
+    float64 sums taken in another order"""
+    mean, std, slope, icpt = P.linear_slope_fit(c["w_in"])
+    want = c["out"]
+    _eq(np.array([mean, std]), want[:2], c.name)
+    tol = 1e-6 if c.tag == "f32" else 1e-12
+    scale = np.nanmax(np.abs(c["w_in"]))
+    assert np.isclose(slope, want[2], rtol=tol, atol=tol * scale / max(c["w_in"].size, 1), equal_nan=True), c.name
+    assert np.isclose(icpt, want[3], rtol=tol, atol=tol * scale, equal_nan=True), c.name
+
+
+def test_linear_slope_fit_vs_oracle_rows(P):
+    rng = np.random.default_rng(91)
+    x = (10000 + 5 * rng.standard_normal((100, 750)) + rng.uniform(-0.02, 0.02, (100, 1)) * np.arange(750)[None, :]).astype(np.float32)
+    x[3, 100] = np.nan
+    got = P.linear_slope_fit(x)
+    want = oracle.linear_slope_fit(x)
+    _eq(got[0], want[0], "mean")
+    _eq(got[1], want[1], "stdev")
+    ok = ~np.isnan(want[2])
+    assert np.array_equal(np.isnan(got[2]), ~ok) and np.isnan(got[3][3])
+    assert np.max(np.abs(got[2][ok] - want[2][ok])) <= 1e-6 * 0.02 + 1e-9 and np.max(np.abs(got[3][ok] - want[3][ok]) / 10000) <= 1e-6
+
+
 @pytest.mark.parametrize("c", cases("current"), ids=lambda c: c.name)
 def test_current_branch_golden(c, P, DSPFatal):
     """upsampler and moving_window_multi against fixtures made from the reference bodies"""

@@ -228,6 +228,33 @@ def test_trapezoid_fused_with_its_reductions_equals_the_unfused_ops(trap, targs)
     assert ei.value.wf_range == range(40, 41)
 
 
+def test_baseline_statistics_feed_thresholds_like_the_icpc_recipe():
+    """icpc-dsp-config.json:45-69, 294-305: linear_slope_fit on the baseline slice gives bl_std, which scales the threshold of the t0
+    search on the asymmetric trapezoid; per-event expression (bl_std * 4), slice of an intermediate, the fused trapezoid reductions"""
+    rng = np.random.default_rng(71)
+    x, bl, t0 = _synth(rng, 60, 4096)
+    wf = x.astype(np.float32)
+    M = "dspeed.processors"
+    rec = {"outputs": ["bl_mean", "bl_std", "bl_slope", "tp_0"], "processors": {
+        "wf_blsub": f"{M}.bl_subtract(waveform, baseline, wf_blsub)",
+        "bl_mean, bl_std, bl_slope, bl_intercept": {"function": "linear_slope_fit", "module": M,
+                                                     "args": ["wf_blsub[0:750]", "bl_mean", "bl_std", "bl_slope", "bl_intercept"]},
+        "wf_pz": f"{M}.pole_zero(wf_blsub, 1716.28, wf_pz)",
+        "wf_atrap": f"{M}.asym_trap_filter(wf_pz, 8, 4, 125, wf_atrap)",
+        "tp_min, tp_max, wf_min, wf_max": {"function": "min_max", "module": M, "args": ["wf_atrap", "tp_min", "tp_max", "wf_min", "wf_max"]},
+        "tp_0": f"{M}.time_point_thresh(wf_atrap, bl_std*4, tp_max, 0, tp_0)"}}
+    _, out = _run(rec, {"waveform": wf, "baseline": bl})
+    xb = oracle.bl_subtract(wf, bl)[0]
+    mean, std, slope, icpt, rc = oracle.linear_slope_fit(np.ascontiguousarray(xb[:, :750]))
+    assert rc == 0
+    assert np.array_equal(out["bl_mean"], mean) and np.array_equal(out["bl_std"], std)
+    assert np.max(np.abs(out["bl_slope"] - slope)) <= 1e-7
+    at = oracle.asym_trap_filter(oracle.pole_zero(xb, 1716.28)[0], 8, 4, 125)[0]
+    tmin, tmax, amin, amax, _ = oracle.min_max(at)
+    tp0 = oracle.time_point_thresh(at, (std * np.float32(4)).astype(np.float32), tmax, 0)[0]
+    assert np.all(np.abs(out["tp_0"] - tp0) <= 1)
+
+
 def test_current_branch_of_the_icpc_recipe():
     """the A/E branch as the production recipe writes it (icpc-dsp-config.json:306-346): windower -> avg_current -> upsampler ->
     moving_window_multi -> min_max -> numpy.add, one device program, against the oracle run processor by processor"""
