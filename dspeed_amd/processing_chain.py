@@ -476,6 +476,13 @@ class _Builder:
             # declaration:  name(length, 'f', ...)
             if f in new or f not in self.vars:
                 if not n.args:
+                    # name(unit='ADC') and the like: keywords only, the shape comes from the processor (reference :1076-1130)
+                    if n.keywords and all(k.arg in ("unit", "period", "offset", "grid", "dtype") for k in n.keywords):
+                        v = self.vars.get(f)
+                        if v is None:
+                            v = Var(f, None)
+                            self.vars[f] = v
+                        return v
                     raise ProcessingChainError(f"declaration '{src}' needs a shape")
                 shape = self._eval(n.args[0], src, new)
                 if isinstance(shape, Quantity):
