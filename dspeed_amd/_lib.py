@@ -22,8 +22,9 @@ IO_WF_IN, IO_WF_OUT, IO_SCALAR_IN, IO_SCALAR_OUT, IO_TAPS = range(5)
 ARG_CONST, ARG_INPUT, ARG_REG = range(3)
 (OP_LOAD, OP_STORE, OP_STORE_SCALAR, OP_BL_SUBTRACT, OP_POLE_ZERO, OP_DOUBLE_POLE_ZERO, OP_TRAP_FILTER, OP_TRAP_NORM,
  OP_ASYM_TRAP, OP_PICKOFF, OP_TIME_POINT_THRESH, OP_MIN_MAX, OP_DWT_HAAR, OP_CONVOLVE, OP_COPY, OP_TRAP_PICKOFF, OP_AMAX,
- OP_SCALAR_AFFINE, OP_MEAN_BELOW, OP_CONVOLVE_AMAX, OP_WINDOWER, OP_AVG_CURRENT, OP_TRAP_WINDOW_PICKOFF, OP_TRAP_REDUCE, OP_UPSAMPLER, OP_MOVING_WINDOW_MULTI, OP_LINEAR_SLOPE_FIT) = range(1, 28)
-MAX_OPS, MAX_SLOTS, MAX_IO, MAX_SREGS = 48, 8, 24, 32
+ OP_SCALAR_AFFINE, OP_MEAN_BELOW, OP_CONVOLVE_AMAX, OP_WINDOWER, OP_AVG_CURRENT, OP_TRAP_WINDOW_PICKOFF, OP_TRAP_REDUCE, OP_UPSAMPLER, OP_MOVING_WINDOW_MULTI, OP_LINEAR_SLOPE_FIT,
+ OP_SCALAR_CONVERT, OP_SCALAR_DIV) = range(1, 30)
+MAX_OPS, MAX_SLOTS, MAX_IO, MAX_SREGS = 192, 32, 64, 128
 
 
 class IoDesc(C.Structure):
@@ -36,7 +37,7 @@ class ScalarArg(C.Structure):
 
 class Op(C.Structure):
     _fields_ = [("opcode", C.c_int32), ("dst", C.c_int32), ("src", C.c_int32), ("io", C.c_int32), ("ip", C.c_int32 * 4),
-                ("sp", ScalarArg * 3)]
+                ("sp", ScalarArg * 4)]
 
 
 _lib = None

@@ -10,6 +10,7 @@
 // reference's own codes/messages (processors/*.py, cited in include/dspeed_hip.h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -347,6 +348,45 @@ static int setup_trap(DevOp& d, int kind_opcode, int rise, int flat, int fall, i
     return DSP_OK;
 }
 
+// waveform slots an op reads or writes (for the lifetime analysis of the LDS packing)
+static int op_slots(const dsp_op& o, int out[3]) {
+    switch (o.opcode) {
+        case DSP_OP_LOAD: out[0] = o.dst; return 1;
+        case DSP_OP_STORE:
+        case DSP_OP_TRAP_PICKOFF:
+        case DSP_OP_TRAP_REDUCE:
+        case DSP_OP_PICKOFF:
+        case DSP_OP_TIME_POINT_THRESH:
+        case DSP_OP_MEAN_BELOW:
+        case DSP_OP_TRAP_WINDOW_PICKOFF:
+        case DSP_OP_MIN_MAX:
+        case DSP_OP_LINEAR_SLOPE_FIT:
+        case DSP_OP_AMAX:
+        case DSP_OP_CONVOLVE_AMAX: out[0] = o.src; return 1;
+        case DSP_OP_BL_SUBTRACT:
+        case DSP_OP_POLE_ZERO:
+        case DSP_OP_DOUBLE_POLE_ZERO:
+        case DSP_OP_TRAP_FILTER:
+        case DSP_OP_TRAP_NORM:
+        case DSP_OP_ASYM_TRAP:
+        case DSP_OP_COPY:
+        case DSP_OP_WINDOWER:
+        case DSP_OP_AVG_CURRENT:
+        case DSP_OP_UPSAMPLER:
+        case DSP_OP_CONVOLVE: out[0] = o.src; out[1] = o.dst; return 2;
+        case DSP_OP_DWT_HAAR: out[0] = o.src; out[1] = o.dst; out[2] = o.ip[2]; return 3;
+        case DSP_OP_MOVING_WINDOW_MULTI:
+            out[0] = o.src;
+            out[1] = o.dst;
+            if (o.ip[1] > 1) {
+                out[2] = o.ip[2];
+                return 3;
+            }
+            return 2;
+        default: return 0;  // scalar ops
+    }
+}
+
 int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_io, const int32_t* slot_len, int n_slots,
                      int n_sregs, int compute_dtype, dsp_chain** out) {
     if (out) *out = nullptr;
@@ -374,23 +414,40 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         bool fir_in = false, only_plain = true;
         for (int i = 0; i < n_ops; ++i) {
             const dsp_op& o = ops[i];
-            const bool reads = (o.opcode != DSP_OP_LOAD && o.opcode != DSP_OP_STORE_SCALAR && o.opcode != DSP_OP_SCALAR_AFFINE && o.src == s);
-            const bool writes = (o.opcode == DSP_OP_LOAD || o.opcode == DSP_OP_BL_SUBTRACT || o.opcode == DSP_OP_POLE_ZERO ||
-                                 o.opcode == DSP_OP_DOUBLE_POLE_ZERO || o.opcode == DSP_OP_TRAP_FILTER || o.opcode == DSP_OP_TRAP_NORM ||
-                                 o.opcode == DSP_OP_ASYM_TRAP || o.opcode == DSP_OP_DWT_HAAR || o.opcode == DSP_OP_CONVOLVE ||
-                                 o.opcode == DSP_OP_COPY || o.opcode == DSP_OP_WINDOWER || o.opcode == DSP_OP_AVG_CURRENT || o.opcode == DSP_OP_UPSAMPLER ||
-                                 o.opcode == DSP_OP_MOVING_WINDOW_MULTI) && o.dst == s;
-            const bool scratch = (o.opcode == DSP_OP_DWT_HAAR || o.opcode == DSP_OP_MOVING_WINDOW_MULTI) && o.ip[2] == s;
-            if (!reads && !writes && !scratch) continue;
-            if ((o.opcode == DSP_OP_CONVOLVE || o.opcode == DSP_OP_CONVOLVE_AMAX) && reads) fir_in = true;
+            int touched[3];
+            const int nt = op_slots(o, touched);
+            bool uses = false;
+            for (int k = 0; k < nt; ++k) uses |= touched[k] == s;
+            if (!uses) continue;
+            const bool conv = o.opcode == DSP_OP_CONVOLVE || o.opcode == DSP_OP_CONVOLVE_AMAX;
+            const bool reads = o.opcode != DSP_OP_LOAD && o.src == s;
+            const bool writes = o.dst == s && (o.opcode == DSP_OP_LOAD || nt >= 2);  // (one-slot ops other than LOAD only read)
+            if (conv && reads) fir_in = true;
             const bool plain = o.opcode == DSP_OP_LOAD || o.opcode == DSP_OP_STORE || o.opcode == DSP_OP_COPY ||
-                               o.opcode == DSP_OP_BL_SUBTRACT || (o.opcode == DSP_OP_CONVOLVE && reads && !writes) ||
-                               (o.opcode == DSP_OP_CONVOLVE_AMAX && reads);
+                               o.opcode == DSP_OP_BL_SUBTRACT || (conv && reads && !writes);
             if (!plain) only_plain = false;
         }
         linear[s] = fir_in && only_plain;
     }
-    int cursor = 0;
+    // Slots whose lifetimes (first .. last op that touches them) do not overlap share LDS: the ICPC recipe has 14 waveform variables
+    // and at most four alive at a time.  Interval packing, first fit by first use; a slot that shares its region gets a
+    // DSP_OP_INTERNAL_ZERO in front of its first op (guards must read 0, pads finite -- also for the next row, which finds the region
+    // as the last tenant of the previous row left it).
+    int first_op[DSP_MAX_SLOTS], last_op[DSP_MAX_SLOTS], foot[DSP_MAX_SLOTS], base[DSP_MAX_SLOTS];
+    for (int s = 0; s < n_slots; ++s) {
+        first_op[s] = n_ops;
+        last_op[s] = -1;
+    }
+    for (int i = 0; i < n_ops; ++i) {
+        int touched[3];
+        const int nt = op_slots(ops[i], touched);
+        for (int k = 0; k < nt; ++k) {
+            const int s = touched[k];
+            if (s < 0 || s >= n_slots) continue;  // (rejected by the op checks below)
+            if (i < first_op[s]) first_op[s] = i;
+            if (i > last_op[s]) last_op[s] = i;
+        }
+    }
     for (int s = 0; s < n_slots; ++s) {
         const int len = slot_len[s];
         if (len <= 0) return fail(DSP_ERR_ARG, "slot %d has length %d", s, len);
@@ -402,9 +459,39 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         d.padw = linear[s] ? 0 : 1;
         d.pitch = C + d.padw;
         d.invC = 1.0f / (float)C;
-        cursor += 2 * d.pitch;
-        d.off = cursor;
-        cursor += 64 * d.pitch + 40;  // tail: the pipelined loops read up to 2 groups + 1 past the last chunk
+        foot[s] = 2 * d.pitch + 64 * d.pitch + 40;  // guard, chunks, tail: the pipelined loops read up to 2 groups + 1 past the last chunk
+        foot[s] = ((foot[s] + 3) / 4) * 4;          // (regions stay 16-byte aligned for the wide clears)
+        if (last_op[s] < 0) {                        // never used: alive throughout, so nothing is placed on top of it
+            first_op[s] = 0;
+            last_op[s] = n_ops - 1;
+        }
+    }
+    int order[DSP_MAX_SLOTS];
+    for (int s = 0; s < n_slots; ++s) order[s] = s;
+    std::stable_sort(order, order + n_slots, [&](int a, int b) { return first_op[a] < first_op[b]; });
+    int cursor = 0;
+    bool shares[DSP_MAX_SLOTS] = {false};
+    for (int oi = 0; oi < n_slots; ++oi) {
+        const int s = order[oi];
+        int at = 0;
+        for (bool moved = true; moved;) {  // lowest offset where no slot alive at the same time lies
+            moved = false;
+            for (int oj = 0; oj < oi; ++oj) {
+                const int t = order[oj];
+                const bool alive_together = first_op[s] <= last_op[t] && first_op[t] <= last_op[s];
+                if (alive_together && at < base[t] + foot[t] && base[t] < at + foot[s]) {
+                    at = base[t] + foot[t];
+                    moved = true;
+                }
+            }
+        }
+        base[s] = at;
+        for (int oj = 0; oj < oi; ++oj) {
+            const int t = order[oj];
+            if (at < base[t] + foot[t] && base[t] < at + foot[s]) shares[s] = shares[t] = true;
+        }
+        P.slots[s].off = at + 2 * P.slots[s].pitch;
+        if (at + foot[s] > cursor) cursor = at + foot[s];
     }
     P.sreg_off = cursor;
     cursor += ((n_sregs + 7) / 8) * 8 + 8;
@@ -457,9 +544,21 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     }
 
     // ---- ops
+    std::vector<int> dev_index(n_ops);  // caller's op -> position in the device program
+    int n_dev_ops = 0;
     for (int i = 0; i < n_ops; ++i) {
         const dsp_op& o = ops[i];
-        DevOp& d = P.ops[i];
+        for (int s = 0; s < n_slots; ++s)
+            if (shares[s] && first_op[s] == i) {
+                DevOp& z = P.ops[n_dev_ops++];
+                memset(&z, 0, sizeof z);
+                z.opcode = DSP_OP_INTERNAL_ZERO;
+                z.dst = s;
+                z.ic[0] = base[s];
+                z.ic[1] = foot[s];
+            }
+        dev_index[i] = n_dev_ops;
+        DevOp& d = P.ops[n_dev_ops++];
         memset(&d, 0, sizeof d);
         d.opcode = o.opcode;
         d.dst = o.dst;
@@ -467,7 +566,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         d.io = o.io;
         memcpy(d.ip, o.ip, sizeof d.ip);
         memcpy(d.sp, o.sp, sizeof d.sp);
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < 4; ++k) {
             const dsp_scalar_arg& a = o.sp[k];
             if (a.kind == DSP_ARG_INPUT && (a.index < 0 || a.index >= n_io || io[a.index].kind != DSP_IO_SCALAR_IN))
                 return fail(DSP_ERR_ARG, "op %d: scalar operand %d is not a scalar input binding", i, k);
@@ -678,11 +777,17 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 break;
             }
             case DSP_OP_SCALAR_AFFINE:
-                if (o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad SCALAR_AFFINE", i);
+            case DSP_OP_SCALAR_DIV:
+                if (o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad scalar arithmetic op", i);
+                break;
+            case DSP_OP_SCALAR_CONVERT:
+                if (o.dst < 0 || o.dst >= n_sregs || o.ip[0] < 0 || o.ip[0] > 4 || o.sp[3].kind != DSP_ARG_CONST)
+                    return fail(DSP_ERR_ARG, "op %d: bad SCALAR_CONVERT (ip[0] = rounding 0..4, sp[3] = constant period ratio)", i);
                 break;
             default: return fail(DSP_ERR_ARG, "op %d: unknown opcode %d", i, o.opcode);
         }
     }
+    P.n_ops = n_dev_ops;
 
     // ---- does the program have the shape LOAD [-> BL_SUBTRACT] -> POLE_ZERO -> TRAP_PICKOFF -> STORE_SCALAR on one slot?
     {
@@ -700,8 +805,8 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         auto f32_col = [&](const dsp_scalar_arg& a) { return a.kind != DSP_ARG_INPUT || io[a.index].dtype == DSP_F32; };
         if (shape && (!bs || f32_col(bs->sp[0])) && f32_col(tp->sp[0])) {
             EnergyArgs& F = ch->fused;
-            const DevOp& dpz = P.ops[pz - ops];
-            const DevOp& dtp = P.ops[tp - ops];
+            const DevOp& dpz = P.ops[dev_index[pz - ops]];
+            const DevOp& dtp = P.ops[dev_index[tp - ops]];
             F.wf_stride = io[ld->io].row_stride;
             F.wf_offset = io[ld->io].offset;
             F.len = slot_len[0];

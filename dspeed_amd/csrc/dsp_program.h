@@ -7,6 +7,7 @@
 
 #define DSP_WAVE 64
 #define DSP_FC 40 /* host-precomputed float64 constants per op */
+#define DSP_OP_INTERNAL_ZERO 100 /* host-inserted: clear slot dst's whole LDS region (guard, chunks, pads, tail) before its first use */
 #define DSP_IC 12 /* host-precomputed integer constants per op */
 
 // One waveform variable living in LDS.  Lane j of the wavefront owns samples [j*C, (j+1)*C) ("chunk");
@@ -33,7 +34,7 @@ struct DevIO {
 struct DevOp {
     int32_t opcode, dst, src, io;
     int32_t ip[4];
-    dsp_scalar_arg sp[3];
+    dsp_scalar_arg sp[4];
     int32_t ic[DSP_IC];
     double fc[DSP_FC];
 };
@@ -46,7 +47,7 @@ struct DevProgram {
     int32_t pad_;
     DevSlot slots[DSP_MAX_SLOTS];
     DevIO io[DSP_MAX_IO];
-    DevOp ops[DSP_MAX_OPS];
+    DevOp ops[DSP_MAX_OPS + DSP_MAX_SLOTS]; // + one region-clearing op per slot that shares LDS (DSP_OP_INTERNAL_ZERO)
 };
 
 struct IoPtrs {

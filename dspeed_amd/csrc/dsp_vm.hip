@@ -46,22 +46,23 @@ struct Ctx {
     }
     int64_t row;             // waveform being processed
     int* err;                // device error word
-    // bit s set: slot s is "all NaN" (the reference's NaN-propagation state; its content is then not maintained);
-    // bit 16 + s set: slot s holds real content with NaN samples in it (windower output reaching past the input) -- consumers
+    // nan_all bit s: slot s is "all NaN" (the reference's NaN-propagation state; its content is then not maintained);
+    // nan_some bit s: slot s holds real content with NaN samples in it (windower output reaching past the input) -- consumers
     // treat it like all-NaN (np.isnan(w_in).any()), a store writes the content
-    uint32_t nan_mask;
+    uint32_t nan_all, nan_some;
 
     __device__ __forceinline__ LT* chunk(const DSP_GLOBAL DevSlot& s) const { return lds + s.off + lane_id() * s.pitch; }
     __device__ __forceinline__ LT* sregs() const { return lds + prog->sreg_off; }
-    __device__ __forceinline__ bool slot_nan(int s) const { return ((nan_mask | (nan_mask >> 16)) >> s) & 1u; }
-    __device__ __forceinline__ bool slot_all_nan(int s) const { return (nan_mask >> s) & 1u; }
+    __device__ __forceinline__ bool slot_nan(int s) const { return ((nan_all | nan_some) >> s) & 1u; }
+    __device__ __forceinline__ bool slot_all_nan(int s) const { return (nan_all >> s) & 1u; }
     __device__ __forceinline__ void set_nan(int s, bool v) {
-        nan_mask &= ~((1u << s) | (1u << (16 + s)));
-        if (v) nan_mask |= 1u << s;
+        nan_all &= ~(1u << s);
+        nan_some &= ~(1u << s);
+        if (v) nan_all |= 1u << s;
     }
     __device__ __forceinline__ void set_some_nan(int s) {
-        nan_mask &= ~(1u << s);
-        nan_mask |= 1u << (16 + s);
+        nan_all &= ~(1u << s);
+        nan_some |= 1u << s;
     }
     __device__ void fatal(int code) const {
         if (lane_id() == 0 && atomicCAS(&err[0], 0, code) == 0) {
@@ -1357,6 +1358,41 @@ __device__ __forceinline__ void op_scalar_affine(Ctx<T>& cx, const DSP_GLOBAL De
     wave_sync();
 }
 
+// numpy.true_divide between two per-event variables (processing_chain.py:832-891 adds the ufunc as a processor)
+template <typename T>
+__device__ __forceinline__ void op_scalar_div(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const T a = cx.scalar(op.sp[0]), b = cx.scalar(op.sp[1]);
+    if (lane_id() == 0) cx.sregs()[op.dst] = a / b;
+    wave_sync();
+}
+
+// A time coordinate moved from one CoordinateGrid to another (unit_conversion.py:16-79): the offsets and the period ratio are float64
+// arguments there, so the arithmetic is float64 whatever the loop type; the result takes the variable's type.
+template <typename T>
+__device__ __forceinline__ void op_scalar_convert(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    auto f64_of = [&](const DSP_GLOBAL dsp_scalar_arg& a) { return a.kind == DSP_ARG_CONST ? a.value : (double)cx.scalar(a); };
+    const double x = (double)cx.scalar(op.sp[0]), off_in = f64_of(op.sp[1]), off_out = f64_of(op.sp[2]), ratio = op.sp[3].value;
+    double r = (x + off_in) * ratio;  // (separate roundings like the reference's expression: no contraction into an fma)
+    asm volatile("" : "+v"(r));
+    r = r - off_out;
+    const int mode = op.ip[0];
+    if (mode == 1) r = __builtin_rint(r);
+    else if (mode == 2) r = __builtin_floor(r);
+    else if (mode == 3) r = __builtin_ceil(r);
+    else if (mode == 4) r = __builtin_trunc(r);
+    if (lane_id() == 0) cx.sregs()[op.dst] = (T)r;
+    wave_sync();
+}
+
+// host-inserted: a slot that shares its LDS region with others starts from the all-zero state the kernel prologue gives the rest
+template <typename T>
+__device__ __forceinline__ void op_zero_region(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const int base = op.ic[0], n = op.ic[1];
+    for (int e = lane_id(); e < n; e += 64) cx.lds[base + e] = (T)0;
+    cx.set_nan(op.dst, false);
+    wave_sync();
+}
+
 // ------------------------------------------------------------------------------------------------
 // the interpreter
 // ------------------------------------------------------------------------------------------------
@@ -1384,7 +1420,7 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 4) dsp_vm_kernel(const DevProgr
     const int n_ops = prog->n_ops;
     for (int64_t row = (int64_t)blockIdx.x * wpb + wave; row < n_wf; row += total_waves) {
         cx.row = row;
-        cx.nan_mask = 0;
+        cx.nan_all = cx.nan_some = 0;
         for (int i = 0; i < n_ops; ++i) {
             const DSP_GLOBAL DevOp& op = cx.prog->ops[i];
             switch (op.opcode) {
@@ -1417,6 +1453,9 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 4) dsp_vm_kernel(const DevProgr
                     if constexpr (FIR) op_convolve<T>(cx, op, op.opcode == DSP_OP_CONVOLVE_AMAX);
                     break;
                 case DSP_OP_SCALAR_AFFINE: op_scalar_affine(cx, op); break;
+                case DSP_OP_SCALAR_DIV: op_scalar_div(cx, op); break;
+                case DSP_OP_SCALAR_CONVERT: op_scalar_convert(cx, op); break;
+                case DSP_OP_INTERNAL_ZERO: op_zero_region(cx, op); break;
                 default: break;
             }
         }

@@ -26,7 +26,9 @@ import json
 import re
 import time
 from collections.abc import MutableMapping
+import math
 from copy import deepcopy
+from types import SimpleNamespace
 
 import numpy as np
 
@@ -46,27 +48,70 @@ class Quantity(float):
 
 
 class WaveformInput:
-    """Input column with sampling information, the role of ``lgdo.WaveformTable`` (values, dt) in the reference
-    (processing_chain.py:2263-2360).  ``dt`` in nanoseconds."""
+    """Input column with sampling information, the role of ``lgdo.WaveformTable`` (values, dt, t0) in the reference
+    (processing_chain.py:2263-2360).  ``dt`` and ``t0`` in nanoseconds; ``t0`` is one number or one value per row (an ndarray or
+    DeviceArray), the time of sample 0 -- the offset of the waveform's coordinate grid."""
 
-    def __init__(self, values, dt: float = 16.0, t0: float = 0.0):
+    def __init__(self, values, dt: float = 16.0, t0=0.0):
         self.values = values
         self.dt = float(dt)
-        self.t0 = float(t0)
+        self.t0 = float(t0) if isinstance(t0, (int, float, np.integer, np.floating)) else t0
 
     def __len__(self):
         return len(self.values)
 
 
-class Var:
-    """A chain variable (the subset of ProcChainVar, processing_chain.py:147-377, that the device path needs)."""
+class Grid:
+    """The reference's CoordinateGrid (processing_chain.py:67-144): sampling period and the time of sample 0, both in ns; the offset
+    is a constant plus, for inputs with one t0 per row, a per-event variable holding ns."""
 
-    def __init__(self, name, kind, length=None, dtype=np.float32, period=None, const=None, source=None, offset=0):
+    __slots__ = ("period", "offset", "offset_var")
+
+    def __init__(self, period, offset=0.0, offset_var=None):
+        self.period, self.offset, self.offset_var = float(period), float(offset), offset_var
+
+    def __eq__(self, other):  # (a variable offset compares by identity, reference :107-113)
+        return (isinstance(other, Grid) and self.period == other.period and self.offset == other.offset
+                and self.offset_var is other.offset_var)
+
+    __hash__ = None
+
+    def key(self):
+        return (self.period, self.offset, id(self.offset_var))
+
+    def shifted(self, first_sample: int, step: int = 1) -> "Grid":
+        """grid of wf[first_sample::step] (reference :1032-1054)"""
+        return Grid(self.period * step, self.offset + first_sample * self.period, self.offset_var)
+
+    def __repr__(self):
+        off = f"{self.offset:g}" + (f"+{self.offset_var.name}" if self.offset_var is not None else "")
+        return f"({self.period:g}*ns,{off})"
+
+
+def _time_unit_ns(unit):
+    """ns per `unit` if it is a time unit, else None (what ureg.is_compatible_with(grid.period, unit) decides, reference :1709-1713)"""
+    if isinstance(unit, Quantity):
+        return float(unit)
+    if isinstance(unit, str):
+        return _UNITS_NS.get(unit)
+    return None
+
+
+class Var:
+    """A chain variable (the subset of ProcChainVar, processing_chain.py:147-377, that the device path needs).  ``unit``,
+    ``is_coord`` (None = the reference's ``auto``) and ``grid`` carry the coordinate information: a per-event variable with
+    ``is_coord`` holds a sample index of ``grid`` and is converted when a processor working on another grid, or an output column in
+    time units, reads it."""
+
+    def __init__(self, name, kind, length=None, dtype=np.float32, period=None, const=None, source=None, offset=0, grid=None,
+                 unit=None, is_coord=None):
         self.name = name
         self.kind = kind          # 'wf' | 'scalar' | 'const' | 'char' | 'taps'
         self.length = length      # samples (wf/taps)
         self.dtype = np.dtype(dtype) if dtype is not None else None
-        self.period = period      # ns per sample
+        self.grid = grid if grid is not None else (Grid(period) if period is not None else None)
+        self.unit = unit
+        self.is_coord = is_coord
         self.const = const        # python value for constants, ndarray for taps
         self.source = source      # input column name for chain inputs
         self.offset = offset      # first sample for sliced inputs
@@ -75,8 +120,34 @@ class Var:
         self.sreg = None
         self.io = None
 
+    @property
+    def period(self):  # ns per sample
+        return self.grid.period if self.grid is not None else None
+
     def __repr__(self):
         return f"<Var {self.name} {self.kind} len={self.length}>"
+
+
+class SExpr:
+    """A per-event value computed inside a recipe argument -- ``tp_0 + 8*us``, ``0.9*trapTmax``, ``QDrift/trapTmax``,
+    ``round(tp, wf.grid)`` -- or a coordinate conversion the chain inserts.  The reference adds a NumPy ufunc or a unit-conversion
+    processor and a new ProcChainVar for each (processing_chain.py:832-917, 1193-1266, 1806-1908); here it becomes one scalar op
+    when something first reads it."""
+
+    kind = "scalar"
+    is_input = False
+
+    def __init__(self, op, args, name, unit=None, is_coord=None, grid=None, mode=0):
+        self.op, self.args, self.name = op, tuple(args), name   # 'affine' (x, mul, add) | 'div' (a, b) | 'convert' (x, off_in, off_out, ratio)
+        self.unit, self.is_coord, self.grid, self.mode = unit, is_coord, grid, mode
+        self.sreg = None
+
+    def __repr__(self):
+        return f"<SExpr {self.name}>"
+
+
+def _is_scalar(a) -> bool:
+    return isinstance(a, SExpr) or (isinstance(a, Var) and a.kind == "scalar")
 
 
 # signatures of the supported processors: argument roles, in recipe order
@@ -91,6 +162,8 @@ _SIGS = {
 }
 _GENERATORS = ("cusp_filter", "zac_filter", "t0_filter", "moving_slope")
 _MODULES = ("dspeed.processors", "dspeed_amd.processors", "numpy", "np")
+_ROUND_MODES = {"round": 1, "floor": 2, "ceil": 3, "trunc": 4}
+_CALLS = ("round", "floor", "ceil", "trunc", "len", "float", "int")  # functions of the argument language (reference :729-751)
 
 
 class ProcessingChain:
@@ -270,6 +343,8 @@ class ProcessingChain:
 
 
 def _column(tb, name):
+    if name not in tb and name.endswith(".t0"):  # the per-row t0 of a WaveformInput
+        return tb[name[:-3]].t0
     col = tb[name]
     return col.values if isinstance(col, WaveformInput) else col
 
@@ -320,7 +395,7 @@ def _normalise(key, node):
                 raise ProcessingChainError(f"Module specified twice for parameter {key}")
             node["function"], node["module"] = f_parse.func.attr, seg(f_parse.func.value)
             node["args"] = [seg(a) for a in f_parse.args + f_parse.keywords]
-        elif f_parse.func.id in ("round", "len", "float", "int") and "module" not in node:
+        elif f_parse.func.id in _CALLS and "module" not in node:
             node["module"], node["args"] = None, [function]
         else:
             node["function"] = f_parse.func.id
@@ -363,11 +438,11 @@ def _names_in(arg: str) -> list[str]:
         return []
     names = []
     for n in ast.walk(tree):
-        if isinstance(n, ast.Call) and isinstance(n.func, ast.Name) and n.func.id not in ("round", "len", "float", "int"):
+        if isinstance(n, ast.Call) and isinstance(n.func, ast.Name) and n.func.id not in _CALLS:
             names.append(n.func.id)  # declaration name(shape, dtype)
     called = set(names)
     for n in ast.walk(tree):
-        if isinstance(n, ast.Name) and n.id not in _UNITS_NS and n.id not in ("round", "len", "float", "int", "np") and n.id not in called:
+        if isinstance(n, ast.Name) and n.id not in _UNITS_NS and n.id not in _CALLS and n.id != "np" and n.id not in called:
             names.append(n.id)
     seen, out = set(), []
     for n in names:
@@ -384,6 +459,7 @@ class _Builder:
         self.vars: dict[str, Var] = {}
         self.steps = []  # (function name, [operands], recipe key)
         self.default_period = None
+        self._conversions = {}  # (id(value), target grid key, rounding) -> SExpr: one conversion per variable and grid (reference :303-313)
         for name, col in self.tb_in.items():
             if isinstance(col, WaveformInput) and self.default_period is None:
                 self.default_period = col.dt
@@ -395,11 +471,18 @@ class _Builder:
         if name not in self.tb_in:
             raise ProcessingChainError(f"'{name}' not found in input table or recipe")
         col = self.tb_in[name]
-        period = col.dt if isinstance(col, WaveformInput) else None
         vals = col.values if isinstance(col, WaveformInput) else col
         shape, dtype = vals.shape, vals.dtype
         if len(shape) == 2:
-            v = Var(name, "wf", shape[1], dtype, period, source=name)
+            grid = None
+            if isinstance(col, WaveformInput):  # (values, dt, t0) -> grid(dt, t0), reference :2277-2299
+                if isinstance(col.t0, float):
+                    grid = Grid(col.dt, col.t0)
+                else:  # one t0 per row: a per-event variable in ns, itself a coordinate on the (1 ns, 0) grid
+                    t0 = Var(f"{name}.t0", "scalar", None, col.t0.dtype, source=f"{name}.t0", grid=Grid(1.0), unit="ns", is_coord=True)
+                    self.vars[t0.name] = t0
+                    grid = Grid(col.dt, 0.0, t0)
+            v = Var(name, "wf", shape[1], dtype, source=name, grid=grid, is_coord=False)
         elif len(shape) == 1:
             v = Var(name, "scalar", None, dtype, source=name)
         else:
@@ -407,9 +490,41 @@ class _Builder:
         self.vars[name] = v
         return v
 
+    # ---- coordinate conversions
+    def offset_ns(self, grid: Grid):
+        """the per-event offset of a grid with one t0 per row, in ns: t0, or t0 + start for a slice (reference :1039-1053)"""
+        ns = grid.offset_var
+        if grid.offset != 0.0:
+            key = (id(ns), "shift", grid.offset)
+            if key not in self._conversions:
+                self._conversions[key] = SExpr("affine", (ns, 1.0, grid.offset), f"({ns.name}+{grid.offset:g}*ns)", "ns", True, Grid(1.0))
+            ns = self._conversions[key]
+        return ns
+
+    def offset_in_periods(self, grid: Grid, period: float):
+        """grid's offset in units of `period`: a number, or a per-event value (CoordinateGrid.get_offset, reference :126-136)"""
+        if grid.offset_var is None:
+            return grid.offset / period
+        return self.converted(self.offset_ns(grid), Grid(period))
+
+    def converted(self, v, to: Grid, rounding: int = 0):
+        """v (a coordinate on v.grid) expressed on `to`: (v + offset_in) * period_ratio - offset_out, UnitConversionManager
+        (reference :1806-1908) with unit_conversion.py:16-79."""
+        if not rounding and v.grid == to:
+            return v
+        key = (id(v), to.key(), rounding)
+        if key not in self._conversions:
+            src = v.grid
+            ratio = src.period / to.period
+            off_in = self.offset_in_periods(src, src.period)
+            off_out = self.offset_in_periods(to, to.period)
+            name = f"{'convert' if not rounding else [k for k, m in _ROUND_MODES.items() if m == rounding][0]}({v.name}, {to})"
+            self._conversions[key] = SExpr("convert", (v, off_in, off_out, ratio), name, v.unit, True, to, rounding)
+        return self._conversions[key]
+
     # ---- expression evaluation
     def eval_arg(self, arg, want_new=None):
-        """Turn a recipe argument into a Var / number / Quantity / char.  ``want_new``: names this processor creates."""
+        """Turn a recipe argument into a Var / SExpr / number / Quantity / char.  ``want_new``: names this processor creates."""
         if not isinstance(arg, str):
             return arg
         tree = ast.parse(arg.strip(), mode="eval").body
@@ -425,7 +540,7 @@ class _Builder:
                 return Quantity(_UNITS_NS[n.id])
             if n.id in self.vars:
                 v = self.vars[n.id]
-                return v.const if v.kind == "const" else v
+                return v.const if isinstance(v, Var) and v.kind == "const" else v
             if n.id in new:
                 v = Var(n.id, None)
                 self.vars[n.id] = v
@@ -433,25 +548,43 @@ class _Builder:
             return self.input_var(n.id)
         if isinstance(n, ast.UnaryOp) and isinstance(n.op, (ast.USub, ast.UAdd)):
             v = self._eval(n.operand, src, new)
+            if _is_scalar(v):
+                if isinstance(n.op, ast.UAdd):
+                    return v
+                return SExpr("affine", (v, -1.0, -0.0), f"(-{v.name})", v.unit, v.is_coord, v.grid)
+            if isinstance(v, (Var, tuple)):
+                raise NotImplementedError(f"expressions on waveforms are not supported on the device: '{src}'")
             return -v if isinstance(n.op, ast.USub) else v
         if isinstance(n, ast.BinOp):
             a, b = self._eval(n.left, src, new), self._eval(n.right, src, new)
-            return self._binop(n.op, a, b)
+            return self._binop(n.op, a, b, src)
         if isinstance(n, ast.Attribute):
-            base = self._eval(n.value, src, new)
-            if isinstance(base, Var) and n.attr == "period":
-                if base.period is None:
-                    raise ProcessingChainError(f"'{base.name}' has no sampling period (wrap the input in WaveformInput)")
-                return Quantity(base.period)
             if isinstance(n.value, ast.Name) and n.value.id == "np" and n.attr in ("pi", "e", "inf", "nan"):
                 return getattr(np, n.attr)
-            raise ProcessingChainError(f"unsupported attribute in '{src}'")
+            base = self._eval(n.value, src, new)
+            if isinstance(base, tuple) and base[0] == "slice":
+                grid, what = _grid_of(base), f"{base[1].name}[{base[2]}:{base[3]}]"
+            elif isinstance(base, (Var, SExpr)):
+                grid, what = base.grid, base.name
+            else:
+                raise ProcessingChainError(f"unsupported attribute in '{src}'")
+            if n.attr not in ("period", "offset", "grid"):
+                raise ProcessingChainError(f"unsupported attribute '.{n.attr}' in '{src}'")
+            if grid is None:
+                raise ProcessingChainError(f"'{what}' has no coordinate grid (wrap the input in WaveformInput, or declare grid=/period=)")
+            if n.attr == "grid":
+                return grid
+            if n.attr == "period":
+                return Quantity(grid.period)
+            if grid.offset_var is None:
+                return Quantity(grid.offset)
+            return self.offset_ns(grid)
         if isinstance(n, ast.Subscript):
             base = self._eval(n.value, src, new)
             if not (isinstance(base, Var) and base.kind == "wf" and isinstance(n.slice, ast.Slice)):
                 raise NotImplementedError(f"only constant slices of waveforms are supported: '{src}'")
-            lo = self._const_int(n.slice.lower, src, new, 0)
-            hi = self._const_int(n.slice.upper, src, new, base.length)
+            lo = self._const_int(n.slice.lower, src, new, 0, base)
+            hi = self._const_int(n.slice.upper, src, new, base.length, base)
             if n.slice.step is not None:
                 raise NotImplementedError(f"strided slices are not supported: '{src}'")
             lo = lo + base.length if lo < 0 else lo
@@ -459,7 +592,7 @@ class _Builder:
             return ("slice", base, lo, hi)
         if isinstance(n, ast.Call) and isinstance(n.func, ast.Name):
             f = n.func.id
-            if f in ("round", "len", "float", "int"):
+            if f in _CALLS:
                 a = [self._eval(x, src, new) for x in n.args]
                 if f == "len":
                     v = a[0]
@@ -468,62 +601,105 @@ class _Builder:
                     if not isinstance(v, Var) or v.length is None:
                         raise ProcessingChainError(f"len() of something without a length in '{src}'")
                     return v.length
-                if f == "round":
-                    if isinstance(a[0], Var):
-                        raise NotImplementedError("round() of per-event variables is not supported on the device")
-                    return type(a[0])(round(float(a[0]))) if isinstance(a[0], Quantity) else int(round(float(a[0])))
+                if f in _ROUND_MODES:
+                    return self._round(f, a, src)
                 return {"float": float, "int": int}[f](a[0])
-            # declaration:  name(length, 'f', ...)
-            if f in new or f not in self.vars:
-                if not n.args:
-                    # name(unit='ADC') and the like: keywords only, the shape comes from the processor (reference :1076-1130)
-                    if n.keywords and all(k.arg in ("unit", "period", "offset", "grid", "dtype") for k in n.keywords):
-                        v = self.vars.get(f)
-                        if v is None:
-                            v = Var(f, None)
-                            self.vars[f] = v
-                        return v
+            # declaration:  name(length, 'f', grid=..., unit=..., period=..., offset=...)  (reference :1101-1122, 334-374)
+            if f in new or f not in self.vars or isinstance(self.vars.get(f), Var):
+                v = self.vars.get(f)
+                if v is None:
+                    v = Var(f, None)
+                    self.vars[f] = v
+                if n.args and v.length is None:
+                    shape = self._eval(n.args[0], src, new)
+                    if isinstance(shape, Quantity):
+                        raise ProcessingChainError(f"shape in '{src}' has time units; divide by a period")
+                    v.kind, v.length = "wf", int(round(float(shape)))
+                    v.dtype = np.dtype(np.float32)
+                    if len(n.args) > 1:
+                        d = self._eval(n.args[1], src, new)
+                        v.dtype = np.dtype(d[1] if isinstance(d, tuple) else d)
+                elif not n.args and not n.keywords:
                     raise ProcessingChainError(f"declaration '{src}' needs a shape")
-                shape = self._eval(n.args[0], src, new)
-                if isinstance(shape, Quantity):
-                    raise ProcessingChainError(f"shape in '{src}' has time units; divide by a period")
-                dtype = np.float32
-                if len(n.args) > 1:
-                    d = self._eval(n.args[1], src, new)
-                    dtype = np.dtype(d[1] if isinstance(d, tuple) else d)
-                v = Var(f, "wf", int(round(float(shape))), dtype)
-                self.vars[f] = v
+                kw = {k.arg: self._eval(k.value, src, new) for k in n.keywords}
+                for k in kw:
+                    if k not in ("unit", "period", "offset", "grid", "dtype", "is_coord"):
+                        raise ProcessingChainError(f"unknown keyword '{k}' in declaration '{src}'")
+                if "dtype" in kw:
+                    d = kw["dtype"]
+                    v.dtype = np.dtype(d[1] if isinstance(d, tuple) else d)
+                if "unit" in kw and v.unit is None:
+                    u = kw["unit"]
+                    v.unit = u[1] if isinstance(u, tuple) else u
+                if "is_coord" in kw and v.is_coord is None:
+                    v.is_coord = bool(kw["is_coord"])
+                if v.grid is None:
+                    if isinstance(kw.get("grid"), Grid):
+                        v.grid = kw["grid"]
+                    elif "period" in kw:
+                        per, off = kw["period"], kw.get("offset", 0.0)
+                        if not isinstance(per, Quantity):
+                            raise ProcessingChainError(f"period= in '{src}' must be a time")
+                        if _is_scalar(off):
+                            if off.is_coord is not True or off.grid is None:
+                                raise NotImplementedError(f"offset= in '{src}': a per-event offset must be a time coordinate")
+                            ns = off if off.grid == Grid(1.0) else self.converted(off, Grid(1.0))
+                            v.grid = Grid(float(per), 0.0, ns)
+                        else:  # a number counts periods (reference :101-102), a time is a time
+                            v.grid = Grid(float(per), float(off) if isinstance(off, Quantity) else float(off) * float(per))
                 return v
         raise ProcessingChainError(f"could not parse argument '{src}'")
 
-    def _const_int(self, node, src, new, default):
+    def _const_int(self, node, src, new, default, base=None):
         if node is None:
             return default
         v = self._eval(node, src, new)
-        if isinstance(v, Quantity):
-            raise ProcessingChainError(f"slice bound with time units in '{src}'; divide by a period")
-        if isinstance(v, (Var, tuple)):
+        if isinstance(v, Quantity):  # a time as slice bound: in samples of the sliced waveform (reference :962-963)
+            if base is None or base.period is None:
+                raise ProcessingChainError(f"slice bound with time units in '{src}' on a waveform without a sampling period")
+            v = float(v) / base.period
+        if isinstance(v, (Var, SExpr, tuple, Grid)):
             raise NotImplementedError(f"slice bounds must be constants: '{src}'")
-        return int(v)
+        return int(round(float(v)))
 
-    def _binop(self, op, a, b):
-        if isinstance(a, (Var, tuple)) or isinstance(b, (Var, tuple)):
-            # per-event scalar (+|-) constant  ->  SCALAR_AFFINE; anything else is outside the subset
-            if isinstance(a, Var) and a.kind == "scalar" and isinstance(b, (int, float)) and isinstance(op, (ast.Add, ast.Sub)):
-                return ("affine", a, 1.0, b if isinstance(op, ast.Add) else -b)
-            if isinstance(b, Var) and b.kind == "scalar" and isinstance(a, (int, float)) and isinstance(op, ast.Add):
-                return ("affine", b, 1.0, a)
-            # per-event scalar (*|/) constant: a multiplication; a division only where multiplying by the reciprocal is the same
-            # operation bit for bit (powers of two: tp_aoe_max / 16 in icpc-dsp-config.json:344)
-            if isinstance(a, Var) and a.kind == "scalar" and isinstance(b, (int, float)) and isinstance(op, ast.Mult):
-                return ("affine", a, float(b), 0.0)
-            if isinstance(b, Var) and b.kind == "scalar" and isinstance(a, (int, float)) and isinstance(op, ast.Mult):
-                return ("affine", b, float(a), 0.0)
-            if isinstance(a, Var) and a.kind == "scalar" and isinstance(b, (int, float)) and isinstance(op, ast.Div) and b != 0:
-                m, e = np.frexp(abs(float(b)))
-                if m == 0.5:
-                    return ("affine", a, 1.0 / float(b), 0.0)
-            raise NotImplementedError("expressions on waveforms / between per-event variables are not supported on the device")
+    def _round(self, f, a, src):
+        """round / floor / ceil / trunc (value, to_nearest = 1) -- reference :1193-1266 with round_to_nearest.py"""
+        fun = {"round": lambda x: float(np.rint(x)), "floor": math.floor, "ceil": math.ceil, "trunc": math.trunc}[f]
+        val, to = a[0], (a[1] if len(a) > 1 else 1)
+        if not isinstance(val, (Var, SExpr, tuple)):
+            if isinstance(to, Grid):
+                raise ProcessingChainError(f"cannot round a constant to a grid in '{src}'; use its period")
+            r = float(to) * fun(float(val) / float(to))
+            if isinstance(val, Quantity) != isinstance(to, Quantity):
+                raise ProcessingChainError(f"'{src}': value and to_nearest must both be times or both be numbers")
+            if isinstance(val, Quantity):
+                return Quantity(r)
+            return int(r) if float(r).is_integer() and not isinstance(to, float) else r
+        if not _is_scalar(val):
+            raise NotImplementedError(f"{f}() of waveforms is not supported on the device: '{src}'")
+        mode = _ROUND_MODES[f]
+        if val.is_coord is True:
+            if val.grid is None:
+                raise ProcessingChainError(f"'{val.name}' in '{src}' has no coordinate grid yet")
+            if isinstance(to, Grid):
+                grid = to
+            elif isinstance(to, Quantity):
+                grid = Grid(float(to), val.grid.offset, val.grid.offset_var)
+            else:
+                grid = Grid(val.grid.period * float(to), val.grid.offset, val.grid.offset_var)
+            return self.converted(val, grid, mode)
+        if isinstance(to, (Grid, Quantity)):
+            raise NotImplementedError(f"'{src}': rounding a per-event variable that is not a time coordinate to a time")
+        q = val if float(to) == 1.0 else SExpr("div", (val, float(to)), f"({val.name}/{to})", val.unit, False, None)
+        r = SExpr("convert", (q, 0.0, 0.0, 1.0), f"{f}({val.name}, {to})", val.unit, False, None, mode)
+        return r if float(to) == 1.0 else SExpr("affine", (r, float(to), -0.0), f"{f}({val.name}, {to})", val.unit, False, None)
+
+    def _binop(self, op, a, b, src=""):
+        sa, sb = _is_scalar(a), _is_scalar(b)
+        if sa or sb:
+            return self._scalar_binop(op, a, b, src)
+        if isinstance(a, (Var, tuple, Grid)) or isinstance(b, (Var, tuple, Grid)):
+            raise NotImplementedError(f"expressions on waveforms are not supported on the device: '{src}'")
         qa, qb = isinstance(a, Quantity), isinstance(b, Quantity)
         fa, fb = float(a), float(b)
         if isinstance(op, ast.Add):
@@ -551,6 +727,114 @@ class _Builder:
         if all(isinstance(x, int) and not isinstance(x, bool) for x in (a, b)) and not isinstance(op, ast.Div):
             return int(r)
         return r
+
+    def _scalar_binop(self, op, a, b, src):
+        """A binary operator with a per-event variable on at least one side: the reference adds the NumPy ufunc as a processor
+        (:832-891), so the operands go through the same unit handling as any processor's (`_resolve`)."""
+        sym = {ast.Add: "+", ast.Sub: "-", ast.Mult: "*", ast.Div: "/"}.get(type(op))
+        if sym is None:
+            raise NotImplementedError(f"operator in '{src}' is not supported between per-event variables")
+        for x in (a, b):
+            if isinstance(x, (tuple, Grid)) or (isinstance(x, Var) and x.kind != "scalar"):
+                raise NotImplementedError(f"expressions on waveforms are not supported on the device: '{src}'")
+        sa, sb = _is_scalar(a), _is_scalar(b)
+        name = f"({a.name if sa else a}{sym}{b.name if sb else b})"
+        if sa and sb:  # reference :848-872
+            ta, tb = _time_unit_ns(a.unit), _time_unit_ns(b.unit)
+            if ta is not None and tb is not None:
+                unit = a.unit if sym in "+-" else None  # (time * time and time / time: not a time any more)
+            elif a.unit is not None and b.unit is not None:
+                unit = f"{a.unit}{sym}{b.unit}" if sym in "*/" else a.unit
+            else:
+                unit = a.unit if a.unit is not None else b.unit
+            both = a.is_coord is True and b.is_coord is True
+            out = SExpr(None, (), name, unit, False if both else None, None)
+        else:
+            v = a if sa else b
+            out = SExpr(None, (), name, v.unit, v.is_coord, None)
+        if sym in "*/" and (isinstance(a, Quantity) or isinstance(b, Quantity)):
+            raise NotImplementedError(f"'{src}': multiplying / dividing a per-event variable by a time is not supported")
+        _, (a, b, _o) = _resolve(self, "ssS", [a, b, out], expression=True)
+        if sym == "+":
+            out.op, out.args = "affine", ((a, 1.0, b) if sa else (b, 1.0, a))
+        elif sym == "-":
+            out.op, out.args = "affine", ((a, 1.0, -b) if not sb else (b, -1.0, a))
+        elif sym == "*":
+            out.op, out.args = "affine", ((a, b, -0.0) if sa else (b, a, -0.0))
+        else:
+            e = np.frexp(abs(float(b)))[0] if not sb and float(b) != 0 else 0
+            if e == 0.5:  # a power of two: multiplying by the reciprocal is the same operation bit for bit
+                out.op, out.args = "affine", (a, 1.0 / float(b), -0.0)
+            else:
+                out.op, out.args = "div", (a, b)
+        return out
+
+
+def _grid_of(a):
+    """coordinate grid of a waveform operand"""
+    if isinstance(a, tuple) and a[0] == "slice":
+        g = a[1].grid
+        return g.shifted(a[2]) if g is not None else None
+    if isinstance(a, Var):
+        return a.grid
+    return None
+
+
+def _resolve(b: _Builder, roles, args, same_dim_out=False, expression=False):
+    """What ProcessorManager.__init__ does with the unit information of its parameters (reference :1556-1732, 1747-1770):
+
+    * the processor's coordinate grid is the first waveform parameter's that has one, else the first time coordinate's;
+    * a per-event parameter whose ``is_coord`` is still open becomes a coordinate on that grid if its unit is a time, a plain number
+      otherwise; coordinates on another grid are converted;
+    * constants with time units are divided by the grid's period;
+    * an output waveform of the same dimension as the input takes over its grid.
+
+    Returns (grid, converted arguments)."""
+    G = None
+    for a, r in zip(args, roles):
+        if r in "wW":
+            g = _grid_of(a)
+            if G is None and g is not None:
+                G = g
+    if G is None:
+        for a in args:
+            if _is_scalar(a) and a.is_coord is True and a.grid is not None:
+                G = a.grid
+                break
+    out = []
+    for a, r in zip(args, roles):
+        if _is_scalar(a):
+            if a.is_coord is True:
+                if a.grid is None and G is not None:
+                    a.grid = G
+            elif a.is_coord is None and not (isinstance(a, Var) and a.kind is None):
+                if _time_unit_ns(a.unit) is not None and G is not None:
+                    a.is_coord = True
+                    if a.grid is None:
+                        a.grid = G
+                else:
+                    a.is_coord = False
+            if r == "s" and a.is_coord is True and G is not None and a.grid is not None and a.grid != G:
+                a = b.converted(a, G)
+        elif isinstance(a, Var) and a.kind is None and r == "S":  # a new per-event output
+            a.kind = "scalar"
+            if a.is_coord is None:
+                a.is_coord = _time_unit_ns(a.unit) is not None and G is not None
+            if a.is_coord and a.grid is None:
+                a.grid = G
+        elif isinstance(a, Quantity) and r in "si":
+            if G is not None:
+                a = float(a) / G.period
+            elif expression:
+                # no coordinate in the expression to take a grid from (the reference refuses: "could not find valid conversion",
+                # :1752-1756); a per-event input column counts samples of the input waveform here
+                if b.default_period is None:
+                    raise ProcessingChainError(f"could not find valid conversion for {a!r}; CoordinateGrid is None")
+                a = float(a) / b.default_period
+        elif r == "W" and isinstance(a, Var) and a.grid is None and same_dim_out:
+            a.grid = next((_grid_of(x) for x, rx in zip(args, roles) if rx == "w"), None)
+        out.append(a)
+    return G, out
 
 
 def build_processing_chain(processors, tb_in=None, db_dict=None, outputs=None, block_width: int = 16):
@@ -646,13 +930,19 @@ def build_processing_chain(processors, tb_in=None, db_dict=None, outputs=None, b
     return chain, leafs + copy_pars, tb_out
 
 
+# processors whose output waveform has the input's dimension name in the gufunc signature ("(n),...->(n)") and therefore its
+# coordinate grid (reference :1601-1619, 1700); the others' outputs have no grid unless the recipe declares one
+_SAME_DIM = ("bl_subtract", "pole_zero", "double_pole_zero", "trap_filter", "trap_norm", "asym_trap_filter", "moving_window_multi")
+
+
 def _add_step(b: _Builder, key, node, new_vars, proc_strings):
     module, function = node["module"], node["function"]
-    if module is None:  # inline expression: alias / constant
+    if module is None:  # inline expression: alias / constant (reference :2676-2696)
         val = b.eval_arg(node["args"][0])
-        if isinstance(val, (Var, tuple)):
-            b.steps.append(("alias", [val], new_vars[0]))
-            b.vars[new_vars[0]] = Var(new_vars[0], "scalar") if not isinstance(val, Var) else val
+        if isinstance(val, tuple):
+            raise NotImplementedError(f"'{key}': naming a slice is not supported on the device path")
+        if isinstance(val, (Var, SExpr)):
+            b.vars[new_vars[0]] = val
         else:
             b.vars[new_vars[0]] = Var(new_vars[0], "const", const=val)
         return
@@ -660,6 +950,14 @@ def _add_step(b: _Builder, key, node, new_vars, proc_strings):
         raise NotImplementedError(f"module '{module}' is not available on the device path (processor {module}.{function})")
     if module in ("numpy", "np") and function not in ("amax", "add"):
         raise NotImplementedError(f"numpy.{function} is not available on the device path")
+    if "unit" in node:  # "unit": one string, or one per new variable (reference :2705-2711)
+        for i, name in enumerate(new_vars):
+            unit = node["unit"][i] if isinstance(node["unit"], (list, tuple)) else node["unit"]
+            v = b.vars.get(name)
+            if v is None:
+                b.vars[name] = Var(name, None, unit=unit)
+            elif isinstance(v, Var) and v.unit is None:
+                v.unit = unit
     args = [b.eval_arg(a, new_vars) for a in node["args"]]
     if function in _GENERATORS:
         _fold_generator(b, function, args, new_vars)
@@ -670,26 +968,24 @@ def _add_step(b: _Builder, key, node, new_vars, proc_strings):
     if len(args) != len(roles):
         raise ProcessingChainError(f"{function} takes {len(roles)} arguments ({len(args)} given) for parameter {key}")
     # give the variables this processor creates their type now, so later recipe entries can slice / measure them
-    src_len = src_period = None
+    src_len = None
     for a, r in zip(args, roles):
         if r == "w":
             if isinstance(a, tuple) and a[0] == "slice":
-                src_len, src_period = a[3] - a[2], a[1].period
+                src_len = a[3] - a[2]
             elif isinstance(a, Var):
-                src_len, src_period = a.length, a.period
+                src_len = a.length
     for a, r in zip(args, roles):
         if r == "W" and isinstance(a, Var):
             if a.kind is None:
                 a.kind = "wf"
-            if a.length is None and function not in ("discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "windower", "avg_current", "upsampler"):
+            if a.length is None and function in _SAME_DIM:
                 a.length = src_len
-            if a.period is None:
-                a.period = src_period
             a.dtype = np.dtype(np.float32)
-        elif r == "S" and isinstance(a, Var) and a.kind is None:
-            a.kind = "scalar"
+            a.is_coord = False
+    _, args = _resolve(b, roles, args, same_dim_out=function in _SAME_DIM)
     b.steps.append((function, args, key))
-    proc_strings.append(f"{function}({', '.join(str(a.name if isinstance(a, Var) else a) for a in args)})")
+    proc_strings.append(f"{function}({', '.join(str(a.name if isinstance(a, (Var, SExpr)) else a) for a in args)})")
 
 
 def _fold_generator(b: _Builder, function, args, new_vars):
@@ -753,7 +1049,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             for x in a2:
                 if isinstance(x, tuple) and x[0] == "slice" and x[1] is v:
                     found.add((x[2], x[3]))
-                elif x is v or (isinstance(x, tuple) and x[0] == "affine" and x[1] is v):
+                elif x is v:
                     plain = True
         return found, plain
 
@@ -783,18 +1079,19 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             v = wf_of(a)
             if v is not None and r in "wts":
                 last_use[v.name] = si
-            if isinstance(a, tuple) and a[0] == "affine":
-                last_use[a[1].name] = si
     for o in out_pars:
         last_use[o] = len(steps) + 1
 
     free_slots, slot_len = [], []
 
     def new_slot(length):
-        for s in free_slots:
-            if slot_len[s] == length:
-                free_slots.remove(s)
-                return s
+        # one slot per waveform variable: dsp_chain_create packs slots with disjoint lifetimes into the same LDS, whatever their
+        # lengths.  Only a recipe with more variables than slot ids goes back to an id whose variable is dead.
+        if len(slot_len) >= _lib.MAX_SLOTS:
+            for s in free_slots:
+                if slot_len[s] == length:
+                    free_slots.remove(s)
+                    return s
         slot_len.append(int(length))
         return len(slot_len) - 1
 
@@ -818,7 +1115,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
                 key = f"{base.name}[{lo}:{hi}]"
                 v = b.vars.get(key)
                 if v is None:
-                    v = Var(key, "wf", hi - lo, base.dtype, base.period, source=base.source, offset=lo)
+                    v = Var(key, "wf", hi - lo, base.dtype, source=base.source, offset=lo, grid=_grid_of(a), is_coord=False)
                     b.vars[key] = v
                     last_use[key] = last_use.get(base.name, si)
                 return ensure_loaded(v, si)
@@ -827,7 +1124,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             if v is not None and v.slot is not None:
                 return v  # the same slice was materialised for an earlier processor and is still alive
             src = ensure_loaded(base, si)
-            v = Var(key, "wf", hi - lo, np.float32, base.period)
+            v = Var(key, "wf", hi - lo, np.float32, grid=_grid_of(a), is_coord=False)
             v.slot = new_slot(v.length)
             p.add_op(_lib.OP_COPY, dst=v.slot, src=src.slot, ip=(lo,))
             b.vars[key] = v
@@ -850,17 +1147,23 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
 
     def scalar_operand(a, args, integer=False, what=""):
         """Scalar argument -> Scalar (const / input column / register)."""
-        if isinstance(a, tuple) and a[0] == "affine":
-            _, base, mul, add = a
-            if isinstance(add, Quantity):
-                per = period_of(args)
-                if per is None:
-                    raise ProcessingChainError(f"{what}: time quantity without a sampling period")
-                add = float(add) / per
-            src = scalar_operand(base, args)
-            r = p.add_sregs(1)
-            p.add_op(_lib.OP_SCALAR_AFFINE, dst=r, sp=(src, Scalar.const(mul), Scalar.const(add)))
-            return Scalar.reg(r)
+        if isinstance(a, SExpr):
+            if a.sreg is None:  # first reader: emit the op (its operands were computed by earlier processors)
+                def opnd(x):
+                    return scalar_operand(x, args, what=what) if isinstance(x, (Var, SExpr)) else Scalar.const(float(x))
+
+                r = p.add_sregs(1)
+                if a.op == "affine":
+                    p.add_op(_lib.OP_SCALAR_AFFINE, dst=r, sp=tuple(opnd(x) for x in a.args))
+                elif a.op == "div":
+                    p.add_op(_lib.OP_SCALAR_DIV, dst=r, sp=tuple(opnd(x) for x in a.args))
+                elif a.op == "convert":
+                    x, off_in, off_out, ratio = a.args
+                    p.add_op(_lib.OP_SCALAR_CONVERT, dst=r, ip=(a.mode,), sp=(opnd(x), opnd(off_in), opnd(off_out), Scalar.const(ratio)))
+                else:
+                    raise ProcessingChainError(f"{what}: cannot evaluate '{a.name}'")
+                a.sreg = r
+            return Scalar.reg(a.sreg)
         if isinstance(a, Var):
             if a.kind == "const":
                 a = a.const
@@ -876,17 +1179,15 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
                 raise ProcessingChainError(f"scalar '{a.name}' is used before it is computed")
             else:
                 raise ProcessingChainError(f"{what}: '{a.name}' is not a scalar")
-        if isinstance(a, Quantity):
+        if isinstance(a, Quantity):  # (no grid on this processor: the reference refuses; the input's sampling period is used)
             per = period_of(args)
             if per is None:
                 raise ProcessingChainError(f"{what}: time quantity without a sampling period (wrap the input in WaveformInput)")
             a = float(a) / per
-            if integer:
-                a = int(round(a))  # reference :1747-1770: integer parameters are rounded after the unit conversion
-        if integer:
-            if float(a) != int(a) and not isinstance(a, int):
-                a = int(round(float(a)))
-            return int(a)
+        if isinstance(a, (tuple, Grid)):
+            raise ProcessingChainError(f"{what}: expected a number or a per-event variable, got {a!r}")
+        if integer:  # reference :1767-1768: integer parameters are rounded after the unit conversion
+            return int(a) if isinstance(a, (int, np.integer)) else int(np.rint(float(a)))
         return Scalar.const(float(a))
 
     def char_of(a):
@@ -906,8 +1207,6 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
         if a.length is None:
             a.length = length
         a.dtype = np.dtype(np.float32)
-        if src_var is not None and a.period is None:
-            a.period = src_var.period
         return a
 
     def out_scalar(a):
@@ -1126,17 +1425,22 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
                 raise ProcessingChainError(f"output waveform '{o}' was never computed")
             io = p.add_io(f"out:{o}", _lib.IO_WF_OUT, ft, v.length)
             p.add_op(_lib.OP_STORE, src=v.slot, io=io)
-            out_bind[f"out:{o}"] = (v, v.length)
+            out_bind[f"out:{o}"] = (SimpleNamespace(name=o), v.length)
             tb_out[o] = np.empty((n_rows, v.length), dtype=ft)
         else:
-            if v.sreg is None:
+            # a time coordinate is written in its unit, not in samples: (index + grid offset) * period (reference :1990-2014, get_buffer(unit))
+            unit_ns = _time_unit_ns(v.unit)
+            if v.is_coord is True and v.grid is not None and unit_ns is not None:
+                v = b.converted(v, Grid(unit_ns))
+            if isinstance(v, Var) and v.sreg is None:
                 if v.is_input:
                     tb_out[o] = _column(b.tb_in, v.source)
                     continue
                 raise ProcessingChainError(f"output '{o}' was never computed")
+            reg = scalar_operand(v, [], what=f"output {o}")
             io = p.add_io(f"out:{o}", _lib.IO_SCALAR_OUT, ft)
-            p.add_op(_lib.OP_STORE_SCALAR, io=io, ip=(v.sreg,))
-            out_bind[f"out:{o}"] = (v, None)
+            p.add_op(_lib.OP_STORE_SCALAR, io=io, ip=(reg.index,))
+            out_bind[f"out:{o}"] = (SimpleNamespace(name=o), None)
             tb_out[o] = np.empty(n_rows, dtype=ft)
     p.slots = slot_len
     if len(p.ops) > _lib.MAX_OPS or len(p.slots) > _lib.MAX_SLOTS or len(p.io) > _lib.MAX_IO or p.n_sregs > _lib.MAX_SREGS:

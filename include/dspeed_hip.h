@@ -111,10 +111,10 @@ const char* dsp_version(void);
  * (processing_chain.py:665-673, 1144-1163).  The host (dspeed_amd.processing_chain) translates a
  * dspeed JSON recipe into this program.
  */
-#define DSP_MAX_OPS 48
-#define DSP_MAX_SLOTS 8
-#define DSP_MAX_IO 24
-#define DSP_MAX_SREGS 32
+#define DSP_MAX_OPS 192   /* a whole LEGEND recipe (tests/configs/icpc-dsp-config.json: 43 processors, 34 outputs) is one program */
+#define DSP_MAX_SLOTS 32  /* waveform variables; slots whose lifetimes do not overlap share LDS (packed by dsp_chain_create) */
+#define DSP_MAX_IO 64
+#define DSP_MAX_SREGS 128
 
 /* I/O binding kinds */
 #define DSP_IO_WF_IN 0      /* waveform input  (n_wf rows of `len` samples starting at `offset` within each row) */
@@ -176,7 +176,12 @@ typedef struct dsp_scalar_arg {
                                   * ip[2] = scratch slot (needed for two or more windows) */
 #define DSP_OP_LINEAR_SLOPE_FIT 27 /* linear_slope_fit.py:11-91  sreg[dst..dst+3] <- mean, stdev (Welford, in the reference's rounding
                                   * sequence), slope, intercept of src */
-#define DSP_OP_SCALAR_AFFINE 18 /* sreg[dst] <- sp[0] * sp[1] + sp[2]  (host-folded expressions such as tp_0 + 10*us) */
+#define DSP_OP_SCALAR_AFFINE 18 /* sreg[dst] <- sp[0] * sp[1] + sp[2]  (recipe expressions: tp_0 + 10*us, 0.9*trapTmax, a + b, a * b, a - b) */
+#define DSP_OP_SCALAR_CONVERT 28 /* unit_conversion.py:16-79  sreg[dst] <- f((sp[0] + sp[1]) * sp[3] - sp[2]) in float64, rounded to the loop type:
+                                  * a time coordinate moved between two CoordinateGrids (processing_chain.py:1806-1908).  sp[1] / sp[2] = offset of
+                                  * the source / target grid in periods, sp[3] = ratio of the periods (constant), ip[0] = f: 0 none, 1 rint,
+                                  * 2 floor, 3 ceil, 4 trunc (round()/floor()/ceil()/trunc() onto a grid, processing_chain.py:1193-1266) */
+#define DSP_OP_SCALAR_DIV 29     /* sreg[dst] <- sp[0] / sp[1]  (numpy.true_divide between per-event variables: QDrift / trapTmax) */
 
 typedef struct dsp_op {
     int32_t opcode;
@@ -184,7 +189,7 @@ typedef struct dsp_op {
     int32_t src; /* waveform slot read */
     int32_t io;  /* I/O binding index (LOAD/STORE/STORE_SCALAR/CONVOLVE) or mode char (TRAP_PICKOFF) */
     int32_t ip[4];
-    dsp_scalar_arg sp[3];
+    dsp_scalar_arg sp[4];
 } dsp_op;
 
 typedef struct dsp_chain dsp_chain; /* opaque */

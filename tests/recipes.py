@@ -75,3 +75,70 @@ C5 = {
                      "args": ["wf_pz", 5, "'h'", "'a'", "dwt_haar(256, 'f')"]},
     },
 }
+
+# The whole Ge recipe with LEGEND's structure (icpc-dsp-config.json:1-347): every branch of it in ONE recipe, written in the
+# reference's full argument language -- units on outputs, grids on declarations, expressions between per-event variables, rounding
+# onto a waveform's grid.  Own parameter values; what matters is that each construct of that file appears.
+_M = "dspeed.processors"
+ICPC = {
+    "outputs": ["tp_min", "tp_max", "wf_min", "wf_max", "bl_mean", "bl_std", "bl_slope", "bl_intercept", "pz_mean", "pz_std", "trapTmax",
+                "tp_0_est", "tp_0_atrap", "tp_10", "tp_50", "tp_90", "tp_99", "tp_100", "A_max", "QDrift", "dt_eff", "tp_aoe_max",
+                "tp_aoe_samp", "trapEmax", "trapEftp", "cuspEmax", "cuspEftp"],
+    "processors": {
+        "tp_min, tp_max, wf_min, wf_max": {"function": "min_max", "module": _M, "args": ["waveform", "tp_min", "tp_max", "wf_min", "wf_max"],
+                                           "unit": ["ns", "ns", "ADC", "ADC"]},
+        "wf_blsub": f"{_M}.bl_subtract(waveform, baseline, wf_blsub(unit='ADC'))",
+        "bl_mean , bl_std, bl_slope, bl_intercept": {"function": "linear_slope_fit", "module": _M, "unit": ["ADC"] * 4,
+                                                      "args": ["wf_blsub[0:700]", "bl_mean", "bl_std", "bl_slope", "bl_intercept"]},
+        "wf_pz": {"function": "pole_zero", "module": _M, "args": ["wf_blsub", "db.pz.tau", "wf_pz"], "unit": "ADC",
+                  "defaults": {"db.pz.tau": "27.46*us"}},
+        "pz_mean , pz_std, pz_slope, pz_intercept": {"function": "linear_slope_fit", "module": _M, "unit": ["ADC"] * 4,
+                                                      "args": ["wf_pz[1600:]", "pz_mean", "pz_std", "pz_slope", "pz_intercept"]},
+        "t0_kernel": {"function": "t0_filter", "module": _M, "unit": "ADC",
+                      "args": ["128*ns/wf_pz.period", "2*us/wf_pz.period", "t0_kernel(round((128*ns+2*us)/wf_pz.period), 'f')"]},
+        "wf_t0_filter": {"function": "convolve_wf", "module": _M, "unit": "ADC",
+                         "args": ["wf_pz", "t0_kernel", "'s'", "wf_t0_filter(len(wf_pz), 'f', grid=wf_pz.grid)"]},
+        "wf_atrap": {"function": "asym_trap_filter", "module": _M, "args": ["wf_pz", "128*ns", "4", "2*us", "wf_atrap"], "unit": "ADC"},
+        "conv_tmin ,tp_start, conv_min, conv_max": {"function": "min_max", "module": _M, "unit": ["ns", "ns", "ADC", "ADC"],
+                                                    "args": ["wf_t0_filter", "conv_tmin", "tp_start", "conv_min", "conv_max"]},
+        "tp_0_atrap": {"function": "time_point_thresh", "module": _M, "args": ["wf_atrap", "bl_std", "tp_start", 0, "tp_0_atrap"], "unit": "ns"},
+        "tp_0_est": {"function": "time_point_thresh", "module": _M, "args": ["wf_t0_filter", "bl_std", "tp_start", 0, "tp_0_est(unit=ns)"],
+                     "unit": "ns"},
+        "wf_trap": {"function": "trap_norm", "module": _M, "args": ["wf_pz", "db.ttrap.rise", "db.ttrap.flat", "wf_trap"], "unit": "ADC",
+                    "defaults": {"db.ttrap.rise": "10*us", "db.ttrap.flat": "3.008*us"}},
+        "trapTmax": {"function": "amax", "module": "numpy", "args": ["wf_trap", 1, "trapTmax"], "unit": "ADC",
+                     "kwargs": {"signature": "(n),()->()", "types": ["fi->f"]}},
+        "wf_etrap": {"function": "trap_norm", "module": _M, "args": ["wf_pz", "db.etrap.rise", "db.etrap.flat", "wf_etrap"], "unit": "ADC",
+                     "defaults": {"db.etrap.rise": "8*us", "db.etrap.flat": "2*us"}},
+        "trapEmax": {"function": "amax", "module": "numpy", "args": ["wf_etrap", 1, "trapEmax"], "unit": "ADC"},
+        "trapEftp": {"function": "fixed_time_pickoff", "module": _M, "unit": "ADC",
+                     "args": ["wf_etrap", "round(tp_0_est+db.etrap.rise+db.etrap.flat*db.etrap.sample, wf_etrap.grid)", "'l'", "trapEftp"],
+                     "defaults": {"db.etrap.rise": "8*us", "db.etrap.flat": "2*us", "db.etrap.sample": "0.8"}},
+        "cusp_kernel": {"function": "cusp_filter", "module": _M, "unit": "ADC",
+                        "args": ["db.cusp.sigma/wf_blsub.period", "round(db.cusp.flat/wf_blsub.period)", "db.pz.tau/wf_blsub.period",
+                                 "cusp_kernel(round(len(wf_blsub)-(33.6*us/wf_blsub.period)-(4.8*us/wf_blsub.period)), 'f')"],
+                        "defaults": {"db.cusp.sigma": "20*us", "db.cusp.flat": "3*us", "db.pz.tau": "450*us"}},
+        "wf_cusp": {"function": "fft_convolve_wf", "module": _M, "unit": "ADC",
+                    "args": ["wf_blsub[:round(len(wf_blsub)-(33.6*us/wf_blsub.period))]", "cusp_kernel", "'v'",
+                             "wf_cusp(round((4.8*us/wf_blsub.period)+1), 'f')"]},
+        "cuspEmax": "numpy.amax(wf_cusp, 1, cuspEmax)",
+        "cuspEftp": {"function": "fixed_time_pickoff", "module": _M, "args": ["wf_cusp", "db.cusp.sample", "'i'", "cuspEftp"], "unit": "ADC",
+                     "defaults": {"db.cusp.sample": "50"}},
+        "tp_100": {"function": "time_point_thresh", "module": _M, "args": ["wf_pz", "trapTmax", "tp_0_est", 1, "tp_100"], "unit": "ns"},
+        "tp_99": {"function": "time_point_thresh", "module": _M, "args": ["wf_pz", "0.99*trapTmax", "tp_0_est", 1, "tp_99"], "unit": "ns"},
+        "tp_90": {"function": "time_point_thresh", "module": _M, "args": ["wf_pz", "trapTmax*0.9", "tp_99", 0, "tp_90"], "unit": "ns"},
+        "tp_50": {"function": "time_point_thresh", "module": _M, "args": ["wf_pz", "trapTmax*0.5", "tp_90", 0, "tp_50"], "unit": "ns"},
+        "tp_10": {"function": "time_point_thresh", "module": _M, "args": ["wf_pz", "trapTmax*0.1", "tp_50", 0, "tp_10"], "unit": "ns"},
+        "wf_trap2": {"function": "trap_norm", "module": _M, "args": ["wf_pz", "4*us", "96*ns", "wf_trap2"], "unit": "ADC"},
+        "trapQftp": {"function": "fixed_time_pickoff", "module": _M, "args": ["wf_trap2", "tp_0_est + 8.096*us", "'l'", "trapQftp"], "unit": "ADC"},
+        "QDrift": "trapQftp * 16",
+        "dt_eff": {"function": "QDrift/trapTmax", "unit": "ns"},
+        "wf_le": {"function": "windower", "module": _M, "args": ["wf_pz", "tp_0_est", "wf_le(301, 'f')"], "unit": "ADC"},
+        "curr": {"function": "avg_current", "module": _M, "args": ["wf_le", 1, "curr(len(wf_le)-1, 'f')"], "unit": "ADC/sample"},
+        "curr_up": {"function": "upsampler", "module": _M, "args": ["curr", "16", "curr_up(4784, 'f')"], "unit": "ADC/sample"},
+        "curr_av": {"function": "moving_window_multi", "module": _M, "args": ["curr_up", "48", 3, 0, "curr_av"], "unit": "ADC/sample"},
+        "aoe_t_min, tp_aoe_max, A_min, A_max": {"function": "min_max", "module": _M, "unit": ["ns", "ns", "ADC/sample", "ADC/sample"],
+                                                "args": ["curr_av", "aoe_t_min", "tp_aoe_max", "A_min", "A_max"]},
+        "tp_aoe_samp": {"function": "add", "module": "numpy", "args": ["tp_0_est", "tp_aoe_max/16", "tp_aoe_samp"], "unit": "ns"},
+    },
+}
