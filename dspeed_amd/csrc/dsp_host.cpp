@@ -728,10 +728,15 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             case DSP_OP_MIN_MAX:
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst + 3 >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad MIN_MAX", i);
                 break;
-            case DSP_OP_LINEAR_SLOPE_FIT:
+            case DSP_OP_LINEAR_SLOPE_FIT: {
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst + 3 >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad LINEAR_SLOPE_FIT", i);
-                if (slot_len[o.src] < 2) return fail(DSP_E_ZERODIV, "%s", dsp_fatal_message(DSP_E_ZERODIV));  // the line fit's denominator
+                const int first = o.ip[0], count = o.ip[1] > 0 ? o.ip[1] : slot_len[o.src] - first;  // ip[1] == 0: to the end of the slot
+                if (first < 0 || count < 0 || first + count > slot_len[o.src]) return fail(DSP_ERR_ARG, "op %d: LINEAR_SLOPE_FIT slice out of range", i);
+                if (count < 2) return fail(DSP_E_ZERODIV, "%s", dsp_fatal_message(DSP_E_ZERODIV));  // the line fit's denominator
+                d.ic[0] = first;
+                d.ic[1] = count;
                 break;
+            }
             case DSP_OP_AMAX:
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad AMAX", i);
                 break;

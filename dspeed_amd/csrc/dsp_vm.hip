@@ -946,7 +946,8 @@ __device__ __forceinline__ void op_moving_window_multi(Ctx<T>& cx, const DSP_GLO
 template <typename T>
 __device__ __forceinline__ void op_linear_slope_fit(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
-    const int n = ss.len, C = ss.C, lane = lane_id();
+    // the fit runs on samples [first, first + n) of the slot: a constant slice wf[a:b] of an intermediate costs no copy
+    const int first = op.ic[0], n = op.ic[1], C = ss.C, lane = lane_id();
     T o_mean = quiet_nan<T>(), o_std = o_mean, o_slope = o_mean, o_icpt = o_mean;
     if (!cx.slot_nan(op.src)) {
         // regression sums
@@ -954,8 +955,8 @@ __device__ __forceinline__ void op_linear_slope_fit(Ctx<T>& cx, const DSP_GLOBAL
         double sy = 0.0, sxy = 0.0;
 #pragma unroll 8
         for (int t = 0; t < C; ++t) {
-            const int i = lane * C + t;
-            if (i < n) {
+            const int i = lane * C + t - first;
+            if (i >= 0 && i < n) {
                 const double x = (double)ps[t];
                 sy += x;
                 sxy += x * (double)i;
@@ -963,18 +964,33 @@ __device__ __forceinline__ void op_linear_slope_fit(Ctx<T>& cx, const DSP_GLOBAL
         }
         sy = readlane(wave_scan_add(sy), 63);
         sxy = readlane(wave_scan_add(sxy), 63);
-        // Welford, sequential
+        // Welford, sequential.  The division by the sample count is the long pole of the dependent chain: 64 samples at a time every
+        // lane fetches one sample and forms one count and its reciprocal (off the chain, one division per lane instead of 64), the
+        // chain takes them by readlane and divides with div_by_count -- the correctly rounded quotient in 3 dependent operations.
+        // A waveform with an infinity in it (sy not finite) keeps the plain division: there the residual of the short form is NaN.
         T m = (T)0, s = (T)0;
-        for (int i0 = 0; i0 < n; i0 += 8) {
-            T x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = cx.lds[padded_index(ss, i0 + u < n ? i0 + u : n - 1)];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (i0 + u < n) {
-                    const T temp = x[u] - m;
-                    m = (T)((double)m + (double)temp / (double)(i0 + u + 1));
-                    s = s + temp * (x[u] - m);
+        const bool finite = (sy - sy) == 0.0;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int il = i0 + lane;
+            const T xl = cx.lds[padded_index(ss, first + (il < n ? il : n - 1))];
+            const double dl = (double)(il + 1), invl = 1.0 / dl;
+            const int cnt = n - i0 < 64 ? n - i0 : 64;
+            if (finite) {
+#pragma unroll 8
+                for (int u = 0; u < cnt; ++u) {
+                    const T x = readlane(xl, u);
+                    const double d = readlane(dl, u), inv = readlane(invl, u);
+                    const T temp = x - m;
+                    const double td = (double)temp, q = td * inv;
+                    m = (T)((double)m + __builtin_fma(__builtin_fma(-q, d, td), inv, q));
+                    s = s + temp * (x - m);
+                }
+            } else {
+                for (int u = 0; u < cnt; ++u) {
+                    const T x = readlane(xl, u);
+                    const T temp = x - m;
+                    m = (T)((double)m + (double)temp / readlane(dl, u));
+                    s = s + temp * (x - m);
                 }
             }
         }
@@ -1282,7 +1298,7 @@ __device__ __forceinline__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
         int kA = uniform(wave_max(ob + (R - 1) + start - (n - 1))), kB = uniform(wave_min(ob + start - (U - 1)));  // (SGPRs: tap addresses stay scalar)
         kA = kA < 0 ? 0 : ((kA + U - 1) / U) * U;
         if (kB > m - U) kB = m - U;
-        if (!linear || kB < kA) {
+        if ((!linear && ss.C < 2 * U) || kB < kA) {
             slow_taps(0, m);
         } else {
             slow_taps(0, kA);
@@ -1292,9 +1308,24 @@ __device__ __forceinline__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
             // (taps as scalar loads -- constant address space, SGPR operands -- were measured slower: v_pk_fma_f32 wants its
             // multiplier pair in VGPRs, so every tap was moved back; the 16-byte vector loads below hit one cache line per wave)
             auto load_block = [&](int k0, T (&wb)[W], T (&hb)[U]) {
-                const auto* base = x0 + (ob + start - k0 - (U - 1));
+                const int i0 = ob + start - k0 - (U - 1);  // first sample of the window
+                if (linear) {
+                    const auto* base = x0 + i0;
 #pragma unroll
-                for (int j = 0; j < W; ++j) wb[j] = base[j];
+                    for (int j = 0; j < W; ++j) wb[j] = base[j];
+                } else {
+                    // chunk-padded input (a waveform the recursive filters also work on): the W samples are W + 1 consecutive LDS
+                    // elements minus the one pad the window may cross (C >= 2U > W: at most one) -- read them all at immediate
+                    // offsets, then drop the pad with one select per sample
+                    const int q = (int)(((float)i0 + 0.5f) * ss.invC);
+                    const int jc = (q + 1) * ss.C - i0;  // first j that lies in the next chunk
+                    const auto* base = x0 + (i0 + q);
+                    T ph[W + 1];
+#pragma unroll
+                    for (int j = 0; j <= W; ++j) ph[j] = base[j];
+#pragma unroll
+                    for (int j = 0; j < W; ++j) wb[j] = j < jc ? ph[j] : ph[j + 1];
+                }
 #pragma unroll
                 for (int u = 0; u < U; ++u) hb[u] = kern[k0 + u];
             };

@@ -1026,11 +1026,64 @@ def _loop_dtype(b: _Builder):
     return np.dtype(np.float32)
 
 
+def _schedule(steps):
+    """Order the processors so that few waveforms are alive at a time -- every waveform variable of a chain lives in LDS, and the
+    LDS a waveform needs decides how many run per compute unit.  The reference's order (depth-first from the outputs,
+    processing_chain.py:2601-2651) is one valid order of a dependency graph; the processors are pure, so any other valid order
+    computes the same values.  List scheduling with two rules: a processor that only reduces waveforms to numbers runs as soon as its
+    operands exist (it can only end lifetimes); among the ones that create a waveform, the one reading the oldest waveform goes
+    first (finish with a waveform before starting on newer ones), an element-wise or recursive filter that may then take its place
+    last."""
+    def leaves(a, acc):
+        if isinstance(a, SExpr):
+            for x in a.args:
+                leaves(x, acc)
+        elif isinstance(a, Var):
+            acc.append(a)
+        elif isinstance(a, tuple) and a and a[0] == "slice":
+            acc.append(a[1])
+        return acc
+
+    producer = {}
+    ins, creates = [], []
+    for j, (fn, args, _k) in enumerate(steps):
+        roles = _SIGS.get(fn, "")
+        mine, reads = [], []
+        for a, r in zip(args, roles):
+            (mine if r in "WS" else reads).extend(leaves(a, []))
+        ins.append(reads)
+        creates.append(any(r == "W" for r in roles))
+        for v in mine:
+            producer.setdefault(id(v), j)
+    deps = [{producer[id(v)] for v in reads if id(v) in producer and producer[id(v)] != j} for j, reads in enumerate(ins)]
+    born = {}  # waveform -> position in the new order of the processor that made it (inputs: -1)
+    order, done = [], set()
+    while len(order) < len(steps):
+        ready = [j for j in range(len(steps)) if j not in done and deps[j] <= done]
+        if not ready:  # (cannot happen for steps that came out of the dependency resolution; keep the given order)
+            return steps
+        reducers = [j for j in ready if not creates[j]]
+        if reducers:
+            j = reducers[0]
+        else:
+            def age(j):
+                wfs = [born.get(id(v), -1) for v in ins[j] if v.kind == "wf"]
+                return min(wfs) if wfs else len(steps)
+            # (same oldest waveform: the one that could overwrite it in place waits until the others have read it)
+            j = min(ready, key=lambda j: (age(j), steps[j][0] in ("bl_subtract", "pole_zero", "double_pole_zero"), j))
+        for a, r in zip(steps[j][1], _SIGS.get(steps[j][0], "")):
+            if r == "W" and isinstance(a, Var):
+                born[id(a)] = len(order)
+        order.append(j)
+        done.add(j)
+    return [steps[j] for j in order]
+
+
 def _compile(b: _Builder, out_pars, n_rows, proc_strings):
     p = Program()
     ft = _loop_dtype(b)
     in_bind, out_bind, consts = {}, {}, {}
-    steps = b.steps
+    steps = b.steps = _schedule(b.steps)
 
     # --- uses: which step reads which variable last (slot reuse, in-place decisions, fusions)
     def wf_of(a):
@@ -1351,13 +1404,16 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             p.add_op(_lib.OP_MEAN_BELOW, dst=o.sreg, src=src.slot, sp=(scalar_operand(args[1], args, what=what),))
             release(src, si)
         elif fn == "linear_slope_fit":
-            src = ensure_loaded(args[0], si)
+            a0, view = args[0], (0, 0)
+            if isinstance(a0, tuple) and a0[0] == "slice" and not a0[1].is_input:  # a window of an intermediate: read in place
+                a0, view = a0[1], (a0[2], a0[3] - a0[2])
+            src = ensure_loaded(a0, si)
             first = p.add_sregs(4)
             for k, a in enumerate(args[1:5]):
                 if not isinstance(a, Var):
                     raise ProcessingChainError("linear_slope_fit outputs must be variable names")
                 a.kind, a.sreg = "scalar", first + k
-            p.add_op(_lib.OP_LINEAR_SLOPE_FIT, dst=first, src=src.slot)
+            p.add_op(_lib.OP_LINEAR_SLOPE_FIT, dst=first, src=src.slot, ip=view)
             release(src, si)
         elif fn == "amax":
             src = ensure_loaded(args[0], si)
@@ -1447,6 +1503,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
         raise NotImplementedError("recipe is too large for one device chain (ops/slots/bindings limit)")
     chain = ProcessingChain(p, in_bind, out_bind, consts, n_rows, proc_strings, ft)
     return chain, tb_out
+
 
 
 def shard_rows(n_rows: int, world_size: int, rank: int) -> tuple[int, int]:

@@ -175,7 +175,7 @@ typedef struct dsp_scalar_arg {
 #define DSP_OP_MOVING_WINDOW_MULTI 26 /* moving_windows.py:117-204  dst <- ip[1] moving averages of src, length sp[0] (constant), ip[0] = mw_type,
                                   * ip[2] = scratch slot (needed for two or more windows) */
 #define DSP_OP_LINEAR_SLOPE_FIT 27 /* linear_slope_fit.py:11-91  sreg[dst..dst+3] <- mean, stdev (Welford, in the reference's rounding
-                                  * sequence), slope, intercept of src */
+                                  * sequence), slope, intercept of src[ip[0] : ip[0] + ip[1]] (ip[1] == 0: to the end of the slot) */
 #define DSP_OP_SCALAR_AFFINE 18 /* sreg[dst] <- sp[0] * sp[1] + sp[2]  (recipe expressions: tp_0 + 10*us, 0.9*trapTmax, a + b, a * b, a - b) */
 #define DSP_OP_SCALAR_CONVERT 28 /* unit_conversion.py:16-79  sreg[dst] <- f((sp[0] + sp[1]) * sp[3] - sp[2]) in float64, rounded to the loop type:
                                   * a time coordinate moved between two CoordinateGrids (processing_chain.py:1806-1908).  sp[1] / sp[2] = offset of
