@@ -9,14 +9,20 @@ What is kept from the reference (so existing LEGEND recipes for the energy chain
   ``defaults`` (:2555-2583), multi-output keys split on ``,``/space (:2480-2483), dependency resolution by
   depth-first search from the requested outputs with cycle detection (:2601-2651), constant folding of processors
   whose inputs are all constants -- how cusp/zac kernels are built once (:2775-2823);
-* argument syntax: literals, ``'c'`` characters, ``N*us`` quantities converted to samples with the waveform period
-  (:1747-1770), output declarations ``name(length, 'f')``, constant slices ``wf[a:b]``, ``len(wf)``, ``round(x)``,
-  ``wf.period``, arithmetic on constants, ``var + constant`` on per-event scalars;
-* the literal module string ``dspeed.processors`` (and ``numpy`` for ``amax``) resolves to this package's registry.
+* argument syntax (:718-1130): literals, ``'c'`` characters, ``N*us`` quantities, output declarations ``name(length, 'f',
+  grid=..., unit=..., period=..., offset=...)``, constant slices ``wf[a:b]`` (bounds may be times), ``len(wf)``,
+  ``round/floor/ceil/trunc(x, to_nearest)``, ``wf.period`` / ``.offset`` / ``.grid``, arithmetic on constants and ``+ - * /``
+  between per-event variables, constants and times (one scalar op each, like the reference's one ufunc processor each), inline
+  definitions (``"QDrift": "trapQftp * 16"``);
+* units and coordinate grids (:67-144, :1556-1732, :1806-1908): a waveform has a grid (period, offset) -- the input's from
+  ``WaveformInput(values, dt, t0)`` --, a processor works on the grid of its first waveform argument, per-event variables with a
+  time unit are sample indices on that grid, converted when another grid reads them and written in their unit;
+* the literal module string ``dspeed.processors`` (and ``numpy`` for ``amax`` / ``add``) resolves to this package's registry.
 
 What is different by design: instead of calling one gufunc per processor per 16-row block, the resolved processor
 list is translated into ONE device program (``dsp_chain_create``) that keeps every intermediate waveform in LDS, and
-``execute`` launches it over the whole buffer.  Anything outside the supported subset raises
+``execute`` launches it over the whole buffer; the processors are ordered for short waveform lifetimes (``_schedule``), which
+is a reordering of pure functions within their dependencies.  Anything outside the supported subset raises
 ``ProcessingChainError``/``NotImplementedError`` -- there is no CPU fallback.
 """
 from __future__ import annotations
