@@ -1,0 +1,179 @@
+"""CPU tests of the recipe language's unit / coordinate-grid layer and of the scheduling of whole recipes (translation only: the device
+chain is created lazily, no GPU needed).  Reference semantics: processing_chain.py:67-144 (CoordinateGrid), :832-891 (operators as
+ufunc processors), :1193-1266 (round & co), :1556-1732 (a processor's grid, is_coord), :1806-1908 + unit_conversion.py:16-79."""
+import numpy as np
+import pytest
+
+import recipes
+from dspeed_amd import _lib
+from dspeed_amd.errors import ProcessingChainError
+from dspeed_amd.processing_chain import Grid, Quantity, WaveformInput, _Builder, build_processing_chain
+
+M = "dspeed.processors"
+SCALAR_OPS = (_lib.OP_SCALAR_AFFINE, _lib.OP_SCALAR_DIV, _lib.OP_SCALAR_CONVERT, _lib.OP_STORE_SCALAR)
+
+
+def _tb(n=4, wf_len=8192, t0=0.0, dtype=np.uint16):
+    return {"waveform": WaveformInput(np.zeros((n, wf_len), dtype=dtype), 16.0, t0), "baseline": np.zeros(n, dtype=np.float32)}
+
+
+def _slots(op):
+    L = _lib
+    opcode, dst, src, _io, ip, _sp = op
+    if opcode == L.OP_LOAD:
+        return (), (dst,)
+    if opcode in (L.OP_STORE, L.OP_TRAP_PICKOFF, L.OP_TRAP_REDUCE, L.OP_PICKOFF, L.OP_TIME_POINT_THRESH, L.OP_MEAN_BELOW,
+                  L.OP_TRAP_WINDOW_PICKOFF, L.OP_MIN_MAX, L.OP_LINEAR_SLOPE_FIT, L.OP_AMAX, L.OP_CONVOLVE_AMAX):
+        return (src,), ()
+    if opcode == L.OP_DWT_HAAR:
+        return (src,), (dst, ip[2])
+    if opcode == L.OP_MOVING_WINDOW_MULTI:
+        return (src,), ((dst, ip[2]) if ip[1] > 1 else (dst,))
+    if opcode in SCALAR_OPS:
+        return (), ()
+    return (src,), (dst,)
+
+
+def _regs_written(op):
+    L = _lib
+    opcode, dst, _src, io, ip, _sp = op
+    if opcode in (L.OP_MIN_MAX, L.OP_LINEAR_SLOPE_FIT):
+        return list(range(dst, dst + 4))
+    if opcode == L.OP_TRAP_REDUCE:
+        return ([] if dst < 0 else list(range(dst, dst + 4))) + ([] if io < 0 else [io])
+    if opcode in (L.OP_PICKOFF, L.OP_TRAP_PICKOFF, L.OP_TIME_POINT_THRESH, L.OP_AMAX, L.OP_CONVOLVE_AMAX, L.OP_MEAN_BELOW,
+                  L.OP_TRAP_WINDOW_PICKOFF, L.OP_SCALAR_AFFINE, L.OP_SCALAR_DIV, L.OP_SCALAR_CONVERT):
+        return [dst]
+    return []
+
+
+def _check_program_order(program):
+    """every waveform slot and scalar register is written before it is read"""
+    have_slot, have_reg = set(), set()
+    for i, op in enumerate(program.ops):
+        reads, writes = _slots(op)
+        for s in reads:
+            assert s in have_slot, f"op {i} reads slot {s} before it is written"
+        if op[0] == _lib.OP_TRAP_REDUCE:  # its threshold walk may start at the t_max its own min_max part just wrote
+            have_reg.update(_regs_written(op))
+        for a in op[5]:
+            if a.kind == _lib.ARG_REG:
+                assert a.index in have_reg, f"op {i} reads register {a.index} before it is written"
+        if op[0] == _lib.OP_STORE_SCALAR:
+            assert op[4][0] in have_reg
+        have_slot.update(writes)
+        have_reg.update(_regs_written(op))
+
+
+def _peak_live_samples(program):
+    first, last = {}, {}
+    for i, op in enumerate(program.ops):
+        reads, writes = _slots(op)
+        for s in set(reads) | set(writes):
+            first.setdefault(s, i)
+            last[s] = i
+    return max(sum(program.slots[s] for s in first if first[s] <= i <= last[s]) for i in range(len(program.ops)))
+
+
+@pytest.mark.parametrize("t0", [48000.0, "per_row"])
+def test_whole_ge_recipe_translates_into_one_program(t0):
+    tb = _tb(t0=np.zeros(4, dtype=np.float32) if t0 == "per_row" else t0)
+    chain, mask, out = build_processing_chain(recipes.ICPC, tb)
+    P = chain.program
+    assert sorted(mask) == ["baseline", "waveform"] and set(out) == set(recipes.ICPC["outputs"])
+    assert len(P.ops) <= _lib.MAX_OPS and len(P.slots) <= _lib.MAX_SLOTS and P.n_sregs <= _lib.MAX_SREGS and len(P.io) <= _lib.MAX_IO
+    _check_program_order(P)
+    # the scheduler keeps at most two 8192-sample waveforms alive (pole_zero in place of the baseline-subtracted waveform, the fits
+    # on slice views, the cusp FIR before the pole-zero correction): two waveforms per compute unit instead of "does not fit"
+    assert _peak_live_samples(P) <= 2 * 8192 + 1024
+    opcodes = [o[0] for o in P.ops]
+    assert opcodes.count(_lib.OP_LOAD) == 1 and opcodes.count(_lib.OP_POLE_ZERO) == 1
+    pz = P.ops[opcodes.index(_lib.OP_POLE_ZERO)]
+    assert pz[1] == pz[2], "pole_zero runs in place"
+    fits = [o for o in P.ops if o[0] == _lib.OP_LINEAR_SLOPE_FIT]
+    assert sorted(o[4] for o in fits) == [(0, 700), (1600, 6592)]
+    # time coordinates leave in ns: one conversion per such output, period ratio 16; tp_aoe_max has no grid and leaves as it is
+    conv = [o for o in P.ops if o[0] == _lib.OP_SCALAR_CONVERT and o[4][0] == 0 and o[5][3].value == 16.0]
+    n_time_outputs = sum(1 for k in recipes.ICPC["outputs"] if k.startswith("tp_") and k != "tp_aoe_max")
+    assert len(conv) == n_time_outputs
+    names = [io[0] for io in P.io]
+    if t0 == "per_row":
+        assert "in:waveform.t0" in names
+        assert all(o[5][1].kind == _lib.ARG_REG for o in conv), "per-row offsets are per-event operands"
+    else:
+        assert all(o[5][1].kind == _lib.ARG_CONST and o[5][1].value == 3000.0 for o in conv)
+    # round(tp_0_est + 8*us + 2*us*0.8, wf_etrap.grid): two additions, one conversion with rint
+    rints = [o for o in P.ops if o[0] == _lib.OP_SCALAR_CONVERT and o[4][0] == 1]
+    assert len(rints) == 1 and rints[0][5][3].value == 1.0
+    adds = [o[5][2].value for o in P.ops if o[0] == _lib.OP_SCALAR_AFFINE and o[5][2].kind == _lib.ARG_CONST]
+    assert 500.0 in adds and 100.0 in adds and 506.0 in adds
+    assert opcodes.count(_lib.OP_SCALAR_DIV) == 1  # QDrift / trapTmax
+
+
+def test_requesting_fewer_outputs_drops_what_they_do_not_need():
+    chain, _, out = build_processing_chain(recipes.ICPC, _tb(), outputs=["bl_std"])
+    assert [o[0] for o in chain.program.ops] == [_lib.OP_LOAD, _lib.OP_BL_SUBTRACT, _lib.OP_LINEAR_SLOPE_FIT, _lib.OP_STORE_SCALAR]
+    assert chain.program.slots == [700], "a constant slice of the input is loaded as such"
+
+
+def test_a_processor_works_on_the_grid_of_its_first_waveform():
+    rec = {"outputs": ["t_whole", "t_win", "a"], "processors": {
+        "t_a, t_whole, lo, hi": {"function": "min_max", "module": M, "args": ["waveform", "t_a", "t_whole", "lo", "hi"], "unit": ["ns", "us", "ADC", "ADC"]},
+        "t_b, t_win, lo2, hi2": {"function": "min_max", "module": M, "args": ["waveform[1000:3000]", "t_b", "t_win", "lo2", "hi2"],
+                                 "unit": ["ns", "ns", "ADC", "ADC"]},
+        "a": {"function": "fixed_time_pickoff", "module": M, "args": ["waveform", "t_win", "'n'", "a"], "unit": "ADC"}}}
+    chain, _, _ = build_processing_chain(rec, _tb(t0=160.0))
+    conv = [o for o in chain.program.ops if o[0] == _lib.OP_SCALAR_CONVERT]
+    by_ratio = {(round(o[5][3].value, 6), round(o[5][1].value, 6), round(o[5][2].value, 6)) for o in conv}
+    # t_whole: grid (16 ns, 160 ns) -> us: (t + 10) * 0.016;  t_win: grid (16 ns, 160 + 16000 ns) -> ns: (t + 1010) * 16
+    # t_win read by a processor on the whole waveform: (t + 1010) * 1 - 10
+    assert by_ratio == {(0.016, 10.0, 0.0), (16.0, 1010.0, 0.0), (1.0, 1010.0, 10.0)}
+
+
+def test_argument_language_on_per_event_variables():
+    b = _Builder(_tb(), {})
+    wf = b.input_var("waveform")
+    assert wf.grid == Grid(16.0, 0.0) and b.eval_arg("waveform.grid") == Grid(16.0)
+    assert isinstance(b.eval_arg("waveform.offset"), Quantity) and float(b.eval_arg("waveform.offset")) == 0.0
+    assert b.eval_arg("waveform[100:200].offset") == Quantity(1600.0)
+    assert b.eval_arg("len(waveform[:round(len(waveform)-(33.6*us/waveform.period))])") == 6092
+    assert b.eval_arg("len(waveform[16*us:32*us])") == 1000, "slice bounds may be times"
+    assert b.eval_arg("round(1*us, waveform.period)") == Quantity(992.0) and b.eval_arg("ceil(1*us, waveform.period)") == Quantity(1008.0)
+    assert b.eval_arg("round(187.5)") == 188 and b.eval_arg("round(186.5)") == 186 and b.eval_arg("floor(-0.5)") == -1
+    rec = {"outputs": ["x", "y", "z", "w"], "processors": {
+        "t_a, t_b, lo, hi": {"function": "min_max", "module": M, "args": ["waveform", "t_a", "t_b", "lo", "hi"], "unit": ["ns", "ns", "ADC", "ADC"]},
+        "x": "hi - lo", "y": "-(lo / hi) * 3", "z": "round(t_b, 4)", "w": "t_b - t_a"}}
+    chain, _, _ = build_processing_chain(rec, _tb())
+    ops = chain.program.ops
+    assert sum(o[0] == _lib.OP_SCALAR_DIV for o in ops) == 1
+    sub = [o for o in ops if o[0] == _lib.OP_SCALAR_AFFINE and o[5][1].kind == _lib.ARG_CONST and o[5][1].value == -1.0 and o[5][2].kind == _lib.ARG_REG]
+    assert len(sub) == 2, "a - b is (-1 * b) + a, one rounding"
+    z = [o for o in ops if o[0] == _lib.OP_SCALAR_CONVERT and o[4][0] == 1]
+    assert len(z) == 1 and z[0][5][3].value == 0.25, "round(t, 4): onto a grid of 4 periods"
+    # the difference of two coordinates is a plain number: written as it is, no conversion to ns
+    w_store = [i for i, io in enumerate(chain.program.io) if io[0] == "out:w"][0]
+    w_reg = [o[4][0] for o in ops if o[0] == _lib.OP_STORE_SCALAR and o[3] == w_store][0]
+    assert any(o[0] == _lib.OP_SCALAR_AFFINE and o[1] == w_reg for o in ops)
+
+
+def test_what_the_language_does_not_take_fails_by_name():
+    for expr, exc in (("waveform * 2", NotImplementedError), ("waveform[0:100:2]", NotImplementedError), ("t_b * (2*ns)", NotImplementedError),
+                      ("baseline.grid", ProcessingChainError), ("t_b // 2", NotImplementedError)):
+        rec = {"outputs": ["x"], "processors": {
+            "t_a, t_b, lo, hi": {"function": "min_max", "module": M, "args": ["waveform", "t_a", "t_b", "lo", "hi"], "unit": ["ns", "ns", "ADC", "ADC"]},
+            "x": {"function": "fixed_time_pickoff", "module": M, "args": ["waveform", expr, "'n'", "x"]}}}
+        with pytest.raises(exc):
+            build_processing_chain(rec, _tb())
+    plain = {"waveform": np.zeros((4, 1024), dtype=np.float32)}  # no WaveformInput: no grid to take a period from
+    with pytest.raises(ProcessingChainError):
+        build_processing_chain({"outputs": ["x"], "processors": {"x": f"{M}.fixed_time_pickoff(waveform, 10*us/waveform.period, 'n', x)"}}, plain)
+
+
+def test_scheduler_only_reorders_within_dependencies():
+    for rec in (recipes.C1, recipes.C2, recipes.C2_UNITS, recipes.C3, recipes.C5, recipes.ICPC):
+        wf_len = 8192 if rec in (recipes.C3, recipes.C5, recipes.ICPC) else 4096
+        tb = _tb(wf_len=wf_len, dtype=np.int16 if rec is recipes.C5 else np.float32)
+        tb["t_pick"] = np.zeros(4, dtype=np.float32)
+        tb["thr"] = np.zeros(4, dtype=np.float32)
+        chain, _, _ = build_processing_chain(rec, tb)
+        _check_program_order(chain.program)
