@@ -30,10 +30,11 @@ def _convert(x, off_in, off_out, ratio, rounding=None):
     return r.astype(x.dtype)
 
 
-def _expected(wf, bl, t0_ns, dt=16.0):
+def _expected(wf, bl, t0_ns, F=np.float32, dt=16.0):
     P = __import__("dspeed_amd.processors", fromlist=["x"])
     e = {}
     w = wf.astype(F)
+    bl, t0_ns = bl.astype(F), t0_ns.astype(F)
     off = _convert(t0_ns, 0.0, 0.0, 1.0 / dt)  # the grid offset in samples, in t0's type (reference :126-136)
     to_ns = lambda t: _convert(t, off.astype(np.float64), 0.0, dt)  # noqa: E731   (index + offset) * period
 
@@ -43,7 +44,7 @@ def _expected(wf, bl, t0_ns, dt=16.0):
     e["bl_mean"], e["bl_std"], e["bl_slope"], e["bl_intercept"], _ = oracle.linear_slope_fit(blsub[:, :700])
     pz = oracle.pole_zero(blsub, F(27460.0 / dt))[0]
     e["pz_mean"], e["pz_std"], _, _, _ = oracle.linear_slope_fit(np.ascontiguousarray(pz[:, 1600:]))
-    k0 = np.zeros(133, dtype=F)
+    k0 = np.zeros(133, dtype=np.float32)  # (declared 'f': float32 taps in either loop)
     P.t0_filter(128.0 / dt, 2000.0 / dt, k0)
     wt0 = oracle.convolve_wf(pz, k0, "s", 8192)[0]
     _, tp_start, _, _, _ = oracle.min_max(wt0)
@@ -58,7 +59,7 @@ def _expected(wf, bl, t0_ns, dt=16.0):
     # round(tp_0_est + 8*us + 2*us*0.8, wf_etrap.grid): two float32 additions, then rint on the same grid
     t_pick = _convert((tp0 + F(8000.0 / dt)) + F(2000.0 * 0.8 / dt), off.astype(np.float64), off.astype(np.float64), 1.0, np.rint)
     e["trapEftp"] = oracle.fixed_time_pickoff(etrap, t_pick, "l")[0]
-    kc = np.zeros(8192 - 2100 - 300, dtype=F)
+    kc = np.zeros(8192 - 2100 - 300, dtype=np.float32)
     P.cusp_filter(20000.0 / dt, float(np.rint(3000.0 / dt)), 450000.0 / dt, kc)
     cusp = oracle.convolve_wf(blsub, kc, "v", 301, in_len=8192 - 2100)[0]
     e["cuspEmax"] = np.max(cusp, axis=1)
@@ -85,20 +86,23 @@ def _expected(wf, bl, t0_ns, dt=16.0):
     return e, tp0
 
 
-@pytest.mark.parametrize("t0_kind", ["per_row", "constant"])
-def test_whole_ge_recipe_is_one_device_program(t0_kind):
+@pytest.mark.parametrize("t0_kind,rows_dtype", [("per_row", np.uint16), ("constant", np.uint16), ("per_row", np.int32)])
+def test_whole_ge_recipe_is_one_device_program(t0_kind, rows_dtype):
+    """uint16 rows run the float32 loop, int32 rows the float64 loop (first castable signature, processing_chain.py:1565-1572)"""
     from dspeed_amd.processing_chain import WaveformInput, build_processing_chain
 
     rng = np.random.default_rng(2026)
     n = 48
     wf, bl = _synth(rng, n)
+    wf = wf.astype(rows_dtype)
+    ft = np.float64 if rows_dtype == np.int32 else np.float32
     t0_ns = (rng.integers(2900, 3100, n) * 16).astype(F) if t0_kind == "per_row" else np.full(n, 48000.0, dtype=F)
     tb = {"waveform": WaveformInput(wf, 16.0, t0_ns if t0_kind == "per_row" else 48000.0), "baseline": bl}
     chain, mask, out = build_processing_chain(recipes.ICPC, tb)
-    assert sorted(mask) == ["baseline", "waveform"]
+    assert sorted(mask) == ["baseline", "waveform"] and chain.loop_dtype == ft
     chain.execute()
-    want, tp0 = _expected(wf, bl, t0_ns)
-    assert set(out) == set(recipes.ICPC["outputs"])
+    want, tp0 = _expected(wf, bl, t0_ns, ft)
+    assert set(out) == set(recipes.ICPC["outputs"]) and all(v.dtype == ft for v in out.values())
 
     # the start of the rise found on the t0-filtered waveform gates everything after it: rows where a 1e-7 difference in a filtered
     # sample moved a threshold crossing are compared on what does not depend on it
