@@ -357,6 +357,7 @@ static int op_slots(const dsp_op& o, int out[3]) {
         case DSP_OP_TRAP_REDUCE:
         case DSP_OP_PICKOFF:
         case DSP_OP_TIME_POINT_THRESH:
+        case DSP_OP_INTERP_TIME_POINT_THRESH:
         case DSP_OP_MEAN_BELOW:
         case DSP_OP_TRAP_WINDOW_PICKOFF:
         case DSP_OP_MIN_MAX:
@@ -666,6 +667,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad PICKOFF", i);
                 break;
             case DSP_OP_TIME_POINT_THRESH:
+            case DSP_OP_INTERP_TIME_POINT_THRESH:
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad TIME_POINT_THRESH", i);
                 break;
             case DSP_OP_MEAN_BELOW:
@@ -1240,7 +1242,9 @@ int g_pickoff(int ty, const WfIn& in, const void* t_dev, double t_in, int32_t mo
     sto.ip[0] = 0;
     return m.run(in.n_wf, st, er);
 }
-int g_tpt(int ty, const WfIn& in, const void* thr_dev, double thr, const void* ts_dev, double ts, double walk, void* out, void* st, int64_t* er) {
+// mode_char 0: time_point_thresh; otherwise interpolated_time_point_thresh with that interpolation mode
+int g_tpt(int ty, const WfIn& in, const void* thr_dev, double thr, const void* ts_dev, double ts, double walk, void* out, void* st, int64_t* er,
+          int mode_char = 0) {
     if (in.n_wf <= 0) return DSP_OK;
     Mini m(ty);
     m.n_sregs = 1;
@@ -1248,7 +1252,8 @@ int g_tpt(int ty, const WfIn& in, const void* thr_dev, double thr, const void* t
     const int io_in = m.add_io(DSP_IO_WF_IN, in.dtype, in.len, in.stride, in.ptr);
     m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
     dsp_scalar_arg a = m.scalar(thr_dev, thr), b = m.scalar(ts_dev, ts), c = m.scalar(nullptr, walk);
-    dsp_op& o = m.add_op(DSP_OP_TIME_POINT_THRESH, 0, s_in, 0);
+    dsp_op& o = m.add_op(mode_char ? DSP_OP_INTERP_TIME_POINT_THRESH : DSP_OP_TIME_POINT_THRESH, 0, s_in, 0);
+    o.ip[0] = mode_char;
     o.sp[0] = a;
     o.sp[1] = b;
     o.sp[2] = c;
@@ -1390,6 +1395,13 @@ int g_min_max(int ty, const WfIn& in, void* t_min, void* t_max, void* a_min, voi
                                     int64_t* err_row) {                                                                                       \
         return g_tpt(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, threshold_dev, (double)threshold, t_start_dev, (double)t_start,         \
                      (double)walk_forward, out, stream, err_row);                                                                             \
+    }                                                                                                                                         \
+    int dsp_interpolated_time_point_thresh_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,              \
+                                                 const FT* threshold_dev, FT threshold, const FT* t_start_dev, FT t_start,                  \
+                                                 int64_t walk_forward, int32_t mode_char, FT* out, void* stream, int64_t* err_row) {       \
+        if (mode_char <= 0 || mode_char > 127) return fail(DSP_ERR_ARG, "interpolated_time_point_thresh: mode must be a character");       \
+        return g_tpt(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, threshold_dev, (double)threshold, t_start_dev, (double)t_start,         \
+                     (double)walk_forward, out, stream, err_row, mode_char);                                                                \
     }                                                                                                                                         \
     int dsp_windower_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const FT* t0_dev, FT t0, FT* out,   \
                            int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row) {                                             \

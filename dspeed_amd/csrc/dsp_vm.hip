@@ -1098,6 +1098,74 @@ __device__ __forceinline__ void op_time_point_thresh(Ctx<T>& cx, const DSP_GLOBA
 }
 
 // ------------------------------------------------------------------------------------------------
+// interpolated_time_point_thresh  (processors/time_point_thresh.py:95-222): the same crossing search with three differences -- the
+// start is truncated by int() and a start outside the waveform gives NaN instead of DSPFatal, the backward walk stops at sample 2
+// (range(int(t_start), 1, -1)) -- and the result placed between samples i_cross and i_cross + 1 by mode.  Typing as numba resolves
+// it: mode 'l' divides in T, adds the int64 index in float64 and rounds to T; 'n' is index + 0.5 in float64.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void op_interp_time_point_thresh(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    const T thr = cx.scalar(op.sp[0]), ts_f = cx.scalar(op.sp[1]), walk_f = cx.scalar(op.sp[2]);
+    const int mode = op.ip[0];
+    T out = quiet_nan<T>();
+    const int n = ss.len, C = ss.C, lane = lane_id();
+    if (!(cx.slot_nan(op.src) || thr != thr || ts_f != ts_f) && ts_f >= (T)0 && ts_f < (T)n) {
+        const int ts = (int)ts_f;
+        const auto* ps = cx.chunk(ss);
+        const int i0 = lane * C;
+        int ic = -1;
+        if (walk_f > (T)0) {
+            int best = 0x7fffffff;  // smallest i in [ts, n-2] with (w[i] <= thr < w[i+1]) or (w[i] >= thr > w[i+1])
+            T cur = ps[0];
+#pragma unroll 8
+            for (int t = 0; t < C; ++t) {
+                const T nxt = (t < C - 1) ? ps[t + 1] : ps[C + 1];
+                const int i = i0 + t;
+                const bool hit = ((cur <= thr && thr < nxt) || (cur >= thr && thr > nxt)) && i >= ts && i < n - 1;
+                if (hit && best == 0x7fffffff) best = i;
+                cur = nxt;
+            }
+            best = wave_min(best);
+            if (best != 0x7fffffff) ic = best;
+        } else {
+            int best = -1;  // largest i in [2, ts] with (w[i-1] < thr <= w[i]) or (w[i-1] > thr >= w[i]); the crossing is at i - 1
+            T prv = (lane > 0) ? ps[-2] : (T)0;
+#pragma unroll 8
+            for (int t = 0; t < C; ++t) {
+                const T cur = ps[t];
+                const int i = i0 + t;
+                const bool hit = ((prv < thr && thr <= cur) || (prv > thr && thr >= cur)) && i >= 2 && i <= ts && i < n;
+                if (hit) best = i;
+                prv = cur;
+            }
+            best = wave_max(best);
+            if (best >= 0) ic = best - 1;
+        }
+        if (ic >= 0) {
+            const T w0 = cx.lds[padded_index(ss, ic)], w1 = cx.lds[padded_index(ss, ic + 1)];
+            if (mode == 'i' || mode == 'b' || mode == 'c') {
+                out = (T)ic;
+            } else if (mode == 'a' || mode == 'f') {
+                out = (T)(ic + 1);
+            } else if (mode == 'r') {
+                const T d0 = thr - w0, d1 = thr - w1;
+                out = (T)((d0 < (T)0 ? -d0 : d0) < (d1 < (T)0 ? -d1 : d1) ? ic : ic + 1);
+            } else if (mode == 'n') {
+                out = (T)((double)ic + 0.5);
+            } else if (mode == 'l') {
+                const T q = (thr - w0) / (w1 - w0);
+                out = (T)((double)ic + (double)q);
+            } else {
+                cx.fatal(DSP_E_FTP_MODE);  // "Unrecognized interpolation mode": raised by the reference once a crossing is found
+            }
+        }
+    }
+    if (lane == 0) cx.sregs()[op.dst] = out;
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
 // min_max  (processors/min_max.py:11-82): first occurrence of the extremes (strict comparisons)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -1471,6 +1539,7 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 4) dsp_vm_kernel(const DevProgr
                 case DSP_OP_LINEAR_SLOPE_FIT: op_linear_slope_fit(cx, op); break;
                 case DSP_OP_MOVING_WINDOW_MULTI: op_moving_window_multi(cx, op); break;
                 case DSP_OP_TIME_POINT_THRESH: op_time_point_thresh(cx, op); break;
+                case DSP_OP_INTERP_TIME_POINT_THRESH: op_interp_time_point_thresh(cx, op); break;
                 case DSP_OP_MIN_MAX: op_min_max(cx, op, false); break;
                 case DSP_OP_AMAX: op_min_max(cx, op, true); break;
                 case DSP_OP_MEAN_BELOW: op_mean_below(cx, op); break;

@@ -161,7 +161,8 @@ def _is_scalar(a) -> bool:
 #   S = scalar out, t = taps in
 _SIGS = {
     "bl_subtract": "wsW", "pole_zero": "wsW", "double_pole_zero": "wsssW", "trap_filter": "wiiW", "trap_norm": "wiiW",
-    "asym_trap_filter": "wiiiW", "fixed_time_pickoff": "wscS", "time_point_thresh": "wsssS", "min_max": "wSSSS",
+    "asym_trap_filter": "wiiiW", "fixed_time_pickoff": "wscS", "time_point_thresh": "wsssS", "interpolated_time_point_thresh": "wssicS",
+    "min_max": "wSSSS",
     "discrete_wavelet_transform": "wiccW", "convolve_wf": "wtcW", "fft_convolve_wf": "wtcW", "amax": "wiS",
     "mean_below_threshold": "wsS", "windower": "wsW", "avg_current": "wsW", "trap_pickoff": "wiisS",
     "upsampler": "wsW", "moving_window_multi": "wsiiW", "add": "ssS", "linear_slope_fit": "wSSSS",
@@ -1356,6 +1357,13 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             sp = tuple(scalar_operand(a, args, what=what) for a in args[1:4])
             o = out_scalar(args[4])
             p.add_op(_lib.OP_TIME_POINT_THRESH, dst=o.sreg, src=src.slot, sp=sp)
+            release(src, si)
+        elif fn == "interpolated_time_point_thresh":
+            src = ensure_loaded(args[0], si)
+            walk = scalar_operand(args[3], args, integer=True, what=what)
+            sp = (scalar_operand(args[1], args, what=what), scalar_operand(args[2], args, what=what), Scalar.const(float(walk)))
+            o = out_scalar(args[5])
+            p.add_op(_lib.OP_INTERP_TIME_POINT_THRESH, dst=o.sreg, src=src.slot, ip=(char_of(args[4]),), sp=sp)
             release(src, si)
         elif fn == "min_max":
             src = ensure_loaded(args[0], si)

@@ -143,6 +143,24 @@ def _time_point_thresh(g, *args):
         st.release()
 
 
+def _interpolated_time_point_thresh(g, *args):
+    ins, outs = _split(g, args)
+    st = Staging()
+    try:
+        ptr, code, n_wf, n, stride, one_d = st.wf_in(ins[0])
+        sfx = loop_suffix(_dtype_of(ins[0]))
+        ft = _F[sfx]
+        ap, av = st.scalar_in(ins[1], n_wf, ft)
+        sp, sv = st.scalar_in(ins[2], n_wf, ft)
+        walk = int(np.asarray(ins[3]).reshape(-1)[0])  # an int64 argument of the gufunc
+        optr, res = st.out(outs[0], () if one_d else (n_wf,), ft)
+        run(entry("interpolated_time_point_thresh", sfx), g.__name__, ptr, code, n_wf, n, stride, ap, av, sp, sv, walk, _mode_char(ins[4]), optr)
+        st.finish()
+        return res[()] if isinstance(res, np.ndarray) and res.ndim == 0 else res
+    finally:
+        st.release()
+
+
 def _linear_slope_fit(g, *args):
     ins, outs = _split(g, args)
     st = Staging()
@@ -193,6 +211,8 @@ fixed_time_pickoff = HipGUFunc("fixed_time_pickoff", "(n),(),()->()", ["ffb->f",
                                "value at a (fractional) sample index, modes i n f c l h (reference processors/fixed_time_pickoff.py:12-125)")
 time_point_thresh = HipGUFunc("time_point_thresh", "(n),(),(),()->()", ["ffff->f", "dddd->d"], _time_point_thresh,
                               "first threshold crossing walking forward/backward (reference processors/time_point_thresh.py:12-92)")
+interpolated_time_point_thresh = HipGUFunc("interpolated_time_point_thresh", "(n),(),(),(),()->()", ["ffflb->f", "dddlb->d"], _interpolated_time_point_thresh,
+                                           "threshold crossing placed between samples, modes i b c a f r n l (reference processors/time_point_thresh.py:95-222)")
 linear_slope_fit = HipGUFunc("linear_slope_fit", "(n)->(),(),(),()", ["f->ffff", "d->dddd"], _linear_slope_fit,
                              "Welford mean / standard deviation and least-squares slope / intercept (reference processors/linear_slope_fit.py:11-91)")
 mean_below_threshold = HipGUFunc("mean_below_threshold", "(n),()->()", ["ff->f", "dd->d"], _mean_below_threshold,
@@ -451,4 +471,4 @@ zac_filter = HipGUFunc("zac_filter", "(),(),(),(n)", ["ffff", "dddd"], _zac_filt
                        "zero-area CUSP kernel generator, host, once (reference processors/energy_kernels.py:76-157)")
 
 __all__ = ["bl_subtract", "pole_zero", "double_pole_zero", "trap_filter", "trap_norm", "asym_trap_filter", "fixed_time_pickoff",
-           "time_point_thresh", "min_max", "linear_slope_fit", "mean_below_threshold", "windower", "avg_current", "upsampler", "moving_window_multi", "trap_pickoff", "discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "cusp_filter", "zac_filter", "t0_filter", "moving_slope"]
+           "time_point_thresh", "interpolated_time_point_thresh", "min_max", "linear_slope_fit", "mean_below_threshold", "windower", "avg_current", "upsampler", "moving_window_multi", "trap_pickoff", "discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "cusp_filter", "zac_filter", "t0_filter", "moving_slope"]

@@ -181,6 +181,9 @@ typedef struct dsp_scalar_arg {
                                   * a time coordinate moved between two CoordinateGrids (processing_chain.py:1806-1908).  sp[1] / sp[2] = offset of
                                   * the source / target grid in periods, sp[3] = ratio of the periods (constant), ip[0] = f: 0 none, 1 rint,
                                   * 2 floor, 3 ceil, 4 trunc (round()/floor()/ceil()/trunc() onto a grid, processing_chain.py:1193-1266) */
+#define DSP_OP_INTERP_TIME_POINT_THRESH 30 /* time_point_thresh.py:95-222 interpolated_time_point_thresh: sreg[dst] <- crossing of sp[0] found from
+                                  * sp[1] walking forward (sp[2] > 0) or backward, placed between the two samples by ip[0] = mode char
+                                  * i b c a f r n l; a start outside the waveform gives NaN (no DSPFatal) */
 #define DSP_OP_SCALAR_DIV 29     /* sreg[dst] <- sp[0] / sp[1]  (numpy.true_divide between per-event variables: QDrift / trapTmax) */
 
 typedef struct dsp_op {
@@ -243,6 +246,9 @@ int dsp_fixed_time_pickoff_f32(const void* in, int in_dtype, int64_t n_wf, int32
 int dsp_time_point_thresh_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
                               const float* threshold_dev, float threshold, const float* t_start_dev, float t_start,
                               float walk_forward, float* out, void* stream, int64_t* err_row);
+int dsp_interpolated_time_point_thresh_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
+                                           const float* threshold_dev, float threshold, const float* t_start_dev, float t_start,
+                                           int64_t walk_forward, int32_t mode_char, float* out, void* stream, int64_t* err_row);
 int dsp_windower_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* t0_dev, float t0,
                      float* out, int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_avg_current_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float length, float* out,
@@ -283,6 +289,9 @@ int dsp_fixed_time_pickoff_f64(const void* in, int in_dtype, int64_t n_wf, int32
 int dsp_time_point_thresh_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
                               const double* threshold_dev, double threshold, const double* t_start_dev, double t_start,
                               double walk_forward, double* out, void* stream, int64_t* err_row);
+int dsp_interpolated_time_point_thresh_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
+                                           const double* threshold_dev, double threshold, const double* t_start_dev, double t_start,
+                                           int64_t walk_forward, int32_t mode_char, double* out, void* stream, int64_t* err_row);
 int dsp_windower_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const double* t0_dev, double t0,
                      double* out, int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_avg_current_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, double length, double* out,

@@ -146,6 +146,17 @@ def time_point_thresh(w, a_threshold, t_start, walk_forward):
     return out, rc
 
 
+def interpolated_time_point_thresh(w, a_threshold, t_start, walk_forward, mode):
+    w = _rows(w)
+    thr, s1 = _vec(a_threshold, w.shape[0], w.dtype)
+    ts, s2 = _vec(t_start, w.shape[0], w.dtype)
+    out = np.empty(w.shape[0], dtype=w.dtype)
+    m = ord(mode) if isinstance(mode, str) else int(mode)
+    rc = _call("interpolated_time_point_thresh", w.dtype, _p(w), C.c_long(w.shape[0]), C.c_int(w.shape[1]), _p(thr), C.c_int(s1), _p(ts),
+               C.c_int(s2), C.c_long(int(walk_forward)), C.c_int(m), _p(out))
+    return out, rc
+
+
 def min_max(w):
     w = _rows(w)
     o = [np.empty(w.shape[0], dtype=w.dtype) for _ in range(4)]

@@ -237,6 +237,50 @@ static int FN(row_time_point_thresh)(const T* w_in, int n, T a_threshold, T t_st
     return 0;
 }
 
+/* time_point_thresh.py:95-222 interpolated_time_point_thresh.  walk_forward is an int64 argument there (never NaN); t_start is truncated by
+ * int(); a start outside the waveform gives NaN, not DSPFatal; the backward walk stops at sample 2 (range(int(t_start), 1, -1)).
+ * Typing of mode 'l': the quotient is T / T -> T, i_cross (int64) + T -> float64, the store rounds to T; 'n': int64 + 0.5 -> float64. */
+static int FN(row_interpolated_time_point_thresh)(const T* w_in, int n, T a_threshold, T t_start, long walk_forward, int mode, T* t_out) {
+    *t_out = (T)NAN;
+    if (FN(row_has_nan)(w_in, n) || isnan(a_threshold) || isnan(t_start)) return 0;
+    if (t_start < 0 || t_start >= (T)n) return 0;
+    long i_cross = -1;
+    if (walk_forward > 0) {
+        for (long i = (long)t_start; i < n - 1; ++i)
+            if ((w_in[i] <= a_threshold && a_threshold < w_in[i + 1]) || (w_in[i] >= a_threshold && a_threshold > w_in[i + 1])) {
+                i_cross = i;
+                break;
+            }
+    } else {
+        for (long i = (long)t_start; i > 1; --i)
+            if ((w_in[i - 1] < a_threshold && a_threshold <= w_in[i]) || (w_in[i - 1] > a_threshold && a_threshold >= w_in[i])) {
+                i_cross = i - 1;
+                break;
+            }
+    }
+    if (i_cross == -1) return 0;
+    switch (mode) {
+        case 'i':
+        case 'b':
+        case 'c': *t_out = (T)i_cross; return 0;
+        case 'a':
+        case 'f': *t_out = (T)(i_cross + 1); return 0;
+        case 'r': {
+            const T d0 = a_threshold - w_in[i_cross], d1 = a_threshold - w_in[i_cross + 1];
+            *t_out = (T)((d0 < 0 ? -d0 : d0) < (d1 < 0 ? -d1 : d1) ? i_cross : i_cross + 1);
+            return 0;
+        }
+        case 'n': *t_out = (T)((double)i_cross + 0.5); return 0;
+        case 'l': {
+            const T num = a_threshold - w_in[i_cross], den = w_in[i_cross + 1] - w_in[i_cross];
+            const T q = num / den;
+            *t_out = (T)((double)i_cross + (double)q);
+            return 0;
+        }
+        default: return ORC_E_FTP_MODE; /* "Unrecognized interpolation mode", raised only once a crossing was found */
+    }
+}
+
 /* min_max.py:11-82: strict comparisons, first occurrence wins */
 static int FN(row_min_max)(const T* w_in, int n, T* t_min, T* t_max, T* a_min, T* a_max) {
     *t_min = *t_max = *a_min = *a_max = (T)NAN;
@@ -503,6 +547,10 @@ int FN(orc_fixed_time_pickoff)(const T* in, long n_wf, int len, const T* t_in, i
 int FN(orc_time_point_thresh)(const T* in, long n_wf, int len, const T* thr, int thr_stride, const T* t_start, int t_start_stride,
                               T walk_forward, T* out, long* err_row) {
     ROWLOOP(FN(row_time_point_thresh)(in + r * len, len, PV(thr, r), PV(t_start, r), walk_forward, out + r))
+}
+int FN(orc_interpolated_time_point_thresh)(const T* in, long n_wf, int len, const T* thr, int thr_stride, const T* t_start, int t_start_stride,
+                                           long walk_forward, int mode, T* out, long* err_row) {
+    ROWLOOP(FN(row_interpolated_time_point_thresh)(in + r * len, len, PV(thr, r), PV(t_start, r), walk_forward, mode, out + r))
 }
 int FN(orc_min_max)(const T* in, long n_wf, int len, T* t_min, T* t_max, T* a_min, T* a_max, long* err_row) {
     ROWLOOP(FN(row_min_max)(in + r * len, len, t_min + r, t_max + r, a_min + r, a_max + r))

@@ -189,6 +189,13 @@ def call_tpt(w, thr, t_start, walk, dt):
     return out[0], fatal
 
 
+def call_itpt(w, thr, t_start, walk, mode, dt):
+    m = _ref("time_point_thresh")
+    out = np.empty(1, dtype=w.dtype)
+    fatal = run_body(m.interpolated_time_point_thresh, w, dt(thr), dt(t_start), int(walk), ord(mode), out)
+    return out[0], fatal
+
+
 def call_min_max(w):
     m = _ref("min_max")
     o = [np.empty(1, dtype=w.dtype) for _ in range(4)]
@@ -727,6 +734,40 @@ def gen_dwt():
     b.save()
 
 
+def gen_itpt():
+    """interpolated_time_point_thresh (time_point_thresh.py:95-222): the reference's own test cases (tests/processors/
+    test_time_point_thresh.py:118-218), every mode on both walks, starts outside the waveform and between samples, no crossing,
+    an unknown mode with and without a crossing, synthetic trapezoid edges."""
+    rng = np.random.default_rng(0x17A7)
+    b = Book("interpolated_time_point_thresh")
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        saw = np.concatenate([np.arange(-1, 5, 1), np.arange(-1, 5, 1)]).astype(dt)
+        sn = saw.copy()
+        sn[4] = np.nan
+        cases = [(sn, 1, 11, 0, "i"), (saw, np.nan, 11, 0, "i"), (saw, 1, np.nan, 0, "i"), (saw, 1, 12, 0, "i"), (saw, 1, -1, 1, "i"),
+                 (saw, 1, 11.7, 0, "l"), (saw, 3, 0.9, 1, "l"), (saw, 10, 11, 0, "l"), (saw, 10, 0, 1, "l"), (saw, 1, 11, 0, "x"),
+                 (saw, 10, 11, 0, "x"), (saw, 1, 2, 0, "i"), (saw, 0, 1, 0, "i"), (saw, 4, 10, 1, "i"), (saw, 4, 11, 1, "i")]
+        for mode in "ibcafrnl":
+            cases += [(saw, 1, 11, 0, mode), (saw, 3, 0, 1, mode), (saw, 1.5, 11, 0, mode), (saw, 3.5, 0, 1, mode), (saw, 2.25, 11, 0, mode),
+                      (saw, 0.75, 3, 1, mode), (-saw, -1.5, 11, 0, mode), (-saw, -3.25, 0, 1, mode)]
+        for k, (w, thr, ts, wf, mode) in enumerate(cases):
+            out, fatal = call_itpt(w, thr, ts, wf, mode, dt)
+            b.add(f"{tag}_case{k}_{mode}", "interpolated_time_point_thresh", tag, {"w_in": w, "t_out": out},
+                  {"a_threshold": float(thr), "t_start": float(ts), "walk_forward": int(wf), "mode": mode}, fatal)
+        for r in range(3):
+            w, t0 = _pz_step(rng, 1024, dt)
+            at, _ = call_trap("asym_trap_filter", w, 8, 4, 125)
+            mm, _ = call_min_max(at)
+            for thr_scale, walk in ((0.05, 0), (0.5, 0), (0.5, 1), (0.93, 0)):
+                for mode in "lrn":
+                    thr = dt(thr_scale * mm[3])
+                    ts = mm[1] if walk == 0 else 0
+                    out, fatal = call_itpt(at, thr, ts, walk, mode, dt)
+                    b.add(f"{tag}_synth{r}_{thr_scale:g}_{walk}_{mode}", "interpolated_time_point_thresh", tag, {"w_in": at, "t_out": out},
+                          {"a_threshold": float(thr), "t_start": float(ts), "walk_forward": int(walk), "mode": mode}, fatal)
+    b.save()
+
+
 def main():
     if "--dwt" in sys.argv:
         gen_dwt()
@@ -747,6 +788,9 @@ def main():
     if "--lsf" in sys.argv:
         gen_linear_slope_fit()
         return
+    if "--itpt" in sys.argv:
+        gen_itpt()
+        return
     rng = np.random.default_rng(0xD5BEED)
     gen_elementwise(rng)
     gen_pole_zero(rng)
@@ -760,6 +804,7 @@ def main():
     gen_kernels()
     gen_current()
     gen_linear_slope_fit()
+    gen_itpt()
 
 
 if __name__ == "__main__":

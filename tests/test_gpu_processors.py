@@ -251,6 +251,39 @@ def test_time_point_thresh_golden(c, P, DSPFatal):
         _eq(out, c["t_out"], c.name)
 
 
+@pytest.mark.parametrize("c", cases("interpolated_time_point_thresh"), ids=lambda c: c.name)
+def test_interpolated_time_point_thresh_golden(c, P, DSPFatal):
+    """both loops; bit-exact: comparisons, and for 'l' one division and one addition in the reference's types"""
+    p = c.params
+    out = _expect(c, DSPFatal, lambda: P.interpolated_time_point_thresh(c["w_in"], p["a_threshold"], p["t_start"], p["walk_forward"], ord(p["mode"])))
+    if out is not None:
+        assert np.asarray(out).dtype == c["w_in"].dtype
+        _eq(out, c["t_out"], c.name)
+
+
+@pytest.mark.parametrize("wf_len", [1000, 4096, 8192])
+def test_interpolated_time_point_thresh_vs_oracle(wf_len, P):
+    """per-row thresholds and starts (fractional, outside the waveform, NaN), every mode, both walks, on trapezoid edges"""
+    rng = np.random.default_rng(100 + wf_len)
+    n_wf = 70
+    w, bl, _ = _synth(rng, n_wf, wf_len)
+    x = oracle.asym_trap_filter(oracle.pole_zero(oracle.bl_subtract(w, bl)[0], 1716.28)[0], 8, 4, min(125, wf_len // 4))[0]
+    x[5, 7] = np.nan
+    _, tmax, _, amax, _ = oracle.min_max(x)
+    thr = (rng.uniform(0.02, 1.1, n_wf) * np.nan_to_num(amax)).astype(np.float32)
+    thr[9] = np.nan
+    back = (np.nan_to_num(tmax) + rng.uniform(0, 1, n_wf)).astype(np.float32)  # int() truncates the start
+    back[11], back[12], back[13] = np.nan, -0.5, wf_len
+    fwd = rng.uniform(0, 40, n_wf).astype(np.float32)
+    for walk, start in ((0, back), (1, fwd), (-3, back)):
+        for mode in "ibcafrnl":
+            got = P.interpolated_time_point_thresh(x, thr, start, walk, ord(mode))
+            want = oracle.interpolated_time_point_thresh(x, thr, start, walk, mode)[0]
+            _eq(got, want, f"itpt walk={walk} mode={mode}")
+            assert np.isnan(want[[5, 9]]).all() and (walk == 1 or np.isnan(want[[11, 12, 13]]).all())
+    assert np.isfinite(P.interpolated_time_point_thresh(x, thr, back, 0, ord("l"))).mean() > 0.5
+
+
 @pytest.mark.parametrize("c", _f32(cases("min_max")), ids=lambda c: c.name)
 def test_min_max_golden(c, P):
     out = P.min_max(c["w_in"])

@@ -282,6 +282,36 @@ def test_current_branch_of_the_icpc_recipe():
     assert np.all(np.abs(out["tp_aoe_samp"] - (est + tmax / 16)) <= 1.0)
 
 
+def test_interpolated_threshold_times_in_a_recipe():
+    """interpolated_time_point_thresh inside a chain: thresholds from numpy.amax of a trapezoid, start from min_max, the time written in
+    ns with the linear interpolation between samples (the docstring example of the reference, time_point_thresh.py:152-167)"""
+    from dspeed_amd.processing_chain import WaveformInput
+
+    rng = np.random.default_rng(33)
+    x, bl, t0 = _synth(rng, 64, 4096)
+    wf = x.astype(np.float32)
+    M = "dspeed.processors"
+    rec = {"outputs": ["tp_50", "tp_50_i"], "processors": {
+        "wf_blsub": f"{M}.bl_subtract(waveform, baseline, wf_blsub)",
+        "wf_pz": f"{M}.pole_zero(wf_blsub, 27.46*us, wf_pz)",
+        "wf_atrap": f"{M}.asym_trap_filter(wf_pz, 128*ns, 64*ns, 2*us, wf_atrap)",
+        "t_lo, t_hi, a_lo, a_hi": {"function": "min_max", "module": M, "args": ["wf_atrap", "t_lo", "t_hi", "a_lo", "a_hi"],
+                                   "unit": ["ns", "ns", "ADC", "ADC"]},
+        "tp_50": {"function": "interpolated_time_point_thresh", "module": M, "unit": "ns",
+                  "args": ["wf_atrap", "0.5*a_hi", "t_hi", 0, "'l'", "tp_50"]},
+        "tp_50_i": {"function": "interpolated_time_point_thresh", "module": M, "unit": "ns",
+                    "args": ["wf_atrap", "0.5*a_hi", "t_hi", 0, "'i'", "tp_50_i"]}}}
+    _, out = _run(rec, {"waveform": WaveformInput(wf, 16.0, 1600.0), "baseline": bl})
+    at = oracle.asym_trap_filter(oracle.pole_zero(oracle.bl_subtract(wf, bl)[0], np.float32(27460.0 / 16))[0], 8, 4, 125)[0]
+    _, thi, _, ahi, _ = oracle.min_max(at)
+    for mode, key in (("l", "tp_50"), ("i", "tp_50_i")):
+        idx = oracle.interpolated_time_point_thresh(at, np.float32(0.5) * ahi, thi, 0, mode)[0]
+        want = ((idx.astype(np.float64) + 100.0) * 16.0).astype(np.float32)
+        same = out[key] == want
+        assert same.mean() >= 0.9 and np.nanmax(np.abs(out[key] - want)) <= 32.0, key
+    assert np.all(out["tp_50"] >= out["tp_50_i"]) and np.all(out["tp_50"] <= out["tp_50_i"] + 16.0)
+
+
 def test_current_branch_recipe_pieces():
     """windower -> avg_current -> min_max (the first steps of the A/E branch, icpc-dsp-config.json:294-346) and trap_pickoff in one
     recipe; a window that reaches past the input makes NaN samples there, and every consumer of it NaN, as in the reference"""

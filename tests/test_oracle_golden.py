@@ -105,6 +105,20 @@ def test_known_time_point_thresh():
     assert oracle.time_point_thresh(np.array([0.0, -1, -2, -3, -4, -5]), -2.5, 0, 1)[0][0] == 2.0
 
 
+def test_known_interpolated_time_point_thresh():
+    """reference tests/processors/test_time_point_thresh.py:118-218"""
+    saw = np.concatenate([np.arange(-1, 5, 1), np.arange(-1, 5, 1)]).astype(float)
+    w = saw.copy()
+    w[4] = np.nan
+    f = lambda *a: oracle.interpolated_time_point_thresh(*a)[0][0]  # noqa: E731
+    assert np.isnan(f(w, 1.0, 11.0, 0, 105)) and np.isnan(f(saw, np.nan, 11.0, 0, 105)) and np.isnan(f(saw, 1.0, np.nan, 0, 105))
+    assert np.isnan(f(saw, 1.0, 12, 0, 105))
+    for thr, ts, walk, mode, want in ((1, 11, 0, 105, 7.0), (3, 0, 1, 105, 4.0), (1, 11, 0, 102, 8.0), (3, 0, 1, 102, 5.0),
+                                      (1, 11, 0, 99, 7.0), (3, 0, 1, 99, 4.0), (1, 11, 0, 110, 7.5), (3, 0, 1, 110, 4.5),
+                                      (1.5, 11, 0, 108, 8.5), (3.5, 0, 1, 108, 4.5)):
+        assert f(saw, thr, ts, walk, mode) == want, (thr, ts, walk, chr(mode))
+
+
 def test_known_dwt():
     """reference tests/processors/test_dwt.py:8-43"""
     out, rc = oracle.dwt_haar(np.ones(16), 2, "a", 4)
@@ -193,6 +207,14 @@ def test_golden_fixed_time_pickoff(c):
 def test_golden_time_point_thresh(c):
     p = c.params
     out, rc = oracle.time_point_thresh(c["w_in"], p["a_threshold"], p["t_start"], p["walk_forward"])
+    _check_fatal(c, rc)
+    _eq(out[0], c["t_out"], c.name)
+
+
+@pytest.mark.parametrize("c", cases("interpolated_time_point_thresh"), ids=lambda c: c.name)
+def test_golden_interpolated_time_point_thresh(c):
+    p = c.params
+    out, rc = oracle.interpolated_time_point_thresh(c["w_in"], p["a_threshold"], p["t_start"], p["walk_forward"], p["mode"])
     _check_fatal(c, rc)
     _eq(out[0], c["t_out"], c.name)
 
