@@ -116,6 +116,21 @@ class Chain:
         specialised kernel (VM layout, bit-identical to the VM; float32 rows only).  Returns whether a specialised kernel is in use."""
         return bool(_lib.lib().dsp_chain_set_fused(self._h, int(enable)))
 
+    def profile(self, enable: bool = True) -> None:
+        """Switch the in-kernel per-op timing on (zeroing the counters) or off; see ``profile_read``."""
+        _lib.check(_lib.lib().dsp_chain_profile(self._h, int(bool(enable))), what=self.name)
+
+    def profile_read(self) -> dict:
+        """Per op of the device program: opcode, the slot it reads and the shader-clock cycles summed over the sampled waveforms
+        (the first wavefront of every workgroup), plus that number of waveforms."""
+        L = _lib.lib()
+        cap = _lib.MAX_OPS + _lib.MAX_SLOTS
+        opcodes, slots, cycles = (C.c_int32 * cap)(), (C.c_int32 * cap)(), (C.c_uint64 * cap)()
+        n, nwf = C.c_int(), C.c_uint64()
+        _lib.check(L.dsp_chain_profile_read(self._h, cap, opcodes, slots, cycles, C.byref(n), C.byref(nwf)), what=self.name)
+        return {"opcodes": list(opcodes[:n.value]), "slots": list(slots[:n.value]), "cycles": list(cycles[:n.value]),
+                "waveforms": int(nwf.value)}
+
     @property
     def kernel_name(self) -> str:
         return _lib.lib().dsp_chain_kernel_name(self._h).decode()

@@ -1020,10 +1020,44 @@ int dsp_chain_check(dsp_chain* ch, void* stream, int64_t* row) {
     return DSP_OK;
 }
 
+int dsp_chain_profile(dsp_chain* ch, int enable) {
+    if (!ch) return fail(DSP_ERR_ARG, "null chain");
+    HIP_TRY(hipSetDevice(ch->device));
+    const size_t bytes = (size_t)(ch->host.n_ops + 1) * sizeof(unsigned long long);
+    if (enable) {
+        if (!ch->host.prof) HIP_TRY(hipMalloc((void**)&ch->host.prof, bytes));
+        HIP_TRY(hipMemset(ch->host.prof, 0, bytes));
+    } else if (ch->host.prof) {
+        HIP_RELEASE(hipFree(ch->host.prof));
+        ch->host.prof = nullptr;
+    }
+    HIP_TRY(hipMemcpy(ch->dev, &ch->host, sizeof(DevProgram), hipMemcpyHostToDevice));
+    return DSP_OK;
+}
+
+int dsp_chain_profile_read(dsp_chain* ch, int capacity, int32_t* opcodes, int32_t* slots, uint64_t* cycles, int* n_ops, uint64_t* n_waveforms) {
+    if (!ch || !n_ops) return fail(DSP_ERR_ARG, "null argument");
+    *n_ops = ch->host.n_ops;
+    if (!ch->host.prof) return fail(DSP_ERR_ARG, "profiling is off: call dsp_chain_profile(chain, 1) and execute first");
+    if (capacity < ch->host.n_ops || !opcodes || !cycles || !slots) return fail(DSP_ERR_ARG, "capacity %d < %d ops", capacity, ch->host.n_ops);
+    HIP_TRY(hipSetDevice(ch->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<unsigned long long> host(ch->host.n_ops + 1);
+    HIP_TRY(hipMemcpy(host.data(), ch->host.prof, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < ch->host.n_ops; ++i) {
+        opcodes[i] = ch->host.ops[i].opcode;
+        slots[i] = ch->host.ops[i].src;
+        cycles[i] = host[i];
+    }
+    if (n_waveforms) *n_waveforms = host[ch->host.n_ops];
+    return DSP_OK;
+}
+
 int dsp_chain_destroy(dsp_chain* ch) {
     if (!ch) return DSP_OK;
     if (ch->dev) (void)hipFree(ch->dev);
     if (ch->dev_err) (void)hipFree(ch->dev_err);
+    if (ch->host.prof) (void)hipFree(ch->host.prof);
     delete ch;
     return DSP_OK;
 }

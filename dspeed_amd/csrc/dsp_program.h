@@ -45,6 +45,8 @@ struct DevProgram {
     int32_t sreg_off;           // element offset of the scalar register file
     int32_t waves_per_block;
     int32_t pad_;
+    // per-op cycle counters (dsp_chain_profile): n_ops + 1 device words, the last counts the waveforms sampled; null = off
+    unsigned long long* prof;
     DevSlot slots[DSP_MAX_SLOTS];
     DevIO io[DSP_MAX_IO];
     DevOp ops[DSP_MAX_OPS + DSP_MAX_SLOTS]; // + one region-clearing op per slot that shares LDS (DSP_OP_INTERNAL_ZERO)

@@ -1517,11 +1517,21 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 4) dsp_vm_kernel(const DevProgr
     cx.err = err;
     const int64_t total_waves = (int64_t)gridDim.x * wpb;
     const int n_ops = prog->n_ops;
+    // dsp_chain_profile: the first wavefront of every workgroup times each op of its waveforms with the shader clock
+    unsigned long long* prof = prog->prof;
+    const bool sampled = prof != nullptr && wave == 0;
+    unsigned long long t_prev = 0;
     for (int64_t row = (int64_t)blockIdx.x * wpb + wave; row < n_wf; row += total_waves) {
         cx.row = row;
         cx.nan_all = cx.nan_some = 0;
+        if (sampled) t_prev = __builtin_amdgcn_s_memtime();
         for (int i = 0; i < n_ops; ++i) {
             const DSP_GLOBAL DevOp& op = cx.prog->ops[i];
+            if (prof && i > 0 && sampled) {  // close the previous op's interval (one s_memtime per op when profiling, none otherwise)
+                const unsigned long long now = __builtin_amdgcn_s_memtime();
+                if (lane_id() == 0) atomicAdd(prof + (i - 1), now - t_prev);
+                t_prev = now;
+            }
             switch (op.opcode) {
                 case DSP_OP_LOAD: op_load(cx, op); break;
                 case DSP_OP_STORE: op_store(cx, op); break;
@@ -1557,6 +1567,13 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 4) dsp_vm_kernel(const DevProgr
                 case DSP_OP_SCALAR_CONVERT: op_scalar_convert(cx, op); break;
                 case DSP_OP_INTERNAL_ZERO: op_zero_region(cx, op); break;
                 default: break;
+            }
+        }
+        if (sampled) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (lane_id() == 0) {
+                atomicAdd(prof + (n_ops - 1), now - t_prev);
+                atomicAdd(prof + n_ops, 1ull);
             }
         }
     }

@@ -211,6 +211,14 @@ int dsp_chain_destroy(dsp_chain* chain);
 /* launch geometry chosen for the chain (for DESIGN.md / profiling): bytes of LDS per wavefront, wavefronts per
  * workgroup, workgroups for a batch of n_wf rows */
 int dsp_chain_geometry(dsp_chain* chain, int64_t n_wf, int* lds_bytes_per_wave, int* waves_per_block, int* blocks);
+/* Where the time goes inside the one kernel a chain is: with profiling on, the first wavefront of every workgroup times each op of
+ * its waveforms with the shader clock (s_memtime).  dsp_chain_profile(chain, 1) zeroes the counters and switches it on, 0 off (the
+ * fused energy kernels have no ops to time: force the interpreter with dsp_chain_set_fused(chain, 0)).  dsp_chain_profile_read waits
+ * for the device and returns, per op of the device program (the caller's ops plus the region-clearing ops dsp_chain_create inserted,
+ * opcode 100), its opcode, the waveform slot it reads and the summed cycles, and the number of waveforms sampled. */
+int dsp_chain_profile(dsp_chain* chain, int enable);
+int dsp_chain_profile_read(dsp_chain* chain, int capacity, int32_t* opcodes, int32_t* slots, uint64_t* cycles, int* n_ops,
+                           uint64_t* n_waveforms);
 /* name of the device kernel the chain launches (what rocprofv3 --kernel-trace lists) */
 const char* dsp_chain_kernel_name(dsp_chain* chain);
 /* A chain of the shape LOAD [-> BL_SUBTRACT] -> POLE_ZERO -> TRAP_PICKOFF -> STORE_SCALAR (the Ge energy chain) runs on a

@@ -5,6 +5,7 @@ import pytest
 
 import oracle
 import recipes
+from dspeed_amd import _lib as _LIB
 from golden_util import assert_rel_to_peak, cases
 
 pytestmark = pytest.mark.gpu
@@ -310,6 +311,31 @@ def test_interpolated_threshold_times_in_a_recipe():
         same = out[key] == want
         assert same.mean() >= 0.9 and np.nanmax(np.abs(out[key] - want)) <= 32.0, key
     assert np.all(out["tp_50"] >= out["tp_50_i"]) and np.all(out["tp_50"] <= out["tp_50_i"] + 16.0)
+
+
+def test_in_kernel_op_profile():
+    """dsp_chain_profile: per-op shader-clock cycles from inside the one kernel a chain is; results are unchanged by it"""
+    rng = np.random.default_rng(5)
+    x, bl, t0 = _synth(rng, 2048, 4096)
+    wf = x.astype(np.float32)
+    tb = {"waveform": wf, "baseline": bl, "t_pick": (t0 + 700).astype(np.float32)}
+    chain, out = _run(recipes.C2, tb)
+    ref = out["trapEftp"].copy()
+    c = chain._chain
+    c.set_fused(0)  # the interpreter: the specialised kernels have no ops to time
+    chain.execute()
+    vm = out["trapEftp"].copy()
+    c.profile(True)
+    chain.execute()
+    pr = c.profile_read()
+    assert np.array_equal(out["trapEftp"], vm) and np.max(np.abs(vm - ref) / np.abs(ref)) <= TOL
+    assert pr["opcodes"] == [o[0] for o in chain.program.ops] and len(pr["cycles"]) == len(pr["opcodes"])
+    assert 0 < pr["waveforms"] <= 2048 and all(cy > 0 for cy in pr["cycles"])
+    heavy = pr["opcodes"][int(np.argmax(pr["cycles"]))]
+    assert heavy in (_LIB.OP_TRAP_PICKOFF, _LIB.OP_POLE_ZERO, _LIB.OP_LOAD)
+    c.profile(False)
+    with pytest.raises(Exception):
+        c.profile_read()
 
 
 def test_current_branch_recipe_pieces():

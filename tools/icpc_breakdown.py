@@ -52,6 +52,38 @@ def main():
         print(json.dumps({"recipe": "ICPC", "outputs": label, "n_outputs": len(outs), "ops": len(chain.program.ops),
                           "slots": len(chain.program.slots), "lds_bytes_per_waveform": lds.value, "waves_per_block": wpb.value,
                           "rows": rows, "waveforms_per_s": round(rows / dt), "us_per_waveform_per_cu": round(dt / rows * 256 * 1e6, 2)}), flush=True)
+    per_op(recipes.ICPC, tb, list(recipes.ICPC["outputs"]), rows, "ICPC")
+    wf5, _bl, _tp = synth(rows, 8192, np.int16, st, bl_lo=-3000.0, bl_hi=3000.0)
+    thr = DeviceArray.from_numpy(np.full(rows, 20.0, dtype=np.float32))
+    sync()
+    per_op(recipes.C5, {"waveform": wf5, "thr": thr}, list(recipes.C5["outputs"]), rows, "C5")
+
+
+def per_op(recipe, tb, outs, rows, label):
+    """cycles per op of the device program, from the in-kernel timers (dsp_chain_profile)"""
+    names = {getattr(_lib, k): k[3:] for k in dir(_lib) if k.startswith("OP_")}
+    names[100] = "(clear shared LDS)"
+    chain, _, _ = build_processing_chain(recipe, tb, outputs=outs)
+    out_cols = {}
+    for k in outs:
+        v = chain._out_vars[f"out:{k}"][1]
+        out_cols[k] = DeviceArray((rows,) if v is None else (rows, v), np.float32)
+    chain.link(tb, out_cols)
+    chain._ensure()
+    chain._chain.set_fused(0)
+    chain.execute()
+    chain._chain.profile(True)
+    chain.execute()
+    pr = chain._chain.profile_read()
+    total = sum(pr["cycles"])
+    agg = {}
+    for oc, cyc in zip(pr["opcodes"], pr["cycles"]):
+        agg[names.get(oc, str(oc))] = agg.get(names.get(oc, str(oc)), 0) + cyc
+    print(json.dumps({"recipe": label, "per_op_profile": True, "waveforms_sampled": pr["waveforms"],
+                      "cycles_per_waveform": round(total / max(pr["waveforms"], 1)),
+                      "share_by_opcode": {k: round(v / total, 4) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])},
+                      "ops": [[names.get(oc, str(oc)), round(c / max(pr["waveforms"], 1))] for oc, c in zip(pr["opcodes"], pr["cycles"])]}), flush=True)
+    chain._chain.profile(False)
 
 
 if __name__ == "__main__":
