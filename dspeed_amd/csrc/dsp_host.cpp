@@ -497,6 +497,8 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     P.sreg_off = cursor;
     cursor += ((n_sregs + 7) / 8) * 8 + 8;
     cursor = ((cursor + 3) / 4) * 4;
+    P.scratch_off = cursor;
+    cursor += DSP_SCRATCH_ELEMS;
     P.lds_elems_per_wave = cursor;
     ch->lds_bytes_per_wave = cursor * esz;
     if (ch->lds_bytes_per_wave > LDS_BYTES_PER_CU)

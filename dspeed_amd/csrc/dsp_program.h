@@ -8,6 +8,7 @@
 #define DSP_WAVE 64
 #define DSP_FC 40 /* host-precomputed float64 constants per op */
 #define DSP_OP_INTERNAL_ZERO 100 /* host-inserted: clear slot dst's whole LDS region (guard, chunks, pads, tail) before its first use */
+#define DSP_SCRATCH_ELEMS 128
 #define DSP_IC 12 /* host-precomputed integer constants per op */
 
 // One waveform variable living in LDS.  Lane j of the wavefront owns samples [j*C, (j+1)*C) ("chunk");
@@ -44,7 +45,7 @@ struct DevProgram {
     int32_t lds_elems_per_wave; // waveform slots + scalar registers, in elements of the compute type
     int32_t sreg_off;           // element offset of the scalar register file
     int32_t waves_per_block;
-    int32_t pad_;
+    int32_t scratch_off;        // element offset of DSP_SCRATCH_ELEMS elements any op may use while it runs (16-byte aligned)
     // per-op cycle counters (dsp_chain_profile): n_ops + 1 device words, the last counts the waveforms sampled; null = off
     unsigned long long* prof;
     DevSlot slots[DSP_MAX_SLOTS];

@@ -986,22 +986,29 @@ __device__ __forceinline__ void op_linear_slope_fit(Ctx<T>& cx, const DSP_GLOBAL
         }
         sy = readlane(wave_scan_add(sy), 63);
         sxy = readlane(wave_scan_add(sxy), 63);
-        // Welford, sequential.  The division by the sample count is the long pole of the dependent chain: 64 samples at a time every
-        // lane fetches one sample and forms one count and its reciprocal (off the chain, one division per lane instead of 64), the
-        // chain takes them by readlane and divides with div_by_count -- the correctly rounded quotient in 3 dependent operations.
-        // A waveform with an infinity in it (sy not finite) keeps the plain division: there the residual of the short form is NaN.
+        // Welford, sequential, by every lane redundantly.  What shortens it: the samples are read as LDS broadcasts at addresses that
+        // stay in scalar registers (chunk by chunk), the reciprocals of the counts are formed by the lanes in parallel (one division
+        // per lane per segment of at most 64 samples, off the chain) and handed over through the scratch area, and the chain divides
+        // with div_by_count -- the correctly rounded quotient in 3 dependent operations.  A waveform with an infinity in it (sy not
+        // finite) keeps the plain division: there the residual of the short form is NaN.
         T m = (T)0, s = (T)0;
         const bool finite = (sy - sy) == 0.0;
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            const int il = i0 + lane;
-            const T xl = cx.lds[padded_index(ss, first + (il < n ? il : n - 1))];
-            const double dl = (double)(il + 1), invl = 1.0 / dl;
-            const int cnt = n - i0 < 64 ? n - i0 : 64;
+        typedef __attribute__((address_space(3))) double lds_f64;
+        auto* scr = (lds_f64*)(cx.lds + cx.prog->scratch_off);
+        int c0 = first / C, t = first - c0 * C;                   // (uniform: chunk and offset of the next sample)
+        const auto* row = cx.lds + ss.off + c0 * ss.pitch;
+        for (int i = 0; i < n;) {
+            int cnt = C - t;
+            if (cnt > 64) cnt = 64;
+            if (cnt > n - i) cnt = n - i;
+            scr[lane] = 1.0 / (double)(i + lane + 1);
+            wave_sync();
+            const auto* p = row + t;
             if (finite) {
 #pragma unroll 8
                 for (int u = 0; u < cnt; ++u) {
-                    const T x = readlane(xl, u);
-                    const double d = readlane(dl, u), inv = readlane(invl, u);
+                    const T x = p[u];
+                    const double inv = scr[u], d = (double)(i + u + 1);
                     const T temp = x - m;
                     const double td = (double)temp, q = td * inv;
                     m = (T)((double)m + __builtin_fma(__builtin_fma(-q, d, td), inv, q));
@@ -1009,11 +1016,18 @@ __device__ __forceinline__ void op_linear_slope_fit(Ctx<T>& cx, const DSP_GLOBAL
                 }
             } else {
                 for (int u = 0; u < cnt; ++u) {
-                    const T x = readlane(xl, u);
+                    const T x = p[u];
                     const T temp = x - m;
-                    m = (T)((double)m + (double)temp / readlane(dl, u));
+                    m = (T)((double)m + (double)temp / (double)(i + u + 1));
                     s = s + temp * (x - m);
                 }
+            }
+            wave_sync();
+            i += cnt;
+            t += cnt;
+            if (t == C) {
+                t = 0;
+                row += ss.pitch;
             }
         }
         s = (T)((double)s / (double)(n - 1));
