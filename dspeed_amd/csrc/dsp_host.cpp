@@ -460,7 +460,17 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         d.padw = linear[s] ? 0 : 1;
         d.pitch = C + d.padw;
         d.invC = 1.0f / (float)C;
-        foot[s] = 2 * d.pitch + 64 * d.pitch + 40;  // guard, chunks, tail: the pipelined loops read up to 2 groups + 1 past the last chunk
+        // a short FIR kernel (the t0 filter) in 'same' / 'full' mode reads up to m - 1 samples past either end of its input: give the
+        // slot a zero tail long enough that those windows need no bounds checks (below sample 0 the guard serves)
+        int fir_taps = 0;
+        for (int i = 0; i < n_ops; ++i)
+            if ((ops[i].opcode == DSP_OP_CONVOLVE || ops[i].opcode == DSP_OP_CONVOLVE_AMAX) && ops[i].src == s && ops[i].io >= 0 &&
+                ops[i].io < n_io && io[ops[i].io].kind == DSP_IO_TAPS && io[ops[i].io].len <= 1024 && io[ops[i].io].len > fir_taps)
+                fir_taps = io[ops[i].io].len;
+        const int tail = 40 + (fir_taps ? fir_taps + 32 : 0);
+        d.zero_below = 2 * d.pitch - 8;
+        d.zero_above = (len == 64 * C) ? tail - 8 : 0;
+        foot[s] = 2 * d.pitch + 64 * d.pitch + tail;  // guard, chunks, tail: the pipelined loops read up to 2 groups + 1 past the last chunk
         foot[s] = ((foot[s] + 3) / 4) * 4;          // (regions stay 16-byte aligned for the wide clears)
         if (last_op[s] < 0) {                        // never used: alive throughout, so nothing is placed on top of it
             first_op[s] = 0;
@@ -768,7 +778,8 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                     return fail(DSP_ERR_ARG, "op %d: bad CONVOLVE destination", i);
                 const int n = slot_len[o.src], m = io[o.io].len, p = fusedmax ? o.ip[2] : slot_len[o.dst], mode = o.ip[0];
                 d.ic[1] = m;
-                d.ic[2] = o.ip[1] ? 1 : 0;  // caller found a NaN among the taps -> output NaN (convolutions.py:45-46)
+                d.ic[2] = (o.ip[1] & 1) ? 1 : 0;  // caller found a NaN among the taps -> output NaN (convolutions.py:45-46)
+                d.ic[5] = (o.ip[1] & 2) ? 1 : 0;  // ... an infinity: 0 * inf is NaN, so windows must not reach into the zero margins
                 d.ic[3] = p;
                 if (m > n) return fail(DSP_E_CONV_LONG, "%s", dsp_fatal_message(DSP_E_CONV_LONG));
                 if (mode == 'f') {
@@ -1247,9 +1258,11 @@ int g_convolve(int ty, const WfIn& in, const void* kernel_dev, int32_t kernel_le
     const size_t esz = ty == DSP_F64 ? 8 : 4;
     std::vector<unsigned char> taps(esz * (size_t)kernel_len);
     HIP_TRY(hipMemcpy(taps.data(), kernel_dev, taps.size(), hipMemcpyDeviceToHost));
-    int has_nan = 0;
-    for (int k = 0; k < kernel_len; ++k)
-        has_nan |= (ty == DSP_F64 ? std::isnan(((const double*)taps.data())[k]) : std::isnan(((const float*)taps.data())[k])) ? 1 : 0;
+    int has_nan = 0;  // bit 0: a NaN among the taps, bit 1: an infinity
+    for (int k = 0; k < kernel_len; ++k) {
+        const double v = ty == DSP_F64 ? ((const double*)taps.data())[k] : (double)((const float*)taps.data())[k];
+        has_nan |= std::isnan(v) ? 1 : (std::isinf(v) ? 2 : 0);
+    }
     Mini m(ty);
     const int s_in = m.add_slot(in.len), s_out = m.add_slot(out_len > 0 ? out_len : 1);
     const int io_in = m.add_io(DSP_IO_WF_IN, in.dtype, in.len, in.stride, in.ptr);

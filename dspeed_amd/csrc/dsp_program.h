@@ -23,6 +23,9 @@ struct DevSlot {
     int32_t pitch; // C + 1
     float invC;    // 1/C for index -> (lane, offset) splits
     int32_t padw;  // pitch - C: 1 (chunk pad) or 0 (linear)
+    // elements that are guaranteed to read 0 below sample 0 (the guard) and above sample len - 1 (the tail; 0 unless len == 64 * C:
+    // a partial last chunk is only "finite"): a FIR window may reach that far outside the waveform without bounds checks
+    int32_t zero_below, zero_above;
 };
 
 struct DevIO {

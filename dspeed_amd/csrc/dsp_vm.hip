@@ -1370,7 +1370,6 @@ __device__ __forceinline__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
     const int n = ss.len, m = op.ic[1], start = op.ic[0], p = op.ic[3], lane = lane_id();
     const bool linear = ss.padw == 0;  // the host lays FIR inputs out without chunk pads: a window is R + U - 1 consecutive elements
     const auto* x0 = cx.lds + ss.off;
-    auto in_at = [&](int i) -> T { return (i >= 0 && i < n) ? cx.lds[padded_index(ss, i)] : (T)0; };
     for (int o0 = 0; o0 < p; o0 += 64 * R) {
         const int ob_true = o0 + lane * R;  // first output of this lane
         // lanes past the end redo the last R outputs (discarded): their windows then stay inside the waveform like everyone's
@@ -1393,13 +1392,19 @@ __device__ __forceinline__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
             for (int k = ka; k < kb; ++k) {
                 const T kv = kern[k];
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc[r] = fma_t(in_at(ob + r + start - k), kv, acc[r]);
+                for (int r = 0; r < R; ++r) {  // (a sample outside the waveform is left out, not multiplied as a zero: 0 * inf is NaN)
+                    const int idx = ob + r + start - k;
+                    if (idx >= 0 && idx < n) acc[r] = fma_t(cx.lds[padded_index(ss, idx)], kv, acc[r]);
+                }
                 if ((k & 63) == 63) flush();
             }
         };
         // tap k pairs with input index (ob + r + start - k).  A block of U taps starting at k0 touches inputs
         // [ob + start - k0 - (U-1), ob + (R-1) + start - k0]: inside the waveform for every lane iff kA <= k0 <= kB
-        int kA = uniform(wave_max(ob + (R - 1) + start - (n - 1))), kB = uniform(wave_min(ob + start - (U - 1)));  // (SGPRs: tap addresses stay scalar)
+        // (the slot reads 0 for zero_below elements under sample 0 and zero_above over sample n - 1: exactly what the reference's
+        // zero padding of the 'same' and 'full' modes supplies, so windows may reach that far)
+        int kA = uniform(wave_max(ob + (R - 1) + start - (n - 1))) - (op.ic[5] ? 0 : ss.zero_above);  // (SGPRs: tap addresses stay scalar)
+        int kB = uniform(wave_min(ob + start - (U - 1))) + (op.ic[5] ? 0 : ss.zero_below);
         kA = kA < 0 ? 0 : ((kA + U - 1) / U) * U;
         if (kB > m - U) kB = m - U;
         if ((!linear && ss.C < 2 * U) || kB < kA) {

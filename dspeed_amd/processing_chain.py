@@ -1462,7 +1462,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             dst = out_wf(args[3], None, src)
             if dst.length is None:
                 raise ProcessingChainError(f"{fn}: declare the output as name(length, 'f')")
-            has_nan = int(np.isnan(taps.const).any())
+            has_nan = int(np.isnan(taps.const).any()) | (2 if np.isinf(taps.const).any() else 0)  # (bit 1: an infinite tap)
             # fusion: the filtered waveform's only consumer is one numpy.amax and it is not an output -> it is never stored
             users = [sj for sj, (f2, a2, _k) in enumerate(steps) if sj != si and any(wf_of(x) is dst for x in a2)]
             if (len(users) == 1 and steps[users[0]][0] == "amax" and steps[users[0]][1][0] is dst and dst.name not in out_pars

@@ -78,3 +78,44 @@ def test_shortest_waveforms_follow_the_reference(P):
     with pytest.raises(DSPFatal):  # trap_filters.py:59-60: 2*rise + flat > len
         P.trap_filter(w3, 2, 0)
     assert np.array_equal(P.pole_zero(np.ones((1, 1), dtype=np.float32), 10.0), np.ones((1, 1), dtype=np.float32))
+
+
+@pytest.mark.parametrize("wf_len,m", [(8192, 133), (4096, 133), (4096, 16), (8192, 300), (6092, 133), (2048, 1000)])
+def test_fir_edges_same_and_full_modes(wf_len, m):
+    """'same' and 'full' convolutions reach past both ends of the waveform, where the reference pads with zeros (np.convolve,
+    convolutions.py:72): the blocked FIR path reads those zeros from the slot's guard and tail instead of checking bounds.  Compared
+    sample by sample with the oracle -- the edges are the point --, as a processor (input alone in its slot: linear layout) and inside
+    a recipe where the pole-zero filter shares the input (chunk-padded layout); an infinite tap must not meet a padding zero."""
+    import oracle
+    from dspeed_amd import processors as P
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    rng = np.random.default_rng(wf_len + m)
+    n_wf = 12
+    w = (1000 + 100 * rng.standard_normal((n_wf, wf_len))).astype(np.float32)
+    k = rng.standard_normal(m).astype(np.float32)
+    for mode, out_len in (("s", wf_len), ("f", wf_len + m - 1), ("v", wf_len - m + 1)):
+        want = oracle.convolve_wf(w, k, mode, out_len)[0]
+        got = P.convolve_wf(w, k, ord(mode), np.empty((n_wf, out_len), dtype=np.float32))
+        # (random zero-mean taps cancel: the error bound of a dot product is relative to sum |k| * max |w|, not to the output)
+        scale = np.sum(np.abs(k)) * np.max(np.abs(w), axis=1, keepdims=True)
+        assert np.max(np.abs(got - want) / scale) <= 2e-7, (mode, "processor")
+    # inside a chain: the FIR input is the pole-zero output (padded layout), 'same' mode, output stored
+    rec = {"outputs": ["wf_f", "wf_pz"], "processors": {
+        "wf_pz": "dspeed.processors.pole_zero(waveform, 500.5, wf_pz)",
+        "kern": {"function": "t0_filter", "module": "dspeed.processors", "args": [8, m - 8, f"kern({m}, 'f')"]},
+        "wf_f": {"function": "convolve_wf", "module": "dspeed.processors", "args": ["wf_pz", "kern", "'s'", f"wf_f({wf_len}, 'f')"]}}}
+    chain, _, out = build_processing_chain(rec, {"waveform": w})
+    chain.execute()
+    kern = np.zeros(m, dtype=np.float32)
+    P.t0_filter(8, m - 8, kern)
+    pz = oracle.pole_zero(w, 500.5)[0]
+    want = oracle.convolve_wf(pz, kern, "s", wf_len)[0]
+    scale = np.max(np.abs(want), axis=1, keepdims=True)
+    assert np.max(np.abs(out["wf_f"] - want) / scale) <= 2e-6, "recipe, padded input"
+    # an infinite tap: no 0 * inf from the padding
+    k2 = k.copy()
+    k2[m // 2] = np.inf
+    want = oracle.convolve_wf(w, k2, "s", wf_len)[0]
+    got = P.convolve_wf(w, k2, ord("s"), np.empty((n_wf, wf_len), dtype=np.float32))
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
