@@ -834,6 +834,31 @@ __device__ __forceinline__ void op_upsampler(Ctx<T>& cx, const DSP_GLOBAL DevOp&
     const int n = ss.len, m = sd.len, cnt = op.ic[0];
     const double up = op.fc[0], half = op.fc[1];
     bool nan = false;
+    if ((double)cnt == up) {
+        // a whole-number factor (the usual case, 16 in the LEGEND recipes): input t lands on outputs [t * cnt - half, t * cnt - half + cnt),
+        // the ranges tile the output, so output j takes input (j + half) / cnt -- integer arithmetic instead of float64 per output
+        const int ihalf = (int)half;
+        const float inv = 1.0f / (float)cnt;
+#pragma unroll 4
+        for (int j = lane_id(); j < 64 * sd.C; j += 64) {
+            T v = (T)0;
+            if (j < m) {
+                const int x = j + ihalf;
+                int t = (int)((float)x * inv);  // x / cnt up to one either way; x < 2^23
+                if ((t + 1) * cnt <= x) ++t;
+                if (t * cnt > x) --t;
+                v = t < n ? (T)cx.lds[padded_index(ss, t)] : quiet_nan<T>();
+                nan |= (v != v);
+            }
+            cx.lds[padded_index(sd, j)] = v;
+        }
+        if (wave_any(nan))
+            cx.set_some_nan(op.dst);
+        else
+            cx.set_nan(op.dst, false);
+        wave_sync();
+        return;
+    }
     for (int j = lane_id(); j < 64 * sd.C; j += 64) {
         T v = (T)0;
         if (j < m) {
@@ -1527,8 +1552,13 @@ __device__ __forceinline__ void op_scalar_convert(Ctx<T>& cx, const DSP_GLOBAL D
 // host-inserted: a slot that shares its LDS region with others starts from the all-zero state the kernel prologue gives the rest
 template <typename T>
 __device__ __forceinline__ void op_zero_region(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const int base = op.ic[0], n = op.ic[1];
-    for (int e = lane_id(); e < n; e += 64) cx.lds[base + e] = (T)0;
+    const int base = op.ic[0], n = op.ic[1];  // (both multiples of 4 elements: 16-byte stores)
+    typedef T vec4_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) vec4_t lds_vec4;
+    auto* p4 = (lds_vec4*)(cx.lds + base);
+    const vec4_t z = {(T)0, (T)0, (T)0, (T)0};
+#pragma unroll 4
+    for (int e = lane_id(); e < n / 4; e += 64) p4[e] = z;
     cx.set_nan(op.dst, false);
     wave_sync();
 }
