@@ -1104,6 +1104,43 @@ __device__ __forceinline__ void op_mean_below(Ctx<T>& cx, const DSP_GLOBAL DevOp
 }
 
 // ------------------------------------------------------------------------------------------------
+// the threshold walk of time_point_thresh / interpolated_time_point_thresh: 64 consecutive samples per step, starting at t_start and
+// moving away from it, and the walk ends with the first step that holds a crossing -- in the recipes the start is the previous time
+// point and the answer lies a few samples away (a walk that finds nothing visits the whole range, like the reference's loop).
+//   forward:  smallest i in [ts, n - 2] with (w[i] <= thr < w[i+1]) or (w[i] >= thr > w[i+1])
+//   backward: largest  i in [back_lo, ts] with (w[i-1] < thr <= w[i]) or (w[i-1] > thr >= w[i])
+// Returns i or -1.  Comparisons only: bit exact whatever the order of the visits.
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename SlotRef>
+__device__ __forceinline__ int find_crossing(Ctx<T>& cx, const SlotRef& ss, T thr, int ts, bool forward, int back_lo) {
+    const int n = ss.len, lane = lane_id();
+    if (forward) {
+        for (int b = ts; b <= n - 2; b += 64) {
+            const int i = b + lane;
+            bool hit = false;
+            if (i <= n - 2) {
+                const T cur = cx.lds[padded_index(ss, i)], nxt = cx.lds[padded_index(ss, i + 1)];
+                hit = (cur <= thr && thr < nxt) || (cur >= thr && thr > nxt);
+            }
+            const unsigned long long found = __ballot(hit);
+            if (found) return b + __builtin_ctzll(found);
+        }
+    } else {
+        for (int b = ts; b >= back_lo; b -= 64) {
+            const int i = b - lane;  // (lane 0 looks at the sample nearest to the start)
+            bool hit = false;
+            if (i >= back_lo) {
+                const T cur = cx.lds[padded_index(ss, i)], prv = cx.lds[padded_index(ss, i - 1)];
+                hit = (prv < thr && thr <= cur) || (prv > thr && thr >= cur);
+            }
+            const unsigned long long found = __ballot(hit);
+            if (found) return b - __builtin_ctzll(found);
+        }
+    }
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // time_point_thresh  (processors/time_point_thresh.py:12-92): comparisons only -> bit exact
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -1111,7 +1148,7 @@ __device__ __forceinline__ void op_time_point_thresh(Ctx<T>& cx, const DSP_GLOBA
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const T thr = cx.scalar(op.sp[0]), ts_f = cx.scalar(op.sp[1]), walk_f = cx.scalar(op.sp[2]);
     T out = quiet_nan<T>();
-    const int n = ss.len, C = ss.C, lane = lane_id();
+    const int n = ss.len, lane = lane_id();
     if (!(cx.slot_nan(op.src) || thr != thr || ts_f != ts_f || walk_f != walk_f)) {
         if (floor((double)ts_f) != (double)ts_f) {
             cx.fatal(DSP_E_TPT_START_INT);
@@ -1120,38 +1157,8 @@ __device__ __forceinline__ void op_time_point_thresh(Ctx<T>& cx, const DSP_GLOBA
         } else if ((long long)ts_f < 0 || (long long)ts_f >= n) {
             cx.fatal(DSP_E_TPT_RANGE);
         } else {
-            const int ts = (int)ts_f;
-            const auto* ps = cx.chunk(ss);
-            const int i0 = lane * C;
-            if ((long long)walk_f == 1) {
-                // smallest i in [ts, n-2] with (w[i] <= thr < w[i+1]) or (w[i] >= thr > w[i+1])
-                int best = 0x7fffffff;
-                T cur = ps[0];
-#pragma unroll 8
-                for (int t = 0; t < C; ++t) {
-                    const T nxt = (t < C - 1) ? ps[t + 1] : ps[C + 1];  // first sample of the next lane's chunk
-                    const int i = i0 + t;
-                    const bool hit = ((cur <= thr && thr < nxt) || (cur >= thr && thr > nxt)) && i >= ts && i < n - 1;
-                    if (hit && best == 0x7fffffff) best = i;
-                    cur = nxt;
-                }
-                best = wave_min(best);
-                if (best != 0x7fffffff) out = (T)best;
-            } else {
-                // largest i in [1, ts] with (w[i-1] < thr <= w[i]) or (w[i-1] > thr >= w[i])
-                int best = -1;
-                T prv = (lane > 0) ? ps[-2] : (T)0;  // last sample of the previous lane's chunk (pad is at ps[-1])
-#pragma unroll 8
-                for (int t = 0; t < C; ++t) {
-                    const T cur = ps[t];
-                    const int i = i0 + t;
-                    const bool hit = ((prv < thr && thr <= cur) || (prv > thr && thr >= cur)) && i >= 1 && i <= ts;
-                    if (hit) best = i;
-                    prv = cur;
-                }
-                best = wave_max(best);
-                if (best >= 0) out = (T)best;
-            }
+            const int found = find_crossing(cx, ss, thr, (int)ts_f, (long long)walk_f == 1, 1);
+            if (found >= 0) out = (T)found;
         }
     }
     if (lane == 0) cx.sregs()[op.dst] = out;
@@ -1170,39 +1177,11 @@ __device__ __forceinline__ void op_interp_time_point_thresh(Ctx<T>& cx, const DS
     const T thr = cx.scalar(op.sp[0]), ts_f = cx.scalar(op.sp[1]), walk_f = cx.scalar(op.sp[2]);
     const int mode = op.ip[0];
     T out = quiet_nan<T>();
-    const int n = ss.len, C = ss.C, lane = lane_id();
+    const int n = ss.len, lane = lane_id();
     if (!(cx.slot_nan(op.src) || thr != thr || ts_f != ts_f) && ts_f >= (T)0 && ts_f < (T)n) {
-        const int ts = (int)ts_f;
-        const auto* ps = cx.chunk(ss);
-        const int i0 = lane * C;
-        int ic = -1;
-        if (walk_f > (T)0) {
-            int best = 0x7fffffff;  // smallest i in [ts, n-2] with (w[i] <= thr < w[i+1]) or (w[i] >= thr > w[i+1])
-            T cur = ps[0];
-#pragma unroll 8
-            for (int t = 0; t < C; ++t) {
-                const T nxt = (t < C - 1) ? ps[t + 1] : ps[C + 1];
-                const int i = i0 + t;
-                const bool hit = ((cur <= thr && thr < nxt) || (cur >= thr && thr > nxt)) && i >= ts && i < n - 1;
-                if (hit && best == 0x7fffffff) best = i;
-                cur = nxt;
-            }
-            best = wave_min(best);
-            if (best != 0x7fffffff) ic = best;
-        } else {
-            int best = -1;  // largest i in [2, ts] with (w[i-1] < thr <= w[i]) or (w[i-1] > thr >= w[i]); the crossing is at i - 1
-            T prv = (lane > 0) ? ps[-2] : (T)0;
-#pragma unroll 8
-            for (int t = 0; t < C; ++t) {
-                const T cur = ps[t];
-                const int i = i0 + t;
-                const bool hit = ((prv < thr && thr <= cur) || (prv > thr && thr >= cur)) && i >= 2 && i <= ts && i < n;
-                if (hit) best = i;
-                prv = cur;
-            }
-            best = wave_max(best);
-            if (best >= 0) ic = best - 1;
-        }
+        const bool forward = walk_f > (T)0;
+        int ic = find_crossing(cx, ss, thr, (int)ts_f, forward, 2);
+        if (!forward && ic >= 0) ic -= 1;  // (the crossing lies between i - 1 and i)
         if (ic >= 0) {
             const T w0 = cx.lds[padded_index(ss, ic)], w1 = cx.lds[padded_index(ss, ic + 1)];
             if (mode == 'i' || mode == 'b' || mode == 'c') {
@@ -1353,7 +1332,8 @@ __device__ __forceinline__ void op_copy(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) 
         return;
     }
     const int total = 64 * sd.C, lane = lane_id();
-    for (int e = lane; e < total; e += 64) {
+#pragma unroll 8
+    for (int e = lane; e < total; e += 64) {  // (unrolled: the LDS reads of eight elements are in flight together)
         const int se = e + op.ip[0];
         cx.lds[padded_index(sd, e)] = (e < sd.len && se < ss.len) ? cx.lds[padded_index(ss, se)] : (T)0;
     }
