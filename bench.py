@@ -46,8 +46,8 @@ HBM_PEAK_GBPS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)  # (the first ~6 launches after start-up run 5-20 % slower: clocks, first touch)
     ap.add_argument("--rows", type=int, default=0, help="rows per rank (default: 1 000 000 at N=1, 1 250 000 at N>1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the single-thread CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (profiling runs)")

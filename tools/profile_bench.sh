@@ -7,7 +7,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p "$OUT"
-BENCH="python3 bench.py --steps 20 --warmup 5 --no-cpu"  # enough launches that first-touch effects do not weigh on the averages
+BENCH="python3 bench.py --no-cpu"  # the default command (30 timed launches after 10 warm-up ones) without the CPU leg
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS \
     --output-format csv -d "$OUT/pmc_sq1" -- $BENCH > /dev/null 2> "$OUT/pmc_sq1.err"
@@ -15,5 +15,5 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS
     --output-format csv -d "$OUT/pmc_sq2" -- $BENCH > /dev/null 2> "$OUT/pmc_sq2.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > /dev/null 2> "$OUT/pmc_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH > /dev/null 2> "$OUT/pmc_write.err"
-python3 bench.py --steps 20 --warmup 3 > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 echo "profile $TAG done"; cat "$OUT/bench_default.json"
