@@ -154,7 +154,10 @@ __device__ __forceinline__ void op_load(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) 
         case DSP_U32: nan = load_slot<T, uint32_t>(cx, s, cx.template io_ptr<const uint32_t>(op.io) + at, io.len, vec_ok); break;
         default: nan = load_slot<T, double>(cx, s, cx.template io_ptr<const double>(op.io) + at, io.len, vec_ok); break;
     }
-    cx.set_nan(op.dst, wave_any(nan));
+    if (wave_any(nan))  // (the samples are all there: what reads the slot as a whole sees a NaN waveform, a store writes it as it is)
+        cx.set_some_nan(op.dst);
+    else
+        cx.set_nan(op.dst, false);
     wave_sync();
 }
 
@@ -198,7 +201,10 @@ __device__ __forceinline__ void op_bl_subtract(Ctx<T>& cx, const DSP_GLOBAL DevO
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
     const T b = cx.scalar(op.sp[0]);
-    if (cx.slot_nan(op.src) || b != b) {
+    // ip[0] = 1: numpy.subtract(w, scalar) -- the same subtraction sample by sample, but NaN samples stay where they are instead of
+    // making the whole waveform NaN (bl_subtract.py:41-44 checks np.isnan(w_in).any(); the ufunc does not)
+    const bool elementwise = op.ip[0] == 1;
+    if ((elementwise ? cx.slot_all_nan(op.src) : cx.slot_nan(op.src)) || b != b) {
         cx.set_nan(op.dst, true);
         return;
     }
@@ -211,7 +217,10 @@ __device__ __forceinline__ void op_bl_subtract(Ctx<T>& cx, const DSP_GLOBAL DevO
         nan |= (v != v);
         pd[t] = v;
     }
-    cx.set_nan(op.dst, wave_any(nan));
+    if (elementwise && wave_any(nan))
+        cx.set_some_nan(op.dst);
+    else
+        cx.set_nan(op.dst, wave_any(nan));
     wave_sync();
 }
 

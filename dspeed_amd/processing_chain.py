@@ -165,10 +165,11 @@ _SIGS = {
     "min_max": "wSSSS",
     "discrete_wavelet_transform": "wiccW", "convolve_wf": "wtcW", "fft_convolve_wf": "wtcW", "amax": "wiS",
     "mean_below_threshold": "wsS", "windower": "wsW", "avg_current": "wsW", "trap_pickoff": "wiisS",
-    "upsampler": "wsW", "moving_window_multi": "wsiiW", "add": "ssS", "linear_slope_fit": "wSSSS",
+    "upsampler": "wsW", "moving_window_multi": "wsiiW", "numpy_subtract": "wsW", "numpy_add": "wsW", "linear_slope_fit": "wSSSS",
 }
 _GENERATORS = ("cusp_filter", "zac_filter", "t0_filter", "moving_slope")
 _MODULES = ("dspeed.processors", "dspeed_amd.processors", "numpy", "np")
+_NUMPY_BINARY = {"add": ast.Add, "subtract": ast.Sub, "multiply": ast.Mult, "divide": ast.Div, "true_divide": ast.Div}
 _ROUND_MODES = {"round": 1, "floor": 2, "ceil": 3, "trunc": 4}
 _CALLS = ("round", "floor", "ceil", "trunc", "len", "float", "int")  # functions of the argument language (reference :729-751)
 
@@ -391,9 +392,12 @@ def _normalise(key, node):
     if isinstance(f_parse, ast.Name):
         pass
     elif isinstance(f_parse, ast.Attribute):
-        if "module" in node:
-            raise ProcessingChainError(f"Module specified twice for parameter {key}")
-        node["function"], node["module"] = f_parse.attr, seg(f_parse.value)
+        if seg(f_parse.value) in ("np", "numpy") and "args" not in node:  # an attribute like np.pi: an inline constant (:2500-2505)
+            node["module"], node["args"] = None, [function]
+        else:
+            if "module" in node:
+                raise ProcessingChainError(f"Module specified twice for parameter {key}")
+            node["function"], node["module"] = f_parse.attr, seg(f_parse.value)
     elif isinstance(f_parse, ast.Call) and isinstance(f_parse.func, (ast.Name, ast.Attribute)):
         if "args" in node:
             raise ProcessingChainError(f"Cannot specify arguments if function is expr for parameter {key}")
@@ -449,7 +453,7 @@ def _names_in(arg: str) -> list[str]:
             names.append(n.func.id)  # declaration name(shape, dtype)
     called = set(names)
     for n in ast.walk(tree):
-        if isinstance(n, ast.Name) and n.id not in _UNITS_NS and n.id not in _CALLS and n.id != "np" and n.id not in called:
+        if isinstance(n, ast.Name) and n.id not in _UNITS_NS and n.id not in _CALLS and n.id not in ("np", "numpy") and n.id not in called:
             names.append(n.id)
     seen, out = set(), []
     for n in names:
@@ -566,7 +570,7 @@ class _Builder:
             a, b = self._eval(n.left, src, new), self._eval(n.right, src, new)
             return self._binop(n.op, a, b, src)
         if isinstance(n, ast.Attribute):
-            if isinstance(n.value, ast.Name) and n.value.id == "np" and n.attr in ("pi", "e", "inf", "nan"):
+            if isinstance(n.value, ast.Name) and n.value.id in ("np", "numpy") and n.attr in ("pi", "e", "inf", "nan", "euler_gamma"):
                 return getattr(np, n.attr)
             base = self._eval(n.value, src, new)
             if isinstance(base, tuple) and base[0] == "slice":
@@ -735,7 +739,7 @@ class _Builder:
             return int(r)
         return r
 
-    def _scalar_binop(self, op, a, b, src):
+    def _scalar_binop(self, op, a, b, src, declared=None):
         """A binary operator with a per-event variable on at least one side: the reference adds the NumPy ufunc as a processor
         (:832-891), so the operands go through the same unit handling as any processor's (`_resolve`)."""
         sym = {ast.Add: "+", ast.Sub: "-", ast.Mult: "*", ast.Div: "/"}.get(type(op))
@@ -759,6 +763,8 @@ class _Builder:
         else:
             v = a if sa else b
             out = SExpr(None, (), name, v.unit, v.is_coord, None)
+        if declared is not None:  # numpy.add(a, b, out) written as a processor: `out` is a declared variable with its own unit
+            out = SExpr(None, (), declared.name, declared.unit, declared.is_coord, declared.grid)
         if sym in "*/" and (isinstance(a, Quantity) or isinstance(b, Quantity)):
             raise NotImplementedError(f"'{src}': multiplying / dividing a per-event variable by a time is not supported")
         _, (a, b, _o) = _resolve(self, "ssS", [a, b, out], expression=True)
@@ -939,7 +945,7 @@ def build_processing_chain(processors, tb_in=None, db_dict=None, outputs=None, b
 
 # processors whose output waveform has the input's dimension name in the gufunc signature ("(n),...->(n)") and therefore its
 # coordinate grid (reference :1601-1619, 1700); the others' outputs have no grid unless the recipe declares one
-_SAME_DIM = ("bl_subtract", "pole_zero", "double_pole_zero", "trap_filter", "trap_norm", "asym_trap_filter", "moving_window_multi")
+_SAME_DIM = ("bl_subtract", "numpy_subtract", "numpy_add", "pole_zero", "double_pole_zero", "trap_filter", "trap_norm", "asym_trap_filter", "moving_window_multi")
 
 
 def _add_step(b: _Builder, key, node, new_vars, proc_strings):
@@ -955,7 +961,7 @@ def _add_step(b: _Builder, key, node, new_vars, proc_strings):
         return
     if module not in _MODULES:
         raise NotImplementedError(f"module '{module}' is not available on the device path (processor {module}.{function})")
-    if module in ("numpy", "np") and function not in ("amax", "add"):
+    if module in ("numpy", "np") and function not in ("amax",) + tuple(_NUMPY_BINARY):
         raise NotImplementedError(f"numpy.{function} is not available on the device path")
     if "unit" in node:  # "unit": one string, or one per new variable (reference :2705-2711)
         for i, name in enumerate(new_vars):
@@ -966,6 +972,21 @@ def _add_step(b: _Builder, key, node, new_vars, proc_strings):
             elif isinstance(v, Var) and v.unit is None:
                 v.unit = unit
     args = [b.eval_arg(a, new_vars) for a in node["args"]]
+    if module in ("numpy", "np") and function in _NUMPY_BINARY:
+        # a NumPy binary ufunc as a processor (numpy.subtract(waveform, bl_mean, wf_blsub), numpy.divide(A_max, trapEmax, AoE)):
+        # between per-event values it is the same scalar op the operators make; waveform -/+ per-event value is the subtraction of
+        # bl_subtract without its NaN rule (a NaN sample stays a NaN sample)
+        if len(args) != 3 or not isinstance(args[2], Var):
+            raise ProcessingChainError(f"numpy.{function} takes two operands and an output variable for parameter {key}")
+        x, y, out = args
+        is_wf = lambda v: (isinstance(v, Var) and v.kind == "wf") or (isinstance(v, tuple) and v and v[0] == "slice")  # noqa: E731
+        if is_wf(x) and not is_wf(y) and function in ("subtract", "add"):
+            function = "numpy_subtract" if function == "subtract" else "numpy_add"
+        elif is_wf(x) or is_wf(y):
+            raise NotImplementedError(f"numpy.{function} on these waveform operands is not available on the device path ({key})")
+        else:
+            b.vars[new_vars[0]] = b._scalar_binop(_NUMPY_BINARY[function](), x, y, str(node["args"]), declared=out)
+            return
     if function in _GENERATORS:
         _fold_generator(b, function, args, new_vars)
         return
@@ -1077,7 +1098,7 @@ def _schedule(steps):
                 wfs = [born.get(id(v), -1) for v in ins[j] if v.kind == "wf"]
                 return min(wfs) if wfs else len(steps)
             # (same oldest waveform: the one that could overwrite it in place waits until the others have read it)
-            j = min(ready, key=lambda j: (age(j), steps[j][0] in ("bl_subtract", "pole_zero", "double_pole_zero"), j))
+            j = min(ready, key=lambda j: (age(j), steps[j][0] in ("bl_subtract", "numpy_subtract", "numpy_add", "pole_zero", "double_pole_zero"), j))
         for a, r in zip(steps[j][1], _SIGS.get(steps[j][0], "")):
             if r == "W" and isinstance(a, Var):
                 born[id(a)] = len(order)
@@ -1287,13 +1308,18 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
         what = f"{fn} ({key})"
         if fn == "alias":
             continue
-        if fn in ("bl_subtract", "pole_zero", "double_pole_zero"):
+        if fn in ("bl_subtract", "numpy_subtract", "numpy_add", "pole_zero", "double_pole_zero"):
             src = ensure_loaded(args[0], si)
             dst = out_wf(args[-1], src.length, src)
             inplace = last_use.get(src.name, -1) <= si
             dst.slot = src.slot if inplace else new_slot(src.length)
             if fn == "bl_subtract":
                 p.add_op(_lib.OP_BL_SUBTRACT, dst=dst.slot, src=src.slot, sp=(scalar_operand(args[1], args, what=what),))
+            elif fn in ("numpy_subtract", "numpy_add"):
+                y = args[1]
+                if fn == "numpy_add":  # w + y = w - (-y), exactly
+                    y = SExpr("affine", (y, -1.0, -0.0), "(-...)", None, False, None) if isinstance(y, (Var, SExpr)) else -float(y)
+                p.add_op(_lib.OP_BL_SUBTRACT, dst=dst.slot, src=src.slot, ip=(1,), sp=(scalar_operand(y, args, what=what),))
             elif fn == "pole_zero":
                 tau = scalar_operand(args[1], args, what=what)
                 p.add_op(_lib.OP_POLE_ZERO, dst=dst.slot, src=src.slot, sp=(tau,))
@@ -1402,10 +1428,6 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             if num > 1 and tmp not in free_slots:
                 free_slots.append(tmp)
             release(src, si)
-        elif fn == "add":  # numpy.add on per-event scalars (icpc-dsp-config.json:341-346): a * 1 + b, exact
-            o = out_scalar(args[2])
-            p.add_op(_lib.OP_SCALAR_AFFINE, dst=o.sreg, sp=(scalar_operand(args[0], args, what=what), Scalar.const(1.0),
-                                                            scalar_operand(args[1], args, what=what)))
         elif fn == "trap_pickoff":
             src = ensure_loaded(args[0], si)
             ints = [scalar_operand(a, args, integer=True, what=what) for a in args[1:3]]

@@ -145,7 +145,7 @@ typedef struct dsp_scalar_arg {
 #define DSP_OP_LOAD 1          /* dst <- io (waveform input; int16/uint16 rows are widened like NumPy's ufunc casting, processing_chain.py:1565-1572) */
 #define DSP_OP_STORE 2         /* io <- src */
 #define DSP_OP_STORE_SCALAR 3  /* io <- sreg[ip[0]] */
-#define DSP_OP_BL_SUBTRACT 4   /* bl_subtract.py:11-46      dst <- src - sp[0] */
+#define DSP_OP_BL_SUBTRACT 4   /* bl_subtract.py:11-46      dst <- src - sp[0]; ip[0] = 1: numpy.subtract(w, scalar), NaN samples stay single */
 #define DSP_OP_POLE_ZERO 5     /* pole_zero.py:24-77        sp[0] = tau (const) */
 #define DSP_OP_DOUBLE_POLE_ZERO 6 /* pole_zero.py:82-198    sp[0..2] = tau1, tau2, frac (const) */
 #define DSP_OP_TRAP_FILTER 7   /* trap_filters.py:12-76     ip[0..1] = rise, flat */

@@ -313,6 +313,66 @@ def test_interpolated_threshold_times_in_a_recipe():
     assert np.all(out["tp_50"] >= out["tp_50_i"]) and np.all(out["tp_50"] <= out["tp_50_i"] + 16.0)
 
 
+def test_numpy_constants_and_ufuncs_in_recipes():
+    """test_numpy_math_constants_dsp of the reference (tests/test_processing_chain.py:120-142) restated, in both spellings its
+    configs use (inline expressions; numpy.subtract processors, tests/configs/numpy-parsing.json), on a float64 column"""
+    n = 500
+    ts = np.random.default_rng(2).uniform(1.5e9, 1.6e9, n)
+    rec = {"outputs": ["timestamp", "calc1", "calc2", "calc3", "calc4", "calc5", "calc6", "d1", "d2", "d4"], "processors": {
+        "calc1": "np.pi*timestamp", "calc2": "np.pi", "calc3": "np.pi*np.e", "calc4": "np.nan", "calc5": "np.inf", "calc6": "np.nan*timestamp",
+        "d1": {"function": "subtract", "module": "numpy", "args": ["timestamp-timestamp", "np.pi*timestamp", "d1"]},
+        "d2": {"function": "subtract", "module": "numpy", "args": ["timestamp-timestamp", "np.pi", "d2"]},
+        "d4": {"function": "divide", "module": "numpy", "args": ["timestamp", "np.e*timestamp", "d4"]}}}
+    chain, out = _run(rec, {"timestamp": ts})
+    assert chain.loop_dtype == np.float64 and chain.program.slots == []
+    assert np.array_equal(out["timestamp"], ts) and np.array_equal(out["calc1"], np.pi * ts)
+    assert np.all(out["calc2"] == np.pi) and np.all(out["calc3"] == np.pi * np.e)
+    assert np.isnan(out["calc4"]).all() and np.isinf(out["calc5"]).all() and np.isnan(out["calc6"]).all()
+    assert np.array_equal(out["d1"], (ts - ts) - np.pi * ts) and np.array_equal(out["d2"], (ts - ts) - np.pi)
+    assert np.array_equal(out["d4"], ts / (np.e * ts))
+
+
+def test_tutorial_recipe_with_numpy_processors():
+    """The shape of the reference's tutorial recipe (docs/source/notebooks/metadata/dsp-config.json): the baseline comes from
+    linear_slope_fit and is removed with numpy.subtract -- a ufunc, so a NaN sample stays one sample instead of voiding the waveform
+    as bl_subtract does --, energies with numpy.amax, A/E with numpy.divide."""
+    from dspeed_amd.processing_chain import WaveformInput
+
+    rng = np.random.default_rng(44)
+    x, _bl, t0 = _synth(rng, 96, 4096)
+    wf = x.astype(np.float32)
+    M = "dspeed.processors"
+    rec = {"outputs": ["trapEmax", "bl_mean", "A_10", "AoE", "wf_blsub", "wf_plus"], "processors": {
+        "bl_mean , bl_sig, bl_slope, bl_intercept": {"function": "linear_slope_fit", "module": M, "unit": ["ADC"] * 4,
+                                                      "args": ["waveform[0: 1000]", "bl_mean", "bl_sig", "bl_slope", "bl_intercept"]},
+        "wf_blsub": {"function": "subtract", "module": "numpy", "args": ["waveform", "bl_mean", "wf_blsub"], "unit": "ADC"},
+        "wf_plus": {"function": "add", "module": "numpy", "args": ["waveform", "bl_mean", "wf_plus"], "unit": "ADC"},
+        "wf_pz": {"function": "pole_zero", "module": M, "args": ["wf_blsub", "db.pz_const", "wf_pz"], "defaults": {"db.pz_const": "27.46*us"}},
+        "wf_trap": {"function": "trap_norm", "module": M, "args": ["wf_pz", "8*us", "4*us", "wf_trap"]},
+        "trapEmax": {"function": "amax", "module": "numpy", "args": ["wf_trap", 1, "trapEmax"], "kwargs": {"signature": "(n),()->()", "types": ["fi->f"]}},
+        "curr10": {"function": "avg_current", "module": M, "args": ["wf_pz", 10, "curr10(len(wf_pz)-10, 'f')"]},
+        "A_10": {"function": "amax", "module": "numpy", "args": ["curr10", 1, "A_10"]},
+        "AoE": {"function": "divide", "module": "numpy", "args": ["A_10", "trapEmax", "AoE"], "unit": "1/sample"}}}
+    _, out = _run(rec, {"waveform": WaveformInput(wf, 16.0)})
+    bm = oracle.linear_slope_fit(wf[:, :1000])[0]
+    assert np.max(np.abs(out["bl_mean"] - bm) / np.abs(bm)) <= 1e-5
+    blsub = wf - out["bl_mean"][:, None]
+    assert np.array_equal(out["wf_blsub"], blsub) and np.array_equal(out["wf_plus"], wf + out["bl_mean"][:, None])
+    pz = oracle.pole_zero(blsub, np.float32(27460.0 / 16))[0]
+    emax = np.max(oracle.trap_norm(pz, 500, 250)[0], axis=1)
+    a10 = np.max(oracle.avg_current(pz, 10)[0], axis=1)
+    assert np.max(np.abs(out["trapEmax"] - emax) / emax) <= 1e-6 and np.max(np.abs(out["A_10"] - a10) / a10) <= 1e-5
+    assert np.array_equal(out["AoE"], out["A_10"] / out["trapEmax"])
+    # one NaN sample: numpy.subtract keeps it one sample (stored as such), everything downstream of it is NaN like the reference
+    wf2 = wf.copy()
+    wf2[3, 2000] = np.nan
+    _, out2 = _run(rec, {"waveform": WaveformInput(wf2, 16.0)})
+    want = wf2 - out2["bl_mean"][:, None]
+    assert np.array_equal(np.isnan(out2["wf_blsub"]), np.isnan(want)) and np.isnan(out2["wf_blsub"][3]).sum() == 1
+    assert np.array_equal(np.nan_to_num(out2["wf_blsub"]), np.nan_to_num(want))
+    assert np.isnan(out2["trapEmax"][3]) and np.isnan(out2["AoE"][3]) and not np.isnan(np.delete(out2["AoE"], 3)).any()
+
+
 def test_in_kernel_op_profile():
     """dsp_chain_profile: per-op shader-clock cycles from inside the one kernel a chain is; results are unchanged by it"""
     rng = np.random.default_rng(5)
