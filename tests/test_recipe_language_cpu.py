@@ -177,3 +177,27 @@ def test_scheduler_only_reorders_within_dependencies():
         tb["thr"] = np.zeros(4, dtype=np.float32)
         chain, _, _ = build_processing_chain(rec, tb)
         _check_program_order(chain.program)
+
+
+REFERENCE_RECIPES = ["tests/configs/icpc-dsp-config.json", "tests/configs/icpc-dsp-config-yaml.yaml", "tests/configs/numpy-parsing.json",
+                     "docs/source/notebooks/metadata/dsp-config.json"]
+
+
+@pytest.mark.parametrize("rel", REFERENCE_RECIPES)
+def test_the_references_own_ge_recipes_translate_as_they_stand(rel):
+    """Drop-in check on the caller's side of the path: the recipe files the reference ships for germanium detectors go through
+    build_processing_chain unmodified and become one program within the device limits.  Only where the reference checkout is
+    mounted (the build container); nothing of it is copied into this repository."""
+    import os
+
+    path = os.path.join("/root/reference", rel)
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not mounted")
+    tb = _tb(t0=np.zeros(4, dtype=np.float32))
+    tb.update({"timestamp": np.zeros(4), "channel": np.zeros(4), "energy": np.zeros(4)})
+    chain, mask, out = build_processing_chain(path, tb)
+    P = chain.program
+    assert len(out) >= 7 and len(P.ops) <= _lib.MAX_OPS and len(P.slots) <= _lib.MAX_SLOTS and P.n_sregs <= _lib.MAX_SREGS
+    _check_program_order(P)
+    if "icpc" in rel:
+        assert len(out) == 34 and _peak_live_samples(P) <= 2 * 8192 + 1024
