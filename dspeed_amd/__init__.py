@@ -4,6 +4,7 @@ Public surface (mirrors the slice of ``dspeed`` that the hot path needs):
 
 * ``dspeed_amd.processors``        -- processor registry, same names as ``dspeed.processors``
 * ``dspeed_amd.build_processing_chain`` / ``ProcessingChain`` -- JSON recipe -> fused device chain
+* ``dspeed_amd.build_dsp``         -- the table loop around it (channels, per-channel recipes and database, row selection, output file)
 * ``dspeed_amd.errors``            -- ``DSPFatal`` / ``ProcessingChainError``
 * ``dspeed_amd.device``            -- device arrays, streams, events
 
@@ -20,4 +21,10 @@ def __getattr__(name):
         from . import processing_chain
 
         return getattr(processing_chain, name)
+    if name == "build_dsp":  # (function and submodule share the name, as in the reference: the function wins on the package)
+        import importlib
+
+        fn = importlib.import_module(".build_dsp", __name__).build_dsp
+        globals()["build_dsp"] = fn
+        return fn
     raise AttributeError(name)
