@@ -12,6 +12,7 @@ The compute path is the HIP library ``libdspeed_hip.so`` (``python -m dspeed_amd
 falls back to the CPU.
 """
 from .errors import DSPError, DSPFatal, ProcessingChainError  # noqa: F401
+from .build_dsp import build_dsp  # noqa: F401,E402  (function and submodule share the name, as in the reference: the function wins)
 
 __version__ = "0.1.0"
 
@@ -21,10 +22,4 @@ def __getattr__(name):
         from . import processing_chain
 
         return getattr(processing_chain, name)
-    if name == "build_dsp":  # (function and submodule share the name, as in the reference: the function wins on the package)
-        import importlib
-
-        fn = importlib.import_module(".build_dsp", __name__).build_dsp
-        globals()["build_dsp"] = fn
-        return fn
     raise AttributeError(name)
