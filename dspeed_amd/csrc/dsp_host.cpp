@@ -365,6 +365,7 @@ static int op_slots(const dsp_op& o, int out[3]) {
         case DSP_OP_AMAX:
         case DSP_OP_CONVOLVE_AMAX: out[0] = o.src; return 1;
         case DSP_OP_BL_SUBTRACT:
+        case DSP_OP_MIN_MAX_NORM:
         case DSP_OP_POLE_ZERO:
         case DSP_OP_DOUBLE_POLE_ZERO:
         case DSP_OP_TRAP_FILTER:
@@ -425,7 +426,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             const bool writes = o.dst == s && (o.opcode == DSP_OP_LOAD || nt >= 2);  // (one-slot ops other than LOAD only read)
             if (conv && reads) fir_in = true;
             const bool plain = o.opcode == DSP_OP_LOAD || o.opcode == DSP_OP_STORE || o.opcode == DSP_OP_COPY ||
-                               o.opcode == DSP_OP_BL_SUBTRACT || (conv && reads && !writes);
+                               o.opcode == DSP_OP_BL_SUBTRACT || o.opcode == DSP_OP_MIN_MAX_NORM || (conv && reads && !writes);
             if (!plain) only_plain = false;
         }
         linear[s] = fir_in && only_plain;
@@ -602,8 +603,9 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 if (!need_io(DSP_IO_SCALAR_OUT) || o.ip[0] < 0 || o.ip[0] >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad STORE_SCALAR", i);
                 break;
             case DSP_OP_BL_SUBTRACT:
+            case DSP_OP_MIN_MAX_NORM:
                 if (!check_slot(P, o.src) || !check_slot(P, o.dst) || slot_len[o.src] != slot_len[o.dst])
-                    return fail(DSP_ERR_ARG, "op %d: bad BL_SUBTRACT", i);
+                    return fail(DSP_ERR_ARG, "op %d: bad element-wise op", i);
                 break;
             case DSP_OP_POLE_ZERO: {
                 if (!check_slot(P, o.src) || !check_slot(P, o.dst) || slot_len[o.src] != slot_len[o.dst])
@@ -1234,6 +1236,21 @@ int g_bl_subtract(int ty, const WfIn& in, const void* bl_dev, double bl, void* o
     const double c[1] = {bl};
     return wf2wf(ty, DSP_OP_BL_SUBTRACT, in, out, in.len, out_stride, nullptr, 0, c, 1, bl_dev, st, er);
 }
+int g_min_max_norm(int ty, const WfIn& in, const void* lo_dev, double lo, const void* hi_dev, double hi, void* out, int64_t out_stride, void* st,
+                   int64_t* er) {
+    if (in.n_wf <= 0) return DSP_OK;
+    Mini m(ty);
+    const int s_in = m.add_slot(in.len);
+    const int io_in = m.add_io(DSP_IO_WF_IN, in.dtype, in.len, in.stride, in.ptr);
+    m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
+    dsp_scalar_arg a = m.scalar(lo_dev, lo), b = m.scalar(hi_dev, hi);
+    dsp_op& o = m.add_op(DSP_OP_MIN_MAX_NORM, s_in, s_in, 0);  // in place
+    o.sp[0] = a;
+    o.sp[1] = b;
+    const int io_out = m.add_io(DSP_IO_WF_OUT, ty, in.len, out_stride, out);
+    m.add_op(DSP_OP_STORE, 0, s_in, io_out);
+    return m.run(in.n_wf, st, er);
+}
 int g_pole_zero(int ty, const WfIn& in, double tau, void* out, int64_t out_stride, void* st, int64_t* er) {
     const double c[1] = {tau};
     return wf2wf(ty, DSP_OP_POLE_ZERO, in, out, in.len, out_stride, nullptr, 0, c, 1, nullptr, st, er);
@@ -1451,6 +1468,11 @@ int g_min_max(int ty, const WfIn& in, void* t_min, void* t_max, void* a_min, voi
         if (mode_char <= 0 || mode_char > 127) return fail(DSP_ERR_ARG, "interpolated_time_point_thresh: mode must be a character");       \
         return g_tpt(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, threshold_dev, (double)threshold, t_start_dev, (double)t_start,         \
                      (double)walk_forward, out, stream, err_row, mode_char);                                                                \
+    }                                                                                                                                         \
+    int dsp_min_max_norm_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const FT* a_min_dev, FT a_min,  \
+                               const FT* a_max_dev, FT a_max, FT* out, int64_t out_stride, void* stream, int64_t* err_row) {                \
+        return g_min_max_norm(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, a_min_dev, (double)a_min, a_max_dev, (double)a_max, out,       \
+                              out_stride, stream, err_row);                                                                                  \
     }                                                                                                                                         \
     int dsp_windower_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const FT* t0_dev, FT t0, FT* out,   \
                            int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row) {                                             \

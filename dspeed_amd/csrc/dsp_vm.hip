@@ -225,6 +225,35 @@ __device__ __forceinline__ void op_bl_subtract(Ctx<T>& cx, const DSP_GLOBAL DevO
 }
 
 // ------------------------------------------------------------------------------------------------
+// min_max_norm  (processors/min_max.py:85-140):  w_out = w_in / max(|a_min|, |a_max|), w_in itself if either bound is 0
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void op_min_max_norm(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+    const T lo = cx.scalar(op.sp[0]), hi = cx.scalar(op.sp[1]);
+    const T amin = lo < (T)0 ? -lo : lo, amax = hi < (T)0 ? -hi : hi;
+    const bool copy = amax == (T)0 || amin == (T)0;
+    // (neither comparison holds with a NaN bound: the output stays NaN, like the reference's if / elif chain)
+    if (cx.slot_nan(op.src) || (!copy && !(amax >= amin) && !(amax < amin))) {
+        cx.set_nan(op.dst, true);
+        return;
+    }
+    const T d = amax >= amin ? amax : amin;
+    const auto* ps = cx.chunk(ss);
+    auto* pd = cx.chunk(sd);
+    bool nan = false;
+#pragma unroll 8
+    for (int t = 0; t < ss.C; ++t) {
+        const T v = copy ? (T)ps[t] : (T)ps[t] / d;
+        nan |= (v != v);
+        pd[t] = v;
+    }
+    cx.set_nan(op.dst, wave_any(nan));
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
 // pole_zero  (processors/pole_zero.py:24-77)
 //   y[0] = x[0];  acc_i = (acc_{i-1} + x[i]) - x[i-1]*c  in float64, y[i] = (T)acc_i,  c = exp(-1/tau) (float64, host libm).
 // Parallel form: acc at the end of sample k is  S(k) - c*S(k-1)  with S = inclusive prefix sum of x, so the carry into
@@ -1597,6 +1626,7 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 4) dsp_vm_kernel(const DevProgr
                 case DSP_OP_STORE: op_store(cx, op); break;
                 case DSP_OP_STORE_SCALAR: op_store_scalar(cx, op); break;
                 case DSP_OP_BL_SUBTRACT: op_bl_subtract(cx, op); break;
+                case DSP_OP_MIN_MAX_NORM: op_min_max_norm(cx, op); break;
                 case DSP_OP_POLE_ZERO: op_pole_zero(cx, op); break;
                 case DSP_OP_DOUBLE_POLE_ZERO: op_double_pole_zero(cx, op); break;
                 case DSP_OP_TRAP_FILTER:

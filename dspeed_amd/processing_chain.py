@@ -165,7 +165,7 @@ _SIGS = {
     "min_max": "wSSSS",
     "discrete_wavelet_transform": "wiccW", "convolve_wf": "wtcW", "fft_convolve_wf": "wtcW", "amax": "wiS",
     "mean_below_threshold": "wsS", "windower": "wsW", "avg_current": "wsW", "trap_pickoff": "wiisS",
-    "upsampler": "wsW", "moving_window_multi": "wsiiW", "numpy_subtract": "wsW", "numpy_add": "wsW", "linear_slope_fit": "wSSSS",
+    "upsampler": "wsW", "moving_window_multi": "wsiiW", "numpy_subtract": "wsW", "numpy_add": "wsW", "min_max_norm": "wssW", "linear_slope_fit": "wSSSS",
 }
 _GENERATORS = ("cusp_filter", "zac_filter", "t0_filter", "moving_slope")
 _MODULES = ("dspeed.processors", "dspeed_amd.processors", "numpy", "np")
@@ -945,7 +945,7 @@ def build_processing_chain(processors, tb_in=None, db_dict=None, outputs=None, b
 
 # processors whose output waveform has the input's dimension name in the gufunc signature ("(n),...->(n)") and therefore its
 # coordinate grid (reference :1601-1619, 1700); the others' outputs have no grid unless the recipe declares one
-_SAME_DIM = ("bl_subtract", "numpy_subtract", "numpy_add", "pole_zero", "double_pole_zero", "trap_filter", "trap_norm", "asym_trap_filter", "moving_window_multi")
+_SAME_DIM = ("bl_subtract", "numpy_subtract", "numpy_add", "min_max_norm", "pole_zero", "double_pole_zero", "trap_filter", "trap_norm", "asym_trap_filter", "moving_window_multi")
 
 
 def _add_step(b: _Builder, key, node, new_vars, proc_strings):
@@ -1098,7 +1098,7 @@ def _schedule(steps):
                 wfs = [born.get(id(v), -1) for v in ins[j] if v.kind == "wf"]
                 return min(wfs) if wfs else len(steps)
             # (same oldest waveform: the one that could overwrite it in place waits until the others have read it)
-            j = min(ready, key=lambda j: (age(j), steps[j][0] in ("bl_subtract", "numpy_subtract", "numpy_add", "pole_zero", "double_pole_zero"), j))
+            j = min(ready, key=lambda j: (age(j), steps[j][0] in ("bl_subtract", "numpy_subtract", "numpy_add", "min_max_norm", "pole_zero", "double_pole_zero"), j))
         for a, r in zip(steps[j][1], _SIGS.get(steps[j][0], "")):
             if r == "W" and isinstance(a, Var):
                 born[id(a)] = len(order)
@@ -1308,7 +1308,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
         what = f"{fn} ({key})"
         if fn == "alias":
             continue
-        if fn in ("bl_subtract", "numpy_subtract", "numpy_add", "pole_zero", "double_pole_zero"):
+        if fn in ("bl_subtract", "numpy_subtract", "numpy_add", "min_max_norm", "pole_zero", "double_pole_zero"):
             src = ensure_loaded(args[0], si)
             dst = out_wf(args[-1], src.length, src)
             inplace = last_use.get(src.name, -1) <= si
@@ -1320,6 +1320,9 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
                 if fn == "numpy_add":  # w + y = w - (-y), exactly
                     y = SExpr("affine", (y, -1.0, -0.0), "(-...)", None, False, None) if isinstance(y, (Var, SExpr)) else -float(y)
                 p.add_op(_lib.OP_BL_SUBTRACT, dst=dst.slot, src=src.slot, ip=(1,), sp=(scalar_operand(y, args, what=what),))
+            elif fn == "min_max_norm":
+                p.add_op(_lib.OP_MIN_MAX_NORM, dst=dst.slot, src=src.slot, sp=(scalar_operand(args[1], args, what=what),
+                                                                                scalar_operand(args[2], args, what=what)))
             elif fn == "pole_zero":
                 tau = scalar_operand(args[1], args, what=what)
                 p.add_op(_lib.OP_POLE_ZERO, dst=dst.slot, src=src.slot, sp=(tau,))

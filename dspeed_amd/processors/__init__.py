@@ -87,6 +87,8 @@ def _as_int(v, what):
 
 bl_subtract = HipGUFunc("bl_subtract", "(n),()->(n)", ["ff->f", "dd->d"], _wf2wf("bl_subtract", scalar_cols=(0,)),
                         "w_out = w_in - a_baseline (reference processors/bl_subtract.py:11-46)")
+min_max_norm = HipGUFunc("min_max_norm", "(n),(),()->(n)", ["fff->f", "ddd->d"], _wf2wf("min_max_norm", scalar_cols=(0, 1)),
+                         "waveform over the larger of |a_min|, |a_max| (reference processors/min_max.py:85-140)")
 pole_zero = HipGUFunc("pole_zero", "(n),()->(n)", ["ff->f", "dd->d"], _wf2wf("pole_zero"),
                       "single pole-zero cancellation (reference processors/pole_zero.py:24-77)")
 double_pole_zero = HipGUFunc("double_pole_zero", "(n),(),(),()->(n)", ["ffff->f", "dddd->d"], _wf2wf("double_pole_zero"),
@@ -471,4 +473,4 @@ zac_filter = HipGUFunc("zac_filter", "(),(),(),(n)", ["ffff", "dddd"], _zac_filt
                        "zero-area CUSP kernel generator, host, once (reference processors/energy_kernels.py:76-157)")
 
 __all__ = ["bl_subtract", "pole_zero", "double_pole_zero", "trap_filter", "trap_norm", "asym_trap_filter", "fixed_time_pickoff",
-           "time_point_thresh", "interpolated_time_point_thresh", "min_max", "linear_slope_fit", "mean_below_threshold", "windower", "avg_current", "upsampler", "moving_window_multi", "trap_pickoff", "discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "cusp_filter", "zac_filter", "t0_filter", "moving_slope"]
+           "time_point_thresh", "interpolated_time_point_thresh", "min_max", "min_max_norm", "linear_slope_fit", "mean_below_threshold", "windower", "avg_current", "upsampler", "moving_window_multi", "trap_pickoff", "discrete_wavelet_transform", "convolve_wf", "fft_convolve_wf", "cusp_filter", "zac_filter", "t0_filter", "moving_slope"]

@@ -185,6 +185,8 @@ typedef struct dsp_scalar_arg {
 #define DSP_OP_INTERP_TIME_POINT_THRESH 30 /* time_point_thresh.py:95-222 interpolated_time_point_thresh: sreg[dst] <- crossing of sp[0] found from
                                   * sp[1] walking forward (sp[2] > 0) or backward, placed between the two samples by ip[0] = mode char
                                   * i b c a f r n l; a start outside the waveform gives NaN (no DSPFatal) */
+#define DSP_OP_MIN_MAX_NORM 31   /* min_max.py:85-140 min_max_norm: dst <- src / max(|sp[0]|, |sp[1]|) (a_min, a_max); src unchanged if either
+                                  * is 0; NaN if src has a NaN or a bound is NaN */
 #define DSP_OP_SCALAR_DIV 29     /* sreg[dst] <- sp[0] / sp[1]  (numpy.true_divide between per-event variables: QDrift / trapTmax) */
 
 typedef struct dsp_op {
@@ -258,6 +260,8 @@ int dsp_time_point_thresh_f32(const void* in, int in_dtype, int64_t n_wf, int32_
 int dsp_interpolated_time_point_thresh_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
                                            const float* threshold_dev, float threshold, const float* t_start_dev, float t_start,
                                            int64_t walk_forward, int32_t mode_char, float* out, void* stream, int64_t* err_row);
+int dsp_min_max_norm_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* a_min_dev, float a_min,
+                         const float* a_max_dev, float a_max, float* out, int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_windower_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* t0_dev, float t0,
                      float* out, int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_avg_current_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float length, float* out,
@@ -301,6 +305,8 @@ int dsp_time_point_thresh_f64(const void* in, int in_dtype, int64_t n_wf, int32_
 int dsp_interpolated_time_point_thresh_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride,
                                            const double* threshold_dev, double threshold, const double* t_start_dev, double t_start,
                                            int64_t walk_forward, int32_t mode_char, double* out, void* stream, int64_t* err_row);
+int dsp_min_max_norm_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const double* a_min_dev, double a_min,
+                         const double* a_max_dev, double a_max, double* out, int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_windower_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const double* t0_dev, double t0,
                      double* out, int32_t out_len, int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_avg_current_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, double length, double* out,

@@ -164,6 +164,15 @@ def min_max(w):
     return (*o, rc)
 
 
+def min_max_norm(w, a_min, a_max):
+    w = _rows(w)
+    lo, s1 = _vec(a_min, w.shape[0], w.dtype)
+    hi, s2 = _vec(a_max, w.shape[0], w.dtype)
+    out = np.empty_like(w)
+    rc = _call("min_max_norm", w.dtype, _p(w), C.c_long(w.shape[0]), C.c_int(w.shape[1]), _p(lo), C.c_int(s1), _p(hi), C.c_int(s2), _p(out))
+    return out, rc
+
+
 def windower(w, t0, out_len):
     w = _rows(w)
     t, st = _vec(t0, w.shape[0], w.dtype)

@@ -62,6 +62,8 @@ enum {
     int orc_interpolated_time_point_thresh_##S(const T* in, long n_wf, int len, const T* thr, int thr_stride, const T* t_start,   \
                                                int t_start_stride, long walk_forward, int mode, T* out, long* err_row);       \
     int orc_min_max_##S(const T* in, long n_wf, int len, T* t_min, T* t_max, T* a_min, T* a_max, long* err_row);              \
+    int orc_min_max_norm_##S(const T* in, long n_wf, int len, const T* a_min, int a_min_stride, const T* a_max, int a_max_stride,   \
+                             T* out, long* err_row);                                                                          \
     int orc_windower_##S(const T* in, long n_wf, int len, const T* t0, int t0_stride, T* out, int m, long* err_row);          \
     int orc_avg_current_##S(const T* in, long n_wf, int len, T length, T* out, int m, long* err_row);                         \
     int orc_trap_pickoff_##S(const T* in, long n_wf, int len, int rise, int flat, const T* tp, int tp_stride, T* out,         \

@@ -281,6 +281,22 @@ static int FN(row_interpolated_time_point_thresh)(const T* w_in, int n, T a_thre
     }
 }
 
+/* min_max.py:85-140 min_max_norm: the waveform over the larger of |a_min|, |a_max|; unchanged if either is 0; NaN if the waveform has
+ * a NaN or neither comparison holds (a NaN bound) */
+static int FN(row_min_max_norm)(const T* w_in, int n, T a_min, T a_max, T* w_out) {
+    for (int i = 0; i < n; ++i) w_out[i] = (T)NAN;
+    if (FN(row_has_nan)(w_in, n)) return 0;
+    const T amax = a_max < 0 ? -a_max : a_max, amin = a_min < 0 ? -a_min : a_min;
+    if (amax == 0 || amin == 0) {
+        for (int i = 0; i < n; ++i) w_out[i] = w_in[i];
+    } else if (amax >= amin) {
+        for (int i = 0; i < n; ++i) w_out[i] = w_in[i] / amax;
+    } else if (amax < amin) {
+        for (int i = 0; i < n; ++i) w_out[i] = w_in[i] / amin;
+    }
+    return 0;
+}
+
 /* min_max.py:11-82: strict comparisons, first occurrence wins */
 static int FN(row_min_max)(const T* w_in, int n, T* t_min, T* t_max, T* a_min, T* a_max) {
     *t_min = *t_max = *a_min = *a_max = (T)NAN;
@@ -554,6 +570,10 @@ int FN(orc_interpolated_time_point_thresh)(const T* in, long n_wf, int len, cons
 }
 int FN(orc_min_max)(const T* in, long n_wf, int len, T* t_min, T* t_max, T* a_min, T* a_max, long* err_row) {
     ROWLOOP(FN(row_min_max)(in + r * len, len, t_min + r, t_max + r, a_min + r, a_max + r))
+}
+int FN(orc_min_max_norm)(const T* in, long n_wf, int len, const T* a_min, int a_min_stride, const T* a_max, int a_max_stride, T* out,
+                         long* err_row) {
+    ROWLOOP(FN(row_min_max_norm)(in + r * len, len, PV(a_min, r), PV(a_max, r), out + r * len))
 }
 int FN(orc_windower)(const T* in, long n_wf, int len, const T* t0, int t0_stride, T* out, int m, long* err_row) {
     ROWLOOP(FN(row_windower)(in + r * len, len, PV(t0, r), out + r * (long)m, m))

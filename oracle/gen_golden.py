@@ -734,6 +734,34 @@ def gen_dwt():
     b.save()
 
 
+def gen_min_max_norm():
+    """min_max_norm (min_max.py:85-140): the reference's test cases (tests/processors/test_min_max_norm.py), zero / NaN / negative
+    bounds, synthetic waveforms normalised by their own extremes.  a_min / a_max are 1-element arrays in the gufunc ("float32[:]")."""
+    rng = np.random.default_rng(0x3A3)
+    b = Book("min_max_norm")
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        ones = np.ones(10, dtype=dt)
+        wn = ones.copy()
+        wn[4] = np.nan
+        ramp = np.linspace(-3, 7, 64).astype(dt)
+        cases = [(wn, 1, 1), (ones, 0, 0), (ones, -1, 2), (ones, -2, 1), (ramp, -3, 7), (ramp, -7, 3), (ramp, 0, 5), (ramp, -5, 0),
+                 (ramp, np.nan, 2), (ramp, -2, np.nan), (ramp, np.nan, 0), (ramp, 0, np.nan), (ramp, -0.0, 3), (ramp, 2, 2), (ramp, -2, 2),
+                 (ramp, np.inf, 1), (ramp, 1e-30, 1e-30)]
+        for k, (w, lo, hi) in enumerate(cases):
+            out = np.empty_like(w)
+            m = _ref("min_max")
+            fatal = run_body(m.min_max_norm, w, np.array([lo], dtype=dt), np.array([hi], dtype=dt), out)
+            b.add(f"{tag}_case{k}", "min_max_norm", tag, {"w_in": w, "w_out": out}, {"a_min": float(lo), "a_max": float(hi)}, fatal)
+        for r in range(3):
+            w, _t0 = _pz_step(rng, 1024, dt)
+            w = w - dt(np.median(w))
+            mm, _ = call_min_max(w)
+            out = np.empty_like(w)
+            fatal = run_body(_ref("min_max").min_max_norm, w, np.array([mm[2]], dtype=dt), np.array([mm[3]], dtype=dt), out)
+            b.add(f"{tag}_synth{r}", "min_max_norm", tag, {"w_in": w, "w_out": out}, {"a_min": float(mm[2]), "a_max": float(mm[3])}, fatal)
+    b.save()
+
+
 def gen_itpt():
     """interpolated_time_point_thresh (time_point_thresh.py:95-222): the reference's own test cases (tests/processors/
     test_time_point_thresh.py:118-218), every mode on both walks, starts outside the waveform and between samples, no crossing,
@@ -791,6 +819,9 @@ def main():
     if "--itpt" in sys.argv:
         gen_itpt()
         return
+    if "--norm" in sys.argv:
+        gen_min_max_norm()
+        return
     rng = np.random.default_rng(0xD5BEED)
     gen_elementwise(rng)
     gen_pole_zero(rng)
@@ -805,6 +836,7 @@ def main():
     gen_current()
     gen_linear_slope_fit()
     gen_itpt()
+    gen_min_max_norm()
 
 
 if __name__ == "__main__":

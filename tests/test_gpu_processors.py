@@ -284,6 +284,40 @@ def test_interpolated_time_point_thresh_vs_oracle(wf_len, P):
     assert np.isfinite(P.interpolated_time_point_thresh(x, thr, back, 0, ord("l"))).mean() > 0.5
 
 
+@pytest.mark.parametrize("c", cases("min_max_norm"), ids=lambda c: c.name)
+def test_min_max_norm_golden(c, P):
+    """both loops; one division per sample: bit exact"""
+    out = P.min_max_norm(c["w_in"], c.params["a_min"], c.params["a_max"])
+    assert np.asarray(out).dtype == c["w_in"].dtype
+    _eq(out, c["w_out"], c.name)
+
+
+def test_min_max_norm_per_event_bounds_and_in_a_recipe(P):
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    rng = np.random.default_rng(77)
+    w, bl, _ = _synth(rng, 90, 4096)
+    x = oracle.bl_subtract(w, bl)[0]
+    x[4, 100] = np.nan
+    _, _, lo, hi, _ = oracle.min_max(x)
+    lo[7], hi[8], lo[9] = 0.0, np.nan, np.nan
+    hi[9] = 0.0
+    _eq(P.min_max_norm(x, lo, hi), oracle.min_max_norm(x, lo, hi)[0], "min_max_norm")
+    M = "dspeed.processors"
+    rec = {"outputs": ["wf_norm", "peak"], "processors": {
+        "wf_blsub": f"{M}.bl_subtract(waveform, baseline, wf_blsub)",
+        "t_lo, t_hi, a_lo, a_hi": {"function": "min_max", "module": M, "args": ["wf_blsub", "t_lo", "t_hi", "a_lo", "a_hi"]},
+        "wf_norm": {"function": "min_max_norm", "module": M, "args": ["wf_blsub", "a_lo", "a_hi", "wf_norm"], "unit": ["ADC"]},
+        "peak": "numpy.amax(wf_norm, 1, peak)"}}
+    chain, _, out = build_processing_chain(rec, {"waveform": w, "baseline": bl})
+    chain.execute()
+    xb = oracle.bl_subtract(w, bl)[0]
+    _, _, lo2, hi2, _ = oracle.min_max(xb)
+    want = oracle.min_max_norm(xb, lo2, hi2)[0]
+    _eq(out["wf_norm"], want, "recipe min_max_norm")
+    assert np.array_equal(out["peak"], want.max(axis=1)) and np.all(np.abs(out["peak"]) <= 1.0)
+
+
 @pytest.mark.parametrize("c", _f32(cases("min_max")), ids=lambda c: c.name)
 def test_min_max_golden(c, P):
     out = P.min_max(c["w_in"])

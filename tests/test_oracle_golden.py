@@ -219,6 +219,23 @@ def test_golden_interpolated_time_point_thresh(c):
     _eq(out[0], c["t_out"], c.name)
 
 
+@pytest.mark.parametrize("c", cases("min_max_norm"), ids=lambda c: c.name)
+def test_golden_min_max_norm(c):
+    out, rc = oracle.min_max_norm(c["w_in"], c.params["a_min"], c.params["a_max"])
+    _check_fatal(c, rc)
+    _eq(out[0], c["w_out"], c.name)
+
+
+def test_known_min_max_norm():
+    """reference tests/processors/test_min_max_norm.py:6-41"""
+    w = np.ones(10)
+    wn = w.copy()
+    wn[4] = np.nan
+    assert np.isnan(oracle.min_max_norm(wn, 1, 1)[0]).all()
+    assert np.allclose(oracle.min_max_norm(w, 0, 0)[0], np.ones(10))
+    assert np.allclose(oracle.min_max_norm(w, -1, 2)[0], np.ones(10) / 2) and np.allclose(oracle.min_max_norm(w, -2, 1)[0], np.ones(10) / 2)
+
+
 @pytest.mark.parametrize("c", cases("min_max"), ids=lambda c: c.name)
 def test_golden_min_max(c):
     *o, rc = oracle.min_max(c["w_in"])
