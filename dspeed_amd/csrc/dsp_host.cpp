@@ -10,6 +10,10 @@
 // reference's own codes/messages (processors/*.py, cited in include/dspeed_hip.h).
 #include <hip/hip_runtime.h>
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -274,6 +278,28 @@ int dsp_event_sync(void* event) {
 int dsp_event_elapsed_ms(void* start, void* stop, float* ms) {
     HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
     return DSP_OK;
+}
+// Diagnostics: the HIP / ROCr runtimes end the process with abort() on some failures (a GPU memory fault, an internal guarantee)
+// without saying where.  With this handler installed SIGABRT first writes the native call stack to stderr, then takes its default
+// course.  async-signal-safe calls only (backtrace_symbols_fd writes straight to the descriptor).
+static struct sigaction g_prev_abort;
+static void abort_trace_handler(int sig) {
+    static const char head[] = "\n[dspeed_hip] SIGABRT -- native call stack:\n";
+    (void)!write(2, head, sizeof head - 1);
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    sigaction(sig, &g_prev_abort, nullptr);  // whoever was there before (Python's faulthandler prints its own stack), then the default
+    raise(sig);
+}
+int dsp_install_abort_trace(void) {
+    void* warm[2];
+    (void)backtrace(warm, 2);  // (loads libgcc's unwinder now, not inside the handler)
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_handler = abort_trace_handler;
+    sigemptyset(&sa.sa_mask);
+    return sigaction(SIGABRT, &sa, &g_prev_abort) == 0 ? DSP_OK : fail(DSP_ERR_ARG, "sigaction(SIGABRT) failed");
 }
 const char* dsp_last_error(void) { return g_last_error.c_str(); }
 const char* dsp_version(void) { return "dspeed_hip 0.1 (gfx950)"; }

@@ -135,6 +135,13 @@ class HostPin:
         self.nbytes = array.nbytes
         self._key = (self.ptr, self.nbytes)
         if _PINNED.get(self._key, 0) == 0:
+            # The runtime locks whole pages and keeps one record per range: a second registration that shares pages with a live one
+            # (a row range of a pinned array, the same start with another length) must not reach it -- its unregister would drop
+            # or orphan the other's record, and an orphaned record outlives the memory it describes.  Such a range stays unpinned.
+            lo, hi = self.ptr & ~0xFFF, (self.ptr + self.nbytes + 0xFFF) & ~0xFFF
+            for (p, n), held in _PINNED.items():
+                if held > 0 and (p & ~0xFFF) < hi and lo < ((p + n + 0xFFF) & ~0xFFF):
+                    raise RuntimeError("HostPin: the range shares pages with one that is already page-locked")
             _lib.check(_lib.lib().dsp_host_register(self.ptr, self.nbytes), what="host_register")
         _PINNED[self._key] = _PINNED.get(self._key, 0) + 1
         self._held = True

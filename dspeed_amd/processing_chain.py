@@ -1061,7 +1061,7 @@ def _schedule(steps):
     computes the same values.  List scheduling with two rules: a processor that only reduces waveforms to numbers runs as soon as its
     operands exist (it can only end lifetimes); among the ones that create a waveform, the one reading the oldest waveform goes
     first (finish with a waveform before starting on newer ones), an element-wise or recursive filter that may then take its place
-    last."""
+    last; a processor whose result could not be consumed yet (a consumer waits for another operand) yields to the others."""
     def leaves(a, acc):
         if isinstance(a, SExpr):
             for x in a.args:
@@ -1084,6 +1084,10 @@ def _schedule(steps):
         for v in mine:
             producer.setdefault(id(v), j)
     deps = [{producer[id(v)] for v in reads if id(v) in producer and producer[id(v)] != j} for j, reads in enumerate(ins)]
+    consumers = [[] for _ in steps]
+    for c, d in enumerate(deps):
+        for j in d:
+            consumers[j].append(c)
     born = {}  # waveform -> position in the new order of the processor that made it (inputs: -1)
     order, done = [], set()
     while len(order) < len(steps):
@@ -1097,8 +1101,16 @@ def _schedule(steps):
             def age(j):
                 wfs = [born.get(id(v), -1) for v in ins[j] if v.kind == "wf"]
                 return min(wfs) if wfs else len(steps)
+            def waits(j):  # a consumer of what j makes still lacks an operand that does not itself come from j: j's waveform
+                family, todo = {j}, [j]  # would sit in LDS until that arrives
+                while todo:
+                    for c in consumers[todo.pop()]:
+                        if c not in family:
+                            family.add(c)
+                            todo.append(c)
+                return any(deps[c] - done - family for c in consumers[j])
             # (same oldest waveform: the one that could overwrite it in place waits until the others have read it)
-            j = min(ready, key=lambda j: (age(j), steps[j][0] in ("bl_subtract", "numpy_subtract", "numpy_add", "min_max_norm", "pole_zero", "double_pole_zero"), j))
+            j = min(ready, key=lambda j: (waits(j), age(j), steps[j][0] in ("bl_subtract", "numpy_subtract", "numpy_add", "min_max_norm", "pole_zero", "double_pole_zero"), j))
         for a, r in zip(steps[j][1], _SIGS.get(steps[j][0], "")):
             if r == "W" and isinstance(a, Var):
                 born[id(a)] = len(order)

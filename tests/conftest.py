@@ -23,3 +23,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _abort_trace():
+    """On the GPU box: if the HIP runtime ever abort()s the test process, leave the native call stack in the log."""
+    if _gpu_present():
+        try:
+            from dspeed_amd import _lib
+
+            _lib.lib().dsp_install_abort_trace()
+        except Exception:
+            pass
+    yield

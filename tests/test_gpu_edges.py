@@ -119,3 +119,30 @@ def test_fir_edges_same_and_full_modes(wf_len, m):
     want = oracle.convolve_wf(w, k2, "s", wf_len)[0]
     got = P.convolve_wf(w, k2, ord("s"), np.empty((n_wf, wf_len), dtype=np.float32))
     assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
+
+
+def test_page_locked_ranges_never_overlap():
+    """HostPin: one record per range at the runtime -- the same array twice shares it, a range that shares pages with a live one is
+    refused (the chain then copies it unpinned), and everything can be locked again once released."""
+    from dspeed_amd.device import _PINNED, HostPin
+
+    a = np.zeros((512, 4096), dtype=np.float32)
+    before = dict(_PINNED)
+    p1 = HostPin(a)
+    p2 = HostPin(a)
+    assert _PINNED[(a.ctypes.data, a.nbytes)] == 2
+    for view in (a[:100], a[100:200], a[511:]):
+        with pytest.raises(RuntimeError):
+            HostPin(view)
+    p1.close()
+    with pytest.raises(RuntimeError):
+        HostPin(a[:100])
+    p2.close()
+    assert dict(_PINNED) == before
+    p3 = HostPin(a[:100])
+    with pytest.raises(RuntimeError):
+        HostPin(a)
+    p4 = HostPin(a[300:400])  # (no page in common with rows 0..99)
+    p3.close()
+    p4.close()
+    assert dict(_PINNED) == before

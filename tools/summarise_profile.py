@@ -74,6 +74,28 @@ summary += ["", "Per waveform (= per wavefront-iteration), SQ counters in quad-c
             "|---|---|---|---|---|---|---|---|---|",
             "| " + " | ".join(f"{per(k):.0f}" for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU",
                                                         "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE")) + " |"]
+# secondary measurements committed beside it (tools/bench_configs.py, tools/icpc_breakdown.py), so that one file tells the round
+other = f"profiles/{tag}_other_configs.jsonl"
+if os.path.exists(other):
+    summary += ["", f"Other BASELINE configs on device-resident batches (`tools/bench_configs.py`, `{other}`):", "",
+                "| config | kernel | rows | waveforms/s | of its bound |", "|---|---|---|---|---|"]
+    for line in open(other):
+        o = json.loads(line)
+        what = f"{o.get('achieved_TFLOPs', 0):.1f} TFLOP/s" if o["bound"] != "hbm" else f"{o['achieved_GBps']:.0f} GB/s"
+        summary.append(f"| {o['config']} | `{o['kernel']}` | {o['rows']} | {o['waveforms_per_s'] / 1e6:.2f} M | {what} = {100 * o['frac']:.1f} % of {o['bound']} |")
+icpc = f"profiles/{tag}_icpc_recipe.jsonl"
+if os.path.exists(icpc):
+    rows_ = [json.loads(line) for line in open(icpc)]
+    summary += ["", f"The whole Ge recipe as one device program (`tools/icpc_breakdown.py`, `{icpc}`; 8192-sample int16 rows):", "",
+                "| outputs requested | ops | LDS per waveform | waveforms/s |", "|---|---|---|---|"]
+    for o in rows_:
+        if "waveforms_per_s" in o:
+            summary.append(f"| {o['outputs']} | {o['ops']} | {o['lds_bytes_per_waveform']} B | {o['waveforms_per_s'] / 1e3:.0f} k |")
+    for o in rows_:
+        if o.get("per_op_profile"):
+            top = ", ".join(f"{k} {100 * v:.0f} %" for k, v in list(o["share_by_opcode"].items())[:6])
+            summary.append("")
+            summary.append(f"In-kernel op timers (`dsp_chain_profile`), {o['recipe']}: {o['cycles_per_waveform']} shader cycles per waveform per wavefront; {top}.")
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(summary) + "\n")
 shutil.copy(f"{src}/bench_default.json", f"profiles/{tag}_bench.json")
 print("\n".join(summary))
