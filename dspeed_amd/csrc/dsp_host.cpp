@@ -268,7 +268,11 @@ int dsp_host_register(void* host, int64_t bytes) {
 }
 int dsp_host_unregister(void* host) {
     if (!host) return DSP_OK;
-    HIP_RELEASE(hipHostUnregister(host));
+    hipError_t e = hipHostUnregister(host);
+    if (e != hipSuccess) {  // the caller must then keep the memory alive: the runtime still holds a record of the range
+        (void)hipGetLastError();
+        return fail(DSP_ERR_HIP, "hipHostUnregister: %s", hipGetErrorString(e));
+    }
     return DSP_OK;
 }
 int dsp_event_sync(void* event) {

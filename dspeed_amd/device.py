@@ -117,6 +117,42 @@ class PinnedArray:
             pass
 
 
+class _Bounce:
+    """One page-locked staging buffer for the synchronous copies (``DeviceArray.copy_from`` / ``to_numpy`` without a stream: the
+    processor-by-processor path).  Copying between device memory and arbitrary NumPy memory makes the runtime page-lock those pages
+    on the fly, per call; NumPy hands megabyte arrays back to the OS when they die and gets the same addresses again, and the
+    runtime's records of such ranges have been seen to end a long test session in abort() inside hipMemcpy.  Through this buffer
+    the device only ever exchanges data with memory the runtime allocated itself; the extra host copy is noise next to PCIe."""
+
+    CHUNK = 32 << 20
+    _buf = None
+
+    @classmethod
+    def get(cls) -> np.ndarray:
+        if cls._buf is None:
+            cls._buf = PinnedArray((cls.CHUNK,), np.uint8)
+        return cls._buf.array
+
+    @classmethod
+    def h2d(cls, dev_ptr: int, a: np.ndarray) -> None:
+        src = a.reshape(-1).view(np.uint8)
+        buf = cls.get()
+        for o in range(0, src.nbytes, cls.CHUNK):
+            n = min(cls.CHUNK, src.nbytes - o)
+            buf[:n] = src[o:o + n]
+            _lib.check(_lib.lib().dsp_h2d(dev_ptr + o, buf.ctypes.data, n), what="h2d")
+
+    @classmethod
+    def d2h(cls, out: np.ndarray, dev_ptr: int) -> None:
+        dst = out.reshape(-1).view(np.uint8)
+        buf = cls.get()
+        for o in range(0, dst.nbytes, cls.CHUNK):
+            n = min(cls.CHUNK, dst.nbytes - o)
+            _lib.check(_lib.lib().dsp_d2h(buf.ctypes.data, dev_ptr + o, n), what="d2h")
+            dst[o:o + n] = buf[:n]
+
+
+_NEVER_FREED = []
 _PINNED = {}  # (address, bytes) -> number of HostPin objects holding that registration (hipHostRegister itself does not count)
 
 
@@ -152,7 +188,8 @@ class HostPin:
             left = _PINNED.get(self._key, 1) - 1
             if left <= 0:
                 _PINNED.pop(self._key, None)
-                _lib.lib().dsp_host_unregister(self.ptr)
+                if _lib.lib().dsp_host_unregister(self.ptr) != 0:
+                    _NEVER_FREED.append(self.array)  # the runtime kept its record of the range: the addresses must not come back
             else:
                 _PINNED[self._key] = left
 
@@ -200,7 +237,8 @@ class DeviceArray:
         a = np.ascontiguousarray(a, dtype=self.dtype)
         assert a.nbytes == self.nbytes, f"size mismatch {a.shape} vs {self.shape}"
         if stream is None:
-            _lib.check(_lib.lib().dsp_h2d(self.ptr, a.ctypes.data, self.nbytes), what="h2d")
+            if self.nbytes:
+                _Bounce.h2d(self.ptr, a)
         else:
             _lib.check(_lib.lib().dsp_h2d_async(self.ptr, a.ctypes.data, self.nbytes, stream.ptr), what="h2d_async")
 
@@ -209,7 +247,8 @@ class DeviceArray:
             out = np.empty(self.shape, dtype=self.dtype)
         assert out.flags.c_contiguous and out.nbytes == self.nbytes
         if stream is None:
-            _lib.check(_lib.lib().dsp_d2h(out.ctypes.data, self.ptr, self.nbytes), what="d2h")
+            if self.nbytes:
+                _Bounce.d2h(out, self.ptr)
         else:
             _lib.check(_lib.lib().dsp_d2h_async(out.ctypes.data, self.ptr, self.nbytes, stream.ptr), what="d2h_async")
         return out
