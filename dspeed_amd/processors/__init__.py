@@ -7,11 +7,8 @@ A dspeed JSON recipe that says ``"module": "dspeed.processors"`` resolves to thi
 """
 from __future__ import annotations
 
-import ctypes as C
-
 import numpy as np
 
-from .. import _lib
 from ..device import DeviceArray
 from ..errors import DSPFatal
 from ..gufunc import HipGUFunc, Staging, entry, loop_suffix, run
