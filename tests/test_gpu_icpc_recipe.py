@@ -183,3 +183,42 @@ def test_rounding_functions_of_the_argument_language():
     assert np.array_equal(np.rint(tp), out["t_round"]) and np.array_equal(np.floor(tp), out["t_floor"])
     assert np.array_equal(np.ceil(tp), out["t_ceil"]) and np.array_equal(np.trunc(tp), out["t_trunc"])
     assert out["c_round"][0] == 992 and out["c_floor"][0] == 992 and out["c_ceil"][0] == 1008 and out["c_trunc"][0] == 992
+
+
+def test_cpu_port_of_the_whole_recipe_beside_the_device():
+    """Not a parity test: times the oracle composition above (the CPU port of the same recipe, one thread, processor by processor on
+    whole arrays) beside the device program on the same rows and leaves both figures in gpurun_out/ for profiles/."""
+    import json
+    import os
+    import time
+
+    from dspeed_amd.device import DeviceArray, sync
+    from dspeed_amd.processing_chain import WaveformInput, build_processing_chain
+
+    rng = np.random.default_rng(11)
+    n_cpu, n_gpu = 128, 32768
+    wf, bl = _synth(rng, n_cpu)
+    t0_ns = np.full(n_cpu, 48000.0, dtype=F)
+    t = time.perf_counter()
+    want, _ = _expected(wf, bl, t0_ns)
+    cpu_rate = n_cpu / (time.perf_counter() - t)
+    reps = n_gpu // n_cpu
+    d_wf, d_bl = DeviceArray.from_numpy(np.tile(wf, (reps, 1))), DeviceArray.from_numpy(np.tile(bl, reps))
+    tb = {"waveform": WaveformInput(d_wf, 16.0, 48000.0), "baseline": d_bl}
+    chain, _, _ = build_processing_chain(recipes.ICPC, tb)
+    outs = {k: DeviceArray((n_gpu,), np.float32) for k in recipes.ICPC["outputs"]}
+    chain.link(tb, outs)
+    chain.execute()
+    sync()
+    t = time.perf_counter()
+    for _ in range(3):
+        chain.execute()
+    sync()
+    gpu_rate = 3 * n_gpu / (time.perf_counter() - t)
+    got = outs["trapEmax"].to_numpy()[:n_cpu]
+    assert np.max(np.abs(got - want["trapEmax"]) / want["trapEmax"]) <= 1e-6
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/icpc_cpu_port.json", "w") as f:
+        json.dump({"recipe": "ICPC structure (tests/recipes.py), 8192-sample uint16 rows", "cpu_port_waveforms_per_s_1_thread": cpu_rate,
+                   "cpu_rows": n_cpu, "device_waveforms_per_s": gpu_rate, "device_rows": n_gpu, "ratio": gpu_rate / cpu_rate}, f, indent=1)
+    assert gpu_rate > 10 * cpu_rate
