@@ -95,7 +95,7 @@ def lib():
         "dsp_asym_trap_filter_f32": [vp, C.c_int, i64, i32, i64, i32, i32, i32, vp, i64, vp, pi64],
         "dsp_fixed_time_pickoff_f32": [vp, C.c_int, i64, i32, i64, vp, f32, i32, vp, vp, pi64],
         "dsp_min_max_norm_f32": [vp, C.c_int, i64, i32, i64, vp, f32, vp, f32, vp, i64, vp, pi64],
-        "dsp_install_abort_trace": [],
+        "dsp_install_abort_trace": [C.c_int],
         "dsp_chain_profile": [vp, C.c_int],
         "dsp_chain_profile_read": [vp, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.POINTER(C.c_int),
                                    C.POINTER(C.c_uint64)],

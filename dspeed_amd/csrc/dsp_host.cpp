@@ -287,16 +287,22 @@ int dsp_event_elapsed_ms(void* start, void* stop, float* ms) {
 // without saying where.  With this handler installed SIGABRT first writes the native call stack to stderr, then takes its default
 // course.  async-signal-safe calls only (backtrace_symbols_fd writes straight to the descriptor).
 static struct sigaction g_prev_abort;
+static int g_abort_fd = 2;
 static void abort_trace_handler(int sig) {
-    static const char head[] = "\n[dspeed_hip] SIGABRT -- native call stack:\n";
-    (void)!write(2, head, sizeof head - 1);
+    static const char head[] = "\n[dspeed_hip] SIGABRT -- native call stack of the aborting thread:\n";
     void* frames[64];
     const int n = backtrace(frames, 64);
-    backtrace_symbols_fd(frames, n, 2);
+    (void)!write(g_abort_fd, head, sizeof head - 1);
+    backtrace_symbols_fd(frames, n, g_abort_fd);
+    if (g_abort_fd != 2) {  // (a test runner may have redirected descriptor 2: say it there as well)
+        (void)!write(2, head, sizeof head - 1);
+        backtrace_symbols_fd(frames, n, 2);
+    }
     sigaction(sig, &g_prev_abort, nullptr);  // whoever was there before (Python's faulthandler prints its own stack), then the default
     raise(sig);
 }
-int dsp_install_abort_trace(void) {
+int dsp_install_abort_trace(int fd) {
+    g_abort_fd = fd >= 0 ? fd : 2;
     void* warm[2];
     (void)backtrace(warm, 2);  // (loads libgcc's unwinder now, not inside the handler)
     struct sigaction sa;

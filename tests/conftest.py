@@ -27,12 +27,24 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope="session", autouse=True)
 def _abort_trace():
-    """On the GPU box: if the HIP runtime ever abort()s the test process, leave the native call stack in the log."""
+    """On the GPU box: if the HIP / ROCr runtime ever abort()s the test process (its way of reporting a GPU fault), leave the native
+    call stack in gpurun_out/abort_native_stack.log -- pytest holds descriptor 2 while tests run, so stderr alone would lose it."""
+    log = None
     if _gpu_present():
         try:
             from dspeed_amd import _lib
 
-            _lib.lib().dsp_install_abort_trace()
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            log = open(os.path.join(ROOT, "gpurun_out", "abort_native_stack.log"), "a")
+            _lib.lib().dsp_install_abort_trace(log.fileno())
         except Exception:
             pass
     yield
+    if log is not None:
+        try:
+            from dspeed_amd import _lib
+
+            _lib.lib().dsp_install_abort_trace(-1)
+            log.close()
+        except Exception:
+            pass
