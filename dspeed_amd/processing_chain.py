@@ -33,6 +33,7 @@ import re
 import time
 from collections.abc import MutableMapping
 import math
+import os
 from copy import deepcopy
 from types import SimpleNamespace
 
@@ -40,7 +41,7 @@ import numpy as np
 
 from . import _lib
 from .chain import Chain, Program, Scalar
-from .device import DeviceArray, Event, HostPin, Stream
+from .device import DeviceArray, Event, HostPin, PinnedArray, Stream
 from .errors import DSPFatal, ProcessingChainError
 
 _UNITS_NS = {"ns": 1.0, "us": 1e3, "ms": 1e6, "s": 1e9}
@@ -194,6 +195,8 @@ class ProcessingChain:
         self._pins = {}           # (address, bytes) -> HostPin of a linked host column (None: registration refused)
         self._piece_key, self._piece_bufs, self._piece_events = None, [], []  # device buffers host columns are streamed through
         self._copy_stream = None  # H2D of the next piece runs here while the compute stream works on the current one
+        self._pool = None         # host threads for staging copies
+        self._stage_key, self._stage = None, []  # page-locked staging buffers (one set per piece slot)
         self._timing = {"h2d": 0.0, "kernel": 0.0, "d2h": 0.0}
         self.proc_strings = proc_strings
 
@@ -227,10 +230,35 @@ class ProcessingChain:
 
     #: bytes of host-resident I/O per pipelined piece: tens of MB keep PCIe transfers efficient, two pieces are in flight
     pipeline_bytes = 64 << 20
+    #: How host-resident columns reach the device.  False (default): through page-locked staging buffers the chain owns
+    #: (hipHostMalloc), filled / emptied by host threads -- the device only exchanges data with memory the runtime allocated itself.
+    #: True: the linked NumPy columns are page-locked in place (hipHostRegister) and copied from directly: the full PCIe rate
+    #: without a host copy, for buffers that live as long as the chain (build_dsp-style refilled tables); DESIGN.md section 5 on why it
+    #: is not the default.  Environment DSPEED_HIP_PIN_IN_PLACE=1 switches it on globally.
+    pin_in_place = os.environ.get("DSPEED_HIP_PIN_IN_PLACE", "0") == "1"
+    #: host threads that move rows between NumPy columns and the staging buffers
+    copy_threads = 8
+
+    def _host_copy(self, dst: np.ndarray, src: np.ndarray) -> None:
+        """dst[...] = src for two equally shaped row blocks, split over the copy threads (NumPy releases the GIL in the copy)."""
+        n = len(src)
+        if n == 0:
+            return
+        if src.nbytes < (4 << 20) or self.copy_threads <= 1:
+            np.copyto(dst, src, casting="unsafe")
+            return
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._pool = ThreadPoolExecutor(max_workers=self.copy_threads)
+        step = -(-n // self.copy_threads)
+        list(self._pool.map(lambda a: np.copyto(dst[a:a + step], src[a:a + step], casting="unsafe"), range(0, n, step)))
 
     def _pinned(self, arr: np.ndarray) -> bool:
         """Page-lock a linked host column in place, once (the reference's build_dsp refills the same buffers for every file
         chunk).  Registration can be refused (read-only or already registered memory): copies then run unpinned, only slower."""
+        if not self.pin_in_place:
+            return False
         if arr.nbytes < (1 << 20):  # small columns: the copy is latency, not bandwidth; and they share pages with their neighbours
             return False
         key = (arr.ctypes.data, arr.nbytes)
@@ -289,12 +317,25 @@ class ProcessingChain:
             self._piece_events = [Event() for _ in range(n_slots)]
             self._piece_key = key
         slots, ev_in = self._piece_bufs, self._piece_events
+        # page-locked staging buffers for the columns that are not page-locked in place: one per piece slot
+        in_place_in = {name for name, arr in host_in.items() if self._pinned(arr)}
+        in_place_out = {name for name, (col, _len, direct) in host_out.items() if direct and self._pinned(col)}
+        skey = (key, tuple(sorted(in_place_in)), tuple(sorted(in_place_out)))
+        if self._stage_key != skey:
+            self._stage = []
+            for _ in range(n_slots):
+                st = {name: PinnedArray((piece, *arr.shape[1:]), arr.dtype) for name, arr in host_in.items() if name not in in_place_in}
+                st.update({name: PinnedArray((piece,) if length is None else (piece, length), self.loop_dtype)
+                           for name, (_c, length, _d) in host_out.items() if name not in in_place_out})
+                self._stage.append(st)
+            self._stage_key = skey
+        stage = self._stage
         if self._copy_stream is None:
             self._copy_stream = Stream()
         s_in, s_c = self._copy_stream, self._stream
 
-        def finish(a, b, temps):
-            """piece [a, b): wait for its kernel and copies, report its DSPFatal with absolute rows, deliver converted outputs"""
+        def finish(a, b, staged):
+            """piece [a, b): wait for its kernel and copies, report its DSPFatal with absolute rows, deliver the staged outputs"""
             t = time.perf_counter()
             try:
                 self._chain.check(s_c, row_offset=a)
@@ -304,20 +345,24 @@ class ProcessingChain:
                 raise
             self._timing["kernel"] += time.perf_counter() - t
             t = time.perf_counter()
-            for col, tmp in temps:
-                col[a:b] = tmp.astype(col.dtype, copy=False)
+            for col, buf in staged:  # (a column of another dtype is converted on the way)
+                self._host_copy(col[a:b], buf[:b - a])
             self._timing["d2h"] += time.perf_counter() - t
 
         # ---- pieces: H2D(k) on the copy stream overlaps kernel(k-1) and D2H(k-1) on the compute stream
         pending = None
         for k, a in enumerate(range(start, stop, piece)):
             b = min(stop, a + piece)
-            m, sl = b - a, slots[k % n_slots]
+            m, sl, st = b - a, slots[k % n_slots], stage[k % n_slots]
             t = time.perf_counter()
             bufs = dict(self._dev)
             for name, arr in host_in.items():  # (slot k % 2 is free: piece k-2 was finished in iteration k-1)
                 d = sl[name].view_rows(0, m)
-                src = arr[a:b]
+                if name in in_place_in:
+                    src = arr[a:b]
+                else:
+                    src = st[name].array[:m]
+                    self._host_copy(src, arr[a:b])
                 _lib.check(lib.dsp_h2d_async(d.ptr, src.ctypes.data, src.nbytes, s_in.ptr), what="h2d_async")
                 bufs[name] = d
             ev_in[k % n_slots].record(s_in)
@@ -329,19 +374,19 @@ class ProcessingChain:
             if pending is not None:
                 finish(*pending)
             s_c.wait_event(ev_in[k % n_slots])
-            temps = []
+            staged = []
             for name in host_out:
                 bufs[name] = sl[name].view_rows(0, m)
             self._chain.execute(bufs, m, s_c)
             for name, (col, length, direct) in host_out.items():
                 d = bufs[name]
-                if direct:
+                if name in in_place_out:
                     dst = col[a:b]
                 else:
-                    dst = np.empty(d.shape, dtype=self.loop_dtype)
-                    temps.append((col, dst))
+                    dst = st[name].array[:m]
+                    staged.append((col, dst))
                 _lib.check(lib.dsp_d2h_async(dst.ctypes.data, d.ptr, d.nbytes, s_c.ptr), what="d2h_async")
-            pending = (a, b, temps)
+            pending = (a, b, staged)
         finish(*pending)
 
     def __call__(self, tb_in, tb_out, begin: int = 0, end: int | None = None):

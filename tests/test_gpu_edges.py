@@ -1,5 +1,7 @@
 """Edge shapes of the gufunc and chain entry points: empty batches, a single 1-D waveform, ragged lengths (not a multiple of the
 wavefront), the longest waveform one wavefront can hold and the first length it cannot, the shortest waveforms."""
+import os
+
 import numpy as np
 import pytest
 
@@ -121,6 +123,8 @@ def test_fir_edges_same_and_full_modes(wf_len, m):
     assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isinf(got), np.isinf(want))
 
 
+@pytest.mark.skipif(os.environ.get("DSPEED_TEST_PIN_IN_PLACE", "0") != "1",
+                    reason="in-place page-locking of NumPy memory is opt-in (DESIGN.md section 5); set DSPEED_TEST_PIN_IN_PLACE=1")
 def test_page_locked_ranges_never_overlap():
     """HostPin: one record per range at the runtime -- the same array twice shares it, a range that shares pages with a live one is
     refused (the chain then copies it unpinned), and everything can be locked again once released."""
@@ -146,3 +150,24 @@ def test_page_locked_ranges_never_overlap():
     p3.close()
     p4.close()
     assert dict(_PINNED) == before
+
+
+@pytest.mark.skipif(os.environ.get("DSPEED_TEST_PIN_IN_PLACE", "0") != "1",
+                    reason="in-place page-locking of NumPy memory is opt-in (DESIGN.md section 5); set DSPEED_TEST_PIN_IN_PLACE=1")
+def test_columns_page_locked_in_place_give_the_same_results():
+    import recipes
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    rng = np.random.default_rng(21)
+    n = 600
+    wf = (10000 + 50 * rng.standard_normal((n, 4096))).astype(np.float32)
+    tb = {"waveform": wf, "baseline": np.full(n, 10000, np.float32), "t_pick": np.full(n, 2823.4, np.float32)}
+    staged, _, o1 = build_processing_chain(recipes.C2, tb)
+    staged.pipeline_bytes = 100 * 4096 * 4
+    staged.execute()
+    ref = o1["trapEftp"].copy()
+    pinned, _, o2 = build_processing_chain(recipes.C2, tb)
+    pinned.pin_in_place = True
+    pinned.pipeline_bytes = 100 * 4096 * 4
+    pinned.execute()
+    assert np.array_equal(o2["trapEftp"], ref) and len(pinned._pins) >= 1
