@@ -153,6 +153,36 @@ struct dsp_chain {
     int io_wf = -1, io_bl = -1, io_tp = -1, io_out = -1;
 };
 
+// Internal copies between this library's own host structures (programs, error words, tap read-backs) and the device go through one
+// page-locked staging buffer: the runtime is never handed heap or stack memory to page-lock on the fly (host memory note).
+static std::mutex g_stage_mu;
+static void* g_stage = nullptr;
+static const size_t STAGE_BYTES = 1 << 20;
+static hipError_t stage_ready() {
+    if (g_stage) return hipSuccess;
+    return hipHostMalloc(&g_stage, STAGE_BYTES, hipHostMallocDefault);
+}
+static hipError_t staged_h2d(void* dev, const void* host, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    hipError_t e = stage_ready();
+    for (size_t o = 0; e == hipSuccess && o < bytes; o += STAGE_BYTES) {
+        const size_t n = bytes - o < STAGE_BYTES ? bytes - o : STAGE_BYTES;
+        memcpy(g_stage, (const char*)host + o, n);
+        e = hipMemcpy((char*)dev + o, g_stage, n, hipMemcpyHostToDevice);
+    }
+    return e;
+}
+static hipError_t staged_d2h(void* host, const void* dev, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    hipError_t e = stage_ready();
+    for (size_t o = 0; e == hipSuccess && o < bytes; o += STAGE_BYTES) {
+        const size_t n = bytes - o < STAGE_BYTES ? bytes - o : STAGE_BYTES;
+        e = hipMemcpy(g_stage, (const char*)dev + o, n, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) memcpy((char*)host + o, g_stage, n);
+    }
+    return e;
+}
+
 extern "C" {
 
 // ------------------------------------------------------------------------------------------------ device / memory
@@ -953,7 +983,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     HIP_TRY(hipGetDeviceProperties(&prop, ch->device));
     ch->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipMalloc((void**)&ch->dev, sizeof(DevProgram)));
-    HIP_TRY(hipMemcpy(ch->dev, &P, sizeof(DevProgram), hipMemcpyHostToDevice));
+    HIP_TRY(staged_h2d(ch->dev, &P, sizeof(DevProgram)));
     HIP_TRY(hipMalloc((void**)&ch->dev_err, DSP_ERR_WORDS * sizeof(int)));
     HIP_TRY(hipMemset(ch->dev_err, 0, DSP_ERR_WORDS * sizeof(int)));
     const int block_lds = ch->lds_bytes_per_wave * ch->waves_per_block;
@@ -1049,7 +1079,7 @@ int dsp_chain_check(dsp_chain* ch, void* stream, int64_t* row) {
     if (!ch) return fail(DSP_ERR_ARG, "null chain");
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     int host_err[DSP_ERR_WORDS] = {0};
-    HIP_TRY(hipMemcpy(host_err, ch->dev_err, sizeof host_err, hipMemcpyDeviceToHost));
+    HIP_TRY(staged_d2h(host_err, ch->dev_err, sizeof host_err));
     if (getenv("DSPEED_HIP_ABLATE") && (atoi(getenv("DSPEED_HIP_ABLATE")) & 8)) {  // diagnostic phase stamps
         unsigned long long ph[6];
         memcpy(ph, host_err + 4, sizeof ph);
@@ -1082,7 +1112,7 @@ int dsp_chain_profile(dsp_chain* ch, int enable) {
         HIP_RELEASE(hipFree(ch->host.prof));
         ch->host.prof = nullptr;
     }
-    HIP_TRY(hipMemcpy(ch->dev, &ch->host, sizeof(DevProgram), hipMemcpyHostToDevice));
+    HIP_TRY(staged_h2d(ch->dev, &ch->host, sizeof(DevProgram)));
     return DSP_OK;
 }
 
@@ -1094,7 +1124,7 @@ int dsp_chain_profile_read(dsp_chain* ch, int capacity, int32_t* opcodes, int32_
     HIP_TRY(hipSetDevice(ch->device));
     HIP_TRY(hipDeviceSynchronize());
     std::vector<unsigned long long> host(ch->host.n_ops + 1);
-    HIP_TRY(hipMemcpy(host.data(), ch->host.prof, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(staged_d2h(host.data(), ch->host.prof, host.size() * sizeof(unsigned long long)));
     for (int i = 0; i < ch->host.n_ops; ++i) {
         opcodes[i] = ch->host.ops[i].opcode;
         slots[i] = ch->host.ops[i].src;
@@ -1310,7 +1340,7 @@ int g_convolve(int ty, const WfIn& in, const void* kernel_dev, int32_t kernel_le
     // NaN among the taps -> NaN output (convolutions.py:45-46): look at them once on the host
     const size_t esz = ty == DSP_F64 ? 8 : 4;
     std::vector<unsigned char> taps(esz * (size_t)kernel_len);
-    HIP_TRY(hipMemcpy(taps.data(), kernel_dev, taps.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(staged_d2h(taps.data(), kernel_dev, taps.size()));
     int has_nan = 0;  // bit 0: a NaN among the taps, bit 1: an infinity
     for (int k = 0; k < kernel_len; ++k) {
         const double v = ty == DSP_F64 ? ((const double*)taps.data())[k] : (double)((const float*)taps.data())[k];
