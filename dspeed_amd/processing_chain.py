@@ -175,6 +175,9 @@ _ROUND_MODES = {"round": 1, "floor": 2, "ceil": 3, "trunc": 4}
 _CALLS = ("round", "floor", "ceil", "trunc", "len", "float", "int")  # functions of the argument language (reference :729-751)
 
 
+_COPY_POOL = None  # host threads that move rows between NumPy columns and staging buffers
+
+
 class ProcessingChain:
     """Runs a translated recipe over a buffer of rows.  ``execute(start, stop)`` has the meaning of the reference's
     (processing_chain.py:665-673); ``__call__(tb_in, tb_out)`` relinks I/O like :675-716."""
@@ -195,7 +198,6 @@ class ProcessingChain:
         self._pins = {}           # (address, bytes) -> HostPin of a linked host column (None: registration refused)
         self._piece_key, self._piece_bufs, self._piece_events = None, [], []  # device buffers host columns are streamed through
         self._copy_stream = None  # H2D of the next piece runs here while the compute stream works on the current one
-        self._pool = None         # host threads for staging copies
         self._stage_key, self._stage = None, []  # page-locked staging buffers (one set per piece slot)
         self._timing = {"h2d": 0.0, "kernel": 0.0, "d2h": 0.0}
         self.proc_strings = proc_strings
@@ -247,12 +249,13 @@ class ProcessingChain:
         if src.nbytes < (4 << 20) or self.copy_threads <= 1:
             np.copyto(dst, src, casting="unsafe")
             return
-        if self._pool is None:
+        global _COPY_POOL
+        if _COPY_POOL is None or _COPY_POOL._max_workers < self.copy_threads:  # (one pool for all chains of the process)
             from concurrent.futures import ThreadPoolExecutor
 
-            self._pool = ThreadPoolExecutor(max_workers=self.copy_threads)
+            _COPY_POOL = ThreadPoolExecutor(max_workers=self.copy_threads, thread_name_prefix="dspeed-copy")
         step = -(-n // self.copy_threads)
-        list(self._pool.map(lambda a: np.copyto(dst[a:a + step], src[a:a + step], casting="unsafe"), range(0, n, step)))
+        list(_COPY_POOL.map(lambda a: np.copyto(dst[a:a + step], src[a:a + step], casting="unsafe"), range(0, n, step)))
 
     def _pinned(self, arr: np.ndarray) -> bool:
         """Page-lock a linked host column in place, once (the reference's build_dsp refills the same buffers for every file
