@@ -1311,6 +1311,30 @@ __device__ __forceinline__ void op_min_max(Ctx<T>& cx, const DSP_GLOBAL DevOp& o
 //   level by level: out[k] = fl(fl(f0*x[2k+1]) + fl(f1*x[2k])), f = (c, c) for 'a', (-c, c) for the last level of 'd'.
 // Runs in place on the scratch slot ip[2] (a copy of src, or src itself when it is dead afterwards).
 // ------------------------------------------------------------------------------------------------
+// Lengths that are a multiple of 2^level and chunks that are, too (4096 / 8192 samples, level <= 5): every output is the tree of one
+// run of G = 2^level consecutive samples of one lane's chunk -- no symmetric extension, no exchange between lanes, no intermediate
+// level in LDS.  The same products and sums per level as the level-by-level form.
+template <typename T, int LEVEL>
+__device__ __forceinline__ void dwt_haar_local(Ctx<T>& cx, const DSP_GLOBAL DevSlot& ss, const DSP_GLOBAL DevSlot& sd, int part) {
+    constexpr int G = 1 << LEVEL;
+    const T c = (T)0.7071067811865476;
+    const int lane = lane_id(), C = ss.C, first = lane * C;
+    const auto* ps = cx.chunk(ss);
+    for (int g0 = 0; g0 < C; g0 += G) {
+        if (first + g0 >= ss.len) break;
+        T v[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) v[k] = ps[g0 + k];
+#pragma unroll
+        for (int l = 0; l < LEVEL; ++l) {
+            const T f0 = (l == LEVEL - 1 && part == 'd') ? -c : c;
+#pragma unroll
+            for (int k = 0; k < (G >> (l + 1)); ++k) v[k] = (T)(f0 * v[2 * k + 1]) + (T)(c * v[2 * k]);
+        }
+        cx.lds[padded_index(sd, (first + g0) >> LEVEL)] = v[0];
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void op_dwt_haar(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
@@ -1321,6 +1345,23 @@ __device__ __forceinline__ void op_dwt_haar(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
         return;
     }
     const int level = op.ip[0], part = op.ip[1], lane = lane_id();
+    constexpr int MAX_LOCAL = sizeof(T) == 8 ? 4 : 5;  // (32 float64 values in registers would spill the lean float64 build)
+    if (level <= MAX_LOCAL && ss.len % (1 << level) == 0 && ss.C % (1 << level) == 0) {
+        switch (level) {
+            case 1: dwt_haar_local<T, 1>(cx, ss, sd, part); break;
+            case 2: dwt_haar_local<T, 2>(cx, ss, sd, part); break;
+            case 3: dwt_haar_local<T, 3>(cx, ss, sd, part); break;
+            case 4: dwt_haar_local<T, 4>(cx, ss, sd, part); break;
+            default:
+                if constexpr (MAX_LOCAL >= 5) dwt_haar_local<T, 5>(cx, ss, sd, part);
+                break;
+        }
+        wave_sync();
+        for (int e = sd.len + lane; e < 64 * sd.C; e += 64) cx.lds[padded_index(sd, e)] = (T)0;
+        cx.set_nan(op.dst, false);
+        wave_sync();
+        return;
+    }
     const T c = (T)0.7071067811865476;
     int len = ss.len;
     for (int l = 0; l < level; ++l) {
