@@ -87,3 +87,31 @@ def test_fatal_rows_and_argument_errors():
     with pytest.raises(RuntimeError):
         build_dsp(42, dsp_config=recipes.C2)
     assert build_dsp({"raw/ch1": t1}, dsp_config=None, chan_config={"*ch9*": recipes.C2}) == {}  # no recipe for the channel: skipped
+
+
+def test_whole_ge_recipe_through_the_table_loop(tmp_path):
+    """the ICPC-structured recipe, written to a JSON file, over two channels with per-row t0 and a row selection: the same numbers as
+    the chain run directly on those rows"""
+    import json
+
+    from dspeed_amd import build_dsp
+    from dspeed_amd.processing_chain import WaveformInput, build_processing_chain
+    from test_gpu_icpc_recipe import _synth
+
+    rng = np.random.default_rng(3)
+    cfg = str(tmp_path / "ge-recipe.json")
+    with open(cfg, "w") as f:
+        json.dump(recipes.ICPC, f)
+    tables = {}
+    for name, n in (("raw/ch1", 40), ("raw/ch2", 24)):
+        wf, bl = _synth(rng, n)
+        tables[name] = {"waveform": WaveformInput(wf, 16.0, (rng.integers(100, 200, n) * 16).astype(np.float32)), "baseline": bl}
+    out = build_dsp(tables, dsp_config=cfg, i_start=4, n_entries=30, buffer_len=7)
+    assert sorted(out) == ["dsp/ch1", "dsp/ch2"] and len(out["dsp/ch1"]["trapEmax"]) == 30 and len(out["dsp/ch2"]["trapEmax"]) == 20
+    for name, rows in (("raw/ch1", slice(4, 34)), ("raw/ch2", slice(4, 24))):
+        t = tables[name]
+        tb = {"waveform": WaveformInput(t["waveform"].values[rows], 16.0, t["waveform"].t0[rows]), "baseline": t["baseline"][rows]}
+        chain, _, direct = build_processing_chain(recipes.ICPC, tb)
+        chain.execute()
+        for k in recipes.ICPC["outputs"]:
+            assert np.array_equal(out[name.replace("raw", "dsp")][k], direct[k], equal_nan=True), (name, k)
