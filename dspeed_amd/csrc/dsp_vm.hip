@@ -17,6 +17,8 @@
 // float32 exactly where the reference stores into a float32 array.  Compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "dsp_program.h"
 #include "dsp_wave.h"
 
@@ -1500,9 +1502,9 @@ __device__ __forceinline__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
             T w[2][W], h[2][U];
             // (taps as scalar loads -- constant address space, SGPR operands -- were measured slower: v_pk_fma_f32 wants its
             // multiplier pair in VGPRs, so every tap was moved back; the 16-byte vector loads below hit one cache line per wave)
-            auto load_block = [&](int k0, T (&wb)[W], T (&hb)[U]) {
+            auto load_block_as = [&](auto lin, int k0, T (&wb)[W], T (&hb)[U]) {  // lin: the layout as a compile-time constant
                 const int i0 = ob + start - k0 - (U - 1);  // first sample of the window
-                if (linear) {
+                if (decltype(lin)::value) {
                     const auto* base = x0 + i0;
 #pragma unroll
                     for (int j = 0; j < W; ++j) wb[j] = base[j];
@@ -1522,7 +1524,15 @@ __device__ __forceinline__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
 #pragma unroll
                 for (int u = 0; u < U; ++u) hb[u] = kern[k0 + u];
             };
+            auto load_block = [&](int k0, T (&wb)[W], T (&hb)[U]) {
+                if (linear)
+                    load_block_as(std::true_type{}, k0, wb, hb);
+                else
+                    load_block_as(std::false_type{}, k0, wb, hb);
+            };
             auto fma_block = [&](const T (&wb)[W], const T (&hb)[U]) {
+                // (five independent sums of plain FMAs: packing outputs pairwise into v_pk_fma_f32 -- explicitly, also with even / odd
+                // taps in separate sums -- measured 18 % slower: the pair shuffles and the fewer chains cost more than the packing saves)
 #pragma unroll
                 for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -1531,7 +1541,34 @@ __device__ __forceinline__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
             const int nblk = (kB - kA) / U + 1;
             load_block(kA, w[0], h[0]);
             int k0 = kA;
-            for (int b = 0; b + 1 < nblk; b += 2) {
+            int b = 0;
+            // steady state: groups of four blocks (64 taps, one flush) as straight-line code -- every block's loads are issued one
+            // block ahead and nothing in the body branches, so the waits the compiler inserts can leave the newest loads in flight
+            // (with branches in the body it waits for everything, which defeats the prefetch).  Entered on a 64-tap boundary with at
+            // least five blocks left, so the prefetch of "the next block" is always a real block.
+            auto groups = [&](auto lin) {
+                for (; b + 5 <= nblk; b += 4) {
+                    load_block_as(lin, k0 + U, w[1], h[1]);
+                    fma_block(w[0], h[0]);
+                    load_block_as(lin, k0 + 2 * U, w[0], h[0]);
+                    fma_block(w[1], h[1]);
+                    load_block_as(lin, k0 + 3 * U, w[1], h[1]);
+                    fma_block(w[0], h[0]);
+                    load_block_as(lin, k0 + 4 * U, w[0], h[0]);
+                    fma_block(w[1], h[1]);
+                    flush();
+                    k0 += 4 * U;
+                }
+            };
+            if constexpr (sizeof(T) == 4) {  // (the float64 build is at its register limit without the second copy of the loop)
+                if ((k0 & 63) == 0) {
+                    if (linear)
+                        groups(std::true_type{});
+                    else
+                        groups(std::false_type{});
+                }
+            }
+            for (; b + 1 < nblk; b += 2) {
                 load_block(k0 + U, w[1], h[1]);
                 fma_block(w[0], h[0]);
                 if (((k0 + U) & 63) == 0) flush();
@@ -1540,7 +1577,7 @@ __device__ __forceinline__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
                 if (((k0 + 2 * U) & 63) == 0) flush();
                 k0 += 2 * U;
             }
-            if (nblk & 1) {
+            if (b < nblk) {
                 fma_block(w[0], h[0]);
                 if (((k0 + U) & 63) == 0) flush();
                 k0 += U;
