@@ -121,6 +121,7 @@ int elem_size(int dtype) {
         case DSP_F32: case DSP_I32: case DSP_U32: return 4;
         case DSP_F64: return 8;
         case DSP_I16: case DSP_U16: return 2;
+        case DSP_BOOL: return 1;
         default: return 0;
     }
 }
@@ -416,7 +417,7 @@ static int setup_trap(DevOp& d, int kind_opcode, int rise, int flat, int fall, i
 }
 
 // waveform slots an op reads or writes (for the lifetime analysis of the LDS packing)
-static int op_slots(const dsp_op& o, int out[3]) {
+static int op_slots(const dsp_op& o, int out[4]) {
     switch (o.opcode) {
         case DSP_OP_LOAD: out[0] = o.dst; return 1;
         case DSP_OP_STORE:
@@ -452,6 +453,14 @@ static int op_slots(const dsp_op& o, int out[3]) {
                 return 3;
             }
             return 2;
+        case DSP_OP_ELEMENTWISE: {
+            int n = 0;
+            out[n++] = o.dst;
+            if (o.src >= 0) out[n++] = o.src;
+            if (o.ip[1] >= 0) out[n++] = o.ip[1];
+            if (o.ip[2] >= 0) out[n++] = o.ip[2];
+            return n;
+        }
         default: return 0;  // scalar ops
     }
 }
@@ -483,14 +492,14 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         bool fir_in = false, only_plain = true;
         for (int i = 0; i < n_ops; ++i) {
             const dsp_op& o = ops[i];
-            int touched[3];
+            int touched[4];
             const int nt = op_slots(o, touched);
             bool uses = false;
             for (int k = 0; k < nt; ++k) uses |= touched[k] == s;
             if (!uses) continue;
             const bool conv = o.opcode == DSP_OP_CONVOLVE || o.opcode == DSP_OP_CONVOLVE_AMAX;
             const bool reads = o.opcode != DSP_OP_LOAD && o.src == s;
-            const bool writes = o.dst == s && (o.opcode == DSP_OP_LOAD || nt >= 2);  // (one-slot ops other than LOAD only read)
+            const bool writes = o.dst == s && (o.opcode == DSP_OP_LOAD || nt >= 2);  // (ELEMENTWISE: dst is touched[0], nt >= 2)  // (one-slot ops other than LOAD only read)
             if (conv && reads) fir_in = true;
             const bool plain = o.opcode == DSP_OP_LOAD || o.opcode == DSP_OP_STORE || o.opcode == DSP_OP_COPY ||
                                o.opcode == DSP_OP_BL_SUBTRACT || o.opcode == DSP_OP_MIN_MAX_NORM || (conv && reads && !writes);
@@ -508,7 +517,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         last_op[s] = -1;
     }
     for (int i = 0; i < n_ops; ++i) {
-        int touched[3];
+        int touched[4];
         const int nt = op_slots(ops[i], touched);
         for (int k = 0; k < nt; ++k) {
             const int s = touched[k];
@@ -614,8 +623,10 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         // which rows may feed which loop: NumPy's can_cast rule as ProcessorManager applies it (processing_chain.py:1565-1572)
         if (a.kind == DSP_IO_WF_IN && !f64 && (a.dtype == DSP_I32 || a.dtype == DSP_U32 || a.dtype == DSP_F64))
             return fail(DSP_ERR_ARG, "io %d: int32/uint32/float64 rows select the float64 loop (compute_dtype DSP_F64)", k);
-        if ((a.kind == DSP_IO_WF_OUT || a.kind == DSP_IO_SCALAR_OUT || a.kind == DSP_IO_TAPS) && a.dtype != compute_dtype)
-            return fail(DSP_ERR_ARG, "io %d: outputs and taps must have the chain's compute type", k);
+        const bool is_out = a.kind == DSP_IO_WF_OUT || a.kind == DSP_IO_SCALAR_OUT;
+        if ((is_out || a.kind == DSP_IO_TAPS) && a.dtype != compute_dtype && !(is_out && a.dtype == DSP_BOOL))
+            return fail(DSP_ERR_ARG, "io %d: outputs have the chain's compute type or DSP_BOOL, taps the compute type", k);
+        if (a.dtype == DSP_BOOL && !is_out) return fail(DSP_ERR_ARG, "io %d: DSP_BOOL is an output type", k);
         d.kind = a.kind;
         d.dtype = a.dtype;
         d.len = a.len;
@@ -746,6 +757,9 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             }
             case DSP_OP_PICKOFF:
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad PICKOFF", i);
+                if (o.ip[1] == 1 && (o.sp[0].kind != DSP_ARG_CONST || o.sp[0].value < 0 || o.sp[0].value >= slot_len[o.src] ||
+                                     o.sp[0].value != std::floor(o.sp[0].value)))
+                    return fail(DSP_ERR_ARG, "op %d: PICKOFF of one sample (ip[1] = 1) needs a constant index inside the waveform", i);
                 break;
             case DSP_OP_TIME_POINT_THRESH:
             case DSP_OP_INTERP_TIME_POINT_THRESH:
@@ -835,9 +849,25 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 break;
             }
             case DSP_OP_COPY:
-                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || o.src == o.dst || o.ip[0] < 0 ||
-                    o.ip[0] + slot_len[o.dst] > slot_len[o.src])
+                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || o.src == o.dst || o.ip[0] < 0 || o.ip[1] < 0 ||
+                    (int64_t)o.ip[0] + (int64_t)(slot_len[o.dst] - 1) * (o.ip[1] > 1 ? o.ip[1] : 1) >= slot_len[o.src])
                     return fail(DSP_ERR_ARG, "op %d: bad COPY", i);
+                break;
+            case DSP_OP_ELEMENTWISE: {
+                if (!check_slot(P, o.dst) || o.ip[0] < 0 || o.ip[0] > DSP_FN_LAST) return fail(DSP_ERR_ARG, "op %d: bad ELEMENTWISE", i);
+                const int opnd[3] = {o.src, o.ip[1], o.ip[2]};
+                int n_wf_opnd = 0;
+                for (int k = 0; k < 3; ++k) {
+                    if (opnd[k] < 0) continue;
+                    if (!check_slot(P, opnd[k]) || slot_len[opnd[k]] != slot_len[o.dst])
+                        return fail(DSP_ERR_ARG, "op %d: ELEMENTWISE operand %d is not a waveform of the length of the result", i, k);
+                    ++n_wf_opnd;
+                }
+                if (!n_wf_opnd) return fail(DSP_ERR_ARG, "op %d: ELEMENTWISE needs a waveform operand (DSP_OP_SCALAR_FUNC otherwise)", i);
+                break;
+            }
+            case DSP_OP_SCALAR_FUNC:
+                if (o.dst < 0 || o.dst >= n_sregs || o.ip[0] < 0 || o.ip[0] > DSP_FN_LAST) return fail(DSP_ERR_ARG, "op %d: bad SCALAR_FUNC", i);
                 break;
             case DSP_OP_CONVOLVE:
             case DSP_OP_CONVOLVE_AMAX: {

@@ -170,6 +170,11 @@ __device__ __forceinline__ void op_store(Ctx<T>& cx, const DSP_GLOBAL DevOp& op)
     DSP_GLOBAL T* g = cx.template io_ptr<T>(op.io) + cx.row * io.row_stride + io.offset;
     const int len = io.len;
     const bool nan = cx.slot_all_nan(op.src);  // (a slot with some NaN samples is stored as it is)
+    if (io.dtype == DSP_BOOL) {  // truth values: one byte each (NaN is true, like ndarray.astype(bool))
+        DSP_GLOBAL uint8_t* gb = cx.template io_ptr<uint8_t>(op.io) + cx.row * io.row_stride + io.offset;
+        for (int e = lane_id(); e < len; e += 64) gb[e] = (nan || cx.lds[padded_index(s, e)] != (T)0) ? 1 : 0;
+        return;
+    }
     constexpr int V = 16 / (int)sizeof(T);
     typedef T vec_t __attribute__((ext_vector_type(V)));
     if (io.vec_ok && ((cx.io_addr(op.io) & 15u) == 0)) {
@@ -192,7 +197,98 @@ __device__ __forceinline__ void op_store(Ctx<T>& cx, const DSP_GLOBAL DevOp& op)
 template <typename T>
 __device__ __forceinline__ void op_store_scalar(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevIO& io = cx.prog->io[op.io];
+    if (io.dtype == DSP_BOOL) {
+        if (lane_id() == 0) cx.template io_ptr<uint8_t>(op.io)[cx.row * io.row_stride + io.offset] = cx.sregs()[op.ip[0]] != (T)0 ? 1 : 0;
+        return;
+    }
     if (lane_id() == 0) cx.template io_ptr<T>(op.io)[cx.row * io.row_stride + io.offset] = cx.sregs()[op.ip[0]];
+}
+
+// ------------------------------------------------------------------------------------------------
+// NumPy ufuncs the recipe language adds as processors (processing_chain.py:832-947, 1266-1420): one IEEE operation per sample in the
+// loop type, truth values as 0 / 1
+// ------------------------------------------------------------------------------------------------
+template <int FN, typename T>
+__device__ __forceinline__ T ew_apply(T a, T b, T c) {
+    if constexpr (FN == DSP_FN_ADD) return a + b;
+    else if constexpr (FN == DSP_FN_SUB) return a - b;
+    else if constexpr (FN == DSP_FN_MUL) return a * b;
+    else if constexpr (FN == DSP_FN_DIV) return a / b;
+    else if constexpr (FN == DSP_FN_LT) return (T)(a < b);
+    else if constexpr (FN == DSP_FN_LE) return (T)(a <= b);
+    else if constexpr (FN == DSP_FN_GT) return (T)(a > b);
+    else if constexpr (FN == DSP_FN_GE) return (T)(a >= b);
+    else if constexpr (FN == DSP_FN_EQ) return (T)(a == b);
+    else if constexpr (FN == DSP_FN_NE) return (T)(a != b);
+    else if constexpr (FN == DSP_FN_WHERE) return a != (T)0 ? b : c;
+    else if constexpr (FN == DSP_FN_ISNAN) return (T)(a != a);
+    else if constexpr (FN == DSP_FN_ISFINITE) return (T)((a - a) == (T)0);
+    else if constexpr (FN == DSP_FN_NEG) return -a;
+    else return a;
+}
+
+template <typename T, typename F>
+__device__ __forceinline__ void ew_dispatch(int fn, F&& f) {
+    switch (fn) {
+        case DSP_FN_ADD: f(std::integral_constant<int, DSP_FN_ADD>()); break;
+        case DSP_FN_SUB: f(std::integral_constant<int, DSP_FN_SUB>()); break;
+        case DSP_FN_MUL: f(std::integral_constant<int, DSP_FN_MUL>()); break;
+        case DSP_FN_DIV: f(std::integral_constant<int, DSP_FN_DIV>()); break;
+        case DSP_FN_LT: f(std::integral_constant<int, DSP_FN_LT>()); break;
+        case DSP_FN_LE: f(std::integral_constant<int, DSP_FN_LE>()); break;
+        case DSP_FN_GT: f(std::integral_constant<int, DSP_FN_GT>()); break;
+        case DSP_FN_GE: f(std::integral_constant<int, DSP_FN_GE>()); break;
+        case DSP_FN_EQ: f(std::integral_constant<int, DSP_FN_EQ>()); break;
+        case DSP_FN_NE: f(std::integral_constant<int, DSP_FN_NE>()); break;
+        case DSP_FN_WHERE: f(std::integral_constant<int, DSP_FN_WHERE>()); break;
+        case DSP_FN_ISNAN: f(std::integral_constant<int, DSP_FN_ISNAN>()); break;
+        case DSP_FN_ISFINITE: f(std::integral_constant<int, DSP_FN_ISFINITE>()); break;
+        case DSP_FN_NEG: f(std::integral_constant<int, DSP_FN_NEG>()); break;
+        default: f(std::integral_constant<int, DSP_FN_COPY>()); break;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void op_elementwise(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+    const int sl[3] = {op.src, op.ip[1], op.ip[2]};
+    const typename Ctx<T>::LT* ps[3];
+    T k[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        // an all-NaN waveform (the NaN rule of a processor upstream) has no content: every sample reads NaN; a per-event operand is the
+        // same number for every sample
+        const bool slot = sl[j] >= 0;
+        k[j] = slot ? quiet_nan<T>() : cx.scalar(op.sp[j]);
+        ps[j] = (slot && !cx.slot_all_nan(sl[j])) ? cx.chunk(cx.prog->slots[sl[j]]) : nullptr;
+    }
+    auto* pd = cx.chunk(sd);
+    const int first = lane_id() * sd.C;
+    bool nan = false;
+    ew_dispatch<T>(op.ip[0], [&](auto fn) {
+#pragma unroll 4
+        for (int t = 0; t < sd.C; ++t) {
+            const T a = ps[0] ? ps[0][t] : k[0], b = ps[1] ? ps[1][t] : k[1], c = ps[2] ? ps[2][t] : k[2];
+            T v = ew_apply<decltype(fn)::value, T>(a, b, c);
+            if (first + t >= sd.len) v = (T)0;  // (beyond the waveform: kept finite)
+            nan |= (v != v);
+            pd[t] = v;
+        }
+    });
+    if (wave_any(nan))
+        cx.set_some_nan(op.dst);  // (sample by sample: NaN samples stay single samples)
+    else
+        cx.set_nan(op.dst, false);
+    wave_sync();
+}
+
+template <typename T>
+__device__ __forceinline__ void op_scalar_func(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+    const T a = cx.scalar(op.sp[0]), b = cx.scalar(op.sp[1]), c = cx.scalar(op.sp[2]);
+    T v = (T)0;
+    ew_dispatch<T>(op.ip[0], [&](auto fn) { v = ew_apply<decltype(fn)::value, T>(a, b, c); });
+    if (lane_id() == 0) cx.sregs()[op.dst] = v;
+    wave_sync();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -714,7 +810,9 @@ __device__ __forceinline__ void op_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& o
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const T t_in = cx.scalar(op.sp[0]);
     T out = quiet_nan<T>();
-    if (op.ip[0] == 's' && !cx.slot_nan(op.src) && pickoff_in_range(t_in, ss.len) && (T)(int)t_in != t_in) {
+    if (op.ip[1] == 1) {  // wf[i] in a recipe (processing_chain.py:986-990): a view of one sample, not the processor -- no NaN rule
+        if (!cx.slot_all_nan(op.src)) out = cx.lds[padded_index(ss, (int)t_in)];
+    } else if (op.ip[0] == 's' && !cx.slot_nan(op.src) && pickoff_in_range(t_in, ss.len) && (T)(int)t_in != t_in) {
         out = pickoff_spline(cx, ss, t_in);
     } else if (!cx.slot_nan(op.src) && pickoff_in_range(t_in, ss.len)) {
         const int i0 = (int)t_in;
@@ -1408,17 +1506,32 @@ template <typename T>
 __device__ __forceinline__ void op_copy(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
-    if (cx.slot_nan(op.src)) {
+    if (cx.slot_all_nan(op.src)) {
         cx.set_nan(op.dst, true);
         return;
     }
-    const int total = 64 * sd.C, lane = lane_id();
+    const int total = 64 * sd.C, lane = lane_id(), step = op.ip[1] > 1 ? op.ip[1] : 1;
+    if (!cx.slot_nan(op.src)) {
 #pragma unroll 8
-    for (int e = lane; e < total; e += 64) {  // (unrolled: the LDS reads of eight elements are in flight together)
-        const int se = e + op.ip[0];
-        cx.lds[padded_index(sd, e)] = (e < sd.len && se < ss.len) ? cx.lds[padded_index(ss, se)] : (T)0;
+        for (int e = lane; e < total; e += 64) {  // (unrolled: the LDS reads of eight elements are in flight together)
+            const int se = e * step + op.ip[0];
+            cx.lds[padded_index(sd, e)] = (e < sd.len && se < ss.len) ? cx.lds[padded_index(ss, se)] : (T)0;
+        }
+        cx.set_nan(op.dst, false);
+    } else {  // a slice is a view: of a waveform with NaN samples it holds the ones inside it (rare: one element at a time)
+        bool nan = false;
+#pragma unroll 1
+        for (int e = lane; e < total; e += 64) {
+            const int se = e * step + op.ip[0];
+            const T v = (e < sd.len && se < ss.len) ? cx.lds[padded_index(ss, se)] : (T)0;
+            nan |= (v != v);
+            cx.lds[padded_index(sd, e)] = v;
+        }
+        if (wave_any(nan))
+            cx.set_some_nan(op.dst);
+        else
+            cx.set_nan(op.dst, false);
     }
-    cx.set_nan(op.dst, false);
     wave_sync();
 }
 
@@ -1732,6 +1845,8 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 4) dsp_vm_kernel(const DevProgr
                     break;
                 case DSP_OP_SCALAR_AFFINE: op_scalar_affine(cx, op); break;
                 case DSP_OP_SCALAR_DIV: op_scalar_div(cx, op); break;
+                case DSP_OP_ELEMENTWISE: op_elementwise(cx, op); break;
+                case DSP_OP_SCALAR_FUNC: op_scalar_func(cx, op); break;
                 case DSP_OP_SCALAR_CONVERT: op_scalar_convert(cx, op); break;
                 case DSP_OP_INTERNAL_ZERO: op_zero_region(cx, op); break;
                 default: break;

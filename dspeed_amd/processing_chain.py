@@ -48,7 +48,12 @@ _UNITS_NS = {"ns": 1.0, "us": 1e3, "ms": 1e6, "s": 1e9}
 
 
 class Quantity(float):
-    """A time in nanoseconds (the only dimension hot-path recipes use)."""
+    """A time in nanoseconds (the only dimension hot-path recipes use); ``unit`` is the unit it was written in."""
+
+    def __new__(cls, value, unit="ns"):
+        q = float.__new__(cls, value)
+        q.unit = unit
+        return q
 
     def __repr__(self):
         return f"{float(self):g}*ns"
@@ -145,9 +150,10 @@ class SExpr:
     is_input = False
 
     def __init__(self, op, args, name, unit=None, is_coord=None, grid=None, mode=0):
-        self.op, self.args, self.name = op, tuple(args), name   # 'affine' (x, mul, add) | 'div' (a, b) | 'convert' (x, off_in, off_out, ratio)
+        self.op, self.args, self.name = op, tuple(args), name   # 'affine' (x, mul, add) | 'div' (a, b) | 'convert' (x, off_in, off_out, ratio) | 'func' (FN_*, a, b, c)
         self.unit, self.is_coord, self.grid, self.mode = unit, is_coord, grid, mode
         self.sreg = None
+        self.dtype = None  # np.bool_ for truth values ('func' results of comparisons, isnan, isfinite)
 
     def __repr__(self):
         return f"<SExpr {self.name}>"
@@ -168,11 +174,37 @@ _SIGS = {
     "mean_below_threshold": "wsS", "windower": "wsW", "avg_current": "wsW", "trap_pickoff": "wiisS",
     "upsampler": "wsW", "moving_window_multi": "wsiiW", "numpy_subtract": "wsW", "numpy_add": "wsW", "min_max_norm": "wssW", "linear_slope_fit": "wSSSS",
 }
+_SIGS.update({"sample": "wiS", "slice": "wiiW"})  # wf[i], wf[lo:hi:step] (reference :948-1071)
+
+
+def _roles(fn) -> str:
+    """argument roles of a step; the recipe language's element-wise steps carry theirs in the name: 'ew:' + one of w / s / c (unused) per
+    operand"""
+    if fn.startswith("ew:"):
+        return "c" + fn[3:] + "W"
+    return _SIGS.get(fn, "")
+
+
+def _is_wf(a) -> bool:
+    return (isinstance(a, Var) and a.kind == "wf") or (isinstance(a, tuple) and len(a) == 4 and a[0] == "slice")
+
+
+def _wf_len(a):
+    return a[3] - a[2] if isinstance(a, tuple) else a.length
+
+
+def _is_int_dtype(a) -> bool:
+    """does the variable select an integer ufunc loop in the reference (np.can_cast on its dtype, :1565-1572)"""
+    v = a[1] if isinstance(a, tuple) else a
+    dt = getattr(v, "dtype", None)
+    return dt is not None and np.dtype(dt).kind in "iub"
+
+
 _GENERATORS = ("cusp_filter", "zac_filter", "t0_filter", "moving_slope")
 _MODULES = ("dspeed.processors", "dspeed_amd.processors", "numpy", "np")
 _NUMPY_BINARY = {"add": ast.Add, "subtract": ast.Sub, "multiply": ast.Mult, "divide": ast.Div, "true_divide": ast.Div}
 _ROUND_MODES = {"round": 1, "floor": 2, "ceil": 3, "trunc": 4}
-_CALLS = ("round", "floor", "ceil", "trunc", "len", "float", "int")  # functions of the argument language (reference :729-751)
+_CALLS = ("round", "floor", "ceil", "trunc", "len", "float", "int", "where", "isnan", "isfinite", "astype")  # functions of the argument language (reference :729-751)
 
 
 _COPY_POOL = None  # host threads that move rows between NumPy columns and staging buffers
@@ -293,17 +325,18 @@ class ProcessingChain:
                 else:
                     self._pinned(a)
                 host_in[name] = a
+        odt = {name: np.dtype(getattr(var, "dtype", None) or self.loop_dtype) for name, (var, _l) in self._out_vars.items()}
         for name, (var, length) in self._out_vars.items():
             col = self._tb_out[var.name]
             if isinstance(col, DeviceArray):
                 dev_out[name] = col
             else:
-                direct = isinstance(col, np.ndarray) and col.flags.c_contiguous and col.dtype == self.loop_dtype
+                direct = isinstance(col, np.ndarray) and col.flags.c_contiguous and col.dtype == odt[name]
                 if direct:
                     self._pinned(col)
                 host_out[name] = (col, length, direct)
         row_bytes = sum(a.nbytes // max(len(a), 1) for a in host_in.values())
-        row_bytes += sum(self.loop_dtype.itemsize * (1 if length is None else length) for _, length, _ in host_out.values())
+        row_bytes += sum(odt[nm].itemsize * (1 if length is None else length) for nm, (_, length, _) in host_out.items())
         piece = n if row_bytes == 0 else int(max(1, min(n, self.pipeline_bytes // row_bytes)))
         n_slots = 2 if piece < n else 1
         # piece buffers live as long as the chain (the reference pre-allocates its ProcChainVar buffers the same way,
@@ -314,7 +347,7 @@ class ProcessingChain:
             self._piece_bufs = []
             for _ in range(n_slots):
                 sl = {name: DeviceArray((piece, *a.shape[1:]), a.dtype) for name, a in host_in.items()}
-                sl.update({name: DeviceArray((piece,) if length is None else (piece, length), self.loop_dtype)
+                sl.update({name: DeviceArray((piece,) if length is None else (piece, length), odt[name])
                            for name, (_, length, _) in host_out.items()})
                 self._piece_bufs.append(sl)
             self._piece_events = [Event() for _ in range(n_slots)]
@@ -328,7 +361,7 @@ class ProcessingChain:
             self._stage = []
             for _ in range(n_slots):
                 st = {name: PinnedArray((piece, *arr.shape[1:]), arr.dtype) for name, arr in host_in.items() if name not in in_place_in}
-                st.update({name: PinnedArray((piece,) if length is None else (piece, length), self.loop_dtype)
+                st.update({name: PinnedArray((piece,) if length is None else (piece, length), odt[name])
                            for name, (_c, length, _d) in host_out.items() if name not in in_place_out})
                 self._stage.append(st)
             self._stage_key = skey
@@ -518,6 +551,8 @@ class _Builder:
         self.vars: dict[str, Var] = {}
         self.steps = []  # (function name, [operands], recipe key)
         self.default_period = None
+        self.cur_key = None   # recipe entry being added (the expression steps it creates carry its name)
+        self._anon = 0        # counter behind the names of expression results
         self._conversions = {}  # (id(value), target grid key, rounding) -> SExpr: one conversion per variable and grid (reference :303-313)
         for name, col in self.tb_in.items():
             if isinstance(col, WaveformInput) and self.default_period is None:
@@ -596,7 +631,7 @@ class _Builder:
             return n.value
         if isinstance(n, ast.Name):
             if n.id in _UNITS_NS:
-                return Quantity(_UNITS_NS[n.id])
+                return Quantity(_UNITS_NS[n.id], n.id)
             if n.id in self.vars:
                 v = self.vars[n.id]
                 return v.const if isinstance(v, Var) and v.kind == "const" else v
@@ -611,9 +646,29 @@ class _Builder:
                 if isinstance(n.op, ast.UAdd):
                     return v
                 return SExpr("affine", (v, -1.0, -0.0), f"(-{v.name})", v.unit, v.is_coord, v.grid)
+            if _is_wf(v):
+                return v if isinstance(n.op, ast.UAdd) else self._elementwise(_lib.FN_NEG, [v], f"(-{self._nm(v)})", src, self._unit_of(v))
             if isinstance(v, (Var, tuple)):
-                raise NotImplementedError(f"expressions on waveforms are not supported on the device: '{src}'")
+                raise ProcessingChainError(f"cannot negate {v!r} in '{src}'")
             return -v if isinstance(n.op, ast.USub) else v
+        if isinstance(n, ast.Compare):  # reference :919-946: the NumPy comparison as a processor, a bool variable
+            if len(n.comparators) != 1:
+                raise ProcessingChainError("Compound comparisons are not supported.")
+            a, b2 = self._eval(n.left, src, new), self._eval(n.comparators[0], src, new)
+            fn, sym = {ast.Lt: (_lib.FN_LT, "<"), ast.LtE: (_lib.FN_LE, "<="), ast.Gt: (_lib.FN_GT, ">"), ast.GtE: (_lib.FN_GE, ">="),
+                       ast.Eq: (_lib.FN_EQ, "=="), ast.NotEq: (_lib.FN_NE, "!=")}.get(type(n.ops[0]), (None, None))
+            if fn is None:
+                raise ProcessingChainError(f"unsupported comparison in '{src}'")
+            if not any(_is_wf(x) or _is_scalar(x) for x in (a, b2)):
+                if any(isinstance(x, (Var, tuple, Grid)) for x in (a, b2)):
+                    raise ProcessingChainError(f"cannot compare {a!r} and {b2!r} in '{src}'")
+                return bool({"<": a < b2, "<=": a <= b2, ">": a > b2, ">=": a >= b2, "==": a == b2, "!=": a != b2}[sym])
+            name = f"({self._nm(a)}{sym}{self._nm(b2)})"
+            if _is_wf(a) or _is_wf(b2):
+                return self._elementwise(fn, [a, b2], name, src, None, np.bool_)
+            return self._scalar_func(fn, [a, b2], name, None, False, None, np.bool_)
+        if isinstance(n, ast.IfExp):  # a if condition else b  (reference :1073-1078)
+            return self._where(self._eval(n.test, src, new), self._eval(n.body, src, new), self._eval(n.orelse, src, new), src)
         if isinstance(n, ast.BinOp):
             a, b = self._eval(n.left, src, new), self._eval(n.right, src, new)
             return self._binop(n.op, a, b, src)
@@ -640,15 +695,47 @@ class _Builder:
             return self.offset_ns(grid)
         if isinstance(n, ast.Subscript):
             base = self._eval(n.value, src, new)
-            if not (isinstance(base, Var) and base.kind == "wf" and isinstance(n.slice, ast.Slice)):
-                raise NotImplementedError(f"only constant slices of waveforms are supported: '{src}'")
+            first = 0
+            if _is_wf(base) and isinstance(base, tuple):  # a slice of a (named) slice: the same view of the waveform underneath
+                first, length, base = base[2], base[3] - base[2], base[1]
+            elif isinstance(base, Var) and base.kind == "wf":
+                length = base.length
+            else:
+                raise ProcessingChainError(f"Cannot apply subscript to {self._nm(base)} in '{src}'")
+            if isinstance(n.slice, ast.Tuple):
+                raise ProcessingChainError("Tuple still isn't implemented...")
+            if not isinstance(n.slice, ast.Slice):  # wf[i]: one sample, a per-event value (reference :980-990; a variable index is not taken)
+                i = self._const_int(n.slice, src, new, 0, base)
+                i = i + length if i < 0 else i
+                if not 0 <= i < length:
+                    raise ProcessingChainError(f"index {i} is out of bounds for '{base.name}' with {length} samples in '{src}'")
+                self._anon += 1
+                out = Var(f"{base.name}[{first + i}]#{self._anon}", None, unit=base.unit, is_coord=False)
+                view = ("slice", base, first + i, first + i + 1) if base.is_input else base  # (of an input only that sample is read)
+                self._step("sample", [view, 0 if base.is_input else first + i, out], "wiS")
+                return out
+            step = self._const_int(n.slice.step, src, new, 1, None)
+            if step < 1:
+                raise NotImplementedError(f"slices with a negative step are not supported: '{src}'")
             lo = self._const_int(n.slice.lower, src, new, 0, base)
-            hi = self._const_int(n.slice.upper, src, new, base.length, base)
-            if n.slice.step is not None:
-                raise NotImplementedError(f"strided slices are not supported: '{src}'")
-            lo = lo + base.length if lo < 0 else lo
-            hi = hi + base.length if hi < 0 else min(hi, base.length)
-            return ("slice", base, lo, hi)
+            hi = self._const_int(n.slice.upper, src, new, length, base)
+            lo = max(lo + length, 0) if lo < 0 else min(lo, length)
+            hi = max(hi + length, 0) if hi < 0 else min(hi, length)
+            view = ("slice", base, first + lo, first + max(hi, lo))
+            if step == 1:
+                return view
+            count = len(range(lo, hi, step))
+            if count < 1:
+                raise ProcessingChainError(f"empty slice in '{src}'")
+            self._anon += 1
+            g = _grid_of(view)
+            out = Var(f"{base.name}[{first + lo}:{first + hi}:{step}]#{self._anon}", "wf", count, np.float32,
+                      grid=Grid(g.period * step, g.offset, g.offset_var) if g is not None else None, unit=base.unit, is_coord=False)
+            if base.is_input:  # only the span the slice covers is read from the input
+                self._step("slice", [("slice", base, first + lo, first + lo + (count - 1) * step + 1), 0, step, out], "wiiW")
+            else:
+                self._step("slice", [base, first + lo, step, out], "wiiW")
+            return out
         if isinstance(n, ast.Call) and isinstance(n.func, ast.Name):
             f = n.func.id
             if f in _CALLS:
@@ -662,6 +749,30 @@ class _Builder:
                     return v.length
                 if f in _ROUND_MODES:
                     return self._round(f, a, src)
+                if f == "where":  # where(condition, a, b, dtype=...)  (reference :1345-1430)
+                    if len(a) != 3:
+                        raise ProcessingChainError(f"where() takes a condition and two values in '{src}'")
+                    return self._where(a[0], a[1], a[2], src)
+                if f in ("isnan", "isfinite"):
+                    x = a[0]
+                    fn = _lib.FN_ISNAN if f == "isnan" else _lib.FN_ISFINITE
+                    if _is_wf(x):
+                        return self._elementwise(fn, [x], f"{f}({self._nm(x)})", src, self._unit_of(x), np.bool_)
+                    if _is_scalar(x):
+                        return self._scalar_func(fn, [x], f"{f}({x.name})", x.unit, x.is_coord, x.grid, np.bool_)
+                    return bool(getattr(np, f)(float(x)))
+                if f == "astype":  # a copy in another type (reference :1268-1300); the device loops are float32 / float64
+                    x, d = a[0], np.dtype(a[1][1] if isinstance(a[1], tuple) else a[1])
+                    if d.kind != "f" or d.itemsize < 4:
+                        raise NotImplementedError(f"astype to {d} is not available on the device path (float32 / float64 loops): '{src}'")
+                    if _is_wf(x):
+                        out = self._elementwise(_lib.FN_COPY, [x], f"{self._nm(x)}.astype(`{d.char}`)", src, self._unit_of(x))
+                    elif _is_scalar(x):
+                        out = self._scalar_func(_lib.FN_COPY, [x], f"{x.name}.astype(`{d.char}`)", x.unit, x.is_coord, x.grid, None)
+                    else:
+                        raise ProcessingChainError(f"cannot call astype() on {x!r}")
+                    out.want_dtype = d
+                    return out
                 return {"float": float, "int": int}[f](a[0])
             # declaration:  name(length, 'f', grid=..., unit=..., period=..., offset=...)  (reference :1101-1122, 334-374)
             if f in new or f not in self.vars or isinstance(self.vars.get(f), Var):
@@ -755,10 +866,12 @@ class _Builder:
 
     def _binop(self, op, a, b, src=""):
         sa, sb = _is_scalar(a), _is_scalar(b)
+        if _is_wf(a) or _is_wf(b):
+            return self._wf_binop(op, a, b, src)
         if sa or sb:
             return self._scalar_binop(op, a, b, src)
         if isinstance(a, (Var, tuple, Grid)) or isinstance(b, (Var, tuple, Grid)):
-            raise NotImplementedError(f"expressions on waveforms are not supported on the device: '{src}'")
+            raise ProcessingChainError(f"operands {a!r} and {b!r} of '{src}' are not numbers or variables")
         qa, qb = isinstance(a, Quantity), isinstance(b, Quantity)
         fa, fb = float(a), float(b)
         if isinstance(op, ast.Add):
@@ -782,10 +895,130 @@ class _Builder:
         else:
             raise ProcessingChainError("unsupported operator in argument expression")
         if q:
-            return Quantity(r)
+            return Quantity(r, getattr(a if qa else b, "unit", "ns"))
         if all(isinstance(x, int) and not isinstance(x, bool) for x in (a, b)) and not isinstance(op, ast.Div):
             return int(r)
         return r
+
+    # ---- the NumPy ufuncs the language adds as processors (reference :832-947, 1266-1430)
+    @staticmethod
+    def _nm(a):
+        if isinstance(a, tuple) and a and a[0] == "slice":
+            return f"{a[1].name}[{a[2]}:{a[3]}]"
+        return a.name if isinstance(a, (Var, SExpr)) else str(a)
+
+    @staticmethod
+    def _unit_of(a):
+        return (a[1] if isinstance(a, tuple) else a).unit
+
+    def _step(self, fn, args, roles):
+        _, args = _resolve(self, roles, args, same_dim_out=True)
+        self.steps.append((fn, args, self.cur_key))
+
+    def _elementwise(self, fn, opnds, name, src, unit=None, dtype=np.float32):
+        """f(A, B, C) sample by sample with at least one waveform among the operands: a new waveform variable and the step that fills it"""
+        ops3 = list(opnds) + [None] * (3 - len(opnds))
+        n = None
+        for a in ops3:
+            if _is_wf(a):
+                if _wf_len(a) is None:
+                    raise ProcessingChainError(f"'{src}': waveform '{self._nm(a)}' has no length yet")
+                if n is not None and _wf_len(a) != n:
+                    raise ProcessingChainError(f"failed to broadcast array dimensions in '{src}': waveforms of {n} and {_wf_len(a)} samples")
+                n = _wf_len(a)
+            elif isinstance(a, (Grid, tuple)) or (isinstance(a, Var) and a.kind not in ("scalar",)):
+                raise ProcessingChainError(f"'{src}': {a!r} is not a number, a per-event variable or a waveform")
+        grid = next((g for g in (_grid_of(a) for a in ops3 if _is_wf(a)) if g is not None), None)
+        self._anon += 1
+        out = Var(f"{name}#{self._anon}", "wf", n, dtype, grid=grid, unit=unit, is_coord=False)
+        roles = "".join("w" if _is_wf(a) else ("c" if a is None else "s") for a in ops3)
+        self._step("ew:" + roles, [int(fn), *ops3, out], "c" + roles + "W")
+        return out
+
+    def _scalar_func(self, fn, opnds, name, unit, is_coord, grid, dtype):
+        """the same between per-event values: one scalar op when something first reads the result"""
+        out = SExpr("func", (), name, unit, is_coord, grid)
+        out.dtype = np.dtype(dtype) if dtype is not None else None
+        _, res = _resolve(self, "s" * len(opnds) + "S", [*opnds, out], expression=True)
+        out.args = (int(fn), *res[:-1])
+        return out
+
+    def _wf_binop(self, op, a, b, src):
+        fn, sym = {ast.Add: (_lib.FN_ADD, "+"), ast.Sub: (_lib.FN_SUB, "-"), ast.Mult: (_lib.FN_MUL, "*"),
+                   ast.Div: (_lib.FN_DIV, "/")}.get(type(op), (None, None))
+        if fn is None:
+            raise NotImplementedError(f"operator in '{src}' is not available on waveforms on the device path")
+        variables = [x for x in (a, b) if _is_wf(x) or _is_scalar(x)]
+        if fn != _lib.FN_DIV and all(_is_int_dtype(x) for x in variables):
+            # every variable is an integer: the reference's first matching ufunc loop is an integer one (:1565-1572), with its wrap-around
+            raise NotImplementedError(f"'{src}' is integer arithmetic in the reference (all operands are integer columns); the device loops "
+                                      "are float32 / float64 -- make one operand a float (astype)")
+        va, vb = _is_wf(a) or _is_scalar(a), _is_wf(b) or _is_scalar(b)
+        ua, ub = (self._unit_of(a) if va else None), (self._unit_of(b) if vb else None)
+        if va and vb:  # reference :848-862
+            ta, tb = _time_unit_ns(ua), _time_unit_ns(ub)
+            if ta is not None and tb is not None:
+                unit = ua if sym in "+-" else None
+            elif ua is not None and ub is not None:
+                unit = f"{ua}{sym}{ub}" if sym in "*/" else ua
+            else:
+                unit = ua if ua is not None else ub
+        else:
+            unit = ua if va else ub
+        return self._elementwise(fn, [a, b], f"({self._nm(a)}{sym}{self._nm(b)})", src, unit)
+
+    def _where(self, cond, a, b, src):
+        """where(condition, a, b) / ``a if condition else b`` (reference :1345-1430)"""
+        if not (isinstance(cond, (Var, SExpr)) and getattr(cond, "dtype", None) == np.dtype(np.bool_)):
+            raise ProcessingChainError(f"{self._nm(cond)} must be a boolean variable")
+        is_var = lambda x: _is_wf(x) or _is_scalar(x)  # noqa: E731
+        grid_of = lambda x: _grid_of(x) if _is_wf(x) else x.grid  # noqa: E731
+        coord_of = lambda x: False if _is_wf(x) else x.is_coord  # noqa: E731
+        for x in (a, b):
+            if not is_var(x) and isinstance(x, (Var, tuple, Grid)):
+                raise ProcessingChainError(f"cannot select {x!r} in '{src}'")
+        name = f"where({self._nm(cond)}, {self._nm(a)}, {self._nm(b)})"
+        if is_var(a) and is_var(b):
+            ga, gb = grid_of(a), grid_of(b)
+            if ga is not None and gb is not None and ga.period != gb.period:  # (a value without a grid goes with any)
+                raise ProcessingChainError(f"Cannot select between {self._nm(a)} and {self._nm(b)} with different periods")
+            if coord_of(a) is not None and coord_of(b) is not None and coord_of(a) != coord_of(b):  # (None: still open, goes with either)
+                raise ProcessingChainError(f"Cannot select between {self._nm(a)} and {self._nm(b)} with different is_coord")
+            if ga is not None and gb is not None and ga != gb:
+                raise NotImplementedError(f"'{src}': the two values have different offsets; an offset chosen per event by the condition is "
+                                          "not supported on the device path")
+            grid, is_coord = (ga if ga is not None else gb), (coord_of(a) if coord_of(a) is not None else coord_of(b))
+            ua, ub = self._unit_of(a), self._unit_of(b)
+            same = ua == ub or (_time_unit_ns(ua) is not None and _time_unit_ns(ua) == _time_unit_ns(ub))
+            if same or not ub:
+                unit = ua
+            elif not ua:
+                unit = ub
+            else:
+                raise ProcessingChainError(f"{self._nm(a)} and {self._nm(b)} do not have compatible units")
+        elif is_var(a) or is_var(b):
+            var, const = (a, b) if is_var(a) else (b, a)
+            grid, is_coord, unit = grid_of(var), coord_of(var), self._unit_of(var)
+            if isinstance(const, Quantity):
+                tu = _time_unit_ns(unit)
+                if tu is None:
+                    raise ProcessingChainError(f"{self._nm(a)} and {self._nm(b)} do not have compatible units")
+                const = float(const) / (grid.period if (is_coord is True and grid is not None) else tu)
+            a, b = (var, const) if is_var(a) else (const, var)
+        else:
+            grid, is_coord = None, False
+            qa, qb = isinstance(a, Quantity), isinstance(b, Quantity)
+            unit = a.unit if qa else (b.unit if qb else None)
+            if unit is not None:
+                a, b = (float(a) / _UNITS_NS[unit] if qa else a), (float(b) / _UNITS_NS[unit] if qb else b)
+        both_bool = all(getattr(x, "dtype", None) == np.dtype(np.bool_) if is_var(x) else isinstance(x, bool) for x in (a, b))
+        dtype = np.bool_ if both_bool else np.float32
+        if any(_is_wf(x) for x in (cond, a, b)):
+            out = self._elementwise(_lib.FN_WHERE, [cond, a, b], name, src, unit, dtype)
+            if grid is not None:
+                out.grid = grid
+            return out
+        return self._scalar_func(_lib.FN_WHERE, [cond, a, b], name, unit, is_coord, grid, dtype if both_bool else None)
 
     def _scalar_binop(self, op, a, b, src, declared=None):
         """A binary operator with a per-event variable on at least one side: the reference adds the NumPy ufunc as a processor
@@ -998,11 +1231,16 @@ _SAME_DIM = ("bl_subtract", "numpy_subtract", "numpy_add", "min_max_norm", "pole
 
 def _add_step(b: _Builder, key, node, new_vars, proc_strings):
     module, function = node["module"], node["function"]
-    if module is None:  # inline expression: alias / constant (reference :2676-2696)
+    b.cur_key = key
+    if module is None:  # inline expression: alias / constant / the result of operators and functions of the language (reference :2676-2696)
         val = b.eval_arg(node["args"][0])
-        if isinstance(val, tuple):
-            raise NotImplementedError(f"'{key}': naming a slice is not supported on the device path")
-        if isinstance(val, (Var, SExpr)):
+        if isinstance(val, tuple) and not _is_wf(val):
+            raise ProcessingChainError(f"'{key}': {val!r} is not a value")
+        if isinstance(val, (Var, SExpr, tuple)):
+            if isinstance(val, (Var, SExpr)) and "#" in val.name and not getattr(val, "is_input", False):
+                val.name = new_vars[0]  # (an expression's result takes the name the recipe gives it)
+            if "unit" in node and isinstance(val, (Var, SExpr)) and val.unit is None and isinstance(node["unit"], str):
+                val.unit = node["unit"]
             b.vars[new_vars[0]] = val
         else:
             b.vars[new_vars[0]] = Var(new_vars[0], "const", const=val)
@@ -1094,7 +1332,7 @@ def _loop_dtype(b: _Builder):
     """float32 loop unless an input selects the float64 one (first castable signature wins, reference :1565-1572, 1654-1664):
     float64 / int32 / uint32 waveforms or float64 scalar columns cannot be cast to float32."""
     for v in b.vars.values():
-        if v.is_input and v.dtype is not None:
+        if isinstance(v, Var) and v.is_input and v.dtype is not None:
             if v.kind == "wf" and v.dtype in (np.dtype(np.float64), np.dtype(np.int32), np.dtype(np.uint32)):
                 return np.dtype(np.float64)
             if v.kind == "scalar" and v.dtype == np.dtype(np.float64):
@@ -1123,7 +1361,7 @@ def _schedule(steps):
     producer = {}
     ins, creates = [], []
     for j, (fn, args, _k) in enumerate(steps):
-        roles = _SIGS.get(fn, "")
+        roles = _roles(fn)
         mine, reads = [], []
         for a, r in zip(args, roles):
             (mine if r in "WS" else reads).extend(leaves(a, []))
@@ -1158,8 +1396,8 @@ def _schedule(steps):
                             todo.append(c)
                 return any(deps[c] - done - family for c in consumers[j])
             # (same oldest waveform: the one that could overwrite it in place waits until the others have read it)
-            j = min(ready, key=lambda j: (waits(j), age(j), steps[j][0] in ("bl_subtract", "numpy_subtract", "numpy_add", "min_max_norm", "pole_zero", "double_pole_zero"), j))
-        for a, r in zip(steps[j][1], _SIGS.get(steps[j][0], "")):
+            j = min(ready, key=lambda j: (waits(j), age(j), steps[j][0].startswith("ew:") or steps[j][0] in ("bl_subtract", "numpy_subtract", "numpy_add", "min_max_norm", "pole_zero", "double_pole_zero"), j))
+        for a, r in zip(steps[j][1], _roles(steps[j][0])):
             if r == "W" and isinstance(a, Var):
                 born[id(a)] = len(order)
         order.append(j)
@@ -1172,6 +1410,12 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
     ft = _loop_dtype(b)
     in_bind, out_bind, consts = {}, {}, {}
     steps = b.steps = _schedule(b.steps)
+    out_names = set(out_pars)  # names of the variables that are outputs (a variable may have another name than the output: alias, named slice)
+    for o in out_pars:
+        ov = b.vars.get(o)
+        ov = ov[1] if _is_wf(ov) and isinstance(ov, tuple) else ov
+        if isinstance(ov, Var):
+            out_names.add(ov.name)
 
     # --- uses: which step reads which variable last (slot reuse, in-place decisions, fusions)
     def wf_of(a):
@@ -1195,7 +1439,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
         return found, plain
 
     for si, (fn, args, key) in enumerate(steps):
-        if fn != "bl_subtract" or not isinstance(args[0], Var) or not isinstance(args[-1], Var) or args[-1].name in out_pars:
+        if fn != "bl_subtract" or not isinstance(args[0], Var) or not isinstance(args[-1], Var) or args[-1].name in out_names:
             continue
         src_v, dst_v = args[0], args[-1]
         found, plain = slices_of(dst_v)
@@ -1215,13 +1459,16 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
 
     last_use = {}
     for si, (fn, args, _) in enumerate(steps):
-        roles = _SIGS.get(fn, "")
+        roles = _roles(fn)
         for a, r in zip(args, roles):
             v = wf_of(a)
             if v is not None and r in "wts":
                 last_use[v.name] = si
-    for o in out_pars:
+    for o in out_pars:  # (a variable may be known by another name than the output's: an alias, a named slice)
         last_use[o] = len(steps) + 1
+        v = wf_of(b.vars.get(o)) if isinstance(b.vars.get(o), (Var, tuple)) else None
+        if v is not None:
+            last_use[v.name] = len(steps) + 1
 
     free_slots, slot_len = [], []
 
@@ -1269,8 +1516,8 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             v.slot = new_slot(v.length)
             p.add_op(_lib.OP_COPY, dst=v.slot, src=src.slot, ip=(lo,))
             b.vars[key] = v
-            last_use[key] = max(sj for sj, (_, a2, _k) in enumerate(steps)
-                                for x in a2 if isinstance(x, tuple) and x[0] == "slice" and x[1] is base and x[2] == lo and x[3] == hi)
+            last_use[key] = max((sj for sj, (_, a2, _k) in enumerate(steps)
+                                 for x in a2 if isinstance(x, tuple) and x[0] == "slice" and x[1] is base and x[2] == lo and x[3] == hi), default=si)
             return v
         v = a
         if v.kind != "wf":
@@ -1298,6 +1545,12 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
                     p.add_op(_lib.OP_SCALAR_AFFINE, dst=r, sp=tuple(opnd(x) for x in a.args))
                 elif a.op == "div":
                     p.add_op(_lib.OP_SCALAR_DIV, dst=r, sp=tuple(opnd(x) for x in a.args))
+                elif a.op == "func":
+                    code, *xs = a.args
+                    if code == _lib.FN_COPY and getattr(a, "want_dtype", None) not in (None, ft):
+                        raise NotImplementedError(f"{what}: astype to {a.want_dtype} in a chain whose loop type is {ft}")
+                    sp = [opnd(x) for x in xs] + [Scalar.const(0.0)] * (3 - len(xs))
+                    p.add_op(_lib.OP_SCALAR_FUNC, dst=r, ip=(code,), sp=tuple(sp))
                 elif a.op == "convert":
                     x, off_in, off_out, ratio = a.args
                     p.add_op(_lib.OP_SCALAR_CONVERT, dst=r, ip=(a.mode,), sp=(opnd(x), opnd(off_in), opnd(off_out), Scalar.const(ratio)))
@@ -1391,6 +1644,37 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
                 p.add_op(_lib.OP_DOUBLE_POLE_ZERO, dst=dst.slot, src=src.slot, sp=sp)
             if not inplace:
                 release(src, si)
+        elif fn.startswith("ew:"):
+            code, *opn, dst = args
+            if code == _lib.FN_COPY and getattr(dst, "want_dtype", None) not in (None, ft):
+                raise NotImplementedError(f"{what}: astype to {dst.want_dtype} in a chain whose loop type is {ft}")
+            slots, sps, srcs = [], [], []
+            for x, r in zip(opn, fn[3:]):
+                if r == "w":
+                    v = ensure_loaded(x, si)
+                    slots.append(v.slot)
+                    sps.append(Scalar.const(0.0))
+                    srcs.append(v)
+                else:
+                    slots.append(-1)
+                    sps.append(scalar_operand(x, args, what=what) if r == "s" else Scalar.const(0.0))
+            dead = next((v for v in srcs if last_use.get(v.name, -1) <= si), None)  # the result may take the place of an operand nobody reads again
+            dst.slot = dead.slot if dead is not None else new_slot(dst.length)
+            p.add_op(_lib.OP_ELEMENTWISE, dst=dst.slot, src=slots[0], ip=(code, slots[1], slots[2]), sp=tuple(sps))
+            for v in srcs:
+                if v is not dead and v.slot != dst.slot:
+                    release(v, si)
+        elif fn == "sample":
+            src = ensure_loaded(args[0], si)
+            o = out_scalar(args[2])
+            p.add_op(_lib.OP_PICKOFF, dst=o.sreg, src=src.slot, ip=(ord("n"), 1), sp=(Scalar.const(float(args[1])),))
+            release(src, si)
+        elif fn == "slice":
+            src = ensure_loaded(args[0], si)
+            dst = args[3]
+            dst.slot = new_slot(dst.length)
+            p.add_op(_lib.OP_COPY, dst=dst.slot, src=src.slot, ip=(int(args[1]), int(args[2])))
+            release(src, si)
         elif fn in trap_ops:
             src = ensure_loaded(args[0], si)
             ints = [scalar_operand(a, args, integer=True, what=what) for a in args[1:-1]]
@@ -1399,7 +1683,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             # fusion: the trapezoid's only consumer is the next fixed_time_pickoff and it is not an output
             nxt = steps[si + 1] if si + 1 < len(steps) else None
             if (nxt and nxt[0] == "fixed_time_pickoff" and wf_of(nxt[1][0]) is dst and last_use.get(dst.name) == si + 1
-                    and dst.name not in out_pars and char_of(nxt[1][2]) != ord("s")):
+                    and dst.name not in out_names and char_of(nxt[1][2]) != ord("s")):
                 t_in = scalar_operand(nxt[1][1], nxt[1], what=what)
                 o = out_scalar(nxt[1][3])
                 p.add_op(_lib.OP_TRAP_PICKOFF, dst=o.sreg, src=src.slot, io=char_of(nxt[1][2]), ip=(*ints, trap_ops[fn]), sp=(t_in,))
@@ -1412,7 +1696,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             users = [sj for sj, (f2, a2, _k) in enumerate(steps) if sj > si and sj not in skip and any(wf_of(x) is dst for x in a2)]
             kinds = [steps[sj][0] for sj in users]
             plain = all(steps[sj][1][0] is dst for sj in users)  # (not through a slice)
-            if (users and plain and dst.name not in out_pars and sorted(kinds) in (["min_max"], ["time_point_thresh"], ["min_max", "time_point_thresh"])
+            if (users and plain and dst.name not in out_names and sorted(kinds) in (["min_max"], ["time_point_thresh"], ["min_max", "time_point_thresh"])
                     and not any(isinstance(x, tuple) and x[0] == "slice" and x[1] is dst for _f, a2, _k in steps for x in a2)):
                 pending_reduce[dst.name] = {"src": src, "ints": ints, "kind": trap_ops[fn], "emit_at": max(users), "mm_first": -1}
                 last_use[src.name] = max(last_use.get(src.name, si), max(users))
@@ -1550,7 +1834,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             has_nan = int(np.isnan(taps.const).any()) | (2 if np.isinf(taps.const).any() else 0)  # (bit 1: an infinite tap)
             # fusion: the filtered waveform's only consumer is one numpy.amax and it is not an output -> it is never stored
             users = [sj for sj, (f2, a2, _k) in enumerate(steps) if sj != si and any(wf_of(x) is dst for x in a2)]
-            if (len(users) == 1 and steps[users[0]][0] == "amax" and steps[users[0]][1][0] is dst and dst.name not in out_pars
+            if (len(users) == 1 and steps[users[0]][0] == "amax" and steps[users[0]][1][0] is dst and dst.name not in out_names
                     and users[0] > si and users[0] not in skip):
                 o = out_scalar(steps[users[0]][1][2])
                 p.add_op(_lib.OP_CONVOLVE_AMAX, dst=o.sreg, src=src.slot, io=taps.io, ip=(char_of(args[2]), has_nan, int(dst.length)))
@@ -1567,6 +1851,8 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
     tb_out = {}
     for o in out_pars:
         v = b.vars.get(o)
+        if _is_wf(v) and isinstance(v, tuple):  # a named slice: of an input it is read straight from the rows, else copied out of its waveform
+            v = ensure_loaded(v, len(steps))
         if v is None or v.kind in (None,):
             raise ProcessingChainError(f"output '{o}' was never computed")
         if v.kind == "const":
@@ -1576,12 +1862,15 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             tb_out[o] = np.broadcast_to(v.const, (n_rows, v.length)).copy()
             continue
         if v.kind == "wf":
+            if v.slot is None and v.is_input:  # (an input under another name, or astype of nothing: load it to store it)
+                v = ensure_loaded(v, len(steps))
             if v.slot is None:
                 raise ProcessingChainError(f"output waveform '{o}' was never computed")
-            io = p.add_io(f"out:{o}", _lib.IO_WF_OUT, ft, v.length)
+            odt = np.dtype(np.bool_) if v.dtype == np.dtype(np.bool_) else ft
+            io = p.add_io(f"out:{o}", _lib.IO_WF_OUT, odt, v.length)
             p.add_op(_lib.OP_STORE, src=v.slot, io=io)
-            out_bind[f"out:{o}"] = (SimpleNamespace(name=o), v.length)
-            tb_out[o] = np.empty((n_rows, v.length), dtype=ft)
+            out_bind[f"out:{o}"] = (SimpleNamespace(name=o, dtype=odt), v.length)
+            tb_out[o] = np.empty((n_rows, v.length), dtype=odt)
         else:
             # a time coordinate is written in its unit, not in samples: (index + grid offset) * period (reference :1990-2014, get_buffer(unit))
             unit_ns = _time_unit_ns(v.unit)
@@ -1593,10 +1882,11 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
                     continue
                 raise ProcessingChainError(f"output '{o}' was never computed")
             reg = scalar_operand(v, [], what=f"output {o}")
-            io = p.add_io(f"out:{o}", _lib.IO_SCALAR_OUT, ft)
+            odt = np.dtype(np.bool_) if getattr(v, "dtype", None) == np.dtype(np.bool_) else ft
+            io = p.add_io(f"out:{o}", _lib.IO_SCALAR_OUT, odt)
             p.add_op(_lib.OP_STORE_SCALAR, io=io, ip=(reg.index,))
-            out_bind[f"out:{o}"] = (SimpleNamespace(name=o), None)
-            tb_out[o] = np.empty(n_rows, dtype=ft)
+            out_bind[f"out:{o}"] = (SimpleNamespace(name=o, dtype=odt), None)
+            tb_out[o] = np.empty(n_rows, dtype=odt)
     p.slots = slot_len
     if len(p.ops) > _lib.MAX_OPS or len(p.slots) > _lib.MAX_SLOTS or len(p.io) > _lib.MAX_IO or p.n_sregs > _lib.MAX_SREGS:
         raise NotImplementedError("recipe is too large for one device chain (ops/slots/bindings limit)")

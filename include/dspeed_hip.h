@@ -73,6 +73,7 @@ extern "C" {
 #define DSP_U16 3
 #define DSP_I32 4
 #define DSP_U32 5
+#define DSP_BOOL 6 /* one byte per element, 0 / 1: chain outputs only (results of comparisons, isnan, isfinite) */
 
 /* ---- device, memory, streams (thin, so a host needs nothing but this library) --------------------- */
 int dsp_device_count(int* count);
@@ -127,7 +128,7 @@ const char* dsp_version(void);
 
 typedef struct dsp_io_desc {
     int32_t kind;       /* DSP_IO_* */
-    int32_t dtype;      /* DSP_F32 ... ; outputs are always the chain's compute type */
+    int32_t dtype;      /* DSP_F32 ... ; outputs have the chain's compute type, or DSP_BOOL (nonzero -> 1) */
     int32_t len;        /* samples per row used by the chain (1 for scalars) */
     int32_t offset;     /* first sample within the row: a constant slice wf[offset:offset+len] costs nothing */
     int64_t row_stride; /* elements between consecutive rows (>= offset+len; 1 for scalars; 0 = same value for all rows) */
@@ -153,13 +154,13 @@ typedef struct dsp_scalar_arg {
 #define DSP_OP_TRAP_FILTER 7   /* trap_filters.py:12-76     ip[0..1] = rise, flat */
 #define DSP_OP_TRAP_NORM 8     /* trap_filters.py:79-149 */
 #define DSP_OP_ASYM_TRAP 9     /* trap_filters.py:152-227   ip[0..2] = rise, flat, fall */
-#define DSP_OP_PICKOFF 10      /* fixed_time_pickoff.py:12-125  sreg[dst] <- src at sp[0]; ip[0] = mode char */
+#define DSP_OP_PICKOFF 10      /* fixed_time_pickoff.py:12-125  sreg[dst] <- src at sp[0]; ip[0] = mode char; ip[1] = 1: the sample src[sp[0]] itself (wf[i] in a recipe) */
 #define DSP_OP_TIME_POINT_THRESH 11 /* time_point_thresh.py:12-92  sreg[dst] <- src; sp[0..2] = threshold, t_start, walk_forward */
 #define DSP_OP_MIN_MAX 12      /* min_max.py:11-82          sreg[dst..dst+3] <- t_min, t_max, a_min, a_max */
 #define DSP_OP_DWT_HAAR 13     /* dwt.py:13-81              dst <- src; ip[0] = level, ip[1] = 'a'|'d', ip[2] = scratch slot */
 #define DSP_OP_CONVOLVE 14     /* convolutions.py:14-72,75-119  dst <- src (*) io taps; ip[0] = mode char f|v|s, ip[1] = what the caller
                                   * found among the taps: bit 0 a NaN (output NaN), bit 1 an infinity */
-#define DSP_OP_COPY 15         /* dst[k] <- src[k + ip[0]]  (constant slice of an intermediate, processing_chain.py:1024-1071) */
+#define DSP_OP_COPY 15         /* dst[k] <- src[ip[0] + k * max(ip[1], 1)]  (constant slice of an intermediate, with a step: processing_chain.py:1024-1071) */
 #define DSP_OP_TRAP_PICKOFF 16 /* fusion of TRAP_FILTER|TRAP_NORM|ASYM_TRAP (ip[3] = which opcode) with PICKOFF: the trap output is
                                   never materialised; sreg[dst] <- trap(src) at sp[0]; ip[0..2] = rise, flat, fall; mode in `io` */
 #define DSP_OP_AMAX 17         /* numpy.amax along the sample axis (icpc-dsp-config.json:123-143): sreg[dst] <- max(src), NaN if any NaN */
@@ -190,6 +191,27 @@ typedef struct dsp_scalar_arg {
 #define DSP_OP_MIN_MAX_NORM 31   /* min_max.py:85-140 min_max_norm: dst <- src / max(|sp[0]|, |sp[1]|) (a_min, a_max); src unchanged if either
                                   * is 0; NaN if src has a NaN or a bound is NaN */
 #define DSP_OP_SCALAR_DIV 29     /* sreg[dst] <- sp[0] / sp[1]  (numpy.true_divide between per-event variables: QDrift / trapTmax) */
+#define DSP_OP_ELEMENTWISE 32    /* NumPy ufuncs the recipe language adds as processors (processing_chain.py:832-947 operators and comparisons,
+                                 * :1266-1420 astype / isnan / isfinite / where), sample by sample: dst[k] <- f(A[k], B[k], C[k]); ip[0] = DSP_FN_*;
+                                 * operand A = waveform slot src if src >= 0 else sp[0], B = slot ip[1] if >= 0 else sp[1], C = slot ip[2] if >= 0
+                                 * else sp[2] (at least one operand is a slot; all of the length of dst); truth values are 0 / 1 in the loop type */
+#define DSP_OP_SCALAR_FUNC 33    /* the same functions between per-event values: sreg[dst] <- f(sp[0], sp[1], sp[2]); ip[0] = DSP_FN_* */
+#define DSP_FN_ADD 0
+#define DSP_FN_SUB 1
+#define DSP_FN_MUL 2
+#define DSP_FN_DIV 3
+#define DSP_FN_LT 4
+#define DSP_FN_LE 5
+#define DSP_FN_GT 6
+#define DSP_FN_GE 7
+#define DSP_FN_EQ 8
+#define DSP_FN_NE 9
+#define DSP_FN_WHERE 10    /* A != 0 ? B : C */
+#define DSP_FN_ISNAN 11
+#define DSP_FN_ISFINITE 12
+#define DSP_FN_NEG 13
+#define DSP_FN_COPY 14     /* astype to the loop type */
+#define DSP_FN_LAST 14
 
 typedef struct dsp_op {
     int32_t opcode;

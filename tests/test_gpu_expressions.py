@@ -1,0 +1,223 @@
+"""The recipe language's operators and functions on waveforms and per-event values, on the device: arithmetic, comparisons, where /
+``a if c else b``, isnan / isfinite, astype, single samples, named and strided slices.  The reference adds the NumPy ufunc as a
+processor for each (processing_chain.py:832-1078, 1266-1430), so NumPy on the same arrays is the oracle; the cases restate the
+reference's own tests (tests/test_processing_chain.py:9-58 slicing, :162-187 comparators, :452-588 where, :590-608 isnan, :611-620
+astype) on synthetic rows."""
+import numpy as np
+import pytest
+
+from dspeed_amd import build_dsp, build_processing_chain
+from dspeed_amd.errors import ProcessingChainError
+from dspeed_amd.processing_chain import WaveformInput
+
+pytestmark = pytest.mark.gpu
+M = "dspeed.processors"
+
+
+def _table(n=48, wf_len=1000, dtype=np.uint16, t0=0.0, seed=3):
+    rng = np.random.default_rng(seed)
+    wf = 1000 + 40 * rng.standard_normal((n, wf_len))
+    wf[:, wf_len // 2:] += rng.uniform(100, 3000, size=(n, 1))
+    return {"waveform": WaveformInput(wf.astype(dtype), 16.0, t0), "baseline": rng.uniform(950, 1050, n).astype(np.float32),
+            "eventnumber": np.arange(n, dtype=np.int32)}
+
+
+def _run(processors, outputs, tb):
+    chain, _, out = build_processing_chain({"outputs": outputs, "processors": processors}, tb)
+    chain.execute()
+    return chain, out
+
+
+def test_waveform_slicing():
+    """reference test_waveform_slicing: wf[50], wf[50:100], wf[50:100:2] as outputs, of the input and of an intermediate"""
+    tb = _table()
+    wf = tb["waveform"].values
+    procs = {"wf_sample": {"function": "waveform[50]"}, "wf_slice": {"function": "waveform[50:100]"},
+             "wf_slice_stride": {"function": "waveform[50:100:2]"}, "wf_last": "waveform[-1]",
+             "wf_blsub": {"function": "bl_subtract", "module": M, "args": ["waveform", "baseline", "wf_blsub"], "unit": "ADC"},
+             "b_sample": "wf_blsub[7]", "b_last": "wf_blsub[-1]", "b_slice": "wf_blsub[10:20]", "b_stride": "wf_blsub[10:990:7]",
+             "b_of_slice": "b_slice[2:5]", "w_down": "waveform[::2]", "w_win2": "waveform[len(waveform)//2:]"}
+    outs = ["wf_sample", "wf_slice", "wf_slice_stride", "wf_last", "b_sample", "b_last", "b_slice", "b_stride", "b_of_slice", "w_down", "w_win2"]
+    chain, out = _run(procs, outs, tb)
+    bl = wf.astype(np.float32) - tb["baseline"][:, None]
+    assert np.array_equal(out["wf_sample"], wf[:, 50]) and out["wf_sample"].shape == (len(wf),)
+    assert np.array_equal(out["wf_last"], wf[:, -1])
+    assert np.array_equal(out["wf_slice"], wf[:, 50:100])
+    assert np.array_equal(out["wf_slice_stride"], wf[:, 50:100:2])
+    assert np.array_equal(out["w_down"], wf[:, ::2]) and np.array_equal(out["w_win2"], wf[:, 500:])
+    assert np.array_equal(out["b_sample"], bl[:, 7]) and np.array_equal(out["b_last"], bl[:, -1])
+    assert np.array_equal(out["b_slice"], bl[:, 10:20]) and np.array_equal(out["b_stride"], bl[:, 10:990:7])
+    assert np.array_equal(out["b_of_slice"], bl[:, 12:15])
+    # of the input only what the slices cover is read: no 1000-sample slot for wf[50] / wf[50:100]
+    chain2, _ = _run({"wf_sample": "waveform[50]", "wf_slice": "waveform[50:100]"}, ["wf_sample", "wf_slice"], tb)
+    assert sorted(chain2.program.slots) == [1, 50]
+
+
+def test_slices_of_a_waveform_with_nan_samples_are_views():
+    tb = _table(dtype=np.float32)
+    tb["waveform"].values[3, 60] = np.nan
+    wf = tb["waveform"].values
+    _, out = _run({"a": "waveform[50:100]", "b": "waveform[100:200:3]", "c": "waveform[60]", "d": "waveform[61]",
+                   "w2": "waveform + 0", "e": "w2[55:65]", "f": "w2[60]", "g": "w2[0:50]"}, ["a", "b", "c", "d", "e", "f", "g"], tb)
+    assert np.array_equal(out["a"], wf[:, 50:100], equal_nan=True) and np.isnan(out["a"][3, 10]) and np.isnan(out["a"]).sum() == 1
+    assert np.array_equal(out["b"], wf[:, 100:200:3]) and np.array_equal(out["c"], wf[:, 60], equal_nan=True)
+    assert np.array_equal(out["d"], wf[:, 61]) and np.array_equal(out["e"], wf[:, 55:65], equal_nan=True)
+    assert np.array_equal(out["f"], wf[:, 60], equal_nan=True) and np.array_equal(out["g"], wf[:, 0:50])
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32, np.int32])
+def test_waveform_arithmetic_is_the_numpy_ufunc_in_the_loop_type(dtype):
+    tb = _table(dtype=dtype)
+    ft = np.float64 if dtype == np.int32 else np.float32
+    wf, bl = tb["waveform"].values.astype(ft), tb["baseline"].astype(ft)
+    procs = {"wf_blsub": "waveform - baseline", "twice": "wf_blsub * 2", "half": "wf_blsub / 2", "third": "wf_blsub / 3",
+             "t_a, t_b, lo, hi": {"function": "min_max", "module": M, "args": ["wf_blsub", "t_a", "t_b", "lo", "hi"], "unit": ["ns", "ns", "ADC", "ADC"]},
+             "norm": "wf_blsub / hi", "sum": "wf_blsub + twice", "prod": "wf_blsub * third", "neg": "-wf_blsub", "rsub": "2.5 - wf_blsub",
+             "rdiv": "hi / wf_blsub", "chain": "(wf_blsub - lo) / (hi - lo) * 100 + 1", "win": "wf_blsub[100:200] - wf_blsub[300:400]",
+             "ratio": "waveform / baseline"}
+    outs = ["wf_blsub", "twice", "half", "third", "norm", "sum", "prod", "neg", "rsub", "rdiv", "chain", "win", "ratio"]
+    _, out = _run(procs, outs, tb)
+    b = wf - bl[:, None]
+    hi, lo = b.max(axis=1)[:, None], b.min(axis=1)[:, None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ref = {"wf_blsub": b, "twice": b * ft(2), "half": b / ft(2), "third": b / ft(3), "norm": b / hi, "sum": b + b * ft(2), "prod": b * (b / ft(3)),
+               "neg": -b, "rsub": ft(2.5) - b, "rdiv": hi / b, "chain": (b - lo) / (hi - lo) * ft(100) + ft(1), "win": b[:, 100:200] - b[:, 300:400],
+               "ratio": wf / bl[:, None]}
+    for k, r in ref.items():
+        assert out[k].dtype == ft and np.array_equal(out[k], r.astype(ft), equal_nan=True), k  # one IEEE operation per sample: bit-identical
+
+
+def test_integer_arithmetic_is_refused_by_name():
+    tb = _table()
+    for expr in ("waveform * 2", "waveform - eventnumber", "waveform + waveform"):
+        with pytest.raises(NotImplementedError, match="integer"):
+            build_processing_chain({"outputs": ["x"], "processors": {"x": expr}}, tb)
+    _, out = _run({"x": "waveform / 2", "y": "astype(waveform, 'float32') * 2"}, ["x", "y"], tb)  # true division and floats are float loops
+    assert np.array_equal(out["x"], tb["waveform"].values.astype(np.float32) / 2) and np.array_equal(out["y"], tb["waveform"].values.astype(np.float32) * 2)
+    with pytest.raises(ProcessingChainError, match="broadcast"):
+        build_processing_chain({"outputs": ["x"], "processors": {"x": "waveform[0:10] / waveform[0:20]"}}, tb)
+
+
+def test_comparators():
+    """reference test_comparators: bool outputs, one row of 0..9"""
+    w_in = np.arange(10, dtype=np.float32).reshape(1, 10)
+    procs = {"eq": "w_in == 5", "neq": "w_in != 5", "gt": "w_in > 5", "gte": "w_in >= 5", "lt": "w_in < 5", "lte": "w_in <= 5"}
+    out = build_dsp({"w_in": w_in}, dsp_config={"outputs": list(procs), "processors": procs}, n_entries=1)
+    assert set(out) == set(procs) and all(v.dtype == np.dtype("bool") and v.shape == (1, 10) for v in out.values())
+    w = w_in[0]
+    for k, r in {"eq": w == 5, "neq": w != 5, "gt": w > 5, "gte": w >= 5, "lt": w < 5, "lte": w <= 5}.items():
+        assert np.array_equal(out[k][0], r), k
+    # per-event values, waveform against waveform and against a per-event value, NaN compares false (!= true)
+    tb = _table(dtype=np.float32)
+    tb["waveform"].values[5, 7] = np.nan
+    wf = tb["waveform"].values
+    _, out = _run({"first": "eventnumber == 0", "big": "baseline > 1000", "above": "waveform > baseline", "rise": "waveform[1:] >= waveform[:-1]",
+                   "ne": "waveform != waveform"}, ["first", "big", "above", "rise", "ne"], tb)
+    assert out["first"].dtype == np.bool_ and np.array_equal(out["first"], tb["eventnumber"] == 0)
+    assert np.array_equal(out["big"], tb["baseline"] > 1000)
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(out["above"], wf > tb["baseline"][:, None]) and np.array_equal(out["rise"], wf[:, 1:] >= wf[:, :-1])
+        assert np.array_equal(out["ne"], wf != wf) and out["ne"].sum() == 1
+    with pytest.raises(ProcessingChainError, match="Compound"):
+        build_processing_chain({"outputs": ["x"], "processors": {"x": "0 < waveform < 5"}}, tb)
+
+
+def test_proc_chain_where():
+    """reference test_proc_chain_where: waveforms, coordinates against times, variable against variable, constants, a if b else c"""
+    tb = _table(n=2, dtype=np.float32)
+    tb["waveform"].values[:] -= 1010  # (both signs)
+    wf = tb["waveform"].values
+    mm = {"tp_min, tp_max, wf_min, wf_max": {"function": "min_max", "module": M, "args": ["waveform", "tp_min", "tp_max", "wf_min", "wf_max"],
+                                             "unit": ["ns", "ns", "ADC", "ADC"]}}
+    procs = dict(mm, test1="where(waveform<0, 0, waveform)", test2="where(waveform<0, waveform, 0)", test3="where(eventnumber==0, tp_min, 1*ns)",
+                 test4="where(eventnumber==0, tp_min, 1*us)", test5="where(eventnumber==0, 1*ns, tp_min)", test6="where(eventnumber==0, 1*us, tp_min)",
+                 test7="where(eventnumber==0, tp_min, wf_min)", test8="0 if waveform<0 else waveform")
+    _, out = _run(procs, ["tp_min", "tp_max", "wf_min", "wf_max", "test1", "test2", "test3", "test4", "test5", "test6", "test8"], tb)
+    assert np.array_equal(out["test1"], np.where(wf < 0, 0, wf)) and np.array_equal(out["test2"], np.where(wf < 0, wf, 0))
+    assert np.array_equal(out["test8"], np.where(wf < 0, 0, wf))
+    tp_min = out["tp_min"]
+    assert np.array_equal(tp_min, wf.argmin(axis=1) * 16.0)
+    assert out["test3"][0] == tp_min[0] and out["test3"][1] == 1 and out["test4"][0] == tp_min[0] and out["test4"][1] == 1000
+    assert out["test5"][0] == 1 and out["test5"][1] == tp_min[1] and out["test6"][0] == 1000 and out["test6"][1] == tp_min[1]
+    with pytest.raises(ProcessingChainError, match="is_coord"):
+        build_processing_chain({"processors": procs}, tb, outputs=["test7"])
+
+    procs = dict(mm, w_downsample="waveform[::2]", w_win1="waveform[:len(waveform)//2]", w_win2="waveform[len(waveform)//2:]",
+                 delta_t="tp_max - tp_min", test1="where(eventnumber==0, w_downsample, w_win1)", test2="where(eventnumber==0, w_win1, w_win2)",
+                 test3="where(eventnumber==0, tp_max, delta_t)", test4="where(eventnumber==0, tp_min, tp_max)",
+                 test5="where(eventnumber==0, w_win1, w_win1 * 2)")
+    with pytest.raises(ProcessingChainError, match="periods"):
+        build_processing_chain({"processors": procs}, tb, outputs=["test1"])
+    with pytest.raises(NotImplementedError, match="offsets"):  # (the reference selects the offset per event as well: not taken)
+        build_processing_chain({"processors": procs}, tb, outputs=["test2"])
+    with pytest.raises(ProcessingChainError, match="is_coord"):
+        build_processing_chain({"processors": procs}, tb, outputs=["test3"])
+    _, out = _run(procs, ["test4", "test5", "tp_min", "tp_max"], tb)
+    assert out["test4"][0] == out["tp_min"][0] and out["test4"][1] == out["tp_max"][1]
+    assert np.array_equal(out["test5"][0], wf[0, :500]) and np.array_equal(out["test5"][1], wf[1, :500] * 2)
+
+    procs = {"test1": "where(eventnumber==0, 10*ns, 1*us, dtype='f')", "test2": "where(eventnumber==0, 10*ns, 1000, dtype='f')",
+             "test3": "where(eventnumber==0, 1000, 10*ns, dtype='f')", "test4": "where(eventnumber==0, 10, 1000, dtype='f')",
+             "test6": "where(eventnumber==0, 1*us, 10*ns)"}
+    _, out = _run(procs, list(procs), tb)
+    for k, (a, b) in {"test1": (10, 1000), "test2": (10, 1000), "test3": (1000, 10), "test4": (10, 1000), "test6": (1, 0.01)}.items():
+        assert out[k][0] == np.float32(a) and out[k][1] == np.float32(b), k
+    with pytest.raises(ProcessingChainError, match="boolean"):
+        build_processing_chain({"outputs": ["x"], "processors": {"x": "where(eventnumber, 1, 2)"}}, tb)
+
+
+def test_where_on_a_coordinate_keeps_its_grid():
+    """the constant of where(c, tp, 1*us) counts periods of tp's grid and the result leaves in tp's unit, whatever the offset"""
+    tb = _table(n=4, dtype=np.float32, t0=480.0)
+    procs = {"tp_min, tp_max, wf_min, wf_max": {"function": "min_max", "module": M, "args": ["waveform[100:]", "tp_min", "tp_max", "wf_min", "wf_max"],
+                                                "unit": ["us", "us", "ADC", "ADC"]},
+             "t": "where(eventnumber>=2, tp_max, tp_min)", "a": {"function": "fixed_time_pickoff", "module": M, "args": ["waveform", "t", "'n'", "a"]}}
+    _, out = _run(procs, ["t", "a", "tp_min", "tp_max"], tb)
+    wf = tb["waveform"].values
+    i_min, i_max = wf[:, 100:].argmin(axis=1) + 100, wf[:, 100:].argmax(axis=1) + 100
+    pick = np.where(np.arange(4) >= 2, i_max, i_min)
+    assert np.allclose(out["t"], (pick * 16.0 + 480.0) / 1000.0, rtol=1e-6)  # (us, like its operands)
+    assert np.array_equal(out["a"], wf[np.arange(4), pick])
+
+
+def test_proc_chain_isnan_and_astype():
+    """reference test_proc_chain_isnan / test_proc_chain_as_type"""
+    col = np.array([1.0, 0.0, np.inf, -np.inf, np.nan], dtype=np.float32)
+    out = build_dsp({"input": col}, dsp_config={"outputs": ["test_nan", "test_finite"], "processors": {"test_nan": "isnan(input)", "test_finite": "isfinite(input)"}})
+    assert out["test_nan"].dtype == np.bool_ and np.array_equal(out["test_nan"], [False, False, False, False, True])
+    assert np.array_equal(out["test_finite"], [True, True, False, False, False])
+    tb = _table(dtype=np.int16)
+    _, out = _run({"waveform_32": "astype(waveform, 'float32')"}, ["waveform_32"], tb)
+    assert out["waveform_32"].dtype == np.float32 and np.array_equal(out["waveform_32"], tb["waveform"].values)
+    with pytest.raises(NotImplementedError, match="astype"):
+        build_processing_chain({"outputs": ["x"], "processors": {"x": "astype(waveform, 'int32')"}}, tb)
+    tb = _table(dtype=np.float32)
+    tb["waveform"].values[2, 3], tb["waveform"].values[4, 5] = np.nan, np.inf
+    wf = tb["waveform"].values
+    _, out = _run({"n": "isnan(waveform)", "f": "isfinite(waveform)", "clean": "where(isfinite(waveform), waveform, baseline)",
+                   "count": "astype(isnan(waveform), 'float32') * 1"}, ["n", "f", "clean", "count"], tb)
+    assert np.array_equal(out["n"], np.isnan(wf)) and np.array_equal(out["f"], np.isfinite(wf))
+    assert np.array_equal(out["clean"], np.where(np.isfinite(wf), wf, tb["baseline"][:, None]))
+    assert np.array_equal(out["count"], np.isnan(wf).astype(np.float32))
+
+
+def test_processors_downstream_of_an_expression():
+    """an expression's result is a waveform variable like any other: processors, fusions and the NaN rules apply to it"""
+    tb = _table(n=64, wf_len=2048, dtype=np.uint16)
+    tb["baseline"][5] = np.nan
+    procs = {"wf_blsub": "waveform - baseline",
+             "wf_pz": {"function": "pole_zero", "module": M, "args": ["wf_blsub", "400*us", "wf_pz"], "unit": "ADC"},
+             "wf_trap": {"function": "trap_filter", "module": M, "args": ["wf_pz", "4*us", "1*us", "wf_trap"], "unit": "ADC"},
+             "e": {"function": "fixed_time_pickoff", "module": M, "args": ["wf_trap", "1500", "'n'", "e"], "unit": "ADC"},
+             "e_cal": "e * 0.5 + 3", "clipped": "where(wf_trap > 1000, 1000, wf_trap)",
+             "cmax": {"function": "amax", "module": "numpy", "args": ["clipped", 1, "cmax"], "kwargs": {"signature": "(n),()->()", "types": ["fi->f"]}}}
+    ref = {"wf_blsub": {"function": "bl_subtract", "module": M, "args": ["waveform", "baseline", "wf_blsub"], "unit": "ADC"}}
+    ref.update({k: procs[k] for k in ("wf_pz", "wf_trap", "e")})
+    _, out = _run(procs, ["e", "e_cal", "cmax", "wf_trap"], tb)
+    _, out_ref = _run(ref, ["e", "wf_trap"], tb)
+    assert np.array_equal(out["e"], out_ref["e"], equal_nan=True) and np.isnan(out["e"][5]) and np.isnan(out["e"]).sum() == 1
+    assert np.array_equal(out["wf_trap"], out_ref["wf_trap"], equal_nan=True)
+    assert np.array_equal(out["e_cal"], out["e"] * np.float32(0.5) + np.float32(3), equal_nan=True)
+    with np.errstate(invalid="ignore"):
+        clipped = np.where(out_ref["wf_trap"] > 1000, np.float32(1000), out_ref["wf_trap"])
+    assert np.array_equal(out["cmax"], clipped.max(axis=1), equal_nan=True)

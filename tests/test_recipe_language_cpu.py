@@ -10,7 +10,7 @@ from dspeed_amd.errors import ProcessingChainError
 from dspeed_amd.processing_chain import Grid, Quantity, WaveformInput, _Builder, build_processing_chain
 
 M = "dspeed.processors"
-SCALAR_OPS = (_lib.OP_SCALAR_AFFINE, _lib.OP_SCALAR_DIV, _lib.OP_SCALAR_CONVERT, _lib.OP_STORE_SCALAR)
+SCALAR_OPS = (_lib.OP_SCALAR_AFFINE, _lib.OP_SCALAR_DIV, _lib.OP_SCALAR_CONVERT, _lib.OP_STORE_SCALAR, _lib.OP_SCALAR_FUNC)
 
 
 def _tb(n=4, wf_len=8192, t0=0.0, dtype=np.uint16):
@@ -31,6 +31,8 @@ def _slots(op):
         return (src,), ((dst, ip[2]) if ip[1] > 1 else (dst,))
     if opcode in SCALAR_OPS:
         return (), ()
+    if opcode == L.OP_ELEMENTWISE:
+        return tuple(x for x in (src, ip[1], ip[2]) if x >= 0), (dst,)
     return (src,), (dst,)
 
 
@@ -42,7 +44,7 @@ def _regs_written(op):
     if opcode == L.OP_TRAP_REDUCE:
         return ([] if dst < 0 else list(range(dst, dst + 4))) + ([] if io < 0 else [io])
     if opcode in (L.OP_PICKOFF, L.OP_TRAP_PICKOFF, L.OP_TIME_POINT_THRESH, L.OP_AMAX, L.OP_CONVOLVE_AMAX, L.OP_MEAN_BELOW,
-                  L.OP_TRAP_WINDOW_PICKOFF, L.OP_SCALAR_AFFINE, L.OP_SCALAR_DIV, L.OP_SCALAR_CONVERT):
+                  L.OP_TRAP_WINDOW_PICKOFF, L.OP_SCALAR_AFFINE, L.OP_SCALAR_DIV, L.OP_SCALAR_CONVERT, L.OP_SCALAR_FUNC):
         return [dst]
     return []
 
@@ -157,7 +159,7 @@ def test_argument_language_on_per_event_variables():
 
 
 def test_what_the_language_does_not_take_fails_by_name():
-    for expr, exc in (("waveform * 2", NotImplementedError), ("waveform[0:100:2]", NotImplementedError), ("t_b * (2*ns)", NotImplementedError),
+    for expr, exc in (("waveform * 2", NotImplementedError), ("waveform[0:100:-2]", NotImplementedError), ("waveform[0:100:2]", ProcessingChainError), ("t_b * (2*ns)", NotImplementedError),
                       ("baseline.grid", ProcessingChainError), ("t_b // 2", NotImplementedError)):
         rec = {"outputs": ["x"], "processors": {
             "t_a, t_b, lo, hi": {"function": "min_max", "module": M, "args": ["waveform", "t_a", "t_b", "lo", "hi"], "unit": ["ns", "ns", "ADC", "ADC"]},
@@ -201,3 +203,34 @@ def test_the_references_own_ge_recipes_translate_as_they_stand(rel):
     _check_program_order(P)
     if "icpc" in rel:
         assert len(out) == 34 and _peak_live_samples(P) <= 2 * 8192 + 1024
+
+
+def test_expressions_on_waveforms_translate_into_elementwise_ops():
+    """operators, comparisons, where, isnan, astype, samples and slices of the language (reference :832-1078, 1266-1430) -> device ops"""
+    tb = _tb(wf_len=1000, dtype=np.float32)
+    tb["eventnumber"] = np.arange(4, dtype=np.int32)
+    procs = {"wf_blsub": "waveform - baseline", "pos": "where(wf_blsub < 0, 0, wf_blsub)", "first": "eventnumber == 0",
+             "pick": "where(first, wf_blsub[10], wf_blsub[-1])", "down": "wf_blsub[::4]", "ok": "isfinite(pos)", "half": "wf_blsub[100:200] / 2"}
+    chain, mask, out = build_processing_chain({"outputs": ["pos", "pick", "down", "ok", "half", "first"], "processors": procs}, tb)
+    P = chain.program
+    _check_program_order(P)
+    ew = [o for o in P.ops if o[0] == _lib.OP_ELEMENTWISE]
+    assert sorted(o[4][0] for o in ew) == sorted([_lib.FN_SUB, _lib.FN_LT, _lib.FN_WHERE, _lib.FN_ISFINITE, _lib.FN_DIV])
+    sub = next(o for o in ew if o[4][0] == _lib.FN_SUB)
+    assert sub[4][1] == -1 and sub[5][1].kind == _lib.ARG_INPUT, "waveform - baseline: slot operand and a per-event column"
+    fn = [o for o in P.ops if o[0] == _lib.OP_SCALAR_FUNC]
+    assert sorted(o[4][0] for o in fn) == sorted([_lib.FN_EQ, _lib.FN_WHERE])
+    samples = [o for o in P.ops if o[0] == _lib.OP_PICKOFF and o[4][1] == 1]
+    assert sorted(o[5][0].value for o in samples) == [10.0, 999.0]
+    copies = [o for o in P.ops if o[0] == _lib.OP_COPY]
+    assert sorted((o[4][0], o[4][1] if len(o[4]) > 1 else 0) for o in copies) == [(0, 4), (100, 0)]
+    assert out["ok"].dtype == np.bool_ and out["first"].dtype == np.bool_ and out["pos"].dtype == np.float32
+    assert out["down"].shape == (4, 250) and out["half"].shape == (4, 100) and sorted(mask) == ["baseline", "eventnumber", "waveform"]
+    io = {name: code for name, _k, code, *_ in P.io}
+    assert io["out:ok"] == _lib.BOOL and io["out:first"] == _lib.BOOL and io["out:pos"] == _lib.F32
+    # grids (reference :1032-1054): a strided slice multiplies the period, a start shifts the offset; a comparison result has the operand's
+    b = _Builder(tb, {})
+    assert float(b.eval_arg("waveform[50:100:2].period")) == 32.0 and float(b.eval_arg("waveform[50:100:2].offset")) == 800.0
+    assert b.eval_arg("(waveform[50:100] * 2).grid") == Grid(16.0, 800.0) and b.eval_arg("len(waveform[50:100:2])") == 25
+    with pytest.raises(ProcessingChainError, match="out of bounds"):
+        b.eval_arg("waveform[1000]")
