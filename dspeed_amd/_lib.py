@@ -36,6 +36,13 @@ class ScalarArg(C.Structure):
     _fields_ = [("kind", C.c_int32), ("index", C.c_int32), ("value", C.c_double)]
 
 
+class FitWindow(C.Structure):  # dsp_fit_window
+    _fields_ = [("stage", C.c_int32), ("first", C.c_int32), ("count", C.c_int32)]
+
+
+FIT_MAX = 4
+
+
 class Op(C.Structure):
     _fields_ = [("opcode", C.c_int32), ("dst", C.c_int32), ("src", C.c_int32), ("io", C.c_int32), ("ip", C.c_int32 * 4),
                 ("sp", ScalarArg * 4)]
@@ -114,6 +121,8 @@ def lib():
         "dsp_convolve_wf_f32": [vp, C.c_int, i64, i32, i64, vp, i32, i32, vp, i32, i64, vp, pi64],
         "dsp_synth_waveforms": [vp, C.c_int, i64, i32, i64, vp, vp, C.c_uint64, i64, f32, f32, f32, f32, f32, f32, f32, vp],
         "dsp_stream_read": [vp, i64, vp, vp],
+        "dsp_linear_slope_fit_rows": [vp, C.c_int, i64, i32, i64, C.c_int, vp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double,
+                                      C.POINTER(FitWindow), C.c_int, vp, vp],
     }
     f64 = C.c_double
     for name in list(sig):  # the float64 loops: same argument order, double scalars
@@ -146,7 +155,7 @@ EXPORTS = [
     "dsp_moving_window_multi_f32", "dsp_moving_window_multi_f64", "dsp_linear_slope_fit_f32", "dsp_linear_slope_fit_f64", "dsp_dwt_haar_f32", "dsp_convolve_wf_f32", "dsp_synth_waveforms", "dsp_stream_read",
     "dsp_bl_subtract_f64", "dsp_pole_zero_f64", "dsp_double_pole_zero_f64", "dsp_trap_filter_f64", "dsp_trap_norm_f64",
     "dsp_asym_trap_filter_f64", "dsp_fixed_time_pickoff_f64", "dsp_time_point_thresh_f64", "dsp_min_max_f64", "dsp_dwt_haar_f64",
-    "dsp_convolve_wf_f64",
+    "dsp_convolve_wf_f64", "dsp_linear_slope_fit_rows",
 ]
 
 

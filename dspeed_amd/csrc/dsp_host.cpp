@@ -35,6 +35,7 @@ extern "C" int dsp_internal_launch_vm_f64(const DevProgram* dev_prog, const IoPt
 extern "C" int dsp_internal_set_vm_lds(int lds_bytes);
 extern "C" const char* dsp_internal_vm_kernel_name();
 extern "C" int dsp_internal_launch_stream_read(const void* src, int64_t bytes, uint32_t* sink, int blocks, hipStream_t stream);
+extern "C" int dsp_internal_launch_fit_rows(const FitArgs* A, int wf_dtype, int compute_dtype, hipStream_t stream);
 extern "C" int dsp_internal_launch_synth(void* wf, int out_dtype, int64_t n_wf, int wf_len, int64_t row_stride, float* baseline,
                                          float* t_pick, uint64_t seed, int64_t first_row, float tau, float sigma, float pick_offset,
                                          float bl_lo, float bl_hi, float amp_lo, float amp_hi, hipStream_t stream);
@@ -1644,6 +1645,55 @@ int dsp_synth_waveforms(void* wf, int out_dtype, int64_t n_wf, int32_t wf_len, i
     hipError_t e = (hipError_t)dsp_internal_launch_synth(wf, out_dtype, n_wf, wf_len, row_stride, baseline, t_pick, seed, first_row, tau,
                                                          sigma, pick_offset, bl_lo, bl_hi, amp_lo, amp_hi, (hipStream_t)stream);
     if (e != hipSuccess) return fail(DSP_ERR_HIP, "synth launch failed: %s", hipGetErrorString(e));
+    return DSP_OK;
+}
+
+int dsp_linear_slope_fit_rows(const void* wf, int wf_dtype, int64_t n_wf, int32_t wf_len, int64_t row_stride, int compute_dtype,
+                              const void* sub_dev, int sub_dtype, double sub_const, int sub_mode, int has_pz, double pz_tau,
+                              const dsp_fit_window* fits, int n_fits, void* out, void* stream) {
+    if (compute_dtype != DSP_F32 && compute_dtype != DSP_F64) return fail(DSP_ERR_ARG, "compute_dtype must be DSP_F32 or DSP_F64");
+    const bool f64 = compute_dtype == DSP_F64;
+    if (!elem_size(wf_dtype) || wf_dtype == DSP_BOOL) return fail(DSP_ERR_ARG, "fit rows: unknown waveform dtype %d", wf_dtype);
+    if (!f64 && (wf_dtype == DSP_I32 || wf_dtype == DSP_U32 || wf_dtype == DSP_F64))
+        return fail(DSP_ERR_ARG, "fit rows: int32/uint32/float64 rows select the float64 loop (compute_dtype DSP_F64)");
+    if (!fits || n_fits < 1 || n_fits > DSP_FIT_MAX) return fail(DSP_ERR_ARG, "fit rows: n_fits=%d out of range (1..%d)", n_fits, DSP_FIT_MAX);
+    if (sub_mode < 0 || sub_mode > 2) return fail(DSP_ERR_ARG, "fit rows: sub_mode must be 0, 1 (bl_subtract) or 2 (numpy.subtract)");
+    if (sub_mode && sub_dev && (!elem_size(sub_dtype) || sub_dtype == DSP_BOOL)) return fail(DSP_ERR_ARG, "fit rows: unknown dtype of the subtracted column");
+    if (n_wf < 0 || wf_len <= 0 || row_stride < wf_len || (n_wf > 0 && (!wf || !out))) return fail(DSP_ERR_ARG, "fit rows: bad rows / buffers");
+    FitArgs A;
+    memset(&A, 0, sizeof A);
+    A.wf = wf;
+    A.n_wf = n_wf;
+    A.row_stride = row_stride;
+    A.wf_len = wf_len;
+    A.sub = sub_mode ? sub_dev : nullptr;
+    A.sub_dtype = sub_dtype;
+    A.sub_mode = sub_mode;
+    A.sub_const = f64 ? sub_const : (double)(float)sub_const;
+    A.has_pz = has_pz ? 1 : 0;
+    if (has_pz) {  // the constant as the chain's POLE_ZERO op forms it: the loop's scalar type, then exp(-1 / tau) in float64 through libm
+        const double tau = f64 ? pz_tau : (double)(float)pz_tau;
+        A.pz_nan = std::isnan(tau) ? 1 : 0;
+        A.pz_c = std::exp(-1.0 / tau);
+    }
+    A.n_fits = n_fits;
+    int max_end = 0;
+    bool whole = sub_mode == 1;
+    for (int k = 0; k < n_fits; ++k) {
+        const dsp_fit_window& w = fits[k];
+        if (w.stage < 0 || w.stage > 1 || (w.stage == 1 && !has_pz)) return fail(DSP_ERR_ARG, "fit rows: window %d: stage 1 is the pole-zero corrected waveform (has_pz)", k);
+        if (w.first < 0 || w.count < 1 || (int64_t)w.first + w.count > wf_len) return fail(DSP_ERR_ARG, "fit rows: window %d is not inside the waveform", k);
+        A.stage[k] = w.stage;
+        A.first[k] = w.first;
+        A.count[k] = w.count;
+        if (w.first + w.count > max_end) max_end = w.first + w.count;
+        whole |= w.stage == 1;
+    }
+    A.n_scan = whole ? wf_len : max_end;  // (the NaN rules of bl_subtract and pole_zero look at the whole waveform)
+    A.out = out;
+    if (n_wf == 0) return DSP_OK;
+    hipError_t e = (hipError_t)dsp_internal_launch_fit_rows(&A, wf_dtype, compute_dtype, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DSP_ERR_HIP, "fit rows launch failed: %s", hipGetErrorString(e));
     return DSP_OK;
 }
 

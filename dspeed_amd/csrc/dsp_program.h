@@ -62,3 +62,19 @@ struct IoPtrs {
 
 // device error word layout: err[0] = DSP_E_* code (0 = none), err[1..2] = row (lo, hi)
 #define DSP_ERR_WORDS 20 /* 4 error words + 6 x 64-bit diagnostic phase-cycle sums */
+
+// arguments of the lane-per-waveform fit kernel (dsp_fit.hip), filled by dsp_linear_slope_fit_rows
+struct FitArgs {
+    const void* wf;
+    int64_t n_wf, row_stride;
+    int32_t wf_len, n_scan;  // samples per row; samples that have to be visited (the NaN rules of bl_subtract / pole_zero look at all)
+    const void* sub;         // per-row value subtracted first (device column) or null: sub_const
+    int32_t sub_dtype, sub_mode;  // 0 nothing, 1 bl_subtract (NaN anywhere -> NaN waveform), 2 numpy.subtract (sample by sample)
+    double sub_const;
+    int32_t has_pz, pz_nan;
+    double pz_c;
+    int32_t n_fits;
+    int32_t stage[DSP_FIT_MAX], first[DSP_FIT_MAX], count[DSP_FIT_MAX];
+    void* out;  // [n_fits][4][n_wf] of the compute type: mean, stdev, slope, intercept
+};
+

@@ -41,7 +41,7 @@ import numpy as np
 
 from . import _lib
 from .chain import Chain, Program, Scalar
-from .device import DeviceArray, Event, HostPin, PinnedArray, Stream
+from .device import DeviceArray, Event, HostPin, PinnedArray, Stream, dtype_code
 from .errors import DSPFatal, ProcessingChainError
 
 _UNITS_NS = {"ns": 1.0, "us": 1e3, "ms": 1e6, "s": 1e9}
@@ -215,12 +215,14 @@ class ProcessingChain:
     (processing_chain.py:665-673); ``__call__(tb_in, tb_out)`` relinks I/O like :675-716."""
 
     def __init__(self, program: Program, inputs: dict, outputs: dict, consts: dict, buffer_len: int, proc_strings: list[str],
-                 loop_dtype=np.float32):
+                 loop_dtype=np.float32, aux=()):
         self._program = program
         self.loop_dtype = np.dtype(loop_dtype)  # float32 or float64 gufunc loop of the whole chain
         self._in_vars = inputs      # binding name -> Var (source column)
         self._out_vars = outputs    # binding name -> (Var, length or None)
         self._consts = consts       # binding name -> ndarray (taps)
+        self._aux = list(aux)       # fits done on the rows ahead of the chain (dsp_linear_slope_fit_rows), results bound as inputs
+        self._aux_bufs = {}
         self._buffer_len = buffer_len
         self._chain = None
         self._stream = None
@@ -413,6 +415,7 @@ class ProcessingChain:
             staged = []
             for name in host_out:
                 bufs[name] = sl[name].view_rows(0, m)
+            self._run_aux(bufs, m, s_c)
             self._chain.execute(bufs, m, s_c)
             for name, (col, length, direct) in host_out.items():
                 d = bufs[name]
@@ -424,6 +427,27 @@ class ProcessingChain:
                 _lib.check(lib.dsp_d2h_async(dst.ctypes.data, d.ptr, d.nbytes, s_c.ptr), what="d2h_async")
             pending = (a, b, staged)
         finish(*pending)
+
+    def _run_aux(self, bufs: dict, m: int, stream) -> None:
+        """linear_slope_fit of the recipe that can run on the rows of the batch, one waveform per lane, ahead of the chain on its stream:
+        fills the columns the chain reads as inputs."""
+        lib = _lib.lib()
+        ft_code, isz = dtype_code(self.loop_dtype), self.loop_dtype.itemsize
+        for gi, g in enumerate(self._aux):
+            n_cols = len(g["names"])
+            out = self._aux_bufs.get(gi)
+            if out is None or out.shape[1] < m:
+                out = self._aux_bufs[gi] = DeviceArray((n_cols, m), self.loop_dtype)
+            wf = bufs[g["wf"]]
+            wf_ptr = (wf.ptr if isinstance(wf, DeviceArray) else int(wf)) + g["lo"] * g["itemsize"]
+            sub = bufs[g["sub"]] if g["sub"] is not None else None
+            sub_ptr = None if sub is None else (sub.ptr if isinstance(sub, DeviceArray) else int(sub))
+            fits = (_lib.FitWindow * len(g["fits"]))(*[_lib.FitWindow(*f) for f in g["fits"]])
+            _lib.check(lib.dsp_linear_slope_fit_rows(wf_ptr, g["dtype"], m, g["len"], g["stride"], ft_code, sub_ptr, g["sub_dtype"], g["sub_const"],
+                                                     g["mode"], int(g["tau"] is not None), float(g["tau"] or 0.0), fits, len(g["fits"]), out.ptr,
+                                                     stream.ptr), what="linear_slope_fit_rows")
+            for j, name in enumerate(g["names"]):
+                bufs[name] = out.ptr + j * m * isz
 
     def __call__(self, tb_in, tb_out, begin: int = 0, end: int | None = None):
         self.link(tb_in, tb_out)
@@ -1409,7 +1433,103 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
     p = Program()
     ft = _loop_dtype(b)
     in_bind, out_bind, consts = {}, {}, {}
-    steps = b.steps = _schedule(b.steps)
+    steps = b.steps
+    # --- linear_slope_fit on the rows of the batch (dsp_linear_slope_fit_rows: one waveform per lane) instead of inside the program,
+    # where its sequential float32 recurrences cost a third of a LEGEND recipe: a fit whose waveform is an input, the input minus a
+    # per-event input / constant (bl_subtract or numpy.subtract), or the pole_zero of that (constant tau), read whole or through a
+    # constant slice.  The kernel runs ahead of the chain on the same stream; the chain reads its results as per-event inputs.
+    aux = []  # one launch per (input waveform, subtraction, pole-zero) pipeline
+    if os.environ.get("DSPEED_HIP_FIT_IN_CHAIN", "0") != "1":
+        producer = {}
+        for fn, args, _k in steps:
+            for a, r in zip(args, _roles(fn)):
+                if r == "W" and isinstance(a, Var):
+                    producer[a.name] = (fn, args)
+
+        def plain_scalar(x):  # a constant or a per-event input column (known before the chain runs)
+            if isinstance(x, Var):
+                return x.kind == "scalar" and x.is_input and x.sreg is None
+            return isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, (bool, Quantity))
+
+        def pipeline_of(v):
+            """(input wf Var, first sample, length, sub operand, sub mode, tau) of waveform v, or None"""
+            tau = None
+            if not v.is_input and v.name in producer and producer[v.name][0] == "pole_zero":
+                _fn, a = producer[v.name]
+                if not isinstance(a[0], Var) or isinstance(a[1], (Var, SExpr, Quantity, tuple)):
+                    return None
+                tau, v = float(a[1]), a[0]
+            sub, mode = None, 0
+            src = v
+            if not v.is_input:
+                if v.name not in producer or producer[v.name][0] not in ("bl_subtract", "numpy_subtract"):
+                    return None
+                fn2, a = producer[v.name]
+                if not plain_scalar(a[1]):
+                    return None
+                sub, mode, src = a[1], (1 if fn2 == "bl_subtract" else 2), a[0]
+            lo, n = 0, None
+            if isinstance(src, tuple) and src[0] == "slice":
+                src, lo, n = src[1], src[2], src[3] - src[2]
+            if not (isinstance(src, Var) and src.is_input and src.kind == "wf" and src.offset == 0):
+                return None
+            return src, lo, (src.length if n is None else n), sub, mode, tau
+
+        kept = []
+        for fn, args, key in steps:
+            done = False
+            if fn == "linear_slope_fit" and all(isinstance(a, Var) for a in args[1:5]):
+                a0, first, count = args[0], 0, None
+                if isinstance(a0, tuple) and a0[0] == "slice":
+                    a0, first, count = a0[1], a0[2], a0[3] - a0[2]
+                pl = pipeline_of(a0) if isinstance(a0, Var) else None
+                if pl is not None:
+                    src, lo, n, sub, mode, tau = pl
+                    count = n - first if count is None else count
+                    if 0 <= first and first + count <= n and count >= 1:
+                        gkey = (src.name, lo, n, id(sub) if isinstance(sub, Var) else ("c", sub), mode)
+                        grp = next((g for g in aux if g["key"] == gkey and len(g["fits"]) < _lib.FIT_MAX
+                                    and (g["tau"] == tau or tau is None or g["tau"] is None)), None)
+                        if grp is None:
+                            grp = {"key": gkey, "src": src, "lo": lo, "len": n, "sub": sub, "mode": mode, "tau": tau, "fits": [], "outs": []}
+                            aux.append(grp)
+                        if tau is not None:
+                            grp["tau"] = tau
+                        grp["fits"].append((1 if tau is not None else 0, first, count))
+                        grp["outs"].append(list(args[1:5]))
+                        done = True
+            if not done:
+                kept.append((fn, args, key))
+        steps = kept
+        if aux:  # what only fed those fits is not computed any more
+            def leaves(a, acc):
+                if isinstance(a, SExpr):
+                    for x in a.args:
+                        leaves(x, acc)
+                elif isinstance(a, Var):
+                    acc.append(a)
+                elif isinstance(a, tuple) and a and a[0] == "slice":
+                    acc.append(a[1])
+                return acc
+
+            needed = {id(v) for o in out_pars for v in leaves(b.vars.get(o), [])}
+            live = []
+            for fn, args, key in reversed(steps):
+                roles = _roles(fn)
+                mine = [v for a, r in zip(args, roles) if r in "WS" for v in leaves(a, [])]
+                if any(id(v) in needed for v in mine):
+                    live.append((fn, args, key))
+                    for a, r in zip(args, roles):
+                        if r not in "WS":
+                            needed.update(id(v) for v in leaves(a, []))
+            steps = live[::-1]
+        for gi, g in enumerate(aux):  # the chain reads the results as per-event input columns
+            for k, outs in enumerate(g["outs"]):
+                for q, o in enumerate(outs):
+                    o.kind = "scalar"
+                    o.aux_io = p.add_io(f"aux:{gi}:{4 * k + q}", _lib.IO_SCALAR_IN, ft)
+
+    steps = b.steps = _schedule(steps)
     out_names = set(out_pars)  # names of the variables that are outputs (a variable may have another name than the output: alias, named slice)
     for o in out_pars:
         ov = b.vars.get(o)
@@ -1564,6 +1684,8 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             elif a.kind == "scalar":
                 if a.sreg is not None:
                     return Scalar.reg(a.sreg)
+                if getattr(a, "aux_io", None) is not None:  # a fit done ahead of the chain
+                    return Scalar.input(a.aux_io)
                 if a.is_input:
                     if a.io is None:
                         col = _column(b.tb_in, a.source)
@@ -1876,6 +1998,9 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             unit_ns = _time_unit_ns(v.unit)
             if v.is_coord is True and v.grid is not None and unit_ns is not None:
                 v = b.converted(v, Grid(unit_ns))
+            if isinstance(v, Var) and v.sreg is None and getattr(v, "aux_io", None) is not None:  # (stores read registers)
+                v.sreg = p.add_sregs(1)
+                p.add_op(_lib.OP_SCALAR_FUNC, dst=v.sreg, ip=(_lib.FN_COPY,), sp=(Scalar.input(v.aux_io), Scalar.const(0.0), Scalar.const(0.0)))
             if isinstance(v, Var) and v.sreg is None:
                 if v.is_input:
                     tb_out[o] = _column(b.tb_in, v.source)
@@ -1887,10 +2012,29 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             p.add_op(_lib.OP_STORE_SCALAR, io=io, ip=(reg.index,))
             out_bind[f"out:{o}"] = (SimpleNamespace(name=o, dtype=odt), None)
             tb_out[o] = np.empty(n_rows, dtype=odt)
+    aux_desc = []
+    for gi, g in enumerate(aux):
+        src = g["src"]
+        col = _column(b.tb_in, src.source)
+        wf_bind = next((nm for nm, v in in_bind.items() if isinstance(v, Var) and v.kind == "wf" and v.source == src.source and v.offset == 0
+                        and v.length == src.length), None)
+        if wf_bind is None:  # (nothing in the program reads the whole row: bind it for the fit alone)
+            wf_bind = f"in:{src.name}:fit{gi}"
+            p.add_io(wf_bind, _lib.IO_WF_IN, col.dtype, src.length, 0, col.shape[1])
+            in_bind[wf_bind] = src
+        sub_bind, sub_const, sub_code = None, 0.0, _lib.F32
+        if isinstance(g["sub"], Var):
+            sub_bind = p.io[scalar_operand(g["sub"], [], what="linear_slope_fit").index][0]
+            sub_code = dtype_code(_column(b.tb_in, g["sub"].source).dtype)
+        elif g["sub"] is not None:
+            sub_const = float(g["sub"])
+        aux_desc.append({"wf": wf_bind, "dtype": dtype_code(col.dtype), "itemsize": np.dtype(col.dtype).itemsize, "lo": g["lo"], "len": g["len"],
+                         "stride": col.shape[1], "sub": sub_bind, "sub_dtype": sub_code, "sub_const": sub_const, "mode": g["mode"],
+                         "tau": g["tau"], "fits": list(g["fits"]), "names": [f"aux:{gi}:{j}" for j in range(4 * len(g["fits"]))]})
     p.slots = slot_len
     if len(p.ops) > _lib.MAX_OPS or len(p.slots) > _lib.MAX_SLOTS or len(p.io) > _lib.MAX_IO or p.n_sregs > _lib.MAX_SREGS:
         raise NotImplementedError("recipe is too large for one device chain (ops/slots/bindings limit)")
-    chain = ProcessingChain(p, in_bind, out_bind, consts, n_rows, proc_strings, ft)
+    chain = ProcessingChain(p, in_bind, out_bind, consts, n_rows, proc_strings, ft, aux_desc)
     return chain, tb_out
 
 

@@ -255,6 +255,24 @@ const char* dsp_chain_kernel_name(dsp_chain* chain);
  * to the interpreter; DSPEED_HIP_VARIANT={1,0,2} picks the kernel variant (tuning). */
 int dsp_chain_set_fused(dsp_chain* chain, int enable);
 
+/* ---- linear_slope_fit over whole batches, one waveform per lane (linear_slope_fit.py:11-91) --------------------------------
+ * The fit's float32 Welford recurrences are sequential per waveform, so inside a chain (one wavefront per waveform) they cost a third
+ * of a LEGEND recipe's time; run over the rows of a batch with 64 waveforms per wavefront they cost nothing to speak of.  One pass
+ * does up to DSP_FIT_MAX fits on windows of the waveform as the recipes read it: after an optional per-row subtraction (sub_mode 1 =
+ * bl_subtract.py:11-46 with its NaN rule, 2 = numpy.subtract; sub_dev a device column of sub_dtype or NULL = sub_const) -- stage 0 --
+ * and after pole_zero (pole_zero.py:24-77, has_pz, constant pz_tau in samples) on that -- stage 1.  out: n_fits x 4 columns of n_wf
+ * values of the compute type (mean, stdev, slope, intercept of fit 0, then fit 1 ...).  dspeed_amd's recipe builder moves eligible
+ * fits of a recipe here and feeds the columns to the chain as per-event inputs. */
+#define DSP_FIT_MAX 4
+typedef struct dsp_fit_window {
+    int32_t stage; /* 0: the (subtracted) waveform, 1: its pole-zero correction */
+    int32_t first; /* window [first, first + count) in samples of the row as bound (wf .. wf + wf_len) */
+    int32_t count;
+} dsp_fit_window;
+int dsp_linear_slope_fit_rows(const void* wf, int wf_dtype, int64_t n_wf, int32_t wf_len, int64_t row_stride, int compute_dtype,
+                              const void* sub_dev, int sub_dtype, double sub_const, int sub_mode, int has_pz, double pz_tau,
+                              const dsp_fit_window* fits, int n_fits, void* out, void* stream);
+
 /* ---- single processors: the gufunc entry points -----------------------------------------------------
  * One call = one reference gufunc call on an (n_wf, wf_len) block: `in`/`out` device pointers, rows
  * `*_stride` elements apart.  Scalar gufunc arguments "()" come as (pointer, value): if the pointer is

@@ -92,8 +92,12 @@ def test_whole_ge_recipe_translates_into_one_program(t0):
     assert opcodes.count(_lib.OP_LOAD) == 1 and opcodes.count(_lib.OP_POLE_ZERO) == 1
     pz = P.ops[opcodes.index(_lib.OP_POLE_ZERO)]
     assert pz[1] == pz[2], "pole_zero runs in place"
-    fits = [o for o in P.ops if o[0] == _lib.OP_LINEAR_SLOPE_FIT]
-    assert sorted(o[4] for o in fits) == [(0, 700), (1600, 6592)]
+    # the two fits (baseline window of the subtracted waveform, tail of the pole-zero corrected one) run on the rows ahead of the chain,
+    # one waveform per lane, in one pass; the chain reads their results as per-event inputs
+    assert not [o for o in P.ops if o[0] == _lib.OP_LINEAR_SLOPE_FIT]
+    (fit,) = chain._aux
+    assert fit["fits"] == [(0, 0, 700), (1, 1600, 6592)] and fit["mode"] == 1 and fit["sub"] == "in:baseline" and fit["wf"] == "in:waveform"
+    assert fit["tau"] == 1716.25 and len(fit["names"]) == 8 and all(nm in [io[0] for io in P.io] for nm in fit["names"])
     # time coordinates leave in ns: one conversion per such output, period ratio 16; tp_aoe_max has no grid and leaves as it is
     conv = [o for o in P.ops if o[0] == _lib.OP_SCALAR_CONVERT and o[4][0] == 0 and o[5][3].value == 16.0]
     n_time_outputs = sum(1 for k in recipes.ICPC["outputs"] if k.startswith("tp_") and k != "tp_aoe_max")
@@ -112,7 +116,12 @@ def test_whole_ge_recipe_translates_into_one_program(t0):
     assert opcodes.count(_lib.OP_SCALAR_DIV) == 1  # QDrift / trapTmax
 
 
-def test_requesting_fewer_outputs_drops_what_they_do_not_need():
+def test_requesting_fewer_outputs_drops_what_they_do_not_need(monkeypatch):
+    chain, _, out = build_processing_chain(recipes.ICPC, _tb(), outputs=["bl_std"])
+    # the fit runs on the rows; nothing of the waveform is left for the program to do
+    assert [o[0] for o in chain.program.ops] == [_lib.OP_SCALAR_FUNC, _lib.OP_STORE_SCALAR] and chain.program.slots == []
+    assert chain._aux[0]["fits"] == [(0, 0, 700)] and chain._aux[0]["wf"] in [io[0] for io in chain.program.io]
+    monkeypatch.setenv("DSPEED_HIP_FIT_IN_CHAIN", "1")
     chain, _, out = build_processing_chain(recipes.ICPC, _tb(), outputs=["bl_std"])
     assert [o[0] for o in chain.program.ops] == [_lib.OP_LOAD, _lib.OP_BL_SUBTRACT, _lib.OP_LINEAR_SLOPE_FIT, _lib.OP_STORE_SCALAR]
     assert chain.program.slots == [700], "a constant slice of the input is loaded as such"
