@@ -876,8 +876,13 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 if (!check_slot(P, o.src) || !need_io(DSP_IO_TAPS)) return fail(DSP_ERR_ARG, "op %d: bad CONVOLVE", i);
                 if (fusedmax ? (o.dst < 0 || o.dst >= n_sregs || o.ip[2] <= 0) : (!check_slot(P, o.dst) || o.src == o.dst))
                     return fail(DSP_ERR_ARG, "op %d: bad CONVOLVE destination", i);
-                const int n = slot_len[o.src], m = io[o.io].len, p = fusedmax ? o.ip[2] : slot_len[o.dst], mode = o.ip[0];
+                // ip[3] > 0: the kernel has ip[3] taps and the binding holds zeros after them (up to a multiple of the tap block, so the
+                // blocked path covers every tap; the op falls back to the true length for a waveform with an infinity in it: 0 * inf)
+                if (o.ip[3] < 0 || o.ip[3] > io[o.io].len) return fail(DSP_ERR_ARG, "op %d: CONVOLVE kernel length beyond its binding", i);
+                const int m = o.ip[3] > 0 ? o.ip[3] : io[o.io].len;
+                const int n = slot_len[o.src], p = fusedmax ? o.ip[2] : slot_len[o.dst], mode = o.ip[0];
                 d.ic[1] = m;
+                d.ic[6] = io[o.io].len;
                 d.ic[2] = (o.ip[1] & 1) ? 1 : 0;  // caller found a NaN among the taps -> output NaN (convolutions.py:45-46)
                 d.ic[5] = (o.ip[1] & 2) ? 1 : 0;  // ... an infinity: 0 * inf is NaN, so windows must not reach into the zero margins
                 d.ic[3] = p;

@@ -1567,6 +1567,19 @@ __device__ __forceinline__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
     constexpr int W = R + U - 1;
     const DSP_GLOBAL T* __restrict__ kern = cx.template io_ptr<const T>(op.io);
     const int n = ss.len, m = op.ic[1], start = op.ic[0], p = op.ic[3], lane = lane_id();
+    // the binding may hold zeros after the m taps (to a multiple of the tap block): the blocked path then runs over them instead of leaving
+    // the last m % 16 taps to the tap-by-tap path -- unless the waveform holds an infinity, which a zero tap would turn into a NaN
+    int m_blk = m;
+    if (op.ic[6] > m) {
+        const auto* pc = cx.chunk(ss);
+        bool nonfinite = false;
+#pragma unroll 8
+        for (int t = 0; t < ss.C; ++t) {
+            const T v = pc[t];
+            nonfinite |= !((v - v) == (T)0);
+        }
+        if (!wave_any(nonfinite)) m_blk = op.ic[6];
+    }
     const bool linear = ss.padw == 0;  // the host lays FIR inputs out without chunk pads: a window is R + U - 1 consecutive elements
     const auto* x0 = cx.lds + ss.off;
     for (int o0 = 0; o0 < p; o0 += 64 * R) {
@@ -1605,7 +1618,7 @@ __device__ __forceinline__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
         int kA = uniform(wave_max(ob + (R - 1) + start - (n - 1))) - (op.ic[5] ? 0 : ss.zero_above);  // (SGPRs: tap addresses stay scalar)
         int kB = uniform(wave_min(ob + start - (U - 1))) + (op.ic[5] ? 0 : ss.zero_below);
         kA = kA < 0 ? 0 : ((kA + U - 1) / U) * U;
-        if (kB > m - U) kB = m - U;
+        if (kB > m_blk - U) kB = m_blk - U;
         if ((!linear && ss.C < 2 * U) || kB < kA) {
             slow_taps(0, m);
         } else {

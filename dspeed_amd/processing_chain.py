@@ -1947,9 +1947,10 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             taps = args[1]
             if not (isinstance(taps, Var) and taps.kind == "taps"):
                 raise NotImplementedError(f"{fn}: the kernel must be a constant computed in the recipe (cusp_filter / zac_filter)")
-            if taps.io is None:
-                taps.io = p.add_io(f"taps:{taps.name}", _lib.IO_TAPS, ft, taps.length, 0, 0)
-                consts[f"taps:{taps.name}"] = taps.const.astype(ft)
+            if taps.io is None:  # (zeros after the taps up to a multiple of the FIR op's tap block: its fast path then covers every tap)
+                padded = -(-taps.length // 16) * 16
+                taps.io = p.add_io(f"taps:{taps.name}", _lib.IO_TAPS, ft, padded, 0, 0)
+                consts[f"taps:{taps.name}"] = np.concatenate([taps.const.astype(ft), np.zeros(padded - taps.length, dtype=ft)])
             dst = out_wf(args[3], None, src)
             if dst.length is None:
                 raise ProcessingChainError(f"{fn}: declare the output as name(length, 'f')")
@@ -1959,13 +1960,13 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             if (len(users) == 1 and steps[users[0]][0] == "amax" and steps[users[0]][1][0] is dst and dst.name not in out_names
                     and users[0] > si and users[0] not in skip):
                 o = out_scalar(steps[users[0]][1][2])
-                p.add_op(_lib.OP_CONVOLVE_AMAX, dst=o.sreg, src=src.slot, io=taps.io, ip=(char_of(args[2]), has_nan, int(dst.length)))
+                p.add_op(_lib.OP_CONVOLVE_AMAX, dst=o.sreg, src=src.slot, io=taps.io, ip=(char_of(args[2]), has_nan, int(dst.length), int(taps.length)))
                 skip.add(users[0])
                 last_use[src.name] = max(last_use.get(src.name, si), si)
                 release(src, si)
                 continue
             dst.slot = new_slot(dst.length)
-            p.add_op(_lib.OP_CONVOLVE, dst=dst.slot, src=src.slot, io=taps.io, ip=(char_of(args[2]), has_nan))
+            p.add_op(_lib.OP_CONVOLVE, dst=dst.slot, src=src.slot, io=taps.io, ip=(char_of(args[2]), has_nan, 0, int(taps.length)))
             release(src, si)
         else:
             raise NotImplementedError(f"processor '{fn}' is not implemented on the device path")

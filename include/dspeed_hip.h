@@ -159,7 +159,9 @@ typedef struct dsp_scalar_arg {
 #define DSP_OP_MIN_MAX 12      /* min_max.py:11-82          sreg[dst..dst+3] <- t_min, t_max, a_min, a_max */
 #define DSP_OP_DWT_HAAR 13     /* dwt.py:13-81              dst <- src; ip[0] = level, ip[1] = 'a'|'d', ip[2] = scratch slot */
 #define DSP_OP_CONVOLVE 14     /* convolutions.py:14-72,75-119  dst <- src (*) io taps; ip[0] = mode char f|v|s, ip[1] = what the caller
-                                  * found among the taps: bit 0 a NaN (output NaN), bit 1 an infinity */
+                                  * found among the taps: bit 0 a NaN (output NaN), bit 1 an infinity; ip[3] > 0: the kernel has ip[3]
+                                  * taps and the binding (longer, ideally a multiple of 16) holds zeros after them -- lets the blocked tap
+                                  * loop cover every tap */
 #define DSP_OP_COPY 15         /* dst[k] <- src[ip[0] + k * max(ip[1], 1)]  (constant slice of an intermediate, with a step: processing_chain.py:1024-1071) */
 #define DSP_OP_TRAP_PICKOFF 16 /* fusion of TRAP_FILTER|TRAP_NORM|ASYM_TRAP (ip[3] = which opcode) with PICKOFF: the trap output is
                                   never materialised; sreg[dst] <- trap(src) at sp[0]; ip[0..2] = rise, flat, fall; mode in `io` */

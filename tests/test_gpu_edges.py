@@ -115,6 +115,22 @@ def test_fir_edges_same_and_full_modes(wf_len, m):
     want = oracle.convolve_wf(pz, kern, "s", wf_len)[0]
     scale = np.max(np.abs(want), axis=1, keepdims=True)
     assert np.max(np.abs(out["wf_f"] - want) / scale) <= 2e-6, "recipe, padded input"
+    # the recipe's tap binding holds zeros up to a multiple of 16 taps (the blocked loop then covers every tap): an infinite SAMPLE must
+    # not meet one of them (0 * inf) -- the op falls back to the true length for such a waveform
+    w_inf = w.copy()
+    w_inf[1, wf_len // 3], w_inf[2, 5] = np.inf, -np.inf
+    rec2 = {"outputs": ["wf_f"], "processors": {"kern": rec["processors"]["kern"], "wf_c": "waveform + 0",
+                                               "wf_f": {"function": "convolve_wf", "module": "dspeed.processors",
+                                                        "args": ["wf_c", "kern", "'s'", f"wf_f({wf_len}, 'f')"]}}}
+    chain, _, out = build_processing_chain(rec2, {"waveform": w_inf})
+    chain.execute()
+    want = oracle.convolve_wf(w_inf, kern, "s", wf_len)[0]
+    assert np.array_equal(np.isnan(out["wf_f"]), np.isnan(want)) and np.array_equal(np.isinf(out["wf_f"]), np.isinf(want))
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(out["wf_f"]), fin)
+    scale = np.max(np.abs(np.where(fin, want, 0)), axis=1, keepdims=True)
+    with np.errstate(invalid="ignore"):
+        assert np.max(np.abs(np.where(fin, out["wf_f"] - want, 0)) / scale) <= 2e-6, "recipe, infinite samples"
     # an infinite tap: no 0 * inf from the padding
     k2 = k.copy()
     k2[m // 2] = np.inf

@@ -195,6 +195,8 @@ def test_t0_filter_recipe_folds_to_taps():
         rec["processors"]["t0_kernel"]["args"] = [8, 125, "t0_kernel(133, 'f')"]
         chain, _, _ = build_processing_chain(rec, _tb())
     taps = chain._consts["taps:t0_kernel"]
-    assert taps.shape == (133,) and taps.dtype == np.float32
-    assert np.isclose(taps[0], 2 * 8 / (8 * 9)) and np.isclose(taps[-1], -1 / 125)
-    assert _lib.OP_CONVOLVE in _ops(chain)
+    # the binding holds zeros after the 133 taps up to a multiple of the FIR op's 16-tap block; the op carries the true length
+    assert taps.shape == (144,) and taps.dtype == np.float32 and not taps[133:].any()
+    assert np.isclose(taps[0], 2 * 8 / (8 * 9)) and np.isclose(taps[132], -1 / 125)
+    conv = next(o for o in chain.program.ops if o[0] == _lib.OP_CONVOLVE)
+    assert conv[4][3] == 133
