@@ -1615,8 +1615,10 @@ __device__ __forceinline__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
         // [ob + start - k0 - (U-1), ob + (R-1) + start - k0]: inside the waveform for every lane iff kA <= k0 <= kB
         // (the slot reads 0 for zero_below elements under sample 0 and zero_above over sample n - 1: exactly what the reference's
         // zero padding of the 'same' and 'full' modes supplies, so windows may reach that far)
-        int kA = uniform(wave_max(ob + (R - 1) + start - (n - 1))) - (op.ic[5] ? 0 : ss.zero_above);  // (SGPRs: tap addresses stay scalar)
-        int kB = uniform(wave_min(ob + start - (U - 1))) + (op.ic[5] ? 0 : ss.zero_below);
+        // (ob grows with the lane: its extremes sit in lanes 63 and 0 -- two readlanes instead of two wavefront reductions; SGPRs: tap
+        // addresses stay scalar)
+        int kA = __builtin_amdgcn_readlane(ob, 63) + (R - 1) + start - (n - 1) - (op.ic[5] ? 0 : ss.zero_above);
+        int kB = __builtin_amdgcn_readfirstlane(ob) + start - (U - 1) + (op.ic[5] ? 0 : ss.zero_below);
         kA = kA < 0 ? 0 : ((kA + U - 1) / U) * U;
         if (kB > m_blk - U) kB = m_blk - U;
         if ((!linear && ss.C < 2 * U) || kB < kA) {
