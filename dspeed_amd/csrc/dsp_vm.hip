@@ -1040,56 +1040,100 @@ __device__ __forceinline__ double div_by_length(double a, double d, double inv_d
     return __builtin_fma(__builtin_fma(-q, d, a), inv_d, q);
 }
 
-template <typename T>
-__device__ __forceinline__ void mw_pass(Ctx<T>& cx, const DSP_GLOBAL DevSlot& in, const DSP_GLOBAL DevSlot& out, int L, T length, bool right) {
+// One pass.  A lane walks its samples v = v0 + t, t = 0 .. C - 1, i.e. elements e = v (from the left) or n - 1 - v (from the right) of
+// the slots, and e -/+ L for the sample leaving the window: consecutive LDS elements with at most one chunk pad on the way, at the same
+// t for every lane (the lanes start C elements apart) -- so each stream is a base pointer plus t, and the loops are cut where a stream
+// steps over its pad instead of turning every index into an address (that arithmetic was a third of the op's instructions).
+template <typename T, bool RIGHT>
+__device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot& in, const DSP_GLOBAL DevSlot& out, int L, T length) {
+    typedef typename Ctx<T>::LT LT;
     const int n = in.len, C = in.C, lane = lane_id(), v0 = lane * C;
-    auto X = [&](int v) -> T { return cx.lds[padded_index(in, right ? n - 1 - v : v)]; };
-    const T x0 = X(0);
+    constexpr int D = RIGHT ? -1 : 1;
+    const T x0 = cx.lds[padded_index(in, RIGHT ? n - 1 : 0)];
     const T inv_len = (T)1 / length;
-    auto inc = [&](int v) -> T {  // what the reference adds to y[v-1]
-        if (v == 0) return x0;
-        const T b = v < L ? x0 : X(v - L);
-        return div_by_length((T)(X(v) - b), length, inv_len);
+    // stream of slot s starting at element e0 (this lane; may lie outside the slot: such elements are never read): base pointer, the t at
+    // which it enters the next chunk (C: never)
+    auto stream = [&](const DSP_GLOBAL DevSlot& s, int e0, LT*& base, int& brk) {
+        const int q = (e0 >= 0 ? e0 : e0 - (C - 1)) / C, r = e0 - q * C;  // floor division: r is the same for every lane
+        base = cx.lds + s.off + q * s.pitch + r;
+        brk = RIGHT ? r + 1 : (r == 0 ? C : C - r);
+    };
+    LT *p_in, *p_lag, *p_out;
+    int brk_io, brk_lag, brk_o;
+    const int e0 = RIGHT ? n - 1 - v0 : v0;
+    stream(in, e0, p_in, brk_io);
+    stream(in, RIGHT ? e0 + L : e0 - L, p_lag, brk_lag);
+    stream(out, e0, p_out, brk_o);  // (same length, same chunks: brk_o == brk_io)
+    brk_io = uniform(brk_io);
+    brk_lag = uniform(brk_lag);
+    const int pad_in = in.padw, pad_out = out.padw;
+    auto next_cut = [&](int t, bool with_lag) {
+        int nb = C;
+        if (brk_io > t && brk_io < nb) nb = brk_io;
+        if (with_lag && brk_lag > t && brk_lag < nb) nb = brk_lag;
+        return nb;
     };
     // pass A: the increments, parked in the output buffer, and their exact (float64) sum over this chunk -> speculative start
     double S = 0.0;
+    for (int t = 0; t < C;) {
+        const int nb = next_cut(t, true);
+        const LT* xi = p_in + D * (t >= brk_io ? pad_in : 0);
+        const LT* xl = p_lag + D * (t >= brk_lag ? pad_in : 0);
+        LT* yo = p_out + D * (t >= brk_io ? pad_out : 0);
 #pragma unroll 4
-    for (int t = 0; t < C; ++t) {
-        const int v = v0 + t;
-        if (v < n) {
-            const T d = inc(v);
-            cx.lds[padded_index(out, right ? n - 1 - v : v)] = d;
-            S += (double)d;
+        for (int u = t; u < nb; ++u) {
+            const int v = v0 + u;
+            if (v < n) {
+                T d = x0;  // (v == 0: what the reference starts from)
+                if (v > 0) {
+                    const T b = v < L ? x0 : xl[D * u];
+                    d = div_by_length((T)(xi[D * u] - b), length, inv_len);
+                }
+                yo[D * u] = d;
+                S += (double)d;
+            }
         }
+        t = nb;
     }
     const double E = wave_exscan_add(S);
     const T g = (lane == 0) ? (T)-0.0 : (T)E;
     // pass B: the reference recurrence from g over the parked increments (each lane reads back what it wrote)
     T y = g;
+    for (int t = 0; t < C;) {
+        const int nb = next_cut(t, false);
+        LT* yo = p_out + D * (t >= brk_io ? pad_out : 0);
 #pragma unroll 4
-    for (int t = 0; t < C; ++t) {
-        const int v = v0 + t;
-        if (v < n) {
-            const int a = padded_index(out, right ? n - 1 - v : v);
-            y = y + cx.lds[a];
-            cx.lds[a] = y;
-        }
-    }
-    // true starts: exact scan of the per-chunk increments (y before sample 0 is 0)
-    const double D = (double)y - (double)g;
-    const double delta = wave_exscan_add(D) - (double)g;
-    wave_sync();
-    if (delta != 0.0) {
-#pragma unroll 4
-        for (int t = 0; t < C; ++t) {
-            const int v = v0 + t;
-            if (v < n) {
-                const int a = padded_index(out, right ? n - 1 - v : v);
-                cx.lds[a] = (T)((double)cx.lds[a] + delta);
+        for (int u = t; u < nb; ++u) {
+            if (v0 + u < n) {
+                y = y + yo[D * u];
+                yo[D * u] = y;
             }
         }
+        t = nb;
+    }
+    // true starts: exact scan of the per-chunk increments (y before sample 0 is 0)
+    const double Dd = (double)y - (double)g;
+    const double delta = wave_exscan_add(Dd) - (double)g;
+    wave_sync();
+    if (delta != 0.0) {
+        for (int t = 0; t < C;) {
+            const int nb = next_cut(t, false);
+            LT* yo = p_out + D * (t >= brk_io ? pad_out : 0);
+#pragma unroll 4
+            for (int u = t; u < nb; ++u)
+                if (v0 + u < n) yo[D * u] = (T)((double)yo[D * u] + delta);
+            t = nb;
+        }
     }
     wave_sync();
+}
+
+template <typename T>
+__device__ __forceinline__ void mw_pass(Ctx<T>& cx, const DSP_GLOBAL DevSlot& in, const DSP_GLOBAL DevSlot& out, int L, T length, bool right) {
+    if (right)
+        mw_pass_dir<T, true>(cx, in, out, L, length);
+    else
+        mw_pass_dir<T, false>(cx, in, out, L, length);
 }
 
 template <typename T>
