@@ -593,18 +593,13 @@ __device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOB
             for (int u = t; u < nb; ++u) {
                 y = trap_step_r<T, KIND>(y, ps[u], l0[u], l1[u], l2[u], rr, ll, inv_rr, inv_ll);
                 if (STORE) pd[u] = y;
-                if (RED) {
+                if (RED) {  // (selects, no branches: strict comparisons keep the first occurrence)
                     const int idx = i_first + u;
-                    if (idx < n_valid) {
-                        if (y < vmin) {
-                            vmin = y;
-                            imin = idx;
-                        }
-                        if (y > vmax) {
-                            vmax = y;
-                            imax = idx;
-                        }
-                    }
+                    const bool lt = idx < n_valid && y < vmin, gt = idx < n_valid && y > vmax;
+                    vmin = lt ? y : vmin;
+                    imin = lt ? idx : imin;
+                    vmax = gt ? y : vmax;
+                    imax = gt ? idx : imax;
                 }
             }
             t = nb;
@@ -683,14 +678,12 @@ __device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOB
                             yy = trap_step_r<T, KIND>(yy, ps[u], l0[u], l1[u], l2[u], rr, ll, inv_rr, inv_ll);
                             const T cur = (T)((double)yy + delta);
                             const int idx = i_first + u;
-                            if (idx < n_valid) {
-                                if (forward) {  // smallest i = idx - 1 in [ts, n-2] with (w[i] <= thr < w[i+1]) or (w[i] >= thr > w[i+1])
-                                    const bool hit = ((prv <= thr && thr < cur) || (prv >= thr && thr > cur)) && idx - 1 >= ts && idx >= 1;
-                                    if (hit && best == 0x7fffffff) best = idx - 1;
-                                } else {        // largest i = idx in [1, ts] with (w[i-1] < thr <= w[i]) or (w[i-1] > thr >= w[i])
-                                    const bool hit = ((prv < thr && thr <= cur) || (prv > thr && thr >= cur)) && idx >= 1 && idx <= ts;
-                                    if (hit) best = idx;
-                                }
+                            if (forward) {  // smallest i = idx - 1 in [ts, n-2] with (w[i] <= thr < w[i+1]) or (w[i] >= thr > w[i+1])
+                                const bool hit = ((prv <= thr && thr < cur) || (prv >= thr && thr > cur)) && idx - 1 >= ts && idx >= 1 && idx < n_valid;
+                                best = (hit && best == 0x7fffffff) ? idx - 1 : best;
+                            } else {        // largest i = idx in [1, ts] with (w[i-1] < thr <= w[i]) or (w[i-1] > thr >= w[i])
+                                const bool hit = ((prv < thr && thr <= cur) || (prv > thr && thr >= cur)) && idx >= 1 && idx <= ts && idx < n_valid;
+                                best = hit ? idx : best;
                             }
                             prv = cur;
                         }
@@ -1406,16 +1399,11 @@ __device__ __forceinline__ void op_min_max(Ctx<T>& cx, const DSP_GLOBAL DevOp& o
         for (int t = 1; t < C; ++t) {
             const T v = ps[t];
             const int i = i0 + t;
-            if (i < n) {
-                if (v < vmin) {
-                    vmin = v;
-                    imin = i;
-                }
-                if (v > vmax) {
-                    vmax = v;
-                    imax = i;
-                }
-            }
+            const bool lt = i < n && v < vmin, gt = i < n && v > vmax;  // (selects, no branches: strict comparisons keep the first occurrence)
+            vmin = lt ? v : vmin;
+            imin = lt ? i : imin;
+            vmax = gt ? v : vmax;
+            imax = gt ? i : imax;
         }
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) {

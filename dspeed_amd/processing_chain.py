@@ -1818,7 +1818,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             users = [sj for sj, (f2, a2, _k) in enumerate(steps) if sj > si and sj not in skip and any(wf_of(x) is dst for x in a2)]
             kinds = [steps[sj][0] for sj in users]
             plain = all(steps[sj][1][0] is dst for sj in users)  # (not through a slice)
-            if (users and plain and dst.name not in out_names and sorted(kinds) in (["min_max"], ["time_point_thresh"], ["min_max", "time_point_thresh"])
+            if (users and plain and dst.name not in out_names and sorted(kinds) in (["min_max"], ["time_point_thresh"], ["min_max", "time_point_thresh"], ["amax"])
                     and not any(isinstance(x, tuple) and x[0] == "slice" and x[1] is dst for _f, a2, _k in steps for x in a2)):
                 pending_reduce[dst.name] = {"src": src, "ints": ints, "kind": trap_ops[fn], "emit_at": max(users), "mm_first": -1}
                 last_use[src.name] = max(last_use.get(src.name, si), max(users))
@@ -1826,9 +1826,14 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             dst.slot = new_slot(src.length)
             p.add_op(trap_ops[fn], dst=dst.slot, src=src.slot, ip=ints)
             release(src, si)
-        elif fn in ("min_max", "time_point_thresh") and isinstance(args[0], Var) and args[0].name in pending_reduce:
+        elif fn in ("min_max", "time_point_thresh", "amax") and isinstance(args[0], Var) and args[0].name in pending_reduce:
             pr = pending_reduce[args[0].name]
-            if fn == "min_max":
+            if fn == "amax":  # numpy.amax of a trapezoid (trapEmax): the a_max of the same reduction (NaN in, NaN out in both)
+                pr["mm_first"] = p.add_sregs(4)
+                if not isinstance(args[2], Var):
+                    raise ProcessingChainError("numpy.amax output must be a variable name")
+                args[2].kind, args[2].sreg = "scalar", pr["mm_first"] + 3
+            elif fn == "min_max":
                 pr["mm_first"] = p.add_sregs(4)
                 for k, a in enumerate(args[1:5]):
                     if not isinstance(a, Var):
