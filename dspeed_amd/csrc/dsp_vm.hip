@@ -309,11 +309,18 @@ __device__ __forceinline__ void op_bl_subtract(Ctx<T>& cx, const DSP_GLOBAL DevO
     const auto* ps = cx.chunk(ss);
     auto* pd = cx.chunk(sd);
     bool nan = false;
-#pragma unroll 8
-    for (int t = 0; t < ss.C; ++t) {
-        T v = ps[t] - b;
-        nan |= (v != v);
-        pd[t] = v;
+    // (eight loads, then eight stores: source and target may be the same slot, so the compiler orders every load behind the store before
+    // it and each sample would wait out a full LDS round trip; C is a multiple of 8)
+    for (int t0 = 0; t0 < ss.C; t0 += 8) {
+        T v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = ps[t0 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = v[k] - b;
+            nan |= (v[k] != v[k]);
+            pd[t0 + k] = v[k];
+        }
     }
     if (elementwise && wave_any(nan))
         cx.set_some_nan(op.dst);
@@ -379,14 +386,19 @@ __device__ __forceinline__ void op_pole_zero(Ctx<T>& cx, const DSP_GLOBAL DevOp&
     double acc = E - c * (E - xprev);
     double xp = xprev;
     bool nan = false;
-#pragma unroll 8
-    for (int t = 0; t < C; ++t) {
-        const double x = (double)ps[t];
-        acc = (acc + x) - xp * c;
-        const T y = (T)acc;
-        nan |= (y != y);
-        pd[t] = y;
-        xp = x;
+    for (int t0 = 0; t0 < C; t0 += 8) {  // (loads of a batch ahead of its stores, as in bl_subtract: the filter usually runs in place)
+        T xs[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xs[k] = ps[t0 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double x = (double)xs[k];
+            acc = (acc + x) - xp * c;
+            const T y = (T)acc;
+            nan |= (y != y);
+            pd[t0 + k] = y;
+            xp = x;
+        }
     }
     if (wave_any(nan)) {  // pole_zero.py:76-77: NaN out of non-NaN input (inf - inf)
         cx.fatal(DSP_E_PZ_NAN);
@@ -571,7 +583,7 @@ __device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOB
         cap_off[c] = ci >= 0 ? ci - cl * C : -1;
         capv[c] = (T)0;
     }
-    typename Ctx<T>::LT* pd = STORE ? cx.chunk(sd) : nullptr;
+    typename Ctx<T>::LT* __restrict__ pd = STORE ? cx.chunk(sd) : nullptr;  // (another slot than the ones the steps read: loads may pass stores)
     T y = g;
     const int n_valid = ss.len, i_first = lane * C;
     T vmin = __builtin_huge_val(), vmax = -__builtin_huge_val();
@@ -1072,7 +1084,7 @@ __device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot
         const int nb = next_cut(t, true);
         const LT* xi = p_in + D * (t >= brk_io ? pad_in : 0);
         const LT* xl = p_lag + D * (t >= brk_lag ? pad_in : 0);
-        LT* yo = p_out + D * (t >= brk_io ? pad_out : 0);
+        LT* __restrict__ yo = p_out + D * (t >= brk_io ? pad_out : 0);  // (another slot than the samples: loads may pass stores)
 #pragma unroll 4
         for (int u = t; u < nb; ++u) {
             const int v = v0 + u;
