@@ -982,18 +982,23 @@ __device__ __forceinline__ void op_upsampler(Ctx<T>& cx, const DSP_GLOBAL DevOp&
         // the ranges tile the output, so output j takes input (j + half) / cnt -- integer arithmetic instead of float64 per output
         const int ihalf = (int)half;
         const float inv = 1.0f / (float)cnt;
-#pragma unroll 4
-        for (int j = lane_id(); j < 64 * sd.C; j += 64) {
-            T v = (T)0;
-            if (j < m) {
-                const int x = j + ihalf;
+        // (four loads, then four stores: both go through the same LDS pointer, so a load is never moved ahead of the store before it and
+        // every element would wait out a full LDS round trip; 64 * C is a multiple of 256)
+        for (int j0 = lane_id(); j0 < 64 * sd.C; j0 += 256) {
+            T v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + 64 * k, x = j + ihalf;
                 int t = (int)((float)x * inv);  // x / cnt up to one either way; x < 2^23
-                if ((t + 1) * cnt <= x) ++t;
-                if (t * cnt > x) --t;
-                v = t < n ? (T)cx.lds[padded_index(ss, t)] : quiet_nan<T>();
-                nan |= (v != v);
+                t = (t + 1) * cnt <= x ? t + 1 : t;
+                t = t * cnt > x ? t - 1 : t;
+                const int tr = t < n ? t : n - 1;
+                const T w = cx.lds[padded_index(ss, tr)];
+                v[k] = j < m ? (t < n ? w : quiet_nan<T>()) : (T)0;
+                nan |= (v[k] != v[k]);
             }
-            cx.lds[padded_index(sd, j)] = v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cx.lds[padded_index(sd, j0 + 64 * k)] = v[k];
         }
         if (wave_any(nan))
             cx.set_some_nan(op.dst);
@@ -1556,10 +1561,19 @@ __device__ __forceinline__ void op_copy(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) 
     }
     const int total = 64 * sd.C, lane = lane_id(), step = op.ip[1] > 1 ? op.ip[1] : 1;
     if (!cx.slot_nan(op.src)) {
-#pragma unroll 8
-        for (int e = lane; e < total; e += 64) {  // (unrolled: the LDS reads of eight elements are in flight together)
-            const int se = e * step + op.ip[0];
-            cx.lds[padded_index(sd, e)] = (e < sd.len && se < ss.len) ? cx.lds[padded_index(ss, se)] : (T)0;
+        // (eight loads, then eight stores -- written out, because through the one LDS pointer the compiler keeps every load behind the
+        // store before it; total is a multiple of 512)
+        for (int e0 = lane; e0 < total; e0 += 512) {
+            T v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + 64 * k, se = e * step + op.ip[0];
+                const bool ok = e < sd.len && se < ss.len;
+                const T w = cx.lds[padded_index(ss, ok ? se : 0)];
+                v[k] = ok ? w : (T)0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cx.lds[padded_index(sd, e0 + 64 * k)] = v[k];
         }
         cx.set_nan(op.dst, false);
     } else {  // a slice is a view: of a waveform with NaN samples it holds the ones inside it (rare: one element at a time)
