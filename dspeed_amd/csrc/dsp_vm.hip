@@ -266,13 +266,23 @@ __device__ __forceinline__ void op_elementwise(Ctx<T>& cx, const DSP_GLOBAL DevO
     const int first = lane_id() * sd.C;
     bool nan = false;
     ew_dispatch<T>(op.ip[0], [&](auto fn) {
-#pragma unroll 4
-        for (int t = 0; t < sd.C; ++t) {
-            const T a = ps[0] ? ps[0][t] : k[0], b = ps[1] ? ps[1][t] : k[1], c = ps[2] ? ps[2][t] : k[2];
-            T v = ew_apply<decltype(fn)::value, T>(a, b, c);
-            if (first + t >= sd.len) v = (T)0;  // (beyond the waveform: kept finite)
-            nan |= (v != v);
-            pd[t] = v;
+        // (the loads of four samples ahead of their four stores: the result may take the place of an operand, so the compiler keeps every
+        // load behind the store before it; C is a multiple of 4)
+        for (int t0 = 0; t0 < sd.C; t0 += 4) {
+            T a[4], b[4], c[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = ps[0] ? ps[0][t0 + j] : k[0];
+                b[j] = ps[1] ? ps[1][t0 + j] : k[1];
+                c[j] = ps[2] ? ps[2][t0 + j] : k[2];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                T v = ew_apply<decltype(fn)::value, T>(a[j], b[j], c[j]);
+                if (first + t0 + j >= sd.len) v = (T)0;  // (beyond the waveform: kept finite)
+                nan |= (v != v);
+                pd[t0 + j] = v;
+            }
         }
     });
     if (wave_any(nan))
