@@ -19,12 +19,26 @@ ProcessingChain runs them: 16-row blocks, one processor call per block) on a bou
 
 Multi-process rendezvous uses torch.distributed with the gloo backend only for the barrier and the
 max-over-ranks of the timing: the path has no exchange step, so no RCCL traffic exists to measure.
+
+Launching.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` every process is one rank
+(RANK / LOCAL_RANK / WORLD_SIZE from the environment).  Started plainly as `python bench.py --gpus N` with N > 1 the
+process becomes a launcher: BEFORE any HIP call (the library is not even loaded) it starts N fresh child processes of
+this script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relays rank 0's JSON line and exits
+non-zero if any child does.  A process that has touched the GPU is never re-executed.  `--dry-run` makes the workers
+skip the device (rendezvous, barrier and the line's bookkeeping only): the CPU tests drive the launcher with it.
+
+The bench refuses to print a number when the result of the timed launches deviates from the oracle by more than the
+parity bar (exit code 3), when DSPEED_HIP_ABLATE / a non-default kernel variant is set without --allow-variants
+(exit code 4), or when fewer GPUs are visible than ranks asked for (exit code 5).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,7 +57,11 @@ BYTES_PER_WF = WF_LEN * 4 + 4 + 4 + 4
 HBM_PEAK_GBPS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def parse():
+PARITY_BAR = 1e-6                      # north_star: float32 filter outputs within 1e-6 relative of the reference arithmetic
+KERNEL_SOURCES = ("dsp_energy.hip", "dsp_vm.hip", "dsp_fit.hip", "dsp_c5.hip", "dsp_fir_mfma.hip", "dsp_host.cpp", "dsp_program.h", "dsp_wave.h")
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -52,11 +70,98 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the single-thread CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (profiling runs)")
     ap.add_argument("--wf-len", type=int, default=0, help="experiment only: other waveform length (trap geometry scaled)")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="workers skip the device: launcher / rendezvous / bookkeeping only (CPU tests)")
+    ap.add_argument("--allow-variants", action="store_true", help="A/B experiments: run although DSPEED_HIP_* kernel switches are set")
+    ap.add_argument("--share-gpus", action="store_true", help="rehearsal only: let ranks share devices when fewer GPUs than ranks are visible")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="(dry run) this rank exits non-zero: tests the launcher's error path")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="launcher: seconds before the ranks are given up")
+    return ap.parse_args(argv)
 
 
-def main():
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources: a recorded PMC traffic figure is only quoted for the code it was measured on."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        path = os.path.join(ROOT, "dspeed_amd", "csrc", name)
+        if os.path.exists(path):
+            with open(path, "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def dspeed_env() -> dict:
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("DSPEED_HIP_")}
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks.  Nothing in this process has loaded the HIP
+    library or torch, so the children are ordinary fresh processes (never an exec of a process that initialised the GPU)."""
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.monotonic() + args.launch_timeout
+    out0, failed = "", None
+    try:
+        pending = set(range(n))
+        while pending and failed is None:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if r == 0:
+                    out0 = procs[0].stdout.read()
+                if rc != 0:
+                    failed = (r, rc)
+                    break
+            if time.monotonic() > deadline:
+                failed = (-1, 124)
+            if pending and failed is None:
+                time.sleep(0.05)
+    finally:
+        for p in procs:  # exactly the processes started here
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    if failed is not None:
+        who = "the launch timeout" if failed[0] < 0 else f"rank {failed[0]} (exit code {failed[1]})"
+        print(f"bench.py: {who} ended the {n}-rank run", file=sys.stderr)
+        return failed[1] or 1
+    line = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if not line:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    print(line[-1])
+    return 0
+
+
+def main() -> int:
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
+    return worker(args)
+
+
+def worker(args) -> int:
     global WF_LEN, RISE, FLAT, BYTES_PER_WF
     if args.wf_len:
         WF_LEN, RISE, FLAT = args.wf_len, 625 * args.wf_len // 4096, 188 * args.wf_len // 4096
@@ -64,23 +169,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(args.gpus, 1) and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != max(args.gpus, 1):
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag must agree", file=sys.stderr)
+        return 2
     n_gpus = world
-
-    # the product path: load the HIP library first (fails loudly if it was not built)
-    from dspeed_amd import _lib
-    from dspeed_amd.chain import Chain, energy_chain_program
-    from dspeed_amd.device import DeviceArray, Event, Stream, device_count, device_info, set_device, sync
-
-    _lib.lib()
-    ndev = device_count()
-    if ndev < 1:
-        raise SystemExit("bench.py needs a GPU: no HIP device visible")
-    set_device(local_rank % ndev)
+    env_switches = dspeed_env()
+    if env_switches and not args.allow_variants:
+        print(f"bench.py: refusing to measure with kernel switches set: {env_switches} (--allow-variants for A/B experiments)", file=sys.stderr)
+        return 4
 
     dist = None
     if world > 1:
+        import torch
         import torch.distributed as dist  # gloo: barrier + max of a timing scalar only
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -90,10 +190,47 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def gather_floats(v: float) -> list:
+        if dist is None:
+            return [float(v)]
+        t = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(t, torch.tensor([float(v)], dtype=torch.float64))
+        return [float(x[0]) for x in t]
+
     rows = args.rows or (1_000_000 if n_gpus == 1 else 1_250_000)
     first_row = rank * rows  # disjoint shards of one global synthetic batch
 
+    if args.dry_run:  # launcher / rendezvous / bookkeeping only: no library, no device, no number
+        barrier()
+        ranks_seen = sorted(int(r) for r in gather_floats(rank))
+        firsts = [int(x) for x in gather_floats(first_row)]
+        pids = [int(x) for x in gather_floats(os.getpid())]
+        barrier()
+        if rank == args.fail_rank:
+            return 7
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": n_gpus, "ranks_seen": ranks_seen, "rows_per_gpu": rows, "first_rows": firsts,
+                              "pids": pids, "launcher_pid": os.getppid(), "value": None}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return 0
+
+    # the product path: load the HIP library first (fails loudly if it was not built)
+    from dspeed_amd import _lib
+    from dspeed_amd.chain import Chain, energy_chain_program
+    from dspeed_amd.device import DeviceArray, Event, Stream, device_count, device_info, set_device, sync
+
     L = _lib.lib()
+    ndev = device_count()
+    if ndev < 1:
+        print("bench.py needs a GPU: no HIP device visible", file=sys.stderr)
+        return 5
+    if ndev < world and not args.share_gpus:
+        print(f"bench.py: {world} ranks but only {ndev} GPU(s) visible (one process per GPU; --share-gpus for a rehearsal)", file=sys.stderr)
+        return 5
+    device = local_rank % ndev
+    set_device(device)
+
     stream = Stream()
     wf = DeviceArray((rows, WF_LEN), np.float32)
     bl = DeviceArray((rows,), np.float32)
@@ -123,28 +260,15 @@ def main():
     barrier()
     t1 = time.perf_counter()
     chain.check(stream, row_offset=first_row)
-    elapsed = t1 - t0
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    elapsed = max(gather_floats(t1 - t0))
     kernel_ms = [starts[k].elapsed_ms(stops[k]) for k in range(args.steps)]
-    avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3 if kernel_ms else float("nan")
+    avg_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    rank_kernel_ms = gather_floats(avg_kernel_ms)
+    ranks_seen = sorted(int(r) for r in gather_floats(rank))
+    devices_seen = [int(d) for d in gather_floats(device)]
 
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-
-    total_rows = rows * n_gpus
-    value = total_rows * args.steps / elapsed
-    achieved = rows * BYTES_PER_WF / avg_kernel_s / 1e9
-    geo = chain.geometry(rows)
-
-    # ---- parity guard + CPU baseline on a bounded sample of the same batch (rank 0, N = 1 only for the baseline)
-    sample_n = 4096
+    # ---- parity guard on the output of the TIMED launches (every rank checks its own shard's first rows against the oracle)
+    sample_n = 4096 if rank == 0 else 512
     wf_s = wf.view_rows(0, sample_n).to_numpy()
     bl_s = bl.view_rows(0, sample_n).to_numpy()
     tp_s = tp.view_rows(0, sample_n).to_numpy()
@@ -153,7 +277,22 @@ def main():
 
     want_s, rc = oracle.chain_energy(wf_s, bl_s, tp_s, TAU, RISE, FLAT, "l")
     ok = ~np.isnan(want_s)
-    parity = float(np.max(np.abs(got_s[ok] - want_s[ok]) / np.abs(want_s[ok]))) if rc == 0 else float("nan")
+    parity = float(np.max(np.abs(got_s[ok] - want_s[ok]) / np.abs(want_s[ok]))) if rc == 0 and ok.any() else float("nan")
+    if not np.array_equal(np.isnan(got_s), np.isnan(want_s)):
+        parity = float("nan")
+    parities = gather_floats(parity)
+    parity = float("nan") if any(p != p for p in parities) else max(parities)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return 0 if parity <= PARITY_BAR else 3
+
+    total_rows = rows * n_gpus
+    value = total_rows * args.steps / elapsed
+    avg_kernel_s = float(np.mean(rank_kernel_ms)) * 1e-3
+    achieved = rows * BYTES_PER_WF / avg_kernel_s / 1e9
+    geo = chain.geometry(rows)
 
     cpu = None
     if n_gpus == 1 and not args.no_cpu:
@@ -175,36 +314,40 @@ def main():
                "sample": f"first {n_cpu} rows of the same synthetic batch, 16-row blocks, one processor call per block (dspeed defaults), {dt1:.1f} s",
                "all_cores": {"value": n_cpu / dtn, "cores": cores, "seconds": round(dtn, 2)}}
 
-    # HBM traffic per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled as the gfx950 guide prescribes),
-    # recorded under profiles/ by tools/profile_bench.sh; null if no recorded measurement matches this workload
+    # HBM traffic per launch: RECORDED from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled as the gfx950 guide
+    # prescribes; tools/profile_bench.sh + tools/summarise_profile.py write the file).  Quoted only when the record is for this
+    # kernel, these rows and exactly these kernel sources (hash); otherwise null -- counters cannot be read from inside the run.
     traffic, traffic_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            t = json.load(f)
-        if t.get("rows") == rows and t.get("wf_len") == WF_LEN and t.get("kernel") == chain.kernel_name:
-            traffic, traffic_src = t["hbm_bytes_per_launch"], t.get("source")
-    except (OSError, ValueError, KeyError):
-        pass
+    src_hash = kernel_source_hash()
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if not name.endswith("_pmc_traffic.json"):
+            continue
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+            if (t.get("rows") == rows and t.get("wf_len") == WF_LEN and t.get("kernel") == chain.kernel_name
+                    and t.get("kernel_source_hash") == src_hash):
+                traffic, traffic_src = t["hbm_bytes_per_launch"], f"recorded: profiles/{name} ({t.get('source')})"
+                break
+        except (OSError, ValueError, KeyError):
+            pass
 
     # measured read-only streaming ceiling of this box: the same batch read once by a trivial kernel, outside the timed region
     stream_gbps = None
     try:
-        from dspeed_amd import _lib
-        from dspeed_amd.device import Event
-
         nbytes = rows * WF_LEN * 4
         e0, e1 = Event(), Event()
         for it in range(4):  # first pass warms the code object
             if it == 1:
                 e0.record(stream)
-            _lib.check(_lib.lib().dsp_stream_read(wf.ptr, nbytes, out.ptr, stream.ptr if stream else None))
+            _lib.check(L.dsp_stream_read(wf.ptr, nbytes, out.ptr, stream.ptr if stream else None))
         e1.record(stream)
         sync()
         stream_gbps = 3 * nbytes / (e0.elapsed_ms(e1) * 1e-3) / 1e9
     except Exception as exc:  # a measurement extra: never fails the bench line
         print(f"[bench] stream-read measurement skipped: {exc}", file=sys.stderr)
 
-    info = device_info(local_rank % ndev)
+    info = device_info(device)
     line = {
         "metric": "waveforms/sec, 4096-sample fp32 trap-energy chain",
         "value": value,
@@ -222,19 +365,26 @@ def main():
                                 "->fixed_time_pickoff('l'); " + ("BASELINE configs[1]" if n_gpus == 1 else "BASELINE configs[3] shard")),
                    "rows_per_gpu": rows, "wf_len": WF_LEN, "sharding": "event axis, no collectives", "device": info["name"],
                    "kernel": chain.kernel_name, "lds_bytes_per_wave": geo["lds_bytes_per_wave"], "waves_per_block": geo["waves_per_block"],
-                   "blocks": geo["blocks"]},
+                   "blocks": geo["blocks"], "ranks_seen": ranks_seen, "devices_seen": devices_seen, "env": env_switches,
+                   "kernel_source_hash": src_hash},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": rows * BYTES_PER_WF,
                      "bytes_per_waveform": BYTES_PER_WF, "kernel_ms_avg": 1e3 * avg_kernel_s,
-                     "kernel_ms_min": float(np.min(kernel_ms)), "measured_stream_read_GBps": stream_gbps,
+                     "kernel_ms_min": float(np.min(kernel_ms)), "kernel_ms_avg_per_rank_min": float(np.min(rank_kernel_ms)),
+                     "kernel_ms_avg_per_rank_max": float(np.max(rank_kernel_ms)), "measured_stream_read_GBps": stream_gbps,
                      "frac_of_measured_stream_read": (achieved / stream_gbps) if stream_gbps else None},
         "cpu_baseline": cpu,
         "parity_max_rel_vs_oracle": parity,
+        "parity_bar": PARITY_BAR,
     }
-    print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+    if not parity <= PARITY_BAR:
+        print(f"bench.py: the timed launches' output deviates from the oracle by {parity} (bar {PARITY_BAR}): no number", file=sys.stderr)
+        return 3
+    print(json.dumps(line))
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -3,6 +3,12 @@
     python -m dspeed_amd.build [--force]
 
 hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels with the tree.
+
+    python -m dspeed_amd.build --diag
+
+builds libdspeed_hip_diag.so beside it: the same sources with -DDSPEED_HIP_DIAG, which compiles the kernels' diagnostic switches
+in (DSPEED_HIP_ABLATE: skip passes / per-phase cycle stamps).  The product library does not contain them; tools select the
+diagnostic one with DSPEED_HIP_LIB=.../libdspeed_hip_diag.so.
 """
 from __future__ import annotations
 
@@ -14,6 +20,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdspeed_hip.so")
+LIB_DIAG = os.path.join(HERE, "libdspeed_hip_diag.so")
 SOURCES = ["dsp_vm.hip", "dsp_energy.hip", "dsp_fit.hip", "dsp_host.cpp"]
 DEPS = SOURCES + ["dsp_program.h", "dsp_wave.h", os.path.join("..", "..", "include", "dspeed_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wall",
@@ -27,22 +34,36 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm)")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def needs_build(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return LIB
-    cmd = [_hipcc(), *FLAGS, "-x", "hip", *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
+def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
+    lib = LIB_DIAG if diag else LIB
+    if not force and not needs_build(lib):
+        return lib
+    # one hipcc process per source (they are independent translation units), then a link: the wall time of the longest file
+    objs, procs = [], []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, "." + src + (".diag.o" if diag else ".o"))
+        cmd = [_hipcc(), *[f for f in FLAGS if f != "-shared"], *(["-DDSPEED_HIP_DIAG"] if diag else []), "-x", "hip", "-c",
+               os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", lib]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB
+        print(" ".join(link))
+    subprocess.check_call(link)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))

@@ -44,8 +44,15 @@ struct EnergyArgs {
     int32_t q[3], rho[3];  // lag = q*C + rho
     int32_t lds_elems_per_wave;
     int32_t slot_off;      // element offset of the slot inside the wave's region (2*pitch guard below it)
-    int32_t ablate;        // timing experiments only (DSPEED_HIP_ABLATE): bit 0/1/2 = skip pass 1/2/3; results are then wrong
+    int32_t ablate;        // diagnostic build only (-DDSPEED_HIP_DIAG, libdspeed_hip_diag.so): bit 0/1/2 = skip pass 1/2/3 (results are then
+                           // wrong), bit 3 = per-phase cycle stamps.  The product library ignores the field: ABLATE below is a constant 0.
 };
+
+#ifdef DSPEED_HIP_DIAG
+#define ABLATE(A) ((A).ablate)
+#else
+#define ABLATE(A) 0
+#endif
 
 namespace {
 
@@ -116,7 +123,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
         }
     };
     if (row < n_wf) prefetch(row);
-    const bool stamps = (A.ablate & 8) != 0;
+    const bool stamps = (ABLATE(A) & 8) != 0;
     unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = stamps ? stamp() : 0;
 
     for (; row < n_wf; row += stride_rows) {
@@ -141,7 +148,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
         float result = quiet_nan<float>();
         // ---- pass 1: per-chunk float64 sum of x = w - baseline; a NaN anywhere (or a NaN baseline) poisons the sum
         double X = 0.0;
-        if (!(A.ablate & 1)) {
+        if (!(ABLATE(A) & 1)) {
             float va[G], vb[G];
             load_group(va, mine);
 #pragma unroll 1
@@ -174,7 +181,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
             const double c = A.c;
             double acc = E - c * (E - xprev0), xp = xprev0;
             float run = 0.0f, cap[3] = {0.0f, 0.0f, 0.0f};
-            if (!(A.ablate & 2)) {
+            if (!(ABLATE(A) & 2)) {
                 float va[G], vb[G];
                 load_group(va, mine);
                 auto body = [&](float (&v)[G], int t) {
@@ -220,7 +227,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_kernel(EnergyArgs A, int64_
             }
             if (pz_nan) {
                 report(DSP_E_PZ_NAN, row);  // pole_zero.py:76-77
-            } else if (!A.all_nan && !(A.ablate & 4) && pickoff_in_range(t_in, len)) {
+            } else if (!A.all_nan && !(ABLATE(A) & 4) && pickoff_in_range(t_in, len)) {
                 // ---- speculative carries: filter value at every chunk boundary from the prefix sums
                 const double Ep = wave_exscan_add((double)run);
                 double Ak[3];
@@ -411,7 +418,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
         }
     };
     if (row < n_wf) prefetch(row);
-    const bool stamps = (A.ablate & 8) != 0;
+    const bool stamps = (ABLATE(A) & 8) != 0;
     unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tlast = stamps ? stamp() : 0;
     // a row's result is stored one iteration late, behind the next prefetch: vmcnt counts stores too, so a store issued
     // at the end of the loop body would sit (a full write latency) in front of the s_waitcnt vmcnt(0) that opens the next staging
@@ -514,7 +521,7 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
             }
             if (pz_nan) {
                 report(DSP_E_PZ_NAN, row);
-            } else if (!A.all_nan && !(A.ablate & 4) && pickoff_in_range(t_in, len)) {
+            } else if (!A.all_nan && !(ABLATE(A) & 4) && pickoff_in_range(t_in, len)) {
                 // ---- speculative carries
                 const double Ep = wave_exscan_add((double)run);
                 float g[S], y[S];

@@ -320,6 +320,7 @@ int dsp_event_elapsed_ms(void* start, void* stop, float* ms) {
 // without saying where.  With this handler installed SIGABRT first writes the native call stack to stderr, then takes its default
 // course.  async-signal-safe calls only (backtrace_symbols_fd writes straight to the descriptor).
 static struct sigaction g_prev_abort;
+static bool g_abort_installed = false;
 static int g_abort_fd = 2;
 static void abort_trace_handler(int sig) {
     static const char head[] = "\n[dspeed_hip] SIGABRT -- native call stack of the aborting thread:\n";
@@ -331,18 +332,44 @@ static void abort_trace_handler(int sig) {
         (void)!write(2, head, sizeof head - 1);
         backtrace_symbols_fd(frames, n, 2);
     }
-    sigaction(sig, &g_prev_abort, nullptr);  // whoever was there before (Python's faulthandler prints its own stack), then the default
+    // whoever was there before (Python's faulthandler prints its own stack), then the default; never this handler again -- a
+    // re-raise into ourselves would loop for ever (the signal is blocked while we run and pends)
+    struct sigaction next = g_prev_abort;
+    if (!g_abort_installed || next.sa_handler == abort_trace_handler) {
+        memset(&next, 0, sizeof next);
+        next.sa_handler = SIG_DFL;
+        sigemptyset(&next.sa_mask);
+    }
+    g_abort_installed = false;
+    sigaction(sig, &next, nullptr);
     raise(sig);
 }
 int dsp_install_abort_trace(int fd) {
     g_abort_fd = fd >= 0 ? fd : 2;
     void* warm[2];
     (void)backtrace(warm, 2);  // (loads libgcc's unwinder now, not inside the handler)
+    struct sigaction cur;
+    if (sigaction(SIGABRT, nullptr, &cur) == 0 && cur.sa_handler == abort_trace_handler) return DSP_OK;  // already there: only the descriptor changed
     struct sigaction sa;
     memset(&sa, 0, sizeof sa);
     sa.sa_handler = abort_trace_handler;
     sigemptyset(&sa.sa_mask);
-    return sigaction(SIGABRT, &sa, &g_prev_abort) == 0 ? DSP_OK : fail(DSP_ERR_ARG, "sigaction(SIGABRT) failed");
+    struct sigaction prev;
+    if (sigaction(SIGABRT, &sa, &prev) != 0) return fail(DSP_ERR_ARG, "sigaction(SIGABRT) failed");
+    g_prev_abort = prev;  // the disposition of the FIRST installation is what an uninstall (or the handler) goes back to
+    g_abort_installed = true;
+    return DSP_OK;
+}
+int dsp_uninstall_abort_trace(void) {
+    struct sigaction cur;
+    if (!g_abort_installed || sigaction(SIGABRT, nullptr, &cur) != 0 || cur.sa_handler != abort_trace_handler) {
+        g_abort_installed = false;  // (somebody else's handler is in place now: leave it)
+        g_abort_fd = 2;
+        return DSP_OK;
+    }
+    g_abort_installed = false;
+    g_abort_fd = 2;
+    return sigaction(SIGABRT, &g_prev_abort, nullptr) == 0 ? DSP_OK : fail(DSP_ERR_ARG, "sigaction(SIGABRT) failed");
 }
 const char* dsp_last_error(void) { return g_last_error.c_str(); }
 const char* dsp_version(void) { return "dspeed_hip 0.1 (gfx950)"; }
@@ -966,7 +993,9 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             }
             F.lds_elems_per_wave = P.lds_elems_per_wave;
             F.slot_off = P.slots[0].off;
-            if (const char* ab = getenv("DSPEED_HIP_ABLATE")) F.ablate = atoi(ab);  // timing experiments only
+#ifdef DSPEED_HIP_DIAG
+            if (const char* ab = getenv("DSPEED_HIP_ABLATE")) F.ablate = atoi(ab);  // diagnostic library only: skip passes / stamp phases
+#endif
             ch->io_wf = ld->io;
             ch->io_out = st->io;
             ch->fused_trap = tp->ip[3];
@@ -1120,6 +1149,7 @@ int dsp_chain_check(dsp_chain* ch, void* stream, int64_t* row) {
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     int host_err[DSP_ERR_WORDS] = {0};
     HIP_TRY(staged_d2h(host_err, ch->dev_err, sizeof host_err));
+#ifdef DSPEED_HIP_DIAG
     if (getenv("DSPEED_HIP_ABLATE") && (atoi(getenv("DSPEED_HIP_ABLATE")) & 8)) {  // diagnostic phase stamps
         unsigned long long ph[6];
         memcpy(ph, host_err + 4, sizeof ph);
@@ -1132,6 +1162,7 @@ int dsp_chain_check(dsp_chain* ch, void* stream, int64_t* row) {
             HIP_TRY(hipMemset(ch->dev_err + 4, 0, sizeof ph));
         }
     }
+#endif
     if (host_err[0] != 0) {
         if (row) *row = ((int64_t)(uint32_t)host_err[2] << 32) | (uint32_t)host_err[1];
         HIP_TRY(hipMemset(ch->dev_err, 0, 4 * sizeof(int)));

@@ -1,33 +1,30 @@
-"""Error types mirroring the reference (src/dspeed/errors.py:4-40): same names, same attributes, same
-string formatting, so code written against ``dspeed.errors`` keeps working."""
+"""The error types of the path, with the names, attributes and message layout that code written against ``dspeed.errors`` relies on
+(reference src/dspeed/errors.py:4-40; the chain fills ``wf_range`` / ``processor`` in, processing_chain.py:1154-1159)."""
 from __future__ import annotations
 
 
 class DSPError(Exception):
-    """Base class for signal processors."""
+    """Root of everything a processor or a chain raises on purpose."""
 
 
 class DSPFatal(DSPError):
-    """Fatal error thrown by DSP processors that halts production.
+    """A configuration-level failure inside a processor: it stops the run (a failure of one waveform is a NaN result instead).
 
-    ``wf_range`` (range of waveform indices) and ``processor`` (processor + arguments string) are set by the
-    chain after the exception is caught and are appended to the message, as in the reference
-    (errors.py:10-34, processing_chain.py:1154-1159).
+    Whoever catches it on the way up may attach ``wf_range`` (the rows being processed, a ``range``) and ``processor`` (the
+    processor call as text); the message then carries one more line for each.
     """
 
-    def __init__(self, *args) -> None:
-        super().__init__(*args)
-        self.wf_range = None
-        self.processor = None
+    wf_range = None
+    processor = None
 
     def __str__(self) -> str:
-        suffix = ""
+        lines = [Exception.__str__(self)]
         if self.wf_range:
-            suffix += "\nThrown while processing entries " + str(self.wf_range)
+            lines.append(f"Thrown while processing entries {self.wf_range}")
         if self.processor:
-            suffix += "\nThrown by " + self.processor
-        return super().__str__() + suffix
+            lines.append(f"Thrown by {self.processor}")
+        return "\n".join(lines)
 
 
 class ProcessingChainError(DSPError):
-    """Error thrown when there is a problem setting up a processing chain."""
+    """A chain could not be set up (unknown variable, shape or unit mismatch, unsupported recipe syntax)."""

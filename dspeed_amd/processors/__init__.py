@@ -434,29 +434,33 @@ moving_window_multi = HipGUFunc("moving_window_multi", "(n),(),(),()->(n)", ["ff
 trap_pickoff = HipGUFunc("trap_pickoff", "(n),(),(),()->()", ["fiif->f", "diid->d"], _trap_pickoff,
                          "normalised difference of two rise-long window sums at an integer pick-off sample (reference processors/trap_filters.py:230-293)")
 def _t0_filter(g, rise, fall, kernel):
-    """kernels.py:12-66: linearly weighted rise (weights 2(r - i) / (r (r + 1))), then -1/fall; object mode -> Python floats"""
+    """t0 kernel: a ramp of weights 2 (r - i) / (r (r + 1)), i = 0 .. r - 1 (they sum to 1), followed by the plateau -1 / fall.
+    Evaluated in float64 and rounded once into the kernel (the reference's generator runs in object mode on Python floats,
+    processors/kernels.py:12-61); the three parameter checks keep the reference's order and texts."""
     rise, fall = _scalar_for(kernel, rise), _scalar_for(kernel, fall)
-    if rise < 0:
-        raise DSPFatal("The length of the rise section must be positive")
-    if fall < 0:
-        raise DSPFatal("The length of the fall section must be positive")
+    for value, what in ((rise, "rise"), (fall, "fall")):
+        if value < 0:
+            raise DSPFatal(f"The length of the {what} section must be positive")
     if len(kernel) != rise + fall:
         raise DSPFatal("The length of the output kernel must equal rise+fall")
-    for i in range(int(rise)):
-        kernel[i] = 2 * (int(rise) - i) / (rise * (rise + 1))
-    for i in range(int(rise), len(kernel)):
-        kernel[i] = -1 / fall
+    r = int(rise)
+    if r > 0:
+        ramp = 2.0 * np.arange(r, 0, -1, dtype=np.float64)  # 2 (r - i): exact integers
+        kernel[:r] = ramp / (rise * (rise + 1))
+    if len(kernel) > r:  # (an empty section divides by nothing)
+        kernel[r:] = -1.0 / fall
     return kernel
 
 
 def _moving_slope(g, kernel):
-    """kernels.py:69-98: least-squares slope weights over len(kernel) samples, reversed for use as a convolution kernel"""
+    """Least-squares slope of n equidistant samples as FIR weights, w_j = (n j - S1) / (n S2 - S1^2) for j = n .. 1 (the order a
+    convolution wants), S1 = sum j, S2 = sum j^2.  Numerator and denominator are rounded to the kernel's type before the division,
+    which is where the reference's in-place array arithmetic rounds (processors/kernels.py:69-100)."""
     n = len(kernel)
-    sum_x = n * (n + 1) / 2
-    sum_x2 = n * (n + 1) * (2 * n + 1) / 6
-    kernel[:] = (np.arange(1, n + 1, 1) * n) - (np.ones(n) * sum_x)
-    kernel[:] /= n * sum_x2 - sum_x * sum_x
-    kernel[:] = kernel[::-1]
+    s1 = n * (n + 1) / 2
+    s2 = n * (n + 1) * (2 * n + 1) / 6
+    numer = (n * np.arange(n, 0, -1, dtype=np.float64) - s1).astype(kernel.dtype)
+    kernel[:] = numer / kernel.dtype.type(n * s2 - s1 * s1)
     return kernel
 
 

@@ -102,7 +102,9 @@ int dsp_stream_wait_event(void* stream, void* event); /* work queued on `stream`
 int dsp_event_sync(void* event);
 int dsp_event_elapsed_ms(void* start, void* stop, float* ms);
 int dsp_install_abort_trace(int fd);           /* diagnostics: on SIGABRT (how the HIP / ROCr runtimes end the process on a GPU fault)
-                                               * write the native call stack to descriptor fd (< 0: stderr) before the default action */
+                                               * write the native call stack to descriptor fd (< 0: stderr) before the default action;
+                                               * calling it again only changes the descriptor */
+int dsp_uninstall_abort_trace(void);           /* put back the SIGABRT disposition found by the first dsp_install_abort_trace */
 const char* dsp_last_error(void);             /* thread-local text of the last failure */
 const char* dsp_fatal_message(int dsp_e_code); /* the reference's DSPFatal message for a DSP_E_* code */
 const char* dsp_version(void);

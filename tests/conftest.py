@@ -44,7 +44,7 @@ def _abort_trace():
         try:
             from dspeed_amd import _lib
 
-            _lib.lib().dsp_install_abort_trace(-1)
+            _lib.lib().dsp_uninstall_abort_trace()
             log.close()
         except Exception:
             pass

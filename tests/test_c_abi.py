@@ -70,3 +70,43 @@ def test_product_path_fails_loudly_without_the_library(monkeypatch, tmp_path):
     finally:
         monkeypatch.delenv("DSPEED_HIP_LIB")
         importlib.reload(_lib)
+
+
+def test_abort_trace_installed_twice_still_terminates(tmp_path):
+    """a second dsp_install_abort_trace must not make the handler its own predecessor (an abort() then looped for ever).
+    Runs in a child process: install(fd), install(-1), abort() -> one trace, death by SIGABRT within seconds."""
+    import signal
+    import subprocess
+    import sys
+
+    log = tmp_path / "trace.log"
+    code = (
+        "import ctypes, os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from dspeed_amd import _lib\n"
+        "L = ctypes.CDLL(_lib.LIB_PATH)\n"
+        f"fd = os.open({str(log)!r}, os.O_WRONLY | os.O_CREAT)\n"
+        "assert L.dsp_install_abort_trace(fd) == 0\n"
+        "assert L.dsp_install_abort_trace(-1) == 0\n"
+        "os.abort()\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == -signal.SIGABRT
+    assert r.stderr.count("SIGABRT -- native call stack") == 1
+
+
+def test_abort_trace_uninstall_restores_the_previous_disposition():
+    import signal
+    import subprocess
+    import sys
+
+    code = (
+        "import ctypes, os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from dspeed_amd import _lib\n"
+        "L = ctypes.CDLL(_lib.LIB_PATH)\n"
+        "assert L.dsp_install_abort_trace(2) == 0 and L.dsp_uninstall_abort_trace() == 0 and L.dsp_uninstall_abort_trace() == 0\n"
+        "os.abort()\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == -signal.SIGABRT and "native call stack" not in r.stderr
