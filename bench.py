@@ -58,7 +58,7 @@ HBM_PEAK_GBPS = 8000.0                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 PARITY_BAR = 1e-6                      # north_star: float32 filter outputs within 1e-6 relative of the reference arithmetic
-KERNEL_SOURCES = ("dsp_energy.hip", "dsp_vm.hip", "dsp_fit.hip", "dsp_c5.hip", "dsp_fir_mfma.hip", "dsp_host.cpp", "dsp_program.h", "dsp_wave.h")
+KERNEL_SOURCES = ("dsp_energy.hip", "dsp_vm.hip", "dsp_fit.hip", "dsp_rows.hip", "dsp_fir_mfma.hip", "dsp_host.cpp", "dsp_program.h", "dsp_wave.h")
 
 
 def parse(argv=None):

@@ -79,6 +79,9 @@ struct EnergyPlan {
 extern "C" int dsp_internal_launch_energy_rr(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int wf_dtype,
                                              int64_t n_wf, int* err, int blocks, int threads, int lds_bytes, hipStream_t stream);
 extern "C" const char* dsp_internal_energy_rr_kernel_name();
+extern "C" int dsp_internal_launch_rows(const RowsArgs* A, int64_t n_wf, int* err, int lds_bytes, hipStream_t stream);
+extern "C" int dsp_internal_set_rows_lds(int lds_bytes);
+extern "C" const char* dsp_internal_rows_kernel_name();
 
 namespace {
 
@@ -154,7 +157,161 @@ struct dsp_chain {
     EnergyPlan plan[2]{};  // [S - 1]
     int rr_lds_bytes = 0;
     int io_wf = -1, io_bl = -1, io_tp = -1, io_out = -1;
+    // lane-per-waveform kernel (dsp_rows.hip): [bl_subtract ->] pole_zero | double_pole_zero -> short trapezoid -> min_max /
+    // time_point_thresh, + Haar DWT of the pole-zero corrected waveform
+    bool rows_ok = false;
+    RowsArgs rows{};
+    int rows_lds_bytes = 0;
+    int rio_wf = -1, rio_bl = -1, rio_thr = -1, rio_ts = -1, rio_mm[4] = {-1, -1, -1, -1}, rio_tpt = -1, rio_dwt = -1;
 };
+
+// Does the program have the shape of the lane-per-waveform kernel?  Fills ch->rows / ch->rio_* and returns true if so.
+//   LOAD s;  [BL_SUBTRACT s <- s];  POLE_ZERO | DOUBLE_POLE_ZERO s <- s;  then in any order: one TRAP_REDUCE of s, at most one DWT_HAAR of s
+//   into a slot that is stored, STORE_SCALARs of the reduction's registers.
+static bool match_rows_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_io, const int32_t* slot_len, int n_slots,
+                             const std::vector<int>& dev_index, bool f64) {
+    const DevProgram& P = ch->host;
+    if (f64 || n_ops < 4 || n_slots < 1 || n_slots > 2) return false;
+    int i = 0;
+    if (ops[i].opcode != DSP_OP_LOAD) return false;
+    const dsp_op& ld = ops[i++];
+    const int s = ld.dst;
+    const int wdt = io[ld.io].dtype, len = slot_len[s];
+    if ((wdt != DSP_F32 && wdt != DSP_I16 && wdt != DSP_U16) || !P.io[ld.io].vec_ok || len % 8 != 0 || len < 16) return false;
+    auto f32_or_const = [&](const dsp_scalar_arg& a) { return a.kind == DSP_ARG_CONST || (a.kind == DSP_ARG_INPUT && io[a.index].dtype == DSP_F32); };
+    const dsp_op* bs = nullptr;
+    if (ops[i].opcode == DSP_OP_BL_SUBTRACT) {
+        bs = &ops[i++];
+        if (bs->dst != s || bs->src != s || !f32_or_const(bs->sp[0])) return false;
+    }
+    if (i >= n_ops || (ops[i].opcode != DSP_OP_POLE_ZERO && ops[i].opcode != DSP_OP_DOUBLE_POLE_ZERO)) return false;
+    const dsp_op& pz = ops[i];
+    const DevOp& dpz = P.ops[dev_index[i]];
+    ++i;
+    if (pz.dst != s || pz.src != s) return false;
+    const dsp_op *tr = nullptr, *dw = nullptr, *st_wf = nullptr;
+    int tr_at = -1;
+    std::vector<const dsp_op*> st_sc;
+    for (; i < n_ops; ++i) {
+        const dsp_op& o = ops[i];
+        if (o.opcode == DSP_OP_TRAP_REDUCE && !tr && o.src == s) {
+            tr = &o;
+            tr_at = i;
+        } else if (o.opcode == DSP_OP_DWT_HAAR && !dw && o.src == s && o.dst != s) {
+            dw = &o;
+        } else if (o.opcode == DSP_OP_STORE_SCALAR) {
+            st_sc.push_back(&o);
+        } else if (o.opcode == DSP_OP_STORE && !st_wf) {
+            st_wf = &o;
+        } else {
+            return false;
+        }
+    }
+    if (!tr || (dw != nullptr) != (st_wf != nullptr)) return false;
+    if (dw && (st_wf->src != dw->dst || io[st_wf->io].dtype != DSP_F32)) return false;
+    const DevOp& dtr = P.ops[dev_index[tr_at]];
+    RowsArgs& A = ch->rows;
+    memset(&A, 0, sizeof A);
+    A.wf_stride = io[ld.io].row_stride;
+    A.wf_offset = io[ld.io].offset;
+    A.len = len;
+    A.in_kind = wdt == DSP_F32 ? 0 : (wdt == DSP_I16 ? 1 : 2);
+    ch->rio_wf = ld.io;
+    if (bs) {
+        A.sub_mode = 1;
+        if (bs->sp[0].kind == DSP_ARG_INPUT) {
+            ch->rio_bl = bs->sp[0].index;
+            A.bl_stride = io[ch->rio_bl].row_stride;
+        } else {
+            A.bl_const = (float)bs->sp[0].value;
+        }
+    }
+    A.pz_kind = pz.opcode == DSP_OP_POLE_ZERO ? 1 : 2;
+    A.pz_param_nan = dpz.ic[0];
+    if (A.pz_kind == 1) {
+        A.pz_c = dpz.fc[0];
+    } else {
+        A.n1 = dpz.fc[0];
+        A.n2 = dpz.fc[1];
+        A.d1 = dpz.fc[2];
+        A.d2 = dpz.fc[3];
+    }
+    // trapezoid: every lag at least one block of the kernel (8 samples), the history ring within half a CU's LDS
+    A.trap_kind = tr->ip[3] == DSP_OP_TRAP_FILTER ? 0 : (tr->ip[3] == DSP_OP_TRAP_NORM ? 1 : 2);
+    int maxlag = 0;
+    for (int k = 0; k < 3; ++k) {
+        A.lag[k] = dtr.ic[k];
+        if (A.lag[k] < 8) return false;
+        if (A.lag[k] > maxlag) maxlag = A.lag[k];
+    }
+    const int R = ((maxlag + 8 + 7) / 8) * 8;  // R > largest lag + 7, a whole number of blocks
+    if ((R + 8) * 256 > LDS_BYTES_PER_CU / 2) return false;
+    A.ring_entries = R;
+    ch->rows_lds_bytes = (R + 8) * 256;
+    A.trap_all_nan = dtr.ic[9];
+    A.rr = dtr.fc[0];
+    A.ll = dtr.fc[1];
+    A.inv_rr = 1.0 / A.rr;
+    A.inv_ll = 1.0 / A.ll;
+    const int rise = tr->ip[0];
+    A.rise_pow2 = (rise > 0 && (rise & (rise - 1)) == 0) ? 1 : 0;
+    // reductions
+    const int mm = tr->dst, tpt_reg = tr->io;
+    if (tpt_reg >= 0) {
+        if (!f32_or_const(tr->sp[0]) || tr->sp[2].kind != DSP_ARG_CONST) return false;
+        if (tr->sp[0].kind == DSP_ARG_INPUT) {
+            ch->rio_thr = tr->sp[0].index;
+            A.thr_stride = io[ch->rio_thr].row_stride;
+        } else {
+            A.thr_const = (float)tr->sp[0].value;
+        }
+        const double walk = (double)(float)tr->sp[2].value;
+        A.walk_nan = std::isnan(walk) ? 1 : 0;
+        A.walk_frac = (!A.walk_nan && std::floor(walk) != walk) ? 1 : 0;
+        const bool forward = !A.walk_nan && !A.walk_frac && (long long)walk == 1;
+        const dsp_scalar_arg& t = tr->sp[1];
+        if (t.kind == DSP_ARG_REG) {
+            if (mm < 0 || (t.index != mm && t.index != mm + 1)) return false;
+            A.tpt_use_min = t.index == mm ? 1 : 0;
+            A.tpt_mode = forward ? 4 : 2;
+        } else {
+            if (!f32_or_const(t)) return false;
+            if (t.kind == DSP_ARG_INPUT) {
+                ch->rio_ts = t.index;
+                A.ts_stride = io[ch->rio_ts].row_stride;
+            } else {
+                A.ts_const = (float)t.value;
+            }
+            A.tpt_mode = forward ? 3 : 1;
+        }
+    }
+    for (const dsp_op* st : st_sc) {
+        const int r = st->ip[0];
+        if (io[st->io].dtype != DSP_F32) return false;
+        if (mm >= 0 && r >= mm && r < mm + 4) {
+            if (ch->rio_mm[r - mm] >= 0) return false;  // (one column per value)
+            ch->rio_mm[r - mm] = st->io;
+            A.out_mm_stride[r - mm] = io[st->io].row_stride;
+        } else if (tpt_reg >= 0 && r == tpt_reg && ch->rio_tpt < 0) {
+            ch->rio_tpt = st->io;
+            A.out_tpt_stride = io[st->io].row_stride;
+        } else {
+            return false;
+        }
+    }
+    if (dw) {
+        const int level = dw->ip[0], outlen = slot_len[dw->dst];
+        const dsp_io_desc& d = io[st_wf->io];
+        if (level < 3 || level > 8 || len % (1 << level) != 0 || outlen != (len >> level) || outlen % 4 != 0 || d.row_stride % 4 != 0 ||
+            d.offset % 4 != 0 || d.len != outlen)
+            return false;
+        A.dwt_level = level;
+        A.dwt_part = dw->ip[1];
+        A.dwt_stride = d.row_stride;
+        ch->rio_dwt = st_wf->io;
+    }
+    return true;
+}
 
 // Internal copies between this library's own host structures (programs, error words, tap read-backs) and the device go through one
 // page-locked staging buffer: the runtime is never handed heap or stack memory to page-lock on the fly (host memory note).
@@ -1044,6 +1201,15 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         }
     }
 
+    ch->rows_ok = match_rows_shape(ch.get(), ops, n_ops, io, n_io, slot_len, n_slots, dev_index, f64);
+    if (!ch->rows_ok) {
+        ch->rio_wf = ch->rio_bl = ch->rio_thr = ch->rio_ts = ch->rio_tpt = ch->rio_dwt = -1;
+        for (int k = 0; k < 4; ++k) ch->rio_mm[k] = -1;
+    } else {
+        const char* env = getenv("DSPEED_HIP_NO_FUSED");
+        ch->fused_on = !(env && env[0] == '1');
+    }
+
     HIP_TRY(hipGetDevice(&ch->device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ch->device));
@@ -1065,8 +1231,20 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         hipError_t e = (hipError_t)dsp_internal_set_energy_lds(ch->fused_trap, ch->fused_npf, classic_lds);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(energy kernel, %d): %s", classic_lds, hipGetErrorString(e));
     }
+    if (ch->rows_ok && ch->rows_lds_bytes > 64 * 1024) {
+        hipError_t e = (hipError_t)dsp_internal_set_rows_lds(ch->rows_lds_bytes);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(rows kernel, %d): %s", ch->rows_lds_bytes, hipGetErrorString(e));
+    }
     *out = ch.release();
     return DSP_OK;
+}
+
+// the lane-per-waveform kernel runs when the program has its shape and the row / coefficient buffers of this call keep 16-byte alignment
+static bool rows_applies(const dsp_chain* ch, void* const* io_ptrs) {
+    if (!ch->rows_ok || !ch->fused_on) return false;
+    if (reinterpret_cast<uintptr_t>(io_ptrs[ch->rio_wf]) & 15u) return false;
+    if (ch->rio_dwt >= 0 && (reinterpret_cast<uintptr_t>(io_ptrs[ch->rio_dwt]) & 15u)) return false;
+    return true;
 }
 
 static int chain_blocks(const dsp_chain* ch, int64_t n_wf, int wpb, int cap_waves) {
@@ -1107,6 +1285,19 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         ptrs.p[k] = io_ptrs[k];
     }
     (void)hipGetLastError();  // launch checks below report this launch, not a stale error of an unrelated earlier call
+    if (rows_applies(ch, io_ptrs)) {
+        RowsArgs A = ch->rows;
+        A.wf = io_ptrs[ch->rio_wf];
+        A.bl = ch->rio_bl >= 0 ? (const float*)io_ptrs[ch->rio_bl] : nullptr;
+        A.thr = ch->rio_thr >= 0 ? (const float*)io_ptrs[ch->rio_thr] : nullptr;
+        A.ts = ch->rio_ts >= 0 ? (const float*)io_ptrs[ch->rio_ts] : nullptr;
+        for (int k = 0; k < 4; ++k) A.out_mm[k] = ch->rio_mm[k] >= 0 ? io_ptrs[ch->rio_mm[k]] : nullptr;
+        A.out_tpt = ch->rio_tpt >= 0 ? io_ptrs[ch->rio_tpt] : nullptr;
+        A.dwt_out = ch->rio_dwt >= 0 ? io_ptrs[ch->rio_dwt] : nullptr;
+        hipError_t e = (hipError_t)dsp_internal_launch_rows(&A, n_wf, ch->dev_err, ch->rows_lds_bytes, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "rows kernel launch failed: %s", hipGetErrorString(e));
+        return DSP_OK;
+    }
     const int blocks = vm_blocks(ch, n_wf);
     const int threads = 64 * ch->waves_per_block;
     const int lds = ch->lds_bytes_per_wave * ch->waves_per_block;
@@ -1216,6 +1407,12 @@ int dsp_chain_destroy(dsp_chain* ch) {
 
 int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int* waves_per_block, int* blocks) {
     if (!ch) return fail(DSP_ERR_ARG, "null chain");
+    if (ch->rows_ok && ch->fused_on) {  // a pair of wavefronts per 64 waveforms shares one history ring
+        if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->rows_lds_bytes / 2;
+        if (waves_per_block) *waves_per_block = 2;
+        if (blocks) *blocks = (int)((n_wf + 63) / 64);
+        return DSP_OK;
+    }
     if (ch->rr_ok && ch->fused_on && ch->variant != 1) {
         int wpb, b;
         rr_geometry(ch, n_wf, &wpb, &b);
@@ -1231,6 +1428,7 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
 }
 
 const char* dsp_chain_kernel_name(dsp_chain* ch) {
+    if (ch && ch->rows_ok && ch->fused_on) return dsp_internal_rows_kernel_name();
     if (ch && ch->rr_ok && ch->fused_on && ch->variant != 1) return dsp_internal_energy_rr_kernel_name();
     return (ch && ch->fused_ok && ch->fused_on) ? dsp_internal_energy_kernel_name() : dsp_internal_vm_kernel_name();
 }
@@ -1242,7 +1440,7 @@ int dsp_chain_set_fused(dsp_chain* ch, int enable) {
     // 7 = classic (VM layout); anything else = default
     const int v = (enable >> 1) & 7;
     ch->variant = (v == 7 || !ch->rr_ok) ? 1 : 6;
-    return ((ch->fused_ok || ch->rr_ok) && ch->fused_on) ? 1 : 0;
+    return ((ch->fused_ok || ch->rr_ok || ch->rows_ok) && ch->fused_on) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ single processors

@@ -78,3 +78,41 @@ struct FitArgs {
     void* out;  // [n_fits][4][n_wf] of the compute type: mean, stdev, slope, intercept
 };
 
+
+// arguments of the lane-per-waveform chain kernel (dsp_rows.hip), filled by dsp_chain_execute when a program has that shape
+struct RowsArgs {
+    const void* wf;          // rows
+    int64_t wf_stride;       // elements between rows
+    int32_t wf_offset, len;  // first sample used, samples per waveform (a multiple of 8)
+    int32_t in_kind;         // 0 float32, 1 int16, 2 uint16 rows
+    int32_t sub_mode;        // 1: bl_subtract first
+    const float* bl;         // per-row baseline column or null: bl_const
+    int64_t bl_stride;
+    float bl_const;
+    int32_t pz_kind;         // 1 pole_zero, 2 double_pole_zero
+    int32_t pz_param_nan;    // a NaN time constant: everything downstream is NaN
+    double pz_c;             // pole_zero: exp(-1/tau)
+    double n1, n2, d1, d2;   // double_pole_zero: numerator / denominator coefficients (pole_zero.py:168-174)
+    int32_t trap_kind;       // 0 trap_filter, 1 trap_norm, 2 asym_trap_filter
+    int32_t rise_pow2;       // rise is a power of two: x / rise == x * (1 / rise) exactly
+    int32_t lag[3];
+    int32_t trap_all_nan;    // trap_filter with rise == 0
+    double rr, ll, inv_rr, inv_ll;
+    void* out_mm[4];         // t_min, t_max, a_min, a_max columns (null: not requested)
+    int64_t out_mm_stride[4];
+    int32_t tpt_mode;        // 0 none, 1 backward from a known start, 2 backward from the arg-extremum, 3 / 4 the same walking forward
+    int32_t tpt_use_min;     // the start is t_min (else t_max)
+    const float* thr;        // threshold column or null: thr_const
+    int64_t thr_stride;
+    const float* ts;         // start column or null: ts_const (modes 1, 3)
+    int64_t ts_stride;
+    float thr_const, ts_const;
+    int32_t walk_nan, walk_frac;  // walk_forward is NaN (output NaN) / not an integer (DSPFatal)
+    void* out_tpt;
+    int64_t out_tpt_stride;
+    int32_t dwt_level, dwt_part;  // Haar level (0: none, else 3..8), 'a' or 'd'
+    void* dwt_out;
+    int64_t dwt_stride;
+    int32_t ring_entries;    // R: history samples kept per lane, a multiple of 8, >= largest lag + 16
+    int32_t pad_;
+};

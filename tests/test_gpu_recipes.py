@@ -21,10 +21,13 @@ def _synth(rng, n_wf, wf_len, bl=(9000, 11000), amp=(500, 15000)):
     return x, B[:, 0].astype(np.float32), t0[:, 0]
 
 
-def _run(recipe, tb, **kw):
+def _run(recipe, tb, vm=False, **kw):
     from dspeed_amd.processing_chain import build_processing_chain
 
     chain, mask, tb_out = build_processing_chain(recipe, tb, **kw)
+    if vm:  # the generic waveform VM, whatever specialised kernel the recipe's shape would select
+        chain._ensure()
+        chain._chain.set_fused(0)
     chain.execute()
     return chain, tb_out
 
@@ -177,8 +180,10 @@ def test_energy_recipe_variants_take_the_specialised_kernel():
 
 @pytest.mark.parametrize("trap,targs", [("asym_trap_filter", "8, 4, 125"), ("trap_filter", "100, 30"), ("trap_norm", "64, 16")])
 def test_trapezoid_fused_with_its_reductions_equals_the_unfused_ops(trap, targs):
-    """a trapezoid that only feeds min_max / time_point_thresh is never stored (TRAP_REDUCE): same numbers as the three ops run one
-    after the other -- forward and backward walks, per-event thresholds, start from t_max / t_min / a column, NaN rows, DSPFatal"""
+    """a trapezoid that only feeds min_max / time_point_thresh is never stored (TRAP_REDUCE): on the waveform VM the same numbers as the
+    three ops run one after the other -- forward and backward walks, per-event thresholds, start from t_max / t_min / a column, NaN rows,
+    DSPFatal.  (Behind a pole-zero stage the shape belongs to the lane-per-waveform kernel, which is bit-exact against the oracle:
+    tests/test_gpu_rows_kernel.py; here the VM's fused op is checked against the VM's own unfused ops.)"""
     from dspeed_amd.errors import DSPFatal
 
     rng = np.random.default_rng(77)
@@ -202,7 +207,7 @@ def test_trapezoid_fused_with_its_reductions_equals_the_unfused_ops(trap, targs)
     tpts = {"tp_b": "thr, t_max, 0", "tp_f": "thr, start, 1"}
     for use in ({"tp_b": tpts["tp_b"]}, {"tp_f": tpts["tp_f"]}, {}):
         names = ["t_min", "t_max", "a_min", "a_max", *use]
-        fused_chain, fused = _run(recipe(names, use), tb)
+        fused_chain, fused = _run(recipe(names, use), tb, vm=True)
         plain_chain, plain = _run(recipe(names + ["wf_t"], use), tb)
         from dspeed_amd import _lib
 

@@ -1,0 +1,226 @@
+"""The lane-per-waveform kernel (dsp_rows.hip): [bl_subtract ->] pole_zero | double_pole_zero -> short trapezoid -> min_max /
+time_point_thresh + Haar DWT (BASELINE.json configs[4]).  Every lane walks its waveform in the reference's own operation order, so EVERY
+output -- extremes, their indices, the threshold time point, the wavelet coefficients -- is bit-identical to the oracle run processor by
+processor (reference pole_zero.py:24-198, trap_filters.py:12-227, min_max.py:11-82, time_point_thresh.py:12-92, dwt.py:13-81)."""
+import numpy as np
+import pytest
+
+import oracle
+import recipes
+from dspeed_amd.errors import DSPFatal
+
+pytestmark = pytest.mark.gpu
+M = "dspeed.processors"
+
+
+def _synth(rng, n_wf, wf_len, bl=(-3000, 3000), amp=(500, 15000), dtype=np.int16):
+    i = np.arange(wf_len, dtype=np.float64)[None, :]
+    B = rng.uniform(*bl, (n_wf, 1))
+    A = rng.uniform(*amp, (n_wf, 1))
+    t0 = np.floor(rng.uniform(0.45, 0.55, (n_wf, 1)) * wf_len)
+    x = B + A * np.exp(-(i - t0) / 1716.28) * (i >= t0) + 5.0 * rng.standard_normal((n_wf, wf_len))
+    if np.dtype(dtype).kind in "iu":
+        x = np.rint(x + (4000 if np.dtype(dtype).kind == "u" else 0))
+    return x.astype(dtype), B[:, 0].astype(np.float32)
+
+
+def _run(recipe, tb, fused=True):
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    chain, _, out = build_processing_chain(recipe, tb)
+    chain._ensure()
+    chain._chain.set_fused(1 if fused else 0)
+    chain.execute()
+    return chain, out
+
+
+def _recipe(pz, trap, tpt_args=None, dwt=None, bl=False, outputs=("tp_min", "tp_max", "wf_min", "wf_max")):
+    """pz: ('pole_zero', tau) | ('double_pole_zero', tau1, tau2, frac); trap: ('asym_trap_filter', r, f, l) | ('trap_filter', r, f) | ..."""
+    procs = {}
+    src = "waveform"
+    if bl:
+        procs["wf_bl"] = f"{M}.bl_subtract(waveform, baseline, wf_bl)"
+        src = "wf_bl"
+    procs["wf_pz"] = {"function": pz[0], "module": M, "args": [src, *[str(v) for v in pz[1:]], "wf_pz"]}
+    procs["wf_tr"] = {"function": trap[0], "module": M, "args": ["wf_pz", *[str(v) for v in trap[1:]], "wf_tr"]}
+    procs["tp_min, tp_max, wf_min, wf_max"] = {"function": "min_max", "module": M, "args": ["wf_tr", "tp_min", "tp_max", "wf_min", "wf_max"]}
+    outs = list(outputs)
+    if tpt_args is not None:
+        procs["tp_0"] = {"function": "time_point_thresh", "module": M, "args": ["wf_tr", *tpt_args, "tp_0"]}
+        outs.append("tp_0")
+    if dwt is not None:
+        level, part, n_out = dwt
+        procs["dwt"] = {"function": "discrete_wavelet_transform", "module": M, "args": ["wf_pz", level, "'h'", f"'{part}'", f"dwt({n_out}, 'f')"]}
+        outs.append("dwt")
+    return {"outputs": outs, "processors": procs}
+
+
+def _oracle(wf, pz, trap, bl=None):
+    w = wf.astype(np.float32)
+    if bl is not None:
+        w = oracle.bl_subtract(w, bl)[0]
+    w1, rc = (oracle.pole_zero(w, pz[1]) if pz[0] == "pole_zero" else oracle.double_pole_zero(w, *pz[1:]))
+    assert rc == 0
+    fn = {"asym_trap_filter": oracle.asym_trap_filter, "trap_filter": oracle.trap_filter, "trap_norm": oracle.trap_norm}[trap[0]]
+    w2, rc = fn(w1, *trap[1:])
+    assert rc == 0
+    return w1, w2
+
+
+def _check_minmax(out, w2):
+    tmin, tmax, amin, amax, rc = oracle.min_max(w2)
+    assert rc == 0
+    for nm, want in (("tp_min", tmin), ("tp_max", tmax), ("wf_min", amin), ("wf_max", amax)):
+        assert np.array_equal(out[nm], want, equal_nan=True), nm
+    return tmin, tmax
+
+
+DPZ = ("double_pole_zero", 1716.28, 62.5, 0.02)
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.uint16, np.float32])
+@pytest.mark.parametrize("n_wf", [1, 64, 131])
+def test_c5_recipe_every_output_bit_exact(dtype, n_wf):
+    rng = np.random.default_rng(5 + n_wf)
+    wf, _ = _synth(rng, n_wf, 8192, dtype=dtype, bl=(-3000, 3000))
+    thr = rng.uniform(5.0, 40.0, n_wf).astype(np.float32)
+    chain, out = _run(recipes.C5, {"waveform": wf, "thr": thr})
+    assert chain._chain.kernel_name == "dsp_rows_kernel"
+    w1, w2 = _oracle(wf, DPZ, ("asym_trap_filter", 8, 4, 125))
+    _, tmax = _check_minmax(out, w2)
+    tp0, rc = oracle.time_point_thresh(w2, thr, tmax, 0)
+    assert rc == 0 and np.array_equal(out["tp_0"], tp0, equal_nan=True)
+    assert n_wf < 64 or np.isfinite(tp0).sum() > 0  # (the walk does find crossings: the comparison is not only NaN against NaN)
+    dwt, rc = oracle.dwt_haar(w1, 5, "a", 256)
+    assert rc == 0 and np.array_equal(out["dwt_haar"], dwt)
+
+
+def test_agrees_with_the_waveform_vm_within_its_tolerance():
+    """the same recipe on the generic VM (scan formulation of double_pole_zero, rounding replay of the trapezoid): 1e-6 of the peak"""
+    rng = np.random.default_rng(77)
+    wf, _ = _synth(rng, 40, 8192)
+    thr = np.full(40, 20.0, dtype=np.float32)
+    _, a = _run(recipes.C5, {"waveform": wf, "thr": thr})
+    chain, b = _run(recipes.C5, {"waveform": wf, "thr": thr}, fused=False)
+    assert chain._chain.kernel_name.startswith("dsp_vm")
+    peak = np.maximum(np.abs(a["wf_max"]), np.abs(a["wf_min"]))
+    assert np.max(np.abs(a["wf_max"] - b["wf_max"]) / peak) <= 1e-6
+    assert np.max(np.abs(a["dwt_haar"] - b["dwt_haar"]) / np.max(np.abs(a["dwt_haar"]), axis=1, keepdims=True)) <= 1e-6
+
+
+@pytest.mark.parametrize("trap", [("asym_trap_filter", 10, 6, 100), ("asym_trap_filter", 16, 8, 64), ("trap_norm", 24, 9), ("trap_norm", 32, 8),
+                                  ("trap_filter", 40, 13), ("asym_trap_filter", 8, 0, 136)])
+@pytest.mark.parametrize("pz", [DPZ, ("pole_zero", 1716.28)])
+def test_other_trapezoids_and_pole_zero(trap, pz):
+    rng = np.random.default_rng(hash((trap, pz[0])) % 2**32)
+    wf, bl = _synth(rng, 70, 2048, dtype=np.float32, bl=(9000, 11000))
+    thr = rng.uniform(5.0, 200.0, 70).astype(np.float32)
+    rec = _recipe(pz, trap, tpt_args=["thr", "tp_max", 0], bl=True)
+    chain, out = _run(rec, {"waveform": wf, "baseline": bl, "thr": thr})
+    assert chain._chain.kernel_name == "dsp_rows_kernel"
+    _, w2 = _oracle(wf, pz, trap, bl=bl)
+    _, tmax = _check_minmax(out, w2)
+    tp0, rc = oracle.time_point_thresh(w2, thr, tmax, 0)
+    assert rc == 0 and np.array_equal(out["tp_0"], tp0, equal_nan=True)
+
+
+@pytest.mark.parametrize("walk", [0, 1])
+@pytest.mark.parametrize("start", ["tp_max", "tp_min", "ts", "3000"])
+def test_time_point_thresh_starts_and_directions(walk, start):
+    rng = np.random.default_rng(11 + walk)
+    n = 96
+    wf, _ = _synth(rng, n, 4096)
+    thr = rng.uniform(-30.0, 60.0, n).astype(np.float32)
+    ts = rng.integers(0, 4096, n).astype(np.float32)
+    ts[:3] = (0, 4095, 1)
+    rec = _recipe(DPZ, ("asym_trap_filter", 8, 4, 125), tpt_args=["thr", start, walk])
+    chain, out = _run(rec, {"waveform": wf, "thr": thr, "ts": ts})
+    assert chain._chain.kernel_name == "dsp_rows_kernel"
+    _, w2 = _oracle(wf, DPZ, ("asym_trap_filter", 8, 4, 125))
+    tmin, tmax = _check_minmax(out, w2)
+    t_start = {"tp_max": tmax, "tp_min": tmin, "ts": ts, "3000": np.float32(3000)}[start]
+    tp0, rc = oracle.time_point_thresh(w2, thr, t_start, walk)
+    assert rc == 0 and np.array_equal(out["tp_0"], tp0, equal_nan=True)
+    assert 0 < np.isfinite(tp0).sum()
+
+
+@pytest.mark.parametrize("level,part", [(3, "a"), (4, "d"), (5, "d"), (6, "a"), (8, "a")])
+def test_haar_levels_and_detail_coefficients(level, part):
+    rng = np.random.default_rng(level)
+    wf, _ = _synth(rng, 65, 4096)
+    n_out = 4096 >> level
+    rec = _recipe(DPZ, ("asym_trap_filter", 8, 4, 125), dwt=(level, part, n_out))
+    chain, out = _run(rec, {"waveform": wf})
+    assert chain._chain.kernel_name == "dsp_rows_kernel"
+    w1, w2 = _oracle(wf, DPZ, ("asym_trap_filter", 8, 4, 125))
+    _check_minmax(out, w2)
+    dwt, rc = oracle.dwt_haar(w1, level, part, n_out)
+    assert rc == 0 and np.array_equal(out["dwt"], dwt)
+
+
+@pytest.mark.parametrize("wf_len", [160, 152, 1024, 8192 + 512])
+def test_lengths_around_the_ring(wf_len):
+    """waveforms shorter than the history ring (152 entries for the 8/4/125 trapezoid), exactly one ring, many rings"""
+    rng = np.random.default_rng(wf_len)
+    wf, _ = _synth(rng, 67, wf_len)
+    thr = np.full(67, 15.0, dtype=np.float32)
+    rec = _recipe(DPZ, ("asym_trap_filter", 8, 4, 125), tpt_args=["thr", "tp_max", 0])
+    chain, out = _run(rec, {"waveform": wf, "thr": thr})
+    assert chain._chain.kernel_name == "dsp_rows_kernel"
+    _, w2 = _oracle(wf, DPZ, ("asym_trap_filter", 8, 4, 125))
+    _, tmax = _check_minmax(out, w2)
+    tp0, rc = oracle.time_point_thresh(w2, thr, tmax, 0)
+    assert rc == 0 and np.array_equal(out["tp_0"], tp0, equal_nan=True)
+
+
+def test_nan_and_infinite_samples_follow_the_reference():
+    rng = np.random.default_rng(3)
+    wf, _ = _synth(rng, 80, 2048, dtype=np.float32, bl=(9000, 11000))
+    wf[5, 1000] = np.nan          # NaN anywhere: every output of that row is NaN (pole_zero.py:159-162 and downstream)
+    wf[9, 0] = np.nan
+    wf[17, 2047] = np.nan         # ... also when it is the very last sample
+    wf[23, 700] = np.inf          # an infinity turns into inf - inf = NaN inside the recursion
+    wf[31, 2047] = np.inf         # in the last sample it stays an infinity: the extremes see it
+    wf[33, 2046] = -np.inf
+    thr = np.full(80, 20.0, dtype=np.float32)
+    thr[40] = np.nan              # NaN threshold: only tp_0 is NaN
+    rec = _recipe(DPZ, ("asym_trap_filter", 8, 4, 125), tpt_args=["thr", "tp_max", 0], dwt=(5, "a", 64))
+    chain, out = _run(rec, {"waveform": wf, "thr": thr})
+    assert chain._chain.kernel_name == "dsp_rows_kernel"
+    w1, _ = oracle.double_pole_zero(wf, *DPZ[1:])
+    w2, _ = oracle.asym_trap_filter(w1, 8, 4, 125)
+    tmin, tmax, amin, amax, _ = oracle.min_max(w2)
+    for nm, want in (("tp_min", tmin), ("tp_max", tmax), ("wf_min", amin), ("wf_max", amax)):
+        assert np.array_equal(out[nm], want, equal_nan=True), nm
+    assert np.isnan(out["wf_max"][[5, 9, 17, 23]]).all() and np.isinf(out["wf_max"][31])
+    tp0, _ = oracle.time_point_thresh(w2, thr, tmax, 0)
+    assert np.array_equal(out["tp_0"], tp0, equal_nan=True) and np.isnan(out["tp_0"][40]) and not np.isnan(out["wf_max"][40])
+    dwt, _ = oracle.dwt_haar(w1, 5, "a", 64)
+    assert np.array_equal(out["dwt"], dwt, equal_nan=True)
+
+
+def test_fatal_start_values_name_the_row():
+    rng = np.random.default_rng(4)
+    wf, _ = _synth(rng, 70, 1024)
+    thr = np.full(70, 20.0, dtype=np.float32)
+    rec = _recipe(DPZ, ("asym_trap_filter", 8, 4, 125), tpt_args=["thr", "ts", 0])
+    ts = np.full(70, 500.0, dtype=np.float32)
+    ts[66] = 500.5
+    with pytest.raises(DSPFatal, match="starting index must be an integer") as e:
+        _run(rec, {"waveform": wf, "thr": thr, "ts": ts})
+    assert e.value.wf_range == range(66, 67)
+    ts[66] = 1024.0
+    with pytest.raises(DSPFatal, match="out of range"):
+        _run(rec, {"waveform": wf, "thr": thr, "ts": ts})
+    ts[66] = np.nan  # a NaN start is a NaN result, not an error (time_point_thresh.py:57-65)
+    _, out = _run(rec, {"waveform": wf, "thr": thr, "ts": ts})
+    assert np.isnan(out["tp_0"][66]) and np.isfinite(out["wf_max"]).all()
+
+
+def test_shapes_outside_the_kernel_fall_back_to_the_vm():
+    """rise shorter than one block of the kernel, or a trapezoid whose history does not fit: the generic VM takes the recipe"""
+    rng = np.random.default_rng(6)
+    wf, _ = _synth(rng, 8, 4096)
+    for trap in (("asym_trap_filter", 4, 4, 125), ("trap_filter", 625, 188)):
+        chain, out = _run(_recipe(DPZ, trap), {"waveform": wf})
+        assert chain._chain.kernel_name.startswith("dsp_vm")
