@@ -82,6 +82,10 @@ extern "C" const char* dsp_internal_energy_rr_kernel_name();
 extern "C" int dsp_internal_launch_rows(const RowsArgs* A, int64_t n_wf, int* err, int lds_bytes, hipStream_t stream);
 extern "C" int dsp_internal_set_rows_lds(int lds_bytes);
 extern "C" const char* dsp_internal_rows_kernel_name();
+extern "C" int dsp_internal_fir_mfma_lds_bytes(int kend);
+extern "C" int dsp_internal_launch_fir_mfma(const FirArgs* A, int64_t n_wf, int lds_bytes, hipStream_t stream);
+extern "C" int dsp_internal_set_fir_mfma_lds(int lds_bytes);
+extern "C" const char* dsp_internal_fir_mfma_kernel_name();
 
 namespace {
 
@@ -163,7 +167,78 @@ struct dsp_chain {
     RowsArgs rows{};
     int rows_lds_bytes = 0;
     int rio_wf = -1, rio_bl = -1, rio_thr = -1, rio_ts = -1, rio_mm[4] = {-1, -1, -1, -1}, rio_tpt = -1, rio_dwt = -1;
+    // matrix-core FIR kernel (dsp_fir_mfma.hip): LOAD [-> BL_SUBTRACT] -> CONVOLVE_AMAX ('v') x 1..4 -> STORE_SCALARs
+    bool fir_ok = false;
+    FirArgs fir{};
+    int fir_lds_bytes = 0;
+    int fio_wf = -1, fio_bl = -1, fio_taps[DSP_FIR_MAXK] = {-1, -1, -1, -1}, fio_out[DSP_FIR_MAXK] = {-1, -1, -1, -1};
 };
+
+static bool match_fir_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, const int32_t* slot_len, int n_slots, bool f64) {
+    const DevProgram& P = ch->host;
+    if (f64 || n_ops < 3 || n_slots != 1 || ops[0].opcode != DSP_OP_LOAD) return false;
+    const dsp_op& ld = ops[0];
+    const int s = ld.dst, wdt = io[ld.io].dtype, n = slot_len[s];
+    if (wdt != DSP_F32 && wdt != DSP_I16 && wdt != DSP_U16) return false;
+    const int es = wdt == DSP_F32 ? 4 : 2, align = wdt == DSP_F32 ? 16 : 8;  // 4 samples per staging load
+    if ((io[ld.io].row_stride * es) % align != 0 || (io[ld.io].offset * es) % align != 0) return false;
+    FirArgs& A = ch->fir;
+    memset(&A, 0, sizeof A);
+    int i = 1;
+    if (ops[i].opcode == DSP_OP_BL_SUBTRACT) {
+        const dsp_op& bs = ops[i++];
+        if (bs.dst != s || bs.src != s) return false;
+        if (bs.sp[0].kind == DSP_ARG_INPUT && io[bs.sp[0].index].dtype == DSP_F32) {
+            ch->fio_bl = bs.sp[0].index;
+            A.bl_stride = io[ch->fio_bl].row_stride;
+        } else if (bs.sp[0].kind == DSP_ARG_CONST) {
+            A.bl_const = (float)bs.sp[0].value;
+        } else {
+            return false;
+        }
+        A.sub_mode = 1;
+    }
+    int regs[DSP_FIR_MAXK], nk = 0, max_m = 0;
+    for (; i < n_ops && ops[i].opcode == DSP_OP_CONVOLVE_AMAX; ++i) {
+        const dsp_op& o = ops[i];
+        if (nk == DSP_FIR_MAXK || o.src != s || o.ip[0] != 'v' || o.ip[1] != 0 || io[o.io].dtype != DSP_F32) return false;
+        const int m = o.ip[3] > 0 ? o.ip[3] : io[o.io].len, p = n - m + 1;
+        if (m < 64 || p < 1 || p > 320 || o.ip[2] != p) return false;  // (a short kernel is the VM's business)
+        ch->fio_taps[nk] = o.io;
+        A.m[nk] = m;
+        A.p[nk] = p;
+        regs[nk] = o.dst;
+        if (m > max_m) max_m = m;
+        ++nk;
+    }
+    if (nk == 0) return false;
+    for (; i < n_ops; ++i) {
+        const dsp_op& o = ops[i];
+        if (o.opcode != DSP_OP_STORE_SCALAR || io[o.io].dtype != DSP_F32) return false;
+        int k = 0;
+        while (k < nk && (regs[k] != o.ip[0] || ch->fio_out[k] >= 0)) ++k;
+        if (k == nk) return false;
+        ch->fio_out[k] = o.io;
+        A.out_stride[k] = io[o.io].row_stride;
+    }
+    for (int k = 0; k < nk; ++k)
+        if (ch->fio_out[k] < 0) return false;
+    int kend = n < 319 + max_m ? n : 319 + max_m;
+    kend = ((kend + 31) / 32) * 32;
+    if (io[ld.io].offset + kend > io[ld.io].row_stride) return false;  // the staging loads run to the end of the last 32-sample stage
+    A.wf_stride = io[ld.io].row_stride;
+    A.wf_offset = io[ld.io].offset;
+    A.n = n;
+    A.in_kind = wdt == DSP_F32 ? 0 : (wdt == DSP_I16 ? 1 : 2);
+    A.n_kernels = nk;
+    A.kend = kend;
+    A.scan_before = ld.ip[0];
+    A.scan_after = ld.ip[1];
+    ch->fio_wf = ld.io;
+    ch->fir_lds_bytes = dsp_internal_fir_mfma_lds_bytes(kend);
+    (void)P;
+    return ch->fir_lds_bytes <= 80 * 1024;
+}
 
 // Does the program have the shape of the lane-per-waveform kernel?  Fills ch->rows / ch->rio_* and returns true if so.
 //   LOAD s;  [BL_SUBTRACT s <- s];  POLE_ZERO | DOUBLE_POLE_ZERO s <- s;  then in any order: one TRAP_REDUCE of s, at most one DWT_HAAR of s
@@ -177,6 +252,7 @@ static bool match_rows_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const 
     const dsp_op& ld = ops[i++];
     const int s = ld.dst;
     const int wdt = io[ld.io].dtype, len = slot_len[s];
+    if (ld.ip[0] != 0 || ld.ip[1] != 0) return false;
     if ((wdt != DSP_F32 && wdt != DSP_I16 && wdt != DSP_U16) || !P.io[ld.io].vec_ok || len % 8 != 0 || len < 16) return false;
     auto f32_or_const = [&](const dsp_scalar_arg& a) { return a.kind == DSP_ARG_CONST || (a.kind == DSP_ARG_INPUT && io[a.index].dtype == DSP_F32); };
     const dsp_op* bs = nullptr;
@@ -857,6 +933,8 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             case DSP_OP_LOAD:
                 if (!check_slot(P, o.dst) || !need_io(DSP_IO_WF_IN)) return fail(DSP_ERR_ARG, "op %d: bad LOAD", i);
                 if (io[o.io].len != slot_len[o.dst]) return fail(DSP_ERR_ARG, "op %d: LOAD length mismatch", i);
+                if (o.ip[0] < 0 || o.ip[1] < 0 || o.ip[0] > io[o.io].offset || (int64_t)io[o.io].offset + io[o.io].len + o.ip[1] > io[o.io].row_stride)
+                    return fail(DSP_ERR_ARG, "op %d: LOAD screens samples outside the row (ip[0], ip[1])", i);
                 break;
             case DSP_OP_STORE:
                 if (!check_slot(P, o.src) || !need_io(DSP_IO_WF_OUT)) return fail(DSP_ERR_ARG, "op %d: bad STORE", i);
@@ -1107,7 +1185,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         const dsp_op* tp = (pz && n_ops > i && ops[i].opcode == DSP_OP_TRAP_PICKOFF) ? &ops[i++] : nullptr;
         const dsp_op* st = (tp && n_ops > i && ops[i].opcode == DSP_OP_STORE_SCALAR) ? &ops[i++] : nullptr;
         const int wdt = ld ? io[ld->io].dtype : -1;
-        const bool shape = !f64 && st && i == n_ops && n_slots == 1 && (wdt == DSP_F32 || wdt == DSP_I16 || wdt == DSP_U16) && P.io[ld->io].vec_ok &&
+        const bool shape = !f64 && st && i == n_ops && n_slots == 1 && ld->ip[0] == 0 && ld->ip[1] == 0 && (wdt == DSP_F32 || wdt == DSP_I16 || wdt == DSP_U16) && P.io[ld->io].vec_ok &&
                            (!bs || (bs->dst == 0 && bs->src == 0 && bs->sp[0].kind != DSP_ARG_REG)) && pz->dst == 0 && pz->src == 0 &&
                            tp->src == 0 && tp->sp[0].kind != DSP_ARG_REG && st->ip[0] == tp->dst &&
                            (slot_len[0] == 1024 || slot_len[0] == 2048 || slot_len[0] == 4096 || slot_len[0] == 8192);
@@ -1201,6 +1279,11 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         }
     }
 
+    ch->fir_ok = match_fir_shape(ch.get(), ops, n_ops, io, slot_len, n_slots, f64);
+    if (ch->fir_ok) {
+        const char* env = getenv("DSPEED_HIP_NO_FUSED");
+        ch->fused_on = !(env && env[0] == '1');
+    }
     ch->rows_ok = match_rows_shape(ch.get(), ops, n_ops, io, n_io, slot_len, n_slots, dev_index, f64);
     if (!ch->rows_ok) {
         ch->rio_wf = ch->rio_bl = ch->rio_thr = ch->rio_ts = ch->rio_tpt = ch->rio_dwt = -1;
@@ -1231,6 +1314,10 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         hipError_t e = (hipError_t)dsp_internal_set_energy_lds(ch->fused_trap, ch->fused_npf, classic_lds);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(energy kernel, %d): %s", classic_lds, hipGetErrorString(e));
     }
+    if (ch->fir_ok && ch->fir_lds_bytes > 64 * 1024) {
+        hipError_t e = (hipError_t)dsp_internal_set_fir_mfma_lds(ch->fir_lds_bytes);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(FIR kernel, %d): %s", ch->fir_lds_bytes, hipGetErrorString(e));
+    }
     if (ch->rows_ok && ch->rows_lds_bytes > 64 * 1024) {
         hipError_t e = (hipError_t)dsp_internal_set_rows_lds(ch->rows_lds_bytes);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(rows kernel, %d): %s", ch->rows_lds_bytes, hipGetErrorString(e));
@@ -1245,6 +1332,11 @@ static bool rows_applies(const dsp_chain* ch, void* const* io_ptrs) {
     if (reinterpret_cast<uintptr_t>(io_ptrs[ch->rio_wf]) & 15u) return false;
     if (ch->rio_dwt >= 0 && (reinterpret_cast<uintptr_t>(io_ptrs[ch->rio_dwt]) & 15u)) return false;
     return true;
+}
+
+static bool fir_applies(const dsp_chain* ch, void* const* io_ptrs) {
+    if (!ch->fir_ok || !ch->fused_on) return false;
+    return (reinterpret_cast<uintptr_t>(io_ptrs[ch->fio_wf]) & 15u) == 0;
 }
 
 static int chain_blocks(const dsp_chain* ch, int64_t n_wf, int wpb, int cap_waves) {
@@ -1285,6 +1377,18 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         ptrs.p[k] = io_ptrs[k];
     }
     (void)hipGetLastError();  // launch checks below report this launch, not a stale error of an unrelated earlier call
+    if (fir_applies(ch, io_ptrs)) {
+        FirArgs A = ch->fir;
+        A.wf = io_ptrs[ch->fio_wf];
+        A.bl = ch->fio_bl >= 0 ? (const float*)io_ptrs[ch->fio_bl] : nullptr;
+        for (int k = 0; k < A.n_kernels; ++k) {
+            A.taps[k] = (const float*)io_ptrs[ch->fio_taps[k]];
+            A.out[k] = io_ptrs[ch->fio_out[k]];
+        }
+        hipError_t e = (hipError_t)dsp_internal_launch_fir_mfma(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "FIR kernel launch failed: %s", hipGetErrorString(e));
+        return DSP_OK;
+    }
     if (rows_applies(ch, io_ptrs)) {
         RowsArgs A = ch->rows;
         A.wf = io_ptrs[ch->rio_wf];
@@ -1407,6 +1511,12 @@ int dsp_chain_destroy(dsp_chain* ch) {
 
 int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int* waves_per_block, int* blocks) {
     if (!ch) return fail(DSP_ERR_ARG, "null chain");
+    if (ch->fir_ok && ch->fused_on) {  // 8 wavefronts per 64 waveforms and kernel
+        if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->fir_lds_bytes / 8;
+        if (waves_per_block) *waves_per_block = 8;
+        if (blocks) *blocks = (int)((n_wf + 63) / 64) * ch->fir.n_kernels;
+        return DSP_OK;
+    }
     if (ch->rows_ok && ch->fused_on) {  // a pair of wavefronts per 64 waveforms shares one history ring
         if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->rows_lds_bytes / 2;
         if (waves_per_block) *waves_per_block = 2;
@@ -1428,6 +1538,7 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
 }
 
 const char* dsp_chain_kernel_name(dsp_chain* ch) {
+    if (ch && ch->fir_ok && ch->fused_on) return dsp_internal_fir_mfma_kernel_name();
     if (ch && ch->rows_ok && ch->fused_on) return dsp_internal_rows_kernel_name();
     if (ch && ch->rr_ok && ch->fused_on && ch->variant != 1) return dsp_internal_energy_rr_kernel_name();
     return (ch && ch->fused_ok && ch->fused_on) ? dsp_internal_energy_kernel_name() : dsp_internal_vm_kernel_name();
@@ -1440,7 +1551,7 @@ int dsp_chain_set_fused(dsp_chain* ch, int enable) {
     // 7 = classic (VM layout); anything else = default
     const int v = (enable >> 1) & 7;
     ch->variant = (v == 7 || !ch->rr_ok) ? 1 : 6;
-    return ((ch->fused_ok || ch->rr_ok || ch->rows_ok) && ch->fused_on) ? 1 : 0;
+    return ((ch->fused_ok || ch->rr_ok || ch->rows_ok || ch->fir_ok) && ch->fused_on) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ single processors

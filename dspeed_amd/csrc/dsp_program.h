@@ -116,3 +116,24 @@ struct RowsArgs {
     int32_t ring_entries;    // R: history samples kept per lane, a multiple of 8, >= largest lag + 16
     int32_t pad_;
 };
+
+// arguments of the matrix-core FIR kernel (dsp_fir_mfma.hip): convolve_wf 'v' + numpy.amax of up to DSP_FIR_MAXK kernels on one waveform
+#define DSP_FIR_MAXK 4
+struct FirArgs {
+    const void* wf;
+    int64_t wf_stride;       // elements between rows
+    int32_t wf_offset, n;    // first sample, samples of the slice the kernels run over
+    int32_t in_kind;         // 0 float32, 1 int16, 2 uint16 rows
+    int32_t sub_mode;        // 1: bl_subtract first
+    const float* bl;
+    int64_t bl_stride;
+    float bl_const;
+    int32_t n_kernels;
+    const float* taps[DSP_FIR_MAXK];  // the kernels as the recipe holds them (np.convolve flips them)
+    int32_t m[DSP_FIR_MAXK], p[DSP_FIR_MAXK];  // taps, valid outputs n - m + 1
+    void* out[DSP_FIR_MAXK];
+    int64_t out_stride[DSP_FIR_MAXK];
+    int32_t kend;            // samples the product runs over: a multiple of 32, <= the row's length
+    int32_t scan_before, scan_after;  // samples before / after the slice that are screened for NaN (DSP_OP_LOAD ip[0..1])
+    int32_t pad_;
+};

@@ -156,6 +156,19 @@ __device__ __forceinline__ void op_load(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) 
         case DSP_U32: nan = load_slot<T, uint32_t>(cx, s, cx.template io_ptr<const uint32_t>(op.io) + at, io.len, vec_ok); break;
         default: nan = load_slot<T, double>(cx, s, cx.template io_ptr<const double>(op.io) + at, io.len, vec_ok); break;
     }
+    if (op.ip[0] > 0 || op.ip[1] > 0) {  // the slice of a longer waveform, first read by a processor whose NaN rule covers all of it
+        for (int part = 0; part < 2; ++part) {
+            const int cnt = op.ip[part];
+            const int64_t first = part == 0 ? at - cnt : at + io.len;
+            for (int e = lane_id(); e < cnt; e += 64) {
+                switch (io.dtype) {
+                    case DSP_F32: { const float x = cx.template io_ptr<const float>(op.io)[first + e]; nan |= (x != x); break; }
+                    case DSP_F64: { const double x = cx.template io_ptr<const double>(op.io)[first + e]; nan |= (x != x); break; }
+                    default: break;  // (integer rows hold no NaN)
+                }
+            }
+        }
+    }
     if (wave_any(nan))  // (the samples are all there: what reads the slot as a whole sees a NaN waveform, a store writes it as it is)
         cx.set_some_nan(op.dst);
     else

@@ -1548,6 +1548,8 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
     # --- slice push-down: an element-wise result (bl_subtract) that is read ONLY through one constant slice [lo:hi] -- the
     # long-FIR recipes do that, icpc-dsp-config.json:160-239 -- is computed on that slice alone: a 6092-sample slot instead of
     # an 8192-sample one plus a copy.  Same values: the op is per sample.
+    whole_nan_rule = {}  # sliced-input variable -> (samples before, samples after) the slice that a LOAD screens for NaN
+
     def slices_of(v):
         found, plain = set(), False
         for _fn, a2, _k in steps:
@@ -1569,6 +1571,11 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
         (lo, hi), = found
         if not (0 <= lo < hi <= (src_v.length or 0)):
             continue
+        # ... except for bl_subtract's NaN rule, which looks at the WHOLE waveform (bl_subtract.py:41-44): the load of the slice also screens
+        # the samples outside it (LOAD ip[0..1]); another processor reading the same slice of the input as a plain view must not see that
+        if any(isinstance(x, tuple) and x[0] == "slice" and x[1] is src_v and (x[2], x[3]) == (lo, hi) for _f, a2, _k in steps for x in a2):
+            continue
+        whole_nan_rule[f"{src_v.name}[{lo}:{hi}]"] = (lo, src_v.length - hi)
         new_args = list(args)
         new_args[0] = ("slice", src_v, lo, hi)
         steps[si] = (fn, new_args, key)
@@ -1650,7 +1657,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             io = p.add_io(f"in:{v.name}", _lib.IO_WF_IN, col.dtype, v.length, v.offset, full_len)
             in_bind[f"in:{v.name}"] = v
             v.slot = new_slot(v.length)
-            p.add_op(_lib.OP_LOAD, dst=v.slot, io=io)
+            p.add_op(_lib.OP_LOAD, dst=v.slot, io=io, ip=whole_nan_rule.get(v.name, ()))
         return v
 
     def scalar_operand(a, args, integer=False, what=""):
