@@ -368,7 +368,7 @@ struct EnergyPlan {
 // IN: waveform element type in HBM: 0 float32, 1 int16, 2 uint16 (digitiser samples; widened to float32 while staging, exactly
 // like the reference's ufunc casting picks the float32 loop for them, processing_chain.py:1565-1572)
 template <int NPF, int KIND, int S, int IN>
-__global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, EnergyPlan PL, int64_t n_wf, int* err) {
+__global__ void __launch_bounds__(256, NPF >= 32 ? 1 : 2) dsp_energy_rr_kernel(EnergyArgs A, EnergyPlan PL, int64_t n_wf, int* err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int C = 4 * NPF + 1, len = 256 * NPF, NG = (C - 1) / 8, CS = (C - 1) / S, NGS = CS / 8;
     constexpr int BS = CS >= 16 ? 16 : CS;  // samples per capture block
@@ -383,8 +383,8 @@ __global__ void __launch_bounds__(256, 2) dsp_energy_rr_kernel(EnergyArgs A, Ene
     float* mine = slot + lane * C;
     // per-lane side array (pitch 9, odd): group-end prefix sums of pass 2, later the group-start states of the replay.  Kept in
     // LDS so that "the value of group gi" with a run-time gi is an address, not a register select chain
-    constexpr int AUXP = 9;
-    static_assert(NG + 1 <= AUXP && S * NGS + 1 <= AUXP, "side array too small");
+    constexpr int AUXP = NG + 1 <= 9 ? 9 : ((NG + 1) | 1);  // (9 for up to 4096 samples, 17 for 8192; the host sizes the region the same way)
+    static_assert(NG + 1 <= AUXP && S * NGS + 1 <= AUXP && (AUXP & 1) == 1, "side array too small");
     float* aux = slot + 64 * C + 16 + lane * AUXP;
     const float* lagp[3];
 #pragma unroll
@@ -715,6 +715,10 @@ int launch_rr_kind(const EnergyArgs& A, const EnergyPlan& PL, int npf, int64_t n
         case 4: hipLaunchKernelGGL((dsp_energy_rr_kernel<4, KIND, S, IN>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
         case 8: hipLaunchKernelGGL((dsp_energy_rr_kernel<8, KIND, S, IN>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
         case 16: hipLaunchKernelGGL((dsp_energy_rr_kernel<16, KIND, S, IN>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 32:  // 8192 samples (production LEGEND rows): 129 samples per lane, one wavefront per SIMD (512-register budget, 36 KB of LDS)
+            if (S != 1) return (int)hipErrorInvalidValue;
+            hipLaunchKernelGGL((dsp_energy_rr_kernel<32, KIND, 1, IN>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err);
+            break;
         default: return (int)hipErrorInvalidValue;
     }
     return (int)hipGetLastError();

@@ -1239,7 +1239,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             ch->wf_dtype = wdt;
             const char* env = getenv("DSPEED_HIP_NO_FUSED");
             ch->fused_on = !(env && env[0] == '1');
-            if (slot_len[0] <= 4096) {  // register-resident kernel: C = len/64 + 1 samples per lane, linear LDS image of the waveform
+            {  // register-resident kernel: C = len/64 + 1 samples per lane, linear LDS image of the waveform (1024 .. 8192 samples)
                 EnergyArgs& I = ch->rr;
                 I = F;
                 const int Ci = slot_len[0] / 64 + 1;
@@ -1249,7 +1249,8 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 int guard = 2 * Ci + 8;  // zeros below the image: lagged reads before sample 0
                 guard = ((guard + 3) / 4) * 4;
                 I.slot_off = guard;
-                int elems = guard + 64 * Ci + 16 + 64 * 9 + 32;  // image, tail, per-lane side array (9 per lane), capture buffer (2 x 16)
+                const int ng1 = (Ci - 1) / 8 + 1, auxp = ng1 <= 9 ? 9 : (ng1 | 1);
+                int elems = guard + 64 * Ci + 16 + 64 * auxp + 32;  // image, tail, per-lane side array (auxp per lane), capture buffer (2 x 16)
                 elems = ((elems + 3) / 4) * 4;
                 I.lds_elems_per_wave = elems;
                 ch->rr_lds_bytes = elems * 4;

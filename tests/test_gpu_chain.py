@@ -68,7 +68,7 @@ def test_energy_chain_vs_oracle(wf_len, rise, flat, fused):
 
 
 @pytest.mark.parametrize("fused", [1, 15])
-@pytest.mark.parametrize("wf_len,rise,flat", [(4096, 300, 50), (2048, 100, 31), (1024, 40, 9)])
+@pytest.mark.parametrize("wf_len,rise,flat", [(4096, 300, 50), (2048, 100, 31), (1024, 40, 9), (8192, 600, 100)])
 def test_energy_pickoff_position_sweep(wf_len, rise, flat, fused):
     """the picked-off samples are caught at run-time positions: sweep the time point over lane-chunk boundaries (C = len/64 + 1
     samples per lane in the default kernel), capture-block boundaries, both ends of the waveform, integer and fractional times"""
@@ -97,7 +97,7 @@ def test_energy_pickoff_position_sweep(wf_len, rise, flat, fused):
 
 
 @pytest.mark.parametrize("dtype", [np.int16, np.uint16])
-@pytest.mark.parametrize("wf_len,rise,flat", [(4096, 625, 188), (2048, 300, 7), (1024, 64, 16)])
+@pytest.mark.parametrize("wf_len,rise,flat", [(4096, 625, 188), (2048, 300, 7), (1024, 64, 16), (8192, 1250, 376)])
 def test_energy_chain_on_digitiser_samples(dtype, wf_len, rise, flat):
     """16-bit rows (what the digitisers write) take the float32 loop like in the reference (ufunc casting, processing_chain.py:1565-1572):
     the default kernel widens them while staging.  Same results as the float32 copy of the same samples, the VM and the oracle."""
