@@ -129,6 +129,129 @@ def test_whole_ge_recipe_is_one_device_program(t0_kind, rows_dtype):
     assert np.all(np.abs(out["tp_0_est"] - (t0_ns + 0.5 * 8192 * 16)) < 0.08 * 8192 * 16)
 
 
+def test_index_outputs_are_bit_exact_on_the_devices_own_waveforms():
+    """SURVEY H5 made checkable: every index / threshold / pick-off / extremum output of the recipe is recomputed by the ORACLE from the
+    DEVICE's own intermediate waveforms and per-event values (requested as extra outputs, a few at a time: they all live in LDS) and must
+    agree bit for bit in 100 % of the rows.  Whatever differs end to end can then only come from the <= 1e-6 differences of the filtered
+    waveforms themselves, which are asserted beside it; and the production program (no extra outputs, fused ops) must print the same
+    numbers as the instrumented ones."""
+    from dspeed_amd.processing_chain import WaveformInput, build_processing_chain
+
+    rng = np.random.default_rng(2027)
+    n, dt = 96, 16.0
+    wf, bl = _synth(rng, n)
+    t0_ns = (rng.integers(2900, 3100, n) * 16).astype(F)
+    tb = {"waveform": WaveformInput(wf, dt, t0_ns), "baseline": bl}
+    off = _convert(t0_ns, 0.0, 0.0, 1.0 / dt)
+    to_ns = lambda t: _convert(t, off.astype(np.float64), 0.0, dt)  # noqa: E731
+    exact = lambda got, want, what: np.testing.assert_array_equal(got, want, err_msg=what)  # noqa: E731  (NaN == NaN; 100 % of the rows)
+
+    def to_index(t_ns, what):
+        """the sample index a device time stands for (the conversion is exact on the way back: checked)"""
+        idx = np.rint(t_ns.astype(np.float64) / dt - off.astype(np.float64)).astype(F)
+        idx[np.isnan(t_ns)] = np.nan
+        exact(to_ns(idx), t_ns, f"{what}: not a sample of the waveform's grid")
+        return idx
+
+    def run(outs):
+        chain, _, o = build_processing_chain(dict(recipes.ICPC, outputs=list(outs)), tb)
+        chain.execute()
+        return o
+
+    chain_p, _, prod = build_processing_chain(recipes.ICPC, tb)
+    chain_p.execute()
+    seen = {}
+
+    def same_as_production(o, names):
+        for k in names:
+            exact(o[k], prod[k], f"instrumented vs production program: {k}")
+            seen[k] = True
+
+    # ---- the t0 search: extremum of the t0-filtered waveform, threshold walks on it and on the asymmetric trapezoid
+    g = run(["bl_std", "tp_0_est", "tp_0_atrap", "tp_start", "wf_t0_filter", "wf_atrap"])
+    _, tp_start, _, _, _ = oracle.min_max(g["wf_t0_filter"])
+    exact(g["tp_start"], to_ns(tp_start), "tp_start")
+    exact(g["tp_0_atrap"], to_ns(oracle.time_point_thresh(g["wf_atrap"], g["bl_std"], tp_start, 0)[0]), "tp_0_atrap")
+    exact(g["tp_0_est"], to_ns(oracle.time_point_thresh(g["wf_t0_filter"], g["bl_std"], tp_start, 0)[0]), "tp_0_est")
+    same_as_production(g, ["bl_std", "tp_0_est", "tp_0_atrap"])
+    wt0_dev, atrap_dev = g["wf_t0_filter"], g["wf_atrap"]
+    # ---- rise-time points on the pole-zero corrected waveform, thresholds from the trapezoid's maximum
+    g = run(["trapTmax", "tp_0_est", "tp_100", "tp_99", "tp_90", "tp_50", "tp_10", "wf_pz", "wf_trap"])
+    pz, tmx = g["wf_pz"], g["trapTmax"]
+    tp0 = to_index(g["tp_0_est"], "tp_0_est")
+    exact(tmx, np.max(g["wf_trap"], axis=1), "trapTmax")
+    t100 = oracle.time_point_thresh(pz, tmx, tp0, 1)[0]
+    t99 = oracle.time_point_thresh(pz, F(0.99) * tmx, tp0, 1)[0]
+    t90 = oracle.time_point_thresh(pz, tmx * F(0.9), t99, 0)[0]
+    t50 = oracle.time_point_thresh(pz, tmx * F(0.5), t90, 0)[0]
+    t10 = oracle.time_point_thresh(pz, tmx * F(0.1), t50, 0)[0]
+    for k, v in (("tp_100", t100), ("tp_99", t99), ("tp_90", t90), ("tp_50", t50), ("tp_10", t10)):
+        exact(g[k], to_ns(v), k)
+    same_as_production(g, ["trapTmax", "tp_100", "tp_99", "tp_90", "tp_50", "tp_10"])
+    pz_dev, trap_dev = pz, g["wf_trap"]
+    # ---- energies: maxima and pick-offs; the time point is formed from the device's tp_0_est exactly as the recipe says
+    g = run(["tp_0_est", "trapTmax", "trapEmax", "trapEftp", "trapQftp", "QDrift", "dt_eff", "wf_etrap", "wf_trap2"])
+    tp0 = to_index(g["tp_0_est"], "tp_0_est")
+    exact(g["trapEmax"], np.max(g["wf_etrap"], axis=1), "trapEmax")
+    t_pick = _convert((tp0 + F(8000.0 / dt)) + F(2000.0 * 0.8 / dt), off.astype(np.float64), off.astype(np.float64), 1.0, np.rint)
+    exact(g["trapEftp"], oracle.fixed_time_pickoff(g["wf_etrap"], t_pick, "l")[0], "trapEftp")
+    q = oracle.fixed_time_pickoff(g["wf_trap2"], tp0 + F(8096.0 / dt), "l")[0]
+    exact(g["trapQftp"], q, "trapQftp")
+    exact(g["QDrift"], q * F(16), "QDrift")
+    exact(g["dt_eff"], g["QDrift"] / g["trapTmax"], "dt_eff")
+    same_as_production(g, ["trapEmax", "trapEftp", "QDrift", "dt_eff"])
+    etrap_dev, trap2_dev = g["wf_etrap"], g["wf_trap2"]
+    # ---- the cusp energy and the current branch
+    g = run(["tp_0_est", "cuspEmax", "cuspEftp", "tp_aoe_max", "A_max", "tp_aoe_samp", "wf_cusp", "curr_av", "wf_pz"])
+    tp0 = to_index(g["tp_0_est"], "tp_0_est")
+    exact(g["cuspEmax"], np.max(g["wf_cusp"], axis=1), "cuspEmax")
+    exact(g["cuspEftp"], oracle.fixed_time_pickoff(g["wf_cusp"], F(50), "i")[0], "cuspEftp")
+    _, ta, _, amax_, _ = oracle.min_max(g["curr_av"])
+    exact(g["tp_aoe_max"], ta, "tp_aoe_max")
+    exact(g["A_max"], amax_, "A_max")
+    exact(g["tp_aoe_samp"], to_ns(tp0 + ta / F(16)), "tp_aoe_samp")
+    same_as_production(g, ["cuspEmax", "cuspEftp", "tp_aoe_max", "A_max", "tp_aoe_samp"])
+    # window, difference quotient and repetition keep the samples as they are; the three moving averages are a filter (1e-6 of the peak)
+    up = oracle.upsampler(oracle.avg_current(oracle.windower(g["wf_pz"], tp0, 301)[0], 1)[0], 16, 4784)[0]
+    av = oracle.moving_window_multi(up, 48, 3, 0)[0]
+    assert np.max(np.nanmax(np.abs(g["curr_av"] - av), axis=1) / np.nanmax(np.abs(av), axis=1)) <= 1e-6
+    cusp_dev = g["wf_cusp"]
+    assert all(seen.get(k) for k in recipes.ICPC["outputs"] if k not in ("tp_min", "tp_max", "wf_min", "wf_max", "bl_mean", "bl_slope",
+                                                                         "bl_intercept", "pz_mean", "pz_std"))
+    # ---- the filtered waveforms against the oracle's own, 1e-6 of each waveform's peak (north_star's bar for float32 filter outputs)
+    w = wf.astype(F)
+    o_bl = oracle.bl_subtract(w, bl)[0]
+    o_pz = oracle.pole_zero(o_bl, F(27460.0 / dt))[0]
+    P = __import__("dspeed_amd.processors", fromlist=["x"])
+    k0 = np.zeros(133, dtype=np.float32)
+    P.t0_filter(128.0 / dt, 2000.0 / dt, k0)
+    kc = np.zeros(8192 - 2100 - 300, dtype=np.float32)
+    P.cusp_filter(20000.0 / dt, float(np.rint(3000.0 / dt)), 450000.0 / dt, kc)
+    pairs = {"wf_pz": (pz_dev, o_pz), "wf_t0_filter": (wt0_dev, oracle.convolve_wf(o_pz, k0, "s", 8192)[0]),
+             "wf_atrap": (atrap_dev, oracle.asym_trap_filter(o_pz, 8, 4, 125)[0]), "wf_trap": (trap_dev, oracle.trap_norm(o_pz, 625, 188)[0]),
+             "wf_etrap": (etrap_dev, oracle.trap_norm(o_pz, 500, 125)[0]), "wf_trap2": (trap2_dev, oracle.trap_norm(o_pz, 250, 6)[0]),
+             "wf_cusp": (cusp_dev, oracle.convolve_wf(o_bl, kc, "v", 301, in_len=8192 - 2100)[0])}
+    worst = {}
+    for k, (got, want) in pairs.items():
+        worst[k] = float(np.max(np.max(np.abs(got - want), axis=1) / np.max(np.abs(want), axis=1)))
+        assert worst[k] <= 1e-6, (k, worst[k])
+    # ---- what that leaves end to end: rows whose index outputs differ from the oracle run on its OWN waveforms, and by how much
+    want_all, _ = _expected(wf, bl, t0_ns)
+    report = {}
+    for k in ("tp_0_est", "tp_0_atrap", "tp_10", "tp_50", "tp_90", "tp_99", "tp_100", "tp_aoe_max"):
+        d = np.abs(prod[k].astype(np.float64) - want_all[k].astype(np.float64)) / (1.0 if k == "tp_aoe_max" else dt)
+        d = np.where(np.isnan(d), 0.0 if np.array_equal(np.isnan(prod[k]), np.isnan(want_all[k])) else np.inf, d)
+        report[k] = {"rows_differing": int(np.sum(d > 0)), "of": n, "max_samples": float(d.max())}
+    print("filter outputs, worst deviation / peak:", {k: f"{v:.1e}" for k, v in worst.items()})
+    print("end-to-end index outputs vs the all-oracle run:", report)
+    import json
+    import os
+
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/icpc_parity_report.json", "w") as f:
+        json.dump({"rows": n, "filter_outputs_worst_rel_to_peak": worst, "end_to_end_index_outputs": report}, f, indent=1)
+
+
 def test_time_coordinates_between_grids():
     """test_proc_chain_coordinate_grid of the reference (tests/test_processing_chain.py:324-386), restated on synthetic rows: a time
     picked off a window of the waveform equals the one picked off the whole waveform, whatever grid the processor works on; and
