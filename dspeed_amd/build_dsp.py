@@ -13,6 +13,12 @@ inside one ``execute``: the host-to-device copy of buffer k+1 overlaps the kerne
 Tables: a mapping ``column -> array | DeviceArray | WaveformInput``; ``raw_in`` is one table, a mapping of tables, or the name of an
 ``.npz`` file whose keys are ``<table>/<column>`` for plain columns and ``<table>/<column>/values``, ``.../dt``, ``.../t0`` for
 waveforms (the group layout of an LH5 WaveformTable).  ``dsp_out`` is ``None`` (return the tables) or the name of an ``.npz``.
+
+LGDO / LH5 (dspeed_amd/lgdo_io.py): ``raw_in`` may also be an ``lgdo.Table``, an ``lh5.LH5Iterator`` -- or anything with their
+protocol -- or the name of an ``.lh5`` file (that needs the ``lgdo`` package).  Chunks are then read one ahead on a thread of their own
+while the device works on the previous one, processed with the chain built from the first chunk (``reset_field_mask`` narrows the
+later reads to the columns the recipe uses, build_dsp.py:369-370) and written as they finish (``LH5Store.write`` with the reference's
+``wo_mode`` / ``write_start``, :416-424) or collected into one table.
 """
 from __future__ import annotations
 
@@ -23,6 +29,7 @@ from fnmatch import fnmatch
 
 import numpy as np
 
+from . import lgdo_io
 from .device import DeviceArray
 from .errors import DSPFatal
 from .processing_chain import WaveformInput, build_processing_chain
@@ -87,12 +94,156 @@ def _select(col, sel):
     return col[sel]
 
 
+def _pick_config(tb, dsp_config, chan_config, database):
+    this_config = dsp_config
+    for pat, cfg in chan_config.items():
+        if fnmatch(tb, pat):
+            this_config = cfg
+            break
+    if tb not in ("", "raw"):
+        chan_name = next(k for k in tb.split("/") if k not in ("", "raw"))
+        db_dict = database.get(chan_name) if database else None
+    else:
+        db_dict = database
+    return this_config, db_dict
+
+
+def _run_chunks(tb, source, this_config, db_dict, outputs, i_start, n_entries, buffer_len, sink):
+    """One table given as an LGDO table or an iterator of chunks: build the chain on the first chunk, then read ahead / process / hand the
+    results of every chunk to ``sink(i_entry, n_rows, {name: ndarray})``.  Returns the number of rows processed."""
+    if this_config.get("inputs"):
+        raise NotImplementedError("auxiliary 'inputs' files (LH5Iterator.add_friend, build_dsp.py:268-330) are not supported")
+    _outputs = this_config["outputs"] if outputs is None else outputs
+    if lgdo_io.is_chunk_iterator(source):
+        it = source
+        if n_entries is not None and hasattr(it, "n_entries"):
+            it.n_entries = min(int(n_entries), len(it))
+        first = next(iter(it), None)
+        if first is None:
+            return 0
+        chain, mask, _tb_out = build_processing_chain(this_config["processors"], lgdo_io.table_columns(first), db_dict=db_dict, outputs=list(_outputs))
+        if hasattr(it, "reset_field_mask"):
+            it.reset_field_mask(mask)
+        chunks = lgdo_io.ChunkReader(it, fields=set(mask))
+    else:  # one table in memory
+        cols = lgdo_io.table_columns(source)
+        n_all = _rows(next(iter(cols.values())))
+        stop = n_all if n_entries is None else min(n_all, i_start + int(n_entries))
+        cols = {k: _select(v, slice(min(i_start, n_all), stop)) for k, v in cols.items()}
+        if _rows(next(iter(cols.values()))) == 0:
+            return 0
+        chain, mask, _tb_out = build_processing_chain(this_config["processors"], cols, db_dict=db_dict, outputs=list(_outputs))
+        chunks = [(0, _rows(next(iter(cols.values()))), cols)]
+    done = 0
+    try:
+        for i_entry, n, cols in chunks:
+            row_bytes = sum(np.asarray(c.values if isinstance(c, WaveformInput) else c).nbytes // max(n, 1) for k, c in cols.items() if k in mask)
+            chain.pipeline_bytes = max(1, int(buffer_len)) * max(row_bytes, 1)
+            out = {name[4:] if name.startswith("out:") else name: np.empty((n,) if length is None else (n, length), dtype=getattr(var, "dtype", None) or chain.loop_dtype)
+                   for name, (var, length) in chain._out_vars.items()}
+            try:
+                chain(cols, out)
+            except DSPFatal as e:
+                e.wf_range = f"{i_entry}-{i_entry + n}"  # the position in the file (build_dsp.py:408-410)
+                raise
+            for c in chain._copy_pars:
+                if c in cols:
+                    col = cols[c]
+                    out[c] = np.asarray(col.values if isinstance(col, WaveformInput) else col)
+            sink(i_entry, n, out)
+            done += n
+    finally:
+        if isinstance(chunks, lgdo_io.ChunkReader):
+            chunks.close()
+    return done
+
+
+def _build_dsp_lgdo(raw_in, dsp_out, dsp_config, lh5_tables, base_group, database, outputs, write_mode, entry_list, entry_mask, i_start,
+                    n_entries, buffer_len, chan_config):
+    dsp_config = _load_config(dsp_config)
+    chan_config = {k: _load_config(v) for k, v in dict(_load_config(chan_config) or {}).items()}
+    database = _load_config(database)
+    if database and not isinstance(database, Mapping):
+        raise ValueError("input database is not a valid JSON or YAML file or dict")
+    lh5_file = isinstance(raw_in, str)
+    if isinstance(lh5_tables, str):
+        lh5_tables = [lh5_tables]
+    store = None
+    if lh5_file:
+        lg, lh5 = lgdo_io.require_lh5(f"reading '{raw_in}'")
+        if base_group is None:
+            base_group = "raw" if lh5.ls(raw_in, "raw") else ""
+        if lh5_tables is None:
+            tables = lh5.ls(raw_in, f"{base_group}/*")
+        else:
+            tables = [t for wc in lh5_tables for t in lh5.ls(raw_in, f"{base_group}/{wc}")]
+        fixed = []
+        for tb in tables:  # 'raw' is sometimes nested, e.g. ch024/raw (build_dsp.py:176-183)
+            if lh5.ls(raw_in, f"{tb}/*") == [f"{tb}/raw"]:
+                fixed.append(f"{tb}/raw")
+            elif lh5.ls(raw_in, tb):
+                fixed.append(tb)
+        tables = fixed
+        if not tables:
+            raise RuntimeError(f"could not find any valid LH5 table in {raw_in}")
+    else:
+        if lh5_tables is not None and len(lh5_tables) > 1:
+            raise RuntimeError("Cannot have more than one value in lh5_tables for input of type Table or LH5Iterator")
+        tables = [lh5_tables[0] if lh5_tables else ""]
+    to_lh5 = dsp_out is not None and not str(dsp_out).endswith(".npz")
+    if dsp_out is not None:
+        if write_mode is None and os.path.isfile(dsp_out):
+            raise FileExistsError(f"output file {dsp_out} exists. Set the 'write_mode' keyword")
+        if write_mode == "r" and os.path.isfile(dsp_out):
+            os.remove(dsp_out)
+        if to_lh5:
+            lg, lh5 = lgdo_io.require_lh5(f"writing '{dsp_out}'")
+            store = lh5.LH5Store(keep_open=True)
+    result = {}
+    for tb in tables:
+        this_config, db_dict = _pick_config(tb, dsp_config, chan_config, database)
+        if this_config is None:
+            continue
+        dsp_name = tb.replace("raw", "dsp")
+        parts = []
+        if lh5_file:
+            source = lh5.LH5Iterator(raw_in, tb, entry_list=entry_list, entry_mask=entry_mask, i_start=i_start, n_entries=n_entries,
+                                     buffer_len=buffer_len)
+        else:
+            source = raw_in
+
+        def sink(i_entry, n, out, _name=dsp_name, _parts=parts):
+            if store is not None:
+                store.write(obj=lgdo_io.results_table(out), name=_name, lh5_file=dsp_out, wo_mode="o" if write_mode == "u" else "a",
+                            write_start=i_start + i_entry, n_rows=n)
+            else:
+                _parts.append(out)
+
+        _run_chunks(tb, source, this_config, db_dict, outputs, i_start, n_entries, buffer_len, sink)
+        if store is None:
+            keys = list(parts[0]) if parts else []
+            result[dsp_name] = {k: np.concatenate([p[k] for p in parts]) for k in keys}
+    if store is not None:
+        return None
+    if dsp_out is None:
+        tabs = {k: lgdo_io.results_table(v) for k, v in result.items()}
+        return tabs[next(iter(tabs))] if not lh5_file and tabs else tabs
+    flat = {f"{t}/{k}" if t else k: np.asarray(v) for t, cols in result.items() for k, v in cols.items()}
+    np.savez(dsp_out + ".tmp.npz", **flat)
+    os.replace(dsp_out + ".tmp.npz", dsp_out)
+    return None
+
+
 def build_dsp(raw_in, dsp_out: str | None = None, dsp_config=None, lh5_tables=None, base_group: str | None = None, database=None,
               outputs: Collection[str] | None = None, write_mode: str | None = None, entry_list=None, entry_mask=None, i_start: int = 0,
               n_entries: int | None = None, buffer_len: int = 3200, block_width: int = 16, chan_config=None):
     """Run recipes over tables of waveforms; returns ``{dsp table name: {parameter: ndarray}}`` (one table: the table itself) when
     ``dsp_out`` is None, else writes them to the ``.npz`` and returns None.  Parameters as in the reference (build_dsp.py:27-127)."""
     del block_width  # (the device processes whole buffers)
+    if (isinstance(raw_in, str) and raw_in.lower().endswith((".lh5", ".h5", ".hdf5"))) or lgdo_io.is_chunk_iterator(raw_in) or \
+            lgdo_io.is_lgdo_table(raw_in):
+        return _build_dsp_lgdo(raw_in, dsp_out, dsp_config, lh5_tables, base_group, database, outputs, write_mode, entry_list, entry_mask,
+                               i_start, n_entries, buffer_len, chan_config)
     if isinstance(lh5_tables, str):
         lh5_tables = [lh5_tables]
     single = False

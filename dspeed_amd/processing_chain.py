@@ -234,6 +234,7 @@ class ProcessingChain:
         self._copy_stream = None  # H2D of the next piece runs here while the compute stream works on the current one
         self._stage_key, self._stage = None, []  # page-locked staging buffers (one set per piece slot)
         self._timing = {"h2d": 0.0, "kernel": 0.0, "d2h": 0.0}
+        self._copy_pars = []      # outputs that are input columns handed through
         self.proc_strings = proc_strings
 
     # -- introspection
@@ -450,8 +451,26 @@ class ProcessingChain:
                 bufs[name] = out.ptr + j * m * isz
 
     def __call__(self, tb_in, tb_out, begin: int = 0, end: int | None = None):
+        """``proc_chain(tb_in, tb_out)`` of the reference (processing_chain.py:675-716).  LGDO tables (or stand-ins with their protocol,
+        dspeed_amd/lgdo_io.py) are taken as they are: the input's columns are read through their ``.nda`` / ``values, dt, t0``, the
+        results are written into the output table's columns."""
+        from . import lgdo_io
+
+        lgdo_out = tb_out if lgdo_io.is_lgdo_table(tb_out) else None
+        if lgdo_io.is_lgdo_table(tb_in):
+            tb_in = lgdo_io.table_columns(tb_in, set(v.source.split(".")[0] for v in self._in_vars.values()) | set(self._copy_pars))
+        if lgdo_out is not None:
+            n = len(_column(tb_in, next(iter(self._in_vars.values())).source)) if self._in_vars else self._buffer_len
+            tb_out = {name[4:] if name.startswith("out:") else name: np.empty((n,) if length is None else (n, length), dtype=getattr(var, "dtype", None) or self.loop_dtype)
+                      for name, (var, length) in self._out_vars.items()}
         self.link(tb_in, tb_out)
         self.execute(begin, end)
+        if lgdo_out is not None:
+            for c in self._copy_pars:
+                if c in tb_in:
+                    tb_out[c] = _column(tb_in, c)
+            lgdo_io.write_back(lgdo_out, tb_out, begin)
+            return lgdo_out
         return tb_out
 
 
@@ -1164,6 +1183,10 @@ def build_processing_chain(processors, tb_in=None, db_dict=None, outputs=None, b
     signature compatibility: the device processes the whole buffer in one launch.
     """
     del block_width
+    from . import lgdo_io
+
+    if tb_in is not None and lgdo_io.is_lgdo_table(tb_in):  # an lgdo.Table (or a stand-in with its protocol): its columns as arrays
+        tb_in = lgdo_io.table_columns(tb_in)
     recipe = _load(processors)
     if outputs is None:
         if "outputs" not in recipe:
@@ -1244,6 +1267,7 @@ def build_processing_chain(processors, tb_in=None, db_dict=None, outputs=None, b
     for c in copy_pars:
         if tb_in is not None and c in tb_in:
             tb_out[c] = _column(tb_in, c)
+    chain._copy_pars = list(copy_pars)
     chain.link(tb_in, tb_out)
     return chain, leafs + copy_pars, tb_out
 
@@ -1357,6 +1381,9 @@ def _loop_dtype(b: _Builder):
     float64 / int32 / uint32 waveforms or float64 scalar columns cannot be cast to float32."""
     for v in b.vars.values():
         if isinstance(v, Var) and v.is_input and v.dtype is not None:
+            if v.source is not None and v.source.endswith(".t0"):
+                continue  # the time of sample 0 is a coordinate offset, not a processor argument: a float64 t0 column (what LH5 files hold)
+                # does not make the processors run their float64 loops (the value enters coordinate conversions in the loop's type)
             if v.kind == "wf" and v.dtype in (np.dtype(np.float64), np.dtype(np.int32), np.dtype(np.uint32)):
                 return np.dtype(np.float64)
             if v.kind == "scalar" and v.dtype == np.dtype(np.float64):

@@ -7,6 +7,7 @@ import oracle
 import recipes
 
 pytestmark = pytest.mark.gpu
+TOL = 1e-6
 
 
 def _table(rng, n, wf_len=4096, t0=0.0):
@@ -115,3 +116,58 @@ def test_whole_ge_recipe_through_the_table_loop(tmp_path):
         chain.execute()
         for k in recipes.ICPC["outputs"]:
             assert np.array_equal(out[name.replace("raw", "dsp")][k], direct[k], equal_nan=True), (name, k)
+
+
+def test_lgdo_tables_and_lh5_iterators_through_the_adaptors():
+    """build_dsp on an LGDO-protocol Table and on an LH5Iterator over it (stand-ins: tests/lgdo_standins.py) -- chunks read ahead on a
+    thread, chain built from the first chunk, field mask pushed back to the iterator, DSPFatal annotated with the file position -- and
+    proc_chain(tb_in, tb_out) writing into an LGDO output table (reference build_dsp.py:256-266, 399-432; processing_chain.py:675-716)."""
+    from lgdo_standins import Array, LH5Iterator, Table, WaveformTable
+
+    from dspeed_amd import lgdo_io
+    from dspeed_amd.build_dsp import build_dsp
+    from dspeed_amd.errors import DSPFatal
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    rng = np.random.default_rng(8)
+    n, wf_len = 1000, 4096
+    i = np.arange(wf_len)[None, :]
+    t0 = np.floor(rng.uniform(0.45, 0.55, (n, 1)) * wf_len)
+    B = rng.uniform(9000, 11000, (n, 1))
+    wf = np.rint(B + rng.uniform(500, 15000, (n, 1)) * np.exp(-(i - t0) / 1716.28) * (i >= t0) + 5 * rng.standard_normal((n, wf_len))).astype(np.uint16)
+    bl = B[:, 0].astype(np.float32)
+    tp = (t0[:, 0] + 625 + 150.4).astype(np.float32)
+    raw = Table(waveform=WaveformTable(wf, 16.0, np.zeros(n)), baseline=Array(bl), t_pick=Array(tp), unused=Array(np.zeros((n, 100), np.float32)))
+    want, rc = oracle.chain_energy(wf.astype(np.float32), bl, tp, 1716.28, 625, 188, "l")
+    assert rc == 0
+
+    def energies(res):
+        col = res["trapEftp"]
+        return np.asarray(col.nda if hasattr(col, "nda") else col)
+
+    # one table in memory; a row range of it
+    assert np.max(np.abs(energies(build_dsp(raw, dsp_config=recipes.C2)) - want) / np.abs(want)) <= TOL
+    part = energies(build_dsp(raw, dsp_config=recipes.C2, i_start=100, n_entries=250))
+    assert part.shape == (250,) and np.array_equal(part, energies(build_dsp(raw, dsp_config=recipes.C2))[100:350])
+    # the same table behind an iterator of 300-row chunks in one refilled buffer
+    it = LH5Iterator(raw, buffer_len=300)
+    got = energies(build_dsp(it, dsp_config=recipes.C2))
+    assert got.shape == (n,) and np.max(np.abs(got - want) / np.abs(want)) <= TOL
+    assert sorted(it.field_mask) == ["baseline", "t_pick", "waveform"]  # the unused column is no longer read
+    assert all("unused" not in keys for _pos, _n, keys in it.reads[1:])
+    # a data-dependent DSPFatal names the rows of the chunk in the file
+    bad = Table(raw)
+    tp_bad = np.floor(tp)  # (mode 'i' wants whole samples: every row but one has them)
+    tp_bad[640] += 0.5
+    bad["t_pick"] = Array(tp_bad)
+    rec_i = {"outputs": ["e"], "processors": dict(recipes.C2["processors"])}
+    rec_i["processors"]["e"] = {"function": "fixed_time_pickoff", "module": "dspeed.processors", "args": ["wf_trap", "t_pick", "'i'", "e"]}
+    with pytest.raises(DSPFatal, match="integer t_in") as ei:
+        build_dsp(LH5Iterator(bad, buffer_len=300), dsp_config=rec_i)
+    assert ei.value.wf_range == "600-900"
+    # proc_chain(tb_in, tb_out) with LGDO tables on both sides
+    chain, _mask, _ = build_processing_chain(recipes.C2, raw)
+    out_tb = Table(trapEftp=Array(np.zeros(0, np.float32)))
+    chain(raw, out_tb)
+    assert np.array_equal(out_tb["trapEftp"].nda, energies(build_dsp(raw, dsp_config=recipes.C2)))
+    assert lgdo_io.is_lgdo_table(out_tb)
