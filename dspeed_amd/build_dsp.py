@@ -150,7 +150,8 @@ def _run_chunks(tb, source, this_config, db_dict, outputs, i_start, n_entries, b
                 if c in cols:
                     col = cols[c]
                     out[c] = np.asarray(col.values if isinstance(col, WaveformInput) else col)
-            sink(i_entry, n, out)
+            # variable-length outputs (declared with vector_len=len(<input>)) leave as VectorOfVectors: padded rows + their lengths
+            sink(i_entry, n, out, {k: np.asarray(cols[src]) for k, src in chain.vector_lens.items() if k in out and src in cols})
             done += n
     finally:
         if isinstance(chunks, lgdo_io.ChunkReader):
@@ -199,7 +200,7 @@ def _build_dsp_lgdo(raw_in, dsp_out, dsp_config, lh5_tables, base_group, databas
         if to_lh5:
             lg, lh5 = lgdo_io.require_lh5(f"writing '{dsp_out}'")
             store = lh5.LH5Store(keep_open=True)
-    result = {}
+    result, result_lens = {}, {}
     for tb in tables:
         this_config, db_dict = _pick_config(tb, dsp_config, chan_config, database)
         if this_config is None:
@@ -212,21 +213,25 @@ def _build_dsp_lgdo(raw_in, dsp_out, dsp_config, lh5_tables, base_group, databas
         else:
             source = raw_in
 
-        def sink(i_entry, n, out, _name=dsp_name, _parts=parts):
+        lens_parts = []
+
+        def sink(i_entry, n, out, lens, _name=dsp_name, _parts=parts, _lens=lens_parts):
             if store is not None:
-                store.write(obj=lgdo_io.results_table(out), name=_name, lh5_file=dsp_out, wo_mode="o" if write_mode == "u" else "a",
+                store.write(obj=lgdo_io.results_table(out, lengths=lens), name=_name, lh5_file=dsp_out, wo_mode="o" if write_mode == "u" else "a",
                             write_start=i_start + i_entry, n_rows=n)
             else:
                 _parts.append(out)
+                _lens.append(lens)
 
         _run_chunks(tb, source, this_config, db_dict, outputs, i_start, n_entries, buffer_len, sink)
         if store is None:
             keys = list(parts[0]) if parts else []
             result[dsp_name] = {k: np.concatenate([p[k] for p in parts]) for k in keys}
+            result_lens[dsp_name] = {k: np.concatenate([p[k] for p in lens_parts]) for k in (lens_parts[0] if lens_parts else {})}
     if store is not None:
         return None
     if dsp_out is None:
-        tabs = {k: lgdo_io.results_table(v) for k, v in result.items()}
+        tabs = {k: lgdo_io.results_table(v, lengths=result_lens.get(k)) for k, v in result.items()}
         return tabs[next(iter(tabs))] if not lh5_file and tabs else tabs
     flat = {f"{t}/{k}" if t else k: np.asarray(v) for t, cols in result.items() for k, v in cols.items()}
     np.savez(dsp_out + ".tmp.npz", **flat)

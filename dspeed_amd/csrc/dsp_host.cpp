@@ -1020,6 +1020,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             }
             case DSP_OP_PICKOFF:
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad PICKOFF", i);
+                if (o.ip[1] < 0 || o.ip[1] > 2) return fail(DSP_ERR_ARG, "op %d: PICKOFF ip[1] must be 0, 1 or 2", i);
                 if (o.ip[1] == 1 && (o.sp[0].kind != DSP_ARG_CONST || o.sp[0].value < 0 || o.sp[0].value >= slot_len[o.src] ||
                                      o.sp[0].value != std::floor(o.sp[0].value)))
                     return fail(DSP_ERR_ARG, "op %d: PICKOFF of one sample (ip[1] = 1) needs a constant index inside the waveform", i);

@@ -249,6 +249,7 @@ __device__ __forceinline__ T ew_apply(T a, T b, T c) {
     else if constexpr (FN == DSP_FN_ISNAN) return (T)(a != a);
     else if constexpr (FN == DSP_FN_ISFINITE) return (T)((a - a) == (T)0);
     else if constexpr (FN == DSP_FN_NEG) return -a;
+    else if constexpr (FN == DSP_FN_FLOORDIV) return floor(a / b);
     else return a;
 }
 
@@ -269,6 +270,7 @@ __device__ __forceinline__ void ew_dispatch(int fn, F&& f) {
         case DSP_FN_ISNAN: f(std::integral_constant<int, DSP_FN_ISNAN>()); break;
         case DSP_FN_ISFINITE: f(std::integral_constant<int, DSP_FN_ISFINITE>()); break;
         case DSP_FN_NEG: f(std::integral_constant<int, DSP_FN_NEG>()); break;
+        case DSP_FN_FLOORDIV: f(std::integral_constant<int, DSP_FN_FLOORDIV>()); break;
         default: f(std::integral_constant<int, DSP_FN_COPY>()); break;
     }
 }
@@ -852,6 +854,16 @@ __device__ __forceinline__ void op_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& o
     T out = quiet_nan<T>();
     if (op.ip[1] == 1) {  // wf[i] in a recipe (processing_chain.py:986-990): a view of one sample, not the processor -- no NaN rule
         if (!cx.slot_all_nan(op.src)) out = cx.lds[padded_index(ss, (int)t_in)];
+    } else if (op.ip[1] == 2) {  // wf[variable]: get_default (processors/get.py:50-92)
+        out = cx.scalar(op.sp[1]);
+        if (!(t_in != t_in) && !cx.slot_all_nan(op.src)) {
+            long long i = (long long)t_in;
+            if (i < 0) i += ss.len;
+            if (i >= 0 && i < ss.len) {
+                const T v = cx.lds[padded_index(ss, (int)i)];
+                if (!(v != v)) out = v;
+            }
+        }
     } else if (op.ip[0] == 's' && !cx.slot_nan(op.src) && pickoff_in_range(t_in, ss.len) && (T)(int)t_in != t_in) {
         out = pickoff_spline(cx, ss, t_in);
     } else if (!cx.slot_nan(op.src) && pickoff_in_range(t_in, ss.len)) {

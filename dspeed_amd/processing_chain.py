@@ -131,6 +131,7 @@ class Var:
         self.slot = None
         self.sreg = None
         self.io = None
+        self.vector_len = None    # per-event number of valid samples of a variable-length array (reference ProcChainVar.vector_len, :164-208)
 
     @property
     def period(self):  # ns per sample
@@ -174,7 +175,7 @@ _SIGS = {
     "mean_below_threshold": "wsS", "windower": "wsW", "avg_current": "wsW", "trap_pickoff": "wiisS",
     "upsampler": "wsW", "moving_window_multi": "wsiiW", "numpy_subtract": "wsW", "numpy_add": "wsW", "min_max_norm": "wssW", "linear_slope_fit": "wSSSS",
 }
-_SIGS.update({"sample": "wiS", "slice": "wiiW"})  # wf[i], wf[lo:hi:step] (reference :948-1071)
+_SIGS.update({"sample": "wiS", "slice": "wiiW", "get": "wsS"})  # wf[i], wf[lo:hi:step], wf[variable] (reference :948-1071)
 
 
 def _roles(fn) -> str:
@@ -235,6 +236,7 @@ class ProcessingChain:
         self._stage_key, self._stage = None, []  # page-locked staging buffers (one set per piece slot)
         self._timing = {"h2d": 0.0, "kernel": 0.0, "d2h": 0.0}
         self._copy_pars = []      # outputs that are input columns handed through
+        self.vector_lens = {}     # variable-length outputs -> input column with their per-event lengths
         self.proc_strings = proc_strings
 
     # -- introspection
@@ -620,6 +622,9 @@ class _Builder:
                     self.vars[t0.name] = t0
                     grid = Grid(col.dt, 0.0, t0)
             v = Var(name, "wf", shape[1], dtype, source=name, grid=grid, is_coord=False)
+            if f"len({name})" in self.tb_in:  # a VectorOfVectors: rows padded to a common length + their true lengths (lgdo_io.RaggedColumn)
+                self.vars[name] = v
+                v.vector_len = self.input_var(f"len({name})")
         elif len(shape) == 1:
             v = Var(name, "scalar", None, dtype, source=name)
         else:
@@ -725,6 +730,8 @@ class _Builder:
                 grid, what = base.grid, base.name
             else:
                 raise ProcessingChainError(f"unsupported attribute in '{src}'")
+            if n.attr == "unit":  # name.unit in a declaration: unit=vov.unit (reference tests/test_processing_chain.py:660)
+                return getattr(base[1] if isinstance(base, tuple) else base, "unit", None)
             if n.attr not in ("period", "offset", "grid"):
                 raise ProcessingChainError(f"unsupported attribute '.{n.attr}' in '{src}'")
             if grid is None:
@@ -747,7 +754,19 @@ class _Builder:
                 raise ProcessingChainError(f"Cannot apply subscript to {self._nm(base)} in '{src}'")
             if isinstance(n.slice, ast.Tuple):
                 raise ProcessingChainError("Tuple still isn't implemented...")
-            if not isinstance(n.slice, ast.Slice):  # wf[i]: one sample, a per-event value (reference :980-990; a variable index is not taken)
+            if not isinstance(n.slice, ast.Slice):  # wf[i]: one sample, a per-event value (reference :976-1005)
+                idx = self._eval(n.slice, src, new)
+                vlen = base.vector_len if isinstance(base, Var) else None
+                if not _is_scalar(idx) and vlen is not None and not isinstance(idx, (Quantity, tuple, Grid)) and float(idx) < 0:
+                    idx = self._scalar_binop(ast.Add(), vlen, int(round(float(idx))), src)  # -k counts from the row's own end (:972-973)
+                if _is_scalar(idx):
+                    # a per-event index: the reference adds get_default(w, i, NaN) (processors/get.py:50-92) -- the sample, or NaN when the
+                    # index lies outside the array or the sample itself is NaN; a negative index counts from the end
+                    self._anon += 1
+                    out = Var(f"{base.name}[{idx.name}]#{self._anon}", None, unit=base.unit, is_coord=False)
+                    whole = base if first == 0 and length == base.length else ("slice", base, first, first + length)
+                    self._step("get", [whole, idx, out], "wsS")
+                    return out
                 i = self._const_int(n.slice, src, new, 0, base)
                 i = i + length if i < 0 else i
                 if not 0 <= i < length:
@@ -785,6 +804,8 @@ class _Builder:
                 a = [self._eval(x, src, new) for x in n.args]
                 if f == "len":
                     v = a[0]
+                    if isinstance(v, Var) and v.vector_len is not None:  # a variable-length array: its per-event length (reference :1182-1183)
+                        return v.vector_len
                     if isinstance(v, tuple) and v[0] == "slice":
                         return v[3] - v[2]
                     if not isinstance(v, Var) or v.length is None:
@@ -836,8 +857,27 @@ class _Builder:
                     raise ProcessingChainError(f"declaration '{src}' needs a shape")
                 kw = {k.arg: self._eval(k.value, src, new) for k in n.keywords}
                 for k in kw:
-                    if k not in ("unit", "period", "offset", "grid", "dtype", "is_coord"):
+                    if k not in ("unit", "period", "offset", "grid", "dtype", "is_coord", "shape", "vector_len"):
                         raise ProcessingChainError(f"unknown keyword '{k}' in declaration '{src}'")
+                if "shape" in kw:
+                    shape = int(round(float(kw["shape"])))
+                    if v.is_input and v.kind == "wf":
+                        # the maximum length of a variable-length input (reference :2213-2232): the rows arrive padded (lgdo_io.RaggedColumn);
+                        # the variable takes the first `shape` samples of them, and no row may hold more
+                        lens = self.tb_in.get(f"len({v.name})")
+                        if shape > v.length:
+                            raise NotImplementedError(f"'{src}': the input arrives padded to {v.length} samples; pad it to {shape} (RaggedColumn.from_vov(max_len=...))")
+                        if lens is not None and len(lens) and int(np.max(np.asarray(lens))) > shape:
+                            raise DSPFatal("VectorOfVectors entry has length larger than array variable length")
+                        v.length = shape
+                    elif v.length is None:
+                        v.kind, v.length = "wf", shape
+                        v.dtype = v.dtype if v.dtype is not None else np.dtype(np.float32)
+                if "vector_len" in kw:
+                    vl = kw["vector_len"]
+                    if not _is_scalar(vl):
+                        raise ProcessingChainError(f"vector_len in '{src}' must be a per-event variable")
+                    v.vector_len = vl
                 if "dtype" in kw:
                     d = kw["dtype"]
                     v.dtype = np.dtype(d[1] if isinstance(d, tuple) else d)
@@ -1067,6 +1107,12 @@ class _Builder:
         """A binary operator with a per-event variable on at least one side: the reference adds the NumPy ufunc as a processor
         (:832-891), so the operands go through the same unit handling as any processor's (`_resolve`)."""
         sym = {ast.Add: "+", ast.Sub: "-", ast.Mult: "*", ast.Div: "/"}.get(type(op))
+        if isinstance(op, ast.FloorDiv):  # numpy.floor_divide as a processor: len(v)//2 and the like (reference :832-847)
+            for x in (a, b):
+                if isinstance(x, (tuple, Grid, Quantity)) or (isinstance(x, Var) and x.kind != "scalar"):
+                    raise NotImplementedError(f"'//' in '{src}' takes per-event variables and plain numbers")
+            v = a if _is_scalar(a) else b
+            return self._scalar_func(_lib.FN_FLOORDIV, [a, b], f"({self._nm(a)}//{self._nm(b)})", v.unit, False, None, None)
         if sym is None:
             raise NotImplementedError(f"operator in '{src}' is not supported between per-event variables")
         for x in (a, b):
@@ -1295,6 +1341,19 @@ def _add_step(b: _Builder, key, node, new_vars, proc_strings):
         return
     if module not in _MODULES:
         raise NotImplementedError(f"module '{module}' is not available on the device path (processor {module}.{function})")
+    if module in ("numpy", "np") and function == "copyto":
+        # numpy.copyto(dst, src) as a processor: the copy of a (variable-length) array into a declared output (reference
+        # tests/test_processing_chain.py:656-674)
+        args = [b.eval_arg(a, new_vars) for a in node["args"]]
+        if len(args) != 2 or not isinstance(args[0], Var) or args[0].length is None or not _is_wf(args[1]):
+            raise ProcessingChainError(f"numpy.copyto takes a declared output array and an array for parameter {key}")
+        dst, src = args
+        if _wf_len(src) < dst.length:
+            raise ProcessingChainError(f"numpy.copyto for parameter {key}: the output holds {dst.length} samples, the source only {_wf_len(src)}")
+        dst.kind = "wf"
+        dst.dtype = dst.dtype if dst.dtype is not None else np.dtype(np.float32)
+        b._step("slice", [src if _wf_len(src) == dst.length else ("slice", *( (src[1], src[2], src[2] + dst.length) if isinstance(src, tuple) else (src, 0, dst.length))), 0, 1, dst], "wiiW")
+        return
     if module in ("numpy", "np") and function not in ("amax",) + tuple(_NUMPY_BINARY):
         raise NotImplementedError(f"numpy.{function} is not available on the device path")
     if "unit" in node:  # "unit": one string, or one per new variable (reference :2705-2711)
@@ -1460,6 +1519,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
     p = Program()
     ft = _loop_dtype(b)
     in_bind, out_bind, consts = {}, {}, {}
+    vector_lens = {}
     steps = b.steps
     # --- linear_slope_fit on the rows of the batch (dsp_linear_slope_fit_rows: one waveform per lane) instead of inside the program,
     # where its sequential float32 recurrences cost a third of a LEGEND recipe: a fit whose waveform is an input, the input minus a
@@ -1825,6 +1885,11 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             o = out_scalar(args[2])
             p.add_op(_lib.OP_PICKOFF, dst=o.sreg, src=src.slot, ip=(ord("n"), 1), sp=(Scalar.const(float(args[1])),))
             release(src, si)
+        elif fn == "get":
+            src = ensure_loaded(args[0], si)
+            o = out_scalar(args[2])
+            p.add_op(_lib.OP_PICKOFF, dst=o.sreg, src=src.slot, ip=(ord("n"), 2), sp=(scalar_operand(args[1], args, what=what), Scalar.const(float("nan"))))
+            release(src, si)
         elif fn == "slice":
             src = ensure_loaded(args[0], si)
             dst = args[3]
@@ -2032,6 +2097,11 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             io = p.add_io(f"out:{o}", _lib.IO_WF_OUT, odt, v.length)
             p.add_op(_lib.OP_STORE, src=v.slot, io=io)
             out_bind[f"out:{o}"] = (SimpleNamespace(name=o, dtype=odt), v.length)
+            if getattr(v, "vector_len", None) is not None:
+                vl = v.vector_len
+                if not (isinstance(vl, Var) and vl.is_input):
+                    raise NotImplementedError(f"output '{o}': vector_len must be the length of an input array (len(<input>))")
+                vector_lens[o] = vl.source
             tb_out[o] = np.empty((n_rows, v.length), dtype=odt)
         else:
             # a time coordinate is written in its unit, not in samples: (index + grid offset) * period (reference :1990-2014, get_buffer(unit))
@@ -2075,6 +2145,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
     if len(p.ops) > _lib.MAX_OPS or len(p.slots) > _lib.MAX_SLOTS or len(p.io) > _lib.MAX_IO or p.n_sregs > _lib.MAX_SREGS:
         raise NotImplementedError("recipe is too large for one device chain (ops/slots/bindings limit)")
     chain = ProcessingChain(p, in_bind, out_bind, consts, n_rows, proc_strings, ft, aux_desc)
+    chain.vector_lens = vector_lens  # variable-length outputs -> the input column that holds their per-event lengths
     return chain, tb_out
 
 

@@ -159,7 +159,9 @@ typedef struct dsp_scalar_arg {
 #define DSP_OP_TRAP_FILTER 7   /* trap_filters.py:12-76     ip[0..1] = rise, flat */
 #define DSP_OP_TRAP_NORM 8     /* trap_filters.py:79-149 */
 #define DSP_OP_ASYM_TRAP 9     /* trap_filters.py:152-227   ip[0..2] = rise, flat, fall */
-#define DSP_OP_PICKOFF 10      /* fixed_time_pickoff.py:12-125  sreg[dst] <- src at sp[0]; ip[0] = mode char; ip[1] = 1: the sample src[sp[0]] itself (wf[i] in a recipe) */
+#define DSP_OP_PICKOFF 10      /* fixed_time_pickoff.py:12-125  sreg[dst] <- src at sp[0]; ip[0] = mode char; ip[1] = 1: the sample src[sp[0]] itself (wf[i] in a recipe);
+                                  * ip[1] = 2: get.py:50-92 get_default -- src[int(sp[0])] with a per-event index (negative: from the end), sp[1] where the
+                                  * index is outside the array or the sample is NaN (wf[variable] in a recipe, processing_chain.py:991-1005) */
 #define DSP_OP_TIME_POINT_THRESH 11 /* time_point_thresh.py:12-92  sreg[dst] <- src; sp[0..2] = threshold, t_start, walk_forward */
 #define DSP_OP_MIN_MAX 12      /* min_max.py:11-82          sreg[dst..dst+3] <- t_min, t_max, a_min, a_max */
 #define DSP_OP_DWT_HAAR 13     /* dwt.py:13-81              dst <- src; ip[0] = level, ip[1] = 'a'|'d', ip[2] = scratch slot */
@@ -218,7 +220,8 @@ typedef struct dsp_scalar_arg {
 #define DSP_FN_ISFINITE 12
 #define DSP_FN_NEG 13
 #define DSP_FN_COPY 14     /* astype to the loop type */
-#define DSP_FN_LAST 14
+#define DSP_FN_FLOORDIV 15 /* floor(A / B): numpy.floor_divide between per-event values that hold integers (len(v) // 2) */
+#define DSP_FN_LAST 15
 
 typedef struct dsp_op {
     int32_t opcode;

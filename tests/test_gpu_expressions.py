@@ -221,3 +221,49 @@ def test_processors_downstream_of_an_expression():
     with np.errstate(invalid="ignore"):
         clipped = np.where(out_ref["wf_trap"] > 1000, np.float32(1000), out_ref["wf_trap"])
     assert np.array_equal(out["cmax"], clipped.max(axis=1), equal_nan=True)
+
+
+def test_variable_index_into_variable_length_arrays():
+    """tests/test_processing_chain.py:75-97 of the reference: a VectorOfVectors input (padded rows + lengths, dspeed_amd/lgdo_io.py), the
+    element in its middle -- vov[len(vov)//2], get_default with a per-event index -- and its last one, vov[-1]; plus indices outside the
+    rows (NaN, processors/get.py:50-92) and a per-event index column into an ordinary waveform"""
+    from lgdo_standins import Table, VectorOfVectors
+
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    vov = VectorOfVectors(np.arange(150.0), [10, 30, 60, 100, 150], {"units": "ns"})
+    rec = {"outputs": ["vals", "v_end", "beyond"], "processors": {"vals": "vov_in(shape=50)[len(vov_in)//2]", "v_end": "vov_in(shape=50)[-1]",
+                                                                  "beyond": "vov_in(shape=50)[len(vov_in)]", "var_slice": "vov_in[indices:20]"}}
+    chain, _, out = build_processing_chain(rec, Table(vov_in=vov))
+    chain.execute()
+    assert np.array_equal(out["vals"], [5.0, 20.0, 45.0, 80.0, 125.0])
+    assert np.array_equal(out["v_end"], [9.0, 29.0, 59.0, 99.0, 149.0])
+    assert np.isnan(out["beyond"][:4]).all() and np.isnan(out["beyond"][4])  # the padding is NaN; index 50 of the longest row is outside
+    rng = np.random.default_rng(3)
+    wf = rng.normal(size=(40, 256)).astype(np.float32)
+    idx = rng.integers(-300, 300, 40).astype(np.float32)
+    wf[5, int(idx[5]) % 256 if -256 <= idx[5] < 256 else 0] = np.nan
+    chain, _, out = build_processing_chain({"outputs": ["s"], "processors": {"s": "waveform[idx]"}}, {"waveform": wf, "idx": idx})
+    chain.execute()
+    want = np.array([wf[r, int(i)] if -256 <= i < 256 else np.nan for r, i in enumerate(idx)], dtype=np.float32)
+    assert np.array_equal(out["s"], want, equal_nan=True)
+
+
+def test_vector_of_vectors_out_again():
+    """tests/test_processing_chain.py:626-690 of the reference: a variable-length array copied into a declared variable-length output
+    (numpy.copyto, vector_len=len(vov), unit=vov.unit) comes back as the same VectorOfVectors"""
+    from lgdo_standins import Table, VectorOfVectors
+
+    from dspeed_amd import lgdo_io
+    from dspeed_amd.build_dsp import build_dsp
+
+    flat = np.arange(28, dtype=np.float32) * 0.5
+    vov = VectorOfVectors(flat, [3, 3, 10, 17, 28], {"units": "ADC"})
+    rec = {"outputs": ["vov_out"], "processors": {"vov_out": {"function": "numpy.copyto", "args": ["vov_out(shape = 12, vector_len = len(vov), unit = vov.unit)", "vov"],
+                                                              "signature": "()->()", "types": "dd"}}}
+    res = build_dsp(Table(vov=vov), dsp_config=rec)["vov_out"]
+    if isinstance(res, lgdo_io.RaggedColumn):
+        f2, cl2 = res.to_flat()
+    else:
+        f2, cl2 = np.asarray(res.flattened_data.nda), np.asarray(res.cumulative_length.nda)
+    assert np.array_equal(f2, flat) and list(cl2) == [3, 3, 10, 17, 28]

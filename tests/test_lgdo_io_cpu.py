@@ -98,3 +98,18 @@ def test_an_lh5_file_needs_the_package_and_says_so():
         pytest.skip("lgdo is installed here")
     with pytest.raises(ImportError, match="lgdo"):
         build_dsp("run0001.lh5", dsp_config=recipes.C2)
+
+
+def test_variable_index_into_a_variable_length_array_translates():
+    """the reference's own case (tests/test_processing_chain.py:75-97): a VectorOfVectors input, its middle and its last element"""
+    vov = VectorOfVectors(np.arange(150.0), [10, 30, 60, 100, 150], {"units": "ns"})
+    rec = {"outputs": ["vals", "v_end"], "processors": {"vals": "vov_in(shape=50)[len(vov_in)//2]", "v_end": "vov_in(shape=50)[-1]",
+                                                        "var_slice": "vov_in[indices:20]"}}
+    chain, mask, out = build_processing_chain(rec, Table(vov_in=vov))
+    ops = chain.program.ops
+    picks = [o for o in ops if o[0] == _lib.OP_PICKOFF]
+    assert len(picks) == 2 and all(o[4][1] == 2 for o in picks)  # get_default with a per-event index
+    assert any(o[0] == _lib.OP_SCALAR_FUNC and o[4][0] == _lib.FN_FLOORDIV for o in ops)
+    assert chain.program.slots == [50] and sorted(mask) == ["vov_in"]  # (the lengths come with the VectorOfVectors itself)
+    with pytest.raises(DSPFatal, match="larger than array variable length"):
+        build_processing_chain({"outputs": ["v"], "processors": {"v": "vov_in(shape=40)[0]"}}, Table(vov_in=vov))
