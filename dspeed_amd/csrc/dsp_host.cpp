@@ -265,6 +265,8 @@ static bool match_rows_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const 
     const DevOp& dpz = P.ops[dev_index[i]];
     ++i;
     if (pz.dst != s || pz.src != s) return false;
+    for (int k = 0; k < (pz.opcode == DSP_OP_POLE_ZERO ? 1 : 3); ++k)
+        if (pz.sp[k].kind != DSP_ARG_CONST) return false;  // (per-event time constants: the VM's ops form the coefficients per row)
     const dsp_op *tr = nullptr, *dw = nullptr, *st_wf = nullptr;
     int tr_at = -1;
     std::vector<const dsp_op*> st_sc;
@@ -951,7 +953,10 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             case DSP_OP_POLE_ZERO: {
                 if (!check_slot(P, o.src) || !check_slot(P, o.dst) || slot_len[o.src] != slot_len[o.dst])
                     return fail(DSP_ERR_ARG, "op %d: bad POLE_ZERO", i);
-                if (o.sp[0].kind != DSP_ARG_CONST) return fail(DSP_ERR_UNSUPPORTED, "op %d: per-waveform tau is not supported", i);
+                if (o.sp[0].kind != DSP_ARG_CONST) {  // one tau per event: the constant is formed on the device (op_pole_zero)
+                    d.ic[1] = 1;
+                    break;
+                }
                 const double tau = cst(0);
                 d.ic[0] = std::isnan(tau) ? 1 : 0;
                 d.fc[0] = std::exp(-1.0 / tau);  // pole_zero.py:60 -- float64 via libm, like numba's lowering
@@ -960,8 +965,13 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             case DSP_OP_DOUBLE_POLE_ZERO: {
                 if (!check_slot(P, o.src) || !check_slot(P, o.dst) || slot_len[o.src] != slot_len[o.dst])
                     return fail(DSP_ERR_ARG, "op %d: bad DOUBLE_POLE_ZERO", i);
-                for (int k = 0; k < 3; ++k)
-                    if (o.sp[k].kind != DSP_ARG_CONST) return fail(DSP_ERR_UNSUPPORTED, "op %d: per-waveform IIR constants are not supported", i);
+                bool per_event = false;
+                for (int k = 0; k < 3; ++k) per_event |= o.sp[k].kind != DSP_ARG_CONST;
+                if (per_event) {  // a time constant or the fraction per event: coefficients and scan matrices are formed on the device
+                    if (slot_len[o.src] <= 3) return fail(DSP_E_DPZ_SHORT, "%s", dsp_fatal_message(DSP_E_DPZ_SHORT));
+                    d.ic[1] = 1;
+                    break;
+                }
                 const double tau1 = cst(0), tau2 = cst(1), fr = cst(2);
                 d.ic[0] = (std::isnan(tau1) || std::isnan(tau2) || std::isnan(fr)) ? 1 : 0;
                 if (!d.ic[0] && slot_len[o.src] <= 3) return fail(DSP_E_DPZ_SHORT, "%s", dsp_fatal_message(DSP_E_DPZ_SHORT));
@@ -1188,6 +1198,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         const int wdt = ld ? io[ld->io].dtype : -1;
         const bool shape = !f64 && st && i == n_ops && n_slots == 1 && ld->ip[0] == 0 && ld->ip[1] == 0 && (wdt == DSP_F32 || wdt == DSP_I16 || wdt == DSP_U16) && P.io[ld->io].vec_ok &&
                            (!bs || (bs->dst == 0 && bs->src == 0 && bs->sp[0].kind != DSP_ARG_REG)) && pz->dst == 0 && pz->src == 0 &&
+                           pz->sp[0].kind == DSP_ARG_CONST &&
                            tp->src == 0 && tp->sp[0].kind != DSP_ARG_REG && st->ip[0] == tp->dst &&
                            (slot_len[0] == 1024 || slot_len[0] == 2048 || slot_len[0] == 4096 || slot_len[0] == 8192);
         auto f32_col = [&](const dsp_scalar_arg& a) { return a.kind != DSP_ARG_INPUT || io[a.index].dtype == DSP_F32; };
@@ -1660,7 +1671,7 @@ struct WfIn {
 
 // waveform -> waveform processors
 int wf2wf(int ty, int opcode, const WfIn& in, void* out, int32_t out_len, int64_t out_stride, const int32_t* ip, int n_ip,
-          const double* consts, int n_c, const void* col0, void* stream, int64_t* err_row) {
+          const double* consts, int n_c, const void* col0, void* stream, int64_t* err_row, const void* const* cols = nullptr) {
     if (in.n_wf <= 0) return DSP_OK;
     Mini m(ty);
     // the per-sample and scan filters work in place: one LDS slot, so a wavefront holds a waveform twice as long (about 38 k float32
@@ -1671,7 +1682,7 @@ int wf2wf(int ty, int opcode, const WfIn& in, void* out, int32_t out_len, int64_
     m.add_op(DSP_OP_LOAD, s_in, 0, io_in);
     dsp_scalar_arg sp[3];
     memset(sp, 0, sizeof sp);
-    for (int k = 0; k < n_c; ++k) sp[k] = m.scalar(k == 0 ? col0 : nullptr, consts[k]);
+    for (int k = 0; k < n_c; ++k) sp[k] = m.scalar(cols ? cols[k] : (k == 0 ? col0 : nullptr), consts[k]);  // device column or constant
     dsp_op& o = m.add_op(opcode, s_out, s_in, 0);
     for (int k = 0; k < n_ip; ++k) o.ip[k] = ip[k];
     for (int k = 0; k < n_c; ++k) o.sp[k] = sp[k];
@@ -1699,13 +1710,14 @@ int g_min_max_norm(int ty, const WfIn& in, const void* lo_dev, double lo, const 
     m.add_op(DSP_OP_STORE, 0, s_in, io_out);
     return m.run(in.n_wf, st, er);
 }
-int g_pole_zero(int ty, const WfIn& in, double tau, void* out, int64_t out_stride, void* st, int64_t* er) {
+int g_pole_zero(int ty, const WfIn& in, const void* tau_dev, double tau, void* out, int64_t out_stride, void* st, int64_t* er) {
     const double c[1] = {tau};
-    return wf2wf(ty, DSP_OP_POLE_ZERO, in, out, in.len, out_stride, nullptr, 0, c, 1, nullptr, st, er);
+    return wf2wf(ty, DSP_OP_POLE_ZERO, in, out, in.len, out_stride, nullptr, 0, c, 1, tau_dev, st, er);
 }
-int g_double_pole_zero(int ty, const WfIn& in, double tau1, double tau2, double frac, void* out, int64_t out_stride, void* st, int64_t* er) {
+int g_double_pole_zero(int ty, const WfIn& in, const void* const* cols, double tau1, double tau2, double frac, void* out, int64_t out_stride, void* st,
+                       int64_t* er) {
     const double c[3] = {tau1, tau2, frac};
-    return wf2wf(ty, DSP_OP_DOUBLE_POLE_ZERO, in, out, in.len, out_stride, nullptr, 0, c, 3, nullptr, st, er);
+    return wf2wf(ty, DSP_OP_DOUBLE_POLE_ZERO, in, out, in.len, out_stride, nullptr, 0, c, 3, cols ? cols[0] : nullptr, st, er, cols);
 }
 int g_trap(int ty, int opcode, const WfIn& in, int32_t rise, int32_t flat, int32_t fall, void* out, int64_t out_stride, void* st, int64_t* er) {
     const int32_t ip[3] = {rise, flat, fall};
@@ -1881,12 +1893,23 @@ int g_min_max(int ty, const WfIn& in, void* t_min, void* t_max, void* a_min, voi
     }                                                                                                                                         \
     int dsp_pole_zero_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, FT tau, FT* out,                   \
                             int64_t out_stride, void* stream, int64_t* err_row) {                                                             \
-        return g_pole_zero(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, (double)tau, out, out_stride, stream, err_row);                   \
+        return g_pole_zero(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, nullptr, (double)tau, out, out_stride, stream, err_row);          \
+    }                                                                                                                                         \
+    int dsp_pole_zero_col_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const FT* tau_dev, FT tau,      \
+                                FT* out, int64_t out_stride, void* stream, int64_t* err_row) {                                                \
+        return g_pole_zero(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, tau_dev, (double)tau, out, out_stride, stream, err_row);          \
+    }                                                                                                                                         \
+    int dsp_double_pole_zero_col_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const FT* tau1_dev,     \
+                                       FT tau1, const FT* tau2_dev, FT tau2, const FT* frac_dev, FT frac, FT* out, int64_t out_stride,        \
+                                       void* stream, int64_t* err_row) {                                                                      \
+        const void* cols[3] = {tau1_dev, tau2_dev, frac_dev};                                                                                 \
+        return g_double_pole_zero(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, cols, (double)tau1, (double)tau2, (double)frac, out,      \
+                                  out_stride, stream, err_row);                                                                              \
     }                                                                                                                                         \
     int dsp_double_pole_zero_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, FT tau1, FT tau2, FT frac,  \
                                    FT* out, int64_t out_stride, void* stream, int64_t* err_row) {                                             \
-        return g_double_pole_zero(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, (double)tau1, (double)tau2, (double)frac, out, out_stride, \
-                                  stream, err_row);                                                                                           \
+        return g_double_pole_zero(TY, WfIn{in, in_dtype, n_wf, wf_len, in_stride}, nullptr, (double)tau1, (double)tau2, (double)frac, out,   \
+                                  out_stride, stream, err_row);                                                                              \
     }                                                                                                                                         \
     int dsp_trap_filter_##SFX(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,      \
                               FT* out, int64_t out_stride, void* stream, int64_t* err_row) {                                                  \

@@ -406,11 +406,19 @@ template <typename T>
 __device__ __forceinline__ void op_pole_zero(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
-    if (cx.slot_nan(op.src) || op.ic[0]) {
+    double c = op.fc[0];
+    bool tau_nan = op.ic[0] != 0;
+    if (op.ic[1]) {  // one time constant per event (the gufunc's "()" slot filled by a per-event variable, pole_zero.py:24-30): the
+        // constant of pole_zero.py:60 is formed here, in float64 like numba forms it (the device's exp may differ from libm's in the last
+        // bit: 1e-16 on the constant, far below the float32 output)
+        const T tau = cx.scalar(op.sp[0]);
+        tau_nan = tau != tau;
+        c = exp(-1.0 / (double)tau);
+    }
+    if (cx.slot_nan(op.src) || tau_nan) {
         cx.set_nan(op.dst, true);
         return;
     }
-    const double c = op.fc[0];
     const auto* ps = cx.chunk(ss);
     auto* pd = cx.chunk(sd);
     const int C = ss.C;
@@ -458,14 +466,49 @@ template <typename T>
 __device__ __forceinline__ void op_double_pole_zero(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
     const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
-    if (cx.slot_nan(op.src) || op.ic[0]) {
+    double n1 = op.fc[0], n2 = op.fc[1], d1 = op.fc[2], d2 = op.fc[3];
+    bool par_nan = op.ic[0] != 0;
+    const int C = ss.C, lane = lane_id();
+    // powers of the recursion's linear part for the scan over the lanes: M^(C 2^d), d = 0..5; precomputed on the host for constant
+    // parameters, formed here (every lane the same 2 x 2 products, in float64) when a time constant or the fraction varies per event
+    double Mp[6][4];
+#pragma unroll
+    for (int d = 0; d < 6; ++d)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Mp[d][k] = op.fc[4 + 4 * d + k];
+    if (op.ic[1]) {
+        const T tau1 = cx.scalar(op.sp[0]), tau2 = cx.scalar(op.sp[1]), fr_t = cx.scalar(op.sp[2]);
+        par_nan = (tau1 != tau1) || (tau2 != tau2) || (fr_t != fr_t);
+        const double a = exp(-1.0 / (double)tau1), b = exp(-1.0 / (double)tau2), fr = (double)fr_t;  // pole_zero.py:168-174
+        d1 = ((fr * b - fr * a) - b) - 1.0;
+        d2 = -1.0 * ((fr * b - fr * a) - b);
+        n1 = -1.0 * (a + b);
+        n2 = a * b;
+        auto mul = [](const double* x, const double* y, double* o) {
+            const double r0 = x[0] * y[0] + x[1] * y[2], r1 = x[0] * y[1] + x[1] * y[3], r2 = x[2] * y[0] + x[3] * y[2], r3 = x[2] * y[1] + x[3] * y[3];
+            o[0] = r0;
+            o[1] = r1;
+            o[2] = r2;
+            o[3] = r3;
+        };
+        double base[4] = {-d1, -d2, 1.0, 0.0}, pw[4] = {1.0, 0.0, 0.0, 1.0};
+        for (int e = C; e; e >>= 1) {  // pw = M^C
+            if (e & 1) mul(pw, base, pw);
+            mul(base, base, base);
+        }
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Mp[d][k] = pw[k];
+            mul(pw, pw, pw);
+        }
+    }
+    if (cx.slot_nan(op.src) || par_nan) {
         cx.set_nan(op.dst, true);
         return;
     }
-    const double n1 = op.fc[0], n2 = op.fc[1], d1 = op.fc[2], d2 = op.fc[3];
     const auto* ps = cx.chunk(ss);
     auto* pd = cx.chunk(sd);
-    const int C = ss.C, lane = lane_id();
     // the two samples preceding this chunk
     const double xm1_in = (double)wave_prev(ps[C - 1]);
     const double xm2_in = (double)wave_prev(ps[C - 2]);
@@ -492,7 +535,7 @@ __device__ __forceinline__ void op_double_pole_zero(Ctx<T>& cx, const DSP_GLOBAL
     double r1 = y1, r0 = y0;
 #pragma unroll
     for (int d = 0; d < 6; ++d) {
-        const auto* M = &op.fc[4 + 4 * d];
+        const double* M = Mp[d];
         const double p1 = wave_shift_up(r1, 1 << d), p0 = wave_shift_up(r0, 1 << d);
         r1 += M[0] * p1 + M[1] * p0;
         r0 += M[2] * p1 + M[3] * p0;

@@ -86,9 +86,9 @@ bl_subtract = HipGUFunc("bl_subtract", "(n),()->(n)", ["ff->f", "dd->d"], _wf2wf
                         "w_out = w_in - a_baseline (reference processors/bl_subtract.py:11-46)")
 min_max_norm = HipGUFunc("min_max_norm", "(n),(),()->(n)", ["fff->f", "ddd->d"], _wf2wf("min_max_norm", scalar_cols=(0, 1)),
                          "waveform over the larger of |a_min|, |a_max| (reference processors/min_max.py:85-140)")
-pole_zero = HipGUFunc("pole_zero", "(n),()->(n)", ["ff->f", "dd->d"], _wf2wf("pole_zero"),
+pole_zero = HipGUFunc("pole_zero", "(n),()->(n)", ["ff->f", "dd->d"], _wf2wf("pole_zero_col", scalar_cols=(0,)),
                       "single pole-zero cancellation (reference processors/pole_zero.py:24-77)")
-double_pole_zero = HipGUFunc("double_pole_zero", "(n),(),(),()->(n)", ["ffff->f", "dddd->d"], _wf2wf("double_pole_zero"),
+double_pole_zero = HipGUFunc("double_pole_zero", "(n),(),(),()->(n)", ["ffff->f", "dddd->d"], _wf2wf("double_pole_zero_col", scalar_cols=(0, 1, 2)),
                              "double pole-zero cancellation (reference processors/pole_zero.py:82-198)")
 trap_filter = HipGUFunc("trap_filter", "(n),(),()->(n)", ["fii->f", "dii->d"], _wf2wf("trap_filter", n_ints=2),
                         "symmetric trapezoidal filter (reference processors/trap_filters.py:12-76)")

@@ -298,6 +298,19 @@ int dsp_pole_zero_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len
                       int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_double_pole_zero_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, float tau1, float tau2,
                              float frac, float* out, int64_t out_stride, void* stream, int64_t* err_row);
+/* pole_zero / double_pole_zero with a time constant (fraction) per waveform: the gufunc layouts "(n),()->(n)" / "(n),(),(),()->(n)" let
+ * ProcessorManager broadcast a per-event variable into a "()" slot (pole_zero.py:24-30, 82-90).  Each *_dev is a device column of n_wf
+ * values or NULL for the constant beside it. */
+int dsp_pole_zero_col_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* tau_dev, float tau,
+                          float* out, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_double_pole_zero_col_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const float* tau1_dev,
+                                 float tau1, const float* tau2_dev, float tau2, const float* frac_dev, float frac, float* out,
+                                 int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_pole_zero_col_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const double* tau_dev, double tau,
+                          double* out, int64_t out_stride, void* stream, int64_t* err_row);
+int dsp_double_pole_zero_col_f64(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, const double* tau1_dev,
+                                 double tau1, const double* tau2_dev, double tau2, const double* frac_dev, double frac, double* out,
+                                 int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_trap_filter_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,
                         float* out, int64_t out_stride, void* stream, int64_t* err_row);
 int dsp_trap_norm_f32(const void* in, int in_dtype, int64_t n_wf, int32_t wf_len, int64_t in_stride, int32_t rise, int32_t flat,
