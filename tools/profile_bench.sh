@@ -3,7 +3,7 @@
 #   tools/profile_bench.sh r01
 # Writes raw rocprofv3 output under gpurun_out/prof_<tag>/ ; tools/summarise_profile.py turns it into profiles/<tag>_*.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 export TMPDIR=/tmp
 mkdir -p "$OUT"

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Everything profiles/<tag>_* is made from, in one gpurun call (about 4 minutes of box time):  tools/profile_round.sh r02
+#   headline (bench.py): kernel-trace stats + PMC passes          -> gpurun_out/prof_<tag>/
+#   phase split of the headline kernel (diagnostic library)       -> gpurun_out/prof_<tag>/phases.txt
+#   C3 / C5 kernels: kernel-trace stats + PMC                     -> gpurun_out/prof_<tag>_c3, _c5
+#   secondary configs, whole recipe                               -> gpurun_out/prof_<tag>/other_configs.jsonl, icpc_recipe.jsonl
+set -u
+TAG=${1:-r02}
+OUT=gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+tools/profile_bench.sh "$TAG" > "$OUT/profile_bench.log" 2>&1
+python3 -m dspeed_amd.build --diag > "$OUT/diag_build.log" 2>&1
+DSPEED_HIP_LIB=$PWD/dspeed_amd/libdspeed_hip_diag.so DSPEED_HIP_ABLATE=8 python3 bench.py --allow-variants --no-cpu --steps 10 --warmup 3 > "$OUT/phases.json" 2> "$OUT/phases.txt"
+tools/pmc_kernel.sh gpurun_out/prof_${TAG}_c3 tools/c3_rate.py 250000 1 > /dev/null 2>&1
+python3 tools/pmc_table.py gpurun_out/prof_${TAG}_c3 "" "$OUT/c3_pmc.json" > /dev/null
+tools/pmc_kernel.sh gpurun_out/prof_${TAG}_c5 tools/c5_rate.py 1000000 1 > /dev/null 2>&1
+python3 tools/pmc_table.py gpurun_out/prof_${TAG}_c5 "" "$OUT/c5_pmc.json" > /dev/null
+python3 tools/c3_rate.py 250000 1 > "$OUT/c3_rate.json" 2>/dev/null
+python3 tools/c5_rate.py 1000000 1 > "$OUT/c5_rate.json" 2>/dev/null
+python3 tools/bench_configs.py 1000000 > "$OUT/other_configs.jsonl" 2> "$OUT/other_configs.err"
+python3 tools/icpc_breakdown.py > "$OUT/icpc_recipe.jsonl" 2> "$OUT/icpc_recipe.err"
+python3 bench.py --wf-len 8192 --rows 500000 --no-cpu --steps 10 --warmup 5 > "$OUT/bench_8192.json" 2>/dev/null
+echo "round profile $TAG done"; tail -2 "$OUT/phases.txt"; cat "$OUT/c3_rate.json" "$OUT/c5_rate.json"

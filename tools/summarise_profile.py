@@ -65,6 +65,7 @@ if "FETCH_SIZE" in pmc:
     summary.append(f"* HBM traffic per launch (PMC, separate passes): FETCH_SIZE x2 = {fetch / 1e9:.3f} GB, WRITE_SIZE = {write / 1e6:.2f} MB; "
                    f"algorithmic {alg / 1e9:.3f} GB -> traffic / algorithmic = {(fetch + write) / alg:.3f}")
     json.dump({"kernel": kernel, "rows": rows, "wf_len": wf_len, "hbm_bytes_per_launch": fetch + write,
+               "kernel_source_hash": bench["config"].get("kernel_source_hash"),  # bench.py quotes the figure only for these sources
                "source": f"profiles/{tag}_pmc.json: FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (rocprofv3 --pmc, separate passes)"},
               open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 n = 1e6 * rows / 1e6
