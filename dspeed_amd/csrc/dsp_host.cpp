@@ -172,6 +172,11 @@ struct dsp_chain {
     FirArgs fir{};
     int fir_lds_bytes = 0;
     int fio_wf = -1, fio_bl = -1, fio_taps[DSP_FIR_MAXK] = {-1, -1, -1, -1}, fio_out[DSP_FIR_MAXK] = {-1, -1, -1, -1};
+    ~dsp_chain() {  // (also on the error paths of dsp_chain_create, which holds the chain in a unique_ptr)
+        if (dev) (void)hipFree(dev);
+        if (dev_err) (void)hipFree(dev_err);
+        if (host.prof) (void)hipFree(host.prof);
+    }
 };
 
 static bool match_fir_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, const int32_t* slot_len, int n_slots, bool f64) {
@@ -1202,7 +1207,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                            tp->src == 0 && tp->sp[0].kind != DSP_ARG_REG && st->ip[0] == tp->dst &&
                            (slot_len[0] == 1024 || slot_len[0] == 2048 || slot_len[0] == 4096 || slot_len[0] == 8192);
         auto f32_col = [&](const dsp_scalar_arg& a) { return a.kind != DSP_ARG_INPUT || io[a.index].dtype == DSP_F32; };
-        if (shape && (!bs || f32_col(bs->sp[0])) && f32_col(tp->sp[0])) {
+        if (shape && (!bs || f32_col(bs->sp[0])) && f32_col(tp->sp[0]) && io[st->io].dtype == DSP_F32) {  // (the kernels store a float)
             EnergyArgs& F = ch->fused;
             const DevOp& dpz = P.ops[dev_index[pz - ops]];
             const DevOp& dtp = P.ops[dev_index[tp - ops]];
@@ -1389,6 +1394,10 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         if (!io_ptrs[k]) return fail(DSP_ERR_ARG, "io binding %d is NULL", k);
         ptrs.p[k] = io_ptrs[k];
     }
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != ch->device) HIP_TRY(hipSetDevice(ch->device));  // the chain's program and error word live there
+    }
     (void)hipGetLastError();  // launch checks below report this launch, not a stale error of an unrelated earlier call
     if (fir_applies(ch, io_ptrs)) {
         FirArgs A = ch->fir;
@@ -1515,9 +1524,6 @@ int dsp_chain_profile_read(dsp_chain* ch, int capacity, int32_t* opcodes, int32_
 
 int dsp_chain_destroy(dsp_chain* ch) {
     if (!ch) return DSP_OK;
-    if (ch->dev) (void)hipFree(ch->dev);
-    if (ch->dev_err) (void)hipFree(ch->dev_err);
-    if (ch->host.prof) (void)hipFree(ch->host.prof);
     delete ch;
     return DSP_OK;
 }
@@ -1635,21 +1641,21 @@ struct Mini {
             for (int k = 0; k < 4; ++k) key.v.push_back(o.ip[k]);
             key.v.push_back(o.io);
         }
+        // The cached chains carry one device error word each and are destroyed when the cache is emptied: look-up, creation, execution and
+        // the check of the error word happen under the cache's lock, so the dsp_<name>_f32/_f64 entry points are serialised within a
+        // process (threads that want concurrency build their own chains with dsp_chain_create).
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        key.v.push_back(dev);
         dsp_chain* ch = nullptr;
-        {
-            std::lock_guard<std::mutex> lk(g_cache_mu);
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            key.v.push_back(dev);
-            auto it = g_cache.find(key);
-            if (it != g_cache.end()) ch = it->second;
-        }
+        auto it = g_cache.find(key);
+        if (it != g_cache.end()) ch = it->second;
         if (!ch) {
             int rc = dsp_chain_create(ops.data(), (int)ops.size(), io.data(), (int)io.size(), slots.data(), (int)slots.size(), n_sregs, ty,
                                       &ch);
             if (rc) return rc;
-            std::lock_guard<std::mutex> lk(g_cache_mu);
-            if (g_cache.size() > 256) {
+            if (g_cache.size() > 256) {  // (nobody is inside a cached chain: we hold the lock)
                 for (auto& kv : g_cache) dsp_chain_destroy(kv.second);
                 g_cache.clear();
             }

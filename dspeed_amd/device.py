@@ -235,13 +235,20 @@ class DeviceArray:
 
     # -- copies
     def copy_from(self, a, stream: Stream | None = None):
+        """Host -> device.  With a stream the copy is asynchronous and reads ``a``'s memory until the stream has passed it: ``a`` must
+        then already be a C-contiguous array of this array's dtype that the caller keeps alive (a converted temporary would be freed
+        under the DMA)."""
+        if stream is not None:
+            if not (isinstance(a, np.ndarray) and a.flags.c_contiguous and a.dtype == self.dtype):
+                raise ValueError("asynchronous copy_from needs a C-contiguous ndarray of the device array's dtype (no temporary copies)")
+            assert a.nbytes == self.nbytes, f"size mismatch {a.shape} vs {self.shape}"
+            self._h2d_src = a  # (kept until the next copy: the stream may still be reading it when the caller drops its reference)
+            _lib.check(_lib.lib().dsp_h2d_async(self.ptr, a.ctypes.data, self.nbytes, stream.ptr), what="h2d_async")
+            return
         a = np.ascontiguousarray(a, dtype=self.dtype)
         assert a.nbytes == self.nbytes, f"size mismatch {a.shape} vs {self.shape}"
-        if stream is None:
-            if self.nbytes:
-                _Bounce.h2d(self.ptr, a)
-        else:
-            _lib.check(_lib.lib().dsp_h2d_async(self.ptr, a.ctypes.data, self.nbytes, stream.ptr), what="h2d_async")
+        if self.nbytes:
+            _Bounce.h2d(self.ptr, a)
 
     def to_numpy(self, out=None, stream: Stream | None = None):
         if out is None:
@@ -257,7 +264,9 @@ class DeviceArray:
     def view_rows(self, start: int, stop: int) -> "DeviceArray":
         """Rows [start, stop) of a 2-D (or 1-D) array, sharing memory."""
         row_bytes = self.nbytes // self.shape[0] if self.shape[0] else 0
-        return DeviceArray((stop - start, *self.shape[1:]), self.dtype, ptr=self.ptr + start * row_bytes, owner=False)
+        v = DeviceArray((stop - start, *self.shape[1:]), self.dtype, ptr=self.ptr + start * row_bytes, owner=False)
+        v._base = self  # (the view keeps the allocation alive)
+        return v
 
     def __len__(self):
         return self.shape[0]

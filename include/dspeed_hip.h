@@ -20,8 +20,9 @@
  *     chain creation, data-dependent ones reported by dsp_chain_check);  nothing throws;
  *   - per-waveform failure is NaN output, never an error (docs/source/manuals/build_dsp.rst:152-175);
  *   - a chain handle is bound to the device current at creation and is not thread-safe; independent
- *     handles may be used from different threads/devices; the only global state is the thread-local
- *     string behind dsp_last_error().
+ *     handles may be used from different threads/devices.  Global state: the thread-local string behind
+ *     dsp_last_error(), and the cache of small chains behind the single-processor entry points
+ *     (dsp_<name>_f32 / _f64), which is guarded by one lock -- those calls are serialised within a process.
  */
 #ifndef DSPEED_HIP_H
 #define DSPEED_HIP_H
