@@ -9,15 +9,24 @@ import sys
 src = sys.argv[1]
 want = sys.argv[2] if len(sys.argv) > 2 else ""
 acc = {}
+
+
+def key(name: str) -> str:
+    """'void (anonymous namespace)::dsp_x_kernel<float, 2>(Args, ...)' -> 'dsp_x_kernel<float, 2>'"""
+    n = name.replace("(anonymous namespace)::", "")
+    n = n[5:] if n.startswith("void ") else n
+    return n.split("(")[0].strip()[:80]
+
+
 for f in glob.glob(f"{src}/*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         if want in r["Kernel_Name"]:
-            acc.setdefault(r["Kernel_Name"].split("(")[0][:60], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            acc.setdefault(key(r["Kernel_Name"]), {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 out = {k: {c: sum(v) / len(v) for c, v in d.items()} | {"dispatches": max(len(v) for v in d.values())} for k, d in acc.items()}
 for f in glob.glob(f"{src}/trace/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         for k in out:
-            if k in r["Name"]:
+            if key(r["Name"]) == k:
                 out[k]["trace_avg_ms"] = float(r["AverageNs"]) / 1e6
                 out[k]["trace_calls"] = int(r["Calls"])
 print(json.dumps(out, indent=1))
