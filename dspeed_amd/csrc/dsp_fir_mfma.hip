@@ -255,7 +255,251 @@ __global__ void __launch_bounds__(512, 2) dsp_fir_mfma_kernel(FirArgs A_, int64_
     }
 }
 
+// ---- the same product with the outputs kept: convolve_wf in any mode whose result is a waveform other processors read (the t0 filter of
+// the Ge recipes: 133 taps, 'same', 8192 outputs).  Output c sums the samples c - d .. c - d + m - 1 (d = 0 'valid', m / 2 'same', m - 1
+// 'full'; samples outside the waveform are the zeros np.convolve pads with), so a tile of 320 columns is the product of the 64 x K window
+// of the rows that starts at sample 320 ct - d (rounded down to a multiple of 4 for the 16-byte loads, the remainder e moves into the tap
+// index) with the same zero-margined reversed kernel; K = 320 + m - 1 + e rounded up to 32.  A wavefront's 80 columns meet the band of a
+// short kernel only in some of the stages: the others are skipped (the tile's barriers stay).  No screening here: dsp_fir_fixup_kernel
+// looks at the rows afterwards and rewrites the ones holding a NaN (all NaN, convolutions.py:40-43) or an infinity (tap by tap).
+constexpr int TB = BN + 4, SCHUNK = 64;
+
+template <int IN>
+__global__ void __launch_bounds__(512, 2) dsp_fir_store_kernel(FirArgs A_, int64_t n_wf) {
+    const FIR_KARG FirArgs& A = *(const FIR_KARG FirArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)A_;
+    extern __shared__ __attribute__((aligned(16))) float fir_smem[];
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int c0 = (int)blockIdx.x * BN;
+    const int64_t row0 = (int64_t)blockIdx.y * BM;
+    const int n = A.n, m = A.m[0], P = A.p[0];
+    const int s0 = c0 - A.dshift;
+    const int ks = (s0 >> 2) << 2, e = s0 - ks;  // (arithmetic shift: rounds down for the negative start of the first tiles)
+    const int cols = P - c0 < BN ? P - c0 : BN;
+    const int kt = ((cols + m - 1 + e + BK - 1) / BK) * BK;
+
+    FIR_LDS float* tapz = (FIR_LDS float*)fir_smem;
+    FIR_LDS float* As = tapz + ((TB + A.kend + 3) & ~3);  // (kend: the longest window of any tile, the host sized the margins for it)
+    {
+        const FIR_GLOBAL float* kp = (const FIR_GLOBAL float*)A.taps[0];
+        for (int idx = tid; idx < TB + kt; idx += 512) {
+            const int t = idx - TB;
+            tapz[idx] = (t >= 0 && t < m) ? kp[m - 1 - t] : 0.0f;
+        }
+    }
+    const int srow = tid >> 3, skc = (tid & 7) * 4;
+    const int64_t grow = row0 + srow < n_wf ? row0 + srow : n_wf - 1;
+    constexpr int ESZ = IN == 0 ? 4 : 2;
+    const FIR_GLOBAL char* rowp = (const FIR_GLOBAL char*)A.wf + (grow * A.wf_stride + A.wf_offset) * ESZ;
+    const float bl = A.sub_mode ? (A.bl ? ((const FIR_GLOBAL float*)A.bl)[grow * A.bl_stride] : A.bl_const) : 0.0f;
+    const bool sub = A.sub_mode != 0;
+    f4 stage_v;
+    auto one = [&](int i) -> float {
+        if (i < 0 || i >= n) return 0.0f;
+        return IN == 0 ? ((const FIR_GLOBAL float*)rowp)[i] : (IN == 1 ? (float)((const FIR_GLOBAL short*)rowp)[i] : (float)((const FIR_GLOBAL unsigned short*)rowp)[i]);
+    };
+    auto fetch = [&](int k0) {
+        const int i = ks + k0 + skc;
+        if (i >= 0 && i + 4 <= n) {
+            if (IN == 0) {
+                stage_v = *(const FIR_GLOBAL f4*)(rowp + (size_t)i * 4);
+            } else {
+                const u2 raw = *(const FIR_GLOBAL u2*)(rowp + (size_t)i * 2);
+                stage_v[0] = IN == 1 ? (float)(short)(raw[0] & 0xffffu) : (float)(raw[0] & 0xffffu);
+                stage_v[1] = IN == 1 ? (float)(short)(raw[0] >> 16) : (float)(raw[0] >> 16);
+                stage_v[2] = IN == 1 ? (float)(short)(raw[1] & 0xffffu) : (float)(raw[1] & 0xffffu);
+                stage_v[3] = IN == 1 ? (float)(short)(raw[1] >> 16) : (float)(raw[1] >> 16);
+            }
+        } else {  // a window end: sample by sample, zeros outside the waveform
+#pragma unroll
+            for (int u = 0; u < 4; ++u) stage_v[u] = one(i + u);
+        }
+    };
+    auto commit = [&](int k0, int buf) {
+        f4 v = stage_v;
+        const int i = ks + k0 + skc;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float x = sub ? v[u] - bl : v[u];
+            v[u] = (i + u >= 0 && i + u < n) ? x : 0.0f;
+        }
+        *(FIR_LDS f4*)(As + buf * BM * APITCH + srow * APITCH + skc) = v;
+    };
+
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    acc_t acc[MT][NT];
+    double tot[MT][NT][4];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            acc[a][b] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tot[a][b][r] = 0.0;
+        }
+    const int j = lane & 15, h4 = lane >> 4;
+    const int a_off = (wm * 32 + j) * APITCH + 4 * h4;
+    const int t_off = TB + 4 * h4 - (wn * 80 + j) - e;
+    // stages in which this wavefront's columns see a tap: window sample kk meets column cl at tap kk - cl - e
+    const int k_lo = wn * 80 + e, k_hi = wn * 80 + 79 + e + m - 1;
+
+    fetch(0);
+    commit(0, 0);
+    __syncthreads();
+    const int n_stage = kt / BK;
+    for (int st = 0; st < n_stage; ++st) {
+        const int buf = st & 1, k0 = st * BK;
+        if (st + 1 < n_stage) fetch(k0 + BK);
+        if (k0 + BK > k_lo && k0 <= k_hi) {
+            const FIR_LDS float* ab = As + buf * BM * APITCH + a_off;
+#pragma unroll
+            for (int g = 0; g < BK / 16; ++g) {
+                f4 a[MT];
+#pragma unroll
+                for (int tm = 0; tm < MT; ++tm) a[tm] = *(const FIR_LDS f4*)(ab + tm * 16 * APITCH + g * 16);
+                float b[NT][4];
+                const FIR_LDS float* tb = tapz + t_off + k0 + g * 16;
+#pragma unroll
+                for (int tn = 0; tn < NT; ++tn)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b[tn][s] = tb[s - tn * 16];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+            }
+        }
+        if (st + 1 < n_stage) commit(k0 + BK, buf ^ 1);
+        if (((st + 1) * BK) % SCHUNK == 0) {  // (64 samples per float32 partial sum, as the waveform VM's op: short differentiating kernels cancel)
+#pragma unroll
+            for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < NT; ++tn) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tot[tm][tn][r] += (double)acc[tm][tn][r];
+                    acc[tm][tn] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+        }
+        __syncthreads();
+    }
+    // ---- the tile's outputs; C layout of a 16 x 16 tile: column = lane & 15, row = 4 (lane >> 4) + r
+    FIR_GLOBAL float* outp = (FIR_GLOBAL float*)A.out[0];
+#pragma unroll
+    for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + wm * 32 + tm * 16 + h4 * 4 + r;
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn) {
+                const int cl = wn * 80 + tn * 16 + j;
+                if (row < n_wf && cl < cols) outp[row * A.out_stride[0] + c0 + cl] = (float)(tot[tm][tn][r] + (double)acc[tm][tn][r]);
+            }
+        }
+}
+
+// One wavefront per row, after dsp_fir_store_kernel: a row with a NaN (in the slice, or anywhere in the waveform when bl_subtract's rule
+// applies: scan_before / scan_after) becomes all NaN; a row with an infinity is recomputed tap by tap over the samples np.convolve
+// multiplies (the product above also multiplied it into the zeros of other windows).
+template <int IN>
+__global__ void __launch_bounds__(256) dsp_fir_fixup_kernel(FirArgs A_, int64_t n_wf) {
+    const FIR_KARG FirArgs& A = *(const FIR_KARG FirArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)A_;
+    const int lane = (int)threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (row >= n_wf) return;
+    constexpr int ESZ = IN == 0 ? 4 : 2;
+    const int n = A.n, m = A.m[0], P = A.p[0], d = A.dshift;
+    const FIR_GLOBAL char* rowp = (const FIR_GLOBAL char*)A.wf + (row * A.wf_stride + A.wf_offset) * ESZ;
+    const float bl = A.sub_mode ? (A.bl ? ((const FIR_GLOBAL float*)A.bl)[row * A.bl_stride] : A.bl_const) : 0.0f;
+    const bool sub = A.sub_mode != 0;
+    auto at = [&](int i) -> float {
+        const float x = IN == 0 ? ((const FIR_GLOBAL float*)rowp)[i] : (IN == 1 ? (float)((const FIR_GLOBAL short*)rowp)[i] : (float)((const FIR_GLOBAL unsigned short*)rowp)[i]);
+        return sub ? x - bl : x;
+    };
+    bool has_nan = false, has_inf = false;
+    if (IN == 0) {
+        const int n4 = n & ~3;
+        for (int i = lane * 4; i < n4; i += 256) {
+            const f4 v = *(const FIR_GLOBAL f4*)(rowp + (size_t)i * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float x = sub ? v[u] - bl : v[u];
+                has_nan |= (x != x);
+                has_inf |= !(__builtin_fabsf(x) <= 3.4028234663852886e38f);
+            }
+        }
+        for (int i = n4 + lane; i < n; i += 64) {
+            const float x = at(i);
+            has_nan |= (x != x);
+            has_inf |= !(__builtin_fabsf(x) <= 3.4028234663852886e38f);
+        }
+        if (sub) {
+            for (int i = -A.scan_before + lane; i < 0; i += 64) has_nan |= (at(i) != at(i));
+            for (int i = n + lane; i < n + A.scan_after; i += 64) has_nan |= (at(i) != at(i));
+        }
+    } else {  // integer samples: only the baseline can be a NaN or an infinity
+        has_nan = sub && (bl != bl);
+        has_inf = sub && !(__builtin_fabsf(bl) <= 3.4028234663852886e38f);
+    }
+    has_nan = __any(has_nan);
+    has_inf = __any(has_inf);
+    if (!has_nan && !has_inf) return;
+    FIR_GLOBAL float* outp = (FIR_GLOBAL float*)A.out[0] + row * A.out_stride[0];
+    if (has_nan) {
+        for (int c = lane; c < P; c += 64) outp[c] = quiet_nan<float>();
+        return;
+    }
+    const FIR_GLOBAL float* kp = (const FIR_GLOBAL float*)A.taps[0];
+    for (int c = lane; c < P; c += 64) {
+        float s = 0.0f;
+        for (int t = 0; t < m; ++t) {  // sample c - d + t meets the reversed kernel's tap t = kernel[m - 1 - t]
+            const int i = c - d + t;
+            if (i >= 0 && i < n) s = __builtin_fmaf(at(i), kp[m - 1 - t], s);
+        }
+        outp[c] = s;
+    }
+}
+
 }  // namespace
+
+extern "C" int dsp_internal_fir_store_lds_bytes(int kend) { return (((TB + kend + 3) & ~3) + 2 * BM * APITCH) * 4; }
+
+extern "C" int dsp_internal_launch_fir_store(const FirArgs* A, int64_t n_wf, int lds_bytes, hipStream_t stream) {
+    if (n_wf <= 0 || A->p[0] <= 0) return 0;
+    const dim3 grid((unsigned)((A->p[0] + BN - 1) / BN), (unsigned)((n_wf + BM - 1) / BM));
+    const dim3 fix((unsigned)((n_wf + 3) / 4));
+    switch (A->in_kind) {
+        case 0:
+            hipLaunchKernelGGL(dsp_fir_store_kernel<0>, grid, dim3(512), lds_bytes, stream, *A, n_wf);
+            hipLaunchKernelGGL(dsp_fir_fixup_kernel<0>, fix, dim3(256), 0, stream, *A, n_wf);
+            break;
+        case 1:
+            hipLaunchKernelGGL(dsp_fir_store_kernel<1>, grid, dim3(512), lds_bytes, stream, *A, n_wf);
+            hipLaunchKernelGGL(dsp_fir_fixup_kernel<1>, fix, dim3(256), 0, stream, *A, n_wf);
+            break;
+        default:
+            hipLaunchKernelGGL(dsp_fir_store_kernel<2>, grid, dim3(512), lds_bytes, stream, *A, n_wf);
+            hipLaunchKernelGGL(dsp_fir_fixup_kernel<2>, fix, dim3(256), 0, stream, *A, n_wf);
+            break;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int dsp_internal_set_fir_store_lds(int lds_bytes) {
+    const void* k[3] = {reinterpret_cast<const void*>(&dsp_fir_store_kernel<0>), reinterpret_cast<const void*>(&dsp_fir_store_kernel<1>),
+                        reinterpret_cast<const void*>(&dsp_fir_store_kernel<2>)};
+    for (int i = 0; i < 3; ++i) {
+        const int rc = (int)hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
+extern "C" const char* dsp_internal_fir_store_kernel_name() { return "dsp_fir_store_kernel"; }
 
 extern "C" int dsp_internal_fir_mfma_lds_bytes(int kend) { return (((BN + kend + 3) & ~3) + 2 * BM * APITCH + BM * 4 * 2) * 4; }
 

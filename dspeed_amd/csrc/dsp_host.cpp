@@ -86,6 +86,10 @@ extern "C" int dsp_internal_fir_mfma_lds_bytes(int kend);
 extern "C" int dsp_internal_launch_fir_mfma(const FirArgs* A, int64_t n_wf, int lds_bytes, hipStream_t stream);
 extern "C" int dsp_internal_set_fir_mfma_lds(int lds_bytes);
 extern "C" const char* dsp_internal_fir_mfma_kernel_name();
+extern "C" int dsp_internal_fir_store_lds_bytes(int kend);
+extern "C" int dsp_internal_launch_fir_store(const FirArgs* A, int64_t n_wf, int lds_bytes, hipStream_t stream);
+extern "C" int dsp_internal_set_fir_store_lds(int lds_bytes);
+extern "C" const char* dsp_internal_fir_store_kernel_name();
 
 namespace {
 
@@ -171,6 +175,7 @@ struct dsp_chain {
     bool fir_ok = false;
     FirArgs fir{};
     int fir_lds_bytes = 0;
+    int64_t fir_out_offset = 0;  // stored variant: first element of the output binding
     int fio_wf = -1, fio_bl = -1, fio_taps[DSP_FIR_MAXK] = {-1, -1, -1, -1}, fio_out[DSP_FIR_MAXK] = {-1, -1, -1, -1};
     ~dsp_chain() {  // (also on the error paths of dsp_chain_create, which holds the chain in a unique_ptr)
         if (dev) (void)hipFree(dev);
@@ -245,6 +250,62 @@ static bool match_fir_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const d
     return ch->fir_lds_bytes <= 80 * 1024;
 }
 
+// The matrix-core FIR with its output kept (dsp_fir_store_kernel):  LOAD s; [BL_SUBTRACT s <- s]; CONVOLVE d <- s (any mode, >= 64 finite taps);
+// STORE d.  What whole recipes run ahead of their program for the filters other processors read (the t0 filter).
+static bool match_fir_store_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, const int32_t* slot_len, int n_slots, bool f64) {
+    if (f64 || n_ops < 3 || n_ops > 4 || n_slots != 2 || ops[0].opcode != DSP_OP_LOAD) return false;
+    const dsp_op& ld = ops[0];
+    const int s = ld.dst, wdt = io[ld.io].dtype, n = slot_len[s];
+    if (wdt != DSP_F32 && wdt != DSP_I16 && wdt != DSP_U16) return false;
+    const int es = wdt == DSP_F32 ? 4 : 2, align = wdt == DSP_F32 ? 16 : 8;
+    if ((io[ld.io].row_stride * es) % align != 0 || (io[ld.io].offset * es) % align != 0) return false;
+    FirArgs& A = ch->fir;
+    memset(&A, 0, sizeof A);
+    ch->fio_bl = -1;
+    int i = 1;
+    if (ops[i].opcode == DSP_OP_BL_SUBTRACT) {
+        const dsp_op& bs = ops[i++];
+        if (bs.dst != s || bs.src != s || bs.ip[0] != 0) return false;
+        if (bs.sp[0].kind == DSP_ARG_INPUT && io[bs.sp[0].index].dtype == DSP_F32) {
+            ch->fio_bl = bs.sp[0].index;
+            A.bl_stride = io[ch->fio_bl].row_stride;
+        } else if (bs.sp[0].kind == DSP_ARG_CONST) {
+            A.bl_const = (float)bs.sp[0].value;
+        } else {
+            return false;
+        }
+        A.sub_mode = 1;
+    }
+    if (i + 2 != n_ops || ops[i].opcode != DSP_OP_CONVOLVE || ops[i + 1].opcode != DSP_OP_STORE) return false;
+    const dsp_op& o = ops[i];
+    const dsp_op& st = ops[i + 1];
+    if (o.src != s || o.dst == s || o.ip[1] != 0 || io[o.io].dtype != DSP_F32 || st.src != o.dst || io[st.io].dtype != DSP_F32) return false;
+    const int m = o.ip[3] > 0 ? o.ip[3] : io[o.io].len;
+    if (m < 64 || m > n) return false;
+    const int mode = o.ip[0];
+    const int P = mode == 'v' ? n - m + 1 : (mode == 's' ? n : (mode == 'f' ? n + m - 1 : -1));
+    if (P < 1 || slot_len[o.dst] != P || io[st.io].len != P) return false;
+    A.store = 1;
+    A.dshift = mode == 'v' ? 0 : (mode == 's' ? m / 2 : m - 1);
+    A.m[0] = m;
+    A.p[0] = P;
+    A.n_kernels = 1;
+    A.out_stride[0] = io[st.io].row_stride;
+    A.wf_stride = io[ld.io].row_stride;
+    A.wf_offset = io[ld.io].offset;
+    A.n = n;
+    A.in_kind = wdt == DSP_F32 ? 0 : (wdt == DSP_I16 ? 1 : 2);
+    A.kend = ((320 + m - 1 + 3 + 31) / 32) * 32;  // the longest window of a 320-column tile (dsp_fir_mfma.hip)
+    A.scan_before = ld.ip[0];
+    A.scan_after = ld.ip[1];
+    ch->fio_wf = ld.io;
+    ch->fio_taps[0] = o.io;
+    ch->fio_out[0] = st.io;
+    ch->fir_out_offset = io[st.io].offset;
+    ch->fir_lds_bytes = dsp_internal_fir_store_lds_bytes(A.kend);
+    return ch->fir_lds_bytes <= 80 * 1024;
+}
+
 // Does the program have the shape of the lane-per-waveform kernel?  Fills ch->rows / ch->rio_* and returns true if so.
 //   LOAD s;  [BL_SUBTRACT s <- s];  POLE_ZERO | DOUBLE_POLE_ZERO s <- s;  then in any order: one TRAP_REDUCE of s, at most one DWT_HAAR of s
 //   into a slot that is stored, STORE_SCALARs of the reduction's registers.
@@ -291,6 +352,7 @@ static bool match_rows_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const 
         }
     }
     if (!tr || (dw != nullptr) != (st_wf != nullptr)) return false;
+    if (tr->ip[3] >> 8) return false;  // (a pick-off or the amax-only form of the reduction: the VM's)
     if (dw && (st_wf->src != dw->dst || io[st_wf->io].dtype != DSP_F32)) return false;
     const DevOp& dtr = P.ops[dev_index[tr_at]];
     RowsArgs& A = ch->rows;
@@ -1027,9 +1089,14 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             case DSP_OP_TRAP_REDUCE: {
                 if (!check_slot(P, o.src) || (o.dst < 0 && o.io < 0) || (o.dst >= 0 && o.dst + 3 >= n_sregs) || o.io >= n_sregs)
                     return fail(DSP_ERR_ARG, "op %d: bad TRAP_REDUCE", i);
-                if (o.ip[3] != DSP_OP_TRAP_FILTER && o.ip[3] != DSP_OP_TRAP_NORM && o.ip[3] != DSP_OP_ASYM_TRAP)
+                const int tk = o.ip[3] & 0xff, pk_mode = (o.ip[3] >> 8) & 0xff, pk_reg = ((o.ip[3] >> 16) & 0x3fff) - 1;
+                if (tk != DSP_OP_TRAP_FILTER && tk != DSP_OP_TRAP_NORM && tk != DSP_OP_ASYM_TRAP)
                     return fail(DSP_ERR_ARG, "op %d: TRAP_REDUCE ip[3] must name a trapezoid opcode", i);
-                int rc = setup_trap(d, o.ip[3], o.ip[0], o.ip[1], o.ip[2], slot_len[o.src], P.slots[o.src].C);
+                if (pk_reg >= n_sregs || (pk_reg >= 0 && (pk_mode == 0 || pk_mode == 's')) || (pk_reg < 0 && pk_mode != 0))
+                    return fail(DSP_ERR_ARG, "op %d: bad pick-off in TRAP_REDUCE (register %d, mode %d)", i, pk_reg, pk_mode);
+                if (((o.ip[3] >> 30) & 1) && (o.dst < 0 || tk == DSP_OP_ASYM_TRAP))
+                    return fail(DSP_ERR_ARG, "op %d: TRAP_REDUCE amax-only needs the min_max registers and trap_filter / trap_norm", i);
+                int rc = setup_trap(d, tk, o.ip[0], o.ip[1], o.ip[2], slot_len[o.src], P.slots[o.src].C);
                 if (rc) return fail(rc, "%s", dsp_fatal_message(rc));
                 break;
             }
@@ -1085,7 +1152,9 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 if ((long long)length < 0 || (long long)length >= n) return fail(DSP_E_MW_LEN_RANGE, "%s", dsp_fatal_message(DSP_E_MW_LEN_RANGE));
                 if (num < 0) return fail(DSP_E_MW_NUM_NEG, "%s", dsp_fatal_message(DSP_E_MW_NUM_NEG));
                 if (num > 0 && (long long)length == 0) return fail(DSP_E_ZERODIV, "%s", dsp_fatal_message(DSP_E_ZERODIV));
-                if (num > 1 && (!check_slot(P, o.ip[2]) || o.ip[2] == o.src || o.ip[2] == o.dst || slot_len[o.ip[2]] != n))
+                // (the scratch may be the source itself when the number of windows is odd: the first pass goes source -> target, so the
+                // source is free from the second pass on -- and is overwritten)
+                if (num > 1 && (!check_slot(P, o.ip[2]) || (o.ip[2] == o.src && num % 2 == 0) || o.ip[2] == o.dst || slot_len[o.ip[2]] != n))
                     return fail(DSP_ERR_ARG, "op %d: MOVING_WINDOW_MULTI with several windows needs a scratch slot of the same length (ip[2])", i);
                 d.ic[0] = (int)length;
                 d.ic[1] = num;
@@ -1298,6 +1367,10 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     }
 
     ch->fir_ok = match_fir_shape(ch.get(), ops, n_ops, io, slot_len, n_slots, f64);
+    if (!ch->fir_ok) {
+        for (int k = 0; k < DSP_FIR_MAXK; ++k) ch->fio_taps[k] = ch->fio_out[k] = -1;
+        ch->fir_ok = match_fir_store_shape(ch.get(), ops, n_ops, io, slot_len, n_slots, f64);
+    }
     if (ch->fir_ok) {
         const char* env = getenv("DSPEED_HIP_NO_FUSED");
         ch->fused_on = !(env && env[0] == '1');
@@ -1333,7 +1406,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(energy kernel, %d): %s", classic_lds, hipGetErrorString(e));
     }
     if (ch->fir_ok && ch->fir_lds_bytes > 64 * 1024) {
-        hipError_t e = (hipError_t)dsp_internal_set_fir_mfma_lds(ch->fir_lds_bytes);
+        hipError_t e = (hipError_t)(ch->fir.store ? dsp_internal_set_fir_store_lds(ch->fir_lds_bytes) : dsp_internal_set_fir_mfma_lds(ch->fir_lds_bytes));
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(FIR kernel, %d): %s", ch->fir_lds_bytes, hipGetErrorString(e));
     }
     if (ch->rows_ok && ch->rows_lds_bytes > 64 * 1024) {
@@ -1407,7 +1480,9 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
             A.taps[k] = (const float*)io_ptrs[ch->fio_taps[k]];
             A.out[k] = io_ptrs[ch->fio_out[k]];
         }
-        hipError_t e = (hipError_t)dsp_internal_launch_fir_mfma(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream);
+        if (A.store) A.out[0] = (float*)A.out[0] + ch->fir_out_offset;
+        hipError_t e = (hipError_t)(A.store ? dsp_internal_launch_fir_store(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream)
+                                            : dsp_internal_launch_fir_mfma(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream));
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "FIR kernel launch failed: %s", hipGetErrorString(e));
         return DSP_OK;
     }
@@ -1533,7 +1608,7 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
     if (ch->fir_ok && ch->fused_on) {  // 8 wavefronts per 64 waveforms and kernel
         if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->fir_lds_bytes / 8;
         if (waves_per_block) *waves_per_block = 8;
-        if (blocks) *blocks = (int)((n_wf + 63) / 64) * ch->fir.n_kernels;
+        if (blocks) *blocks = (int)((n_wf + 63) / 64) * (ch->fir.store ? (ch->fir.p[0] + 319) / 320 : ch->fir.n_kernels);
         return DSP_OK;
     }
     if (ch->rows_ok && ch->fused_on) {  // a pair of wavefronts per 64 waveforms shares one history ring
@@ -1557,7 +1632,7 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
 }
 
 const char* dsp_chain_kernel_name(dsp_chain* ch) {
-    if (ch && ch->fir_ok && ch->fused_on) return dsp_internal_fir_mfma_kernel_name();
+    if (ch && ch->fir_ok && ch->fused_on) return ch->fir.store ? dsp_internal_fir_store_kernel_name() : dsp_internal_fir_mfma_kernel_name();
     if (ch && ch->rows_ok && ch->fused_on) return dsp_internal_rows_kernel_name();
     if (ch && ch->rr_ok && ch->fused_on && ch->variant != 1) return dsp_internal_energy_rr_kernel_name();
     return (ch && ch->fused_ok && ch->fused_on) ? dsp_internal_energy_kernel_name() : dsp_internal_vm_kernel_name();

@@ -135,5 +135,6 @@ struct FirArgs {
     int64_t out_stride[DSP_FIR_MAXK];
     int32_t kend;            // samples the product runs over: a multiple of 32, <= the row's length
     int32_t scan_before, scan_after;  // samples before / after the slice that are screened for NaN (DSP_OP_LOAD ip[0..1])
-    int32_t pad_;
+    int32_t store;           // 1: ONE kernel whose p[0] outputs are written to out[0] as a waveform (dsp_fir_store_kernel), any mode
+    int32_t dshift;          // store: output c is the sum over samples c - dshift .. c - dshift + m - 1 ('v' 0, 's' m / 2, 'f' m - 1)
 };

@@ -593,7 +593,8 @@ constexpr int TRAP_NCAP = 4;
 // RED (with STORE false): the filtered waveform only feeds reductions -- min_max and / or time_point_thresh -- and is never stored
 // (DSP_OP_TRAP_REDUCE): extremes are tracked during the replay (the correction by delta_j is monotone, so the extreme of the
 // corrected values is the corrected extreme), the threshold walk is a second replay comparing consecutive corrected samples.
-template <typename T, int KIND, bool STORE, bool RED = false>
+// RED = 2: only the maximum is wanted (numpy.amax of the trapezoid): one compare per sample instead of two extremes with their indices.
+template <typename T, int KIND, bool STORE, int RED = 0>
 __device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOBAL DevSlot& ss, const DSP_GLOBAL DevSlot& sd, const int* cap_idx, T* cap_val) {
     const int C = ss.C, lane = lane_id();
     const auto* ps = cx.chunk(ss);
@@ -685,7 +686,9 @@ __device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOB
             for (int u = t; u < nb; ++u) {
                 y = trap_step_r<T, KIND>(y, ps[u], l0[u], l1[u], l2[u], rr, ll, inv_rr, inv_ll);
                 if (STORE) pd[u] = y;
-                if (RED) {  // (selects, no branches: strict comparisons keep the first occurrence)
+                if (RED == 2) {
+                    vmax = (i_first + u < n_valid && y > vmax) ? y : vmax;
+                } else if (RED) {  // (selects, no branches: strict comparisons keep the first occurrence)
                     const int idx = i_first + u;
                     const bool lt = idx < n_valid && y < vmin, gt = idx < n_valid && y > vmax;
                     vmin = lt ? y : vmin;
@@ -715,7 +718,16 @@ __device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOB
         const T v = (T)((double)capv[c] + delta);
         cap_val[c] = cap_lane[c] >= 0 ? readlane(v, cap_lane[c]) : (T)0;
     }
-    if constexpr (RED) {
+    if constexpr (RED == 2) {
+        T cmax = vmax != -__builtin_huge_val() ? (T)((double)vmax + delta) : vmax;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const T o = __shfl_xor(cmax, m);
+            cmax = o > cmax ? o : cmax;
+        }
+        if (lane == 0) cx.sregs()[op.dst + 3] = cmax;
+        wave_sync();
+    } else if constexpr (RED != 0) {
         // ---- min_max (min_max.py:11-82) over the corrected values: lowest index wins ties
         T cmin = imin != 0x7fffffff ? (T)((double)vmin + delta) : vmin, cmax = imax != 0x7fffffff ? (T)((double)vmax + delta) : vmax;
 #pragma unroll
@@ -803,24 +815,58 @@ __device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOB
 template <typename T>
 __device__ __forceinline__ void op_trap_reduce(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+    // ip[3]: bits 0-7 the trapezoid's opcode; bits 8-15 the mode of a fixed_time_pickoff that also reads the trapezoid (0: none), at
+    // sp[3], into register bits 16-29 minus one; bit 30: of the four min_max values only a_max is wanted (numpy.amax)
+    const int kind = op.ip[3] & 0xff, pk_mode = (op.ip[3] >> 8) & 0xff, pk_reg = ((op.ip[3] >> 16) & 0x3fff) - 1;
+    const bool amax_only = ((op.ip[3] >> 30) & 1) != 0;
     if (cx.slot_nan(op.src) || op.ic[9]) {
         if (lane_id() == 0) {
             auto* r = cx.sregs();
             if (op.dst >= 0)
                 for (int k = 0; k < 4; ++k) r[op.dst + k] = quiet_nan<T>();
             if (op.io >= 0) r[op.io] = quiet_nan<T>();
+            if (pk_reg >= 0) r[pk_reg] = quiet_nan<T>();
         }
         wave_sync();
         return;
     }
-    const int none[TRAP_NCAP] = {-1, -1, -1, -1};
-    T dummy[TRAP_NCAP];
-    if (op.ip[3] == DSP_OP_TRAP_FILTER)
-        trap_core<T, TRAP_FILTER, false, true>(cx, op, ss, ss, none, dummy);
-    else if (op.ip[3] == DSP_OP_TRAP_NORM)
-        trap_core<T, TRAP_NORM, false, true>(cx, op, ss, ss, none, dummy);
+    int idx[TRAP_NCAP] = {-1, -1, -1, -1};
+    T w4[TRAP_NCAP];
+    T t_in = (T)0;
+    bool pick = false;
+    if (pk_reg >= 0) {
+        t_in = cx.scalar(op.sp[3]);
+        pick = pickoff_in_range(t_in, ss.len);
+        if (pick) {
+            const int i0 = (int)t_in;
+#pragma unroll
+            for (int k = 0; k < TRAP_NCAP; ++k) {
+                const int e = i0 - 1 + k;
+                const bool need = (k == 1) || (k == 2) || pk_mode == 'h';
+                idx[k] = (need && e >= 0 && e < ss.len) ? e : -1;
+            }
+        }
+    }
+    if (amax_only && kind == DSP_OP_TRAP_FILTER)
+        trap_core<T, TRAP_FILTER, false, 2>(cx, op, ss, ss, idx, w4);
+    else if (amax_only && kind == DSP_OP_TRAP_NORM)
+        trap_core<T, TRAP_NORM, false, 2>(cx, op, ss, ss, idx, w4);
+    else if (kind == DSP_OP_TRAP_FILTER)
+        trap_core<T, TRAP_FILTER, false, 1>(cx, op, ss, ss, idx, w4);
+    else if (kind == DSP_OP_TRAP_NORM)
+        trap_core<T, TRAP_NORM, false, 1>(cx, op, ss, ss, idx, w4);
     else
-        trap_core<T, TRAP_ASYM, false, true>(cx, op, ss, ss, none, dummy);
+        trap_core<T, TRAP_ASYM, false, 1>(cx, op, ss, ss, idx, w4);
+    if (pk_reg >= 0) {
+        T out = quiet_nan<T>();
+        if (pick) {
+            int fc = 0;
+            out = pickoff_eval(t_in, pk_mode, ss.len, w4, fc);
+            if (fc) cx.fatal(fc);
+        }
+        if (lane_id() == 0) cx.sregs()[pk_reg] = out;
+        wave_sync();
+    }
 }
 
 template <typename T>
@@ -1248,7 +1294,7 @@ __device__ __forceinline__ void op_moving_window_multi(Ctx<T>& cx, const DSP_GLO
     }
     for (int e = lane_id(); e < 64 * sd.C; e += 64) {  // pads of both targets stay finite
         cx.lds[padded_index(sd, e)] = (T)0;
-        if (num > 1) cx.lds[padded_index(sq, e)] = (T)0;
+        if (num > 1 && op.ip[2] != op.src) cx.lds[padded_index(sq, e)] = (T)0;  // (the source as scratch: written whole by its producer)
     }
     wave_sync();
     const T length = (T)op.fc[0];

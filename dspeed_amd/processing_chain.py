@@ -216,7 +216,7 @@ class ProcessingChain:
     (processing_chain.py:665-673); ``__call__(tb_in, tb_out)`` relinks I/O like :675-716."""
 
     def __init__(self, program: Program, inputs: dict, outputs: dict, consts: dict, buffer_len: int, proc_strings: list[str],
-                 loop_dtype=np.float32, aux=()):
+                 loop_dtype=np.float32, aux=(), stages=(), ext_alias=None):
         self._program = program
         self.loop_dtype = np.dtype(loop_dtype)  # float32 or float64 gufunc loop of the whole chain
         self._in_vars = inputs      # binding name -> Var (source column)
@@ -224,6 +224,8 @@ class ProcessingChain:
         self._consts = consts       # binding name -> ndarray (taps)
         self._aux = list(aux)       # fits done on the rows ahead of the chain (dsp_linear_slope_fit_rows), results bound as inputs
         self._aux_bufs = {}
+        self._stages = list(stages)  # programs that run ahead of the main one and leave rows / columns in HBM for it (_extract_stages)
+        self._ext_alias = dict(ext_alias or {})  # binding of the program -> buffer a fit or a stage filled
         self._buffer_len = buffer_len
         self._chain = None
         self._stream = None
@@ -266,6 +268,9 @@ class ProcessingChain:
             self._stream = Stream()
             for name, arr in self._consts.items():
                 self._dev[name] = DeviceArray.from_numpy(arr)
+            for k, st in enumerate(self._stages):
+                st["chain"] = Chain(st["program"], f"processing_chain stage {k} ({st['what']})", self.loop_dtype)
+                st["dev"] = {name: DeviceArray.from_numpy(arr) for name, arr in st["consts"].items()}
 
     #: bytes of host-resident I/O per pipelined piece: tens of MB keep PCIe transfers efficient, two pieces are in flight
     pipeline_bytes = 64 << 20
@@ -379,6 +384,8 @@ class ProcessingChain:
             """piece [a, b): wait for its kernel and copies, report its DSPFatal with absolute rows, deliver the staged outputs"""
             t = time.perf_counter()
             try:
+                for stg in self._stages:
+                    stg["chain"].check(s_c, row_offset=a)
                 self._chain.check(s_c, row_offset=a)
             except DSPFatal as e:  # the reference annotates and re-raises (processing_chain.py:1154-1159)
                 if e.wf_range is None:
@@ -451,6 +458,19 @@ class ProcessingChain:
                                                      stream.ptr), what="linear_slope_fit_rows")
             for j, name in enumerate(g["names"]):
                 bufs[name] = out.ptr + j * m * isz
+        for st in self._stages:  # in launch order: a stage may read what an earlier one wrote
+            sb = dict(bufs)
+            sb.update(st["dev"])
+            for io_name, key in st["alias"].items():
+                sb[io_name] = bufs[key]
+            for out_name, key, length in st["outs"]:
+                buf = st["bufs"].get(key)
+                if buf is None or buf.shape[0] < m:
+                    buf = st["bufs"][key] = DeviceArray((m,) if length is None else (m, length), self.loop_dtype)
+                sb[out_name] = bufs[key] = buf
+            st["chain"].execute(sb, m, stream)
+        for io_name, key in self._ext_alias.items():
+            bufs[io_name] = bufs[key]
 
     def __call__(self, tb_in, tb_out, begin: int = 0, end: int | None = None):
         """``proc_chain(tb_in, tb_out)`` of the reference (processing_chain.py:675-716).  LGDO tables (or stand-ins with their protocol,
@@ -1515,10 +1535,166 @@ def _schedule(steps):
     return [steps[j] for j in order]
 
 
-def _compile(b: _Builder, out_pars, n_rows, proc_strings):
+def _leaves(a, acc):
+    if isinstance(a, SExpr):
+        for x in a.args:
+            _leaves(x, acc)
+    elif isinstance(a, Var):
+        acc.append(a)
+    elif isinstance(a, tuple) and a and a[0] == "slice":
+        acc.append(a[1])
+    return acc
+
+
+def _live_steps(b: _Builder, steps, out_pars):
+    """the steps the outputs depend on, in their order"""
+    needed = {id(v) for o in out_pars for v in _leaves(b.vars.get(o), [])}
+    live = []
+    for fn, args, key in reversed(steps):
+        roles = _roles(fn)
+        mine = [v for a, r in zip(args, roles) if r in "WS" for v in _leaves(a, [])]
+        if any(id(v) in needed for v in mine):
+            live.append((fn, args, key))
+            for a, r in zip(args, roles):
+                if r not in "WS":
+                    needed.update(id(v) for v in _leaves(a, []))
+    return live[::-1]
+
+
+#: taps from which a convolve_wf / fft_convolve_wf goes to the matrix-core FIR kernels ahead of the program (dsp_fir_mfma.hip needs 64)
+STAGE_MIN_TAPS = 64
+
+
+def _extract_stages(b: _Builder, steps, out_pars, n_rows, ft):
+    """Long FIRs leave the program: each ``convolve_wf`` with a constant kernel of STAGE_MIN_TAPS or more taps becomes a launch of the
+    matrix-core FIR kernels ahead of the program (one waveform per wavefront is the wrong shape for 133 x 8192 or 5792 x 301
+    multiply-adds per waveform; 64 waveforms x 320 outputs per workgroup on the MFMA units is 4 - 40 times faster, and the filter's
+    input and output slots leave the program's LDS).  The FIR kernels read rows from HBM, so a filter's input is a chain input, the
+    input minus a per-event value (bl_subtract: done while staging), or -- anything else, the pole-zero corrected waveform of the Ge
+    recipes -- a waveform that a small program of its own writes to HBM first (32 kB per waveform: noise at a recipe's rate).  What a
+    stage wrote is an input of the later stages and of the program; processors that only fed a stage drop out of the program.
+    Returns (steps left to the program, stages in launch order)."""
+    import copy
+
+    if all(st[0] in ("convolve_wf", "fft_convolve_wf", "amax", "bl_subtract", "alias") for st in steps):
+        return steps, []  # the program is nothing but filters (BASELINE configs[2]): dsp_chain_create gives it the FIR kernel as a whole
+    out_names = set(out_pars)
+    for o in out_pars:
+        for v in _leaves(b.vars.get(o), []):
+            out_names.add(v.name)
+    stages = []
+
+    def base_of(a):
+        if isinstance(a, Var):
+            return a
+        if isinstance(a, tuple) and a and a[0] == "slice":
+            return a[1]
+        return None
+
+    def producer_of(v):
+        for st in steps:
+            for a, r in zip(st[1], _roles(st[0])):
+                if r in "WS" and a is v:
+                    return st
+        return None
+
+    def plain_scalar(x):  # a constant, a per-event input column or a fit / stage result: in HBM before the stage runs
+        if isinstance(x, Var):
+            return x.kind == "scalar" and x.sreg is None and ((x.is_input and x.source is not None) or getattr(x, "ext_key", None) is not None)
+        return isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, (bool, Quantity))
+
+    def row_input(v):  # rows of the input table or of an earlier stage
+        return isinstance(v, Var) and v.kind == "wf" and ((v.is_input and v.source is not None) or getattr(v, "ext_key", None) is not None)
+
+    def ancestors(v):
+        """steps that compute v from inputs and earlier results, in order"""
+        want, todo = [], [v]
+        seen = set()
+        while todo:
+            x = todo.pop()
+            if id(x) in seen or row_input(x):
+                continue
+            seen.add(id(x))
+            st = producer_of(x)
+            if st is None:
+                continue
+            if not any(st is w for w in want):
+                want.append(st)
+            for a, r in zip(st[1], _roles(st[0])):
+                if r not in "WS":
+                    todo.extend(_leaves(a, []))
+        return [st for st in steps if any(st is w for w in want)]
+
+    def build(stage_steps, outs, what):
+        """compile stage_steps (on copies of the variables) into a program that writes the variables ``outs``"""
+        vars2, steps2 = copy.deepcopy((b.vars, stage_steps))
+        b2 = copy.copy(b)
+        b2.vars, b2.steps, b2._conversions, b2.stage_ft = vars2, list(steps2), {}, ft
+        for v in vars2.values():
+            if isinstance(v, Var) and getattr(v, "aux_io", None) is not None:
+                v.aux_io = None  # (an index into the main program's bindings; the stage binds the fit's column by its name)
+        pc, _tb = _compile(b2, [o.name for o in outs], n_rows, [], stage_mode=True)
+        rec = {"what": what, "program": pc._program, "consts": pc._consts, "in_vars": pc._in_vars, "alias": pc._ext_alias,
+               "outs": [(f"out:{o.name}", f"in:{o.name}", o.length if o.kind == "wf" else None) for o in outs], "chain": None, "bufs": {}}
+        stages.append(rec)
+        for o in outs:  # from here on the variable is a row / column in HBM
+            o.ext_key, o.is_input, o.slot, o.sreg = f"in:{o.name}", True, None, None
+            if o.kind == "wf":
+                o.ext_len, o.offset, o.dtype = o.length, 0, np.dtype(np.float32)
+
+    for st in list(steps):
+        fn, args, key = st
+        if fn not in ("convolve_wf", "fft_convolve_wf") or not any(st is x for x in steps):
+            continue
+        taps, out = args[1], args[3]
+        if not (isinstance(taps, Var) and taps.kind == "taps" and taps.const is not None and isinstance(out, Var) and out.length):
+            continue
+        m = int(taps.length)
+        base, n_in = base_of(args[0]), _wf_len(args[0])
+        if base is None or n_in is None or m < STAGE_MIN_TAPS or m > n_in or not np.isfinite(taps.const).all():
+            continue
+        mode = args[2][1][0] if isinstance(args[2], tuple) and args[2][0] == "char" else (chr(args[2]) if isinstance(args[2], (int, np.integer)) else None)
+        want_len = {"v": n_in - m + 1, "s": n_in, "f": n_in + m - 1}.get(mode)
+        if want_len is None or want_len != out.length:
+            continue  # (the program's own op reports it)
+        # --- the filter's input as rows in HBM
+        pre = []
+        if not row_input(base):
+            pst = producer_of(base)
+            direct = (pst is not None and pst[0] == "bl_subtract" and row_input(base_of(pst[1][0])) and plain_scalar(pst[1][1])
+                      and base.name not in out_names)
+            if direct:
+                pre = [pst]
+            else:
+                anc = ancestors(base)
+                if not anc or any(a[0] in ("convolve_wf", "fft_convolve_wf") for a in anc):
+                    continue
+                build(anc, [base], f"{base.name} -> HBM")
+        # --- the filter itself; numpy.amax goes along when it is the only reader
+        users = [x for x in steps if x is not st and any(base_of(a) is out for a, r in zip(x[1], _roles(x[0])) if r not in "WS")]
+        if len(users) == 1 and users[0][0] == "amax" and users[0][1][0] is out and out.name not in out_names and isinstance(users[0][1][2], Var):
+            build(pre + [st, users[0]], [users[0][1][2]], f"{fn} {key} + amax")
+            users[0][1][2].kind = "scalar"
+            gone = [st, users[0]]
+        else:
+            build(pre + [st], [out], f"{fn} {key}")
+            gone = [st]
+        steps = [x for x in steps if not any(x is g for g in gone)]
+    if not stages:
+        return steps, stages
+    # what the stages' results replaced is not computed any more: producers of staged variables, and whatever only fed them
+    staged = {id(v) for v in b.vars.values() if isinstance(v, Var) and getattr(v, "ext_key", None) is not None and getattr(v, "aux_io", None) is None}
+    steps = [x for x in steps if not any(r in "WS" and id(a) in staged for a, r in zip(x[1], _roles(x[0])))]
+    return _live_steps(b, steps, out_pars), stages
+
+
+def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
+    """``stage_mode``: the program of a stage that runs ahead of the main program (_extract_stages): fits and other stages are not taken
+    out of it again; their results arrive as bindings (``Var.ext_key``)."""
     p = Program()
-    ft = _loop_dtype(b)
+    ft = b.stage_ft if stage_mode else _loop_dtype(b)
     in_bind, out_bind, consts = {}, {}, {}
+    ext_alias = {}  # binding name -> name of the buffer a fit / stage ahead of the program filled (a slice of it has a name of its own)
     vector_lens = {}
     steps = b.steps
     # --- linear_slope_fit on the rows of the batch (dsp_linear_slope_fit_rows: one waveform per lane) instead of inside the program,
@@ -1526,7 +1702,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
     # per-event input / constant (bl_subtract or numpy.subtract), or the pole_zero of that (constant tau), read whole or through a
     # constant slice.  The kernel runs ahead of the chain on the same stream; the chain reads its results as per-event inputs.
     aux = []  # one launch per (input waveform, subtraction, pole-zero) pipeline
-    if os.environ.get("DSPEED_HIP_FIT_IN_CHAIN", "0") != "1":
+    if not stage_mode and os.environ.get("DSPEED_HIP_FIT_IN_CHAIN", "0") != "1":
         producer = {}
         for fn, args, _k in steps:
             for a, r in zip(args, _roles(fn)):
@@ -1615,6 +1791,12 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
                 for q, o in enumerate(outs):
                     o.kind = "scalar"
                     o.aux_io = p.add_io(f"aux:{gi}:{4 * k + q}", _lib.IO_SCALAR_IN, ft)
+                    o.ext_key = f"aux:{gi}:{4 * k + q}"
+
+    # --- long FIRs on the matrix cores, ahead of the program: their results are bindings of the program
+    stages = []
+    if not stage_mode and ft == np.dtype(np.float32) and os.environ.get("DSPEED_HIP_NO_STAGES", "0") != "1":
+        steps, stages = _extract_stages(b, steps, out_pars, n_rows, ft)
 
     steps = b.steps = _schedule(steps)
     out_names = set(out_pars)  # names of the variables that are outputs (a variable may have another name than the output: alias, named slice)
@@ -1718,6 +1900,9 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
                 v = b.vars.get(key)
                 if v is None:
                     v = Var(key, "wf", hi - lo, base.dtype, source=base.source, offset=lo, grid=_grid_of(a), is_coord=False)
+                    v.is_input = True
+                    if getattr(base, "ext_key", None) is not None:  # (a waveform a stage wrote: same buffer, first sample lo)
+                        v.ext_key, v.ext_len = base.ext_key, getattr(base, "ext_len", base.length)
                     b.vars[key] = v
                     last_use[key] = last_use.get(base.name, si)
                 return ensure_loaded(v, si)
@@ -1739,10 +1924,14 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
         if v.slot is None:
             if not v.is_input:
                 raise ProcessingChainError(f"waveform '{v.name}' is used before it is computed")
-            col = _column(b.tb_in, v.source)
-            full_len = col.shape[1]
-            io = p.add_io(f"in:{v.name}", _lib.IO_WF_IN, col.dtype, v.length, v.offset, full_len)
-            in_bind[f"in:{v.name}"] = v
+            if getattr(v, "ext_key", None) is not None:  # written by a stage ahead of the program: float32 rows of the variable's length
+                io = p.add_io(f"in:{v.name}", _lib.IO_WF_IN, np.float32, v.length, v.offset, getattr(v, "ext_len", v.length))
+                ext_alias[f"in:{v.name}"] = v.ext_key
+            else:
+                col = _column(b.tb_in, v.source)
+                full_len = col.shape[1]
+                io = p.add_io(f"in:{v.name}", _lib.IO_WF_IN, col.dtype, v.length, v.offset, full_len)
+                in_bind[f"in:{v.name}"] = v
             v.slot = new_slot(v.length)
             p.add_op(_lib.OP_LOAD, dst=v.slot, io=io, ip=whole_nan_rule.get(v.name, ()))
         return v
@@ -1780,6 +1969,11 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
                     return Scalar.reg(a.sreg)
                 if getattr(a, "aux_io", None) is not None:  # a fit done ahead of the chain
                     return Scalar.input(a.aux_io)
+                if getattr(a, "ext_key", None) is not None:  # a fit or a stage ahead of this program
+                    if a.io is None:
+                        a.io = p.add_io(f"in:{a.name}", _lib.IO_SCALAR_IN, ft)
+                        ext_alias[f"in:{a.name}"] = a.ext_key
+                    return Scalar.input(a.io)
                 if a.is_input:
                     if a.io is None:
                         col = _column(b.tb_in, a.source)
@@ -1917,7 +2111,9 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             users = [sj for sj, (f2, a2, _k) in enumerate(steps) if sj > si and sj not in skip and any(wf_of(x) is dst for x in a2)]
             kinds = [steps[sj][0] for sj in users]
             plain = all(steps[sj][1][0] is dst for sj in users)  # (not through a slice)
-            if (users and plain and dst.name not in out_names and sorted(kinds) in (["min_max"], ["time_point_thresh"], ["min_max", "time_point_thresh"], ["amax"])
+            pick_ok = all(char_of(steps[sj][1][2]) != ord("s") for sj in users if steps[sj][0] == "fixed_time_pickoff")
+            if (users and plain and pick_ok and dst.name not in out_names
+                    and sorted(kinds) in (["min_max"], ["time_point_thresh"], ["min_max", "time_point_thresh"], ["amax"], ["amax", "fixed_time_pickoff"])
                     and not any(isinstance(x, tuple) and x[0] == "slice" and x[1] is dst for _f, a2, _k in steps for x in a2)):
                 pending_reduce[dst.name] = {"src": src, "ints": ints, "kind": trap_ops[fn], "emit_at": max(users), "mm_first": -1}
                 last_use[src.name] = max(last_use.get(src.name, si), max(users))
@@ -1925,10 +2121,13 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             dst.slot = new_slot(src.length)
             p.add_op(trap_ops[fn], dst=dst.slot, src=src.slot, ip=ints)
             release(src, si)
-        elif fn in ("min_max", "time_point_thresh", "amax") and isinstance(args[0], Var) and args[0].name in pending_reduce:
+        elif fn in ("min_max", "time_point_thresh", "amax", "fixed_time_pickoff") and isinstance(args[0], Var) and args[0].name in pending_reduce:
             pr = pending_reduce[args[0].name]
-            if fn == "amax":  # numpy.amax of a trapezoid (trapEmax): the a_max of the same reduction (NaN in, NaN out in both)
+            if fn == "fixed_time_pickoff":  # trapEftp beside trapEmax: the samples around the pick-off time are captured in the same pass
+                pr["pick"] = (scalar_operand(args[1], args, what=what), char_of(args[2]), out_scalar(args[3]))
+            elif fn == "amax":  # numpy.amax of a trapezoid (trapEmax): the a_max of the same reduction (NaN in, NaN out in both)
                 pr["mm_first"] = p.add_sregs(4)
+                pr["amax_only"] = pr["kind"] != _lib.OP_ASYM_TRAP
                 if not isinstance(args[2], Var):
                     raise ProcessingChainError("numpy.amax output must be a variable name")
                 args[2].kind, args[2].sreg = "scalar", pr["mm_first"] + 3
@@ -1942,8 +2141,13 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
                 pr["tpt"] = (tuple(scalar_operand(a, args, what=what) for a in args[1:4]), out_scalar(args[4]))
             if si == pr["emit_at"]:
                 sp, o = pr.get("tpt", ((), None))
+                code = pr["kind"] | ((1 << 30) if pr.get("amax_only") else 0)
+                if "pick" in pr:
+                    t_in, mode, po = pr["pick"]
+                    code |= (mode << 8) | ((po.sreg + 1) << 16)
+                    sp = tuple(sp) + (Scalar.const(0.0),) * (3 - len(sp)) + (t_in,)
                 p.add_op(_lib.OP_TRAP_REDUCE, dst=pr["mm_first"], src=pr["src"].slot, io=(o.sreg if o is not None else -1),
-                         ip=(*pr["ints"], pr["kind"]), sp=sp)
+                         ip=(*pr["ints"], code), sp=sp)
                 release(pr["src"], si)
                 del pending_reduce[args[0].name]
         elif fn == "fixed_time_pickoff":
@@ -1996,9 +2200,12 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             typ = scalar_operand(args[3], args, integer=True, what=what)
             dst = out_wf(args[4], src.length, src)
             dst.slot = new_slot(src.length)
-            tmp = new_slot(src.length) if num > 1 else dst.slot  # ping-pong target of the passes before the last
+            # ping-pong target of the passes before the last: with an odd number of windows the first pass goes source -> target, so a
+            # source nobody reads again serves (one waveform less in LDS: 19 kB for the upsampled current of the Ge recipes)
+            own = num > 1 and not (num % 2 == 1 and last_use.get(src.name, -1) <= si)
+            tmp = new_slot(src.length) if own else (src.slot if num > 1 else dst.slot)
             p.add_op(_lib.OP_MOVING_WINDOW_MULTI, dst=dst.slot, src=src.slot, ip=(typ, num, tmp), sp=(scalar_operand(args[1], args, what=what),))
-            if num > 1 and tmp not in free_slots:
+            if own and tmp not in free_slots:
                 free_slots.append(tmp)
             release(src, si)
         elif fn == "trap_pickoff":
@@ -2108,9 +2315,10 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
             unit_ns = _time_unit_ns(v.unit)
             if v.is_coord is True and v.grid is not None and unit_ns is not None:
                 v = b.converted(v, Grid(unit_ns))
-            if isinstance(v, Var) and v.sreg is None and getattr(v, "aux_io", None) is not None:  # (stores read registers)
+            if isinstance(v, Var) and v.sreg is None and (getattr(v, "aux_io", None) is not None or getattr(v, "ext_key", None) is not None):
+                src_op = scalar_operand(v, [], what=f"output {o}")  # (stores read registers)
                 v.sreg = p.add_sregs(1)
-                p.add_op(_lib.OP_SCALAR_FUNC, dst=v.sreg, ip=(_lib.FN_COPY,), sp=(Scalar.input(v.aux_io), Scalar.const(0.0), Scalar.const(0.0)))
+                p.add_op(_lib.OP_SCALAR_FUNC, dst=v.sreg, ip=(_lib.FN_COPY,), sp=(src_op, Scalar.const(0.0), Scalar.const(0.0)))
             if isinstance(v, Var) and v.sreg is None:
                 if v.is_input:
                     tb_out[o] = _column(b.tb_in, v.source)
@@ -2144,7 +2352,10 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings):
     p.slots = slot_len
     if len(p.ops) > _lib.MAX_OPS or len(p.slots) > _lib.MAX_SLOTS or len(p.io) > _lib.MAX_IO or p.n_sregs > _lib.MAX_SREGS:
         raise NotImplementedError("recipe is too large for one device chain (ops/slots/bindings limit)")
-    chain = ProcessingChain(p, in_bind, out_bind, consts, n_rows, proc_strings, ft, aux_desc)
+    for st in stages:  # columns of the input table that only a stage reads are linked like the program's own
+        for nm, v in st["in_vars"].items():
+            in_bind.setdefault(nm, v)
+    chain = ProcessingChain(p, in_bind, out_bind, consts, n_rows, proc_strings, ft, aux_desc, stages=stages, ext_alias=ext_alias)
     chain.vector_lens = vector_lens  # variable-length outputs -> the input column that holds their per-event lengths
     return chain, tb_out
 

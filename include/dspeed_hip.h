@@ -184,10 +184,14 @@ typedef struct dsp_scalar_arg {
                                   * minus the rise samples ending rise+flat earlier) / rise; ip[0..1] = rise, flat */
 #define DSP_OP_TRAP_REDUCE 24    /* fusion of TRAP_FILTER|TRAP_NORM|ASYM_TRAP (ip[3]) with the min_max and / or time_point_thresh that are its only
                                   * consumers: the filtered waveform is never stored.  dst = first of 4 registers t_min,t_max,a_min,a_max
-                                  * (or -1), io = time_point_thresh register (or -1), sp[0..2] = threshold, t_start, walk_forward */
+                                  * (or -1), io = time_point_thresh register (or -1), sp[0..2] = threshold, t_start, walk_forward.
+                                  * ip[3] bits 0-7 = the trapezoid's opcode; bits 8-15 = mode char of a fixed_time_pickoff that also reads
+                                  * the trapezoid (0: none; not 's'), at sp[3], into register (bits 16-29) - 1; bit 30: only a_max of the
+                                  * four values is wanted (numpy.amax: trapEmax + trapEftp of the Ge recipes in one pass) */
 #define DSP_OP_UPSAMPLER 25      /* upsampler.py:13-56        dst <- every sample of src repeated int(sp[0]) times (constant factor), NaN where nothing lands */
 #define DSP_OP_MOVING_WINDOW_MULTI 26 /* moving_windows.py:117-204  dst <- ip[1] moving averages of src, length sp[0] (constant), ip[0] = mw_type,
-                                  * ip[2] = scratch slot (needed for two or more windows) */
+                                  * ip[2] = scratch slot (needed for two or more windows; with an odd number of windows it may be src
+                                  * itself, which is then overwritten) */
 #define DSP_OP_LINEAR_SLOPE_FIT 27 /* linear_slope_fit.py:11-91  sreg[dst..dst+3] <- mean, stdev (Welford, in the reference's rounding
                                   * sequence), slope, intercept of src[ip[0] : ip[0] + ip[1]] (ip[1] == 0: to the end of the slot) */
 #define DSP_OP_SCALAR_AFFINE 18 /* sreg[dst] <- sp[0] * sp[1] + sp[2]  (recipe expressions: tp_0 + 10*us, 0.9*trapTmax, a + b, a * b, a - b) */

@@ -162,3 +162,92 @@ def test_shapes_outside_the_kernel_stay_on_the_vm():
     for kernels, lo, hi in (({"a": ("cusp_filter", (100, 20, 2000), 700)}, 0, 1200), ({"a": ("t0_filter", (8, 40), 48)}, 0, 300)):
         chain, _ = _run(_recipe(kernels, lo, hi), {"waveform": wf, "baseline": bl})
         assert chain._chain.kernel_name.startswith("dsp_vm")
+
+
+# ---- the same product with the filtered waveform kept (dsp_fir_store_kernel): any mode, 320-column tiles, window edges padded with zeros
+def _store_recipe(m, mode, n, lo=0, hi=None, bl=True, gen=("t0_filter", None)):
+    hi = n if hi is None else hi
+    ln = hi - lo
+    p = {"v": ln - m + 1, "s": ln, "f": ln + m - 1}[mode]
+    procs = {}
+    src = "waveform"
+    if bl:
+        procs["wf_bl"] = f"{M}.bl_subtract(waveform, baseline, wf_bl)"
+        src = "wf_bl"
+    g, args = gen
+    args = args if args is not None else (m // 3, m - m // 3)
+    procs["k"] = {"function": g, "module": M, "args": [*[str(a) for a in args], f"k({m}, 'f')"]}
+    sl = src if (lo, hi) == (0, n) else f"{src}[{lo}:{hi}]"
+    procs["wf_f"] = {"function": "convolve_wf", "module": M, "args": [sl, "k", f"'{mode}'", f"wf_f({p}, 'f')"]}
+    return {"outputs": ["wf_f"], "processors": procs}, p
+
+
+def _conv64(x, k, mode):
+    return np.stack([np.convolve(r.astype(np.float64), np.asarray(k, dtype=np.float64), mode={"v": "valid", "s": "same", "f": "full"}[mode]) for r in x])
+
+
+@pytest.mark.parametrize("mode", ["s", "v", "f"])
+@pytest.mark.parametrize("m,n,n_wf", [(133, 8192, 70), (64, 1000, 64), (200, 2048, 131), (700, 1024, 3), (321, 644, 65)])
+def test_stored_output_all_modes(mode, m, n, n_wf):
+    rng = np.random.default_rng(m + n)
+    wf, bl = _synth(rng, n_wf, n, bl=(1000, 3000))
+    rec, p = _store_recipe(m, mode, n)
+    chain, out = _run(rec, {"waveform": wf, "baseline": bl})
+    assert chain._chain.kernel_name == "dsp_fir_store_kernel"
+    xb = oracle.bl_subtract(wf, bl)[0]
+    k = chain._consts["taps:k"][:m]
+    ref = _conv64(xb, k, mode)
+    assert out["wf_f"].shape == ref.shape == (n_wf, p)
+    peak = np.abs(ref).max(axis=1, keepdims=True)
+    assert np.max(np.abs(out["wf_f"] - ref) / peak) <= 6e-7  # (float64 sums; the t0 kernel differentiates: partial sums far above the output)
+    conv, rc = oracle.convolve_wf(xb, k, mode, p)
+    assert rc == 0
+    assert np.max(np.abs(out["wf_f"] - conv) / np.abs(conv).max(axis=1, keepdims=True)) <= TOL
+    # and the waveform VM's op on the same chain
+    _, b = _run(rec, {"waveform": wf, "baseline": bl}, fused=False)
+    assert np.max(np.abs(out["wf_f"] - b["wf_f"]) / peak) <= TOL
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.uint16])
+def test_stored_output_integer_rows_slices_and_no_baseline(dtype):
+    rng = np.random.default_rng(77)
+    wf, bl = _synth(rng, 90, 4096, dtype=dtype, bl=(1000, 3000))
+    for lo, hi, use_bl in ((0, 4096, True), (128, 3000, True), (64, 2112, False)):
+        rec, p = _store_recipe(133, "s", 4096, lo, hi, bl=use_bl)
+        chain, out = _run(rec, {"waveform": wf, "baseline": bl})
+        assert chain._chain.kernel_name == "dsp_fir_store_kernel", (lo, hi, use_bl)
+        x = oracle.bl_subtract(wf.astype(np.float32), bl)[0] if use_bl else wf.astype(np.float32)
+        k = chain._consts["taps:k"][:133]
+        ref = _conv64(x[:, lo:hi], k, "s")
+        assert np.max(np.abs(out["wf_f"] - ref) / np.abs(ref).max(axis=1, keepdims=True)) <= 6e-7, (lo, hi, use_bl)
+
+
+def test_stored_output_nan_and_infinite_rows():
+    rng = np.random.default_rng(5)
+    wf, bl = _synth(rng, 70, 2048, bl=(1000, 3000))
+    wf[3, 100] = np.nan
+    wf[7, 2047] = np.nan
+    wf[10, 500] = np.inf
+    wf[11, 2] = -np.inf
+    bl[20] = np.nan
+    bl[21] = np.inf
+    rec, p = _store_recipe(133, "s", 2048)
+    chain, out = _run(rec, {"waveform": wf, "baseline": bl})
+    assert chain._chain.kernel_name == "dsp_fir_store_kernel"
+    with np.errstate(invalid="ignore", over="ignore"):
+        xb = oracle.bl_subtract(wf, bl)[0]
+        k = chain._consts["taps:k"][:133]
+        conv, rc = oracle.convolve_wf(xb, k, "s", p)
+    assert rc == 0
+    got = out["wf_f"]
+    for r in (3, 7, 20):
+        assert np.isnan(got[r]).all() and np.isnan(conv[r]).all(), r
+    for r in (10, 11, 21):  # infinities: where the reference is finite so is the device, same infinities / NaN elsewhere
+        fin = np.isfinite(conv[r])
+        assert np.array_equal(np.isnan(got[r]), np.isnan(conv[r])), r
+        assert np.array_equal(got[r][~fin & ~np.isnan(conv[r])], conv[r][~fin & ~np.isnan(conv[r])]), r
+        if fin.any():
+            assert np.max(np.abs(got[r][fin] - conv[r][fin])) <= 1e-5 * np.abs(conv[r][fin]).max(), r
+    clean = np.ones(70, bool)
+    clean[[3, 7, 10, 11, 20, 21]] = False
+    assert np.max(np.abs(got[clean] - conv[clean]) / np.abs(conv[clean]).max(axis=1, keepdims=True)) <= TOL

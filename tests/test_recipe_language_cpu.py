@@ -42,7 +42,8 @@ def _regs_written(op):
     if opcode in (L.OP_MIN_MAX, L.OP_LINEAR_SLOPE_FIT):
         return list(range(dst, dst + 4))
     if opcode == L.OP_TRAP_REDUCE:
-        return ([] if dst < 0 else list(range(dst, dst + 4))) + ([] if io < 0 else [io])
+        pick = ((ip[3] >> 16) & 0x3fff) - 1  # (register of a pick-off done in the same pass)
+        return ([] if dst < 0 else list(range(dst, dst + 4))) + ([] if io < 0 else [io]) + ([] if pick < 0 else [pick])
     if opcode in (L.OP_PICKOFF, L.OP_TRAP_PICKOFF, L.OP_TIME_POINT_THRESH, L.OP_AMAX, L.OP_CONVOLVE_AMAX, L.OP_MEAN_BELOW,
                   L.OP_TRAP_WINDOW_PICKOFF, L.OP_SCALAR_AFFINE, L.OP_SCALAR_DIV, L.OP_SCALAR_CONVERT, L.OP_SCALAR_FUNC):
         return [dst]
@@ -77,8 +78,33 @@ def _peak_live_samples(program):
     return max(sum(program.slots[s] for s in first if first[s] <= i <= last[s]) for i in range(len(program.ops)))
 
 
+def test_long_filters_of_the_ge_recipe_run_ahead_of_the_program():
+    """the t0 filter and the cusp FIR leave the program for the matrix-core FIR kernels (_extract_stages): the pole-zero corrected
+    waveform is written to HBM by a small program of its own, the filters read rows, the program reads their results"""
+    chain, mask, out = build_processing_chain(recipes.ICPC, _tb())
+    P = chain.program
+    assert sorted(mask) == ["baseline", "waveform"] and set(out) == set(recipes.ICPC["outputs"])
+    _check_program_order(P)
+    opcodes = [o[0] for o in P.ops]
+    assert _lib.OP_CONVOLVE not in opcodes and _lib.OP_CONVOLVE_AMAX not in opcodes and _lib.OP_POLE_ZERO not in opcodes
+    what = [[o[0] for o in st["program"].ops] for st in chain._stages]
+    assert what == [[_lib.OP_LOAD, _lib.OP_BL_SUBTRACT, _lib.OP_POLE_ZERO, _lib.OP_STORE],
+                    [_lib.OP_LOAD, _lib.OP_CONVOLVE, _lib.OP_STORE],
+                    [_lib.OP_LOAD, _lib.OP_BL_SUBTRACT, _lib.OP_CONVOLVE, _lib.OP_STORE]]
+    pz, t0f, cusp = chain._stages
+    assert pz["outs"] == [("out:wf_pz", "in:wf_pz", 8192)] and t0f["alias"] == {"in:wf_pz": "in:wf_pz"}
+    assert t0f["outs"] == [("out:wf_t0_filter", "in:wf_t0_filter", 8192)] and cusp["outs"] == [("out:wf_cusp", "in:wf_cusp", 301)]
+    assert cusp["program"].ops[0][4] == (0, 8192 - 6092), "bl_subtract's NaN rule covers the whole waveform: the load screens the rest"
+    names = [io[0] for io in P.io]
+    assert {"in:wf_pz", "in:wf_t0_filter", "in:wf_cusp"} <= set(names) and chain._ext_alias["in:wf_cusp"] == "in:wf_cusp"
+    assert "in:waveform[0:6092]" in chain._in_vars, "columns only a stage reads are linked with the program's own"
+    for st in chain._stages:
+        _check_program_order(st["program"])
+
+
 @pytest.mark.parametrize("t0", [48000.0, "per_row"])
-def test_whole_ge_recipe_translates_into_one_program(t0):
+def test_whole_ge_recipe_translates_into_one_program(t0, monkeypatch):
+    monkeypatch.setenv("DSPEED_HIP_NO_STAGES", "1")
     tb = _tb(t0=np.zeros(4, dtype=np.float32) if t0 == "per_row" else t0)
     chain, mask, out = build_processing_chain(recipes.ICPC, tb)
     P = chain.program
