@@ -1175,6 +1175,16 @@ __device__ __forceinline__ void op_upsampler(Ctx<T>& cx, const DSP_GLOBAL DevOp&
 // ------------------------------------------------------------------------------------------------
 // a / d for an integer-valued window length d in the loop type, correctly rounded: the same three-operation form as div_by_count
 // (checked against the IEEE quotient on 200 000 random float32 cases, lengths 1 .. 8192); tiny and non-finite operands divide plainly
+__device__ __forceinline__ float mw_abs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double mw_abs(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float mw_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double mw_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <typename T> __device__ __forceinline__ T mw_qmax();
+template <> __device__ __forceinline__ float mw_qmax<float>() { return 3.0e38f; }
+template <> __device__ __forceinline__ double mw_qmax<double>() { return 1.0e308; }
+template <typename T> __device__ __forceinline__ T mw_amin();
+template <> __device__ __forceinline__ float mw_amin<float>() { return 1.0e-30f; }
+template <> __device__ __forceinline__ double mw_amin<double>() { return 1.0e-290; }
 __device__ __forceinline__ float div_by_length(float a, float d, float inv_d) {
     const float q = a * inv_d;
     if (__builtin_expect(!(__builtin_fabsf(q) <= 3.0e38f && __builtin_fabsf(a) >= 1.0e-30f), 0)) return a / d;
@@ -1219,6 +1229,12 @@ __device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot
         if (with_lag && brk_lag > t && brk_lag < nb) nb = brk_lag;
         return nb;
     };
+    // Every loop below works on groups of eight samples: the loads of a group first, then its arithmetic with selects instead of branches
+    // (v == 0, v < L, v >= n), then its stores -- with a branch per sample the compiler waits for every LDS access on its own, three
+    // round trips per sample and pass.  Lanes past the end of the waveform compute on whatever their elements hold and store zeros (the
+    // tail of a slot is zero); a lagged element before the slot (v < L) is read -- the guard below, or another region: LDS reads cannot
+    // fault -- and dropped by the select.
+    constexpr int G = 8;
     // pass A: the increments, parked in the output buffer, and their exact (float64) sum over this chunk -> speculative start
     double S = 0.0;
     for (int t = 0; t < C;) {
@@ -1226,18 +1242,45 @@ __device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot
         const LT* xi = p_in + D * (t >= brk_io ? pad_in : 0);
         const LT* xl = p_lag + D * (t >= brk_lag ? pad_in : 0);
         LT* __restrict__ yo = p_out + D * (t >= brk_io ? pad_out : 0);  // (another slot than the samples: loads may pass stores)
-#pragma unroll 4
-        for (int u = t; u < nb; ++u) {
-            const int v = v0 + u;
-            if (v < n) {
-                T d = x0;  // (v == 0: what the reference starts from)
-                if (v > 0) {
-                    const T b = v < L ? x0 : xl[D * u];
-                    d = div_by_length((T)(xi[D * u] - b), length, inv_len);
-                }
-                yo[D * u] = d;
-                S += (double)d;
+        int u = t;
+        for (; u + G <= nb; u += G) {
+            T a[G], bq[G], d[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                a[k] = xi[D * (u + k)];
+                bq[k] = xl[D * (u + k)];
             }
+            bool odd = false;  // an operand the three-operation quotient is not proven for: tiny, infinite or NaN
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int v = v0 + u + k;
+                a[k] = a[k] - (v < L ? x0 : bq[k]);
+                const T q = a[k] * inv_len;
+                odd |= !(mw_abs(q) <= mw_qmax<T>() && mw_abs(a[k]) >= mw_amin<T>()) && a[k] != (T)0;
+                d[k] = mw_fma(mw_fma(-q, length, a[k]), inv_len, q);
+            }
+            if (wave_any(odd)) {
+#pragma unroll
+                for (int k = 0; k < G; ++k) d[k] = a[k] / length;
+            }
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int v = v0 + u + k;
+                d[k] = v == 0 ? x0 : d[k];
+                d[k] = v < n ? d[k] : (T)0;
+                yo[D * (u + k)] = d[k];
+                S += (double)d[k];
+            }
+        }
+        for (; u < nb; ++u) {
+            const int v = v0 + u;
+            const T xa = xi[D * u], xb = xl[D * u];
+            const T df = xa - (v < L ? x0 : xb);
+            T d = div_by_length(df, length, inv_len);
+            d = v == 0 ? x0 : d;
+            d = v < n ? d : (T)0;
+            yo[D * u] = d;
+            S += (double)d;
         }
         t = nb;
     }
@@ -1248,12 +1291,22 @@ __device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot
     for (int t = 0; t < C;) {
         const int nb = next_cut(t, false);
         LT* yo = p_out + D * (t >= brk_io ? pad_out : 0);
-#pragma unroll 4
-        for (int u = t; u < nb; ++u) {
-            if (v0 + u < n) {
-                y = y + yo[D * u];
-                yo[D * u] = y;
+        int u = t;
+        for (; u + G <= nb; u += G) {
+            T d[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) d[k] = yo[D * (u + k)];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                y = y + d[k];  // (zero past the end of the waveform)
+                d[k] = v0 + u + k < n ? y : (T)0;
             }
+#pragma unroll
+            for (int k = 0; k < G; ++k) yo[D * (u + k)] = d[k];
+        }
+        for (; u < nb; ++u) {
+            y = y + yo[D * u];
+            yo[D * u] = v0 + u < n ? y : (T)0;
         }
         t = nb;
     }
@@ -1265,9 +1318,17 @@ __device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot
         for (int t = 0; t < C;) {
             const int nb = next_cut(t, false);
             LT* yo = p_out + D * (t >= brk_io ? pad_out : 0);
-#pragma unroll 4
-            for (int u = t; u < nb; ++u)
-                if (v0 + u < n) yo[D * u] = (T)((double)yo[D * u] + delta);
+            int u = t;
+            for (; u + G <= nb; u += G) {
+                T d[G];
+#pragma unroll
+                for (int k = 0; k < G; ++k) d[k] = yo[D * (u + k)];
+#pragma unroll
+                for (int k = 0; k < G; ++k) d[k] = v0 + u + k < n ? (T)((double)d[k] + delta) : (T)0;
+#pragma unroll
+                for (int k = 0; k < G; ++k) yo[D * (u + k)] = d[k];
+            }
+            for (; u < nb; ++u) yo[D * u] = v0 + u < n ? (T)((double)yo[D * u] + delta) : (T)0;
             t = nb;
         }
     }

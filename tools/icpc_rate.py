@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""The whole Ge recipe on a device-resident batch, nothing else: for rocprofv3 --kernel-trace --stats (which launches make up a pass) and for
+A/B runs.  python tools/icpc_rate.py [rows] [steps]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import recipes  # noqa: E402
+from bench_configs import synth, timed  # noqa: E402
+from dspeed_amd.device import DeviceArray, Stream, sync  # noqa: E402
+from dspeed_amd.processing_chain import WaveformInput, build_processing_chain  # noqa: E402
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+st = Stream()
+wf, bl, _tp = synth(rows, 8192, np.int16, st, bl_lo=-3000.0, bl_hi=3000.0)
+sync()
+tb = {"waveform": WaveformInput(wf, 16.0, 48000.0), "baseline": bl}
+outs = list(recipes.ICPC["outputs"])
+chain, _, _ = build_processing_chain(recipes.ICPC, tb, outputs=outs)
+chain.link(tb, {k: DeviceArray((rows,), np.float32) for k in outs})
+chain._ensure()
+dt = timed(chain, steps=steps, warmup=2)
+print(json.dumps({"recipe": "ICPC", "rows": rows, "steps": steps, "ms_per_pass": dt * 1e3, "waveforms_per_s": round(rows / dt),
+                  "kernels": [s["chain"].kernel_name for s in chain._stages] + [chain._chain.kernel_name],
+                  "stages": [s["what"] for s in chain._stages]}))
