@@ -17,7 +17,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libdsp_oracle.so")
+_LIB_PATH = os.environ.get("DSP_ORACLE_LIB") or os.path.join(_HERE, "libdsp_oracle.so")  # (override: the sanitizer build, tests/test_oracle_sanitizers.py)
 _lib = None
 
 E_NAMES = {
@@ -28,6 +28,8 @@ E_NAMES = {
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("DSP_ORACLE_LIB"):
+        return _LIB_PATH
     src = [os.path.join(_HERE, f) for f in ("dsp_oracle.c", "dsp_oracle_impl.h", "dsp_oracle.h")]
     if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
