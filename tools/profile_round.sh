@@ -4,7 +4,9 @@
 #   phase split of the headline kernel (diagnostic library)       -> gpurun_out/prof_<tag>/phases.txt
 #   C3 / C5 kernels: kernel-trace stats + PMC                     -> gpurun_out/prof_<tag>_c3, _c5
 #   secondary configs, whole recipe                               -> gpurun_out/prof_<tag>/other_configs.jsonl, icpc_recipe.jsonl
+#   the recipe's launches (stages + program), stored FIR, VM PMC  -> gpurun_out/prof_<tag>/icpc_trace, icpc_rate.json, fir_store_rate.json, prof_<tag>_vm
 set -u
+export TMPDIR=/tmp
 TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -19,5 +21,10 @@ python3 tools/c3_rate.py 250000 1 > "$OUT/c3_rate.json" 2>/dev/null
 python3 tools/c5_rate.py 1000000 1 > "$OUT/c5_rate.json" 2>/dev/null
 python3 tools/bench_configs.py 1000000 > "$OUT/other_configs.jsonl" 2> "$OUT/other_configs.err"
 python3 tools/icpc_breakdown.py > "$OUT/icpc_recipe.jsonl" 2> "$OUT/icpc_recipe.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/icpc_trace" -- python3 tools/icpc_rate.py 131072 5 > "$OUT/icpc_rate_traced.json" 2> "$OUT/icpc_trace.err"
+python3 tools/icpc_rate.py 131072 5 > "$OUT/icpc_rate.json" 2> /dev/null
+python3 tools/fir_store_rate.py 100000 1 > "$OUT/fir_store_rate.json" 2> /dev/null
+DSPEED_HIP_NO_FUSED=1 tools/pmc_kernel.sh gpurun_out/prof_${TAG}_vm bench.py --allow-variants --no-cpu --rows 500000 --steps 5 --warmup 2 > /dev/null 2>&1
+python3 tools/pmc_table.py gpurun_out/prof_${TAG}_vm "dsp_vm" "$OUT/vm_pmc.json" > /dev/null
 python3 bench.py --wf-len 8192 --rows 500000 --no-cpu --steps 10 --warmup 5 > "$OUT/bench_8192.json" 2>/dev/null
 echo "round profile $TAG done"; tail -2 "$OUT/phases.txt"; cat "$OUT/c3_rate.json" "$OUT/c5_rate.json"

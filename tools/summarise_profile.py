@@ -97,6 +97,21 @@ if os.path.exists(icpc):
             top = ", ".join(f"{k} {100 * v:.0f} %" for k, v in list(o["share_by_opcode"].items())[:6])
             summary.append("")
             summary.append(f"In-kernel op timers (`dsp_chain_profile`), {o['recipe']}: {o['cycles_per_waveform']} shader cycles per waveform per wavefront; {top}.")
+rate = f"{src}/icpc_rate.json"
+if os.path.exists(rate) and os.path.getsize(rate):
+    r = json.load(open(rate))
+    shutil.copy(rate, f"profiles/{tag}_icpc_rate.json")
+    summary += ["", f"The recipe's launches per pass over {r['rows']} rows (`tools/icpc_rate.py`: {r['waveforms_per_s'] / 1e6:.2f} M waveforms/s, {r['ms_per_pass']:.1f} ms per pass; "
+                f"`rocprofv3 --kernel-trace --stats` of the same command, `profiles/{tag}_icpc_kernel_stats.csv`):", "", "| kernel | launches | average ms |", "|---|---|---|"]
+    for f in newest(f"{src}/icpc_trace/*/*_kernel_stats.csv"):
+        shutil.copy(f, f"profiles/{tag}_icpc_kernel_stats.csv")
+        for row in csv.DictReader(open(f)):
+            if "dsp_" in row["Name"] and "synth" not in row["Name"]:
+                nm = row["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                summary.append(f"| `{nm}` | {row['Calls']} | {float(row['AverageNs']) / 1e6:.3f} |")
+fsr = f"{src}/fir_store_rate.json"
+if os.path.exists(fsr) and os.path.getsize(fsr):
+    shutil.copy(fsr, f"profiles/{tag}_fir_store_rate.json")
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(summary) + "\n")
 shutil.copy(f"{src}/bench_default.json", f"profiles/{tag}_bench.json")
 print("\n".join(summary))
