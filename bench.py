@@ -319,7 +319,8 @@ def worker(args) -> int:
     # kernel, these rows and exactly these kernel sources (hash); otherwise null -- counters cannot be read from inside the run.
     traffic, traffic_src = None, None
     src_hash = kernel_source_hash()
-    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+    prof_dir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(prof_dir) if os.path.isdir(prof_dir) else [], reverse=True):
         if not name.endswith("_pmc_traffic.json"):
             continue
         try:

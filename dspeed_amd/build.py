@@ -27,6 +27,30 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-Wno-unused-function"]
 
 
+#: kernels that must not use scratch memory: name fragment -> why.  The waveform VM keeps its interpreter state (Ctx) in registers; it
+#: lands in scratch memory -- and every op of every chain pays -- as soon as a helper that takes the state by reference is not inlined
+#: (the compiler decides by size: one more branch in op_pickoff did it once, C2 on the VM 129 -> 113 M waveforms/s) or an indexed local
+#: array appears.  The build fails rather than ship that.
+NO_SCRATCH = {"dsp_vm.hip": "dsp_vm_kernel"}
+
+
+def _check_scratch(src: str, remarks: str) -> None:
+    frag, name, bad = NO_SCRATCH[src], None, []
+    for line in remarks.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split()[0]
+        elif "ScratchSize [bytes/lane]:" in line and name and frag in name:
+            n = int(line.split("ScratchSize [bytes/lane]:")[1].split()[0])
+            if n:
+                bad.append((name, n))
+    for line in remarks.splitlines():  # (the compiler's other diagnostics stay visible)
+        if "-Rpass-analysis=kernel-resource-usage" not in line and "remark:" not in line:
+            sys.stderr.write(line + "\n")
+    if bad:
+        raise RuntimeError(f"{src}: scratch memory in " + ", ".join(f"{n} ({b} B/lane)" for n, b in bad) +
+                           " -- a helper taking Ctx& was outlined, or a local array is indexed at run time (see NO_SCRATCH in build.py)")
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -51,13 +75,21 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
         obj = os.path.join(CSRC, "." + src + (".diag.o" if diag else ".o"))
         cmd = [_hipcc(), *[f for f in FLAGS if f != "-shared"], *(["-DDSPEED_HIP_DIAG"] if diag else []), "-x", "hip", "-c",
                os.path.join(CSRC, src), "-o", obj]
+        guard = src in NO_SCRATCH
+        if guard:
+            cmd.append("-Rpass-analysis=kernel-resource-usage")
         if verbose:
             print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
+        procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE if guard else None, text=True if guard else None), src))
         objs.append(obj)
-    for cmd, p in procs:
+    for cmd, p, src in procs:
+        err = p.communicate()[1] if src in NO_SCRATCH else None
         if p.wait() != 0:
+            if err:
+                sys.stderr.write(err)
             raise subprocess.CalledProcessError(p.returncode, cmd)
+        if err is not None:
+            _check_scratch(src, err)
     link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", lib]
     if verbose:
         print(" ".join(link))

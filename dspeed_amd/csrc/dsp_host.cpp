@@ -922,7 +922,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         return fail(DSP_ERR_TOO_LONG, "chain needs %d bytes of LDS per waveform; a CU has %d", ch->lds_bytes_per_wave, LDS_BYTES_PER_CU);
     // wavefronts per workgroup (1..4): the size that fits the most wavefronts into a CU's LDS and register budget (25 KB per
     // waveform: 3 per group and 2 groups = 6 wavefronts, where 4 per group would leave one group of 4); ties go to the larger group.
-    // Register budget: the VM without the FIR op and 4 wavefronts per SIMD = 16 per CU, everything else 2 per SIMD = 8 per CU.
+    // Register budget: the VM without the FIR op and 3 wavefronts per SIMD = 12 per CU, everything else 2 per SIMD = 8 per CU.
     for (int i = 0; i < n_ops; ++i) ch->has_fir |= (ops[i].opcode == DSP_OP_CONVOLVE || ops[i].opcode == DSP_OP_CONVOLVE_AMAX);
     auto pick_wpb = [&](int cap_waves) {
         int best_w = 1, best_waves = 0;
@@ -937,7 +937,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         }
         return best_w;
     };
-    int wpb = pick_wpb(ch->has_fir ? 8 : 16);
+    int wpb = pick_wpb(ch->has_fir ? 8 : 12);
     ch->classic_wpb = pick_wpb(8);
     ch->waves_per_block = wpb;
     P.waves_per_block = wpb;
@@ -1103,6 +1103,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             case DSP_OP_PICKOFF:
                 if (!check_slot(P, o.src) || o.dst < 0 || o.dst >= n_sregs) return fail(DSP_ERR_ARG, "op %d: bad PICKOFF", i);
                 if (o.ip[1] < 0 || o.ip[1] > 2) return fail(DSP_ERR_ARG, "op %d: PICKOFF ip[1] must be 0, 1 or 2", i);
+                if (o.ip[1] == 2 && o.sp[1].kind != DSP_ARG_CONST) return fail(DSP_ERR_ARG, "op %d: PICKOFF ip[1] = 2 takes a constant default (sp[1])", i);
                 if (o.ip[1] == 1 && (o.sp[0].kind != DSP_ARG_CONST || o.sp[0].value < 0 || o.sp[0].value >= slot_len[o.src] ||
                                      o.sp[0].value != std::floor(o.sp[0].value)))
                     return fail(DSP_ERR_ARG, "op %d: PICKOFF of one sample (ip[1] = 1) needs a constant index inside the waveform", i);
@@ -1440,7 +1441,7 @@ static int chain_blocks(const dsp_chain* ch, int64_t n_wf, int wpb, int cap_wave
     int64_t b = want < cap ? want : cap;
     return (int)(b > 0 ? b : 1);
 }
-static int vm_blocks(const dsp_chain* ch, int64_t n_wf) { return chain_blocks(ch, n_wf, ch->waves_per_block, ch->has_fir ? 8 : 16); }
+static int vm_blocks(const dsp_chain* ch, int64_t n_wf) { return chain_blocks(ch, n_wf, ch->waves_per_block, ch->has_fir ? 8 : 12); }
 
 // launch geometry of the register-resident kernel: up to 4 wavefronts per block, 2 wavefronts per SIMD (its register budget)
 static void rr_geometry(const dsp_chain* ch, int64_t n_wf, int* wpb_out, int* blocks_out) {

@@ -402,6 +402,10 @@ __device__ __forceinline__ void op_min_max_norm(Ctx<T>& cx, const DSP_GLOBAL Dev
 // lane j's chunk is  E_j - c*(E_j - x[jC-1])  with E_j the exclusive scan of the per-chunk sums; inside the chunk the
 // recurrence runs with the reference's operation order.  fc[0] = c, ic[0] = tau is NaN.
 // ------------------------------------------------------------------------------------------------
+// exp(-1 / tau) in float64 for a time constant that varies per event: out of line, so that the 200 instructions of the device's exp do
+// not sit in the middle of the op every recipe runs with a constant tau
+__device__ __attribute__((noinline)) double pz_decay(double tau) { return exp(-1.0 / tau); }
+
 template <typename T>
 __device__ __forceinline__ void op_pole_zero(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
     const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
@@ -413,7 +417,7 @@ __device__ __forceinline__ void op_pole_zero(Ctx<T>& cx, const DSP_GLOBAL DevOp&
         // bit: 1e-16 on the constant, far below the float32 output)
         const T tau = cx.scalar(op.sp[0]);
         tau_nan = tau != tau;
-        c = exp(-1.0 / (double)tau);
+        c = pz_decay((double)tau);
     }
     if (cx.slot_nan(op.src) || tau_nan) {
         cx.set_nan(op.dst, true);
@@ -470,38 +474,40 @@ __device__ __forceinline__ void op_double_pole_zero(Ctx<T>& cx, const DSP_GLOBAL
     bool par_nan = op.ic[0] != 0;
     const int C = ss.C, lane = lane_id();
     // powers of the recursion's linear part for the scan over the lanes: M^(C 2^d), d = 0..5; precomputed on the host for constant
-    // parameters, formed here (every lane the same 2 x 2 products, in float64) when a time constant or the fraction varies per event
-    double Mp[6][4];
-#pragma unroll
-    for (int d = 0; d < 6; ++d)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) Mp[d][k] = op.fc[4 + 4 * d + k];
-    if (op.ic[1]) {
+    // parameters (read from the op where the scan uses them), formed here when a time constant or the fraction varies per event -- every
+    // lane the same 2 x 2 products in float64 -- and parked in the LDS scratch area: 24 doubles held in registers across the passes
+    // below cost the whole interpreter its register budget (spills in every op: C2 on the VM 129 -> 106 M waveforms/s)
+    typedef __attribute__((address_space(3))) double lds_f64;
+    auto* mscr = (lds_f64*)(cx.lds + cx.prog->scratch_off);
+    const bool per_event = op.ic[1] != 0;
+    if (per_event) {
         const T tau1 = cx.scalar(op.sp[0]), tau2 = cx.scalar(op.sp[1]), fr_t = cx.scalar(op.sp[2]);
         par_nan = (tau1 != tau1) || (tau2 != tau2) || (fr_t != fr_t);
-        const double a = exp(-1.0 / (double)tau1), b = exp(-1.0 / (double)tau2), fr = (double)fr_t;  // pole_zero.py:168-174
+        const double a = pz_decay((double)tau1), b = pz_decay((double)tau2), fr = (double)fr_t;  // pole_zero.py:168-174
         d1 = ((fr * b - fr * a) - b) - 1.0;
         d2 = -1.0 * ((fr * b - fr * a) - b);
         n1 = -1.0 * (a + b);
         n2 = a * b;
-        auto mul = [](const double* x, const double* y, double* o) {
-            const double r0 = x[0] * y[0] + x[1] * y[2], r1 = x[0] * y[1] + x[1] * y[3], r2 = x[2] * y[0] + x[3] * y[2], r3 = x[2] * y[1] + x[3] * y[3];
-            o[0] = r0;
-            o[1] = r1;
-            o[2] = r2;
-            o[3] = r3;
+        struct M2 {
+            double a, b, c, d;  // [[a, b], [c, d]]
         };
-        double base[4] = {-d1, -d2, 1.0, 0.0}, pw[4] = {1.0, 0.0, 0.0, 1.0};
+        auto mul = [](M2 x, M2 y) { return M2{x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d}; };
+        M2 base{-d1, -d2, 1.0, 0.0}, pw{1.0, 0.0, 0.0, 1.0};  // (values, not arrays: an indexed local array would live in scratch memory)
         for (int e = C; e; e >>= 1) {  // pw = M^C
-            if (e & 1) mul(pw, base, pw);
-            mul(base, base, base);
+            if (e & 1) pw = mul(pw, base);
+            base = mul(base, base);
         }
-#pragma unroll
+#pragma unroll 1
         for (int d = 0; d < 6; ++d) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) Mp[d][k] = pw[k];
-            mul(pw, pw, pw);
+            if (lane == 0) {
+                mscr[4 * d] = pw.a;
+                mscr[4 * d + 1] = pw.b;
+                mscr[4 * d + 2] = pw.c;
+                mscr[4 * d + 3] = pw.d;
+            }
+            pw = mul(pw, pw);
         }
+        wave_sync();
     }
     if (cx.slot_nan(op.src) || par_nan) {
         cx.set_nan(op.dst, true);
@@ -535,11 +541,14 @@ __device__ __forceinline__ void op_double_pole_zero(Ctx<T>& cx, const DSP_GLOBAL
     double r1 = y1, r0 = y0;
 #pragma unroll
     for (int d = 0; d < 6; ++d) {
-        const double* M = Mp[d];
+        double M[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) M[k] = per_event ? (double)mscr[4 * d + k] : op.fc[4 + 4 * d + k];
         const double p1 = wave_shift_up(r1, 1 << d), p0 = wave_shift_up(r0, 1 << d);
         r1 += M[0] * p1 + M[1] * p0;
         r0 += M[2] * p1 + M[3] * p0;
     }
+    wave_sync();  // (the scratch area is free again)
     // carry in = state at the end of the previous chunk
     y1 = wave_prev(r1);
     y0 = wave_prev(r0);
@@ -900,12 +909,19 @@ __device__ __forceinline__ void op_trap(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) 
 // Lane l therefore rebuilds u[i0 + l] from a 48-sample warm-up in the reference's operation order (exact from sample 1 when
 // the window reaches it), and the back substitution runs over the 64 lanes' values (the tail beyond them is dropped the same way).
 // The forward coefficient w2[i] = -0.5 / (0.5 w2[i-1] + 2) is data independent and stationary in float64 from i = 15 on.
+// Out of line on purpose, with everything it needs passed by value: the spline mode is rare, and an outlined function that took the
+// interpreter state by reference would force that state into memory for every op (which is what happened when the compiler outlined it
+// by itself: C2 on the VM 129 -> 113 M waveforms/s).
+struct SlotView {
+    int off, len, padw;
+    float invC;
+};
 template <typename T>
-__device__ T pickoff_spline(Ctx<T>& cx, const DSP_GLOBAL DevSlot& ss, T t_in) {
+__device__ __attribute__((noinline)) T pickoff_spline(const typename Ctx<T>::LT* lds, SlotView ss, T t_in) {
     const int n = ss.len, lane = lane_id();
     const int i0 = (int)t_in;  // 0 <= i0 <= n - 2: the caller handles integer t_in
     const double t0 = (double)t_in - (double)i0, t1 = 1.0 - t0;
-    auto X = [&](int i) -> double { return (double)cx.lds[padded_index(ss, i)]; };
+    auto X = [&](int i) -> double { return (double)lds[padded_index(ss, i)]; };
     constexpr int WARM = 48;
     constexpr double W2_FIX = -0.2679491924311227;
     const int j = i0 + lane;
@@ -943,18 +959,19 @@ __device__ __forceinline__ void op_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& o
     T out = quiet_nan<T>();
     if (op.ip[1] == 1) {  // wf[i] in a recipe (processing_chain.py:986-990): a view of one sample, not the processor -- no NaN rule
         if (!cx.slot_all_nan(op.src)) out = cx.lds[padded_index(ss, (int)t_in)];
-    } else if (op.ip[1] == 2) {  // wf[variable]: get_default (processors/get.py:50-92)
-        out = cx.scalar(op.sp[1]);
-        if (!(t_in != t_in) && !cx.slot_all_nan(op.src)) {
-            long long i = (long long)t_in;
-            if (i < 0) i += ss.len;
+    } else if (op.ip[1] == 2) {  // wf[variable]: get_default (processors/get.py:50-92); the default is a constant (sp[1], checked at creation)
+        out = (T)op.sp[1].value;
+        const T n_f = (T)ss.len;
+        if (t_in > -n_f - (T)1 && t_in < n_f && !cx.slot_all_nan(op.src)) {  // (a NaN index fails both comparisons)
+            int i = (int)t_in;  // truncation toward zero, like int()
+            i = i < 0 ? i + ss.len : i;
             if (i >= 0 && i < ss.len) {
-                const T v = cx.lds[padded_index(ss, (int)i)];
-                if (!(v != v)) out = v;
+                const T v = cx.lds[padded_index(ss, i)];
+                out = (v != v) ? out : v;
             }
         }
     } else if (op.ip[0] == 's' && !cx.slot_nan(op.src) && pickoff_in_range(t_in, ss.len) && (T)(int)t_in != t_in) {
-        out = pickoff_spline(cx, ss, t_in);
+        out = pickoff_spline<T>(cx.lds, SlotView{ss.off, ss.len, ss.padw, ss.invC}, t_in);
     } else if (!cx.slot_nan(op.src) && pickoff_in_range(t_in, ss.len)) {
         const int i0 = (int)t_in;
         T w4[4];
@@ -2048,7 +2065,10 @@ __device__ __forceinline__ void op_zero_region(Ctx<T>& cx, const DSP_GLOBAL DevO
 // FIR: the interpreter with the long-FIR op compiled in.  That op's register needs (183 VGPRs with it, 113 without) would cap every
 // chain at 2 wavefronts per SIMD, so programs without a CONVOLVE run the lean build: 4 wavefronts per SIMD where LDS allows.
 template <typename T, bool FIR>
-__global__ void __launch_bounds__(256, FIR ? 2 : 4) dsp_vm_kernel(const DevProgram* __restrict__ prog, IoPtrs ptrs, int64_t n_wf, int* err) {
+// (the build without the long-FIR op: 3 wavefronts per SIMD = 168 registers.  At 4 per SIMD -- 128 registers -- the interpreter spilled in
+// every op once the per-event pole-zero forms and the recipe language's pick-off modes were in: C2 on the VM 129 -> 106 M waveforms/s; and a
+// waveform of 4096 samples leaves LDS for 9 wavefronts per CU anyway)
+__global__ void __launch_bounds__(256, FIR ? 2 : 3) dsp_vm_kernel(const DevProgram* __restrict__ prog, IoPtrs ptrs, int64_t n_wf, int* err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably wave-uniform -> rows, pointers in SGPRs
     const int wpb = (int)(blockDim.x >> 6);
