@@ -43,8 +43,14 @@ def _check_scratch(src: str, remarks: str) -> None:
             n = int(line.split("ScratchSize [bytes/lane]:")[1].split()[0])
             if n:
                 bad.append((name, n))
-    for line in remarks.splitlines():  # (the compiler's other diagnostics stay visible)
-        if "-Rpass-analysis=kernel-resource-usage" not in line and "remark:" not in line:
+    skip = 0
+    for line in remarks.splitlines():  # (the compiler's other diagnostics stay visible; a remark is followed by its source excerpt)
+        if "remark:" in line:
+            skip = 2
+        elif skip and (line.lstrip()[:1].isdigit() or line.lstrip().startswith("|")):
+            skip -= 1
+        else:
+            skip = 0
             sys.stderr.write(line + "\n")
     if bad:
         raise RuntimeError(f"{src}: scratch memory in " + ", ".join(f"{n} ({b} B/lane)" for n, b in bad) +

@@ -741,6 +741,7 @@ static int setup_trap(DevOp& d, int kind_opcode, int rise, int flat, int fall, i
     }
     // trap_filter with rise == 0 reads w_out[-1] (the NaN fill) in its first step: the whole output is NaN
     d.ic[9] = (kind_opcode == DSP_OP_TRAP_FILTER && rise == 0) ? 1 : 0;
+    d.ic[10] = (rise > 0 && (rise & (rise - 1)) == 0) ? 1 : 0;  // rise is a power of two: x / rise == x * (1 / rise), exactly
     d.fc[0] = (double)rise;
     d.fc[1] = (double)fall;
     return DSP_OK;

@@ -66,21 +66,21 @@ struct Ctx {
         nan_all &= ~(1u << s);
         nan_some |= 1u << s;
     }
-    __device__ void fatal(int code) const {
+    __device__ __forceinline__ void fatal(int code) const {
         if (lane_id() == 0 && atomicCAS(&err[0], 0, code) == 0) {
             err[1] = (int)(row & 0xffffffffll);
             err[2] = (int)(row >> 32);
         }
     }
     // scalar operand: constant, per-waveform input column, or scalar register
-    __device__ T scalar(const DSP_GLOBAL dsp_scalar_arg& a) const { return make_uniform(scalar_raw(a)); }
+    __device__ __forceinline__ T scalar(const DSP_GLOBAL dsp_scalar_arg& a) const { return make_uniform(scalar_raw(a)); }
     static __device__ __forceinline__ float make_uniform(float v) {
         return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
     }
     static __device__ __forceinline__ double make_uniform(double v) {
         return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
     }
-    __device__ T scalar_raw(const DSP_GLOBAL dsp_scalar_arg& a) const {
+    __device__ __forceinline__ T scalar_raw(const DSP_GLOBAL dsp_scalar_arg& a) const {
         if (a.kind == DSP_ARG_CONST) return (T)a.value;
         if (a.kind == DSP_ARG_REG) return sregs()[a.index];
         const DSP_GLOBAL DevIO& io = prog->io[a.index];
@@ -98,7 +98,7 @@ struct Ctx {
 // LOAD / STORE: coalesced 16-byte global accesses <-> chunked LDS layout
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename InT>
-__device__ bool load_slot(Ctx<T>& cx, const DSP_GLOBAL DevSlot& s, const DSP_GLOBAL InT* __restrict__ g, int len, bool vec_ok) {
+__device__ __forceinline__ bool load_slot(Ctx<T>& cx, const DSP_GLOBAL DevSlot& s, const DSP_GLOBAL InT* __restrict__ g, int len, bool vec_ok) {
     constexpr int V = 16 / (int)sizeof(InT);
     typedef InT vec_t __attribute__((ext_vector_type(V)));
     const int total = 64 * s.C;
@@ -603,8 +603,9 @@ constexpr int TRAP_NCAP = 4;
 // (DSP_OP_TRAP_REDUCE): extremes are tracked during the replay (the correction by delta_j is monotone, so the extreme of the
 // corrected values is the corrected extreme), the threshold walk is a second replay comparing consecutive corrected samples.
 // RED = 2: only the maximum is wanted (numpy.amax of the trapezoid): one compare per sample instead of two extremes with their indices.
+// RED = 3: only the threshold walk is wanted (no min_max registers): the first replay tracks nothing, it just yields the carries.
 template <typename T, int KIND, bool STORE, int RED = 0>
-__device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOBAL DevSlot& ss, const DSP_GLOBAL DevSlot& sd, const int* cap_idx, T* cap_val) {
+__device__ __forceinline__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOBAL DevSlot& ss, const DSP_GLOBAL DevSlot& sd, const int* cap_idx, T* cap_val) {
     const int C = ss.C, lane = lane_id();
     const auto* ps = cx.chunk(ss);
     const double rr = op.fc[0], ll = op.fc[1];
@@ -697,7 +698,7 @@ __device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOB
                 if (STORE) pd[u] = y;
                 if (RED == 2) {
                     vmax = (i_first + u < n_valid && y > vmax) ? y : vmax;
-                } else if (RED) {  // (selects, no branches: strict comparisons keep the first occurrence)
+                } else if (RED == 1) {  // (selects, no branches: strict comparisons keep the first occurrence)
                     const int idx = i_first + u;
                     const bool lt = idx < n_valid && y < vmin, gt = idx < n_valid && y > vmax;
                     vmin = lt ? y : vmin;
@@ -737,6 +738,7 @@ __device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOB
         if (lane == 0) cx.sregs()[op.dst + 3] = cmax;
         wave_sync();
     } else if constexpr (RED != 0) {
+      if constexpr (RED == 1) {
         // ---- min_max (min_max.py:11-82) over the corrected values: lowest index wins ties
         T cmin = imin != 0x7fffffff ? (T)((double)vmin + delta) : vmin, cmax = imax != 0x7fffffff ? (T)((double)vmax + delta) : vmax;
 #pragma unroll
@@ -760,6 +762,7 @@ __device__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOB
             r[op.dst + 3] = cmax;
         }
         wave_sync();
+      }
         // ---- time_point_thresh (time_point_thresh.py:12-92) on the corrected values: second replay, consecutive samples compared
         if (op.io >= 0) {
             const T thr = cx.scalar(op.sp[0]), ts_f = cx.scalar(op.sp[1]), walk_f = cx.scalar(op.sp[2]);  // (t_start may be the t_max just written)
@@ -864,6 +867,10 @@ __device__ __forceinline__ void op_trap_reduce(Ctx<T>& cx, const DSP_GLOBAL DevO
         trap_core<T, TRAP_FILTER, false, 1>(cx, op, ss, ss, idx, w4);
     else if (kind == DSP_OP_TRAP_NORM)
         trap_core<T, TRAP_NORM, false, 1>(cx, op, ss, ss, idx, w4);
+    else if (op.dst < 0 && op.ic[10])  // the t0 chain of the Ge recipes: asymmetric trapezoid, rise a power of two, threshold walk only
+        trap_core<T, TRAP_ASYM_P2, false, 3>(cx, op, ss, ss, idx, w4);
+    else if (op.dst < 0)
+        trap_core<T, TRAP_ASYM, false, 3>(cx, op, ss, ss, idx, w4);
     else
         trap_core<T, TRAP_ASYM, false, 1>(cx, op, ss, ss, idx, w4);
     if (pk_reg >= 0) {
@@ -1520,8 +1527,12 @@ __device__ __forceinline__ void op_mean_below(Ctx<T>& cx, const DSP_GLOBAL DevOp
 template <typename T, typename SlotRef>
 __device__ __forceinline__ int find_crossing(Ctx<T>& cx, const SlotRef& ss, T thr, int ts, bool forward, int back_lo) {
     const int n = ss.len, lane = lane_id();
+    // The first two steps one at a time (that is where the recipes' walks end); a walk that goes on takes four steps per round, their
+    // eight LDS reads in flight together -- a threshold that is never reached (tp_100 of a pulse below its own flat top) used to cost
+    // an LDS round trip for each of the 128 steps of an 8192-sample waveform.
     if (forward) {
-        for (int b = ts; b <= n - 2; b += 64) {
+        int b = ts;
+        for (int k = 0; k < 2 && b <= n - 2; ++k, b += 64) {
             const int i = b + lane;
             bool hit = false;
             if (i <= n - 2) {
@@ -1531,8 +1542,25 @@ __device__ __forceinline__ int find_crossing(Ctx<T>& cx, const SlotRef& ss, T th
             const unsigned long long found = __ballot(hit);
             if (found) return b + __builtin_ctzll(found);
         }
+        for (; b <= n - 2; b += 256) {
+            T cur[4], nxt[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = b + 64 * k + lane, ic = i <= n - 2 ? i : n - 2;  // (clamped: the read is always inside the waveform)
+                cur[k] = cx.lds[padded_index(ss, ic)];
+                nxt[k] = cx.lds[padded_index(ss, ic + 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = b + 64 * k + lane;
+                const bool hit = i <= n - 2 && ((cur[k] <= thr && thr < nxt[k]) || (cur[k] >= thr && thr > nxt[k]));
+                const unsigned long long found = __ballot(hit);
+                if (found) return b + 64 * k + __builtin_ctzll(found);
+            }
+        }
     } else {
-        for (int b = ts; b >= back_lo; b -= 64) {
+        int b = ts;
+        for (int k = 0; k < 2 && b >= back_lo; ++k, b -= 64) {
             const int i = b - lane;  // (lane 0 looks at the sample nearest to the start)
             bool hit = false;
             if (i >= back_lo) {
@@ -1541,6 +1569,22 @@ __device__ __forceinline__ int find_crossing(Ctx<T>& cx, const SlotRef& ss, T th
             }
             const unsigned long long found = __ballot(hit);
             if (found) return b - __builtin_ctzll(found);
+        }
+        for (; b >= back_lo; b -= 256) {
+            T cur[4], prv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = b - 64 * k - lane, ic = i >= back_lo ? i : back_lo;
+                cur[k] = cx.lds[padded_index(ss, ic)];
+                prv[k] = cx.lds[padded_index(ss, ic - 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = b - 64 * k - lane;
+                const bool hit = i >= back_lo && ((prv[k] < thr && thr <= cur[k]) || (prv[k] > thr && thr >= cur[k]));
+                const unsigned long long found = __ballot(hit);
+                if (found) return b - 64 * k - __builtin_ctzll(found);
+            }
         }
     }
     return -1;

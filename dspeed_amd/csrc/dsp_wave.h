@@ -99,7 +99,7 @@ __device__ __forceinline__ T quiet_nan() {
 // per-sample step of the trapezoidal filters, in the reference's operation order
 // (processors/trap_filters.py :62-76 trap_filter, :130-149 trap_norm, :211-227 asym_trap_filter)
 // ------------------------------------------------------------------------------------------------
-enum { TRAP_FILTER = 0, TRAP_NORM = 1, TRAP_ASYM = 2 };
+enum { TRAP_FILTER = 0, TRAP_NORM = 1, TRAP_ASYM = 2, TRAP_ASYM_P2 = 3 };
 
 // x / d for a positive integer-valued float64 d (a rise or fall time in samples), correctly rounded like the IEEE division
 // the reference performs: q = RN(x * RN(1/d)), one exact residual, one correction (Markstein: with a correctly rounded
@@ -133,6 +133,9 @@ __device__ __forceinline__ T trap_step_r(T y, T a, T b1, T b2, T b3, double rr, 
     } else if (KIND == TRAP_NORM) {
         const T e = ((a - b1) - b2) + b3;
         return (T)((double)y + div_by_count((double)e, rr, inv_rr));
+    } else if (KIND == TRAP_ASYM_P2) {  // rise is a power of two (the usual 128 ns at 16 ns): e1 * (1 / rise) IS the correctly rounded quotient
+        const T e1 = a - b1, e2 = b2 - b3;
+        return (T)(((double)y + (double)e1 * inv_rr) - div_by_count((double)e2, ll, inv_ll));
     } else {
         const T e1 = a - b1, e2 = b2 - b3;
         return (T)(((double)y + div_by_count((double)e1, rr, inv_rr)) - div_by_count((double)e2, ll, inv_ll));
@@ -145,7 +148,7 @@ __device__ __forceinline__ T trap_step_r(T y, T a, T b1, T b2, T b3, double rr, 
 // reference would raise DSPFatal for this (non-integer) t_in
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ T pickoff_eval(T t_in, int mode, int n, const T* w4, int& fatal_code) {
+__device__ __forceinline__ T pickoff_eval(T t_in, int mode, int n, const T* w4, int& fatal_code) {  // (inlined: w4 / fatal_code are the caller's registers)
     const int i0 = (int)t_in;
     if ((T)i0 == t_in) return w4[1];
     const double t0 = (double)t_in - (double)i0;
