@@ -274,6 +274,8 @@ class ProcessingChain:
 
     #: bytes of host-resident I/O per pipelined piece: tens of MB keep PCIe transfers efficient, two pieces are in flight
     pipeline_bytes = 64 << 20
+    #: upper bound of the intermediate rows the stages ahead of the program keep in HBM (per piece)
+    stage_bytes = 8 << 30
     #: How host-resident columns reach the device.  False (default): through page-locked staging buffers the chain owns
     #: (hipHostMalloc), filled / emptied by host threads -- the device only exchanges data with memory the runtime allocated itself.
     #: True: the linked NumPy columns are page-locked in place (hipHostRegister) and copied from directly: the full PCIe rate
@@ -348,6 +350,12 @@ class ProcessingChain:
         row_bytes = sum(a.nbytes // max(len(a), 1) for a in host_in.values())
         row_bytes += sum(odt[nm].itemsize * (1 if length is None else length) for nm, (_, length, _) in host_out.items())
         piece = n if row_bytes == 0 else int(max(1, min(n, self.pipeline_bytes // row_bytes)))
+        # what the stages ahead of the program leave in HBM (the pole-zero corrected waveform, filtered waveforms: 64 kB per row of the Ge
+        # recipe) is per piece: a device-resident batch of a million rows is walked in pieces so that those buffers stay bounded
+        stage_row_bytes = sum(self.loop_dtype.itemsize * (1 if length is None else length) for st in self._stages for _o, _k, length in st["outs"])
+        if stage_row_bytes and piece > self.stage_bytes // stage_row_bytes:
+            cap = max(1, self.stage_bytes // stage_row_bytes)
+            piece = -(-n // -(-n // cap))  # (equal pieces: no short last one)
         n_slots = 2 if piece < n else 1
         # piece buffers live as long as the chain (the reference pre-allocates its ProcChainVar buffers the same way,
         # processing_chain.py:259-269): build_dsp calls execute() once per file chunk with the same shapes

@@ -345,3 +345,38 @@ def test_cpu_port_of_the_whole_recipe_beside_the_device():
         json.dump({"recipe": "ICPC structure (tests/recipes.py), 8192-sample uint16 rows", "cpu_port_waveforms_per_s_1_thread": cpu_rate,
                    "cpu_rows": n_cpu, "device_waveforms_per_s": gpu_rate, "device_rows": n_gpu, "ratio": gpu_rate / cpu_rate}, f, indent=1)
     assert gpu_rate > 10 * cpu_rate
+
+
+def test_stage_buffers_are_bounded_and_pieces_give_the_same_results():
+    """the rows the stages ahead of the program leave in HBM (64 kB per waveform here) are allocated per piece: with a small bound the batch
+    is walked in equal pieces -- host-resident and device-resident -- and every output equals the one-piece run bit for bit"""
+    from dspeed_amd.device import DeviceArray
+    from dspeed_amd.processing_chain import WaveformInput, build_processing_chain
+
+    rng = np.random.default_rng(7)
+    n = 150
+    wf, bl = _synth(rng, n)
+    wf = wf.astype(np.uint16)
+    tb = {"waveform": WaveformInput(wf, 16.0, 48000.0), "baseline": bl}
+    chain, _, out = build_processing_chain(recipes.ICPC, tb)
+    assert len(chain._stages) == 3
+    chain.execute()
+    ref = {k: np.array(v) for k, v in out.items()}
+    per_row = sum(4 * (1 if ln is None else ln) for st in chain._stages for _o, _k, ln in st["outs"])
+    chain.stage_bytes = 40 * per_row  # -> 4 pieces of 38 rows
+    for v in out.values():
+        v[...] = 0
+    chain.execute()
+    assert max(len(b) for st in chain._stages for b in st["bufs"].values()) >= 150  # (allocated by the first run; not grown)
+    for k in ref:
+        assert np.array_equal(out[k], ref[k], equal_nan=True), k
+    # device-resident rows: views of the columns per piece
+    chain2, _, out2 = build_processing_chain(recipes.ICPC, tb)
+    chain2.stage_bytes = 40 * per_row
+    d_in = {"waveform": WaveformInput(DeviceArray.from_numpy(wf), 16.0, 48000.0), "baseline": DeviceArray.from_numpy(bl)}
+    d_out = {k: DeviceArray(v.shape, v.dtype) for k, v in out2.items()}
+    chain2.link(d_in, d_out)
+    chain2.execute()
+    assert max(len(b) for st in chain2._stages for b in st["bufs"].values()) == 38
+    for k in ref:
+        assert np.array_equal(d_out[k].to_numpy(), ref[k], equal_nan=True), k
