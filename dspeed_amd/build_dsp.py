@@ -6,8 +6,9 @@ that is not HDF5 is mirrored here with the same parameter names and meaning: the
 one recipe per channel pattern (``chan_config``, first match wins, :225-230), the per-channel parameter database (:232-238), row
 selection (``entry_list`` / ``entry_mask`` / ``i_start`` / ``n_entries``), default outputs from the recipe (:333-336), the
 ``raw`` -> ``dsp`` renaming of the output tables (:375), ``DSPFatal`` annotated with the row range (:400-404), the write modes of the
-output file (:204-213).  ``buffer_len`` keeps its meaning -- rows moved per transfer -- but the buffers of one table are pipelined
-inside one ``execute``: the host-to-device copy of buffer k+1 overlaps the kernel and the device-to-host copy of buffer k
+output file (:204-213).  ``buffer_len`` keeps its meaning -- rows moved per transfer; left at ``None`` the chain picks the size (256 MiB
+of rows: the reference's 3200 rows are a fraction of a millisecond of device work, and a recipe's one-waveform-per-lane kernels take
+milliseconds whatever the number of rows) -- but the buffers of one table are pipelined inside one ``execute``: the host-to-device copy of buffer k+1 overlaps the kernel and the device-to-host copy of buffer k
 (``ProcessingChain.execute``), instead of read / process / write in turn.
 
 Tables: a mapping ``column -> array | DeviceArray | WaveformInput``; ``raw_in`` is one table, a mapping of tables, or the name of an
@@ -138,7 +139,8 @@ def _run_chunks(tb, source, this_config, db_dict, outputs, i_start, n_entries, b
     try:
         for i_entry, n, cols in chunks:
             row_bytes = sum(np.asarray(c.values if isinstance(c, WaveformInput) else c).nbytes // max(n, 1) for k, c in cols.items() if k in mask)
-            chain.pipeline_bytes = max(1, int(buffer_len)) * max(row_bytes, 1)
+            if buffer_len is not None:
+                chain.pipeline_bytes = max(1, int(buffer_len)) * max(row_bytes, 1)
             out = {name[4:] if name.startswith("out:") else name: np.empty((n,) if length is None else (n, length), dtype=getattr(var, "dtype", None) or chain.loop_dtype)
                    for name, (var, length) in chain._out_vars.items()}
             try:
@@ -209,7 +211,7 @@ def _build_dsp_lgdo(raw_in, dsp_out, dsp_config, lh5_tables, base_group, databas
         parts = []
         if lh5_file:
             source = lh5.LH5Iterator(raw_in, tb, entry_list=entry_list, entry_mask=entry_mask, i_start=i_start, n_entries=n_entries,
-                                     buffer_len=buffer_len)
+                                     buffer_len=buffer_len if buffer_len is not None else 32768)  # (rows per read: a chunk is one execute)
         else:
             source = raw_in
 
@@ -241,7 +243,7 @@ def _build_dsp_lgdo(raw_in, dsp_out, dsp_config, lh5_tables, base_group, databas
 
 def build_dsp(raw_in, dsp_out: str | None = None, dsp_config=None, lh5_tables=None, base_group: str | None = None, database=None,
               outputs: Collection[str] | None = None, write_mode: str | None = None, entry_list=None, entry_mask=None, i_start: int = 0,
-              n_entries: int | None = None, buffer_len: int = 3200, block_width: int = 16, chan_config=None):
+              n_entries: int | None = None, buffer_len: int | None = None, block_width: int = 16, chan_config=None):
     """Run recipes over tables of waveforms; returns ``{dsp table name: {parameter: ndarray}}`` (one table: the table itself) when
     ``dsp_out`` is None, else writes them to the ``.npz`` and returns None.  Parameters as in the reference (build_dsp.py:27-127)."""
     del block_width  # (the device processes whole buffers)
@@ -324,7 +326,8 @@ def build_dsp(raw_in, dsp_out: str | None = None, dsp_config=None, lh5_tables=No
             # rows per transfer: the chain streams host columns through pairs of device buffers of this many rows
             row_bytes = sum((np.asarray(c.values if isinstance(c, WaveformInput) else c).nbytes // max(tot_n_rows, 1))
                             for k, c in tb_in.items() if k in _mask and not isinstance(c.values if isinstance(c, WaveformInput) else c, DeviceArray))
-            proc_chain.pipeline_bytes = max(1, int(buffer_len)) * max(row_bytes, 1)
+            if buffer_len is not None:
+                proc_chain.pipeline_bytes = max(1, int(buffer_len)) * max(row_bytes, 1)
             try:
                 proc_chain.execute(0, tot_n_rows)
             except DSPFatal as e:

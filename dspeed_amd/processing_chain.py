@@ -272,8 +272,10 @@ class ProcessingChain:
                 st["chain"] = Chain(st["program"], f"processing_chain stage {k} ({st['what']})", self.loop_dtype)
                 st["dev"] = {name: DeviceArray.from_numpy(arr) for name, arr in st["consts"].items()}
 
-    #: bytes of host-resident I/O per pipelined piece: tens of MB keep PCIe transfers efficient, two pieces are in flight
-    pipeline_bytes = 64 << 20
+    #: bytes of host-resident I/O per pipelined piece, two pieces in flight.  Tens of MB are enough for the PCIe transfers; the size is set
+    #: by the kernels that run one waveform per lane (the fits of a whole recipe take 4 ms whether a piece has 4 000 rows or 60 000:
+    #: tools/e2e_recipe_rate.py, 0.31 M waveforms/s with 64 MiB pieces, 0.81 M with 256 MiB)
+    pipeline_bytes = 256 << 20
     #: upper bound of the intermediate rows the stages ahead of the program keep in HBM (per piece)
     stage_bytes = 8 << 30
     #: How host-resident columns reach the device.  False (default): through page-locked staging buffers the chain owns
