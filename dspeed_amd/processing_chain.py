@@ -277,7 +277,7 @@ class ProcessingChain:
     #: tools/e2e_recipe_rate.py, 0.31 M waveforms/s with 64 MiB pieces, 0.81 M with 256 MiB)
     pipeline_bytes = 256 << 20
     #: upper bound of the intermediate rows the stages ahead of the program keep in HBM (per piece)
-    stage_bytes = 8 << 30
+    stage_bytes = 16 << 30
     #: How host-resident columns reach the device.  False (default): through page-locked staging buffers the chain owns
     #: (hipHostMalloc), filled / emptied by host threads -- the device only exchanges data with memory the runtime allocated itself.
     #: True: the linked NumPy columns are page-locked in place (hipHostRegister) and copied from directly: the full PCIe rate
