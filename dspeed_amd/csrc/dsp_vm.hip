@@ -1255,9 +1255,10 @@ __device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot
     };
     // Every loop below works on groups of eight samples: the loads of a group first, then its arithmetic with selects instead of branches
     // (v == 0, v < L, v >= n), then its stores -- with a branch per sample the compiler waits for every LDS access on its own, three
-    // round trips per sample and pass.  Lanes past the end of the waveform compute on whatever their elements hold and store zeros (the
-    // tail of a slot is zero); a lagged element before the slot (v < L) is read -- the guard below, or another region: LDS reads cannot
-    // fault -- and dropped by the select.
+    // round trips per sample and pass.  Lanes past the end of the waveform compute on whatever their elements hold and store nothing
+    // (predicated stores: in a pass from the right their elements would lie below the slot, in another slot or another wavefront's
+    // region); a lagged element before the slot (v < L) is read -- the guard below, or another region: LDS reads cannot fault -- and
+    // dropped by the select.
     constexpr int G = 8;
     // pass A: the increments, parked in the output buffer, and their exact (float64) sum over this chunk -> speculative start
     double S = 0.0;
@@ -1292,7 +1293,7 @@ __device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot
                 const int v = v0 + u + k;
                 d[k] = v == 0 ? x0 : d[k];
                 d[k] = v < n ? d[k] : (T)0;
-                yo[D * (u + k)] = d[k];
+                if (v < n) yo[D * (u + k)] = d[k];  // (a lane past the end stores nothing: from the right its elements lie below the slot)
                 S += (double)d[k];
             }
         }
@@ -1303,7 +1304,7 @@ __device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot
             T d = div_by_length(df, length, inv_len);
             d = v == 0 ? x0 : d;
             d = v < n ? d : (T)0;
-            yo[D * u] = d;
+            if (v < n) yo[D * u] = d;
             S += (double)d;
         }
         t = nb;
@@ -1322,15 +1323,18 @@ __device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot
             for (int k = 0; k < G; ++k) d[k] = yo[D * (u + k)];
 #pragma unroll
             for (int k = 0; k < G; ++k) {
-                y = y + d[k];  // (zero past the end of the waveform)
-                d[k] = v0 + u + k < n ? y : (T)0;
+                y = v0 + u + k < n ? y + d[k] : y;
+                d[k] = y;
             }
 #pragma unroll
-            for (int k = 0; k < G; ++k) yo[D * (u + k)] = d[k];
+            for (int k = 0; k < G; ++k)
+                if (v0 + u + k < n) yo[D * (u + k)] = d[k];
         }
         for (; u < nb; ++u) {
-            y = y + yo[D * u];
-            yo[D * u] = v0 + u < n ? y : (T)0;
+            if (v0 + u < n) {
+                y = y + yo[D * u];
+                yo[D * u] = y;
+            }
         }
         t = nb;
     }
@@ -1348,11 +1352,13 @@ __device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot
 #pragma unroll
                 for (int k = 0; k < G; ++k) d[k] = yo[D * (u + k)];
 #pragma unroll
-                for (int k = 0; k < G; ++k) d[k] = v0 + u + k < n ? (T)((double)d[k] + delta) : (T)0;
+                for (int k = 0; k < G; ++k) d[k] = (T)((double)d[k] + delta);
 #pragma unroll
-                for (int k = 0; k < G; ++k) yo[D * (u + k)] = d[k];
+                for (int k = 0; k < G; ++k)
+                    if (v0 + u + k < n) yo[D * (u + k)] = d[k];
             }
-            for (; u < nb; ++u) yo[D * u] = v0 + u < n ? (T)((double)yo[D * u] + delta) : (T)0;
+            for (; u < nb; ++u)
+                if (v0 + u < n) yo[D * u] = (T)((double)yo[D * u] + delta);
             t = nb;
         }
     }
