@@ -779,7 +779,7 @@ static int op_slots(const dsp_op& o, int out[4]) {
         case DSP_OP_MOVING_WINDOW_MULTI:
             out[0] = o.src;
             out[1] = o.dst;
-            if (o.ip[1] > 1) {
+            if (o.ip[1] > 1 || o.ip[3] == 1) {
                 out[2] = o.ip[2];
                 return 3;
             }
@@ -1145,7 +1145,8 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 break;
             }
             case DSP_OP_MOVING_WINDOW_MULTI: {
-                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || o.src == o.dst || slot_len[o.src] != slot_len[o.dst])
+                const bool in_place = o.ip[3] == 1;
+                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || (o.src == o.dst) != in_place || slot_len[o.src] != slot_len[o.dst])
                     return fail(DSP_ERR_ARG, "op %d: bad MOVING_WINDOW_MULTI", i);
                 if (o.sp[0].kind != DSP_ARG_CONST) return fail(DSP_ERR_UNSUPPORTED, "moving_window_multi: the window length must be a constant");
                 const double length = f64 ? o.sp[0].value : (double)(float)o.sp[0].value;
@@ -1156,6 +1157,12 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 if (num > 0 && (long long)length == 0) return fail(DSP_E_ZERODIV, "%s", dsp_fatal_message(DSP_E_ZERODIV));
                 // (the scratch may be the source itself when the number of windows is odd: the first pass goes source -> target, so the
                 // source is free from the second pass on -- and is overwritten)
+                if (in_place) {  // ip[2]: a side slot for the ends of the chunks, 64 lanes x (L | 1) elements; the window inside one chunk
+                    const long long Lw = (long long)length;
+                    if (!check_slot(P, o.ip[2]) || o.ip[2] == o.src || Lw > P.slots[o.src].C || 64 * (Lw | 1) > 64LL * P.slots[o.ip[2]].pitch)
+                        return fail(DSP_ERR_ARG, "op %d: MOVING_WINDOW_MULTI in place needs a window of at most %d samples and a side slot of 64 x window samples (ip[2])",
+                                    i, P.slots[o.src].C);
+                } else
                 if (num > 1 && (!check_slot(P, o.ip[2]) || (o.ip[2] == o.src && num % 2 == 0) || o.ip[2] == o.dst || slot_len[o.ip[2]] != n))
                     return fail(DSP_ERR_ARG, "op %d: MOVING_WINDOW_MULTI with several windows needs a scratch slot of the same length (ip[2])", i);
                 d.ic[0] = (int)length;

@@ -1224,8 +1224,13 @@ __device__ __forceinline__ double div_by_length(double a, double d, double inv_d
 // the slots, and e -/+ L for the sample leaving the window: consecutive LDS elements with at most one chunk pad on the way, at the same
 // t for every lane (the lanes start C elements apart) -- so each stream is a base pointer plus t, and the loops are cut where a stream
 // steps over its pad instead of turning every index into an address (that arithmetic was a third of the op's instructions).
-template <typename T, bool RIGHT>
-__device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot& in, const DSP_GLOBAL DevSlot& out, int L, T length) {
+// INPLACE: out is in.  What stands in the way is the sample leaving the window, x[v - L]: inside the lane's own chunk it is still there if
+// the chunk is walked downwards (what has been overwritten lies above), and the L samples below the chunk -- the end of the previous
+// lane's chunk, which that lane overwrites first -- are copied to `side` (64 x Ls elements) before anybody writes.  Needs L <= C.  One
+// 4784-sample waveform less in LDS for the current branch of the Ge recipes: four waveforms per CU instead of three.
+template <typename T, bool RIGHT, bool INPLACE = false>
+__device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot& in, const DSP_GLOBAL DevSlot& out, int L, T length,
+                                            typename Ctx<T>::LT* side = nullptr, int Ls = 0) {
     typedef typename Ctx<T>::LT LT;
     const int n = in.len, C = in.C, lane = lane_id(), v0 = lane * C;
     constexpr int D = RIGHT ? -1 : 1;
@@ -1262,6 +1267,54 @@ __device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot
     constexpr int G = 8;
     // pass A: the increments, parked in the output buffer, and their exact (float64) sum over this chunk -> speculative start
     double S = 0.0;
+    if constexpr (INPLACE) {
+        auto own = [&](int t) -> LT* { return p_in + D * (t + (t >= brk_io ? pad_in : 0)); };  // (t and the break are uniform: scalar selects)
+        for (int k0 = 0; k0 < L; k0 += G) {  // the end of every chunk, before anybody overwrites it
+            T tmp[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) tmp[k] = k0 + k < L ? (T)*own(C - L + k0 + k) : (T)0;
+#pragma unroll
+            for (int k = 0; k < G; ++k)
+                if (k0 + k < L) side[lane * Ls + k0 + k] = tmp[k];
+        }
+        wave_sync();
+        const LT* below = side + (lane > 0 ? lane - 1 : 0) * Ls;  // (lane 0: v < L there, the value is dropped for x0)
+        for (int tb = C - G; tb >= 0; tb -= G) {
+            T a[G], bq[G], d[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int t = tb + k;
+                a[k] = *own(t);
+                if (tb >= L)
+                    bq[k] = *own(t - L);
+                else if (tb + G <= L)
+                    bq[k] = below[t];
+                else
+                    bq[k] = t >= L ? (T)*own(t - L) : (T)below[t];
+            }
+            bool odd = false;
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int v = v0 + tb + k;
+                a[k] = a[k] - (v < L ? x0 : bq[k]);
+                const T q = a[k] * inv_len;
+                odd |= !(mw_abs(q) <= mw_qmax<T>() && mw_abs(a[k]) >= mw_amin<T>()) && a[k] != (T)0;
+                d[k] = mw_fma(mw_fma(-q, length, a[k]), inv_len, q);
+            }
+            if (wave_any(odd)) {
+#pragma unroll
+                for (int k = 0; k < G; ++k) d[k] = a[k] / length;
+            }
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int v = v0 + tb + k;
+                d[k] = v == 0 ? x0 : d[k];
+                d[k] = v < n ? d[k] : (T)0;
+                if (v < n) *own(tb + k) = d[k];
+                S += (double)d[k];
+            }
+        }
+    } else
     for (int t = 0; t < C;) {
         const int nb = next_cut(t, true);
         const LT* xi = p_in + D * (t >= brk_io ? pad_in : 0);
@@ -1372,6 +1425,13 @@ __device__ __forceinline__ void mw_pass(Ctx<T>& cx, const DSP_GLOBAL DevSlot& in
     else
         mw_pass_dir<T, false>(cx, in, out, L, length);
 }
+template <typename T>
+__device__ __forceinline__ void mw_pass_inplace(Ctx<T>& cx, const DSP_GLOBAL DevSlot& io, typename Ctx<T>::LT* side, int Ls, int L, T length, bool right) {
+    if (right)
+        mw_pass_dir<T, true, true>(cx, io, io, L, length, side, Ls);
+    else
+        mw_pass_dir<T, false, true>(cx, io, io, L, length, side, Ls);
+}
 
 template <typename T>
 __device__ __forceinline__ void op_moving_window_multi(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
@@ -1381,6 +1441,14 @@ __device__ __forceinline__ void op_moving_window_multi(Ctx<T>& cx, const DSP_GLO
     const int L = op.ic[0], num = op.ic[1], type = op.ic[2];
     if (cx.slot_nan(op.src) || num == 0) {  // (no window at all leaves the output as it was initialised: NaN)
         cx.set_nan(op.dst, true);
+        return;
+    }
+    if (op.ip[3] == 1) {  // in place (dst is src), ip[2] = a side slot of 64 * L samples for the chunk ends: every pass in the same buffer
+        const T length = (T)op.fc[0];
+        for (int p = 0; p < num; ++p)
+            mw_pass_inplace<T>(cx, ss, cx.lds + sq.off, L | 1, L, length, ((p % 2 == 1) && type == 0) || type == 2);
+        cx.set_nan(op.dst, false);
+        wave_sync();
         return;
     }
     for (int e = lane_id(); e < 64 * sd.C; e += 64) {  // pads of both targets stay finite

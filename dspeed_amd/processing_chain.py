@@ -2209,9 +2209,22 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
             num = scalar_operand(args[2], args, integer=True, what=what)
             typ = scalar_operand(args[3], args, integer=True, what=what)
             dst = out_wf(args[4], src.length, src)
+            win = args[1]
+            chunk = -(-(-(-src.length // 64)) // 16) * 16  # samples of a waveform per lane (dsp_chain_create: a multiple of 16)
+            if (last_use.get(src.name, -1) <= si and num >= 1 and isinstance(win, (int, float, np.integer, np.floating)) and not isinstance(win, Quantity)
+                    and float(win) == int(win) and 1 <= int(win) <= chunk):
+                # in place: a source nobody reads again is overwritten pass by pass; only the ends of the lanes' chunks (64 x window
+                # samples) are kept aside.  One waveform instead of two in LDS for the averaged current of the Ge recipes (22 + 13 kB
+                # instead of 43): with that the whole recipe fits four times into a CU instead of three
+                dst.slot = src.slot
+                side = new_slot(64 * int(win))
+                p.add_op(_lib.OP_MOVING_WINDOW_MULTI, dst=dst.slot, src=src.slot, ip=(typ, num, side, 1), sp=(scalar_operand(win, args, what=what),))
+                if side not in free_slots:
+                    free_slots.append(side)
+                continue
             dst.slot = new_slot(src.length)
             # ping-pong target of the passes before the last: with an odd number of windows the first pass goes source -> target, so a
-            # source nobody reads again serves (one waveform less in LDS: 19 kB for the upsampled current of the Ge recipes)
+            # source nobody reads again serves
             own = num > 1 and not (num % 2 == 1 and last_use.get(src.name, -1) <= si)
             tmp = new_slot(src.length) if own else (src.slot if num > 1 else dst.slot)
             p.add_op(_lib.OP_MOVING_WINDOW_MULTI, dst=dst.slot, src=src.slot, ip=(typ, num, tmp), sp=(scalar_operand(args[1], args, what=what),))

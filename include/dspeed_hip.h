@@ -191,7 +191,8 @@ typedef struct dsp_scalar_arg {
 #define DSP_OP_UPSAMPLER 25      /* upsampler.py:13-56        dst <- every sample of src repeated int(sp[0]) times (constant factor), NaN where nothing lands */
 #define DSP_OP_MOVING_WINDOW_MULTI 26 /* moving_windows.py:117-204  dst <- ip[1] moving averages of src, length sp[0] (constant), ip[0] = mw_type,
                                   * ip[2] = scratch slot (needed for two or more windows; with an odd number of windows it may be src
-                                  * itself, which is then overwritten) */
+                                  * itself, which is then overwritten).  ip[3] = 1: in place -- dst is src, every pass overwrites it, ip[2]
+                                  * is a side slot of 64 x window samples (the ends of the lanes' chunks); the window must fit one chunk */
 #define DSP_OP_LINEAR_SLOPE_FIT 27 /* linear_slope_fit.py:11-91  sreg[dst..dst+3] <- mean, stdev (Welford, in the reference's rounding
                                   * sequence), slope, intercept of src[ip[0] : ip[0] + ip[1]] (ip[1] == 0: to the end of the slot) */
 #define DSP_OP_SCALAR_AFFINE 18 /* sreg[dst] <- sp[0] * sp[1] + sp[2]  (recipe expressions: tp_0 + 10*us, 0.9*trapTmax, a + b, a * b, a - b) */

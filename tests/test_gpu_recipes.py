@@ -501,3 +501,37 @@ def test_float64_inputs_run_the_float64_chain():
     assert_rel_to_peak(out["wf_trap"], tr, 1e-12, "wf_trap f64")
     e = oracle.fixed_time_pickoff(tr, tp, "l")[0]
     assert np.max(np.abs(out["trapEftp"] - e) / np.abs(e)) <= 1e-12
+
+
+@pytest.mark.parametrize("L,num,typ", [(48, 3, 0), (48, 1, 2), (7, 2, 1), (1, 4, 0), (80, 3, 0), (75, 2, 2), (300, 2, 0)])
+@pytest.mark.parametrize("n", [4784, 4096, 1000])
+def test_moving_window_multi_in_a_chain_in_place_and_between_two_buffers(L, num, typ, n):
+    """a source nobody reads again is overwritten pass by pass when the window fits a lane's chunk (DSP_OP_MOVING_WINDOW_MULTI ip[3] = 1),
+    else the passes go between two buffers; both against the oracle, and a neighbouring waveform of the same program stays intact"""
+    from dspeed_amd import _lib
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    rng = np.random.default_rng(L * 100 + num * 10 + typ + n)
+    x = (50 * rng.standard_normal((200, n)) + 2000 * np.exp(-((np.arange(n)[None, :] - rng.uniform(0.3 * n, 0.7 * n, (200, 1))) / 200.0) ** 2)).astype(np.float32)
+    x[5, 7] = np.nan
+    bl = rng.uniform(-50, 50, 200).astype(np.float32)
+    M = "dspeed.processors"
+    rec = {"outputs": ["wf_mw", "t_lo", "t_hi", "a_lo", "a_hi"], "processors": {
+        "t_lo, t_hi, a_lo, a_hi": f"{M}.min_max(waveform, t_lo, t_hi, a_lo, a_hi)",  # (registers written before the averages run)
+        "wf_bl": f"{M}.bl_subtract(waveform, baseline, wf_bl)",
+        "wf_mw": f"{M}.moving_window_multi(wf_bl, {L}, {num}, {typ}, wf_mw)"}}
+    chain, _, out = build_processing_chain(rec, {"waveform": x, "baseline": bl})
+    mw = [o for o in chain.program.ops if o[0] == _lib.OP_MOVING_WINDOW_MULTI][0]
+    chunk = -(-(-(-n // 64)) // 16) * 16
+    in_place = len(mw[4]) > 3 and mw[4][3] == 1
+    assert in_place == (L <= chunk) and (mw[1] == mw[2]) == in_place
+    chain.execute()
+    xb = oracle.bl_subtract(x, bl)[0]
+    want = oracle.moving_window_multi(xb, L, num, typ)[0]
+    ok = ~np.isnan(want).all(axis=1)
+    peak = np.nanmax(np.abs(np.where(ok[:, None], want, 0.0)), axis=1, keepdims=True)
+    assert np.array_equal(np.isnan(out["wf_mw"]), np.isnan(want))
+    assert np.nanmax(np.abs(out["wf_mw"][ok] - want[ok]) / peak[ok]) <= 1e-6
+    tl, th, al, ah = oracle.min_max(x)[:4]
+    for k, w in (("t_lo", tl), ("t_hi", th), ("a_lo", al), ("a_hi", ah)):
+        assert np.array_equal(out[k], w, equal_nan=True), k
