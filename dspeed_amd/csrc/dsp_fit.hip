@@ -28,6 +28,48 @@ __device__ __forceinline__ T fit_scalar(const void* p, int dtype, int64_t at) {
     }
 }
 
+// A stretch [a, b) of a tile in which the same fits are active: none (K = -1) or exactly fit K -- what the recipes have (a baseline
+// window at the start, a tail window after the rise).  Groups of eight samples: their LDS reads first (the lane's column of the tile,
+// the reciprocals of the counts), then the recurrences; with the window tests and the LDS reads inside a per-sample loop every sample
+// paid two LDS round trips and four uniform branches on top of its dependent chain.
+template <typename T, int K>
+__device__ __forceinline__ void fit_stretch(const T* mine, const double* invk, int a, int b, int j_a, bool sub, T bsub, bool has_pz, double c, bool stage1,
+                                            double& acc, double& xp, bool& nan_y, T& m, T& s, double& sy, double& sxy) {
+    constexpr int G = 8;
+    auto one = [&](T x, double inv, int j) {
+        const T y = sub ? x - bsub : x;  // bl_subtract.py:45 / numpy.subtract: one float subtraction
+        nan_y |= (y != y);
+        T z = y;
+        if (has_pz) {  // pole_zero.py:60-72: float64 state, the store rounds
+            const double yd = (double)y;
+            acc = (acc + yd) - xp * c;
+            z = (T)acc;
+            xp = yd;
+        }
+        if constexpr (K >= 0) {
+            const T v = stage1 ? z : y;
+            const T temp = v - m;
+            m = (T)((double)m + div_by_count((double)temp, (double)(j + 1), inv));
+            s = s + temp * (v - m);
+            sy += (double)v;
+            sxy += (double)v * (double)j;
+        }
+    };
+    int u = a;
+    for (; u + G <= b; u += G) {
+        T xs[G];
+        double iv[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            xs[k] = mine[u + k];
+            iv[k] = K >= 0 ? invk[u + k] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < G; ++k) one(xs[k], iv[k], j_a + (u - a) + k);
+    }
+    for (; u < b; ++u) one(mine[u], K >= 0 ? invk[u] : 0.0, j_a + (u - a));
+}
+
 template <typename T, typename InT>
 __global__ __launch_bounds__(64) void dsp_fit_rows_kernel(FitArgs A) {
     constexpr int TS = 64, PITCH = TS + 1;
@@ -41,6 +83,7 @@ __global__ __launch_bounds__(64) void dsp_fit_rows_kernel(FitArgs A) {
     T b = (T)A.sub_const;
     if (A.sub_mode && A.sub && live) b = fit_scalar<T>(A.sub, A.sub_dtype, row);
     const double c = A.pz_c;
+    const bool sub = A.sub_mode != 0, has_pz = A.has_pz != 0;
     double acc = 0.0, xp = 0.0;
     bool nan_y = false;
     T m[DSP_FIT_MAX], s[DSP_FIT_MAX];
@@ -50,11 +93,35 @@ __global__ __launch_bounds__(64) void dsp_fit_rows_kernel(FitArgs A) {
         m[k] = s[k] = (T)0;
         sy[k] = sxy[k] = 0.0;
     }
+    // Whole tiles of whole blocks are fetched with 16-byte loads -- V samples of a row per lane, V rows per instruction -- one tile ahead,
+    // into registers, and written to LDS (transposed: one row of the tile per waveform) when the tile before has been consumed; the
+    // last rows of a batch, the last samples of a row and rows that are not 16-byte aligned take the element-wise path.
+    constexpr int V = 16 / (int)sizeof(InT), NV = TS / V;  // samples per load, loads per lane and tile
+    typedef InT vec_t __attribute__((ext_vector_type(V)));
+    const bool wide = rows_here == 64 && (A.row_stride * (int64_t)sizeof(InT)) % 16 == 0 && ((uintptr_t)g & 15u) == 0;
+    vec_t pf[NV];
+    const int pr = lane / (TS / V), pc = (lane % (TS / V)) * V;  // row within a group of V rows, first sample of this lane's piece
+    auto fetch = [&](int s0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) pf[q] = *(const vec_t*)(g + (r0 + q * V + pr) * A.row_stride + s0 + pc);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < NV; ++q)
+#pragma unroll
+            for (int e = 0; e < V; ++e) tile[(q * V + pr) * PITCH + pc + e] = (T)pf[q][e];
+    };
+    if (wide && A.n_scan >= TS) fetch(0);
     for (int s0 = 0; s0 < A.n_scan; s0 += TS) {
         const int w = A.n_scan - s0 < TS ? A.n_scan - s0 : TS;
-        // stage: 64 samples of each of the rows, along the rows (one 64-element coalesced load per row)
+        if (wide && w == TS) {
+            commit();
+            if (s0 + 2 * TS <= A.n_scan) fetch(s0 + TS);
+        } else {
+            // stage: 64 samples of each of the rows, along the rows (one 64-element coalesced load per row)
 #pragma unroll 8
-        for (int r = 0; r < rows_here; ++r) tile[r * PITCH + lane] = lane < w ? (T)g[(r0 + r) * A.row_stride + s0 + lane] : (T)0;
+            for (int r = 0; r < rows_here; ++r) tile[r * PITCH + lane] = lane < w ? (T)g[(r0 + r) * A.row_stride + s0 + lane] : (T)0;
+        }
         // 1 / (j + 1) for the samples of this tile, one correctly rounded division per lane and fit, off the chains
 #pragma unroll
         for (int k = 0; k < DSP_FIT_MAX; ++k) {
@@ -64,29 +131,66 @@ __global__ __launch_bounds__(64) void dsp_fit_rows_kernel(FitArgs A) {
         wave_sync();
         if (live) {
             const T* mine = tile + lane * PITCH;
-            for (int u = 0; u < w; ++u) {
-                const T x = mine[u];
-                const T y = A.sub_mode ? x - b : x;  // bl_subtract.py:45 / numpy.subtract: one float subtraction
-                nan_y |= (y != y);
-                T z = y;
-                if (A.has_pz) {  // pole_zero.py:60-72: float64 state, the store rounds
-                    const double yd = (double)y;
-                    acc = (acc + yd) - xp * c;
-                    z = (T)acc;
-                    xp = yd;
-                }
+            // the tile in stretches with a constant set of active fits (all of this is uniform)
+            int lo[DSP_FIT_MAX], hi[DSP_FIT_MAX];
+#pragma unroll
+            for (int k = 0; k < DSP_FIT_MAX; ++k) {
+                int l = A.first[k] - s0, h = A.first[k] + A.count[k] - s0;
+                l = l < 0 ? 0 : (l > w ? w : l);
+                h = h < 0 ? 0 : (h > w ? w : h);
+                lo[k] = k < A.n_fits ? l : 0;
+                hi[k] = k < A.n_fits ? h : 0;
+            }
+            for (int cur = 0; cur < w;) {
+                int nxt = w, n_act = 0, which = -1;
 #pragma unroll
                 for (int k = 0; k < DSP_FIT_MAX; ++k) {
-                    const int j = s0 + u - A.first[k];
-                    if (k < A.n_fits && j >= 0 && j < A.count[k]) {  // (uniform)
-                        const T v = A.stage[k] ? z : y;
-                        const T temp = v - m[k];
-                        m[k] = (T)((double)m[k] + div_by_count((double)temp, (double)(j + 1), inv[k][u]));
-                        s[k] = s[k] + temp * (v - m[k]);
-                        sy[k] += (double)v;
-                        sxy[k] += (double)v * (double)j;
+                    if (lo[k] > cur && lo[k] < nxt) nxt = lo[k];
+                    if (hi[k] > cur && hi[k] < nxt) nxt = hi[k];
+                    if (lo[k] <= cur && cur < hi[k]) {
+                        ++n_act;
+                        which = k;
                     }
                 }
+                if (n_act == 0) {
+                    T dm = (T)0, ds = (T)0;
+                    double dy = 0.0, dxy = 0.0;
+                    fit_stretch<T, -1>(mine, inv[0], cur, nxt, 0, sub, b, has_pz, c, false, acc, xp, nan_y, dm, ds, dy, dxy);
+                } else if (n_act == 1) {
+                    const int j_a = s0 + cur - A.first[which];
+                    switch (which) {
+                        case 0: fit_stretch<T, 0>(mine, inv[0], cur, nxt, j_a, sub, b, has_pz, c, A.stage[0] != 0, acc, xp, nan_y, m[0], s[0], sy[0], sxy[0]); break;
+                        case 1: fit_stretch<T, 1>(mine, inv[1], cur, nxt, j_a, sub, b, has_pz, c, A.stage[1] != 0, acc, xp, nan_y, m[1], s[1], sy[1], sxy[1]); break;
+                        case 2: fit_stretch<T, 2>(mine, inv[2], cur, nxt, j_a, sub, b, has_pz, c, A.stage[2] != 0, acc, xp, nan_y, m[2], s[2], sy[2], sxy[2]); break;
+                        default: fit_stretch<T, 3>(mine, inv[3], cur, nxt, j_a, sub, b, has_pz, c, A.stage[3] != 0, acc, xp, nan_y, m[3], s[3], sy[3], sxy[3]); break;
+                    }
+                } else {  // windows that overlap: sample by sample, every fit tested
+                    for (int u = cur; u < nxt; ++u) {
+                        const T x = mine[u];
+                        const T y = sub ? x - b : x;
+                        nan_y |= (y != y);
+                        T z = y;
+                        if (has_pz) {
+                            const double yd = (double)y;
+                            acc = (acc + yd) - xp * c;
+                            z = (T)acc;
+                            xp = yd;
+                        }
+#pragma unroll
+                        for (int k = 0; k < DSP_FIT_MAX; ++k) {
+                            const int j = s0 + u - A.first[k];
+                            if (k < A.n_fits && j >= 0 && j < A.count[k]) {  // (uniform)
+                                const T v = A.stage[k] ? z : y;
+                                const T temp = v - m[k];
+                                m[k] = (T)((double)m[k] + div_by_count((double)temp, (double)(j + 1), inv[k][u]));
+                                s[k] = s[k] + temp * (v - m[k]);
+                                sy[k] += (double)v;
+                                sxy[k] += (double)v * (double)j;
+                            }
+                        }
+                    }
+                }
+                cur = nxt;
             }
         }
         wave_sync();
