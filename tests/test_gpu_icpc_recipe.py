@@ -380,3 +380,25 @@ def test_stage_buffers_are_bounded_and_pieces_give_the_same_results():
     assert max(len(b) for st in chain2._stages for b in st["bufs"].values()) == 38
     for k in ref:
         assert np.array_equal(d_out[k].to_numpy(), ref[k], equal_nan=True), k
+
+
+def test_results_do_not_depend_on_the_neighbours():
+    """the wavefronts of a workgroup keep their waveforms in neighbouring LDS regions, and which rows are neighbours depends on the
+    launch: the same rows in one launch of 2 000 and in launches of 37 must give the same bits (a store past a slot's guard into the
+    next region would show here)"""
+    from dspeed_amd.processing_chain import WaveformInput, build_processing_chain
+
+    rng = np.random.default_rng(99)
+    n = 2000
+    wf, bl = _synth(rng, n)
+    wf = wf.astype(np.uint16)
+    tb = {"waveform": WaveformInput(wf, 16.0, 48000.0), "baseline": bl}
+    chain, _, out = build_processing_chain(recipes.ICPC, tb)
+    chain.execute()
+    whole = {k: np.array(v) for k, v in out.items()}
+    for v in out.values():
+        v[...] = 0
+    for a in range(0, n, 37):
+        chain.execute(a, min(n, a + 37))
+    for k in whole:
+        assert np.array_equal(out[k], whole[k], equal_nan=True), k
