@@ -24,6 +24,8 @@ python3 tools/icpc_breakdown.py > "$OUT/icpc_recipe.jsonl" 2> "$OUT/icpc_recipe.
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/icpc_trace" -- python3 tools/icpc_rate.py 131072 5 > "$OUT/icpc_rate_traced.json" 2> "$OUT/icpc_trace.err"
 python3 tools/icpc_rate.py 131072 5 > "$OUT/icpc_rate.json" 2> /dev/null
 python3 tools/fir_store_rate.py 100000 1 > "$OUT/fir_store_rate.json" 2> /dev/null
+python3 tools/e2e_recipe_rate.py 100000 > "$OUT/e2e_recipe_rate.json" 2> /dev/null
+for r in 4096 16384 65536; do python3 tools/icpc_rate.py $r 10; done > "$OUT/icpc_rate_small.jsonl" 2> /dev/null
 DSPEED_HIP_NO_FUSED=1 tools/pmc_kernel.sh gpurun_out/prof_${TAG}_vm bench.py --allow-variants --no-cpu --rows 500000 --steps 5 --warmup 2 > /dev/null 2>&1
 python3 tools/pmc_table.py gpurun_out/prof_${TAG}_vm "dsp_vm" "$OUT/vm_pmc.json" > /dev/null
 python3 bench.py --wf-len 8192 --rows 500000 --no-cpu --steps 10 --warmup 5 > "$OUT/bench_8192.json" 2>/dev/null

@@ -109,6 +109,18 @@ if os.path.exists(rate) and os.path.getsize(rate):
             if "dsp_" in row["Name"] and "synth" not in row["Name"]:
                 nm = row["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
                 summary.append(f"| `{nm}` | {row['Calls']} | {float(row['AverageNs']) / 1e6:.3f} |")
+small = f"{src}/icpc_rate_small.jsonl"
+if os.path.exists(small) and os.path.getsize(small):
+    shutil.copy(small, f"profiles/{tag}_icpc_rate_small.jsonl")
+    rs = [json.loads(line) for line in open(small) if line.strip()]
+    summary += ["", "The recipe on smaller device-resident batches (what a piece of a host-resident batch is): " +
+                ", ".join(f"{r['rows']} rows {r['waveforms_per_s'] / 1e6:.2f} M/s" for r in rs) + "."]
+e2e = f"{src}/e2e_recipe_rate.json"
+if os.path.exists(e2e) and os.path.getsize(e2e):
+    shutil.copy(e2e, f"profiles/{tag}_e2e_recipe_rate.json")
+    ee = json.load(open(e2e))
+    summary += ["", f"From host memory (NumPy rows in, NumPy columns out, `tools/e2e_recipe_rate.py`, {ee['rows']} rows): " +
+                ", ".join(f"{k}: {v['waveforms_per_s'] / 1e6:.2f} M waveforms/s = {v['GB_per_s_over_pcie']} GB/s over PCIe" for k, v in ee["results"].items()) + "."]
 fsr = f"{src}/fir_store_rate.json"
 if os.path.exists(fsr) and os.path.getsize(fsr):
     shutil.copy(fsr, f"profiles/{tag}_fir_store_rate.json")
