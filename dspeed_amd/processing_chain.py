@@ -1682,7 +1682,8 @@ def _extract_stages(b: _Builder, steps, out_pars, n_rows, ft):
                 build(anc, [base], f"{base.name} -> HBM")
         # --- the filter itself; numpy.amax goes along when it is the only reader
         users = [x for x in steps if x is not st and any(base_of(a) is out for a, r in zip(x[1], _roles(x[0])) if r not in "WS")]
-        if len(users) == 1 and users[0][0] == "amax" and users[0][1][0] is out and out.name not in out_names and isinstance(users[0][1][2], Var):
+        if (len(users) == 1 and users[0][0] == "amax" and users[0][1][0] is out and out.name not in out_names and isinstance(users[0][1][2], Var)
+                and mode == "v" and out.length <= 320):  # (what the amax form of the kernel takes; else the filtered waveform is kept)
             build(pre + [st, users[0]], [users[0][1][2]], f"{fn} {key} + amax")
             users[0][1][2].kind = "scalar"
             gone = [st, users[0]]

@@ -251,3 +251,68 @@ def test_stored_output_nan_and_infinite_rows():
     clean = np.ones(70, bool)
     clean[[3, 7, 10, 11, 20, 21]] = False
     assert np.max(np.abs(got[clean] - conv[clean]) / np.abs(conv[clean]).max(axis=1, keepdims=True)) <= TOL
+
+
+# ---- whole recipes: filters staged ahead of the program (processing_chain._extract_stages) against the same recipe in one program
+def _both_ways(rec, tb, monkeypatch):
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    chain, _, out = build_processing_chain(rec, tb)
+    chain.execute()
+    staged = {k: np.array(v) for k, v in out.items()}
+    monkeypatch.setenv("DSPEED_HIP_NO_STAGES", "1")
+    one, _, out1 = build_processing_chain(rec, tb)
+    monkeypatch.delenv("DSPEED_HIP_NO_STAGES")
+    assert not one._stages
+    one.execute()
+    return chain, staged, {k: np.array(v) for k, v in out1.items()}
+
+
+def test_staged_filters_agree_with_the_one_program_form(monkeypatch):
+    """baseline from a fit on the rows (a column the stage binds by name), two filters on the same staged waveform, a filtered waveform
+    that is an output, a slice of it read by a processor, a filter straight on the input"""
+    rng = np.random.default_rng(21)
+    wf, bl = _synth(rng, 130, 4096, bl=(1000, 3000))
+    rec = {"outputs": ["bl_mean", "wf_a", "a_max", "b_max", "t_a", "c_max", "head_max"], "processors": {
+        "bl_mean, bl_std, bl_slope, bl_icpt": f"{M}.linear_slope_fit(waveform[0:500], bl_mean, bl_std, bl_slope, bl_icpt)",
+        "wf_bl": f"{M}.bl_subtract(waveform, bl_mean, wf_bl)",
+        "wf_pz": f"{M}.pole_zero(wf_bl, 1716.28, wf_pz)",
+        "ka": {"function": "t0_filter", "module": M, "args": ["8", "125", "ka(133, 'f')"]},
+        "kb": {"function": "t0_filter", "module": M, "args": ["30", "70", "kb(100, 'f')"]},
+        "kc": {"function": "cusp_filter", "module": M, "args": ["100", "20", "2000", "kc(700, 'f')"]},
+        "wf_a": {"function": "convolve_wf", "module": M, "args": ["wf_pz", "ka", "'s'", "wf_a(4096, 'f')"]},
+        "wf_b": {"function": "convolve_wf", "module": M, "args": ["wf_pz", "kb", "'f'", "wf_b(4195, 'f')"]},
+        "wf_c": {"function": "convolve_wf", "module": M, "args": ["waveform[0:960]", "kc", "'v'", "wf_c(261, 'f')"]},
+        "a_max": "numpy.amax(wf_a, 1, a_max)",
+        "b_max": "numpy.amax(wf_b, 1, b_max)",
+        "c_max": "numpy.amax(wf_c, 1, c_max)",
+        "head_max": "numpy.amax(wf_a[0:2048], 1, head_max)",
+        "t_lo, t_a, v_lo, v_hi": f"{M}.min_max(wf_a, t_lo, t_a, v_lo, v_hi)"}}
+    chain, staged, one = _both_ways(rec, {"waveform": wf}, monkeypatch)
+    kinds = sorted(st["chain"].kernel_name for st in chain._stages)
+    assert kinds == ["dsp_fir_mfma_kernel", "dsp_fir_store_kernel", "dsp_fir_store_kernel", "dsp_vm_kernel<float>"], kinds
+    assert np.array_equal(staged["bl_mean"], one["bl_mean"])
+    peak = np.abs(one["wf_a"]).max(axis=1)
+    assert np.max(np.abs(staged["wf_a"] - one["wf_a"]) / peak[:, None]) <= 2e-6
+    for k, scale in (("a_max", peak), ("head_max", peak), ("b_max", np.abs(one["b_max"]))):
+        assert np.max(np.abs(staged[k] - one[k]) / scale) <= 2e-6, k
+    # (the cusp kernel on rows that still carry their baseline of 1000 - 3000: the maximum is a tenth of the filtered waveform's swing)
+    assert np.max(np.abs(staged["c_max"] - one["c_max"]) / np.abs(one["c_max"])) <= 2e-5
+    # the position of the maximum: the same sample unless two samples within the filters' agreement compete
+    same = staged["t_a"] == one["t_a"]
+    assert same.mean() >= 0.95
+    rows = np.nonzero(~same)[0]
+    a = one["wf_a"]
+    assert all(abs(a[r, int(staged["t_a"][r])] - a[r, int(one["t_a"][r])]) <= 4e-6 * peak[r] for r in rows)
+    # and against the oracle, filter by filter
+    xb = oracle.bl_subtract(wf, one["bl_mean"])[0]
+    pz = oracle.pole_zero(xb, np.float32(1716.28))[0]
+    conv, rc = oracle.convolve_wf(pz, chain._stages[1]["consts"]["taps:ka"][:133] if "taps:ka" in chain._stages[1]["consts"] else one_taps(chain, "ka"), "s", 4096)
+    assert rc == 0 and np.max(np.abs(staged["wf_a"] - conv) / np.abs(conv).max(axis=1, keepdims=True)) <= TOL
+
+
+def one_taps(chain, name):
+    for st in chain._stages:
+        if f"taps:{name}" in st["consts"]:
+            return st["consts"][f"taps:{name}"][:133]
+    raise KeyError(name)
