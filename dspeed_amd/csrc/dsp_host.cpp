@@ -312,7 +312,7 @@ static bool match_fir_store_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, c
 static bool match_rows_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_io, const int32_t* slot_len, int n_slots,
                              const std::vector<int>& dev_index, bool f64) {
     const DevProgram& P = ch->host;
-    if (f64 || n_ops < 4 || n_slots < 1 || n_slots > 2) return false;
+    if (f64 || n_ops < 3 || n_slots < 1 || n_slots > 2) return false;
     int i = 0;
     if (ops[i].opcode != DSP_OP_LOAD) return false;
     const dsp_op& ld = ops[i++];
@@ -326,13 +326,17 @@ static bool match_rows_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const 
         bs = &ops[i++];
         if (bs->dst != s || bs->src != s || !f32_or_const(bs->sp[0])) return false;
     }
-    if (i >= n_ops || (ops[i].opcode != DSP_OP_POLE_ZERO && ops[i].opcode != DSP_OP_DOUBLE_POLE_ZERO)) return false;
-    const dsp_op& pz = ops[i];
-    const DevOp& dpz = P.ops[dev_index[i]];
-    ++i;
-    if (pz.dst != s || pz.src != s) return false;
-    for (int k = 0; k < (pz.opcode == DSP_OP_POLE_ZERO ? 1 : 3); ++k)
-        if (pz.sp[k].kind != DSP_ARG_CONST) return false;  // (per-event time constants: the VM's ops form the coefficients per row)
+    if (i >= n_ops) return false;
+    // (no pole-zero step at all: the rows are a waveform another program already corrected -- what whole recipes stage in HBM)
+    const bool has_pz = ops[i].opcode == DSP_OP_POLE_ZERO || ops[i].opcode == DSP_OP_DOUBLE_POLE_ZERO;
+    const dsp_op& pz = ops[has_pz ? i : 0];
+    const DevOp& dpz = P.ops[dev_index[has_pz ? i : 0]];
+    if (has_pz) {
+        ++i;
+        if (pz.dst != s || pz.src != s) return false;
+        for (int k = 0; k < (pz.opcode == DSP_OP_POLE_ZERO ? 1 : 3); ++k)
+            if (pz.sp[k].kind != DSP_ARG_CONST) return false;  // (per-event time constants: the VM's ops form the coefficients per row)
+    }
     const dsp_op *tr = nullptr, *dw = nullptr, *st_wf = nullptr;
     int tr_at = -1;
     std::vector<const dsp_op*> st_sc;
@@ -371,9 +375,11 @@ static bool match_rows_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const 
             A.bl_const = (float)bs->sp[0].value;
         }
     }
-    A.pz_kind = pz.opcode == DSP_OP_POLE_ZERO ? 1 : 2;
-    A.pz_param_nan = dpz.ic[0];
-    if (A.pz_kind == 1) {
+    A.pz_kind = !has_pz ? 0 : (pz.opcode == DSP_OP_POLE_ZERO ? 1 : 2);
+    A.pz_param_nan = has_pz ? dpz.ic[0] : 0;
+    if (A.pz_kind == 0) {
+        if (dw) return false;  // (the Haar transform of the kernel is the one of the pole-zero output)
+    } else if (A.pz_kind == 1) {
         A.pz_c = dpz.fc[0];
     } else {
         A.n1 = dpz.fc[0];

@@ -131,7 +131,9 @@ __device__ __forceinline__ void rows_produce(const ROWS_KARG RowsArgs& A, ROWS_L
 #pragma unroll
                 for (int j = 0; j < RB; ++j) {
                     const double xd = (double)x[j];
-                    if (PZ == 1) {
+                    if (PZ == 0) {  // rows that are the corrected waveform already
+                        w[j] = x[j];
+                    } else if (PZ == 1) {
                         if (FIRST && j == 0) {  // pole_zero.py:66-67
                             w[j] = x[j];
                             acc = xd;
@@ -212,7 +214,7 @@ __device__ __forceinline__ void rows_produce(const ROWS_KARG RowsArgs& A, ROWS_L
         }
     }
     // ---- what only shows at the end
-    const bool state_nan = PZ == 1 ? (acc != acc) : (t1 != t1 || t0 != t0);
+    const bool state_nan = PZ == 0 ? false : (PZ == 1 ? (acc != acc) : (t1 != t1 || t0 != t0));
     if (PZ == 1 && live && state_nan && !in_nan && !A.pz_param_nan && !(bl != bl)) rows_report(err, DSP_E_PZ_NAN, row);  // pole_zero.py:76-77
     if (L > 0 && live && (state_nan || in_nan || A.pz_param_nan)) {  // dwt.py:70-71: a NaN anywhere in w1 -> NaN coefficients
         const float nanv = quiet_nan<float>();
@@ -399,12 +401,15 @@ __global__ void __launch_bounds__(128, 2) dsp_rows_kernel(RowsArgs A_, int64_t n
     for (int e = (int)threadIdx.x; e < (A.ring_entries + RB) * 64; e += 128) ring[e] = 0.0f;  // samples before the waveform are zeros
     __syncthreads();
     if (wave == 0) {
-        switch (A.in_kind * 2 + (A.pz_kind - 1)) {
-            case 0: rows_produce<0, 1>(A, ring, n_wf, err); break;
-            case 1: rows_produce<0, 2>(A, ring, n_wf, err); break;
-            case 2: rows_produce<1, 1>(A, ring, n_wf, err); break;
-            case 3: rows_produce<1, 2>(A, ring, n_wf, err); break;
-            case 4: rows_produce<2, 1>(A, ring, n_wf, err); break;
+        switch (A.in_kind * 3 + A.pz_kind) {
+            case 0: rows_produce<0, 0>(A, ring, n_wf, err); break;
+            case 1: rows_produce<0, 1>(A, ring, n_wf, err); break;
+            case 2: rows_produce<0, 2>(A, ring, n_wf, err); break;
+            case 3: rows_produce<1, 0>(A, ring, n_wf, err); break;
+            case 4: rows_produce<1, 1>(A, ring, n_wf, err); break;
+            case 5: rows_produce<1, 2>(A, ring, n_wf, err); break;
+            case 6: rows_produce<2, 0>(A, ring, n_wf, err); break;
+            case 7: rows_produce<2, 1>(A, ring, n_wf, err); break;
             default: rows_produce<2, 2>(A, ring, n_wf, err); break;
         }
     } else {

@@ -1693,6 +1693,83 @@ def _extract_stages(b: _Builder, steps, out_pars, n_rows, ft):
         steps = [x for x in steps if not any(x is g for g in gone)]
     if not stages:
         return steps, stages
+
+    # --- short trapezoids that only feed min_max / time_point_thresh, on rows: the lane-per-waveform kernel (dsp_rows.hip) runs the
+    # reference's recurrence as it is, 64 waveforms per instruction, where the program replays it twice per waveform (the t0 chain of the
+    # Ge recipes, asym_trap_filter -> time_point_thresh: a fifth of the program).  The kernel reads rows, so the trapezoid's input must
+    # be rows (an input or what a stage above wrote) and every per-event operand a column in HBM: what such an operand depends on --
+    # min_max of the t0-filtered waveform -- moves ahead of the program as well, as a small program of its own on the same rows.
+    def rows_steps(v):
+        """steps that read only the rows v and per-event values already in HBM and make per-event values only; in order, closed under
+        their own results"""
+        made, picked = set(), []
+        for st in steps:
+            roles = _roles(st[0])
+            ins = [(a, r) for a, r in zip(st[1], roles) if r not in "WS"]
+            outs = [a for a, r in zip(st[1], roles) if r in "WS"]
+            if not outs or any(r == "W" for r in roles) or st[0] in ("alias",) or not any(base_of(a) is v and isinstance(a, Var) for a, r in ins):
+                continue
+            ok = True
+            for a, r in ins:
+                if base_of(a) is v and isinstance(a, Var):
+                    continue
+                if isinstance(a, (Var, SExpr, tuple)) and not (isinstance(a, tuple) and a and a[0] == "char"):
+                    ok = ok and isinstance(a, Var) and (plain_scalar(a) or id(a) in made)
+            if ok and all(isinstance(o, Var) and o.name not in out_names for o in outs[:0]) and all(isinstance(o, Var) for o in outs):
+                picked.append(st)
+                made.update(id(o) for o in outs)
+        return picked
+
+    trap_fns = ("trap_filter", "trap_norm", "asym_trap_filter")
+    for st in list(steps):
+        fn, args, key = st
+        if fn not in trap_fns or not any(st is x for x in steps):
+            continue
+        src, dst = args[0], args[-1]
+        ints = args[1:-1]
+        if not (isinstance(src, Var) and row_input(src) and isinstance(dst, Var) and dst.name not in out_names and src.length and src.length % 8 == 0
+                and src.length >= 16 and all(isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, (bool, Quantity)) and float(x) == int(x)
+                                             for x in ints)):
+            continue
+        iv = [int(x) for x in ints]
+        lags = (iv[0], iv[0] + iv[1], iv[0] + iv[1] + iv[2]) if fn == "asym_trap_filter" else (iv[0], iv[0] + iv[1], 2 * iv[0] + iv[1])
+        if min(lags) < 8 or (((max(lags) + 8 + 7) // 8) * 8 + 8) * 256 > 80 * 1024:
+            continue
+        users = [x for x in steps if x is not st and any(base_of(a) is dst for a, r in zip(x[1], _roles(x[0])) if r not in "WS")]
+        kinds = sorted(x[0] for x in users)
+        if kinds not in (["min_max"], ["time_point_thresh"], ["min_max", "time_point_thresh"]) or not all(x[1][0] is dst for x in users):
+            continue
+        mm_outs = [o for x in users if x[0] == "min_max" for o in x[1][1:5]]
+        # per-event operands of the walk: in HBM already, the reduction's own t_min / t_max, or movable ahead of the program
+        need = [a for x in users if x[0] == "time_point_thresh" for a in x[1][1:4] if isinstance(a, (Var, SExpr))]
+        movers, fine = [], True
+        for a in need:
+            if isinstance(a, Var) and (plain_scalar(a) or any(a is o for o in mm_outs)):
+                continue
+            pst = producer_of(a) if isinstance(a, Var) else None
+            rows_v = next((base_of(x) for x, r in zip(pst[1], _roles(pst[0])) if r not in "WS" and isinstance(x, Var) and row_input(x)), None) if pst else None
+            group = rows_steps(rows_v) if rows_v is not None else []
+            if pst is None or not any(pst is g for g in group):
+                fine = False
+                break
+            movers.append((rows_v, group))
+        if not fine:
+            continue
+        for rows_v, group in movers:
+            group = [g for g in group if any(g is x for x in steps)]
+            if not group:
+                continue
+            outs = [o for g in group for o, r in zip(g[1], _roles(g[0])) if r in "WS"]
+            build(group, outs, f"per-event values of {rows_v.name}")
+            for o in outs:
+                o.kind = "scalar"
+            steps = [x for x in steps if not any(x is g for g in group)]
+        outs = [o for x in users for o, r in zip(x[1], _roles(x[0])) if r in "WS"]
+        build([st] + users, outs, f"{fn} {key} on rows")
+        for o in outs:
+            o.kind = "scalar"
+        steps = [x for x in steps if x is not st and not any(x is u for u in users)]
+
     # what the stages' results replaced is not computed any more: producers of staged variables, and whatever only fed them
     staged = {id(v) for v in b.vars.values() if isinstance(v, Var) and getattr(v, "ext_key", None) is not None and getattr(v, "aux_io", None) is None}
     steps = [x for x in steps if not any(r in "WS" and id(a) in staged for a, r in zip(x[1], _roles(x[0])))]
@@ -2337,7 +2414,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
         else:
             # a time coordinate is written in its unit, not in samples: (index + grid offset) * period (reference :1990-2014, get_buffer(unit))
             unit_ns = _time_unit_ns(v.unit)
-            if v.is_coord is True and v.grid is not None and unit_ns is not None:
+            if v.is_coord is True and v.grid is not None and unit_ns is not None and not stage_mode:  # (a stage hands on sample indices)
                 v = b.converted(v, Grid(unit_ns))
             if isinstance(v, Var) and v.sreg is None and (getattr(v, "aux_io", None) is not None or getattr(v, "ext_key", None) is not None):
                 src_op = scalar_operand(v, [], what=f"output {o}")  # (stores read registers)

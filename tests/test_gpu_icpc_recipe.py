@@ -359,7 +359,7 @@ def test_stage_buffers_are_bounded_and_pieces_give_the_same_results():
     wf = wf.astype(np.uint16)
     tb = {"waveform": WaveformInput(wf, 16.0, 48000.0), "baseline": bl}
     chain, _, out = build_processing_chain(recipes.ICPC, tb)
-    assert len(chain._stages) == 3
+    assert len(chain._stages) == 5
     chain.execute()
     ref = {k: np.array(v) for k, v in out.items()}
     per_row = sum(4 * (1 if ln is None else ln) for st in chain._stages for _o, _k, ln in st["outs"])

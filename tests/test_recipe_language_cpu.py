@@ -90,13 +90,21 @@ def test_long_filters_of_the_ge_recipe_run_ahead_of_the_program():
     what = [[o[0] for o in st["program"].ops] for st in chain._stages]
     assert what == [[_lib.OP_LOAD, _lib.OP_BL_SUBTRACT, _lib.OP_POLE_ZERO, _lib.OP_STORE],
                     [_lib.OP_LOAD, _lib.OP_CONVOLVE, _lib.OP_STORE],
-                    [_lib.OP_LOAD, _lib.OP_BL_SUBTRACT, _lib.OP_CONVOLVE, _lib.OP_STORE]]
-    pz, t0f, cusp = chain._stages
+                    [_lib.OP_LOAD, _lib.OP_BL_SUBTRACT, _lib.OP_CONVOLVE, _lib.OP_STORE],
+                    # the t0 chain: what the walk on the asymmetric trapezoid starts from (min_max of the t0-filtered waveform; tp_0_est
+                    # reads the same rows and goes along), then the short trapezoid -> threshold walk in the shape of the rows kernel;
+                    # both hand on sample indices (no unit conversion before the stores)
+                    [_lib.OP_LOAD, _lib.OP_MIN_MAX, _lib.OP_TIME_POINT_THRESH] + [_lib.OP_STORE_SCALAR] * 5,
+                    [_lib.OP_LOAD, _lib.OP_TRAP_REDUCE, _lib.OP_STORE_SCALAR]]
+    pz, t0f, cusp, t0v, atrap = chain._stages
+    assert [o[1] for o in t0v["outs"]] == ["in:conv_tmin", "in:tp_start", "in:conv_min", "in:conv_max", "in:tp_0_est"]
+    assert atrap["alias"] == {"in:wf_pz": "in:wf_pz", "in:bl_std": "aux:0:1", "in:tp_start": "in:tp_start"} and atrap["outs"] == [("out:tp_0_atrap", "in:tp_0_atrap", None)]
+    assert _lib.OP_TRAP_REDUCE in opcodes and "in:wf_t0_filter" not in [io[0] for io in P.io], "the program no longer touches the t0-filtered waveform"
     assert pz["outs"] == [("out:wf_pz", "in:wf_pz", 8192)] and t0f["alias"] == {"in:wf_pz": "in:wf_pz"}
     assert t0f["outs"] == [("out:wf_t0_filter", "in:wf_t0_filter", 8192)] and cusp["outs"] == [("out:wf_cusp", "in:wf_cusp", 301)]
     assert cusp["program"].ops[0][4] == (0, 8192 - 6092), "bl_subtract's NaN rule covers the whole waveform: the load screens the rest"
     names = [io[0] for io in P.io]
-    assert {"in:wf_pz", "in:wf_t0_filter", "in:wf_cusp"} <= set(names) and chain._ext_alias["in:wf_cusp"] == "in:wf_cusp"
+    assert {"in:wf_pz", "in:tp_0_est", "in:tp_0_atrap", "in:wf_cusp"} <= set(names) and chain._ext_alias["in:wf_cusp"] == "in:wf_cusp"
     assert "in:waveform[0:6092]" in chain._in_vars, "columns only a stage reads are linked with the program's own"
     for st in chain._stages:
         _check_program_order(st["program"])
