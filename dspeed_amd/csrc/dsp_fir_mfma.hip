@@ -341,9 +341,11 @@ __global__ void __launch_bounds__(512, 2) dsp_fir_store_kernel(FirArgs A_, int64
         }
     const int j = lane & 15, h4 = lane >> 4;
     const int a_off = (wm * 32 + j) * APITCH + 4 * h4;
-    const int t_off = TB + 4 * h4 - (wn * 80 + j) - e;
-    // stages in which this wavefront's columns see a tap: window sample kk meets column cl at tap kk - cl - e
-    const int k_lo = wn * 80 + e, k_hi = wn * 80 + 79 + e + m - 1;
+    // Column tiles are dealt out to the four wavefronts of a row block in turn (tile tn of wavefront wn: columns 16 (wn + 4 tn) ..): the band
+    // of a short kernel covers about half of a tile row's 20 column tiles in any stage -- neighbouring ones -- and this way every wavefront
+    // holds its share of them instead of two wavefronts holding all and two none.  A 16-column tile meets a 16-sample group of the
+    // window only where a tap lies: window sample kk meets column cl at tap kk - cl - e.
+    const int t_off = TB + 4 * h4 - (wn * 16 + j) - e;
 
     fetch(0);
     commit(0, 0);
@@ -352,25 +354,30 @@ __global__ void __launch_bounds__(512, 2) dsp_fir_store_kernel(FirArgs A_, int64
     for (int st = 0; st < n_stage; ++st) {
         const int buf = st & 1, k0 = st * BK;
         if (st + 1 < n_stage) fetch(k0 + BK);
-        if (k0 + BK > k_lo && k0 <= k_hi) {
+        {
             const FIR_LDS float* ab = As + buf * BM * APITCH + a_off;
 #pragma unroll
             for (int g = 0; g < BK / 16; ++g) {
+                const int kb = k0 + g * 16;  // this group: window samples kb .. kb + 15
                 f4 a[MT];
 #pragma unroll
                 for (int tm = 0; tm < MT; ++tm) a[tm] = *(const FIR_LDS f4*)(ab + tm * 16 * APITCH + g * 16);
                 float b[NT][4];
-                const FIR_LDS float* tb = tapz + t_off + k0 + g * 16;
+                const FIR_LDS float* tb = tapz + t_off + kb;
 #pragma unroll
                 for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) b[tn][s] = tb[s - tn * 16];
+                    for (int s = 0; s < 4; ++s) b[tn][s] = tb[s - tn * 64];
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int tn = 0; tn < NT; ++tn) {
+                    const int c_lo = 16 * (wn + 4 * tn) + e;  // (uniform: a scalar branch around the tile's eight matrix instructions)
+                    if (kb + 15 >= c_lo && kb <= c_lo + 14 + m) {
 #pragma unroll
-                    for (int tm = 0; tm < MT; ++tm)
+                        for (int s = 0; s < 4; ++s)
 #pragma unroll
-                        for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+                            for (int tm = 0; tm < MT; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+                    }
+                }
             }
         }
         if (st + 1 < n_stage) commit(k0 + BK, buf ^ 1);
@@ -395,7 +402,7 @@ __global__ void __launch_bounds__(512, 2) dsp_fir_store_kernel(FirArgs A_, int64
             const int64_t row = row0 + wm * 32 + tm * 16 + h4 * 4 + r;
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn) {
-                const int cl = wn * 80 + tn * 16 + j;
+                const int cl = 16 * (wn + 4 * tn) + j;
                 if (row < n_wf && cl < cols) outp[row * A.out_stride[0] + c0 + cl] = (float)(tot[tm][tn][r] + (double)acc[tm][tn][r]);
             }
         }
