@@ -116,6 +116,11 @@ class Chain:
         specialised kernel (VM layout, bit-identical to the VM; float32 rows only).  Returns whether a specialised kernel is in use."""
         return bool(_lib.lib().dsp_chain_set_fused(self._h, int(enable)))
 
+    def set_async_check(self, enable: bool = True) -> None:
+        """the error word travels with every launch (a page-locked mirror): ``check`` then issues no transfer of its own -- for pipelines
+        that send the next buffer to the device meanwhile"""
+        _lib.check(_lib.lib().dsp_chain_set_async_check(self._h, int(bool(enable))), what=self.name)
+
     def profile(self, enable: bool = True) -> None:
         """Switch the in-kernel per-op timing on (zeroing the counters) or off; see ``profile_read``."""
         _lib.check(_lib.lib().dsp_chain_profile(self._h, int(bool(enable))), what=self.name)

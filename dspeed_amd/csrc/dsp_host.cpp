@@ -177,10 +177,14 @@ struct dsp_chain {
     int fir_lds_bytes = 0;
     int64_t fir_out_offset = 0;  // stored variant: first element of the output binding
     int fio_wf = -1, fio_bl = -1, fio_taps[DSP_FIR_MAXK] = {-1, -1, -1, -1}, fio_out[DSP_FIR_MAXK] = {-1, -1, -1, -1};
+    // the error word handed to the host by a copy that is part of the launch (dsp_chain_set_async_check): dsp_chain_check then needs no
+    // transfer of its own -- one issued while a large host-to-device copy of the next buffer is in flight queues up behind it
+    int* err_mirror = nullptr;  // page-locked
     ~dsp_chain() {  // (also on the error paths of dsp_chain_create, which holds the chain in a unique_ptr)
         if (dev) (void)hipFree(dev);
         if (dev_err) (void)hipFree(dev_err);
         if (host.prof) (void)hipFree(host.prof);
+        if (err_mirror) (void)hipHostFree(err_mirror);
     }
 };
 
@@ -1474,6 +1478,11 @@ static void rr_geometry(const dsp_chain* ch, int64_t n_wf, int* wpb_out, int* bl
     *blocks_out = (int)(want < cap ? want : cap);
 }
 
+static int post_err(dsp_chain* ch, void* stream) {
+    if (ch->err_mirror) HIP_TRY(hipMemcpyAsync(ch->err_mirror, ch->dev_err, 4 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return DSP_OK;
+}
+
 int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* stream) {
     if (!ch || !io_ptrs) return fail(DSP_ERR_ARG, "null chain or io_ptrs");
     if (n_wf <= 0) return DSP_OK;
@@ -1499,7 +1508,7 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         hipError_t e = (hipError_t)(A.store ? dsp_internal_launch_fir_store(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream)
                                             : dsp_internal_launch_fir_mfma(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream));
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "FIR kernel launch failed: %s", hipGetErrorString(e));
-        return DSP_OK;
+        return post_err(ch, stream);
     }
     if (rows_applies(ch, io_ptrs)) {
         RowsArgs A = ch->rows;
@@ -1512,7 +1521,7 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         A.dwt_out = ch->rio_dwt >= 0 ? io_ptrs[ch->rio_dwt] : nullptr;
         hipError_t e = (hipError_t)dsp_internal_launch_rows(&A, n_wf, ch->dev_err, ch->rows_lds_bytes, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "rows kernel launch failed: %s", hipGetErrorString(e));
-        return DSP_OK;
+        return post_err(ch, stream);
     }
     const int blocks = vm_blocks(ch, n_wf);
     const int threads = 64 * ch->waves_per_block;
@@ -1529,7 +1538,7 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         hipError_t e = (hipError_t)dsp_internal_launch_energy_rr(&F, &ch->plan[S - 1], ch->fused_trap, ch->fused_npf, S, ch->wf_dtype, n_wf,
                                                                  ch->dev_err, rblocks, 64 * rwpb, ch->rr_lds_bytes * rwpb, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy kernel launch failed: %s", hipGetErrorString(e));
-        return DSP_OK;
+        return post_err(ch, stream);
     }
     if (ch->fused_ok && ch->fused_on && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
         EnergyArgs F = ch->fused;
@@ -1541,21 +1550,25 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         hipError_t e = (hipError_t)dsp_internal_launch_energy(&F, ch->fused_trap, ch->fused_npf, n_wf, ch->dev_err, chain_blocks(ch, n_wf, cw, 8),
                                                               64 * cw, ch->lds_bytes_per_wave * cw, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "energy kernel launch failed: %s", hipGetErrorString(e));
-        return DSP_OK;
+        return post_err(ch, stream);
     }
     hipError_t e = ch->f64 ? (hipError_t)dsp_internal_launch_vm_f64(ch->dev, &ptrs, n_wf, ch->dev_err, blocks, threads, lds, ch->has_fir,
                                                                     (hipStream_t)stream)
                            : (hipError_t)dsp_internal_launch_vm_f32(ch->dev, &ptrs, n_wf, ch->dev_err, blocks, threads, lds, ch->has_fir,
                                                                     (hipStream_t)stream);
     if (e != hipSuccess) return fail(DSP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
-    return DSP_OK;
+    return post_err(ch, stream);
 }
 
 int dsp_chain_check(dsp_chain* ch, void* stream, int64_t* row) {
     if (!ch) return fail(DSP_ERR_ARG, "null chain");
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     int host_err[DSP_ERR_WORDS] = {0};
-    HIP_TRY(staged_d2h(host_err, ch->dev_err, sizeof host_err));
+    if (ch->err_mirror) {
+        memcpy(host_err, ch->err_mirror, 4 * sizeof(int));  // (copied by the launch itself, on its stream)
+    } else {
+        HIP_TRY(staged_d2h(host_err, ch->dev_err, sizeof host_err));
+    }
 #ifdef DSPEED_HIP_DIAG
     if (getenv("DSPEED_HIP_ABLATE") && (atoi(getenv("DSPEED_HIP_ABLATE")) & 8)) {  // diagnostic phase stamps
         unsigned long long ph[6];
@@ -1651,6 +1664,18 @@ const char* dsp_chain_kernel_name(dsp_chain* ch) {
     if (ch && ch->rows_ok && ch->fused_on) return dsp_internal_rows_kernel_name();
     if (ch && ch->rr_ok && ch->fused_on && ch->variant != 1) return dsp_internal_energy_rr_kernel_name();
     return (ch && ch->fused_ok && ch->fused_on) ? dsp_internal_energy_kernel_name() : dsp_internal_vm_kernel_name();
+}
+
+int dsp_chain_set_async_check(dsp_chain* ch, int enable) {
+    if (!ch) return fail(DSP_ERR_ARG, "null chain");
+    if (enable && !ch->err_mirror) {
+        HIP_TRY(hipHostMalloc((void**)&ch->err_mirror, DSP_ERR_WORDS * sizeof(int), hipHostMallocDefault));
+        memset(ch->err_mirror, 0, DSP_ERR_WORDS * sizeof(int));
+    } else if (!enable && ch->err_mirror) {
+        (void)hipHostFree(ch->err_mirror);
+        ch->err_mirror = nullptr;
+    }
+    return DSP_OK;
 }
 
 int dsp_chain_set_fused(dsp_chain* ch, int enable) {

@@ -265,11 +265,13 @@ class ProcessingChain:
     def _ensure(self):
         if self._chain is None:
             self._chain = Chain(self._program, "processing_chain", self.loop_dtype)
+            self._chain.set_async_check(True)  # (pieces of a host-resident batch: the check must not wait behind the next piece's transfer)
             self._stream = Stream()
             for name, arr in self._consts.items():
                 self._dev[name] = DeviceArray.from_numpy(arr)
             for k, st in enumerate(self._stages):
                 st["chain"] = Chain(st["program"], f"processing_chain stage {k} ({st['what']})", self.loop_dtype)
+                st["chain"].set_async_check(True)
                 st["dev"] = {name: DeviceArray.from_numpy(arr) for name, arr in st["consts"].items()}
 
     #: bytes of host-resident I/O per pipelined piece, two pieces in flight.  Tens of MB are enough for the PCIe transfers; the size is set
@@ -407,21 +409,29 @@ class ProcessingChain:
                 self._host_copy(col[a:b], buf[:b - a])
             self._timing["d2h"] += time.perf_counter() - t
 
-        # ---- pieces: H2D(k) on the copy stream overlaps kernel(k-1) and D2H(k-1) on the compute stream
-        pending = None
-        for k, a in enumerate(range(start, stop, piece)):
-            b = min(stop, a + piece)
+        # ---- pieces.  The rows of piece k + 1 are copied into their page-locked staging buffer and sent to the device (block by block: the
+        # transfer of a block runs while the next one is copied) while the device works on piece k; the results of piece k are waited for
+        # after that, so only the tail of the last block's transfer is exposed.  One piece's kernels are in flight at a time (a DSPFatal
+        # belongs to the piece being finished).
+        pieces = [(a, min(stop, a + piece)) for a in range(start, stop, piece)]
+        SUB = 4  # blocks of a piece's rows: copy one, send it, copy the next
+
+        def stage_in(k):
+            a, b = pieces[k]
             m, sl, st = b - a, slots[k % n_slots], stage[k % n_slots]
             t = time.perf_counter()
             bufs = dict(self._dev)
-            for name, arr in host_in.items():  # (slot k % 2 is free: piece k-2 was finished in iteration k-1)
+            for name, arr in host_in.items():  # (slot k % 2 is free: piece k - 2 was finished before piece k - 1 was launched)
                 d = sl[name].view_rows(0, m)
-                if name in in_place_in:
-                    src = arr[a:b]
-                else:
-                    src = st[name].array[:m]
-                    self._host_copy(src, arr[a:b])
-                _lib.check(lib.dsp_h2d_async(d.ptr, src.ctypes.data, src.nbytes, s_in.ptr), what="h2d_async")
+                step = -(-m // SUB) if (name not in in_place_in and arr.nbytes // max(len(arr), 1) * m >= (8 << 20)) else m
+                for r0 in range(0, m, step):
+                    r1 = min(m, r0 + step)
+                    if name in in_place_in:
+                        src = arr[a + r0:a + r1]
+                    else:
+                        src = st[name].array[r0:r1]
+                        self._host_copy(src, arr[a + r0:a + r1])
+                    _lib.check(lib.dsp_h2d_async(d.view_rows(r0, r1).ptr, src.ctypes.data, src.nbytes, s_in.ptr), what="h2d_async")
                 bufs[name] = d
             ev_in[k % n_slots].record(s_in)
             for name, col in dev_in.items():
@@ -429,8 +439,12 @@ class ProcessingChain:
             for name, col in dev_out.items():
                 bufs[name] = col.view_rows(a, b)
             self._timing["h2d"] += time.perf_counter() - t
-            if pending is not None:
-                finish(*pending)
+            return bufs
+
+        nxt = stage_in(0)
+        for k, (a, b) in enumerate(pieces):
+            m, sl, st = b - a, slots[k % n_slots], stage[k % n_slots]
+            bufs = nxt
             s_c.wait_event(ev_in[k % n_slots])
             staged = []
             for name in host_out:
@@ -445,8 +459,9 @@ class ProcessingChain:
                     dst = st[name].array[:m]
                     staged.append((col, dst))
                 _lib.check(lib.dsp_d2h_async(dst.ctypes.data, d.ptr, d.nbytes, s_c.ptr), what="d2h_async")
-            pending = (a, b, staged)
-        finish(*pending)
+            if k + 1 < len(pieces):
+                nxt = stage_in(k + 1)
+            finish(a, b, staged)
 
     def _run_aux(self, bufs: dict, m: int, stream) -> None:
         """linear_slope_fit of the recipe that can run on the rows of the batch, one waveform per lane, ahead of the chain on its stream:

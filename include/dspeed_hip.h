@@ -270,6 +270,11 @@ const char* dsp_chain_kernel_name(dsp_chain* chain);
  * 5 = 4 sub-chains per lane.  Returns 1 if a specialised kernel will be used.  Environment DSPEED_HIP_NO_FUSED=1 sets the default
  * to the interpreter; DSPEED_HIP_VARIANT={1,0,2} picks the kernel variant (tuning). */
 int dsp_chain_set_fused(dsp_chain* chain, int enable);
+/* enable = 1: every dsp_chain_execute also copies the chain's error word to page-locked host memory on its stream, and dsp_chain_check reads
+ * it there after the stream synchronisation instead of issuing a transfer of its own.  For pipelines that send the next buffer to the
+ * device while the current one is processed (the reference's build_dsp.py:399-432 loop, overlapped): a transfer issued by the check
+ * would queue up behind that buffer's megabytes.  One launch per chain in flight at a time, as before. */
+int dsp_chain_set_async_check(dsp_chain* chain, int enable);
 
 /* ---- linear_slope_fit over whole batches, one waveform per lane (linear_slope_fit.py:11-91) --------------------------------
  * The fit's float32 Welford recurrences are sequential per waveform, so inside a chain (one wavefront per waveform) they cost a third
