@@ -330,11 +330,16 @@ class ProcessingChain:
         lib = _lib.lib()
         # ---- sort the linked columns: device-resident ones are used in place, host ones are streamed through piece buffers
         dev_in, host_in, dev_out, host_out = {}, {}, {}, {}
+        same_col = {}  # binding -> the binding of the same column that is sent (a stage's slice of the waveform, the fits' view of it)
+        first_of = {}
         for name, var in self._in_vars.items():
             col = _column(self._tb_in, var.source)
             if isinstance(col, DeviceArray):
                 dev_in[name] = col
+            elif var.source in first_of:
+                same_col[name] = first_of[var.source]
             else:
+                first_of[var.source] = name
                 a = np.asarray(col)
                 if not a.flags.c_contiguous:
                     a = np.ascontiguousarray(a)
@@ -433,6 +438,8 @@ class ProcessingChain:
                         self._host_copy(src, arr[a + r0:a + r1])
                     _lib.check(lib.dsp_h2d_async(d.view_rows(r0, r1).ptr, src.ctypes.data, src.nbytes, s_in.ptr), what="h2d_async")
                 bufs[name] = d
+            for name, first in same_col.items():
+                bufs[name] = bufs[first]
             ev_in[k % n_slots].record(s_in)
             for name, col in dev_in.items():
                 bufs[name] = col.view_rows(a, b)
