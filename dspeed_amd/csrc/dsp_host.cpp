@@ -1278,6 +1278,20 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             default: return fail(DSP_ERR_ARG, "op %d: unknown opcode %d", i, o.opcode);
         }
     }
+    // LOAD s; BL_SUBTRACT s <- s (what nearly every recipe starts with): the load subtracts while it writes the samples to LDS and the
+    // second op becomes a no-op -- one pass over the waveform in LDS less.  Same results: one float subtraction per sample in the loop's
+    // type, and the NaN rule of bl_subtract.py:41-44 (a NaN anywhere, or a NaN baseline: a NaN waveform) is the load's own flag.
+    for (int i = 0; i + 1 < n_ops; ++i) {
+        const dsp_op &ld = ops[i], &bs = ops[i + 1];
+        if (ld.opcode == DSP_OP_LOAD && bs.opcode == DSP_OP_BL_SUBTRACT && bs.src == ld.dst && bs.dst == ld.dst && bs.ip[0] == 0 &&
+            dev_index[i + 1] == dev_index[i] + 1) {
+            DevOp& L = P.ops[dev_index[i]];
+            DevOp& B = P.ops[dev_index[i + 1]];
+            L.ic[0] = 1;
+            L.sp[0] = B.sp[0];
+            B.opcode = DSP_OP_INTERNAL_NOP;
+        }
+    }
     P.n_ops = n_dev_ops;
 
     // ---- does the program have the shape LOAD [-> BL_SUBTRACT] -> POLE_ZERO -> TRAP_PICKOFF -> STORE_SCALAR on one slot?

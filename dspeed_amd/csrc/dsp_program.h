@@ -7,6 +7,7 @@
 
 #define DSP_WAVE 64
 #define DSP_FC 40 /* host-precomputed float64 constants per op */
+#define DSP_OP_INTERNAL_NOP 101  /* host-made: a BL_SUBTRACT that the LOAD in front of it does while it writes the samples (DevOp ic[0] of the LOAD) */
 #define DSP_OP_INTERNAL_ZERO 100 /* host-inserted: clear slot dst's whole LDS region (guard, chunks, pads, tail) before its first use */
 #define DSP_SCRATCH_ELEMS 128
 #define DSP_IC 12 /* host-precomputed integer constants per op */

@@ -98,7 +98,8 @@ struct Ctx {
 // LOAD / STORE: coalesced 16-byte global accesses <-> chunked LDS layout
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename InT>
-__device__ __forceinline__ bool load_slot(Ctx<T>& cx, const DSP_GLOBAL DevSlot& s, const DSP_GLOBAL InT* __restrict__ g, int len, bool vec_ok) {
+__device__ __forceinline__ bool load_slot(Ctx<T>& cx, const DSP_GLOBAL DevSlot& s, const DSP_GLOBAL InT* __restrict__ g, int len, bool vec_ok, bool sub,
+                                          T bsub) {
     constexpr int V = 16 / (int)sizeof(InT);
     typedef InT vec_t __attribute__((ext_vector_type(V)));
     const int total = 64 * s.C;
@@ -108,11 +109,12 @@ __device__ __forceinline__ bool load_slot(Ctx<T>& cx, const DSP_GLOBAL DevSlot& 
         // code: with a bounds test in front of every load the compiler waits for each load before the next branch and the loads go to
         // HBM one at a time (C2 on the VM: 121 -> 128 M waveforms/s).
         constexpr int B = 8;
-        auto put = [&](const vec_t& vv, int e) {
+        auto put = [&](const vec_t& vv, int e, bool inside = false) {
             const int a = padded_index(s, e);
 #pragma unroll
             for (int m = 0; m < V; ++m) {
                 T x = (T)vv[m];
+                x = (sub && (inside || e + m < len)) ? x - bsub : x;  // (a BL_SUBTRACT folded into the load; the zero fill past the end stays zero)
                 nan |= (x != x);
                 cx.lds[a + m] = x;
             }
@@ -124,7 +126,7 @@ __device__ __forceinline__ bool load_slot(Ctx<T>& cx, const DSP_GLOBAL DevSlot& 
 #pragma unroll
                 for (int b = 0; b < B; ++b) v[b] = *(const DSP_GLOBAL vec_t*)(g + e0 + b * 64 * V);
 #pragma unroll
-                for (int b = 0; b < B; ++b) put(v[b], e0 + b * 64 * V);
+                for (int b = 0; b < B; ++b) put(v[b], e0 + b * 64 * V, true);
             } else {  // the batch that holds the end of the row (and the zero fill of the last chunk)
 #pragma unroll
                 for (int b = 0; b < B; ++b) {
@@ -146,6 +148,7 @@ __device__ __forceinline__ bool load_slot(Ctx<T>& cx, const DSP_GLOBAL DevSlot& 
     } else {
         for (int e = lane_id(); e < total; e += 64) {
             T x = (e < len) ? (T)g[e] : (T)0;
+            x = (sub && e < len) ? x - bsub : x;
             nan |= (x != x);
             cx.lds[padded_index(s, e)] = x;
         }
@@ -159,14 +162,16 @@ __device__ __forceinline__ void op_load(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) 
     const DSP_GLOBAL DevIO& io = cx.prog->io[op.io];
     const int64_t at = cx.row * io.row_stride + io.offset;
     const bool vec_ok = io.vec_ok && ((cx.io_addr(op.io) & 15u) == 0);
+    const bool sub = op.ic[0] != 0;  // the BL_SUBTRACT behind this load, folded in by dsp_chain_create
+    const T bsub = sub ? cx.scalar(op.sp[0]) : (T)0;
     bool nan;
     switch (io.dtype) {
-        case DSP_F32: nan = load_slot<T, float>(cx, s, cx.template io_ptr<const float>(op.io) + at, io.len, vec_ok); break;
-        case DSP_I16: nan = load_slot<T, int16_t>(cx, s, cx.template io_ptr<const int16_t>(op.io) + at, io.len, vec_ok); break;
-        case DSP_U16: nan = load_slot<T, uint16_t>(cx, s, cx.template io_ptr<const uint16_t>(op.io) + at, io.len, vec_ok); break;
-        case DSP_I32: nan = load_slot<T, int32_t>(cx, s, cx.template io_ptr<const int32_t>(op.io) + at, io.len, vec_ok); break;
-        case DSP_U32: nan = load_slot<T, uint32_t>(cx, s, cx.template io_ptr<const uint32_t>(op.io) + at, io.len, vec_ok); break;
-        default: nan = load_slot<T, double>(cx, s, cx.template io_ptr<const double>(op.io) + at, io.len, vec_ok); break;
+        case DSP_F32: nan = load_slot<T, float>(cx, s, cx.template io_ptr<const float>(op.io) + at, io.len, vec_ok, sub, bsub); break;
+        case DSP_I16: nan = load_slot<T, int16_t>(cx, s, cx.template io_ptr<const int16_t>(op.io) + at, io.len, vec_ok, sub, bsub); break;
+        case DSP_U16: nan = load_slot<T, uint16_t>(cx, s, cx.template io_ptr<const uint16_t>(op.io) + at, io.len, vec_ok, sub, bsub); break;
+        case DSP_I32: nan = load_slot<T, int32_t>(cx, s, cx.template io_ptr<const int32_t>(op.io) + at, io.len, vec_ok, sub, bsub); break;
+        case DSP_U32: nan = load_slot<T, uint32_t>(cx, s, cx.template io_ptr<const uint32_t>(op.io) + at, io.len, vec_ok, sub, bsub); break;
+        default: nan = load_slot<T, double>(cx, s, cx.template io_ptr<const double>(op.io) + at, io.len, vec_ok, sub, bsub); break;
     }
     if (op.ip[0] > 0 || op.ip[1] > 0) {  // the slice of a longer waveform, first read by a processor whose NaN rule covers all of it
         for (int part = 0; part < 2; ++part) {
@@ -181,7 +186,9 @@ __device__ __forceinline__ void op_load(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) 
             }
         }
     }
-    if (wave_any(nan))  // (the samples are all there: what reads the slot as a whole sees a NaN waveform, a store writes it as it is)
+    if (sub)  // bl_subtract.py:41-44: a NaN anywhere (or a NaN baseline, which made every sample NaN) is a NaN waveform
+        cx.set_nan(op.dst, wave_any(nan));
+    else if (wave_any(nan))  // (the samples are all there: what reads the slot as a whole sees a NaN waveform, a store writes it as it is)
         cx.set_some_nan(op.dst);
     else
         cx.set_nan(op.dst, false);
@@ -2257,6 +2264,7 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 3) dsp_vm_kernel(const DevProgr
                 case DSP_OP_SCALAR_FUNC: op_scalar_func(cx, op); break;
                 case DSP_OP_SCALAR_CONVERT: op_scalar_convert(cx, op); break;
                 case DSP_OP_INTERNAL_ZERO: op_zero_region(cx, op); break;
+                case DSP_OP_INTERNAL_NOP: break;
                 default: break;
             }
         }
