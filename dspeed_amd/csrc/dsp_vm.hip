@@ -626,21 +626,22 @@ __device__ __forceinline__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op
     // ---- pass A: running sum of the input in T (it only feeds the speculative carries, which need not be exact),
     // captured at the three offsets the lagged chunk boundaries fall on
     T run = (T)0, cap[3] = {(T)0, (T)0, (T)0};
+    int coff[3];  // offset in the chunk at which the lagged chunk boundary falls: (C - rho) mod C without the integer division (0 <= rho < C)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) coff[k] = rho[k] ? C - rho[k] : 0;
     {
         int t = 0;
         while (t < C) {
             int nb = C;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int o = (C - rho[k]) % C;
-                if (o > t && o < nb) nb = o;
-            }
+            for (int k = 0; k < 3; ++k)
+                if (coff[k] > t && coff[k] < nb) nb = coff[k];
 #pragma unroll 8
             for (int u = t; u < nb; ++u) run += ps[u];
             t = nb;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                if (t == (C - rho[k]) % C) cap[k] = run;
+                if (t == coff[k]) cap[k] = run;
         }
     }
     const double E = wave_exscan_add((double)run);
@@ -648,7 +649,7 @@ __device__ __forceinline__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op
     double A[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int o = (C - rho[k]) % C;
+        const int o = coff[k];
         const double ak = E + (o == 0 ? 0.0 : (double)cap[k]);  // prefix up to (chunk, offset o)
         A[k] = wave_shift_up(ak, q[k] + (rho[k] > 0 ? 1 : 0));  // the chunk that index jC - L_k falls into
     }
