@@ -24,6 +24,9 @@
 
 // pointers into device memory (the program, I/O buffers) carry their address space in the type, see Ctx
 #define DSP_GLOBAL __attribute__((address_space(1)))
+// The device program (ops, slot and binding descriptors) is read-only for the kernel: read through the constant address space its uniform
+// loads are scalar loads (SMEM, the scalar cache) instead of vector loads that every op start had to wait for with vmcnt(0).
+#define DSP_PROG __attribute__((address_space(4)))
 
 namespace {
 
@@ -36,7 +39,7 @@ struct Ctx {
     // otherwise see a generic pointer and access LDS through flat_load / flat_store (measured: the FIR op 5x slower)
     typedef __attribute__((address_space(3))) T LT;
     LT* lds;                 // this wavefront's LDS region
-    const DSP_GLOBAL DevProgram* prog;  // device copy of the program
+    const DSP_PROG DevProgram* prog;  // device copy of the program
     // I/O device pointers of this launch: read straight from the kernel-argument segment (constant address space, scalar loads with a
     // run-time index); taking the address of the by-value IoPtrs argument instead makes the compiler copy it to scratch
     const __attribute__((address_space(4))) uint64_t* kptrs;
@@ -53,7 +56,7 @@ struct Ctx {
     // treat it like all-NaN (np.isnan(w_in).any()), a store writes the content
     uint32_t nan_all, nan_some;
 
-    __device__ __forceinline__ LT* chunk(const DSP_GLOBAL DevSlot& s) const { return lds + s.off + lane_id() * s.pitch; }
+    __device__ __forceinline__ LT* chunk(const DSP_PROG DevSlot& s) const { return lds + s.off + lane_id() * s.pitch; }
     __device__ __forceinline__ LT* sregs() const { return lds + prog->sreg_off; }
     __device__ __forceinline__ bool slot_nan(int s) const { return ((nan_all | nan_some) >> s) & 1u; }
     __device__ __forceinline__ bool slot_all_nan(int s) const { return (nan_all >> s) & 1u; }
@@ -73,17 +76,17 @@ struct Ctx {
         }
     }
     // scalar operand: constant, per-waveform input column, or scalar register
-    __device__ __forceinline__ T scalar(const DSP_GLOBAL dsp_scalar_arg& a) const { return make_uniform(scalar_raw(a)); }
+    __device__ __forceinline__ T scalar(const DSP_PROG dsp_scalar_arg& a) const { return make_uniform(scalar_raw(a)); }
     static __device__ __forceinline__ float make_uniform(float v) {
         return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
     }
     static __device__ __forceinline__ double make_uniform(double v) {
         return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
     }
-    __device__ __forceinline__ T scalar_raw(const DSP_GLOBAL dsp_scalar_arg& a) const {
+    __device__ __forceinline__ T scalar_raw(const DSP_PROG dsp_scalar_arg& a) const {
         if (a.kind == DSP_ARG_CONST) return (T)a.value;
         if (a.kind == DSP_ARG_REG) return sregs()[a.index];
-        const DSP_GLOBAL DevIO& io = prog->io[a.index];
+        const DSP_PROG DevIO& io = prog->io[a.index];
         const int64_t at = (int64_t)io.offset + row * io.row_stride;
         if (io.dtype == DSP_F32) return (T)io_ptr<const float>(a.index)[at];
         if (io.dtype == DSP_F64) return (T)io_ptr<const double>(a.index)[at];
@@ -98,7 +101,7 @@ struct Ctx {
 // LOAD / STORE: coalesced 16-byte global accesses <-> chunked LDS layout
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename InT>
-__device__ __forceinline__ bool load_slot(Ctx<T>& cx, const DSP_GLOBAL DevSlot& s, const DSP_GLOBAL InT* __restrict__ g, int len, bool vec_ok, bool sub,
+__device__ __forceinline__ bool load_slot(Ctx<T>& cx, const DSP_PROG DevSlot& s, const DSP_GLOBAL InT* __restrict__ g, int len, bool vec_ok, bool sub,
                                           T bsub) {
     constexpr int V = 16 / (int)sizeof(InT);
     typedef InT vec_t __attribute__((ext_vector_type(V)));
@@ -157,9 +160,9 @@ __device__ __forceinline__ bool load_slot(Ctx<T>& cx, const DSP_GLOBAL DevSlot& 
 }
 
 template <typename T>
-__device__ __forceinline__ void op_load(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& s = cx.prog->slots[op.dst];
-    const DSP_GLOBAL DevIO& io = cx.prog->io[op.io];
+__device__ __forceinline__ void op_load(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& s = cx.prog->slots[op.dst];
+    const DSP_PROG DevIO& io = cx.prog->io[op.io];
     const int64_t at = cx.row * io.row_stride + io.offset;
     const bool vec_ok = io.vec_ok && ((cx.io_addr(op.io) & 15u) == 0);
     const bool sub = op.ic[0] != 0;  // the BL_SUBTRACT behind this load, folded in by dsp_chain_create
@@ -196,9 +199,9 @@ __device__ __forceinline__ void op_load(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) 
 }
 
 template <typename T>
-__device__ __forceinline__ void op_store(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& s = cx.prog->slots[op.src];
-    const DSP_GLOBAL DevIO& io = cx.prog->io[op.io];
+__device__ __forceinline__ void op_store(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& s = cx.prog->slots[op.src];
+    const DSP_PROG DevIO& io = cx.prog->io[op.io];
     DSP_GLOBAL T* g = cx.template io_ptr<T>(op.io) + cx.row * io.row_stride + io.offset;
     const int len = io.len;
     const bool nan = cx.slot_all_nan(op.src);  // (a slot with some NaN samples is stored as it is)
@@ -227,8 +230,8 @@ __device__ __forceinline__ void op_store(Ctx<T>& cx, const DSP_GLOBAL DevOp& op)
 }
 
 template <typename T>
-__device__ __forceinline__ void op_store_scalar(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevIO& io = cx.prog->io[op.io];
+__device__ __forceinline__ void op_store_scalar(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevIO& io = cx.prog->io[op.io];
     if (io.dtype == DSP_BOOL) {
         if (lane_id() == 0) cx.template io_ptr<uint8_t>(op.io)[cx.row * io.row_stride + io.offset] = cx.sregs()[op.ip[0]] != (T)0 ? 1 : 0;
         return;
@@ -283,8 +286,8 @@ __device__ __forceinline__ void ew_dispatch(int fn, F&& f) {
 }
 
 template <typename T>
-__device__ __forceinline__ void op_elementwise(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+__device__ __forceinline__ void op_elementwise(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& sd = cx.prog->slots[op.dst];
     const int sl[3] = {op.src, op.ip[1], op.ip[2]};
     const typename Ctx<T>::LT* ps[3];
     T k[3];
@@ -327,7 +330,7 @@ __device__ __forceinline__ void op_elementwise(Ctx<T>& cx, const DSP_GLOBAL DevO
 }
 
 template <typename T>
-__device__ __forceinline__ void op_scalar_func(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_scalar_func(Ctx<T>& cx, const DSP_PROG DevOp& op) {
     const T a = cx.scalar(op.sp[0]), b = cx.scalar(op.sp[1]), c = cx.scalar(op.sp[2]);
     T v = (T)0;
     ew_dispatch<T>(op.ip[0], [&](auto fn) { v = ew_apply<decltype(fn)::value, T>(a, b, c); });
@@ -339,9 +342,9 @@ __device__ __forceinline__ void op_scalar_func(Ctx<T>& cx, const DSP_GLOBAL DevO
 // bl_subtract  (processors/bl_subtract.py:11-46):  w_out = w_in - a_baseline, both T
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void op_bl_subtract(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
-    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+__device__ __forceinline__ void op_bl_subtract(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_PROG DevSlot& sd = cx.prog->slots[op.dst];
     const T b = cx.scalar(op.sp[0]);
     // ip[0] = 1: numpy.subtract(w, scalar) -- the same subtraction sample by sample, but NaN samples stay where they are instead of
     // making the whole waveform NaN (bl_subtract.py:41-44 checks np.isnan(w_in).any(); the ufunc does not)
@@ -377,9 +380,9 @@ __device__ __forceinline__ void op_bl_subtract(Ctx<T>& cx, const DSP_GLOBAL DevO
 // min_max_norm  (processors/min_max.py:85-140):  w_out = w_in / max(|a_min|, |a_max|), w_in itself if either bound is 0
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void op_min_max_norm(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
-    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+__device__ __forceinline__ void op_min_max_norm(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_PROG DevSlot& sd = cx.prog->slots[op.dst];
     const T lo = cx.scalar(op.sp[0]), hi = cx.scalar(op.sp[1]);
     const T amin = lo < (T)0 ? -lo : lo, amax = hi < (T)0 ? -hi : hi;
     const bool copy = amax == (T)0 || amin == (T)0;
@@ -414,9 +417,9 @@ __device__ __forceinline__ void op_min_max_norm(Ctx<T>& cx, const DSP_GLOBAL Dev
 __device__ __attribute__((noinline)) double pz_decay(double tau) { return exp(-1.0 / tau); }
 
 template <typename T>
-__device__ __forceinline__ void op_pole_zero(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
-    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+__device__ __forceinline__ void op_pole_zero(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_PROG DevSlot& sd = cx.prog->slots[op.dst];
     double c = op.fc[0];
     bool tau_nan = op.ic[0] != 0;
     if (op.ic[1]) {  // one time constant per event (the gufunc's "()" slot filled by a per-event variable, pole_zero.py:24-30): the
@@ -474,9 +477,9 @@ __device__ __forceinline__ void op_pole_zero(Ctx<T>& cx, const DSP_GLOBAL DevOp&
 // fc: 0 n1, 1 n2, 2 d1, 3 d2, 4.. six 2x2 matrices M^{C}, M^{2C}, ... M^{32C} (row major); ic[0] = parameter NaN.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void op_double_pole_zero(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
-    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+__device__ __forceinline__ void op_double_pole_zero(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_PROG DevSlot& sd = cx.prog->slots[op.dst];
     double n1 = op.fc[0], n2 = op.fc[1], d1 = op.fc[2], d2 = op.fc[3];
     bool par_nan = op.ic[0] != 0;
     const int C = ss.C, lane = lane_id();
@@ -612,7 +615,7 @@ constexpr int TRAP_NCAP = 4;
 // RED = 2: only the maximum is wanted (numpy.amax of the trapezoid): one compare per sample instead of two extremes with their indices.
 // RED = 3: only the threshold walk is wanted (no min_max registers): the first replay tracks nothing, it just yields the carries.
 template <typename T, int KIND, bool STORE, int RED = 0>
-__device__ __forceinline__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const DSP_GLOBAL DevSlot& ss, const DSP_GLOBAL DevSlot& sd, const int* cap_idx, T* cap_val) {
+__device__ __forceinline__ void trap_core(Ctx<T>& cx, const DSP_PROG DevOp& op, const DSP_PROG DevSlot& ss, const DSP_PROG DevSlot& sd, const int* cap_idx, T* cap_val) {
     const int C = ss.C, lane = lane_id();
     const auto* ps = cx.chunk(ss);
     const double rr = op.fc[0], ll = op.fc[1];
@@ -833,8 +836,8 @@ __device__ __forceinline__ void trap_core(Ctx<T>& cx, const DSP_GLOBAL DevOp& op
 // dst = first of the four min_max registers (t_min, t_max, a_min, a_max) or -1; io = time_point_thresh register or -1;
 // sp[0..2] = threshold, t_start, walk_forward; ip[0..2] = rise, flat, fall; ip[3] = trapezoid opcode
 template <typename T>
-__device__ __forceinline__ void op_trap_reduce(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+__device__ __forceinline__ void op_trap_reduce(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
     // ip[3]: bits 0-7 the trapezoid's opcode; bits 8-15 the mode of a fixed_time_pickoff that also reads the trapezoid (0: none), at
     // sp[3], into register bits 16-29 minus one; bit 30: of the four min_max values only a_max is wanted (numpy.amax)
     const int kind = op.ip[3] & 0xff, pk_mode = (op.ip[3] >> 8) & 0xff, pk_reg = ((op.ip[3] >> 16) & 0x3fff) - 1;
@@ -894,9 +897,9 @@ __device__ __forceinline__ void op_trap_reduce(Ctx<T>& cx, const DSP_GLOBAL DevO
 }
 
 template <typename T>
-__device__ __forceinline__ void op_trap(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
-    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+__device__ __forceinline__ void op_trap(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_PROG DevSlot& sd = cx.prog->slots[op.dst];
     // ic[9]: static "output is all NaN" (rise == 0: the reference reads w_out[-1] = NaN, trap_filters.py:65-66)
     if (cx.slot_nan(op.src) || op.ic[9]) {
         cx.set_nan(op.dst, true);
@@ -968,8 +971,8 @@ __device__ __attribute__((noinline)) T pickoff_spline(const typename Ctx<T>::LT*
 }
 
 template <typename T>
-__device__ __forceinline__ void op_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+__device__ __forceinline__ void op_pickoff(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
     const T t_in = cx.scalar(op.sp[0]);
     T out = quiet_nan<T>();
     if (op.ip[1] == 1) {  // wf[i] in a recipe (processing_chain.py:986-990): a view of one sample, not the processor -- no NaN rule
@@ -1006,8 +1009,8 @@ __device__ __forceinline__ void op_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& o
 
 // TRAP_PICKOFF: trap filter whose only consumer is a fixed_time_pickoff -- the filtered waveform never exists.
 template <typename T>
-__device__ __forceinline__ void op_trap_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+__device__ __forceinline__ void op_trap_pickoff(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
     const T t_in = cx.scalar(op.sp[0]);
     T out = quiet_nan<T>();
     if (!cx.slot_nan(op.src) && !op.ic[9] && pickoff_in_range(t_in, ss.len)) {
@@ -1039,9 +1042,9 @@ __device__ __forceinline__ void op_trap_pickoff(Ctx<T>& cx, const DSP_GLOBAL Dev
 // windower (processors/windower.py:12-54): w_out[k] = w_in[int(t0) + k], NaN where the window reaches outside the input
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void op_windower(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
-    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+__device__ __forceinline__ void op_windower(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_PROG DevSlot& sd = cx.prog->slots[op.dst];
     const T t0 = cx.scalar(op.sp[0]);
     if (cx.slot_nan(op.src) || t0 != t0) {
         cx.set_nan(op.dst, true);
@@ -1068,9 +1071,9 @@ __device__ __forceinline__ void op_windower(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
 // avg_current (processors/moving_windows.py:206-249): w_out = (w_in[L:] - w_in[:-L]) / length in T; ic[0] = L, fc[0] = length
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void op_avg_current(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
-    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+__device__ __forceinline__ void op_avg_current(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_PROG DevSlot& sd = cx.prog->slots[op.dst];
     if (cx.slot_nan(op.src)) {
         cx.set_nan(op.dst, true);
         return;
@@ -1099,8 +1102,8 @@ __device__ __forceinline__ void op_avg_current(Ctx<T>& cx, const DSP_GLOBAL DevO
 // wavefront scan adds the partial sums (float64 sums of one waveform's float32 samples are exact, so order does not matter).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void op_trap_window_pickoff(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+__device__ __forceinline__ void op_trap_window_pickoff(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
     const T tp = cx.scalar(op.sp[0]);
     const int n = ss.len, rise = op.ip[0], flat = op.ip[1];
     T out = quiet_nan<T>();
@@ -1135,9 +1138,9 @@ __device__ __forceinline__ void op_trap_window_pickoff(Ctx<T>& cx, const DSP_GLO
 // starts are at least int(upsample) apart).  fc[0] = upsample, fc[1] = floor(upsample / 2), ic[0] = int(upsample)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void op_upsampler(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
-    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+__device__ __forceinline__ void op_upsampler(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_PROG DevSlot& sd = cx.prog->slots[op.dst];
     if (cx.slot_nan(op.src)) {
         cx.set_nan(op.dst, true);
         return;
@@ -1237,7 +1240,7 @@ __device__ __forceinline__ double div_by_length(double a, double d, double inv_d
 // lane's chunk, which that lane overwrites first -- are copied to `side` (64 x Ls elements) before anybody writes.  Needs L <= C.  One
 // 4784-sample waveform less in LDS for the current branch of the Ge recipes: four waveforms per CU instead of three.
 template <typename T, bool RIGHT, bool INPLACE = false>
-__device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot& in, const DSP_GLOBAL DevSlot& out, int L, T length,
+__device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_PROG DevSlot& in, const DSP_PROG DevSlot& out, int L, T length,
                                             typename Ctx<T>::LT* side = nullptr, int Ls = 0) {
     typedef typename Ctx<T>::LT LT;
     const int n = in.len, C = in.C, lane = lane_id(), v0 = lane * C;
@@ -1246,7 +1249,7 @@ __device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot
     const T inv_len = (T)1 / length;
     // stream of slot s starting at element e0 (this lane; may lie outside the slot: such elements are never read): base pointer, the t at
     // which it enters the next chunk (C: never)
-    auto stream = [&](const DSP_GLOBAL DevSlot& s, int e0, LT*& base, int& brk) {
+    auto stream = [&](const DSP_PROG DevSlot& s, int e0, LT*& base, int& brk) {
         const int q = (e0 >= 0 ? e0 : e0 - (C - 1)) / C, r = e0 - q * C;  // floor division: r is the same for every lane
         base = cx.lds + s.off + q * s.pitch + r;
         brk = RIGHT ? r + 1 : (r == 0 ? C : C - r);
@@ -1427,14 +1430,14 @@ __device__ __forceinline__ void mw_pass_dir(Ctx<T>& cx, const DSP_GLOBAL DevSlot
 }
 
 template <typename T>
-__device__ __forceinline__ void mw_pass(Ctx<T>& cx, const DSP_GLOBAL DevSlot& in, const DSP_GLOBAL DevSlot& out, int L, T length, bool right) {
+__device__ __forceinline__ void mw_pass(Ctx<T>& cx, const DSP_PROG DevSlot& in, const DSP_PROG DevSlot& out, int L, T length, bool right) {
     if (right)
         mw_pass_dir<T, true>(cx, in, out, L, length);
     else
         mw_pass_dir<T, false>(cx, in, out, L, length);
 }
 template <typename T>
-__device__ __forceinline__ void mw_pass_inplace(Ctx<T>& cx, const DSP_GLOBAL DevSlot& io, typename Ctx<T>::LT* side, int Ls, int L, T length, bool right) {
+__device__ __forceinline__ void mw_pass_inplace(Ctx<T>& cx, const DSP_PROG DevSlot& io, typename Ctx<T>::LT* side, int Ls, int L, T length, bool right) {
     if (right)
         mw_pass_dir<T, true, true>(cx, io, io, L, length, side, Ls);
     else
@@ -1442,10 +1445,10 @@ __device__ __forceinline__ void mw_pass_inplace(Ctx<T>& cx, const DSP_GLOBAL Dev
 }
 
 template <typename T>
-__device__ __forceinline__ void op_moving_window_multi(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
-    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
-    const DSP_GLOBAL DevSlot& sq = cx.prog->slots[op.ip[2]];
+__device__ __forceinline__ void op_moving_window_multi(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_PROG DevSlot& sd = cx.prog->slots[op.dst];
+    const DSP_PROG DevSlot& sq = cx.prog->slots[op.ip[2]];
     const int L = op.ic[0], num = op.ic[1], type = op.ic[2];
     if (cx.slot_nan(op.src) || num == 0) {  // (no window at all leaves the output as it was initialised: NaN)
         cx.set_nan(op.dst, true);
@@ -1468,7 +1471,7 @@ __device__ __forceinline__ void op_moving_window_multi(Ctx<T>& cx, const DSP_GLO
     for (int p = 0; p < num; ++p) {
         const bool right = ((p % 2 == 1) && type == 0) || type == 2;
         const bool to_dst = ((num - 1 - p) % 2) == 0;  // the last pass lands in dst
-        const DSP_GLOBAL DevSlot& in = p == 0 ? ss : (to_dst ? sq : sd);
+        const DSP_PROG DevSlot& in = p == 0 ? ss : (to_dst ? sq : sd);
         mw_pass(cx, in, to_dst ? sd : sq, L, length, right);
     }
     cx.set_nan(op.dst, false);
@@ -1486,8 +1489,8 @@ __device__ __forceinline__ void op_moving_window_multi(Ctx<T>& cx, const DSP_GLO
 // temp / (i + 1) and stdev / (n - 1) in float64 rounded back to T.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void op_linear_slope_fit(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+__device__ __forceinline__ void op_linear_slope_fit(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
     // the fit runs on samples [first, first + n) of the slot: a constant slice wf[a:b] of an intermediate costs no copy
     const int first = op.ic[0], n = op.ic[1], C = ss.C, lane = lane_id();
     T o_mean = quiet_nan<T>(), o_std = o_mean, o_slope = o_mean, o_icpt = o_mean;
@@ -1574,8 +1577,8 @@ __device__ __forceinline__ void op_linear_slope_fit(Ctx<T>& cx, const DSP_GLOBAL
 // waveform's dynamic range the float64 sums are exact, hence order independent; otherwise the last float64 bit may differ.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void op_mean_below(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+__device__ __forceinline__ void op_mean_below(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
     const T thr = cx.scalar(op.sp[0]);
     T out = quiet_nan<T>();
     if (!cx.slot_nan(op.src) && !(thr != thr)) {
@@ -1676,8 +1679,8 @@ __device__ __forceinline__ int find_crossing(Ctx<T>& cx, const SlotRef& ss, T th
 // time_point_thresh  (processors/time_point_thresh.py:12-92): comparisons only -> bit exact
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void op_time_point_thresh(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+__device__ __forceinline__ void op_time_point_thresh(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
     const T thr = cx.scalar(op.sp[0]), ts_f = cx.scalar(op.sp[1]), walk_f = cx.scalar(op.sp[2]);
     T out = quiet_nan<T>();
     const int n = ss.len, lane = lane_id();
@@ -1704,8 +1707,8 @@ __device__ __forceinline__ void op_time_point_thresh(Ctx<T>& cx, const DSP_GLOBA
 // it: mode 'l' divides in T, adds the int64 index in float64 and rounds to T; 'n' is index + 0.5 in float64.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void op_interp_time_point_thresh(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+__device__ __forceinline__ void op_interp_time_point_thresh(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
     const T thr = cx.scalar(op.sp[0]), ts_f = cx.scalar(op.sp[1]), walk_f = cx.scalar(op.sp[2]);
     const int mode = op.ip[0];
     T out = quiet_nan<T>();
@@ -1741,8 +1744,8 @@ __device__ __forceinline__ void op_interp_time_point_thresh(Ctx<T>& cx, const DS
 // min_max  (processors/min_max.py:11-82): first occurrence of the extremes (strict comparisons)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void op_min_max(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, bool amax_only) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
+__device__ __forceinline__ void op_min_max(Ctx<T>& cx, const DSP_PROG DevOp& op, bool amax_only) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
     const int n = ss.len, C = ss.C, lane = lane_id();
     T o_tmin = quiet_nan<T>(), o_tmax = o_tmin, o_amin = o_tmin, o_amax = o_tmin;
     if (!cx.slot_nan(op.src)) {
@@ -1804,7 +1807,7 @@ __device__ __forceinline__ void op_min_max(Ctx<T>& cx, const DSP_GLOBAL DevOp& o
 // run of G = 2^level consecutive samples of one lane's chunk -- no symmetric extension, no exchange between lanes, no intermediate
 // level in LDS.  The same products and sums per level as the level-by-level form.
 template <typename T, int LEVEL>
-__device__ __forceinline__ void dwt_haar_local(Ctx<T>& cx, const DSP_GLOBAL DevSlot& ss, const DSP_GLOBAL DevSlot& sd, int part) {
+__device__ __forceinline__ void dwt_haar_local(Ctx<T>& cx, const DSP_PROG DevSlot& ss, const DSP_PROG DevSlot& sd, int part) {
     constexpr int G = 1 << LEVEL;
     const T c = (T)0.7071067811865476;
     const int lane = lane_id(), C = ss.C, first = lane * C;
@@ -1825,10 +1828,10 @@ __device__ __forceinline__ void dwt_haar_local(Ctx<T>& cx, const DSP_GLOBAL DevS
 }
 
 template <typename T>
-__device__ __forceinline__ void op_dwt_haar(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
-    const DSP_GLOBAL DevSlot& st = cx.prog->slots[op.ip[2]];
-    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+__device__ __forceinline__ void op_dwt_haar(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_PROG DevSlot& st = cx.prog->slots[op.ip[2]];
+    const DSP_PROG DevSlot& sd = cx.prog->slots[op.dst];
     if (cx.slot_nan(op.src)) {
         cx.set_nan(op.dst, true);
         return;
@@ -1854,9 +1857,9 @@ __device__ __forceinline__ void op_dwt_haar(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
     const T c = (T)0.7071067811865476;
     int len = ss.len;
     for (int l = 0; l < level; ++l) {
-        const DSP_GLOBAL DevSlot& in = (l == 0) ? ss : st;
+        const DSP_PROG DevSlot& in = (l == 0) ? ss : st;
         const bool last = (l == level - 1);
-        const DSP_GLOBAL DevSlot& out = last ? sd : st;
+        const DSP_PROG DevSlot& out = last ? sd : st;
         const int half = (len + 1) >> 1;
         const T f0 = (last && part == 'd') ? -c : c;
         // NB rounds of 64 outputs at a time: their 2 * NB * 64 inputs are all read before any of their outputs is written (the
@@ -1892,9 +1895,9 @@ __device__ __forceinline__ void op_dwt_haar(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
 
 // dst[k] = src[k + ip[0]]
 template <typename T>
-__device__ __forceinline__ void op_copy(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
-    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[op.dst];
+__device__ __forceinline__ void op_copy(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_PROG DevSlot& sd = cx.prog->slots[op.dst];
     if (cx.slot_all_nan(op.src)) {
         cx.set_nan(op.dst, true);
         return;
@@ -1946,9 +1949,9 @@ __device__ __forceinline__ double fma_t(double a, double b, double c) { return _
 
 // AMAX: fused with numpy.amax over the output (DSP_OP_CONVOLVE_AMAX): nothing is stored, sreg[dst] receives the maximum
 template <typename T>
-__device__ __forceinline__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& op, const bool AMAX) {  // (one body for both: the tap loop is the big part)
-    const DSP_GLOBAL DevSlot& ss = cx.prog->slots[op.src];
-    const DSP_GLOBAL DevSlot& sd = cx.prog->slots[AMAX ? op.src : op.dst];  // (unused when AMAX)
+__device__ __forceinline__ void op_convolve(Ctx<T>& cx, const DSP_PROG DevOp& op, const bool AMAX) {  // (one body for both: the tap loop is the big part)
+    const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
+    const DSP_PROG DevSlot& sd = cx.prog->slots[AMAX ? op.src : op.dst];  // (unused when AMAX)
     if (cx.slot_nan(op.src) || op.ic[2]) {
         if (AMAX) {
             if (lane_id() == 0) cx.sregs()[op.dst] = quiet_nan<T>();
@@ -2139,7 +2142,7 @@ __device__ __forceinline__ void op_convolve(Ctx<T>& cx, const DSP_GLOBAL DevOp& 
 }
 
 template <typename T>
-__device__ __forceinline__ void op_scalar_affine(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_scalar_affine(Ctx<T>& cx, const DSP_PROG DevOp& op) {
     const T a = cx.scalar(op.sp[0]), b = cx.scalar(op.sp[1]), c = cx.scalar(op.sp[2]);
     if (lane_id() == 0) cx.sregs()[op.dst] = a * b + c;
     wave_sync();
@@ -2147,7 +2150,7 @@ __device__ __forceinline__ void op_scalar_affine(Ctx<T>& cx, const DSP_GLOBAL De
 
 // numpy.true_divide between two per-event variables (processing_chain.py:832-891 adds the ufunc as a processor)
 template <typename T>
-__device__ __forceinline__ void op_scalar_div(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_scalar_div(Ctx<T>& cx, const DSP_PROG DevOp& op) {
     const T a = cx.scalar(op.sp[0]), b = cx.scalar(op.sp[1]);
     if (lane_id() == 0) cx.sregs()[op.dst] = a / b;
     wave_sync();
@@ -2156,8 +2159,8 @@ __device__ __forceinline__ void op_scalar_div(Ctx<T>& cx, const DSP_GLOBAL DevOp
 // A time coordinate moved from one CoordinateGrid to another (unit_conversion.py:16-79): the offsets and the period ratio are float64
 // arguments there, so the arithmetic is float64 whatever the loop type; the result takes the variable's type.
 template <typename T>
-__device__ __forceinline__ void op_scalar_convert(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
-    auto f64_of = [&](const DSP_GLOBAL dsp_scalar_arg& a) { return a.kind == DSP_ARG_CONST ? a.value : (double)cx.scalar(a); };
+__device__ __forceinline__ void op_scalar_convert(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    auto f64_of = [&](const DSP_PROG dsp_scalar_arg& a) { return a.kind == DSP_ARG_CONST ? a.value : (double)cx.scalar(a); };
     const double x = (double)cx.scalar(op.sp[0]), off_in = f64_of(op.sp[1]), off_out = f64_of(op.sp[2]), ratio = op.sp[3].value;
     double r = (x + off_in) * ratio;  // (separate roundings like the reference's expression: no contraction into an fma)
     asm volatile("" : "+v"(r));
@@ -2173,7 +2176,7 @@ __device__ __forceinline__ void op_scalar_convert(Ctx<T>& cx, const DSP_GLOBAL D
 
 // host-inserted: a slot that shares its LDS region with others starts from the all-zero state the kernel prologue gives the rest
 template <typename T>
-__device__ __forceinline__ void op_zero_region(Ctx<T>& cx, const DSP_GLOBAL DevOp& op) {
+__device__ __forceinline__ void op_zero_region(Ctx<T>& cx, const DSP_PROG DevOp& op) {
     const int base = op.ic[0], n = op.ic[1];  // (both multiples of 4 elements: 16-byte stores)
     typedef T vec4_t __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) vec4_t lds_vec4;
@@ -2205,7 +2208,7 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 3) dsp_vm_kernel(const DevProgr
 
     Ctx<T> cx;
     cx.lds = lds;
-    cx.prog = (const DSP_GLOBAL DevProgram*)prog;
+    cx.prog = (const DSP_PROG DevProgram*)prog;
     // kernel arguments: (const DevProgram*, IoPtrs, int64_t, int*) -> the pointer table starts 8 bytes into the segment
     static_assert(sizeof(const DevProgram*) == 8 && alignof(IoPtrs) == 8, "kernel-argument layout");
     cx.kptrs = (const __attribute__((address_space(4))) uint64_t*)__builtin_amdgcn_kernarg_segment_ptr() + 1;
@@ -2222,7 +2225,7 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 3) dsp_vm_kernel(const DevProgr
         cx.nan_all = cx.nan_some = 0;
         if (sampled) t_prev = __builtin_amdgcn_s_memtime();
         for (int i = 0; i < n_ops; ++i) {
-            const DSP_GLOBAL DevOp& op = cx.prog->ops[i];
+            const DSP_PROG DevOp& op = cx.prog->ops[i];
             if (prof && i > 0 && sampled) {  // close the previous op's interval (one s_memtime per op when profiling, none otherwise)
                 const unsigned long long now = __builtin_amdgcn_s_memtime();
                 if (lane_id() == 0) atomicAdd(prof + (i - 1), now - t_prev);
