@@ -64,11 +64,27 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm)")
 
 
+def _stamp(diag: bool) -> str:
+    """what a library was built from: the compiler flags, the scratch guard and the content of every source and header"""
+    import hashlib
+
+    h = hashlib.sha256(repr((FLAGS, sorted(NO_SCRATCH.items()), diag)).encode())
+    for d in DEPS:
+        with open(os.path.join(CSRC, d), "rb") as f:
+            h.update(d.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def _stamp_file(lib: str) -> str:
+    return lib + ".stamp"
+
+
 def needs_build(lib: str = LIB) -> bool:
-    if not os.path.exists(lib):
+    """True unless `lib` exists and was built from exactly these sources with exactly these flags (a stamp file beside it says so)"""
+    if not os.path.exists(lib) or not os.path.exists(_stamp_file(lib)):
         return True
-    t = os.path.getmtime(lib)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    with open(_stamp_file(lib)) as f:
+        return f.read().strip() != _stamp(lib == LIB_DIAG)
 
 
 def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
@@ -88,18 +104,33 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE if guard else None, text=True if guard else None), src))
         objs.append(obj)
-    for cmd, p, src in procs:
-        err = p.communicate()[1] if src in NO_SCRATCH else None
-        if p.wait() != 0:
-            if err:
-                sys.stderr.write(err)
-            raise subprocess.CalledProcessError(p.returncode, cmd)
-        if err is not None:
-            _check_scratch(src, err)
+    failed = None
+    try:
+        for cmd, p, src in procs:
+            err = p.communicate()[1] if src in NO_SCRATCH else None
+            if p.wait() != 0:
+                if err:
+                    sys.stderr.write(err)
+                raise subprocess.CalledProcessError(p.returncode, cmd)
+            if err is not None:
+                _check_scratch(src, err)
+    except BaseException as e:
+        failed = e
+    if failed is not None:  # stop the compiles still running and leave no object behind for a later link to pick up
+        for _cmd, p, _src in procs:
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+        for obj in objs:
+            if os.path.exists(obj):
+                os.remove(obj)
+        raise failed
     link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", lib]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
+    with open(_stamp_file(lib), "w") as f:
+        f.write(_stamp(diag) + "\n")
     return lib
 
 

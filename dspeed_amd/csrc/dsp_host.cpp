@@ -175,7 +175,6 @@ struct dsp_chain {
     bool fir_ok = false;
     FirArgs fir{};
     int fir_lds_bytes = 0;
-    int64_t fir_out_offset = 0;  // stored variant: first element of the output binding
     int fio_wf = -1, fio_bl = -1, fio_taps[DSP_FIR_MAXK] = {-1, -1, -1, -1}, fio_out[DSP_FIR_MAXK] = {-1, -1, -1, -1};
     // the error word handed to the host by a copy that is part of the launch (dsp_chain_set_async_check): dsp_chain_check then needs no
     // transfer of its own -- one issued while a large host-to-device copy of the next buffer is in flight queues up behind it
@@ -305,7 +304,6 @@ static bool match_fir_store_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, c
     ch->fio_wf = ld.io;
     ch->fio_taps[0] = o.io;
     ch->fio_out[0] = st.io;
-    ch->fir_out_offset = io[st.io].offset;
     ch->fir_lds_bytes = dsp_internal_fir_store_lds_bytes(A.kend);
     return ch->fir_lds_bytes <= 80 * 1024;
 }
@@ -1454,7 +1452,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
 static bool rows_applies(const dsp_chain* ch, void* const* io_ptrs) {
     if (!ch->rows_ok || !ch->fused_on) return false;
     if (reinterpret_cast<uintptr_t>(io_ptrs[ch->rio_wf]) & 15u) return false;
-    if (ch->rio_dwt >= 0 && (reinterpret_cast<uintptr_t>(io_ptrs[ch->rio_dwt]) & 15u)) return false;
+    if (ch->rio_dwt >= 0 && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->rio_dwt]) + 4u * (uintptr_t)ch->host.io[ch->rio_dwt].offset) & 15u)) return false;
     return true;
 }
 
@@ -1492,6 +1490,22 @@ static void rr_geometry(const dsp_chain* ch, int64_t n_wf, int* wpb_out, int* bl
     *blocks_out = (int)(want < cap ? want : cap);
 }
 
+// makes `device` current for the calling thread and puts the previous one back when it goes out of scope
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false, ok = true;
+    explicit DeviceScope(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) {
+            ok = hipSetDevice(device) == hipSuccess;
+            switched = ok;
+        }
+    }
+    ~DeviceScope() {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 static int post_err(dsp_chain* ch, void* stream) {
     if (ch->err_mirror) HIP_TRY(hipMemcpyAsync(ch->err_mirror, ch->dev_err, 4 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     return DSP_OK;
@@ -1505,20 +1519,21 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         if (!io_ptrs[k]) return fail(DSP_ERR_ARG, "io binding %d is NULL", k);
         ptrs.p[k] = io_ptrs[k];
     }
-    {
-        int cur = -1;
-        if (hipGetDevice(&cur) == hipSuccess && cur != ch->device) HIP_TRY(hipSetDevice(ch->device));  // the chain's program and error word live there
-    }
+    DeviceScope on_chain_device(ch->device);  // the chain's program and error word live there; the caller's current device comes back on return
+    if (!on_chain_device.ok) return fail(DSP_ERR_HIP, "hipSetDevice(%d) failed", ch->device);
     (void)hipGetLastError();  // launch checks below report this launch, not a stale error of an unrelated earlier call
+    // a binding's first element: io_ptrs[k] + offset (the waveform input's offset travels in the kernels' arguments instead)
+    auto at = [&](int k) -> void* {
+        return k < 0 ? nullptr : (void*)((char*)io_ptrs[k] + (int64_t)ch->host.io[k].offset * elem_size(ch->host.io[k].dtype));
+    };
     if (fir_applies(ch, io_ptrs)) {
         FirArgs A = ch->fir;
         A.wf = io_ptrs[ch->fio_wf];
-        A.bl = ch->fio_bl >= 0 ? (const float*)io_ptrs[ch->fio_bl] : nullptr;
+        A.bl = (const float*)at(ch->fio_bl);
         for (int k = 0; k < A.n_kernels; ++k) {
-            A.taps[k] = (const float*)io_ptrs[ch->fio_taps[k]];
-            A.out[k] = io_ptrs[ch->fio_out[k]];
+            A.taps[k] = (const float*)at(ch->fio_taps[k]);
+            A.out[k] = at(ch->fio_out[k]);
         }
-        if (A.store) A.out[0] = (float*)A.out[0] + ch->fir_out_offset;
         hipError_t e = (hipError_t)(A.store ? dsp_internal_launch_fir_store(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream)
                                             : dsp_internal_launch_fir_mfma(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream));
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "FIR kernel launch failed: %s", hipGetErrorString(e));
@@ -1527,12 +1542,12 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
     if (rows_applies(ch, io_ptrs)) {
         RowsArgs A = ch->rows;
         A.wf = io_ptrs[ch->rio_wf];
-        A.bl = ch->rio_bl >= 0 ? (const float*)io_ptrs[ch->rio_bl] : nullptr;
-        A.thr = ch->rio_thr >= 0 ? (const float*)io_ptrs[ch->rio_thr] : nullptr;
-        A.ts = ch->rio_ts >= 0 ? (const float*)io_ptrs[ch->rio_ts] : nullptr;
-        for (int k = 0; k < 4; ++k) A.out_mm[k] = ch->rio_mm[k] >= 0 ? io_ptrs[ch->rio_mm[k]] : nullptr;
-        A.out_tpt = ch->rio_tpt >= 0 ? io_ptrs[ch->rio_tpt] : nullptr;
-        A.dwt_out = ch->rio_dwt >= 0 ? io_ptrs[ch->rio_dwt] : nullptr;
+        A.bl = (const float*)at(ch->rio_bl);
+        A.thr = (const float*)at(ch->rio_thr);
+        A.ts = (const float*)at(ch->rio_ts);
+        for (int k = 0; k < 4; ++k) A.out_mm[k] = at(ch->rio_mm[k]);
+        A.out_tpt = at(ch->rio_tpt);
+        A.dwt_out = at(ch->rio_dwt);
         hipError_t e = (hipError_t)dsp_internal_launch_rows(&A, n_wf, ch->dev_err, ch->rows_lds_bytes, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "rows kernel launch failed: %s", hipGetErrorString(e));
         return post_err(ch, stream);
@@ -1543,9 +1558,9 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
     if (ch->rr_ok && ch->fused_on && ch->variant != 1 && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
         EnergyArgs F = ch->rr;
         F.wf = io_ptrs[ch->io_wf];
-        F.bl = ch->io_bl >= 0 ? (const float*)io_ptrs[ch->io_bl] : nullptr;
-        F.tp = ch->io_tp >= 0 ? (const float*)io_ptrs[ch->io_tp] : nullptr;
-        F.out = (float*)io_ptrs[ch->io_out];
+        F.bl = (const float*)at(ch->io_bl);
+        F.tp = (const float*)at(ch->io_tp);
+        F.out = (float*)at(ch->io_out);
         const int S = (ch->variant == 8 && ch->wf_dtype == DSP_F32) ? 2 : 1;
         int rwpb, rblocks;
         rr_geometry(ch, n_wf, &rwpb, &rblocks);
@@ -1557,9 +1572,9 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
     if (ch->fused_ok && ch->fused_on && ((reinterpret_cast<uintptr_t>(io_ptrs[ch->io_wf]) & 15u) == 0)) {
         EnergyArgs F = ch->fused;
         F.wf = io_ptrs[ch->io_wf];
-        F.bl = ch->io_bl >= 0 ? (const float*)io_ptrs[ch->io_bl] : nullptr;
-        F.tp = ch->io_tp >= 0 ? (const float*)io_ptrs[ch->io_tp] : nullptr;
-        F.out = (float*)io_ptrs[ch->io_out];
+        F.bl = (const float*)at(ch->io_bl);
+        F.tp = (const float*)at(ch->io_tp);
+        F.out = (float*)at(ch->io_out);
         const int cw = ch->classic_wpb;
         hipError_t e = (hipError_t)dsp_internal_launch_energy(&F, ch->fused_trap, ch->fused_npf, n_wf, ch->dev_err, chain_blocks(ch, n_wf, cw, 8),
                                                               64 * cw, ch->lds_bytes_per_wave * cw, (hipStream_t)stream);
@@ -1599,7 +1614,8 @@ int dsp_chain_check(dsp_chain* ch, void* stream, int64_t* row) {
 #endif
     if (host_err[0] != 0) {
         if (row) *row = ((int64_t)(uint32_t)host_err[2] << 32) | (uint32_t)host_err[1];
-        HIP_TRY(hipMemset(ch->dev_err, 0, 4 * sizeof(int)));
+        if (ch->err_mirror) memset(ch->err_mirror, 0, 4 * sizeof(int));  // consumed: a second check without a launch in between reports nothing
+        HIP_TRY(hipMemsetAsync(ch->dev_err, 0, 4 * sizeof(int), (hipStream_t)stream));  // (in stream order, ahead of the next launch)
         g_last_error = dsp_fatal_message(host_err[0]);
         return host_err[0];
     }

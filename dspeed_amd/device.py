@@ -7,6 +7,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -126,13 +127,14 @@ class _Bounce:
     the device only ever exchanges data with memory the runtime allocated itself; the extra host copy is noise next to PCIe."""
 
     CHUNK = 32 << 20
-    _buf = None
+    _local = threading.local()  # one buffer per thread: worker threads of a multi-device build_dsp copy at the same time
 
     @classmethod
     def get(cls) -> np.ndarray:
-        if cls._buf is None:
-            cls._buf = PinnedArray((cls.CHUNK,), np.uint8)
-        return cls._buf.array
+        buf = getattr(cls._local, "buf", None)
+        if buf is None:
+            buf = cls._local.buf = PinnedArray((cls.CHUNK,), np.uint8)
+        return buf.array
 
     @classmethod
     def h2d(cls, dev_ptr: int, a: np.ndarray) -> None:

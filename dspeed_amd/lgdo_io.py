@@ -133,9 +133,12 @@ def column(obj, max_len: int | None = None):
             t0 = np.asarray(obj.t0.nda)
             period = float(dt[0]) * TIME_NS[dt_u] if len(dt) else 1.0  # one sampling period per table (reference: wf_table.dt[0])
             t0_ns = t0.astype(np.float64 if t0.dtype.itemsize > 4 or t0.dtype.kind in "iu" else np.float32) * TIME_NS[t0_u]
-            if isinstance(vals, RaggedColumn):
-                raise NotImplementedError("WaveformTable whose values are a VectorOfVectors: pass a maximum length and use the padded array")
-            return WaveformInput(vals, period, t0_ns if t0_ns.size != 1 else float(t0_ns.reshape(-1)[0]))
+            t0_arg = t0_ns if t0_ns.size != 1 else float(t0_ns.reshape(-1)[0])
+            if isinstance(vals, RaggedColumn):  # variable-length waveforms (:2327-2328): padded rows on the grid + the variable len(<name>)
+                wf = WaveformInput(vals.padded, period, t0_arg)
+                wf.lengths = vals.lengths
+                return wf
+            return WaveformInput(vals, period, t0_arg)
         return vals  # no usable time units: a plain array without a coordinate grid (:2304-2308)
     if is_vov(obj):
         return RaggedColumn.from_vov(obj, max_len)
@@ -156,7 +159,38 @@ def table_columns(tb, fields=None) -> dict:
             out[f"len({k})"] = c.lengths
         else:
             out[k] = c
+            if getattr(c, "lengths", None) is not None:  # a WaveformTable of variable-length waveforms
+                out[f"len({k})"] = c.lengths
     return out
+
+
+#: callables ``(file, group, iterator=False, n_rows=None, **row selection) -> table | chunk iterator | None`` tried in turn before the
+#: built-in ways of opening an auxiliary input (other file formats, tests)
+FRIEND_OPENERS: list = []
+
+
+def open_friend(file, group, iterator: bool = False, n_rows: int | None = None, **selection):
+    """The table ``group`` of ``file`` that a recipe's ``inputs`` joins to the table being processed (reference build_dsp.py:304-330): a
+    chunk iterator over it (``iterator=True``: what ``LH5Iterator.add_friend`` takes) or its first ``n_rows`` rows in memory.  ``.npz``
+    files laid out like an LH5 file are read here; LH5 files through ``lgdo.lh5``."""
+    for opener in FRIEND_OPENERS:
+        got = opener(file, group, iterator=iterator, n_rows=n_rows, **selection)
+        if got is not None:
+            return got
+    if isinstance(file, str) and file.endswith(".npz"):
+        if iterator:
+            raise NotImplementedError("an '.npz' friend of a chunk iterator: give the friend as an LH5 file, or the main table as arrays")
+        from .build_dsp import _read_npz, _select
+
+        tables = _read_npz(file)
+        key = group if group in tables else group.strip("/")
+        if key not in tables:
+            raise ProcessingChainError(f"auxiliary input: no table '{group}' in {file}")
+        return {k: _select(v, slice(0, n_rows)) if n_rows is not None else v for k, v in tables[key].items()}
+    _, lh5 = require_lh5(f"reading the auxiliary input '{file}'")
+    if iterator:
+        return lh5.LH5Iterator(file, group, **selection)
+    return lh5.LH5Store(keep_open=True).read(group, file, n_rows=n_rows)
 
 
 def snapshot(cols: dict) -> dict:
@@ -167,6 +201,8 @@ def snapshot(cols: dict) -> dict:
     for k, c in cols.items():
         if isinstance(c, WaveformInput):
             out[k] = WaveformInput(np.array(c.values, copy=True), c.dt, c.t0 if isinstance(c.t0, float) else np.array(c.t0, copy=True))
+            if getattr(c, "lengths", None) is not None:
+                out[k].lengths = np.array(c.lengths, copy=True)
         else:
             out[k] = np.array(c, copy=True)
     return out

@@ -30,6 +30,7 @@ from __future__ import annotations
 import ast
 import json
 import re
+import threading
 import time
 from collections.abc import MutableMapping
 import math
@@ -41,8 +42,9 @@ import numpy as np
 
 from . import _lib
 from .chain import Chain, Program, Scalar
-from .device import DeviceArray, Event, HostPin, PinnedArray, Stream, dtype_code
+from .device import DeviceArray, Event, HostPin, PinnedArray, Stream, dtype_code, set_device
 from .errors import DSPFatal, ProcessingChainError
+from .recipe import LANGUAGE_CALLS as _CALLS, Recipe
 
 _UNITS_NS = {"ns": 1.0, "us": 1e3, "ms": 1e6, "s": 1e9}
 
@@ -205,10 +207,10 @@ _GENERATORS = ("cusp_filter", "zac_filter", "t0_filter", "moving_slope")
 _MODULES = ("dspeed.processors", "dspeed_amd.processors", "numpy", "np")
 _NUMPY_BINARY = {"add": ast.Add, "subtract": ast.Sub, "multiply": ast.Mult, "divide": ast.Div, "true_divide": ast.Div}
 _ROUND_MODES = {"round": 1, "floor": 2, "ceil": 3, "trunc": 4}
-_CALLS = ("round", "floor", "ceil", "trunc", "len", "float", "int", "where", "isnan", "isfinite", "astype")  # functions of the argument language (reference :729-751)
 
 
 _COPY_POOL = None  # host threads that move rows between NumPy columns and staging buffers
+_COPY_POOL_LOCK = threading.Lock()
 
 
 class ProcessingChain:
@@ -240,6 +242,7 @@ class ProcessingChain:
         self._copy_pars = []      # outputs that are input columns handed through
         self.vector_lens = {}     # variable-length outputs -> input column with their per-event lengths
         self.proc_strings = proc_strings
+        self.device = None        # GPU ordinal the chain is bound to (None: the current device of the thread that first executes it)
 
     # -- introspection
     @property
@@ -298,10 +301,11 @@ class ProcessingChain:
             np.copyto(dst, src, casting="unsafe")
             return
         global _COPY_POOL
-        if _COPY_POOL is None or _COPY_POOL._max_workers < self.copy_threads:  # (one pool for all chains of the process)
-            from concurrent.futures import ThreadPoolExecutor
+        with _COPY_POOL_LOCK:
+            if _COPY_POOL is None or _COPY_POOL._max_workers < self.copy_threads:  # (one pool for all chains of the process)
+                from concurrent.futures import ThreadPoolExecutor
 
-            _COPY_POOL = ThreadPoolExecutor(max_workers=self.copy_threads, thread_name_prefix="dspeed-copy")
+                _COPY_POOL = ThreadPoolExecutor(max_workers=self.copy_threads, thread_name_prefix="dspeed-copy")
         step = -(-n // self.copy_threads)
         list(_COPY_POOL.map(lambda a: np.copyto(dst[a:a + step], src[a:a + step], casting="unsafe"), range(0, n, step)))
 
@@ -326,6 +330,8 @@ class ProcessingChain:
         n = stop - start
         if n <= 0:
             return
+        if self.device is not None:
+            set_device(self.device)
         self._ensure()
         lib = _lib.lib()
         # ---- sort the linked columns: device-resident ones are used in place, host ones are streamed through piece buffers
@@ -523,7 +529,9 @@ class ProcessingChain:
             for c in self._copy_pars:
                 if c in tb_in:
                     tb_out[c] = _column(tb_in, c)
-            lgdo_io.write_back(lgdo_out, tb_out, begin)
+            # only the rows this call computed go back into the table, at their own positions
+            stop = self._buffer_len if end is None else min(int(end), self._buffer_len)
+            lgdo_io.write_back(lgdo_out, {k: np.asarray(v)[begin:stop] for k, v in tb_out.items()}, begin)
             return lgdo_out
         return tb_out
 
@@ -538,7 +546,6 @@ def _column(tb, name):
 # ----------------------------------------------------------------------------------------------------------------
 # recipe parsing
 # ----------------------------------------------------------------------------------------------------------------
-_db_parser = re.compile(r"(?![^\w_.])db\.[\w_.]+")
 
 
 def _load(processors):
@@ -556,89 +563,6 @@ def _load(processors):
     if isinstance(processors, MutableMapping):
         return deepcopy(dict(processors))
     raise ValueError("processors must be a dict, json/yaml file, or None")
-
-
-def _normalise(key, node):
-    """Bring one recipe node to {'function', 'module', 'args'} (reference :2486-2553)."""
-    if isinstance(node, str):
-        node = {"function": node}
-    if "function" not in node:
-        raise ProcessingChainError(f"no function for parameter {key}")
-    function = node["function"]
-    f_parse = ast.parse(function, mode="eval").body
-    seg = lambda n: function[n.col_offset: n.end_col_offset]  # noqa: E731
-    if isinstance(f_parse, ast.Name):
-        pass
-    elif isinstance(f_parse, ast.Attribute):
-        if seg(f_parse.value) in ("np", "numpy") and "args" not in node:  # an attribute like np.pi: an inline constant (:2500-2505)
-            node["module"], node["args"] = None, [function]
-        else:
-            if "module" in node:
-                raise ProcessingChainError(f"Module specified twice for parameter {key}")
-            node["function"], node["module"] = f_parse.attr, seg(f_parse.value)
-    elif isinstance(f_parse, ast.Call) and isinstance(f_parse.func, (ast.Name, ast.Attribute)):
-        if "args" in node:
-            raise ProcessingChainError(f"Cannot specify arguments if function is expr for parameter {key}")
-        if isinstance(f_parse.func, ast.Attribute):
-            if "module" in node:
-                raise ProcessingChainError(f"Module specified twice for parameter {key}")
-            node["function"], node["module"] = f_parse.func.attr, seg(f_parse.func.value)
-            node["args"] = [seg(a) for a in f_parse.args + f_parse.keywords]
-        elif f_parse.func.id in _CALLS and "module" not in node:
-            node["module"], node["args"] = None, [function]
-        else:
-            node["function"] = f_parse.func.id
-            node["args"] = [seg(a) for a in f_parse.args + f_parse.keywords]
-    else:  # inline expression
-        if "args" in node or "module" in node:
-            raise ProcessingChainError(f"Cannot specify arguments/module if function is expr for parameter {key}")
-        node["module"], node["args"] = None, [function]
-    if "module" not in node:
-        raise ProcessingChainError(f"Could not find module for parameter {key}")
-    if "args" not in node:
-        raise ProcessingChainError(f"Could not find args for parameter {key}")
-    return node
-
-
-def _substitute_db(node, db_dict):
-    args = node["args"]
-    for i, arg in enumerate(args):
-        if not isinstance(arg, str):
-            continue
-        for db_var in _db_parser.findall(arg):
-            try:
-                db_node = db_dict
-                for k in db_var[3:].split("."):
-                    db_node = db_node[k]
-            except (KeyError, TypeError):
-                try:
-                    db_node = node["defaults"][db_var]
-                except (KeyError, TypeError):
-                    raise ProcessingChainError(f"did not find {db_var} in database, and could not find default value.") from None
-            arg = db_node if arg == db_var else arg.replace(db_var, str(db_node))
-        args[i] = arg
-
-
-def _names_in(arg: str) -> list[str]:
-    """Variable names an argument string refers to (get_variable(..., get_names_only=True) in the reference)."""
-    try:
-        tree = ast.parse(arg, mode="eval")
-    except SyntaxError:
-        return []
-    names = []
-    for n in ast.walk(tree):
-        if isinstance(n, ast.Call) and isinstance(n.func, ast.Name) and n.func.id not in _CALLS:
-            names.append(n.func.id)  # declaration name(shape, dtype)
-    called = set(names)
-    for n in ast.walk(tree):
-        if isinstance(n, ast.Name) and n.id not in _UNITS_NS and n.id not in _CALLS and n.id not in ("np", "numpy") and n.id not in called:
-            names.append(n.id)
-    seen, out = set(), []
-    for n in names:
-        if n not in seen:
-            seen.add(n)
-            out.append(n)
-    return out
 
 
 class _Builder:
@@ -1272,13 +1196,15 @@ def _resolve(b: _Builder, roles, args, same_dim_out=False, expression=False):
     return G, out
 
 
-def build_processing_chain(processors, tb_in=None, db_dict=None, outputs=None, block_width: int = 16):
+def build_processing_chain(processors, tb_in=None, db_dict=None, outputs=None, block_width: int = 16, device: int | None = None):
     """Translate a dspeed recipe into a device chain.
 
     Returns ``(proc_chain, field_mask, tb_out)`` like the reference (processing_chain.py:2363-2369): ``tb_in`` is a
     mapping ``name -> ndarray | DeviceArray | WaveformInput``; ``tb_out`` a dict of freshly allocated NumPy arrays for
     the requested outputs; ``field_mask`` the input columns actually used.  ``block_width`` is accepted for
-    signature compatibility: the device processes the whole buffer in one launch.
+    signature compatibility: the device processes the whole buffer in one launch.  ``device``: the GPU this chain lives on (its handle,
+    streams and buffers are created there, and ``execute`` makes it the calling thread's current device); default: whatever device is
+    current when the chain first runs.
     """
     del block_width
     from . import lgdo_io
@@ -1293,53 +1219,8 @@ def build_processing_chain(processors, tb_in=None, db_dict=None, outputs=None, b
     nodes = dict(recipe["processors"]) if "processors" in recipe else dict(recipe)
     nodes.pop("outputs", None)
 
-    multi = {}
-    for key in list(nodes):
-        keys = [k for k in re.split(",| ", key) if k]
-        if len(keys) > 1:
-            for k in keys:
-                multi[k] = key
-        node = _normalise(key, nodes[key])
-        nodes[key] = node
-        _substitute_db(node, db_dict or {})
-        if "prereqs" not in node:
-            pre = []
-            for arg in node["args"]:
-                if isinstance(arg, str):
-                    for nm in _names_in(arg):
-                        if nm not in pre and nm not in keys:
-                            pre.append(nm)
-            node["prereqs"] = pre
-    nodes.update(multi)
-
-    order, leafs = [], []
-
-    def resolve(par, unresolved):
-        if par in order:
-            return
-        if par in unresolved:
-            raise ProcessingChainError(f"Circular references detected for parameter '{par}'")
-        node = nodes.get(par)
-        if node is None:
-            if par not in leafs:
-                leafs.append(par)
-            return
-        if isinstance(node, str):
-            resolve(node, unresolved)
-            return
-        unresolved.append(par)
-        for edge in node["prereqs"]:
-            resolve(edge, unresolved)
-        order.append(par)
-        unresolved.remove(par)
-
-    copy_pars, out_pars = [], []
-    for o in outputs:
-        if o not in nodes:
-            copy_pars.append(o)
-        else:
-            resolve(o, [])
-            out_pars.append(o)
+    book = Recipe(nodes, db_dict)
+    order, leafs, out_pars, copy_pars = book.plan(outputs)
 
     b = _Builder(tb_in, db_dict)
     for leaf in leafs:
@@ -1348,16 +1229,13 @@ def build_processing_chain(processors, tb_in=None, db_dict=None, outputs=None, b
         b.input_var(leaf)
 
     proc_strings = []
-    for key in order:
-        node = nodes[key]
-        new_vars = [k for k in re.split(",| ", key) if k]
+    for entry in order:
         try:
-            _add_step(b, key, node, new_vars, proc_strings)
+            _add_step(b, entry.key, entry, list(entry.targets), proc_strings)
         except (ProcessingChainError, NotImplementedError, DSPFatal):
             raise
         except Exception as e:
-            raise ProcessingChainError("Exception raised while attempting to add processor:\n" + json.dumps(node, indent=2, default=str)) from e
-
+            raise ProcessingChainError("Exception raised while attempting to add processor:\n" + json.dumps(entry.as_dict(), indent=2, default=str)) from e
     n_rows = 0
     if tb_in:
         n_rows = len(_column(tb_in, next(iter(tb_in))))
@@ -1366,6 +1244,7 @@ def build_processing_chain(processors, tb_in=None, db_dict=None, outputs=None, b
         if tb_in is not None and c in tb_in:
             tb_out[c] = _column(tb_in, c)
     chain._copy_pars = list(copy_pars)
+    chain.device = None if device is None else int(device)
     chain.link(tb_in, tb_out)
     return chain, leafs + copy_pars, tb_out
 
