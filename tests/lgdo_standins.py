@@ -52,6 +52,10 @@ class Table(dict):
     def __len__(self):  # rows, like lgdo.Table (``if self`` would ask for the length again: count the keys through dict)
         return len(next(iter(self.values()))) if dict.__len__(self) else 0
 
+    def join(self, other, prefix="", suffix=""):  # lgdo.Table.join: the other table's columns under prefixed / suffixed names
+        for k in other.keys():
+            self[f"{prefix}{k}{suffix}"] = other[k]
+
 
 def _slice(col, a, b):
     if isinstance(col, WaveformTable):
@@ -73,6 +77,12 @@ class LH5Iterator:
         self.field_mask = None
         self.reads = []
         self._buf = {}
+        self.friends = []
+
+    def add_friend(self, other, prefix="", suffix=""):
+        """lh5.LH5Iterator.add_friend: the friend is read in step and its columns appear in every chunk under prefixed / suffixed names"""
+        assert other.buffer_len == self.buffer_len and len(other) >= len(self)
+        self.friends.append((other, prefix, suffix))
 
     def __len__(self):
         return self.n_entries
@@ -81,6 +91,22 @@ class LH5Iterator:
         self.field_mask = list(mask)
 
     def __iter__(self):
+        if self.friends:
+            own = LH5Iterator.__iter__
+            streams = [iter(f) for f, _p, _s in self.friends]
+            friends, self.friends = self.friends, []
+            try:
+                for chunk in own(self):
+                    for (f, prefix, suffix), st in zip(friends, streams):
+                        part = next(st)
+                        for k in part.keys():
+                            name = f"{prefix}{k}{suffix}"
+                            if self.field_mask is None or name in self.field_mask:
+                                chunk[name] = part[k]
+                    yield chunk
+            finally:
+                self.friends = friends
+            return
         self.current_i_entry = 0
         pos = 0
         while pos < self.n_entries:
