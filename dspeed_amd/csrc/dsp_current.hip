@@ -1,0 +1,253 @@
+// dsp_current.hip -- one waveform per LANE: the current branch of the LEGEND Ge recipes
+//   windower(t0) -> avg_current -> upsampler(x cnt) -> moving_window_multi(L, 3 passes, alternating) -> min_max      (A/E: A_max, tp_aoe_max)
+// as ONE kernel on rows in HBM (what whole recipes run ahead of their program: the pole-zero corrected waveform is rows there already and
+// the window start, tp_0_est, a column).
+//
+// Why.  Inside the program (one wavefront per waveform) the three moving averages are float32 recurrences that round after every
+// operation: they need the rounding replay of the trapezoids (two runs per pass) and were 30 % of the LEGEND program.  One waveform per
+// lane runs the reference's loops as they are written, 64 waveforms per instruction, every output bit-identical to the numba loop.
+//
+// The catch is the middle pass.  moving_window_multi with mw_type 0 goes left -> right, right -> left, left -> right, so a pass needs the
+// WHOLE output of the pass before it, in the opposite order: 4784 floats per waveform, 1.2 MB per 64 lanes -- not LDS, and streaming it
+// through HBM would cost 77 kB of traffic per waveform.  Instead only CHECKPOINTS are kept (the running value of a pass every 16 samples:
+// 2 x 299 floats per waveform, in a scratch area that stays in L2) and the samples between two checkpoints are recomputed, in registers,
+// when the next pass needs them -- a recurrence restarted from its own intermediate value reproduces its values bit for bit:
+//   sweep A (blocks 0 .. nb-1):  pass 1 values, checkpoint P0[b] = value before block b
+//   sweep B (blocks nb-1 .. 0):  pass 1 block b again from P0[b]; pass 2 steps on it (the lagged operand: block b + L/16, kept in an LDS
+//                                ring of L/16 + 1 blocks); checkpoint P1[b] = pass 2 value before block b in walking order
+//   sweep C (blocks 0 .. nb-1):  pass 1 block b + L/16 from P0, pass 2 block b from P1, pass 3 steps on it + the running min / max
+// 54 divisions per 16 samples instead of 34 (pass 1's increments repeat cnt times: it divides once per run), no sample array anywhere.
+//
+// Shape taken (anything else runs on the waveform VM): float32 rows; an upsampling factor in {1, 2, 4, 8, 16}; window length L a multiple
+// of 16 with L / 16 <= 7; three alternating windows; an upsampled length that is a multiple of 16.
+// Reference bodies: processors/windower.py:12-54, moving_windows.py:206-249 (avg_current) and :117-204 (moving_window_multi),
+// upsampler.py:13-56, min_max.py:11-82.  Compiled with -ffp-contract=off: one rounding per written operation.
+#include <hip/hip_runtime.h>
+
+#include "dsp_program.h"
+#include "dsp_wave.h"
+
+#define CUR_LDS __attribute__((address_space(3)))
+#define CUR_GLOBAL __attribute__((address_space(1)))
+#define CUR_KARG __attribute__((address_space(4)))
+
+namespace {
+
+constexpr int CB = 16;  // samples per block (= per checkpoint)
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// e / d in float32, correctly rounded: the float64 quotient (div_by_count: correctly rounded) rounds to the float32 one without a
+// double-rounding error (53 >= 2 * 24 + 2); infinities and NaN through the hardware's division fix-up
+__device__ __forceinline__ float div_f32(float e, double d, double inv_d) {
+    const double x = (double)e;
+    const double q = x * inv_d;
+    const double r = __builtin_fma(-q, d, x);
+    return (float)__builtin_amdgcn_div_fixup(__builtin_fma(r, inv_d, q), d, x);
+}
+
+__global__ void __launch_bounds__(64, 1) dsp_current_kernel(CurrentArgs A_, int64_t n_wf) {
+    const CUR_KARG CurrentArgs& A = *(const CUR_KARG CurrentArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)A_;
+    extern __shared__ __attribute__((aligned(16))) float cur_smem[];
+    const int lane = lane_id();
+    const int q = A.ma_len / CB, nring = q + 1;
+    CUR_LDS float* ring0 = (CUR_LDS float*)cur_smem;            // pass-1 blocks: [nring][CB][64]
+    CUR_LDS float* ring1 = ring0 + nring * CB * 64;             // pass-2 blocks
+    const int n_c = A.n_c, nb = A.n_up / CB, L = A.ma_len;
+    const int sh = A.up_shift, half = A.up_half, cnt = 1 << sh, ql = L >> sh;  // u[i] = c[(i + half) >> sh]; u[i - L] = c[((i + half) >> sh) - ql]
+    const double len_d = (double)A.ma_length, inv_len = 1.0 / len_d;
+    const double acl_d = (double)A.ac_length, inv_acl = 1.0 / acl_d;
+    CUR_GLOBAL float* scr = (CUR_GLOBAL float*)A.scratch + (int64_t)blockIdx.x * A.scratch_per_wave + lane;
+    CUR_GLOBAL float* ctab = scr;                     // c[k]   at ctab[k * 64]
+    CUR_GLOBAL float* P0 = scr + (int64_t)n_c * 64;   // P0[b]  at P0[b * 64]
+    CUR_GLOBAL float* P1 = P0 + (int64_t)nb * 64;
+    const int64_t n_groups = (n_wf + 63) / 64;
+
+    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const int64_t row = g * 64 + lane;
+        const bool live = row < n_wf;
+        const int64_t rowc = live ? row : n_wf - 1;
+        // ---- NaN anywhere in the row -> NaN window (windower.py:36): the wavefront screens its 64 rows together, 1 KiB per load
+        unsigned long long nan_rows = 0ull;
+        {
+            const int nv = A.n_in >> 2;  // float4 per row (n_in is a multiple of 4: the matcher's vec_ok)
+            for (int r = 0; r < 64; ++r) {
+                int64_t rr = g * 64 + r;
+                rr = rr < n_wf ? rr : n_wf - 1;
+                const CUR_GLOBAL f4* p = (const CUR_GLOBAL f4*)((const CUR_GLOBAL float*)A.wf + rr * A.wf_stride + A.wf_offset);
+                bool bad = false;
+                for (int v0 = 0; v0 < nv; v0 += 64 * 4) {
+                    f4 x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int v = v0 + u * 64 + lane;
+                        x[u] = p[v < nv ? v : nv - 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) bad |= (x[u][0] != x[u][0]) | (x[u][1] != x[u][1]) | (x[u][2] != x[u][2]) | (x[u][3] != x[u][3]);
+                }
+                if (wave_any(bad)) nan_rows |= 1ull << r;
+            }
+        }
+        // ---- windower + avg_current: c[k] = (w[k + La] - w[k]) / length, w[j] = x[beg + j]
+        const float t0 = A.t0 ? ((const CUR_GLOBAL float*)A.t0)[rowc * A.t0_stride] : A.t0_const;
+        const int m = A.win_len, n_in = A.n_in, La = A.ac_lag;
+        // int(t0) truncates toward zero; a start outside [0, n_in - m] leaves NaN samples in the window (windower.py:41-54), and one NaN in
+        // the window makes every later waveform NaN (avg_current, upsampler, moving_window_multi, min_max each return NaN for a NaN input)
+        bool valid = !((nan_rows >> lane) & 1ull) && !(t0 != t0) && t0 > -1.0f && t0 < (float)(n_in - m + 1) && !A.all_nan;
+        const int beg = valid ? (int)t0 : 0;
+        valid = valid && beg >= 0 && beg + m <= n_in;
+        const CUR_GLOBAL float* xw = (const CUR_GLOBAL float*)A.wf + rowc * A.wf_stride + A.wf_offset + (valid ? beg : 0);
+        bool c_nan = false;
+        for (int k = 0; k < n_c; ++k) {
+            const float e = xw[k + La] - xw[k];
+            const float c = div_f32(e, acl_d, inv_acl);
+            c_nan |= (c != c);
+            ctab[(int64_t)k * 64] = c;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (own stores, own loads: program order is all that is needed)
+
+        // pass 1 (left -> right) on block b from the value before it: o[j] = out0[16 b + j]
+        auto pass1_block = [&](int b, float acc, float (&o)[CB]) {
+            float qv = 0.0f;
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                const int i = b * CB + j;
+                if (j == 0 || ((i + half) & (cnt - 1)) == 0) {  // (uniform) a new run of equal samples: one division for all of it
+                    const int th = (i + half) >> sh;
+                    const float uh = ctab[(int64_t)th * 64];
+                    const float ul = ctab[(int64_t)(b < q ? 0 : th - ql) * 64];  // the first L samples subtract w_buf[0] = c[0]
+                    qv = div_f32(uh - ul, len_d, inv_len);
+                    if (i == 0) acc = uh;  // w_out[0] = w_buf[0]
+                }
+                if (i != 0) acc = acc + qv;
+                o[j] = acc;
+            }
+            return acc;
+        };
+        // pass 2 (right -> left) on block b: out1[k] = out1[k + 1] + (out0[k] - out0[k + L]) / length, the last L samples subtract out1[n - 1]
+        auto pass2_block = [&](int b, float acc, const float (&o0)[CB], const float (&lag)[CB], float first1, float (&o1)[CB]) {
+            const bool tail = b >= nb - q;
+#pragma unroll
+            for (int j = CB - 1; j >= 0; --j) {
+                if (b == nb - 1 && j == CB - 1) {
+                    acc = o0[j];  // w_out[-1] = w_buf[-1]
+                } else {
+                    const float e = o0[j] - (tail ? first1 : lag[j]);
+                    acc = acc + div_f32(e, len_d, inv_len);
+                }
+                o1[j] = acc;
+            }
+            return acc;
+        };
+
+        // ---- sweep A: pass 1, checkpoints
+        float acc0 = 0.0f;
+        for (int b = 0; b < nb; ++b) {
+            float o[CB];
+            P0[(int64_t)b * 64] = acc0;
+            acc0 = pass1_block(b, acc0, o);
+        }
+        const float first1 = acc0;  // out0[n - 1] = out1[n - 1]
+        // ---- sweep B: pass 2 over recomputed pass-1 blocks, checkpoints
+        float acc1 = 0.0f;
+        for (int b = nb - 1; b >= 0; --b) {
+            float o0[CB], lag[CB], o1[CB];
+            pass1_block(b, P0[(int64_t)b * 64], o0);
+            CUR_LDS float* w0 = ring0 + (b % nring) * CB * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < CB; ++j) w0[j * 64] = o0[j];
+            if (b + q < nb) {
+                const CUR_LDS float* r0 = ring0 + ((b + q) % nring) * CB * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < CB; ++j) lag[j] = r0[j * 64];
+            } else {
+#pragma unroll
+                for (int j = 0; j < CB; ++j) lag[j] = 0.0f;
+            }
+            P1[(int64_t)b * 64] = acc1;
+            acc1 = pass2_block(b, acc1, o0, lag, first1, o1);
+        }
+        const float first2 = acc1;  // out1[0] = out2[0]
+        // ---- sweep C: pass 3 over recomputed pass-2 blocks, running extremes
+        for (int bb = 0; bb < q && bb < nb; ++bb) {
+            float o0[CB];
+            pass1_block(bb, P0[(int64_t)bb * 64], o0);
+            CUR_LDS float* w0 = ring0 + (bb % nring) * CB * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < CB; ++j) w0[j * 64] = o0[j];
+        }
+        float acc2 = 0.0f, vmin = __builtin_inff(), vmax = -__builtin_inff();
+        int imin = 0, imax = 0;
+        for (int b = 0; b < nb; ++b) {
+            float o0[CB], lag0[CB], o1[CB], lag1[CB];
+            if (b + q < nb) {
+                pass1_block(b + q, P0[(int64_t)(b + q) * 64], lag0);
+                CUR_LDS float* w0 = ring0 + ((b + q) % nring) * CB * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < CB; ++j) w0[j * 64] = lag0[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < CB; ++j) lag0[j] = 0.0f;
+            }
+            {
+                const CUR_LDS float* r0 = ring0 + (b % nring) * CB * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < CB; ++j) o0[j] = r0[j * 64];
+            }
+            pass2_block(b, P1[(int64_t)b * 64], o0, lag0, first1, o1);
+            CUR_LDS float* w1 = ring1 + (b % nring) * CB * 64 + lane;
+#pragma unroll
+            for (int j = 0; j < CB; ++j) w1[j * 64] = o1[j];
+            if (b >= q) {
+                const CUR_LDS float* r1 = ring1 + ((b - q) % nring) * CB * 64 + lane;
+#pragma unroll
+                for (int j = 0; j < CB; ++j) lag1[j] = r1[j * 64];
+            }
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                const int i = b * CB + j;
+                if (i == 0) {
+                    acc2 = o1[0];
+                } else {
+                    const float e = o1[j] - (b < q ? first2 : lag1[j]);
+                    acc2 = acc2 + div_f32(e, len_d, inv_len);
+                }
+                const bool lt = acc2 < vmin, gt = acc2 > vmax;  // min_max.py:73-77: strict, the first occurrence stays
+                vmin = lt ? acc2 : vmin;
+                imin = lt ? i : imin;
+                vmax = gt ? acc2 : vmax;
+                imax = gt ? i : imax;
+            }
+        }
+        // ---- results: a NaN anywhere is still in the last value (every pass feeds its output back; pass 2 carries a NaN of pass 1 down to
+        // sample 0, where pass 3 starts)
+        if (live) {
+            const bool nan_all = !valid || c_nan || (acc2 != acc2) || (first1 != first1);
+            const float nanv = quiet_nan<float>();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!A.out[k]) continue;
+                const float v = k == 0 ? (float)imin : (k == 1 ? (float)imax : (k == 2 ? vmin : vmax));
+                ((CUR_GLOBAL float*)A.out[k])[row * A.out_stride[k]] = nan_all ? nanv : v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dsp_internal_current_lds_bytes(int ma_len) { return 2 * (ma_len / CB + 1) * CB * 64 * 4; }
+
+extern "C" int dsp_internal_launch_current(const CurrentArgs* A, int64_t n_wf, int blocks, int lds_bytes, hipStream_t stream) {
+    if (n_wf <= 0) return 0;
+    hipLaunchKernelGGL(dsp_current_kernel, dim3((unsigned)blocks), dim3(64), lds_bytes, stream, *A, n_wf);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dsp_internal_set_current_lds(int lds_bytes) {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dsp_current_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+}
+
+extern "C" const char* dsp_internal_current_kernel_name() { return "dsp_current_kernel"; }

@@ -82,6 +82,10 @@ extern "C" const char* dsp_internal_energy_rr_kernel_name();
 extern "C" int dsp_internal_launch_rows(const RowsArgs* A, int64_t n_wf, int* err, int lds_bytes, hipStream_t stream);
 extern "C" int dsp_internal_set_rows_lds(int lds_bytes);
 extern "C" const char* dsp_internal_rows_kernel_name();
+extern "C" int dsp_internal_current_lds_bytes(int ma_len);
+extern "C" int dsp_internal_launch_current(const CurrentArgs* A, int64_t n_wf, int blocks, int lds_bytes, hipStream_t stream);
+extern "C" int dsp_internal_set_current_lds(int lds_bytes);
+extern "C" const char* dsp_internal_current_kernel_name();
 extern "C" int dsp_internal_fir_mfma_lds_bytes(int kend);
 extern "C" int dsp_internal_launch_fir_mfma(const FirArgs* A, int64_t n_wf, int lds_bytes, hipStream_t stream);
 extern "C" int dsp_internal_set_fir_mfma_lds(int lds_bytes);
@@ -176,6 +180,12 @@ struct dsp_chain {
     FirArgs fir{};
     int fir_lds_bytes = 0;
     int fio_wf = -1, fio_bl = -1, fio_taps[DSP_FIR_MAXK] = {-1, -1, -1, -1}, fio_out[DSP_FIR_MAXK] = {-1, -1, -1, -1};
+    // lane-per-waveform current-branch kernel (dsp_current.hip)
+    bool cur_ok = false;
+    CurrentArgs cur{};
+    int cur_lds_bytes = 0, cio_wf = -1, cio_t0 = -1, cio_out[4] = {-1, -1, -1, -1};
+    float* cur_scratch = nullptr;  // allocated at the first launch
+    int cur_blocks_cap = 0;
     // the error word handed to the host by a copy that is part of the launch (dsp_chain_set_async_check): dsp_chain_check then needs no
     // transfer of its own -- one issued while a large host-to-device copy of the next buffer is in flight queues up behind it
     int* err_mirror = nullptr;  // page-locked
@@ -184,8 +194,75 @@ struct dsp_chain {
         if (dev_err) (void)hipFree(dev_err);
         if (host.prof) (void)hipFree(host.prof);
         if (err_mirror) (void)hipHostFree(err_mirror);
+        if (cur_scratch) (void)hipFree(cur_scratch);
     }
 };
+
+// Does the program have the shape of the current-branch kernel (dsp_current.hip)?
+//   LOAD s0;  WINDOWER s1 <- s0 (start: constant or float32 column);  AVG_CURRENT s2 <- s1;  UPSAMPLER s3 <- s2;
+//   MOVING_WINDOW_MULTI d <- s3 (3 windows, alternating);  MIN_MAX of d;  STORE_SCALARs of its four registers
+static bool match_current_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, const int32_t* slot_len, bool f64) {
+    if (f64 || n_ops < 7) return false;
+    const dsp_op &ld = ops[0], &wi = ops[1], &ac = ops[2], &up = ops[3], &mw = ops[4], &mm = ops[5];
+    if (ld.opcode != DSP_OP_LOAD || wi.opcode != DSP_OP_WINDOWER || ac.opcode != DSP_OP_AVG_CURRENT || up.opcode != DSP_OP_UPSAMPLER ||
+        mw.opcode != DSP_OP_MOVING_WINDOW_MULTI || mm.opcode != DSP_OP_MIN_MAX)
+        return false;
+    if (wi.src != ld.dst || ac.src != wi.dst || up.src != ac.dst || mw.src != up.dst || mm.src != mw.dst) return false;
+    const dsp_io_desc& w = io[ld.io];
+    if (w.dtype != DSP_F32 || ld.ip[0] != 0 || ld.ip[1] != 0 || (w.row_stride % 4) != 0 || (w.offset % 4) != 0 || (w.len % 4) != 0) return false;
+    CurrentArgs& A = ch->cur;
+    memset(&A, 0, sizeof A);
+    A.wf_stride = w.row_stride;
+    A.wf_offset = w.offset;
+    A.n_in = w.len;
+    if (wi.sp[0].kind == DSP_ARG_INPUT && io[wi.sp[0].index].dtype == DSP_F32) {
+        ch->cio_t0 = wi.sp[0].index;
+        A.t0_stride = io[ch->cio_t0].row_stride;
+    } else if (wi.sp[0].kind == DSP_ARG_CONST) {
+        A.t0_const = (float)wi.sp[0].value;
+    } else {
+        return false;
+    }
+    A.win_len = slot_len[wi.dst];
+    if (A.win_len < 2 || A.win_len >= A.n_in) return false;
+    // avg_current: an integer-valued length inside the window
+    if (ac.sp[0].kind != DSP_ARG_CONST) return false;
+    const float acl = (float)ac.sp[0].value;
+    if (!(acl >= 1.0f) || std::floor(acl) != acl || acl >= (float)A.win_len) return false;
+    A.ac_lag = (int)acl;
+    A.ac_length = acl;
+    A.n_c = A.win_len - A.ac_lag;
+    if (slot_len[ac.dst] != A.n_c) return false;
+    // upsampler: a factor in {1, 2, 4, 8, 16}, every output sample reached by an input sample
+    if (up.sp[0].kind != DSP_ARG_CONST) return false;
+    const float upf = (float)up.sp[0].value;
+    int shift = -1;
+    for (int k = 0; k <= 4; ++k)
+        if (upf == (float)(1 << k)) shift = k;
+    if (shift < 0) return false;
+    A.up_shift = shift;
+    A.up_half = (1 << shift) / 2;
+    A.n_up = slot_len[up.dst];
+    if (A.n_up < 32 || A.n_up % 16 != 0 || ((A.n_up - 1 + A.up_half) >> shift) >= A.n_c) return false;
+    // moving_window_multi: three alternating windows whose length is a multiple of 16 samples
+    if (mw.sp[0].kind != DSP_ARG_CONST || mw.ip[0] != 0 || mw.ip[1] != 3 || slot_len[mw.dst] != A.n_up) return false;
+    const float mal = (float)mw.sp[0].value;
+    if (!(mal >= 16.0f) || std::floor(mal) != mal || mal > 112.0f || ((int)mal % 16) != 0 || (int)mal >= A.n_up) return false;
+    A.ma_len = (int)mal;
+    A.ma_length = mal;
+    for (int i = 6; i < n_ops; ++i) {
+        const dsp_op& o = ops[i];
+        if (o.opcode != DSP_OP_STORE_SCALAR || io[o.io].dtype != DSP_F32) return false;
+        const int k = o.ip[0] - mm.dst;
+        if (k < 0 || k > 3 || ch->cio_out[k] >= 0) return false;
+        ch->cio_out[k] = o.io;
+        A.out_stride[k] = io[o.io].row_stride;
+    }
+    A.scratch_per_wave = (int64_t)(A.n_c + 2 * (A.n_up / 16)) * 64;
+    ch->cio_wf = ld.io;
+    ch->cur_lds_bytes = dsp_internal_current_lds_bytes(A.ma_len);
+    return true;
+}
 
 static bool match_fir_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, const int32_t* slot_len, int n_slots, bool f64) {
     const DevProgram& P = ch->host;
@@ -1415,6 +1492,15 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         ch->fused_on = !(env && env[0] == '1');
     }
 
+    ch->cur_ok = match_current_shape(ch.get(), ops, n_ops, io, slot_len, f64);
+    if (!ch->cur_ok) {
+        ch->cio_wf = ch->cio_t0 = -1;
+        for (int k = 0; k < 4; ++k) ch->cio_out[k] = -1;
+    } else {
+        const char* env = getenv("DSPEED_HIP_NO_FUSED");
+        ch->fused_on = !(env && env[0] == '1');
+    }
+
     HIP_TRY(hipGetDevice(&ch->device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, ch->device));
@@ -1439,6 +1525,10 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     if (ch->fir_ok && ch->fir_lds_bytes > 64 * 1024) {
         hipError_t e = (hipError_t)(ch->fir.store ? dsp_internal_set_fir_store_lds(ch->fir_lds_bytes) : dsp_internal_set_fir_mfma_lds(ch->fir_lds_bytes));
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(FIR kernel, %d): %s", ch->fir_lds_bytes, hipGetErrorString(e));
+    }
+    if (ch->cur_ok && ch->cur_lds_bytes > 64 * 1024) {
+        hipError_t e = (hipError_t)dsp_internal_set_current_lds(ch->cur_lds_bytes);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(current kernel, %d): %s", ch->cur_lds_bytes, hipGetErrorString(e));
     }
     if (ch->rows_ok && ch->rows_lds_bytes > 64 * 1024) {
         hipError_t e = (hipError_t)dsp_internal_set_rows_lds(ch->rows_lds_bytes);
@@ -1526,6 +1616,26 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
     auto at = [&](int k) -> void* {
         return k < 0 ? nullptr : (void*)((char*)io_ptrs[k] + (int64_t)ch->host.io[k].offset * elem_size(ch->host.io[k].dtype));
     };
+    if (ch->cur_ok && ch->fused_on && (reinterpret_cast<uintptr_t>(io_ptrs[ch->cio_wf]) & 15u) == 0) {
+        // persistent wavefronts, as many as a CU's LDS takes (at most 8 per CU): each keeps its scratch area for the groups of rows it walks
+        int per_cu = LDS_BYTES_PER_CU / ch->cur_lds_bytes;
+        if (per_cu > 8) per_cu = 8;
+        const int cap = ch->num_cu * (per_cu < 1 ? 1 : per_cu);
+        if (!ch->cur_scratch) {
+            HIP_TRY(hipMalloc((void**)&ch->cur_scratch, (size_t)cap * (size_t)ch->cur.scratch_per_wave * sizeof(float)));
+            ch->cur_blocks_cap = cap;
+        }
+        CurrentArgs A = ch->cur;
+        A.wf = io_ptrs[ch->cio_wf];
+        A.t0 = (const float*)at(ch->cio_t0);
+        for (int k = 0; k < 4; ++k) A.out[k] = at(ch->cio_out[k]);
+        A.scratch = ch->cur_scratch;
+        const int64_t groups = (n_wf + 63) / 64;
+        const int blocks = (int)(groups < ch->cur_blocks_cap ? groups : ch->cur_blocks_cap);
+        hipError_t e = (hipError_t)dsp_internal_launch_current(&A, n_wf, blocks, ch->cur_lds_bytes, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "current kernel launch failed: %s", hipGetErrorString(e));
+        return post_err(ch, stream);
+    }
     if (fir_applies(ch, io_ptrs)) {
         FirArgs A = ch->fir;
         A.wf = io_ptrs[ch->fio_wf];
@@ -1663,6 +1773,15 @@ int dsp_chain_destroy(dsp_chain* ch) {
 
 int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int* waves_per_block, int* blocks) {
     if (!ch) return fail(DSP_ERR_ARG, "null chain");
+    if (ch->cur_ok && ch->fused_on) {
+        int per_cu = LDS_BYTES_PER_CU / ch->cur_lds_bytes;
+        if (per_cu > 8) per_cu = 8;
+        const int64_t groups = (n_wf + 63) / 64, cap = (int64_t)ch->num_cu * (per_cu < 1 ? 1 : per_cu);
+        if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->cur_lds_bytes;
+        if (waves_per_block) *waves_per_block = 1;
+        if (blocks) *blocks = (int)(groups < cap ? groups : cap);
+        return DSP_OK;
+    }
     if (ch->fir_ok && ch->fused_on) {  // 8 wavefronts per 64 waveforms and kernel
         if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->fir_lds_bytes / 8;
         if (waves_per_block) *waves_per_block = 8;
@@ -1690,6 +1809,7 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
 }
 
 const char* dsp_chain_kernel_name(dsp_chain* ch) {
+    if (ch && ch->cur_ok && ch->fused_on) return dsp_internal_current_kernel_name();
     if (ch && ch->fir_ok && ch->fused_on) return ch->fir.store ? dsp_internal_fir_store_kernel_name() : dsp_internal_fir_mfma_kernel_name();
     if (ch && ch->rows_ok && ch->fused_on) return dsp_internal_rows_kernel_name();
     if (ch && ch->rr_ok && ch->fused_on && ch->variant != 1) return dsp_internal_energy_rr_kernel_name();
@@ -1715,7 +1835,7 @@ int dsp_chain_set_fused(dsp_chain* ch, int enable) {
     // 7 = classic (VM layout); anything else = default
     const int v = (enable >> 1) & 7;
     ch->variant = (v == 7 || !ch->rr_ok) ? 1 : 6;
-    return ((ch->fused_ok || ch->rr_ok || ch->rows_ok || ch->fir_ok) && ch->fused_on) ? 1 : 0;
+    return ((ch->fused_ok || ch->rr_ok || ch->rows_ok || ch->fir_ok || ch->cur_ok) && ch->fused_on) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ single processors

@@ -118,6 +118,30 @@ struct RowsArgs {
     int32_t pad_;
 };
 
+// arguments of the lane-per-waveform current-branch kernel (dsp_current.hip), filled by dsp_chain_execute when a program has that shape:
+//   LOAD -> WINDOWER -> AVG_CURRENT -> UPSAMPLER -> MOVING_WINDOW_MULTI (3 alternating windows) -> MIN_MAX -> STORE_SCALARs
+struct CurrentArgs {
+    const void* wf;          // float32 rows
+    int64_t wf_stride;
+    int32_t wf_offset, n_in; // first sample, samples per row (a multiple of 4)
+    const float* t0;         // window start column or null: t0_const
+    int64_t t0_stride;
+    float t0_const;
+    int32_t win_len;         // samples of the window
+    int32_t ac_lag;          // avg_current: int(length)
+    float ac_length;
+    int32_t n_c;             // samples of the current waveform: win_len - ac_lag
+    int32_t up_shift, up_half;  // upsampling factor 1 << up_shift, floor(factor / 2)
+    int32_t n_up;            // samples of the upsampled waveform (a multiple of 16)
+    int32_t ma_len;          // moving-window length (a multiple of 16, at most 112)
+    float ma_length;
+    int32_t all_nan;         // reserved
+    void* out[4];            // t_min, t_max, a_min, a_max columns (null: not requested)
+    int64_t out_stride[4];
+    float* scratch;          // scratch_per_wave floats per resident wavefront: the current waveform and the checkpoints of two passes
+    int64_t scratch_per_wave;
+};
+
 // arguments of the matrix-core FIR kernel (dsp_fir_mfma.hip): convolve_wf 'v' + numpy.amax of up to DSP_FIR_MAXK kernels on one waveform
 #define DSP_FIR_MAXK 4
 struct FirArgs {

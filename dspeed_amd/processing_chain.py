@@ -29,6 +29,7 @@ from __future__ import annotations
 
 import ast
 import json
+import queue
 import re
 import threading
 import time
@@ -371,7 +372,8 @@ class ProcessingChain:
         if stage_row_bytes and piece > self.stage_bytes // stage_row_bytes:
             cap = max(1, self.stage_bytes // stage_row_bytes)
             piece = -(-n // -(-n // cap))  # (equal pieces: no short last one)
-        n_slots = 2 if piece < n else 1
+        n_pieces = -(-n // piece)
+        n_slots = min(3, n_pieces)
         # piece buffers live as long as the chain (the reference pre-allocates its ProcChainVar buffers the same way,
         # processing_chain.py:259-269): build_dsp calls execute() once per file chunk with the same shapes
         key = (piece, n_slots, tuple((nm, a.shape[1:], a.dtype.str) for nm, a in host_in.items()),
@@ -402,6 +404,7 @@ class ProcessingChain:
         if self._copy_stream is None:
             self._copy_stream = Stream()
         s_in, s_c = self._copy_stream, self._stream
+        pieces = [(a, min(stop, a + piece)) for a in range(start, stop, piece)]
 
         def finish(a, b, staged):
             """piece [a, b): wait for its kernel and copies, report its DSPFatal with absolute rows, deliver the staged outputs"""
@@ -420,61 +423,89 @@ class ProcessingChain:
                 self._host_copy(col[a:b], buf[:b - a])
             self._timing["d2h"] += time.perf_counter() - t
 
-        # ---- pieces.  The rows of piece k + 1 are copied into their page-locked staging buffer and sent to the device (block by block: the
-        # transfer of a block runs while the next one is copied) while the device works on piece k; the results of piece k are waited for
-        # after that, so only the tail of the last block's transfer is exposed.  One piece's kernels are in flight at a time (a DSPFatal
-        # belongs to the piece being finished).
-        pieces = [(a, min(stop, a + piece)) for a in range(start, stop, piece)]
-        SUB = 4  # blocks of a piece's rows: copy one, send it, copy the next
+        # ---- the feeder: one host thread walks the pieces ahead of the device.  It copies a block of rows into the page-locked staging
+        # buffer of the piece's slot (split over the copy threads) and queues its transfer on the copy stream, block after block: the
+        # transfer of block j runs while block j + 1 is being copied, across piece boundaries, so the link sees one continuous stream of
+        # rows at min(host copy rate, PCIe rate).  Three slots: piece k is being processed, k + 1 is on the link, k + 2 is being copied.  A
+        # slot is handed back when its piece has been finished (its kernels read the slot's device buffers until then).
+        BLOCK_BYTES = 32 << 20
+        slot_free = [threading.Semaphore(1) for _ in range(n_slots)]
+        arrived: queue.Queue = queue.Queue()  # piece index (or the feeder's exception), in order
+        stop_feeding = threading.Event()
 
-        def stage_in(k):
-            a, b = pieces[k]
-            m, sl, st = b - a, slots[k % n_slots], stage[k % n_slots]
-            t = time.perf_counter()
-            bufs = dict(self._dev)
-            for name, arr in host_in.items():  # (slot k % 2 is free: piece k - 2 was finished before piece k - 1 was launched)
-                d = sl[name].view_rows(0, m)
-                step = -(-m // SUB) if (name not in in_place_in and arr.nbytes // max(len(arr), 1) * m >= (8 << 20)) else m
-                for r0 in range(0, m, step):
-                    r1 = min(m, r0 + step)
-                    if name in in_place_in:
-                        src = arr[a + r0:a + r1]
+        def feed():
+            try:
+                set_current = self.device
+                if set_current is not None:
+                    set_device(set_current)
+                for k, (a, b) in enumerate(pieces):
+                    while not slot_free[k % n_slots].acquire(timeout=0.05):
+                        if stop_feeding.is_set():
+                            return
+                    if stop_feeding.is_set():
+                        return
+                    m, sl, st = b - a, slots[k % n_slots], stage[k % n_slots]
+                    t = time.perf_counter()
+                    for name, arr in host_in.items():
+                        d = sl[name].view_rows(0, m)
+                        row_bytes_col = arr.nbytes // max(len(arr), 1)
+                        step = m if name in in_place_in else max(1, min(m, BLOCK_BYTES // max(row_bytes_col, 1)))
+                        for r0 in range(0, m, step):
+                            if stop_feeding.is_set():
+                                return
+                            r1 = min(m, r0 + step)
+                            if name in in_place_in:
+                                src = arr[a + r0:a + r1]
+                            else:
+                                src = st[name].array[r0:r1]
+                                self._host_copy(src, arr[a + r0:a + r1])
+                            _lib.check(lib.dsp_h2d_async(d.view_rows(r0, r1).ptr, src.ctypes.data, src.nbytes, s_in.ptr), what="h2d_async")
+                    ev_in[k % n_slots].record(s_in)
+                    self._timing["h2d"] += time.perf_counter() - t
+                    arrived.put(k)
+            except BaseException as e:  # noqa: BLE001 -- re-raised by the consumer
+                arrived.put(e)
+
+        feeder = threading.Thread(target=feed, name="dspeed-feeder", daemon=True)
+        feeder.start()
+        completed = False
+        try:
+            for k, (a, b) in enumerate(pieces):
+                got = arrived.get()
+                if isinstance(got, BaseException):
+                    raise got
+                m, sl, st = b - a, slots[k % n_slots], stage[k % n_slots]
+                bufs = dict(self._dev)
+                for name in host_in:
+                    bufs[name] = sl[name].view_rows(0, m)
+                for name, first in same_col.items():
+                    bufs[name] = bufs[first]
+                for name, col in dev_in.items():
+                    bufs[name] = col.view_rows(a, b)
+                for name, col in dev_out.items():
+                    bufs[name] = col.view_rows(a, b)
+                for name in host_out:
+                    bufs[name] = sl[name].view_rows(0, m)
+                s_c.wait_event(ev_in[k % n_slots])
+                staged = []
+                self._run_aux(bufs, m, s_c)
+                self._chain.execute(bufs, m, s_c)
+                for name, (col, length, direct) in host_out.items():
+                    d = bufs[name]
+                    if name in in_place_out:
+                        dst = col[a:b]
                     else:
-                        src = st[name].array[r0:r1]
-                        self._host_copy(src, arr[a + r0:a + r1])
-                    _lib.check(lib.dsp_h2d_async(d.view_rows(r0, r1).ptr, src.ctypes.data, src.nbytes, s_in.ptr), what="h2d_async")
-                bufs[name] = d
-            for name, first in same_col.items():
-                bufs[name] = bufs[first]
-            ev_in[k % n_slots].record(s_in)
-            for name, col in dev_in.items():
-                bufs[name] = col.view_rows(a, b)
-            for name, col in dev_out.items():
-                bufs[name] = col.view_rows(a, b)
-            self._timing["h2d"] += time.perf_counter() - t
-            return bufs
-
-        nxt = stage_in(0)
-        for k, (a, b) in enumerate(pieces):
-            m, sl, st = b - a, slots[k % n_slots], stage[k % n_slots]
-            bufs = nxt
-            s_c.wait_event(ev_in[k % n_slots])
-            staged = []
-            for name in host_out:
-                bufs[name] = sl[name].view_rows(0, m)
-            self._run_aux(bufs, m, s_c)
-            self._chain.execute(bufs, m, s_c)
-            for name, (col, length, direct) in host_out.items():
-                d = bufs[name]
-                if name in in_place_out:
-                    dst = col[a:b]
-                else:
-                    dst = st[name].array[:m]
-                    staged.append((col, dst))
-                _lib.check(lib.dsp_d2h_async(dst.ctypes.data, d.ptr, d.nbytes, s_c.ptr), what="d2h_async")
-            if k + 1 < len(pieces):
-                nxt = stage_in(k + 1)
-            finish(a, b, staged)
+                        dst = st[name].array[:m]
+                        staged.append((col, dst))
+                    _lib.check(lib.dsp_d2h_async(dst.ctypes.data, d.ptr, d.nbytes, s_c.ptr), what="d2h_async")
+                finish(a, b, staged)
+                slot_free[k % n_slots].release()
+            completed = True
+        finally:
+            stop_feeding.set()
+            feeder.join()
+            if not completed:  # (a failed pass leaves transfers of later pieces behind: they must not meet the next call's copies)
+                s_in.sync()
 
     def _run_aux(self, bufs: dict, m: int, stream) -> None:
         """linear_slope_fit of the recipe that can run on the rows of the batch, one waveform per lane, ahead of the chain on its stream:
@@ -1670,6 +1701,37 @@ def _extract_stages(b: _Builder, steps, out_pars, n_rows, ft):
         for o in outs:
             o.kind = "scalar"
         steps = [x for x in steps if x is not st and not any(x is u for u in users)]
+
+    # --- the current branch (windower -> avg_current -> upsampler -> moving_window_multi -> min_max, the A/E part of the Ge recipes) on
+    # rows: three moving averages that alternate direction are float32 recurrences over 4784 samples each -- 30 % of the program, which
+    # replays their rounding twice per pass.  dsp_current.hip gives every waveform a lane and runs them as written (bit-exact), keeping
+    # checkpoints instead of the intermediate waveforms.  Needs the window's source as rows in HBM and its start as a column there.
+    def only_user(v, fn_name):
+        users = [x for x in steps if any(base_of(a) is v for a, r in zip(x[1], _roles(x[0])) if r not in "WS")]
+        return users[0] if len(users) == 1 and users[0][0] == fn_name and users[0][1][0] is v and v.name not in out_names else None
+
+    for st in list(steps):
+        if st[0] != "windower" or not any(st is x for x in steps):
+            continue
+        src, start, w_le = st[1]
+        if not (isinstance(src, Var) and row_input(src) and np.dtype(src.dtype) == np.dtype(np.float32) and plain_scalar(start) and isinstance(w_le, Var)):
+            continue
+        chain_steps, v = [st], w_le
+        for fn_name in ("avg_current", "upsampler", "moving_window_multi", "min_max"):
+            nxt = only_user(v, fn_name)
+            if nxt is None:
+                break
+            chain_steps.append(nxt)
+            v = nxt[1][-1]
+        if len(chain_steps) != 5:
+            continue
+        outs = [o for o in chain_steps[-1][1][1:5]]
+        if not all(isinstance(o, Var) for o in outs):
+            continue
+        build(chain_steps, outs, f"current branch of {src.name} on rows")
+        for o in outs:
+            o.kind = "scalar"
+        steps = [x for x in steps if not any(x is c for c in chain_steps)]
 
     # what the stages' results replaced is not computed any more: producers of staged variables, and whatever only fed them
     staged = {id(v) for v in b.vars.values() if isinstance(v, Var) and getattr(v, "ext_key", None) is not None and getattr(v, "aux_io", None) is None}
