@@ -215,6 +215,7 @@ static bool match_current_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, con
     A.wf_stride = w.row_stride;
     A.wf_offset = w.offset;
     A.n_in = w.len;
+    A.scan_rows = (ld.ip[2] & 1) ? 0 : 1;
     if (wi.sp[0].kind == DSP_ARG_INPUT && io[wi.sp[0].index].dtype == DSP_F32) {
         ch->cio_t0 = wi.sp[0].index;
         A.t0_stride = io[ch->cio_t0].row_stride;

@@ -135,7 +135,7 @@ struct CurrentArgs {
     int32_t n_up;            // samples of the upsampled waveform (a multiple of 16)
     int32_t ma_len;          // moving-window length (a multiple of 16, at most 112)
     float ma_length;
-    int32_t all_nan;         // reserved
+    int32_t scan_rows;       // 1: the kernel screens the whole rows for NaN; 0: a NaN anywhere means NaN everywhere (DSP_OP_LOAD ip[2])
     void* out[4];            // t_min, t_max, a_min, a_max columns (null: not requested)
     int64_t out_stride[4];
     float* scratch;          // scratch_per_wave floats per resident wavefront: the current waveform and the checkpoints of two passes

@@ -232,6 +232,7 @@ class ProcessingChain:
         self._buffer_len = buffer_len
         self._chain = None
         self._stream = None
+        self._lanes = []          # [0] = the chain itself; further lanes for pieces of a batch that run at the same time (_lane)
         self._dev = {}
         self._tb_in = None
         self._tb_out = None
@@ -277,6 +278,24 @@ class ProcessingChain:
                 st["chain"] = Chain(st["program"], f"processing_chain stage {k} ({st['what']})", self.loop_dtype)
                 st["chain"].set_async_check(True)
                 st["dev"] = {name: DeviceArray.from_numpy(arr) for name, arr in st["consts"].items()}
+            self._lanes = [SimpleNamespace(stream=self._stream, chain=self._chain, stage_chains=[st["chain"] for st in self._stages],
+                                           stage_bufs=[st["bufs"] for st in self._stages], aux_bufs=self._aux_bufs)]
+
+    def _lane(self, k: int):
+        """Lane k of the chain: its own handles (error words), compute stream and intermediate buffers, so that the kernels of two pieces of
+        a batch can be on the device at the same time.  Lane 0 is the chain itself; the others are made when a batch first needs them."""
+        self._ensure()
+        while len(self._lanes) <= k:
+            ch = Chain(self._program, f"processing_chain (lane {len(self._lanes)})", self.loop_dtype)
+            ch.set_async_check(True)
+            stage_chains = []
+            for j, st in enumerate(self._stages):
+                c = Chain(st["program"], f"processing_chain stage {j} ({st['what']}, lane {len(self._lanes)})", self.loop_dtype)
+                c.set_async_check(True)
+                stage_chains.append(c)
+            self._lanes.append(SimpleNamespace(stream=Stream(), chain=ch, stage_chains=stage_chains, stage_bufs=[{} for _ in self._stages],
+                                               aux_bufs={}))
+        return self._lanes[k]
 
     #: bytes of host-resident I/O per pipelined piece, two pieces in flight.  Tens of MB are enough for the PCIe transfers; the size is set
     #: by the kernels that run one waveform per lane (the fits of a whole recipe take 4 ms whether a piece has 4 000 rows or 60 000:
@@ -290,8 +309,11 @@ class ProcessingChain:
     #: without a host copy, for buffers that live as long as the chain (build_dsp-style refilled tables); DESIGN.md section 5 on why it
     #: is not the default.  Environment DSPEED_HIP_PIN_IN_PLACE=1 switches it on globally.
     pin_in_place = os.environ.get("DSPEED_HIP_PIN_IN_PLACE", "0") == "1"
-    #: host threads that move rows between NumPy columns and the staging buffers
-    copy_threads = 8
+    #: host threads that move rows between NumPy columns and the staging buffers (tools/host_copy_rate.py: 8 threads move 79 GB/s in 32 MiB
+    #: blocks, 12 threads 145 GB/s in 256 MiB blocks; the link takes 53)
+    copy_threads = 12
+    #: pieces of a host-resident batch whose kernels may be on the device at the same time (each on its own stream and chain handles)
+    pieces_in_flight = 2
 
     def _host_copy(self, dst: np.ndarray, src: np.ndarray) -> None:
         """dst[...] = src for two equally shaped row blocks, split over the copy threads (NumPy releases the GIL in the copy)."""
@@ -373,7 +395,8 @@ class ProcessingChain:
             cap = max(1, self.stage_bytes // stage_row_bytes)
             piece = -(-n // -(-n // cap))  # (equal pieces: no short last one)
         n_pieces = -(-n // piece)
-        n_slots = min(3, n_pieces)
+        n_lanes = min(self.pieces_in_flight, n_pieces)  # pieces whose kernels are on the device at the same time
+        n_slots = min(n_lanes + 2, n_pieces)            # ... + the one on the link + the one being copied
         # piece buffers live as long as the chain (the reference pre-allocates its ProcChainVar buffers the same way,
         # processing_chain.py:259-269): build_dsp calls execute() once per file chunk with the same shapes
         key = (piece, n_slots, tuple((nm, a.shape[1:], a.dtype.str) for nm, a in host_in.items()),
@@ -403,16 +426,17 @@ class ProcessingChain:
         stage = self._stage
         if self._copy_stream is None:
             self._copy_stream = Stream()
-        s_in, s_c = self._copy_stream, self._stream
+        s_in = self._copy_stream
+        lanes = [self._lane(j) for j in range(n_lanes)]
         pieces = [(a, min(stop, a + piece)) for a in range(start, stop, piece)]
 
-        def finish(a, b, staged):
+        def finish(a, b, staged, lane):
             """piece [a, b): wait for its kernel and copies, report its DSPFatal with absolute rows, deliver the staged outputs"""
             t = time.perf_counter()
             try:
-                for stg in self._stages:
-                    stg["chain"].check(s_c, row_offset=a)
-                self._chain.check(s_c, row_offset=a)
+                for ch in lane.stage_chains:
+                    ch.check(lane.stream, row_offset=a)
+                lane.chain.check(lane.stream, row_offset=a)
             except DSPFatal as e:  # the reference annotates and re-raises (processing_chain.py:1154-1159)
                 if e.wf_range is None:
                     e.wf_range = range(a, b)
@@ -426,9 +450,12 @@ class ProcessingChain:
         # ---- the feeder: one host thread walks the pieces ahead of the device.  It copies a block of rows into the page-locked staging
         # buffer of the piece's slot (split over the copy threads) and queues its transfer on the copy stream, block after block: the
         # transfer of block j runs while block j + 1 is being copied, across piece boundaries, so the link sees one continuous stream of
-        # rows at min(host copy rate, PCIe rate).  Three slots: piece k is being processed, k + 1 is on the link, k + 2 is being copied.  A
+        # rows at min(host copy rate, PCIe rate).  Slots: the pieces being processed (one per lane), one on the link, one being copied.  A
         # slot is handed back when its piece has been finished (its kernels read the slot's device buffers until then).
-        BLOCK_BYTES = 32 << 20
+        # Two lanes: the kernels of piece k + 1 are queued (on their own stream, with their own chain handles) while piece k still runs --
+        # the kernels that give every waveform a lane fill one wavefront per compute unit for a piece of 16 k rows and take a millisecond
+        # whatever the piece's size; side by side with the other piece's kernels that time is not lost, and no launch gap opens between pieces.
+        BLOCK_BYTES = 64 << 20
         slot_free = [threading.Semaphore(1) for _ in range(n_slots)]
         arrived: queue.Queue = queue.Queue()  # piece index (or the feeder's exception), in order
         stop_feeding = threading.Event()
@@ -469,11 +496,18 @@ class ProcessingChain:
         feeder = threading.Thread(target=feed, name="dspeed-feeder", daemon=True)
         feeder.start()
         completed = False
+        in_flight = []  # (piece index, a, b, staged outputs, lane), oldest first
         try:
             for k, (a, b) in enumerate(pieces):
                 got = arrived.get()
                 if isinstance(got, BaseException):
                     raise got
+                if len(in_flight) == n_lanes:  # the lane this piece takes is the oldest one's: finish that first
+                    k0, a0, b0, staged0, lane0 = in_flight.pop(0)
+                    finish(a0, b0, staged0, lane0)
+                    slot_free[k0 % n_slots].release()
+                lane = lanes[k % n_lanes]
+                s_c = lane.stream
                 m, sl, st = b - a, slots[k % n_slots], stage[k % n_slots]
                 bufs = dict(self._dev)
                 for name in host_in:
@@ -488,8 +522,8 @@ class ProcessingChain:
                     bufs[name] = sl[name].view_rows(0, m)
                 s_c.wait_event(ev_in[k % n_slots])
                 staged = []
-                self._run_aux(bufs, m, s_c)
-                self._chain.execute(bufs, m, s_c)
+                self._run_aux(bufs, m, s_c, lane)
+                lane.chain.execute(bufs, m, s_c)
                 for name, (col, length, direct) in host_out.items():
                     d = bufs[name]
                     if name in in_place_out:
@@ -498,25 +532,36 @@ class ProcessingChain:
                         dst = st[name].array[:m]
                         staged.append((col, dst))
                     _lib.check(lib.dsp_d2h_async(dst.ctypes.data, d.ptr, d.nbytes, s_c.ptr), what="d2h_async")
-                finish(a, b, staged)
-                slot_free[k % n_slots].release()
+                in_flight.append((k, a, b, staged, lane))
+            while in_flight:
+                k0, a0, b0, staged0, lane0 = in_flight.pop(0)
+                finish(a0, b0, staged0, lane0)
+                slot_free[k0 % n_slots].release()
             completed = True
         finally:
             stop_feeding.set()
             feeder.join()
-            if not completed:  # (a failed pass leaves transfers of later pieces behind: they must not meet the next call's copies)
+            if not completed:  # (a failed pass leaves transfers and kernels of later pieces behind: they must not meet the next call's)
                 s_in.sync()
+                for ln in lanes:
+                    ln.stream.sync()
+                    for ch in (*ln.stage_chains, ln.chain):  # their error words belong to the abandoned pieces
+                        try:
+                            ch.check(ln.stream)
+                        except DSPFatal:
+                            pass
 
-    def _run_aux(self, bufs: dict, m: int, stream) -> None:
+    def _run_aux(self, bufs: dict, m: int, stream, lane=None) -> None:
         """linear_slope_fit of the recipe that can run on the rows of the batch, one waveform per lane, ahead of the chain on its stream:
         fills the columns the chain reads as inputs."""
         lib = _lib.lib()
+        lane = lane if lane is not None else self._lane(0)
         ft_code, isz = dtype_code(self.loop_dtype), self.loop_dtype.itemsize
         for gi, g in enumerate(self._aux):
             n_cols = len(g["names"])
-            out = self._aux_bufs.get(gi)
+            out = lane.aux_bufs.get(gi)
             if out is None or out.shape[1] < m:
-                out = self._aux_bufs[gi] = DeviceArray((n_cols, m), self.loop_dtype)
+                out = lane.aux_bufs[gi] = DeviceArray((n_cols, m), self.loop_dtype)
             wf = bufs[g["wf"]]
             wf_ptr = (wf.ptr if isinstance(wf, DeviceArray) else int(wf)) + g["lo"] * g["itemsize"]
             sub = bufs[g["sub"]] if g["sub"] is not None else None
@@ -527,17 +572,18 @@ class ProcessingChain:
                                                      stream.ptr), what="linear_slope_fit_rows")
             for j, name in enumerate(g["names"]):
                 bufs[name] = out.ptr + j * m * isz
-        for st in self._stages:  # in launch order: a stage may read what an earlier one wrote
+        for j, st in enumerate(self._stages):  # in launch order: a stage may read what an earlier one wrote
             sb = dict(bufs)
             sb.update(st["dev"])
             for io_name, key in st["alias"].items():
                 sb[io_name] = bufs[key]
+            held = lane.stage_bufs[j]
             for out_name, key, length in st["outs"]:
-                buf = st["bufs"].get(key)
+                buf = held.get(key)
                 if buf is None or buf.shape[0] < m:
-                    buf = st["bufs"][key] = DeviceArray((m,) if length is None else (m, length), self.loop_dtype)
+                    buf = held[key] = DeviceArray((m,) if length is None else (m, length), self.loop_dtype)
                 sb[out_name] = bufs[key] = buf
-            st["chain"].execute(sb, m, stream)
+            lane.stage_chains[j].execute(sb, m, stream)
         for io_name, key in self._ext_alias.items():
             bufs[io_name] = bufs[key]
 
@@ -1580,6 +1626,9 @@ def _extract_stages(b: _Builder, steps, out_pars, n_rows, ft):
                "outs": [(f"out:{o.name}", f"in:{o.name}", o.length if o.kind == "wf" else None) for o in outs], "chain": None, "bufs": {}}
         stages.append(rec)
         for o in outs:  # from here on the variable is a row / column in HBM
+            if o.kind == "wf":  # pole_zero returns an all-NaN waveform for an input with a NaN and DSPFatal for a NaN of its own making
+                made_by = producer_of(o)
+                o.nan_uniform = made_by is not None and made_by[0] == "pole_zero"
             o.ext_key, o.is_input, o.slot, o.sreg = f"in:{o.name}", True, None, None
             if o.kind == "wf":
                 o.ext_len, o.offset, o.dtype = o.length, 0, np.dtype(np.float32)
@@ -1984,7 +2033,10 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
                 io = p.add_io(f"in:{v.name}", _lib.IO_WF_IN, col.dtype, v.length, v.offset, full_len)
                 in_bind[f"in:{v.name}"] = v
             v.slot = new_slot(v.length)
-            p.add_op(_lib.OP_LOAD, dst=v.slot, io=io, ip=whole_nan_rule.get(v.name, ()))
+            screens = whole_nan_rule.get(v.name, ())
+            if getattr(v, "nan_uniform", False):  # rows a stage wrote with pole_zero's rule: all NaN or free of NaN (DSP_OP_LOAD ip[2])
+                screens = (*(screens or (0, 0)), 1)
+            p.add_op(_lib.OP_LOAD, dst=v.slot, io=io, ip=screens)
         return v
 
     def scalar_operand(a, args, integer=False, what=""):

@@ -151,7 +151,9 @@ typedef struct dsp_scalar_arg {
 #define DSP_OP_LOAD 1          /* dst <- io (waveform input; int16/uint16 rows are widened like NumPy's ufunc casting, processing_chain.py:1565-1572);
                                   * ip[0] / ip[1] > 0: the binding is a slice of a longer waveform whose first consumer is a processor with the
                                   * "NaN anywhere -> NaN waveform" rule applied to the WHOLE waveform (bl_subtract.py:41-44): the ip[0] samples
-                                  * before and the ip[1] samples after the slice are screened too, a NaN there marks the slot NaN */
+                                  * before and the ip[1] samples after the slice are screened too, a NaN there marks the slot NaN;
+                                  * ip[2] bit 0: a promise about the rows -- a NaN anywhere in a row means every sample of it is NaN (what
+                                  * pole_zero writes): a kernel that reads only part of a row need not screen the rest of it */
 #define DSP_OP_STORE 2         /* io <- src */
 #define DSP_OP_STORE_SCALAR 3  /* io <- sreg[ip[0]] */
 #define DSP_OP_BL_SUBTRACT 4   /* bl_subtract.py:11-46      dst <- src - sp[0]; ip[0] = 1: numpy.subtract(w, scalar), NaN samples stay single */

@@ -210,11 +210,20 @@ def test_index_outputs_are_bit_exact_on_the_devices_own_waveforms():
     exact(g["tp_aoe_max"], ta, "tp_aoe_max")
     exact(g["A_max"], amax_, "A_max")
     exact(g["tp_aoe_samp"], to_ns(tp0 + ta / F(16)), "tp_aoe_samp")
-    same_as_production(g, ["cuspEmax", "cuspEftp", "tp_aoe_max", "A_max", "tp_aoe_samp"])
-    # window, difference quotient and repetition keep the samples as they are; the three moving averages are a filter (1e-6 of the peak)
+    same_as_production(g, ["cuspEmax", "cuspEftp"])
+    # window, difference quotient and repetition keep the samples as they are; the three moving averages are a filter: inside a program
+    # (the instrumented one, which keeps curr_av) they replay the reference's rounding, 1e-6 of the peak ...
     up = oracle.upsampler(oracle.avg_current(oracle.windower(g["wf_pz"], tp0, 301)[0], 1)[0], 16, 4784)[0]
     av = oracle.moving_window_multi(up, 48, 3, 0)[0]
     assert np.max(np.nanmax(np.abs(g["curr_av"] - av), axis=1) / np.nanmax(np.abs(av), axis=1)) <= 1e-6
+    # ... and the production recipe runs the branch on the lane-per-waveform kernel (dsp_current.hip), which walks the reference's loops
+    # themselves: its outputs are the ORACLE's on the device's pole-zero rows and start time, bit for bit
+    _, ta_x, _, amax_x, _ = oracle.min_max(av)
+    exact(prod["tp_aoe_max"], ta_x, "tp_aoe_max (production)")
+    exact(prod["A_max"], amax_x, "A_max (production)")
+    exact(prod["tp_aoe_samp"], to_ns(tp0 + ta_x / F(16)), "tp_aoe_samp (production)")
+    assert "dsp_current_kernel" in [st["chain"].kernel_name for st in chain_p._stages]
+    seen.update({"tp_aoe_max": True, "A_max": True, "tp_aoe_samp": True})
     cusp_dev = g["wf_cusp"]
     assert all(seen.get(k) for k in recipes.ICPC["outputs"] if k not in ("tp_min", "tp_max", "wf_min", "wf_max", "bl_mean", "bl_slope",
                                                                          "bl_intercept", "pz_mean", "pz_std"))
@@ -359,7 +368,7 @@ def test_stage_buffers_are_bounded_and_pieces_give_the_same_results():
     wf = wf.astype(np.uint16)
     tb = {"waveform": WaveformInput(wf, 16.0, 48000.0), "baseline": bl}
     chain, _, out = build_processing_chain(recipes.ICPC, tb)
-    assert len(chain._stages) == 5
+    assert len(chain._stages) == 6
     chain.execute()
     ref = {k: np.array(v) for k, v in out.items()}
     per_row = sum(4 * (1 if ln is None else ln) for st in chain._stages for _o, _k, ln in st["outs"])
@@ -378,6 +387,7 @@ def test_stage_buffers_are_bounded_and_pieces_give_the_same_results():
     chain2.link(d_in, d_out)
     chain2.execute()
     assert max(len(b) for st in chain2._stages for b in st["bufs"].values()) == 38
+    assert len(chain2._lanes) == 2 and max(len(b) for held in chain2._lanes[1].stage_bufs for b in held.values()) == 38  # two pieces in flight
     for k in ref:
         assert np.array_equal(d_out[k].to_numpy(), ref[k], equal_nan=True), k
 

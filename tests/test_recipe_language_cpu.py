@@ -95,8 +95,14 @@ def test_long_filters_of_the_ge_recipe_run_ahead_of_the_program():
                     # reads the same rows and goes along), then the short trapezoid -> threshold walk in the shape of the rows kernel;
                     # both hand on sample indices (no unit conversion before the stores)
                     [_lib.OP_LOAD, _lib.OP_MIN_MAX, _lib.OP_TIME_POINT_THRESH] + [_lib.OP_STORE_SCALAR] * 5,
-                    [_lib.OP_LOAD, _lib.OP_TRAP_REDUCE, _lib.OP_STORE_SCALAR]]
-    pz, t0f, cusp, t0v, atrap = chain._stages
+                    [_lib.OP_LOAD, _lib.OP_TRAP_REDUCE, _lib.OP_STORE_SCALAR],
+                    # the current branch in the shape of dsp_current.hip: window at tp_0_est (a column by now) of the pole-zero rows
+                    [_lib.OP_LOAD, _lib.OP_WINDOWER, _lib.OP_AVG_CURRENT, _lib.OP_UPSAMPLER, _lib.OP_MOVING_WINDOW_MULTI, _lib.OP_MIN_MAX]
+                    + [_lib.OP_STORE_SCALAR] * 4]
+    pz, t0f, cusp, t0v, atrap, current = chain._stages
+    assert [o[1] for o in current["outs"]] == ["in:aoe_t_min", "in:tp_aoe_max", "in:A_min", "in:A_max"]
+    assert current["alias"] == {"in:wf_pz": "in:wf_pz", "in:tp_0_est": "in:tp_0_est"}
+    assert not {_lib.OP_WINDOWER, _lib.OP_UPSAMPLER, _lib.OP_MOVING_WINDOW_MULTI} & set(opcodes), "the program no longer runs the moving averages"
     assert [o[1] for o in t0v["outs"]] == ["in:conv_tmin", "in:tp_start", "in:conv_min", "in:conv_max", "in:tp_0_est"]
     assert atrap["alias"] == {"in:wf_pz": "in:wf_pz", "in:bl_std": "aux:0:1", "in:tp_start": "in:tp_start"} and atrap["outs"] == [("out:tp_0_atrap", "in:tp_0_atrap", None)]
     assert _lib.OP_TRAP_REDUCE in opcodes and "in:wf_t0_filter" not in [io[0] for io in P.io], "the program no longer touches the t0-filtered waveform"

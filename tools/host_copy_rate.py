@@ -25,7 +25,7 @@ for block_mib in (32, 256):
         step = -(-rows // threads)
 
         def copy(base):
-            list(pool.map(lambda a: np.copyto(dst[a:a + step], src[base + a:base + a + step]), range(0, rows, step)))
+            list(pool.map(lambda a: np.copyto(dst[a:min(rows, a + step)], src[base + a:base + min(rows, a + step)]), range(0, rows, step)))
 
         copy(0)
         t = time.perf_counter()
