@@ -394,7 +394,20 @@ class ProcessingChain:
         if stage_row_bytes and piece > self.stage_bytes // stage_row_bytes:
             cap = max(1, self.stage_bytes // stage_row_bytes)
             piece = -(-n // -(-n // cap))  # (equal pieces: no short last one)
-        n_pieces = -(-n // piece)
+        # Host-resident batches of more than two pieces start with a quarter and a half piece and end with a half piece: the device idles
+        # while the first piece crosses the link and the link idles while the last piece is processed, so both are made short.
+        ramp = row_bytes > 0 and n > 2 * piece and piece >= 4
+        if ramp:
+            sizes = [piece // 4, piece // 2]
+            tail = piece // 2
+            body = n - sum(sizes) - tail
+            left = body % piece
+            if left <= piece - tail:  # (a short piece costs the device as much as a long one: what is left over joins the last piece)
+                left, tail = 0, tail + left
+            sizes += [piece] * (body // piece) + ([left] if left else []) + [tail]
+        else:
+            sizes = [piece] * (n // piece) + ([n % piece] if n % piece else [])
+        n_pieces = len(sizes)
         n_lanes = min(self.pieces_in_flight, n_pieces)  # pieces whose kernels are on the device at the same time
         n_slots = min(n_lanes + 2, n_pieces)            # ... + the one on the link + the one being copied
         # piece buffers live as long as the chain (the reference pre-allocates its ProcChainVar buffers the same way,
@@ -428,7 +441,10 @@ class ProcessingChain:
             self._copy_stream = Stream()
         s_in = self._copy_stream
         lanes = [self._lane(j) for j in range(n_lanes)]
-        pieces = [(a, min(stop, a + piece)) for a in range(start, stop, piece)]
+        pieces, at = [], start
+        for size in sizes:
+            pieces.append((at, at + size))
+            at += size
 
         def finish(a, b, staged, lane):
             """piece [a, b): wait for its kernel and copies, report its DSPFatal with absolute rows, deliver the staged outputs"""

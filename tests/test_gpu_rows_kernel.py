@@ -2,6 +2,8 @@
 time_point_thresh + Haar DWT (BASELINE.json configs[4]).  Every lane walks its waveform in the reference's own operation order, so EVERY
 output -- extremes, their indices, the threshold time point, the wavelet coefficients -- is bit-identical to the oracle run processor by
 processor (reference pole_zero.py:24-198, trap_filters.py:12-227, min_max.py:11-82, time_point_thresh.py:12-92, dwt.py:13-81)."""
+import zlib
+
 import numpy as np
 import pytest
 
@@ -112,7 +114,7 @@ def test_agrees_with_the_waveform_vm_within_its_tolerance():
                                   ("trap_filter", 40, 13), ("asym_trap_filter", 8, 0, 136)])
 @pytest.mark.parametrize("pz", [DPZ, ("pole_zero", 1716.28)])
 def test_other_trapezoids_and_pole_zero(trap, pz):
-    rng = np.random.default_rng(hash((trap, pz[0])) % 2**32)
+    rng = np.random.default_rng(zlib.crc32(repr((trap, pz[0])).encode()))  # (the same rows in every process: str hashes are salted)
     wf, bl = _synth(rng, 70, 2048, dtype=np.float32, bl=(9000, 11000))
     thr = rng.uniform(5.0, 200.0, 70).astype(np.float32)
     rec = _recipe(pz, trap, tpt_args=["thr", "tp_max", 0], bl=True)

@@ -15,5 +15,10 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS
     --output-format csv -d "$OUT/pmc_sq2" -- $BENCH > /dev/null 2> "$OUT/pmc_sq2.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > /dev/null 2> "$OUT/pmc_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH > /dev/null 2> "$OUT/pmc_write.err"
+# the shard a rank of a multi-GPU run processes (1 250 000 rows): HBM traffic of its launches
+SHARD="python3 bench.py --no-cpu --rows 1250000 --steps 10 --warmup 5"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_shard" -- $SHARD > /dev/null 2> "$OUT/pmc_fetch_shard.err"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_shard" -- $SHARD > /dev/null 2> "$OUT/pmc_write_shard.err"
+$SHARD > "$OUT/bench_shard.json" 2> "$OUT/bench_shard.err"
 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 echo "profile $TAG done"; cat "$OUT/bench_default.json"

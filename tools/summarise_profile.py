@@ -64,10 +64,35 @@ if "FETCH_SIZE" in pmc:
     alg = rows * (wf_len * 4 + 12)
     summary.append(f"* HBM traffic per launch (PMC, separate passes): FETCH_SIZE x2 = {fetch / 1e9:.3f} GB, WRITE_SIZE = {write / 1e6:.2f} MB; "
                    f"algorithmic {alg / 1e9:.3f} GB -> traffic / algorithmic = {(fetch + write) / alg:.3f}")
+    geometry = {k: bench["config"][k] for k in ("lds_bytes_per_wave", "waves_per_block", "blocks")}
     json.dump({"kernel": kernel, "rows": rows, "wf_len": wf_len, "hbm_bytes_per_launch": fetch + write,
                "kernel_source_hash": bench["config"].get("kernel_source_hash"),  # bench.py quotes the figure only for these sources
+               "geometry": geometry,                                             # ... and this launch geometry
                "source": f"profiles/{tag}_pmc.json: FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (rocprofv3 --pmc, separate passes)"},
               open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+    # the shard of a multi-GPU run (1 250 000 rows per rank): its own PMC passes, its own record
+    shard = {}
+    for d in ("pmc_fetch_shard", "pmc_write_shard"):
+        for f in newest(f"{src}/{d}/*/*_counter_collection.csv"):
+            acc = {}
+            for r in csv.DictReader(open(f)):
+                if kernel in r["Kernel_Name"]:
+                    acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            for k, v in acc.items():
+                shard[k] = sum(v) / len(v)
+    shard_bench = f"{src}/bench_shard.json"
+    if "FETCH_SIZE" in shard and os.path.exists(shard_bench) and os.path.getsize(shard_bench):
+        sb = json.load(open(shard_bench))
+        srows = sb["config"]["rows_per_gpu"]
+        sbytes = shard["FETCH_SIZE"] * 1024 * 2 + shard.get("WRITE_SIZE", 0.0) * 1024
+        salg = srows * (wf_len * 4 + 12)
+        summary.append(f"* the same for the {srows}-row shard of a multi-GPU run (`--rows {srows}`): {sbytes / 1e9:.3f} GB per launch, "
+                       f"traffic / algorithmic = {sbytes / salg:.3f}")
+        json.dump({"kernel": kernel, "rows": srows, "wf_len": wf_len, "hbm_bytes_per_launch": sbytes,
+                   "kernel_source_hash": sb["config"].get("kernel_source_hash"),
+                   "geometry": {k: sb["config"][k] for k in ("lds_bytes_per_wave", "waves_per_block", "blocks")},
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of `python bench.py --no-cpu --rows %d` (separate passes): FETCH_SIZE*1024*2 + WRITE_SIZE*1024" % srows},
+                  open(f"profiles/{tag}_shard_pmc_traffic.json", "w"), indent=1)
 n = 1e6 * rows / 1e6
 per = lambda k: pmc.get(k, float("nan")) / rows  # noqa: E731
 summary += ["", "Per waveform (= per wavefront-iteration), SQ counters in quad-cycles:", "",
