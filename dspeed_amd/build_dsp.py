@@ -315,6 +315,10 @@ class _ChunkWorker:
                                                            device=device)
         return self.mask
 
+    @property
+    def attrs(self):
+        return self.chain.output_attrs if self.chain is not None else {}
+
     def process(self, i_entry, n, columns):
         chain = self.chain
         _set_buffer_len(chain, self.buffer_len, columns, self.mask, n)
@@ -347,6 +351,7 @@ def _run_chunks(source, recipe, db_block, outputs, rows: RowSelection, buffer_le
             return 0
         first_cols = lgdo_io.table_columns(first)
         masks = team.run([lambda dev, w=w: w.build(first_cols, dev) for w in workers])
+        deliver.attrs.update(workers[0].attrs)
         if hasattr(source, "reset_field_mask"):
             source.reset_field_mask(masks[0])
         chunks = lgdo_io.ChunkReader(source, fields=set(masks[0]))
@@ -358,6 +363,7 @@ def _run_chunks(source, recipe, db_block, outputs, rows: RowSelection, buffer_le
         if n == 0:
             return 0
         team.run([lambda dev, w=w: w.build(cols, dev) for w in workers])
+        deliver.attrs.update(workers[0].attrs)
         bounds = shard_bounds(n, min(len(workers), n)) if team.parallel else [(0, n)]
         chunks = [(lo, hi - lo, {k: _select(v, slice(lo, hi)) for k, v in cols.items()}) for lo, hi in bounds]
     done = 0
@@ -540,12 +546,14 @@ class _MemorySink:
     """results stay in memory: {table: {column: ndarray}} (+ per-row lengths of variable-length columns)"""
 
     def __init__(self):
-        self.tables, self.lengths = {}, {}
+        self.tables, self.lengths, self.attrs = {}, {}, {}
 
-    def table_done(self, name, columns, lengths=None):
+    def table_done(self, name, columns, lengths=None, attrs=None):
         self.tables[name] = columns
         if lengths:
             self.lengths[name] = lengths
+        if attrs:
+            self.attrs[name] = attrs
 
     def chunk_writer(self, name):
         parts, lens = [], []
@@ -554,9 +562,11 @@ class _MemorySink:
             parts.append(columns)
             lens.append(lengths)
 
+        deliver.attrs = {}  # output -> attributes of its column: filled in once the chain is built
+
         def close():
             merged = {k: np.concatenate([p[k] for p in parts]) for k in (parts[0] if parts else [])}
-            self.table_done(name, merged, {k: np.concatenate([p[k] for p in lens]) for k in (lens[0] if lens else {})})
+            self.table_done(name, merged, {k: np.concatenate([p[k] for p in lens]) for k in (lens[0] if lens else {})}, deliver.attrs)
 
         return deliver, close
 
@@ -594,9 +604,10 @@ class _Lh5Sink:
 
     def chunk_writer(self, name):
         def deliver(i_entry, n, columns, lengths):
-            self.store.write(obj=lgdo_io.results_table(columns, lengths=lengths), name=name, lh5_file=self.path, wo_mode=self.wo_mode,
-                             write_start=self.i_start + i_entry, n_rows=n)
+            self.store.write(obj=lgdo_io.results_table(columns, lengths=lengths, attrs=deliver.attrs), name=name, lh5_file=self.path,
+                             wo_mode=self.wo_mode, write_start=self.i_start + i_entry, n_rows=n)
 
+        deliver.attrs = {}
         return deliver, (lambda: None)
 
     def table_done(self, name, columns, lengths=None):
@@ -651,6 +662,6 @@ def build_dsp(raw_in, dsp_out: str | None = None, dsp_config=None, lh5_tables=No
         sink.finish()
         return None
     if chunked:
-        tabs = {k: lgdo_io.results_table(v, lengths=sink.lengths.get(k)) for k, v in sink.tables.items()}
+        tabs = {k: lgdo_io.results_table(v, lengths=sink.lengths.get(k), attrs=sink.attrs.get(k)) for k, v in sink.tables.items()}
         return tabs[next(iter(tabs))] if not source.from_file and tabs else tabs
     return sink.tables[next(iter(sink.tables))] if source.single and sink.tables else sink.tables

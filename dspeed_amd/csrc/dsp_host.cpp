@@ -1291,11 +1291,14 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 if (len != slot_len[o.dst]) return fail(DSP_E_DWT_OUTLEN, "%s (got %d, expect %d)", dsp_fatal_message(DSP_E_DWT_OUTLEN), slot_len[o.dst], len);
                 break;
             }
-            case DSP_OP_COPY:
-                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || o.src == o.dst || o.ip[0] < 0 || o.ip[1] < 0 ||
-                    (int64_t)o.ip[0] + (int64_t)(slot_len[o.dst] - 1) * (o.ip[1] > 1 ? o.ip[1] : 1) >= slot_len[o.src])
+            case DSP_OP_COPY: {  // dst[k] = src[ip[0] + k * step], step = ip[1] (0 means 1; negative: backwards)
+                const int64_t step = o.ip[1] != 0 ? o.ip[1] : 1;
+                const int64_t last = check_slot(P, o.dst) ? (int64_t)o.ip[0] + (int64_t)(slot_len[o.dst] - 1) * step : -1;
+                if (!check_slot(P, o.src) || !check_slot(P, o.dst) || o.src == o.dst || o.ip[0] < 0 || o.ip[0] >= slot_len[o.src] || last < 0 ||
+                    last >= slot_len[o.src])
                     return fail(DSP_ERR_ARG, "op %d: bad COPY", i);
                 break;
+            }
             case DSP_OP_ELEMENTWISE: {
                 if (!check_slot(P, o.dst) || o.ip[0] < 0 || o.ip[0] > DSP_FN_LAST) return fail(DSP_ERR_ARG, "op %d: bad ELEMENTWISE", i);
                 const int opnd[3] = {o.src, o.ip[1], o.ip[2]};

@@ -1902,7 +1902,7 @@ __device__ __forceinline__ void op_copy(Ctx<T>& cx, const DSP_PROG DevOp& op) {
         cx.set_nan(op.dst, true);
         return;
     }
-    const int total = 64 * sd.C, lane = lane_id(), step = op.ip[1] > 1 ? op.ip[1] : 1;
+    const int total = 64 * sd.C, lane = lane_id(), step = op.ip[1] != 0 ? op.ip[1] : 1;  // (a negative step walks the source backwards)
     if (!cx.slot_nan(op.src)) {
         // (eight loads, then eight stores -- written out, because through the one LDS pointer the compiler keeps every load behind the
         // store before it; total is a multiple of 512)
@@ -1911,7 +1911,7 @@ __device__ __forceinline__ void op_copy(Ctx<T>& cx, const DSP_PROG DevOp& op) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int e = e0 + 64 * k, se = e * step + op.ip[0];
-                const bool ok = e < sd.len && se < ss.len;
+                const bool ok = e < sd.len && se >= 0 && se < ss.len;
                 const T w = cx.lds[padded_index(ss, ok ? se : 0)];
                 v[k] = ok ? w : (T)0;
             }
@@ -1924,7 +1924,7 @@ __device__ __forceinline__ void op_copy(Ctx<T>& cx, const DSP_PROG DevOp& op) {
 #pragma unroll 1
         for (int e = lane; e < total; e += 64) {
             const int se = e * step + op.ip[0];
-            const T v = (e < sd.len && se < ss.len) ? cx.lds[padded_index(ss, se)] : (T)0;
+            const T v = (e < sd.len && se >= 0 && se < ss.len) ? cx.lds[padded_index(ss, se)] : (T)0;
             nan |= (v != v);
             cx.lds[padded_index(sd, e)] = v;
         }

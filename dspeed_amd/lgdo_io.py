@@ -208,27 +208,49 @@ def snapshot(cols: dict) -> dict:
     return out
 
 
-def results_table(cols: dict, units: dict | None = None, lengths: dict | None = None):
+class Column(np.ndarray):
+    """an output column with the attributes an LGDO array would carry (``.attrs``: units, lh5_attrs, description) -- what
+    ``results_table`` hands out where the lgdo package is absent; ``.nda`` is the plain array, as on ``lgdo.Array``"""
+
+    def __new__(cls, values, attrs=None):
+        obj = np.asarray(values).view(cls)
+        obj.attrs = dict(attrs or {})
+        return obj
+
+    def __array_finalize__(self, obj):
+        self.attrs = dict(getattr(obj, "attrs", None) or {})
+
+    @property
+    def nda(self):
+        return np.asarray(self)
+
+
+def results_table(cols: dict, units: dict | None = None, lengths: dict | None = None, attrs: dict | None = None):
     """{name: ndarray} -> an ``lgdo.Table`` (Array / ArrayOfEqualSizedArrays / VectorOfVectors columns with their units) when lgdo is
-    installed, else the dict itself.  ``lengths``: name -> per-row lengths of a variable-length output."""
+    installed, else a dict of ``Column``s.  ``lengths``: name -> per-row lengths of a variable-length output; ``attrs``: name -> the
+    attributes of the column (units, lh5_attrs, description)."""
     lg = lgdo_or_none()
-    units, lengths = units or {}, lengths or {}
+    lengths, attrs = lengths or {}, {k: dict(v) for k, v in (attrs or {}).items()}
+    for k, u in (units or {}).items():
+        if u:
+            attrs.setdefault(k, {}).setdefault("units", u)
+    units = {k: v.get("units") for k, v in attrs.items()}
     if lg is None:
         out = {}
         for k, v in cols.items():
-            out[k] = RaggedColumn(np.asarray(v), np.asarray(lengths[k]), units.get(k)) if k in lengths else v
+            out[k] = RaggedColumn(np.asarray(v), np.asarray(lengths[k]), units.get(k)) if k in lengths else Column(v, attrs.get(k))
         return out
     tb = lg.Table(size=len(next(iter(cols.values()))) if cols else 0)
     for k, v in cols.items():
         a = np.asarray(v)
-        attrs = {"units": units[k]} if units.get(k) else {}
+        attrs_k = attrs.get(k, {})
         if k in lengths:
             flat, cl = RaggedColumn(a, np.asarray(lengths[k])).to_flat()
-            tb.add_field(k, lg.VectorOfVectors(flattened_data=flat, cumulative_length=cl, attrs=attrs))
+            tb.add_field(k, lg.VectorOfVectors(flattened_data=flat, cumulative_length=cl, attrs=attrs_k))
         elif a.ndim == 1:
-            tb.add_field(k, lg.Array(a, attrs=attrs))
+            tb.add_field(k, lg.Array(a, attrs=attrs_k))
         else:
-            tb.add_field(k, lg.ArrayOfEqualSizedArrays(nda=a, attrs=attrs))
+            tb.add_field(k, lg.ArrayOfEqualSizedArrays(nda=a, attrs=attrs_k))
     return tb
 
 

@@ -243,6 +243,7 @@ class ProcessingChain:
         self._timing = {"h2d": 0.0, "kernel": 0.0, "d2h": 0.0}
         self._copy_pars = []      # outputs that are input columns handed through
         self.vector_lens = {}     # variable-length outputs -> input column with their per-event lengths
+        self.output_attrs = {}    # output -> attributes of its LGDO column (units, lh5_attrs, description)
         self.proc_strings = proc_strings
         self.device = None        # GPU ordinal the chain is bound to (None: the current device of the thread that first executes it)
 
@@ -742,6 +743,8 @@ class _Builder:
         return self._eval(tree, arg, want_new or ())
 
     def _eval(self, n, src, new):
+        if isinstance(n, ast.List):  # [1, 2, 3]: a constant array (reference :806-810), the same for every row
+            return np.array(ast.literal_eval(src[n.col_offset:n.end_col_offset]))
         if isinstance(n, ast.Constant):
             if isinstance(n.value, str):
                 return ("char", n.value)
@@ -846,8 +849,25 @@ class _Builder:
                 self._step("sample", [view, 0 if base.is_input else first + i, out], "wiS")
                 return out
             step = self._const_int(n.slice.step, src, new, 1, None)
-            if step < 1:
-                raise NotImplementedError(f"slices with a negative step are not supported: '{src}'")
+            if step == 0:
+                raise ProcessingChainError(f"slice step cannot be zero in '{src}'")
+            if step < 0:  # wf[::-1], wf[100:10:-2]: NumPy's slice of the buffer (reference :1009-1048), a copy with a negative stride here
+                lower = None if n.slice.lower is None else self._const_int(n.slice.lower, src, new, 0, base)
+                upper = None if n.slice.upper is None else self._const_int(n.slice.upper, src, new, 0, base)
+                picks = range(*slice(lower, upper, step).indices(length))
+                if len(picks) < 1:
+                    raise ProcessingChainError(f"empty slice in '{src}'")
+                self._anon += 1
+                g = _grid_of(base if isinstance(base, Var) else ("slice", base, first, first + length))
+                if g is not None:  # the period times the step; the offset moves only for an explicit positive start (reference :1031-1048)
+                    g = Grid(g.period * step, g.offset + (lower * g.period if lower is not None and lower > 0 else 0.0), g.offset_var)
+                out = Var(f"{base.name}[{'' if lower is None else first + lower}:{'' if upper is None else first + upper}:{step}]#{self._anon}",
+                          "wf", len(picks), np.float32, grid=g, unit=base.unit, is_coord=False)
+                if base.is_input:  # only the span the slice covers is read from the input
+                    self._step("slice", [("slice", base, first + picks[-1], first + picks[0] + 1), picks[0] - picks[-1], step, out], "wiiW")
+                else:
+                    self._step("slice", [base, first + picks[0], step, out], "wiiW")
+                return out
             lo = self._const_int(n.slice.lower, src, new, 0, base)
             hi = self._const_int(n.slice.upper, src, new, length, base)
             lo = max(lo + length, 0) if lo < 0 else min(lo, length)
@@ -1018,12 +1038,22 @@ class _Builder:
 
     def _binop(self, op, a, b, src=""):
         sa, sb = _is_scalar(a), _is_scalar(b)
+        if (isinstance(a, np.ndarray) or isinstance(b, np.ndarray)) and (_is_wf(a) or _is_wf(b) or sa or sb):
+            raise NotImplementedError(f"a constant array beside a variable in '{src}': declare it as the kernel of a processor, or spell the "
+                                      "operation per sample")
         if _is_wf(a) or _is_wf(b):
             return self._wf_binop(op, a, b, src)
         if sa or sb:
             return self._scalar_binop(op, a, b, src)
         if isinstance(a, (Var, tuple, Grid)) or isinstance(b, (Var, tuple, Grid)):
             raise ProcessingChainError(f"operands {a!r} and {b!r} of '{src}' are not numbers or variables")
+        if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):  # constant arrays: the NumPy operation itself, once, on the host
+            if isinstance(a, Quantity) or isinstance(b, Quantity):
+                raise ProcessingChainError(f"a constant array and a time in '{src}'")
+            fn = {ast.Add: np.add, ast.Sub: np.subtract, ast.Mult: np.multiply, ast.Div: np.divide, ast.FloorDiv: np.floor_divide}.get(type(op))
+            if fn is None:
+                raise ProcessingChainError("unsupported operator in argument expression")
+            return fn(a, b)
         qa, qb = isinstance(a, Quantity), isinstance(b, Quantity)
         fa, fb = float(a), float(b)
         if isinstance(op, ast.Add):
@@ -1337,6 +1367,18 @@ def build_processing_chain(processors, tb_in=None, db_dict=None, outputs=None, b
         if tb_in is not None and c in tb_in:
             tb_out[c] = _column(tb_in, c)
     chain._copy_pars = list(copy_pars)
+    # what the LGDO output columns carry besides their values (reference :1990-2014 units, :2725-2740 lh5_attrs / description)
+    chain.output_attrs = {}
+    for o in out_pars:
+        v, entry, a = b.vars.get(o), book.defined_by.get(o), {}
+        unit = getattr(v, "unit", None)
+        if isinstance(unit, str):
+            a["units"] = unit
+        if entry is not None:
+            a.update(entry.get("lh5_attrs") or {})
+            if entry.get("description") is not None:
+                a["description"] = entry.get("description")
+        chain.output_attrs[o] = a
     chain.device = None if device is None else int(device)
     chain.link(tb_in, tb_out)
     return chain, leafs + copy_pars, tb_out
@@ -2422,7 +2464,8 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
         if v is None or v.kind in (None,):
             raise ProcessingChainError(f"output '{o}' was never computed")
         if v.kind == "const":
-            tb_out[o] = np.full(n_rows, v.const)
+            c = np.asarray(v.const)  # a number, or a constant array ("a1": "[1, 2, 3]"): every row holds it
+            tb_out[o] = np.broadcast_to(c, (n_rows, *c.shape)).copy()
             continue
         if v.kind == "taps":
             tb_out[o] = np.broadcast_to(v.const, (n_rows, v.length)).copy()

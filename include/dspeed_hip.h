@@ -172,7 +172,7 @@ typedef struct dsp_scalar_arg {
                                   * found among the taps: bit 0 a NaN (output NaN), bit 1 an infinity; ip[3] > 0: the kernel has ip[3]
                                   * taps and the binding (longer, ideally a multiple of 16) holds zeros after them -- lets the blocked tap
                                   * loop cover every tap */
-#define DSP_OP_COPY 15         /* dst[k] <- src[ip[0] + k * max(ip[1], 1)]  (constant slice of an intermediate, with a step: processing_chain.py:1024-1071) */
+#define DSP_OP_COPY 15         /* dst[k] <- src[ip[0] + k * step], step = ip[1] (0 stands for 1; negative: backwards)  (constant slice of an intermediate: processing_chain.py:1009-1071) */
 #define DSP_OP_TRAP_PICKOFF 16 /* fusion of TRAP_FILTER|TRAP_NORM|ASYM_TRAP (ip[3] = which opcode) with PICKOFF: the trap output is
                                   never materialised; sreg[dst] <- trap(src) at sp[0]; ip[0..2] = rise, flat, fall; mode in `io` */
 #define DSP_OP_AMAX 17         /* numpy.amax along the sample axis (icpc-dsp-config.json:123-143): sreg[dst] <- max(src), NaN if any NaN */

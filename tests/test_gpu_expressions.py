@@ -267,3 +267,48 @@ def test_vector_of_vectors_out_again():
     else:
         f2, cl2 = np.asarray(res.flattened_data.nda), np.asarray(res.cumulative_length.nda)
     assert np.array_equal(f2, flat) and list(cl2) == [3, 3, 10, 17, 28]
+
+
+def test_negative_step_slices_and_list_literals():
+    """wf[::-1], wf[a:b:-s] of the input and of an intermediate are NumPy's slices of the rows (reference processing_chain.py:1009-1048); a list
+    literal is a constant array (reference test_list_parsing, tests/test_processing_chain.py:145-159)"""
+    tb = _table()
+    wf = tb["waveform"].values.astype(np.float32)
+    bls = wf - tb["baseline"][:, None]
+    procs = {"wf_blsub": {"function": "bl_subtract", "module": M, "args": ["waveform", "baseline", "wf_blsub"]},
+             "w_rev": "waveform[::-1]", "w_back": "waveform[100:10:-2]", "w_tail": "waveform[-1:-20:-3]",
+             "b_rev": "wf_blsub[::-1]", "b_back": "wf_blsub[900:100:-7]", "b_rev_of_rev": "b_rev[::-1]",
+             "a1": "[1,2,3,4,5]", "wf_out": "a1+[6,7,8,9,10]",
+             "tp_min, tp_max, lo, hi": {"function": "min_max", "module": M, "args": ["b_rev", "tp_min", "tp_max", "lo", "hi"]}}
+    outs = ["w_rev", "w_back", "w_tail", "b_rev", "b_back", "b_rev_of_rev", "a1", "wf_out", "tp_max"]
+    _chain, out = _run(procs, outs, tb)
+    assert np.array_equal(out["w_rev"], wf[:, ::-1]) and np.array_equal(out["w_back"], wf[:, 100:10:-2]) and np.array_equal(out["w_tail"], wf[:, -1:-20:-3])
+    assert np.array_equal(out["b_rev"], bls[:, ::-1]) and np.array_equal(out["b_back"], bls[:, 900:100:-7]) and np.array_equal(out["b_rev_of_rev"], bls)
+    assert np.all(out["a1"] == [1, 2, 3, 4, 5]) and np.all(out["wf_out"] == [7, 9, 11, 13, 15]) and out["wf_out"].shape == (len(wf), 5)
+    assert np.array_equal(out["tp_max"], np.argmax(bls[:, ::-1], axis=1).astype(np.float32))  # (a processor reads the reversed waveform)
+
+
+def test_database_params_inside_an_expression_and_column_attributes():
+    """reference test_database_params (tests/test_processing_chain.py:764-782): db.x references inside an inline expression, names that merely
+    contain 'db' left alone; and the attributes of output columns (test_output_attrs :694-708, test_output_description :711-761, the units
+    of :86-96) on an LGDO-protocol table"""
+    from lgdo_standins import Array, Table, WaveformTable
+
+    tb = _table(n=6)
+    rec = {"outputs": ["test"], "processors": {
+        "dbabc": "waveform[0]*0", "redberry": "dbabc+1",
+        "test": {"function": "db.a + dbabc + redberry + db.b*db.c", "defaults": {"db.a": 1, "db.b": 2, "db.c": 3}}}}
+    assert build_dsp(tb, dsp_config=rec)["test"][0] == 8
+    assert build_dsp(tb, dsp_config=rec, database={"a": 2, "c": 0})["test"][0] == 3
+    lg = Table(waveform=WaveformTable(tb["waveform"].values, 16.0, np.zeros(6)), baseline=Array(tb["baseline"]))
+    rec = {"outputs": ["wf_blsub", "tp_min", "wf_max", "plain"], "processors": {
+        "wf_blsub": {"function": "bl_subtract", "module": M, "args": ["waveform[0:100]", "baseline", "wf_blsub"], "unit": "ADC",
+                     "lh5_attrs": {"test_attr": "This is a test"}, "description": "baseline-subtracted waveform"},
+        "tp_min, tp_max, wf_min, wf_max": {"function": "min_max", "module": M, "args": ["waveform", "tp_min", "tp_max", "wf_min", "wf_max"],
+                                           "unit": ["ns", "ns", "ADC", "ADC"], "description": "find max and min of waveform with corresponding time points"},
+        "plain": "wf_max * 2"}}
+    res = build_dsp(lg, dsp_config=rec)
+    assert res["wf_blsub"].attrs == {"units": "ADC", "test_attr": "This is a test", "description": "baseline-subtracted waveform"}
+    assert res["tp_min"].attrs == {"units": "ns", "description": "find max and min of waveform with corresponding time points"}
+    assert res["wf_max"].attrs["units"] == "ADC" and "description" not in res["plain"].attrs
+    assert np.asarray(res["wf_blsub"].nda).shape == (6, 100)

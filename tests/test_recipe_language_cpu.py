@@ -208,7 +208,7 @@ def test_argument_language_on_per_event_variables():
 
 
 def test_what_the_language_does_not_take_fails_by_name():
-    for expr, exc in (("waveform * 2", NotImplementedError), ("waveform[0:100:-2]", NotImplementedError), ("waveform[0:100:2]", ProcessingChainError), ("t_b * (2*ns)", NotImplementedError),
+    for expr, exc in (("waveform * 2", NotImplementedError), ("waveform[0:100:-2]", ProcessingChainError), ("waveform[0:100:2]", ProcessingChainError), ("t_b * (2*ns)", NotImplementedError),
                       ("baseline.grid", ProcessingChainError), ("t_b % 2", (NotImplementedError, ProcessingChainError))):
         rec = {"outputs": ["x"], "processors": {
             "t_a, t_b, lo, hi": {"function": "min_max", "module": M, "args": ["waveform", "t_a", "t_b", "lo", "hi"], "unit": ["ns", "ns", "ADC", "ADC"]},
@@ -283,3 +283,35 @@ def test_expressions_on_waveforms_translate_into_elementwise_ops():
     assert b.eval_arg("(waveform[50:100] * 2).grid") == Grid(16.0, 800.0) and b.eval_arg("len(waveform[50:100:2])") == 25
     with pytest.raises(ProcessingChainError, match="out of bounds"):
         b.eval_arg("waveform[1000]")
+
+
+def test_list_literals_are_constant_arrays():
+    """test_list_parsing of the reference (tests/test_processing_chain.py:145-159): a list is a constant array, arithmetic between constant
+    arrays is NumPy's, and as an output every row holds the array"""
+    rec = {"outputs": ["a1", "a2", "wf_out", "half"], "processors": {"a1": "[1,2,3,4,5]", "a2": "[[1, 2], [3, 4]]", "wf_out": "a1+[6,7,8,9,10]",
+                                                                      "half": "wf_out / 2"}}
+    chain, mask, out = build_processing_chain(rec, _tb())
+    n = len(_tb()["baseline"])
+    assert mask == [] and out["a1"].shape == (n, 5) and out["a2"].shape == (n, 2, 2)
+    assert np.all(out["a1"] == np.array([1, 2, 3, 4, 5])) and np.all(out["a2"] == np.array([[1, 2], [3, 4]]))
+    assert np.all(out["wf_out"] == np.array([7, 9, 11, 13, 15])) and out["wf_out"].dtype.kind == "i"
+    assert np.all(out["half"] == np.array([3.5, 4.5, 5.5, 6.5, 7.5]))
+    with pytest.raises(NotImplementedError, match="constant array beside a variable"):
+        build_processing_chain({"outputs": ["x"], "processors": {"x": "waveform[0:3] + [1, 2, 3]"}}, _tb())
+
+
+def test_negative_steps_become_backward_copies():
+    """wf[::-1], wf[100:10:-2] (NumPy's slice of the buffer in the reference, processing_chain.py:1009-1048): a COPY with a negative stride; of
+    a chain input only the span the slice covers is loaded; the grid's period takes the sign of the step"""
+    tb = _tb()
+    L = tb["waveform"].values.shape[1]
+    chain, _, out = build_processing_chain({"outputs": ["r", "s"], "processors": {
+        "wf_blsub": f"{M}.bl_subtract(waveform, baseline, wf_blsub)", "r": "wf_blsub[::-1]", "s": "waveform[100:10:-2]"}}, tb)
+    assert out["r"].shape[1] == L and out["s"].shape[1] == 45
+    copies = [o for o in chain.program.ops if o[0] == _lib.OP_COPY]
+    assert sorted((o[4][0], o[4][1]) for o in copies) == [(88, -2), (L - 1, -1)]  # (first source sample, step): 100 is sample 88 of the span 12..100
+    spans = {io[0]: (io[3], io[4]) for io in chain.program.io if io[0].startswith("in:waveform")}
+    assert spans["in:waveform[12:101]"] == (89, 12)
+    for expr in ("waveform[10:100:-1]", "waveform[::0]"):
+        with pytest.raises(ProcessingChainError):
+            build_processing_chain({"outputs": ["x"], "processors": {"x": expr}}, tb)
