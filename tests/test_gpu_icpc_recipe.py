@@ -104,27 +104,23 @@ def test_whole_ge_recipe_is_one_device_program(t0_kind, rows_dtype):
     want, tp0 = _expected(wf, bl, t0_ns, ft)
     assert set(out) == set(recipes.ICPC["outputs"]) and all(v.dtype == ft for v in out.values())
 
-    # the start of the rise found on the t0-filtered waveform gates everything after it: rows where a 1e-7 difference in a filtered
-    # sample moved a threshold crossing are compared on what does not depend on it
-    same_t0 = out["tp_0_est"] == want["tp_0_est"]
-    assert same_t0.mean() >= 0.9, f"tp_0_est differs in {np.sum(~same_t0)} of {n} rows"
-    exact = ["tp_min", "tp_max", "wf_min", "wf_max"]
-    times = ["tp_0_est", "tp_0_atrap", "tp_10", "tp_50", "tp_90", "tp_99", "tp_100", "tp_aoe_max", "tp_aoe_samp"]
-    rel = {"bl_mean": 1e-4, "bl_std": 1e-4, "bl_slope": 1e-3, "bl_intercept": 1e-4, "pz_mean": 1e-4, "pz_std": 1e-4, "trapTmax": 1e-6,
-           "trapEmax": 1e-6, "trapEftp": 1e-6, "cuspEmax": 1e-6, "cuspEftp": 1e-6, "QDrift": 1e-5, "dt_eff": 1e-5, "A_max": 1e-5}
+    # Measured on this batch (tools/icpc_parity_measure.py, profiles/r03_icpc_parity_by_output.json): every index / time output, the six fit
+    # outputs (the fits run on the rows exactly as the oracle's loops do) and the current branch (dsp_current.hip) equal the all-oracle run
+    # bit for bit in 48 of 48 rows, in the float32 and in the float64 loop; the energies differ by what the trapezoid replay and the FIR's
+    # summation order leave: <= 3e-7 of the value in float32, <= 4e-14 in float64.  The assertions are those numbers, not a blanket bound.
+    exact = ["tp_min", "tp_max", "wf_min", "wf_max", "tp_0_est", "tp_0_atrap", "tp_10", "tp_50", "tp_90", "tp_99", "tp_100", "tp_aoe_max",
+             "tp_aoe_samp", "bl_mean", "bl_std", "bl_slope", "bl_intercept", "pz_mean", "pz_std"]
+    if ft == np.float32:
+        exact.append("A_max")
+    tol = 1e-6 if ft == np.float32 else 1e-12
+    rel = {"trapTmax": tol, "trapEmax": tol, "trapEftp": tol, "cuspEmax": tol, "cuspEftp": tol, "QDrift": tol, "dt_eff": tol, "A_max": tol}
     for k in exact:
-        assert np.array_equal(out[k], want[k]), k
-    for k in times:
-        rows = same_t0 if k not in ("tp_0_atrap",) else np.ones(n, dtype=bool)
-        agree = np.mean(out[k][rows] == want[k][rows])
-        assert agree >= 0.9, f"{k}: {agree:.2f} of the rows agree"
-        assert np.nanmax(np.abs(out[k][rows] - want[k][rows])) <= 16.0 * 4, k
-    for k, tol in rel.items():
-        rows = same_t0 if k in ("trapEftp", "QDrift", "dt_eff", "A_max") else np.ones(n, dtype=bool)
-        scale = np.maximum(np.abs(want[k][rows]), 1e-3 * np.max(np.abs(want[k])))
-        assert not np.isnan(out[k][rows]).any(), k
-        err = np.max(np.abs(out[k][rows] - want[k][rows]) / scale)
-        assert err <= tol, f"{k}: {err:.3g}"
+        assert np.array_equal(out[k], want[k], equal_nan=True), (k, int(np.sum(out[k] != want[k])))
+    for k, bound in rel.items():
+        scale = np.maximum(np.abs(want[k]), 1e-3 * np.max(np.abs(want[k])))
+        assert not np.isnan(out[k]).any(), k
+        err = np.max(np.abs(out[k] - want[k]) / scale)
+        assert err <= bound, f"{k}: {err:.3g}"
     # the times are in ns with the waveform's t0 in them: the rise sits ~ t0 + 0.5 * 8192 * 16 ns
     assert np.all(np.abs(out["tp_0_est"] - (t0_ns + 0.5 * 8192 * 16)) < 0.08 * 8192 * 16)
 
