@@ -87,15 +87,20 @@ def needs_build(lib: str = LIB) -> bool:
         return f.read().strip() != _stamp(lib == LIB_DIAG)
 
 
-def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, diag: bool = False, variant: str | None = None, defines=()) -> str:
+    """``variant`` / ``defines``: an experiment library libdspeed_hip_<variant>.so compiled with -D<define>... beside the product one
+    (A/B runs of kernel variants in one GPU session: tools select it with DSPEED_HIP_LIB); always rebuilt."""
     lib = LIB_DIAG if diag else LIB
+    if variant:
+        lib = os.path.join(HERE, f"libdspeed_hip_{variant}.so")
+        force = True
     if not force and not needs_build(lib):
         return lib
     # one hipcc process per source (they are independent translation units), then a link: the wall time of the longest file
     objs, procs = [], []
     for src in SOURCES:
-        obj = os.path.join(CSRC, "." + src + (".diag.o" if diag else ".o"))
-        cmd = [_hipcc(), *[f for f in FLAGS if f != "-shared"], *(["-DDSPEED_HIP_DIAG"] if diag else []), "-x", "hip", "-c",
+        obj = os.path.join(CSRC, "." + src + (f".{variant}.o" if variant else (".diag.o" if diag else ".o")))
+        cmd = [_hipcc(), *[f for f in FLAGS if f != "-shared"], *(["-DDSPEED_HIP_DIAG"] if diag else []), *[f"-D{d}" for d in defines], "-x", "hip", "-c",
                os.path.join(CSRC, src), "-o", obj]
         guard = src in NO_SCRATCH
         if guard:
@@ -129,10 +134,16 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
+    if variant:
+        for obj in objs:
+            os.remove(obj)
+        return lib
     with open(_stamp_file(lib), "w") as f:
         f.write(_stamp(diag) + "\n")
     return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv))
+    _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    _defines = [sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--define"]
+    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv, variant=_variant, defines=_defines))

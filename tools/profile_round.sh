@@ -7,7 +7,7 @@
 #   the recipe's launches (stages + program), stored FIR, VM PMC  -> gpurun_out/prof_<tag>/icpc_trace, icpc_rate.json, fir_store_rate.json, prof_<tag>_vm
 set -u
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 tools/profile_bench.sh "$TAG" > "$OUT/profile_bench.log" 2>&1
@@ -24,9 +24,12 @@ python3 tools/icpc_breakdown.py > "$OUT/icpc_recipe.jsonl" 2> "$OUT/icpc_recipe.
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/icpc_trace" -- python3 tools/icpc_rate.py 131072 5 > "$OUT/icpc_rate_traced.json" 2> "$OUT/icpc_trace.err"
 python3 tools/icpc_rate.py 131072 5 > "$OUT/icpc_rate.json" 2> /dev/null
 python3 tools/fir_store_rate.py 100000 1 > "$OUT/fir_store_rate.json" 2> /dev/null
-python3 tools/e2e_recipe_rate.py 100000 > "$OUT/e2e_recipe_rate.json" 2> /dev/null
-for r in 4096 16384 65536; do python3 tools/icpc_rate.py $r 10; done > "$OUT/icpc_rate_small.jsonl" 2> /dev/null
+python3 tools/e2e_recipe_rate.py 400000 > "$OUT/e2e_recipe_rate.json" 2> /dev/null
+for r in 16384 32768 65536; do python3 tools/icpc_rate.py $r 10; done > "$OUT/icpc_rate_small.jsonl" 2> /dev/null
 DSPEED_HIP_NO_FUSED=1 tools/pmc_kernel.sh gpurun_out/prof_${TAG}_vm bench.py --allow-variants --no-cpu --rows 500000 --steps 5 --warmup 2 > /dev/null 2>&1
 python3 tools/pmc_table.py gpurun_out/prof_${TAG}_vm "dsp_vm" "$OUT/vm_pmc.json" > /dev/null
 python3 bench.py --wf-len 8192 --rows 500000 --no-cpu --steps 10 --warmup 5 > "$OUT/bench_8192.json" 2>/dev/null
+tools/pmc_kernel.sh gpurun_out/prof_${TAG}_icpc tools/icpc_rate.py 131072 3 > /dev/null 2>&1
+python3 tools/pmc_table.py gpurun_out/prof_${TAG}_icpc "" "$OUT/icpc_pmc.json" > /dev/null
+python3 tools/c5_instruction_roofline.py "$OUT/c5_rate.json" "$OUT/c5_pmc.json" > "$OUT/c5_rate_roofline.json" 2> /dev/null
 echo "round profile $TAG done"; tail -2 "$OUT/phases.txt"; cat "$OUT/c3_rate.json" "$OUT/c5_rate.json"
