@@ -82,6 +82,9 @@ extern "C" const char* dsp_internal_energy_rr_kernel_name();
 extern "C" int dsp_internal_launch_rows(const RowsArgs* A, int64_t n_wf, int* err, int lds_bytes, hipStream_t stream);
 extern "C" int dsp_internal_set_rows_lds(int lds_bytes);
 extern "C" const char* dsp_internal_rows_kernel_name();
+extern "C" int dsp_internal_launch_scalar(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int n_sregs, int f64, hipStream_t stream);
+extern "C" int dsp_internal_set_scalar_lds(int lds_bytes);
+extern "C" const char* dsp_internal_scalar_kernel_name();
 extern "C" int dsp_internal_current_lds_bytes(int ma_len);
 extern "C" int dsp_internal_launch_current(const CurrentArgs* A, int64_t n_wf, int blocks, int lds_bytes, hipStream_t stream);
 extern "C" int dsp_internal_set_current_lds(int lds_bytes);
@@ -180,6 +183,8 @@ struct dsp_chain {
     FirArgs fir{};
     int fir_lds_bytes = 0;
     int fio_wf = -1, fio_bl = -1, fio_taps[DSP_FIR_MAXK] = {-1, -1, -1, -1}, fio_out[DSP_FIR_MAXK] = {-1, -1, -1, -1};
+    // a program of scalar ops only (dsp_scalar.hip: a row per lane)
+    bool scalar_ok = false;
     // lane-per-waveform current-branch kernel (dsp_current.hip)
     bool cur_ok = false;
     CurrentArgs cur{};
@@ -1496,6 +1501,19 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         ch->fused_on = !(env && env[0] == '1');
     }
 
+    {  // nothing but arithmetic between per-event values and stores: one row per lane instead of one per wavefront
+        bool only_scalar = true;
+        for (int i = 0; i < n_ops; ++i) {
+            const int oc = ops[i].opcode;
+            only_scalar &= oc == DSP_OP_SCALAR_AFFINE || oc == DSP_OP_SCALAR_DIV || oc == DSP_OP_SCALAR_CONVERT || oc == DSP_OP_SCALAR_FUNC ||
+                           oc == DSP_OP_STORE_SCALAR;
+        }
+        ch->scalar_ok = only_scalar && n_dev_ops == n_ops;
+        if (ch->scalar_ok) {
+            const char* env = getenv("DSPEED_HIP_NO_FUSED");
+            ch->fused_on = !(env && env[0] == '1');
+        }
+    }
     ch->cur_ok = match_current_shape(ch.get(), ops, n_ops, io, slot_len, f64);
     if (!ch->cur_ok) {
         ch->cio_wf = ch->cio_t0 = -1;
@@ -1529,6 +1547,10 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     if (ch->fir_ok && ch->fir_lds_bytes > 64 * 1024) {
         hipError_t e = (hipError_t)(ch->fir.store ? dsp_internal_set_fir_store_lds(ch->fir_lds_bytes) : dsp_internal_set_fir_mfma_lds(ch->fir_lds_bytes));
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(FIR kernel, %d): %s", ch->fir_lds_bytes, hipGetErrorString(e));
+    }
+    if (ch->scalar_ok && n_sregs * 64 * esz > 48 * 1024) {
+        hipError_t e = (hipError_t)dsp_internal_set_scalar_lds(n_sregs * 64 * esz);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(scalar kernel): %s", hipGetErrorString(e));
     }
     if (ch->cur_ok && ch->cur_lds_bytes > 64 * 1024) {
         hipError_t e = (hipError_t)dsp_internal_set_current_lds(ch->cur_lds_bytes);
@@ -1620,6 +1642,11 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
     auto at = [&](int k) -> void* {
         return k < 0 ? nullptr : (void*)((char*)io_ptrs[k] + (int64_t)ch->host.io[k].offset * elem_size(ch->host.io[k].dtype));
     };
+    if (ch->scalar_ok && ch->fused_on) {
+        hipError_t e = (hipError_t)dsp_internal_launch_scalar(ch->dev, &ptrs, n_wf, ch->host.n_sregs, ch->f64 ? 1 : 0, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "scalar kernel launch failed: %s", hipGetErrorString(e));
+        return post_err(ch, stream);
+    }
     if (ch->cur_ok && ch->fused_on && (reinterpret_cast<uintptr_t>(io_ptrs[ch->cio_wf]) & 15u) == 0) {
         // persistent wavefronts, as many as a CU's LDS takes (at most 8 per CU): each keeps its scratch area for the groups of rows it walks
         int per_cu = LDS_BYTES_PER_CU / ch->cur_lds_bytes;
@@ -1777,6 +1804,12 @@ int dsp_chain_destroy(dsp_chain* ch) {
 
 int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int* waves_per_block, int* blocks) {
     if (!ch) return fail(DSP_ERR_ARG, "null chain");
+    if (ch->scalar_ok && ch->fused_on) {
+        if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->host.n_sregs * 64 * (ch->f64 ? 8 : 4);
+        if (waves_per_block) *waves_per_block = 1;
+        if (blocks) *blocks = (int)((n_wf + 63) / 64);
+        return DSP_OK;
+    }
     if (ch->cur_ok && ch->fused_on) {
         int per_cu = LDS_BYTES_PER_CU / ch->cur_lds_bytes;
         if (per_cu > 8) per_cu = 8;
@@ -1813,6 +1846,7 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
 }
 
 const char* dsp_chain_kernel_name(dsp_chain* ch) {
+    if (ch && ch->scalar_ok && ch->fused_on) return dsp_internal_scalar_kernel_name();
     if (ch && ch->cur_ok && ch->fused_on) return dsp_internal_current_kernel_name();
     if (ch && ch->fir_ok && ch->fused_on) return ch->fir.store ? dsp_internal_fir_store_kernel_name() : dsp_internal_fir_mfma_kernel_name();
     if (ch && ch->rows_ok && ch->fused_on) return dsp_internal_rows_kernel_name();
@@ -1839,7 +1873,7 @@ int dsp_chain_set_fused(dsp_chain* ch, int enable) {
     // 7 = classic (VM layout); anything else = default
     const int v = (enable >> 1) & 7;
     ch->variant = (v == 7 || !ch->rr_ok) ? 1 : 6;
-    return ((ch->fused_ok || ch->rr_ok || ch->rows_ok || ch->fir_ok || ch->cur_ok) && ch->fused_on) ? 1 : 0;
+    return ((ch->fused_ok || ch->rr_ok || ch->rows_ok || ch->fir_ok || ch->cur_ok || ch->scalar_ok) && ch->fused_on) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ single processors

@@ -219,8 +219,9 @@ class ProcessingChain:
     (processing_chain.py:665-673); ``__call__(tb_in, tb_out)`` relinks I/O like :675-716."""
 
     def __init__(self, program: Program, inputs: dict, outputs: dict, consts: dict, buffer_len: int, proc_strings: list[str],
-                 loop_dtype=np.float32, aux=(), stages=(), ext_alias=None):
+                 loop_dtype=np.float32, aux=(), stages=(), ext_alias=None, tail=None):
         self._program = program
+        self._tail = tail         # the program's all-scalar tail as a program of its own, run behind it with a row per lane (_split_scalar_tail)
         self.loop_dtype = np.dtype(loop_dtype)  # float32 or float64 gufunc loop of the whole chain
         self._in_vars = inputs      # binding name -> Var (source column)
         self._out_vars = outputs    # binding name -> (Var, length or None)
@@ -280,7 +281,30 @@ class ProcessingChain:
                 st["chain"].set_async_check(True)
                 st["dev"] = {name: DeviceArray.from_numpy(arr) for name, arr in st["consts"].items()}
             self._lanes = [SimpleNamespace(stream=self._stream, chain=self._chain, stage_chains=[st["chain"] for st in self._stages],
-                                           stage_bufs=[st["bufs"] for st in self._stages], aux_bufs=self._aux_bufs)]
+                                           stage_bufs=[st["bufs"] for st in self._stages], aux_bufs=self._aux_bufs, tail=self._tail_chain(0),
+                                           tail_bufs={})]
+
+    def _tail_chain(self, lane_no: int):
+        if self._tail is None:
+            return None
+        ch = Chain(self._tail["program"], f"processing_chain scalar tail (lane {lane_no})", self.loop_dtype)
+        ch.set_async_check(True)
+        return ch
+
+    def _run_tail(self, bufs: dict, m: int, stream, lane) -> None:
+        """the main program's scalar tail, behind it on its stream: the registers it takes over arrive as columns"""
+        if lane.tail is None:
+            return
+        lane.tail.execute(bufs, m, stream)
+
+    def _handover_bufs(self, bufs: dict, m: int, lane) -> None:
+        if self._tail is None:
+            return
+        for name in self._tail["handover"]:
+            buf = lane.tail_bufs.get(name)
+            if buf is None or buf.shape[0] < m:
+                buf = lane.tail_bufs[name] = DeviceArray((m,), self.loop_dtype)
+            bufs[name] = buf
 
     def _lane(self, k: int):
         """Lane k of the chain: its own handles (error words), compute stream and intermediate buffers, so that the kernels of two pieces of
@@ -295,7 +319,7 @@ class ProcessingChain:
                 c.set_async_check(True)
                 stage_chains.append(c)
             self._lanes.append(SimpleNamespace(stream=Stream(), chain=ch, stage_chains=stage_chains, stage_bufs=[{} for _ in self._stages],
-                                               aux_bufs={}))
+                                               aux_bufs={}, tail=self._tail_chain(len(self._lanes)), tail_bufs={}))
         return self._lanes[k]
 
     #: bytes of host-resident I/O per pipelined piece, two pieces in flight.  Tens of MB are enough for the PCIe transfers; the size is set
@@ -540,7 +564,9 @@ class ProcessingChain:
                 s_c.wait_event(ev_in[k % n_slots])
                 staged = []
                 self._run_aux(bufs, m, s_c, lane)
+                self._handover_bufs(bufs, m, lane)
                 lane.chain.execute(bufs, m, s_c)
+                self._run_tail(bufs, m, s_c, lane)
                 for name, (col, length, direct) in host_out.items():
                     d = bufs[name]
                     if name in in_place_out:
@@ -2530,9 +2556,66 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
     for st in stages:  # columns of the input table that only a stage reads are linked like the program's own
         for nm, v in st["in_vars"].items():
             in_bind.setdefault(nm, v)
-    chain = ProcessingChain(p, in_bind, out_bind, consts, n_rows, proc_strings, ft, aux_desc, stages=stages, ext_alias=ext_alias)
+    tail = None
+    if not stage_mode and os.environ.get("DSPEED_HIP_NO_SCALAR_TAIL", "0") != "1":
+        tail = _split_scalar_tail(p, ft)
+    chain = ProcessingChain(p, in_bind, out_bind, consts, n_rows, proc_strings, ft, aux_desc, stages=stages, ext_alias=ext_alias, tail=tail)
     chain.vector_lens = vector_lens  # variable-length outputs -> the input column that holds their per-event lengths
     return chain, tb_out
+
+
+_SCALAR_OPS = (_lib.OP_SCALAR_AFFINE, _lib.OP_SCALAR_DIV, _lib.OP_SCALAR_CONVERT, _lib.OP_SCALAR_FUNC, _lib.OP_STORE_SCALAR)
+#: a tail is cut off when it has at least this many ops (a launch and a column per handed-over register have to pay for themselves)
+SCALAR_TAIL_MIN_OPS = 8
+
+
+def _split_scalar_tail(p: Program, ft):
+    """Cut the all-scalar tail off a program: the ops after the last one that touches a waveform -- arithmetic between per-event values,
+    unit conversions, stores; two thirds of a whole recipe's ops -- become a program of their own that ``dsp_chain_create`` gives to the
+    row-per-lane kernel (dsp_scalar.hip: 64 rows per interpreter dispatch instead of one).  The head stores every register the tail
+    reads and does not make itself into a column (``tail:r<k>``), the tail starts by loading them.  ``p`` is changed in place; returns the
+    tail's description ({"program", "handover": [binding names]}) or None when the program has no tail worth a launch."""
+    ops = p.ops
+    k = len(ops)
+    while k > 0 and ops[k - 1][0] in _SCALAR_OPS:
+        k -= 1
+    if k == 0 or len(ops) - k < SCALAR_TAIL_MIN_OPS:
+        return None
+    tail_ops = ops[k:]
+    written, live_in = set(), []
+    for opcode, dst, _src, _io, ip, sp in tail_ops:
+        reads = [a.index for a in sp if a.kind == _lib.ARG_REG]
+        if opcode == _lib.OP_STORE_SCALAR:
+            reads.append(ip[0])
+        for r in reads:
+            if r not in written and r not in live_in:
+                live_in.append(r)
+        if opcode != _lib.OP_STORE_SCALAR:
+            written.add(dst)
+    t = Program()
+    t.n_sregs = p.n_sregs
+    io_map = {}  # binding of the head -> the tail's copy of it
+
+    def tail_io(idx):
+        if idx not in io_map:
+            name, kind, code, length, offset, stride = p.io[idx]
+            io_map[idx] = t.add_io(name, kind, code, length, offset, stride)
+        return io_map[idx]
+
+    handover = []
+    del ops[k:]
+    for r in live_in:
+        name = f"tail:r{r}"
+        handover.append(name)
+        p.add_op(_lib.OP_STORE_SCALAR, io=p.add_io(name, _lib.IO_SCALAR_OUT, ft), ip=(r,))
+        t.add_op(_lib.OP_SCALAR_FUNC, dst=r, ip=(_lib.FN_COPY,),
+                 sp=(Scalar.input(t.add_io(name, _lib.IO_SCALAR_IN, ft)), Scalar.const(0.0), Scalar.const(0.0)))
+    for opcode, dst, src, io, ip, sp in tail_ops:
+        sp2 = tuple(Scalar.input(tail_io(a.index)) if a.kind == _lib.ARG_INPUT else a for a in sp)
+        t.add_op(opcode, dst=dst, src=src, io=tail_io(io) if opcode == _lib.OP_STORE_SCALAR else io, ip=ip, sp=sp2)
+    if len(t.io) > _lib.MAX_IO or len(p.io) > _lib.MAX_IO or len(p.ops) > _lib.MAX_OPS:
+        raise NotImplementedError("recipe is too large for one device chain (ops/slots/bindings limit)")
+    return {"program": t, "handover": handover}
 
 
 

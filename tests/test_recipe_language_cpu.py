@@ -13,6 +13,14 @@ M = "dspeed.processors"
 SCALAR_OPS = (_lib.OP_SCALAR_AFFINE, _lib.OP_SCALAR_DIV, _lib.OP_SCALAR_CONVERT, _lib.OP_STORE_SCALAR, _lib.OP_SCALAR_FUNC)
 
 
+
+@pytest.fixture(autouse=True)
+def _programs_whole(monkeypatch):
+    """these tests read the arithmetic between per-event values where the builder generated it: the all-scalar tail stays in the program
+    (the test of the split itself takes the switch off again)"""
+    monkeypatch.setenv("DSPEED_HIP_NO_SCALAR_TAIL", "1")
+
+
 def _tb(n=4, wf_len=8192, t0=0.0, dtype=np.uint16):
     return {"waveform": WaveformInput(np.zeros((n, wf_len), dtype=dtype), 16.0, t0), "baseline": np.zeros(n, dtype=np.float32)}
 
@@ -315,3 +323,32 @@ def test_negative_steps_become_backward_copies():
     for expr in ("waveform[10:100:-1]", "waveform[::0]"):
         with pytest.raises(ProcessingChainError):
             build_processing_chain({"outputs": ["x"], "processors": {"x": expr}}, tb)
+
+
+def test_the_scalar_tail_of_a_program_becomes_a_program_of_its_own(monkeypatch):
+    monkeypatch.delenv("DSPEED_HIP_NO_SCALAR_TAIL")
+    """everything behind the last op that touches a waveform -- arithmetic between per-event values, unit conversions, stores -- is cut off
+    (processing_chain._split_scalar_tail) for the row-per-lane kernel; the head hands the registers the tail reads over as columns"""
+    scalar = (_lib.OP_SCALAR_AFFINE, _lib.OP_SCALAR_DIV, _lib.OP_SCALAR_CONVERT, _lib.OP_SCALAR_FUNC, _lib.OP_STORE_SCALAR)
+    chain, _, out = build_processing_chain(recipes.ICPC, _tb())
+    head, tail = chain.program, chain._tail["program"]
+    assert tail.slots == [] and all(o[0] in scalar for o in tail.ops) and len(tail.ops) >= 40
+    hand = chain._tail["handover"]
+    # the head ends with one store per handed-over register, the tail starts with one load per register, same names, same registers
+    n = len(hand)
+    assert [o[0] for o in head.ops[-n:]] == [_lib.OP_STORE_SCALAR] * n and [head.io[o[3]][0] for o in head.ops[-n:]] == hand
+    assert [o[0] for o in tail.ops[:n]] == [_lib.OP_SCALAR_FUNC] * n and [tail.io[o[5][0].index][0] for o in tail.ops[:n]] == hand
+    assert [o[4][0] for o in head.ops[-n:]] == [o[1] for o in tail.ops[:n]]
+    assert head.ops[-n - 1][0] not in scalar, "the cut is right behind the last waveform op"
+    # every output column of the recipe is stored exactly once, by one of the two programs
+    stored = [prog.io[o[3]][0] for prog in (head, tail) for o in prog.ops if o[0] == _lib.OP_STORE_SCALAR and prog.io[o[3]][0].startswith("out:")]
+    assert sorted(stored) == sorted(f"out:{k}" for k in out)
+    # a register the tail computes itself is not handed over; a short tail stays where it is
+    written = set()
+    for o in tail.ops[n:]:
+        for a in o[5]:
+            assert a.kind != _lib.ARG_REG or a.index in written or f"tail:r{a.index}" in hand
+        if o[0] != _lib.OP_STORE_SCALAR:
+            written.add(o[1])
+    small, _, _ = build_processing_chain(recipes.C2, _tb(wf_len=4096) | {"t_pick": np.zeros(4, dtype=np.float32)})
+    assert small._tail is None
