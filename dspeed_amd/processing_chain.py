@@ -256,6 +256,18 @@ class ProcessingChain:
     def get_timing(self) -> dict:
         return dict(self._timing)
 
+    def kernels(self) -> list:
+        """Which kernel every launch of a pass runs on, in launch order: [(what, kernel name)] -- the fits on the rows, the stages ahead of
+        the program, the program, its scalar tail.  A stage or program that misses the specialised shapes shows up here
+        as ``dsp_vm_kernel``: the place to look when a recipe is slower than its neighbours."""
+        self._ensure()
+        rep = [(f"linear_slope_fit x {len(g['fits'])} on the rows of {g['wf']}", "dsp_fit_rows_kernel") for g in self._aux]
+        rep += [(st["what"], st["chain"].kernel_name) for st in self._stages]
+        rep.append(("program", self._chain.kernel_name))
+        if self._lanes and self._lanes[0].tail is not None:
+            rep.append(("scalar tail of the program", self._lanes[0].tail.kernel_name))
+        return rep
+
     def __str__(self):
         return "Input variables: " + str(list(self._in_vars)) + "\nProcessors:\n  " + "\n  ".join(self.proc_strings)
 
