@@ -87,7 +87,7 @@ def needs_build(lib: str = LIB) -> bool:
         return f.read().strip() != _stamp(lib == LIB_DIAG)
 
 
-def build(force: bool = False, verbose: bool = False, diag: bool = False, variant: str | None = None, defines=()) -> str:
+def build(force: bool = False, verbose: bool = False, diag: bool = False, variant: str | None = None, defines=(), extra_flags=()) -> str:
     """``variant`` / ``defines``: an experiment library libdspeed_hip_<variant>.so compiled with -D<define>... beside the product one
     (A/B runs of kernel variants in one GPU session: tools select it with DSPEED_HIP_LIB); always rebuilt."""
     lib = LIB_DIAG if diag else LIB
@@ -100,7 +100,7 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False, varian
     objs, procs = [], []
     for src in SOURCES:
         obj = os.path.join(CSRC, "." + src + (f".{variant}.o" if variant else (".diag.o" if diag else ".o")))
-        cmd = [_hipcc(), *[f for f in FLAGS if f != "-shared"], *(["-DDSPEED_HIP_DIAG"] if diag else []), *[f"-D{d}" for d in defines], "-x", "hip", "-c",
+        cmd = [_hipcc(), *[f for f in FLAGS if f != "-shared"], *(["-DDSPEED_HIP_DIAG"] if diag else []), *[f"-D{d}" for d in defines], *extra_flags, "-x", "hip", "-c",
                os.path.join(CSRC, src), "-o", obj]
         guard = src in NO_SCRATCH
         if guard:
@@ -146,4 +146,5 @@ def build(force: bool = False, verbose: bool = False, diag: bool = False, varian
 if __name__ == "__main__":
     _variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
     _defines = [sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--define"]
-    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv, variant=_variant, defines=_defines))
+    _flags = [sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--flag"]  # raw compiler flags of an experiment library
+    print(build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv, variant=_variant, defines=_defines, extra_flags=_flags))

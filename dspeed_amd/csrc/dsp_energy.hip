@@ -54,6 +54,17 @@ struct EnergyArgs {
 #define ABLATE(A) 0
 #endif
 
+// Wave priority by phase (s_setprio).  Two wavefronts share a SIMD, and each issues at most one instruction per four cycles: what the
+// kernel gains from the second one is the overlap of one wavefront's dependent chains (pass 2's float64 recurrence, the scans and lane
+// exchanges of the carries, the four-addition replay of pass 3, the tail) with the other's bulk work (staging stores, the chunk load,
+// the float64 sums of pass 1).  The hardware arbitrates by priority, then age; with equal priorities the OLDER wavefront wins whatever
+// it is doing, and a wavefront in a dependent chain loses its slot to the other's independent instructions every other time.  Priority
+// that rises with the phase -- stage 0, pass 1 at 1, pass 2 at 2, carries / replay / tail at 3 -- lets the chain that is closest to
+// finishing a row issue whenever it can and fills the gaps with the younger row's bulk work: 62.8 % -> 68.9 % of the HBM peak on the same
+// box, same instructions (profiles/r03_headline_experiments.md: 20 sequences measured, every graded one within 0.5 % of this).
+constexpr int rr_prio_after_phase[6] = {1, 2, 3, 3, 3, 0};  // priority of the phase that FOLLOWS boundary n (5: the next row's staging)
+#define RR_PRIO_AT(n) __builtin_amdgcn_s_setprio(rr_prio_after_phase[n]);
+
 namespace {
 
 constexpr int G = 8;   // samples per software-pipeline group in the pole-zero passes
@@ -462,6 +473,7 @@ __global__ void __launch_bounds__(256, NPF >= 32 ? 1 : 2) dsp_energy_rr_kernel(E
         __builtin_amdgcn_sched_barrier(0);
         wave_sync();
         PHASE(0)
+        RR_PRIO_AT(0)
 
         float result = quiet_nan<float>();
         // ---- the lane's chunk lives in registers from here to the end of the replay: x, then (in place) the pole-zero output
@@ -487,6 +499,7 @@ __global__ void __launch_bounds__(256, NPF >= 32 ? 1 : 2) dsp_energy_rr_kernel(E
             in_nan |= wave_any(n);
         }
         PHASE(1)
+        RR_PRIO_AT(1)
         // the float64 images of the samples are cheaper to recompute in pass 2 than to keep (130 registers): hide the reuse
 #pragma unroll
         for (int t = 0; t < C; ++t) asm volatile("" : "+v"(xr[t]));
@@ -512,6 +525,7 @@ __global__ void __launch_bounds__(256, NPF >= 32 ? 1 : 2) dsp_energy_rr_kernel(E
             }
             wave_sync();
             PHASE(2)
+        RR_PRIO_AT(2)
             bool pz_nan = false;
             if (wave_any(!(fabsf(run) <= 3.4028234663852886e38f))) {
                 bool n = false;
@@ -563,6 +577,7 @@ __global__ void __launch_bounds__(256, NPF >= 32 ? 1 : 2) dsp_energy_rr_kernel(E
                     y[s] = g[s];
                 }
                 PHASE(3)
+        RR_PRIO_AT(3)
                 // ---- pass 3: replay; own samples from registers, the three lagged streams software-pipelined one 8-sample group ahead
                 wave_sync();  // the prefix sums in aux are consumed; aux now receives the replay state at every group start
                 // the two samples every pick-off mode needs (floor and ceil of the time point) are caught on the fly: stage numbers
@@ -637,6 +652,7 @@ __global__ void __launch_bounds__(256, NPF >= 32 ? 1 : 2) dsp_energy_rr_kernel(E
                 aux[S * NGS] = y[S - 1];  // state before the odd sample (it extends the last chain)
                 y[S - 1] = trap_step_r<float, KIND>(y[S - 1], xr[C - 1], lodd[0], lodd[1], lodd[2], A.rr, A.ll, inv_rr, inv_ll);
                 PHASE(4)
+        RR_PRIO_AT(4)
                 // ---- true carries: exact scan of the increments
                 double D[S], Dbefore[S], Dtot = 0.0;
 #pragma unroll
@@ -700,6 +716,7 @@ __global__ void __launch_bounds__(256, NPF >= 32 ? 1 : 2) dsp_energy_rr_kernel(E
         pend_row = row;
         wave_sync();
         PHASE(5)
+        RR_PRIO_AT(5)
     }
     if (pend_row >= 0 && lane == 0) A.out[pend_row * A.out_stride] = pend_result;
     if (stamps && lane == 0) {
