@@ -1859,8 +1859,21 @@ def _extract_stages(b: _Builder, steps, out_pars, n_rows, ft):
         if st[0] != "windower" or not any(st is x for x in steps):
             continue
         src, start, w_le = st[1]
-        if not (isinstance(src, Var) and row_input(src) and np.dtype(src.dtype) == np.dtype(np.float32) and plain_scalar(start) and isinstance(w_le, Var)):
+        if not (isinstance(src, Var) and row_input(src) and np.dtype(src.dtype) == np.dtype(np.float32) and isinstance(w_le, Var)):
             continue
+        if not plain_scalar(start):
+            # the window's start (tp_0_est) is computed by the program from rows in HBM (the t0-filtered waveform): what computes it moves ahead
+            # as a small program of its own on those rows, like the operands of the t0 chain's walk above
+            pst = producer_of(start) if isinstance(start, Var) else None
+            rows_v = next((base_of(x) for x, r in zip(pst[1], _roles(pst[0])) if r not in "WS" and isinstance(x, Var) and row_input(x)), None) if pst else None
+            group = [g for g in (rows_steps(rows_v) if rows_v is not None else []) if any(g is x for x in steps)]
+            if pst is None or not any(pst is g for g in group):
+                continue
+            moved = [o for g in group for o, r in zip(g[1], _roles(g[0])) if r in "WS"]
+            build(group, moved, f"per-event values of {rows_v.name}")
+            for o in moved:
+                o.kind = "scalar"
+            steps = [x for x in steps if not any(x is g for g in group)]
         chain_steps, v = [st], w_le
         for fn_name in ("avg_current", "upsampler", "moving_window_multi", "min_max"):
             nxt = only_user(v, fn_name)

@@ -410,3 +410,23 @@ def test_results_do_not_depend_on_the_neighbours():
         chain.execute(a, min(n, a + 37))
     for k in whole:
         assert np.array_equal(out[k], whole[k], equal_nan=True), k
+
+
+def test_current_branch_alone_moves_its_start_ahead_too():
+    """asked for the current branch only, the recipe has no t0 chain on rows that would have put tp_0_est into HBM: the builder moves what
+    computes the window's start ahead of the program by itself, the branch runs on the lane-per-waveform kernel, and the numbers are the
+    full recipe's"""
+    from dspeed_amd.processing_chain import WaveformInput, build_processing_chain
+
+    rng = np.random.default_rng(31)
+    n = 70
+    wf, bl = _synth(rng, n)
+    tb = {"waveform": WaveformInput(wf, 16.0, 48000.0), "baseline": bl}
+    full, _, ref = build_processing_chain(recipes.ICPC, tb)
+    full.execute()
+    part, _, out = build_processing_chain(recipes.ICPC, tb, outputs=["A_max", "tp_aoe_max", "tp_aoe_samp"])
+    part.execute()
+    assert [st["what"] for st in part._stages][-2:] == ["per-event values of wf_t0_filter", "current branch of wf_pz on rows"]
+    assert "dsp_current_kernel" in [k for _w, k in part.kernels()]
+    for k in out:
+        assert np.array_equal(out[k], ref[k], equal_nan=True), k
