@@ -24,7 +24,18 @@ ARG_CONST, ARG_INPUT, ARG_REG = range(3)
  OP_ASYM_TRAP, OP_PICKOFF, OP_TIME_POINT_THRESH, OP_MIN_MAX, OP_DWT_HAAR, OP_CONVOLVE, OP_COPY, OP_TRAP_PICKOFF, OP_AMAX,
  OP_SCALAR_AFFINE, OP_MEAN_BELOW, OP_CONVOLVE_AMAX, OP_WINDOWER, OP_AVG_CURRENT, OP_TRAP_WINDOW_PICKOFF, OP_TRAP_REDUCE, OP_UPSAMPLER, OP_MOVING_WINDOW_MULTI, OP_LINEAR_SLOPE_FIT,
  OP_SCALAR_CONVERT, OP_SCALAR_DIV, OP_INTERP_TIME_POINT_THRESH, OP_MIN_MAX_NORM, OP_ELEMENTWISE, OP_SCALAR_FUNC) = range(1, 34)
-(FN_ADD, FN_SUB, FN_MUL, FN_DIV, FN_LT, FN_LE, FN_GT, FN_GE, FN_EQ, FN_NE, FN_WHERE, FN_ISNAN, FN_ISFINITE, FN_NEG, FN_COPY, FN_FLOORDIV) = range(16)
+(FN_ADD, FN_SUB, FN_MUL, FN_DIV, FN_LT, FN_LE, FN_GT, FN_GE, FN_EQ, FN_NE, FN_WHERE, FN_ISNAN, FN_ISFINITE, FN_NEG, FN_COPY, FN_FLOORDIV,
+ FN_IADD, FN_ISUB, FN_IMUL, FN_IFLOORDIV, FN_ICAST) = range(21)
+
+
+def fn_int(code, dtype):
+    """ip[0] of an integer loop: DSP_FN_I* | DSP_FN_INT(bits, signed)  (dspeed_hip.h)"""
+    import numpy as np
+
+    dtype = np.dtype(dtype)
+    return code | (dtype.itemsize * 8) << 8 | (1 << 16 if dtype.kind == "i" else 0)
+
+
 MAX_OPS, MAX_SLOTS, MAX_IO, MAX_SREGS = 192, 32, 64, 128
 
 

@@ -206,6 +206,15 @@ struct dsp_chain {
 // Does the program have the shape of the current-branch kernel (dsp_current.hip)?
 //   LOAD s0;  WINDOWER s1 <- s0 (start: constant or float32 column);  AVG_CURRENT s2 <- s1;  UPSAMPLER s3 <- s2;
 //   MOVING_WINDOW_MULTI d <- s3 (3 windows, alternating);  MIN_MAX of d;  STORE_SCALARs of its four registers
+// ip[0] of ELEMENTWISE / SCALAR_FUNC: a DSP_FN_* code; the integer loops carry their type (8, 16 or 32 bits; 32 only in the float64 chain,
+// whose values hold every 32-bit integer), the float ones nothing
+static bool fn_code_ok(int ip0, bool f64) {
+    const int code = DSP_FN_CODE(ip0), bits = DSP_FN_INT_BITS(ip0);
+    if (ip0 < 0 || code > DSP_FN_LAST || (ip0 >> 17) != 0) return false;
+    if (code >= DSP_FN_IADD && code <= DSP_FN_ICAST) return bits == 8 || bits == 16 || (bits == 32 && f64);
+    return (ip0 >> 8) == 0;
+}
+
 static bool match_current_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, const int32_t* slot_len, bool f64) {
     if (f64 || n_ops < 7) return false;
     const dsp_op &ld = ops[0], &wi = ops[1], &ac = ops[2], &up = ops[3], &mw = ops[4], &mm = ops[5];
@@ -1305,7 +1314,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 break;
             }
             case DSP_OP_ELEMENTWISE: {
-                if (!check_slot(P, o.dst) || o.ip[0] < 0 || o.ip[0] > DSP_FN_LAST) return fail(DSP_ERR_ARG, "op %d: bad ELEMENTWISE", i);
+                if (!check_slot(P, o.dst) || !fn_code_ok(o.ip[0], f64)) return fail(DSP_ERR_ARG, "op %d: bad ELEMENTWISE", i);
                 const int opnd[3] = {o.src, o.ip[1], o.ip[2]};
                 int n_wf_opnd = 0;
                 for (int k = 0; k < 3; ++k) {
@@ -1318,7 +1327,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 break;
             }
             case DSP_OP_SCALAR_FUNC:
-                if (o.dst < 0 || o.dst >= n_sregs || o.ip[0] < 0 || o.ip[0] > DSP_FN_LAST) return fail(DSP_ERR_ARG, "op %d: bad SCALAR_FUNC", i);
+                if (o.dst < 0 || o.dst >= n_sregs || !fn_code_ok(o.ip[0], f64)) return fail(DSP_ERR_ARG, "op %d: bad SCALAR_FUNC", i);
                 break;
             case DSP_OP_CONVOLVE:
             case DSP_OP_CONVOLVE_AMAX: {

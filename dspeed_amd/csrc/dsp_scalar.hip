@@ -19,7 +19,9 @@
 namespace {
 
 template <typename T>
-__device__ __forceinline__ T sc_apply(int fn, T a, T b, T c) {
+__device__ __forceinline__ T sc_apply(int ip0, T a, T b, T c) {
+    const int fn = DSP_FN_CODE(ip0);
+    if (fn >= DSP_FN_IADD && fn <= DSP_FN_ICAST) return int_loop_apply<T>(fn, a, b, ip0);  // (the integer loops: dsp_wave.h)
     switch (fn) {
         case DSP_FN_ADD: return a + b;
         case DSP_FN_SUB: return a - b;

@@ -244,8 +244,9 @@ __device__ __forceinline__ void op_store_scalar(Ctx<T>& cx, const DSP_PROG DevOp
 // loop type, truth values as 0 / 1
 // ------------------------------------------------------------------------------------------------
 template <int FN, typename T>
-__device__ __forceinline__ T ew_apply(T a, T b, T c) {
-    if constexpr (FN == DSP_FN_ADD) return a + b;
+__device__ __forceinline__ T ew_apply(T a, T b, T c, int meta) {
+    if constexpr (FN >= DSP_FN_IADD && FN <= DSP_FN_ICAST) return int_loop_apply<T>(FN, a, b, meta);  // (the integer loops: dsp_wave.h)
+    else if constexpr (FN == DSP_FN_ADD) return a + b;
     else if constexpr (FN == DSP_FN_SUB) return a - b;
     else if constexpr (FN == DSP_FN_MUL) return a * b;
     else if constexpr (FN == DSP_FN_DIV) return a / b;
@@ -265,7 +266,12 @@ __device__ __forceinline__ T ew_apply(T a, T b, T c) {
 
 template <typename T, typename F>
 __device__ __forceinline__ void ew_dispatch(int fn, F&& f) {
-    switch (fn) {
+    switch (DSP_FN_CODE(fn)) {
+        case DSP_FN_IADD: f(std::integral_constant<int, DSP_FN_IADD>()); break;
+        case DSP_FN_ISUB: f(std::integral_constant<int, DSP_FN_ISUB>()); break;
+        case DSP_FN_IMUL: f(std::integral_constant<int, DSP_FN_IMUL>()); break;
+        case DSP_FN_IFLOORDIV: f(std::integral_constant<int, DSP_FN_IFLOORDIV>()); break;
+        case DSP_FN_ICAST: f(std::integral_constant<int, DSP_FN_ICAST>()); break;
         case DSP_FN_ADD: f(std::integral_constant<int, DSP_FN_ADD>()); break;
         case DSP_FN_SUB: f(std::integral_constant<int, DSP_FN_SUB>()); break;
         case DSP_FN_MUL: f(std::integral_constant<int, DSP_FN_MUL>()); break;
@@ -315,7 +321,7 @@ __device__ __forceinline__ void op_elementwise(Ctx<T>& cx, const DSP_PROG DevOp&
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                T v = ew_apply<decltype(fn)::value, T>(a[j], b[j], c[j]);
+                T v = ew_apply<decltype(fn)::value, T>(a[j], b[j], c[j], op.ip[0]);
                 if (first + t0 + j >= sd.len) v = (T)0;  // (beyond the waveform: kept finite)
                 nan |= (v != v);
                 pd[t0 + j] = v;
@@ -333,7 +339,7 @@ template <typename T>
 __device__ __forceinline__ void op_scalar_func(Ctx<T>& cx, const DSP_PROG DevOp& op) {
     const T a = cx.scalar(op.sp[0]), b = cx.scalar(op.sp[1]), c = cx.scalar(op.sp[2]);
     T v = (T)0;
-    ew_dispatch<T>(op.ip[0], [&](auto fn) { v = ew_apply<decltype(fn)::value, T>(a, b, c); });
+    ew_dispatch<T>(op.ip[0], [&](auto fn) { v = ew_apply<decltype(fn)::value, T>(a, b, c, op.ip[0]); });
     if (lane_id() == 0) cx.sregs()[op.dst] = v;
     wave_sync();
 }

@@ -177,5 +177,49 @@ __device__ __forceinline__ bool pickoff_in_range(T t_in, int n) {
     return !(t_in != t_in) && !(t_in < (T)0) && !(t_in > (T)(n - 1));
 }
 
+// ------------------------------------------------------------------------------------------------
+// NumPy's integer ufunc loops on values held in the float loop type (DSP_FN_IADD ... DSP_FN_ICAST, dspeed_hip.h): exact 64-bit integer
+// arithmetic, then the wrap to the loop's integer type
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t int_loop_value(double a) {
+    // (integer variables hold integers; anything else -- a NaN waveform of a processor upstream -- becomes x86-64's "integer indefinite")
+    return (a == a && __builtin_fabs(a) < 9223372036854775808.0) ? (int64_t)a : INT64_MIN;
+}
+
+__device__ __forceinline__ double int_loop_wrap(int64_t r, int meta) {
+    const int bits = DSP_FN_INT_BITS(meta);  // 8, 16, 32
+    const uint64_t m = (uint64_t)r & ((1ull << bits) - 1ull);
+    int64_t v = (int64_t)m;
+    if (DSP_FN_INT_SIGNED(meta) && ((m >> (bits - 1)) & 1ull)) v -= (int64_t)1 << bits;
+    return (double)v;
+}
+
+template <typename T>
+__device__ __forceinline__ T int_loop_apply(int fn, T a_, T b_, int meta) {
+    if (fn == DSP_FN_ICAST) {
+        const double t = __builtin_trunc((double)a_);
+        int64_t r;
+        if (DSP_FN_INT_BITS(meta) == 32 && !DSP_FN_INT_SIGNED(meta))
+            r = int_loop_value(t);  // (npy_uint)x goes through the 64-bit conversion
+        else
+            r = (t >= -2147483648.0 && t <= 2147483647.0) ? (int64_t)t : (int64_t)INT32_MIN;  // ... the others through the 32-bit one
+        return (T)int_loop_wrap(r, meta);
+    }
+    const int64_t a = int_loop_value((double)a_), b = int_loop_value((double)b_);
+    uint64_t r;
+    if (fn == DSP_FN_IADD) r = (uint64_t)a + (uint64_t)b;
+    else if (fn == DSP_FN_ISUB) r = (uint64_t)a - (uint64_t)b;
+    else if (fn == DSP_FN_IMUL) r = (uint64_t)a * (uint64_t)b;
+    else {  // DSP_FN_IFLOORDIV
+        if (b == 0) r = 0;
+        else if (b == -1) r = 0ull - (uint64_t)a;  // (the type's minimum // -1 wraps back to the minimum, as NumPy's loop returns it)
+        else {
+            int64_t q = a / b;
+            if ((a % b != 0) && ((a < 0) != (b < 0))) q -= 1;
+            r = (uint64_t)q;
+        }
+    }
+    return (T)int_loop_wrap((int64_t)r, meta);
+}
 
 }  // namespace

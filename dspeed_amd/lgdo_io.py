@@ -193,6 +193,33 @@ def open_friend(file, group, iterator: bool = False, n_rows: int | None = None, 
     return lh5.LH5Store(keep_open=True).read(group, file, n_rows=n_rows)
 
 
+#: callables ``(file, path) -> array | number | None`` tried in turn before the built-in ways of loading a constant (other formats, tests)
+CONSTANT_LOADERS: list = []
+
+
+def load_constant(file: str, path: str):
+    """``loadlh5(file, path)`` of the recipe language: the object ``path`` of ``file`` as a constant of the chain -- an array (the taps of a
+    filter) or a number (reference processing_chain.py:1444-1467).  ``.npz`` files are read here (``path`` names the array), LH5 files
+    through ``lgdo.lh5``."""
+    for loader in CONSTANT_LOADERS:
+        got = loader(file, path)
+        if got is not None:
+            return got
+    try:
+        if isinstance(file, str) and file.endswith(".npz"):
+            with np.load(file) as z:
+                key = path if path in z.files else path.strip("/")
+                if key not in z.files:
+                    raise ValueError(f"no array '{path}'")
+                got = z[key]
+            return got[()] if got.ndim == 0 else got
+        _, lh5 = require_lh5(f"loadlh5('{file}', '{path}')")
+        obj = lh5.read(path, file)
+        return obj.value if hasattr(obj, "value") else np.asarray(obj.nda)
+    except (ValueError, OSError, KeyError) as exc:
+        raise ProcessingChainError(f"LH5 file not found: {file}") from exc
+
+
 def snapshot(cols: dict) -> dict:
     """own copies of a chunk's columns: an LH5Iterator refills the same buffers on its next read"""
     from .processing_chain import WaveformInput

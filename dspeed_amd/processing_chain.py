@@ -204,6 +204,33 @@ def _is_int_dtype(a) -> bool:
     return dt is not None and np.dtype(dt).kind in "iub"
 
 
+_INT_LOOPS = "bBhHiIlLqQ"  # the integer signatures of numpy.add / subtract / multiply / floor_divide / negative, in the order of ufunc.types
+
+
+def _int_loop_of(variables, src):
+    """The integer ufunc loop the reference picks for these variables: the first signature every variable can be cast to
+    (np.can_cast per parameter, reference :1565-1572; the first one left, :1654-1664).  Constants do not take part: they are converted to
+    the loop's type afterwards (:1765-1768)."""
+    dts = [np.dtype((v[1] if isinstance(v, tuple) else v).dtype) for v in variables]
+    if all(d == np.dtype(np.bool_) for d in dts):
+        raise NotImplementedError(f"'{src}' is arithmetic between truth values (NumPy's '??' loops: logical or / and); not available on the device path")
+    c = next((c for c in _INT_LOOPS if all(np.can_cast(d, c) for d in dts)), None)
+    if c is None or np.dtype(c).itemsize > 4:
+        raise NotImplementedError(f"'{src}' selects a 64-bit integer loop in the reference ({', '.join(d.name for d in dts)}); the device path holds "
+                                  "integers of up to 32 bits -- make one operand a float (astype)")
+    return np.dtype(c)
+
+
+def _int_loop_const(c, dt, src):
+    """a constant beside integer variables: the reference converts it to the loop's type, dtype.type(np.round(c))  (:1765-1768)"""
+    if isinstance(c, Quantity):
+        raise NotImplementedError(f"'{src}': a time beside integer variables")
+    r = int(np.round(float(c)))
+    if not np.iinfo(dt).min <= r <= np.iinfo(dt).max:
+        raise NotImplementedError(f"'{src}': {c} does not fit the {dt.name} loop the integer operands select (the reference wraps it around)")
+    return float(r)
+
+
 _GENERATORS = ("cusp_filter", "zac_filter", "t0_filter", "moving_slope")
 _MODULES = ("dspeed.processors", "dspeed_amd.processors", "numpy", "np")
 _NUMPY_BINARY = {"add": ast.Add, "subtract": ast.Sub, "multiply": ast.Mult, "divide": ast.Div, "true_divide": ast.Div}
@@ -803,9 +830,17 @@ class _Builder:
             if _is_scalar(v):
                 if isinstance(n.op, ast.UAdd):
                     return v
+                if _is_int_dtype(v):  # numpy.negative's integer loops: 0 - v in the variable's type
+                    dt = _int_loop_of([v], src)
+                    return self._scalar_func(_lib.fn_int(_lib.FN_ISUB, dt), [0.0, v], f"(-{v.name})", v.unit, v.is_coord, v.grid, dt)
                 return SExpr("affine", (v, -1.0, -0.0), f"(-{v.name})", v.unit, v.is_coord, v.grid)
             if _is_wf(v):
-                return v if isinstance(n.op, ast.UAdd) else self._elementwise(_lib.FN_NEG, [v], f"(-{self._nm(v)})", src, self._unit_of(v))
+                if isinstance(n.op, ast.UAdd):
+                    return v
+                if _is_int_dtype(v):
+                    dt = _int_loop_of([v], src)
+                    return self._elementwise(_lib.fn_int(_lib.FN_ISUB, dt), [0.0, v], f"(-{self._nm(v)})", src, self._unit_of(v), dt)
+                return self._elementwise(_lib.FN_NEG, [v], f"(-{self._nm(v)})", src, self._unit_of(v))
             if isinstance(v, (Var, tuple)):
                 raise ProcessingChainError(f"cannot negate {v!r} in '{src}'")
             return -v if isinstance(n.op, ast.USub) else v
@@ -868,7 +903,7 @@ class _Builder:
                 idx = self._eval(n.slice, src, new)
                 vlen = base.vector_len if isinstance(base, Var) else None
                 if not _is_scalar(idx) and vlen is not None and not isinstance(idx, (Quantity, tuple, Grid)) and float(idx) < 0:
-                    idx = self._scalar_binop(ast.Add(), vlen, int(round(float(idx))), src)  # -k counts from the row's own end (:972-973)
+                    idx = self._scalar_binop(ast.Sub(), vlen, -int(round(float(idx))), src)  # -k counts from the row's own end: "len-k" (:972-973)
                 if _is_scalar(idx):
                     # a per-event index: the reference adds get_default(w, i, NaN) (processors/get.py:50-92) -- the sample, or NaN when the
                     # index lies outside the array or the sample itself is NaN; a negative index counts from the end
@@ -927,6 +962,12 @@ class _Builder:
             return out
         if isinstance(n, ast.Call) and isinstance(n.func, ast.Name):
             f = n.func.id
+            if f == "loadlh5":  # loadlh5(file, path): an object of an LH5 file as a constant (reference :1444-1467)
+                if len(n.args) != 2 or not all(isinstance(x, ast.Constant) and isinstance(x.value, str) for x in n.args):
+                    raise ProcessingChainError(f"loadlh5() takes a file and a path in it, both strings, in '{src}'")
+                from .lgdo_io import load_constant
+
+                return load_constant(n.args[0].value, n.args[1].value)
             if f in _CALLS:
                 a = [self._eval(x, src, new) for x in n.args]
                 if f == "len":
@@ -954,8 +995,20 @@ class _Builder:
                     return bool(getattr(np, f)(float(x)))
                 if f == "astype":  # a copy in another type (reference :1268-1300); the device loops are float32 / float64
                     x, d = a[0], np.dtype(a[1][1] if isinstance(a[1], tuple) else a[1])
+                    if not (_is_wf(x) or _is_scalar(x)):
+                        raise ProcessingChainError(f"cannot call astype() on {x!r}")
+                    if d.kind in "iu" and d.itemsize <= 4:  # numpy.copyto(casting="unsafe"): truncation, then the wrap to the type
+                        fn, nm = _lib.fn_int(_lib.FN_ICAST, d), f"{self._nm(x)}.astype(`{d.char}`)"
+                        if _is_wf(x):
+                            return self._elementwise(fn, [x], nm, src, self._unit_of(x), d)
+                        return self._scalar_func(fn, [x], nm, x.unit, x.is_coord, x.grid, d)
+                    if d == np.dtype(np.bool_):  # ... to a truth value: x != 0
+                        nm = f"{self._nm(x)}.astype(`?`)"
+                        if _is_wf(x):
+                            return self._elementwise(_lib.FN_NE, [x, 0.0], nm, src, self._unit_of(x), np.bool_)
+                        return self._scalar_func(_lib.FN_NE, [x, 0.0], nm, x.unit, x.is_coord, x.grid, np.bool_)
                     if d.kind != "f" or d.itemsize < 4:
-                        raise NotImplementedError(f"astype to {d} is not available on the device path (float32 / float64 loops): '{src}'")
+                        raise NotImplementedError(f"astype to {d} is not available on the device path (float32 / float64 loops, integers of up to 32 bits): '{src}'")
                     if _is_wf(x):
                         out = self._elementwise(_lib.FN_COPY, [x], f"{self._nm(x)}.astype(`{d.char}`)", src, self._unit_of(x))
                     elif _is_scalar(x):
@@ -1164,15 +1217,18 @@ class _Builder:
         return out
 
     def _wf_binop(self, op, a, b, src):
-        fn, sym = {ast.Add: (_lib.FN_ADD, "+"), ast.Sub: (_lib.FN_SUB, "-"), ast.Mult: (_lib.FN_MUL, "*"),
-                   ast.Div: (_lib.FN_DIV, "/")}.get(type(op), (None, None))
-        if fn is None:
-            raise NotImplementedError(f"operator in '{src}' is not available on waveforms on the device path")
+        fn, sym = {ast.Add: (_lib.FN_ADD, "+"), ast.Sub: (_lib.FN_SUB, "-"), ast.Mult: (_lib.FN_MUL, "*"), ast.Div: (_lib.FN_DIV, "/"),
+                   ast.FloorDiv: (_lib.FN_FLOORDIV, "//")}.get(type(op), (None, None))
         variables = [x for x in (a, b) if _is_wf(x) or _is_scalar(x)]
-        if fn != _lib.FN_DIV and all(_is_int_dtype(x) for x in variables):
+        int_loop = fn not in (None, _lib.FN_DIV) and all(_is_int_dtype(x) for x in variables)
+        if fn is None or (fn == _lib.FN_FLOORDIV and not int_loop):
+            raise NotImplementedError(f"operator in '{src}' is not available on waveforms on the device path")
+        dtype = np.float32
+        if int_loop:
             # every variable is an integer: the reference's first matching ufunc loop is an integer one (:1565-1572), with its wrap-around
-            raise NotImplementedError(f"'{src}' is integer arithmetic in the reference (all operands are integer columns); the device loops "
-                                      "are float32 / float64 -- make one operand a float (astype)")
+            dtype = _int_loop_of(variables, src)
+            fn = _lib.fn_int({_lib.FN_ADD: _lib.FN_IADD, _lib.FN_SUB: _lib.FN_ISUB, _lib.FN_MUL: _lib.FN_IMUL, _lib.FN_FLOORDIV: _lib.FN_IFLOORDIV}[fn], dtype)
+            a, b = (x if (_is_wf(x) or _is_scalar(x)) else _int_loop_const(x, dtype, src) for x in (a, b))
         va, vb = _is_wf(a) or _is_scalar(a), _is_wf(b) or _is_scalar(b)
         ua, ub = (self._unit_of(a) if va else None), (self._unit_of(b) if vb else None)
         if va and vb:  # reference :848-862
@@ -1180,12 +1236,12 @@ class _Builder:
             if ta is not None and tb is not None:
                 unit = ua if sym in "+-" else None
             elif ua is not None and ub is not None:
-                unit = f"{ua}{sym}{ub}" if sym in "*/" else ua
+                unit = f"{ua}{sym}{ub}" if sym in ("*", "/", "//") else ua
             else:
                 unit = ua if ua is not None else ub
         else:
             unit = ua if va else ub
-        return self._elementwise(fn, [a, b], f"({self._nm(a)}{sym}{self._nm(b)})", src, unit)
+        return self._elementwise(fn, [a, b], f"({self._nm(a)}{sym}{self._nm(b)})", src, unit, dtype)
 
     def _where(self, cond, a, b, src):
         """where(condition, a, b) / ``a if condition else b`` (reference :1345-1430)"""
@@ -1244,11 +1300,18 @@ class _Builder:
         """A binary operator with a per-event variable on at least one side: the reference adds the NumPy ufunc as a processor
         (:832-891), so the operands go through the same unit handling as any processor's (`_resolve`)."""
         sym = {ast.Add: "+", ast.Sub: "-", ast.Mult: "*", ast.Div: "/"}.get(type(op))
+        # every variable an integer column: the reference's first matching ufunc loop is an integer one (:1565-1572), with its wrap-around
+        int_dt = None
+        if type(op) in (ast.Add, ast.Sub, ast.Mult, ast.FloorDiv) and all(_is_int_dtype(x) for x in (a, b) if _is_scalar(x)):
+            int_dt = _int_loop_of([x for x in (a, b) if _is_scalar(x)], src)
         if isinstance(op, ast.FloorDiv):  # numpy.floor_divide as a processor: len(v)//2 and the like (reference :832-847)
             for x in (a, b):
                 if isinstance(x, (tuple, Grid, Quantity)) or (isinstance(x, Var) and x.kind != "scalar"):
                     raise NotImplementedError(f"'//' in '{src}' takes per-event variables and plain numbers")
             v = a if _is_scalar(a) else b
+            if int_dt is not None:
+                a, b = (x if _is_scalar(x) else _int_loop_const(x, int_dt, src) for x in (a, b))
+                return self._scalar_func(_lib.fn_int(_lib.FN_IFLOORDIV, int_dt), [a, b], f"({self._nm(a)}//{self._nm(b)})", v.unit, False, None, int_dt)
             return self._scalar_func(_lib.FN_FLOORDIV, [a, b], f"({self._nm(a)}//{self._nm(b)})", v.unit, False, None, None)
         if sym is None:
             raise NotImplementedError(f"operator in '{src}' is not supported between per-event variables")
@@ -1274,7 +1337,13 @@ class _Builder:
             out = SExpr(None, (), declared.name, declared.unit, declared.is_coord, declared.grid)
         if sym in "*/" and (isinstance(a, Quantity) or isinstance(b, Quantity)):
             raise NotImplementedError(f"'{src}': multiplying / dividing a per-event variable by a time is not supported")
+        a0, b0 = a, b
         _, (a, b, _o) = _resolve(self, "ssS", [a, b, out], expression=True)
+        if int_dt is not None and all(x is x0 for x, x0 in ((a, a0), (b, b0)) if _is_scalar(x0)):  # (a converted coordinate is a float)
+            a, b = (x if _is_scalar(x) else _int_loop_const(x, int_dt, src) for x in (a, b))
+            code = {"+": _lib.FN_IADD, "-": _lib.FN_ISUB, "*": _lib.FN_IMUL}[sym]
+            out.op, out.args, out.dtype = "func", (_lib.fn_int(code, int_dt), a, b), int_dt
+            return out
         if sym == "+":
             out.op, out.args = "affine", ((a, 1.0, b) if sa else (b, 1.0, a))
         elif sym == "-":
@@ -1508,9 +1577,27 @@ def _add_step(b: _Builder, key, node, new_vars, proc_strings):
                 a.length = src_len
             a.dtype = np.dtype(np.float32)
             a.is_coord = False
+    args = [_as_taps(b, a, function) if r == "t" else a for a, r in zip(args, roles)]
     _, args = _resolve(b, roles, args, same_dim_out=function in _SAME_DIM)
     b.steps.append((function, args, key))
     proc_strings.append(f"{function}({', '.join(str(a.name if isinstance(a, (Var, SExpr)) else a) for a in args)})")
+
+
+def _as_taps(b: _Builder, a, function):
+    """A constant array given where a processor takes its kernel -- a list literal, loadlh5(...), or a recipe entry holding one -- becomes
+    the same kind of variable a kernel generator leaves.  The reference passes the array itself, and its type takes part in the choice of
+    the loop (:1565-1572): a float64 or integer array selects the processor's float64 loop, which the float32 chain does not run."""
+    arr = a.const if isinstance(a, Var) and a.kind == "const" and isinstance(a.const, np.ndarray) else a
+    if not isinstance(arr, np.ndarray):
+        return a
+    if arr.ndim != 1 or arr.size < 1:
+        raise ProcessingChainError(f"{function}: the kernel must be a one-dimensional array, not one of shape {arr.shape}")
+    if not np.can_cast(arr.dtype, np.float32):
+        raise NotImplementedError(f"{function}: a {arr.dtype.name} kernel selects the float64 loop of the processor in the reference; give it "
+                                  "as float32 values")
+    b._anon += 1
+    name = a.name if isinstance(a, Var) else f"kernel#{b._anon}"
+    return Var(name, "taps", int(arr.size), np.float32, const=np.ascontiguousarray(arr, dtype=np.float32))
 
 
 def _fold_generator(b: _Builder, function, args, new_vars):
@@ -2164,6 +2251,13 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
                     code, *xs = a.args
                     if code == _lib.FN_COPY and getattr(a, "want_dtype", None) not in (None, ft):
                         raise NotImplementedError(f"{what}: astype to {a.want_dtype} in a chain whose loop type is {ft}")
+                    if (code >> 8) & 0xff == 32 and ft != np.dtype(np.float64):
+                        # a 32-bit integer loop between per-event values of a float32 chain (len(v) // 2, eventnumber + 1): the registers are
+                        # float32, so the operation is the float one -- the same integer as long as operands and result stay below 2**24
+                        float_fn = {_lib.FN_IADD: _lib.FN_ADD, _lib.FN_ISUB: _lib.FN_SUB, _lib.FN_IMUL: _lib.FN_MUL, _lib.FN_IFLOORDIV: _lib.FN_FLOORDIV}
+                        if code & 0xff not in float_fn:
+                            raise NotImplementedError(f"{what}: astype to a 32-bit integer in a chain whose loop type is {ft}")
+                        code = float_fn[code & 0xff]
                     sp = [opnd(x) for x in xs] + [Scalar.const(0.0)] * (3 - len(xs))
                     p.add_op(_lib.OP_SCALAR_FUNC, dst=r, ip=(code,), sp=tuple(sp))
                 elif a.op == "convert":
@@ -2270,6 +2364,9 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
             code, *opn, dst = args
             if code == _lib.FN_COPY and getattr(dst, "want_dtype", None) not in (None, ft):
                 raise NotImplementedError(f"{what}: astype to {dst.want_dtype} in a chain whose loop type is {ft}")
+            if (code >> 8) & 0xff == 32 and ft != np.dtype(np.float64):
+                raise NotImplementedError(f"{what}: a 32-bit integer loop on waveforms in a chain whose loop type is {ft} (its values do not hold every "
+                                          "32-bit integer); make one operand a float (astype)")
             slots, sps, srcs = [], [], []
             for x, r in zip(opn, fn[3:]):
                 if r == "w":
@@ -2535,7 +2632,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
                 if not (isinstance(vl, Var) and vl.is_input):
                     raise NotImplementedError(f"output '{o}': vector_len must be the length of an input array (len(<input>))")
                 vector_lens[o] = vl.source
-            tb_out[o] = np.empty((n_rows, v.length), dtype=odt)
+            tb_out[o] = np.empty((n_rows, v.length), dtype=v.dtype if _is_int_dtype(v) and v.dtype.kind != "b" else odt)
         else:
             # a time coordinate is written in its unit, not in samples: (index + grid offset) * period (reference :1990-2014, get_buffer(unit))
             unit_ns = _time_unit_ns(v.unit)
@@ -2555,7 +2652,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
             io = p.add_io(f"out:{o}", _lib.IO_SCALAR_OUT, odt)
             p.add_op(_lib.OP_STORE_SCALAR, io=io, ip=(reg.index,))
             out_bind[f"out:{o}"] = (SimpleNamespace(name=o, dtype=odt), None)
-            tb_out[o] = np.empty(n_rows, dtype=odt)
+            tb_out[o] = np.empty(n_rows, dtype=v.dtype if isinstance(v, SExpr) and _is_int_dtype(v) and v.dtype.kind != "b" else odt)
     aux_desc = []
     for gi, g in enumerate(aux):
         src = g["src"]

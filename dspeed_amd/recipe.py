@@ -23,7 +23,7 @@ from functools import reduce
 from .errors import ProcessingChainError
 
 #: functions of the argument language: ``round(x, 16*ns)`` as a recipe entry is an expression, not a processor call (reference :729-751)
-LANGUAGE_CALLS = ("round", "floor", "ceil", "trunc", "len", "float", "int", "where", "isnan", "isfinite", "astype")
+LANGUAGE_CALLS = ("round", "floor", "ceil", "trunc", "len", "float", "int", "where", "isnan", "isfinite", "astype", "loadlh5")
 #: module prefixes whose bare attributes are inline constants (``np.pi``)
 CONSTANT_MODULES = ("np", "numpy")
 #: names that are units, not variables

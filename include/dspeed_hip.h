@@ -229,7 +229,21 @@ typedef struct dsp_scalar_arg {
 #define DSP_FN_NEG 13
 #define DSP_FN_COPY 14     /* astype to the loop type */
 #define DSP_FN_FLOORDIV 15 /* floor(A / B): numpy.floor_divide between per-event values that hold integers (len(v) // 2) */
-#define DSP_FN_LAST 15
+/* NumPy's INTEGER ufunc loops (the first signature every operand can be cast to is an integer one when all operands are integer columns,
+ * processing_chain.py:1565-1572, 1654-1664): the operands hold integers exactly in the loop type, the operation is done on 64-bit integers
+ * and the result wrapped to the loop's integer type, the way 'hh->h', 'HH->H', 'ii->i' ... do.  ip[0] = DSP_FN_I* | DSP_FN_INT(bits, signed)
+ * with bits 8, 16 or 32 (32 needs the float64 chain: a float32 does not hold every int32). */
+#define DSP_FN_IADD 16
+#define DSP_FN_ISUB 17
+#define DSP_FN_IMUL 18
+#define DSP_FN_IFLOORDIV 19 /* floor division, 0 where B == 0 (numpy.floor_divide's integer loops) */
+#define DSP_FN_ICAST 20     /* astype to an integer type (:1268-1300, numpy.copyto(casting="unsafe")): truncation towards zero, then the wrap; a value the
+                             * C conversion does not define (NaN, beyond the 32-bit / 64-bit range it goes through) gives what x86-64's cvtt* gives */
+#define DSP_FN_LAST 20
+#define DSP_FN_INT(bits, is_signed) (((bits) << 8) | ((is_signed) ? 1 << 16 : 0))
+#define DSP_FN_CODE(ip0) ((ip0) & 0xff)
+#define DSP_FN_INT_BITS(ip0) (((ip0) >> 8) & 0xff)
+#define DSP_FN_INT_SIGNED(ip0) (((ip0) >> 16) & 1)
 
 typedef struct dsp_op {
     int32_t opcode;

@@ -87,15 +87,85 @@ def test_waveform_arithmetic_is_the_numpy_ufunc_in_the_loop_type(dtype):
         assert out[k].dtype == ft and np.array_equal(out[k], r.astype(ft), equal_nan=True), k  # one IEEE operation per sample: bit-identical
 
 
-def test_integer_arithmetic_is_refused_by_name():
+def _int_table(n=40, wf_len=256, seed=11):
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, 65536, (n, wf_len)).astype(np.uint16)
+    h = rng.integers(-32768, 32768, (n, wf_len)).astype(np.int16)
+    h[:, ::17] = 0
+    h[3, :8] = [-32768, -1, 1, 32767, -32768, 7, -7, 0]
+    return {"u": u, "h": h, "ev": rng.integers(0, 65536, n).astype(np.uint16), "k": rng.integers(-300, 300, n).astype(np.int16),
+            "baseline": rng.uniform(-100, 100, n).astype(np.float32)}
+
+
+def test_integer_ufunc_loops_wrap_the_way_numpys_do():
+    """every operand an integer column: the reference's first matching loop is an integer one (processing_chain.py:1565-1572, 1654-1664);
+    constants are rounded into the loop's type (:1765-1768)"""
+    tb = _int_table()
+    u, h, ev, k = tb["u"], tb["h"], tb["ev"], tb["k"]
+    procs = {"a": "u * 3", "b": "u + u", "c": "u - ev", "d": "h * h", "e": "h - 30000", "f": "-u", "g": "-h", "q": "h // 7", "r": "u // h2",
+             "h2": "astype(h, 'uint16')", "s": "h // k", "t": "u * 2.5", "ev3": "ev * 3", "evn": "-ev", "kq": "k // 7", "kk": "k * k - ev2",
+             "ev2": "astype(ev, 'int16')", "z": "h // 0"}
+    outs = ["a", "b", "c", "d", "e", "f", "g", "q", "r", "s", "t", "ev3", "evn", "kq", "kk", "z", "h2"]
+    chain, out = _run(procs, outs, tb)
+    assert chain.loop_dtype == np.float32
+    with np.errstate(all="ignore"):
+        h2 = h.astype(np.uint16)
+        want = {"a": u * np.uint16(3), "b": u + u, "c": u - ev[:, None], "d": h * h, "e": h - np.int16(30000), "f": -u, "g": -h, "q": h // np.int16(7),
+                "r": u // h2, "s": h // k[:, None], "t": u * np.uint16(2), "ev3": ev * np.uint16(3), "evn": -ev, "kq": k // np.int16(7),
+                "kk": k * k - ev.astype(np.int16), "z": h // np.int16(0), "h2": h2}
+    for name, w in want.items():
+        assert out[name].dtype == w.dtype and np.array_equal(out[name], w), name
+    assert (want["a"] != u.astype(np.int64) * 3).any() and (want["d"] != h.astype(np.int64) ** 2).any()  # (the inputs do wrap)
+
+
+def test_integer_loops_of_32_bits_run_in_the_float64_chain():
+    rng = np.random.default_rng(12)
+    n, L = 24, 128
+    w = rng.integers(-2**31, 2**31, (n, L)).astype(np.int32)
+    w[0, :4] = [-2**31, -1, 2**31 - 1, 0]
+    m = rng.integers(-50000, 50000, (n, L)).astype(np.int32)
+    m[:, ::9] = 0
+    m[0, :4] = -1
+    ev = rng.integers(0, 2**32, n).astype(np.uint32)
+    tb = {"w": w, "m": m, "ev": ev, "u": rng.integers(0, 65536, (n, L)).astype(np.uint16)}
+    procs = {"a": "w * m", "b": "w + w", "c": "w // m", "d": "-w", "e": "u * m", "ev3": "ev * 3", "evm": "ev - 4000000000", "cast": "astype(w / 7, 'int32')",
+             "ucast": "astype(m / 3, 'uint32')", "b8": "astype(m, 'int8')"}
+    chain, out = _run(procs, list(procs), tb)
+    assert chain.loop_dtype == np.float64
+    with np.errstate(all="ignore"):
+        want = {"a": w * m, "b": w + w, "c": w // m, "d": -w, "e": u32_or(tb["u"], m), "ev3": ev * np.uint32(3), "evm": ev - np.uint32(4000000000),
+                "cast": (w / 7).astype(np.int32), "ucast": np.trunc(m / 3).astype(np.int64).astype(np.uint32), "b8": m.astype(np.int8)}
+    for name, x in want.items():
+        assert out[name].dtype == x.dtype and np.array_equal(out[name], x), name
+    # uint32 beside int32 is NumPy's int64 loop; a 32-bit result on waveforms needs the float64 chain: both say so
+    with pytest.raises(NotImplementedError, match="64-bit integer loop"):
+        build_processing_chain({"outputs": ["x"], "processors": {"x": "w * ev"}}, tb)
+    tb16 = _int_table()
+    with pytest.raises(NotImplementedError, match="32-bit integer loop"):
+        build_processing_chain({"outputs": ["x"], "processors": {"x": "u * h"}}, tb16)  # uint16 x int16 -> int32, in a float32 chain
+    with pytest.raises(NotImplementedError, match="does not fit"):
+        build_processing_chain({"outputs": ["x"], "processors": {"x": "u + 70000"}}, tb16)
+
+
+def u32_or(u, m):
+    return u * m  # uint16 x int32 -> int32 ('ii->i')
+
+
+def test_floats_beside_integers_and_casts_to_integers():
     tb = _table()
-    for expr in ("waveform * 2", "waveform - eventnumber", "waveform + waveform"):
-        with pytest.raises(NotImplementedError, match="integer"):
-            build_processing_chain({"outputs": ["x"], "processors": {"x": expr}}, tb)
-    _, out = _run({"x": "waveform / 2", "y": "astype(waveform, 'float32') * 2"}, ["x", "y"], tb)  # true division and floats are float loops
-    assert np.array_equal(out["x"], tb["waveform"].values.astype(np.float32) / 2) and np.array_equal(out["y"], tb["waveform"].values.astype(np.float32) * 2)
+    wf = tb["waveform"].values
+    _, out = _run({"x": "waveform / 2", "y": "astype(waveform, 'float32') * 2", "z": "waveform * baseline", "i": "astype(waveform - baseline, 'int16')",
+                   "t": "astype(waveform - baseline, '?')", "ib": "astype(baseline * -1.7, 'int16')"}, ["x", "y", "z", "i", "t", "ib"], tb)
+    f = wf.astype(np.float32)
+    assert np.array_equal(out["x"], f / 2) and np.array_equal(out["y"], f * 2) and np.array_equal(out["z"], f * tb["baseline"][:, None])
+    d = f - tb["baseline"][:, None]
+    assert out["i"].dtype == np.int16 and np.array_equal(out["i"], d.astype(np.int16))  # truncation towards zero
+    assert out["t"].dtype == np.bool_ and np.array_equal(out["t"], d != 0)
+    assert out["ib"].dtype == np.int16 and np.array_equal(out["ib"], (tb["baseline"] * np.float32(-1.7)).astype(np.int16))
     with pytest.raises(ProcessingChainError, match="broadcast"):
         build_processing_chain({"outputs": ["x"], "processors": {"x": "waveform[0:10] / waveform[0:20]"}}, tb)
+    with pytest.raises(NotImplementedError, match="32-bit integer loop"):
+        build_processing_chain({"outputs": ["x"], "processors": {"x": "waveform - eventnumber"}}, tb)  # uint16 - int32 -> int32
 
 
 def test_comparators():

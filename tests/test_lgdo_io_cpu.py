@@ -109,7 +109,8 @@ def test_variable_index_into_a_variable_length_array_translates():
     ops = chain.program.ops
     picks = [o for o in ops if o[0] == _lib.OP_PICKOFF]
     assert len(picks) == 2 and all(o[4][1] == 2 for o in picks)  # get_default with a per-event index
-    assert any(o[0] == _lib.OP_SCALAR_FUNC and o[4][0] == _lib.FN_FLOORDIV for o in ops)
+    # len(vov_in) // 2: the lengths are uint32, so NumPy's 'II->I' loop (the float64 rows make this the float64 chain, which holds them)
+    assert any(o[0] == _lib.OP_SCALAR_FUNC and o[4][0] == _lib.fn_int(_lib.FN_IFLOORDIV, np.uint32) for o in ops)
     assert chain.program.slots == [50] and sorted(mask) == ["vov_in"]  # (the lengths come with the VectorOfVectors itself)
     with pytest.raises(DSPFatal, match="larger than array variable length"):
         build_processing_chain({"outputs": ["v"], "processors": {"v": "vov_in(shape=40)[0]"}}, Table(vov_in=vov))

@@ -216,7 +216,7 @@ def test_argument_language_on_per_event_variables():
 
 
 def test_what_the_language_does_not_take_fails_by_name():
-    for expr, exc in (("waveform * 2", NotImplementedError), ("waveform[0:100:-2]", ProcessingChainError), ("waveform[0:100:2]", ProcessingChainError), ("t_b * (2*ns)", NotImplementedError),
+    for expr, exc in (("waveform * 2", ProcessingChainError), ("waveform[0:100:-2]", ProcessingChainError), ("waveform[0:100:2]", ProcessingChainError), ("t_b * (2*ns)", NotImplementedError),
                       ("baseline.grid", ProcessingChainError), ("t_b % 2", (NotImplementedError, ProcessingChainError))):
         rec = {"outputs": ["x"], "processors": {
             "t_a, t_b, lo, hi": {"function": "min_max", "module": M, "args": ["waveform", "t_a", "t_b", "lo", "hi"], "unit": ["ns", "ns", "ADC", "ADC"]},
@@ -226,6 +226,35 @@ def test_what_the_language_does_not_take_fails_by_name():
     plain = {"waveform": np.zeros((4, 1024), dtype=np.float32)}  # no WaveformInput: no grid to take a period from
     with pytest.raises(ProcessingChainError):
         build_processing_chain({"outputs": ["x"], "processors": {"x": f"{M}.fixed_time_pickoff(waveform, 10*us/waveform.period, 'n', x)"}}, plain)
+
+
+def test_integer_columns_select_numpys_integer_loops():
+    """the first ufunc signature every variable can be cast to (reference :1565-1572, 1654-1664); constants are rounded into its type (:1765-1768)"""
+    from dspeed_amd.processing_chain import Var, _int_loop_const, _int_loop_of
+
+    v = lambda dt: Var("v", "wf", 8, dt)  # noqa: E731
+    for dts, want in ((("uint16",), "uint16"), (("int16", "int16"), "int16"), (("uint16", "int16"), "int32"), (("bool", "int16"), "int16"),
+                      (("uint16", "int32"), "int32"), (("uint32",), "uint32")):
+        assert _int_loop_of([v(d) for d in dts], "x") == np.dtype(want), dts
+        assert np.dtype(want).char == next(t[0] for t in np.add.types if all(np.can_cast(d, t[0]) for d in dts) and t[0] != "?")
+    for dts in (("int32", "uint32"), ("int64",), ("bool", "bool")):
+        with pytest.raises(NotImplementedError):
+            _int_loop_of([v(d) for d in dts], "x")
+    assert _int_loop_const(2.5, np.dtype("uint16"), "x") == 2.0 and _int_loop_const(3.5, np.dtype("uint16"), "x") == 4.0  # np.round: half to even
+    with pytest.raises(NotImplementedError, match="does not fit"):
+        _int_loop_const(-1, np.dtype("uint16"), "x")
+    tb = {"u": np.zeros((4, 64), np.uint16), "h": np.zeros((4, 64), np.int16), "ev": np.zeros(4, np.uint16), "n32": np.zeros(4, np.int32)}
+    procs = {"a": "u * 2.5", "b": "-h", "c": "ev // 3", "d": "astype(h, 'uint16') + u", "e": "n32 // 2", "f": "u / 2"}
+    chain, _, out = build_processing_chain({"outputs": list(procs), "processors": procs}, tb)
+    assert {k: x.dtype.name for k, x in out.items()} == {"a": "uint16", "b": "int16", "c": "uint16", "d": "uint16", "e": "int32", "f": "float32"}
+    ew = {o[4][0] for o in chain.program.ops if o[0] == _lib.OP_ELEMENTWISE}
+    assert ew == {_lib.fn_int(_lib.FN_IMUL, np.uint16), _lib.fn_int(_lib.FN_ISUB, np.int16), _lib.fn_int(_lib.FN_ICAST, np.uint16),
+                  _lib.fn_int(_lib.FN_IADD, np.uint16), _lib.FN_DIV}
+    sf = {o[4][0] for o in chain.program.ops if o[0] == _lib.OP_SCALAR_FUNC}
+    # (a 32-bit loop between per-event values of a float32 chain is the float operation: exact below 2**24)
+    assert sf == {_lib.fn_int(_lib.FN_IFLOORDIV, np.uint16), _lib.FN_FLOORDIV}
+    mul = next(o for o in chain.program.ops if o[0] == _lib.OP_ELEMENTWISE and o[4][0] == _lib.fn_int(_lib.FN_IMUL, np.uint16))
+    assert mul[5][1].value == 2.0
 
 
 def test_scheduler_only_reorders_within_dependencies():
@@ -306,6 +335,30 @@ def test_list_literals_are_constant_arrays():
     assert np.all(out["half"] == np.array([3.5, 4.5, 5.5, 6.5, 7.5]))
     with pytest.raises(NotImplementedError, match="constant array beside a variable"):
         build_processing_chain({"outputs": ["x"], "processors": {"x": "waveform[0:3] + [1, 2, 3]"}}, _tb())
+
+
+def test_loadlh5_gives_a_constant(tmp_path):
+    """loadlh5(file, path) (reference processing_chain.py:1444-1467): the taps of a filter kept in a file beside the recipe"""
+    from dspeed_amd import lgdo_io
+
+    taps = np.array([0.25, 0.5, 0.25, -0.125], dtype=np.float32)
+    f = str(tmp_path / "kernels.npz")
+    np.savez(f, taps=taps, gain=np.float64(2.5))
+    rec = {"outputs": ["w", "k", "g"], "processors": {"k": f"loadlh5('{f}', 'taps')", "g": f"loadlh5('{f}', '/gain')",
+                                                      "w": f"{M}.convolve_wf(waveform, k, 'f', w(8195, 'f'))"}}
+    chain, _, out = build_processing_chain(rec, _tb())
+    n = len(_tb()["baseline"])
+    assert np.array_equal(out["k"], np.broadcast_to(taps, (n, 4))) and np.all(out["g"] == 2.5)
+    held = [c for consts in (chain._consts, *(st["consts"] for st in chain._stages)) for name, c in consts.items() if name.startswith("taps:")]
+    assert len(held) == 1 and np.array_equal(held[0][:4], taps)
+    with pytest.raises(ProcessingChainError, match="LH5 file not found"):
+        build_processing_chain({"outputs": ["k"], "processors": {"k": f"loadlh5('{f}', 'nothing')"}}, _tb())
+    lgdo_io.CONSTANT_LOADERS.append(lambda file, path: np.arange(3.0) if file == "mem:" else None)
+    try:
+        _, _, out = build_processing_chain({"outputs": ["k"], "processors": {"k": "loadlh5('mem:', 'x')"}}, _tb())
+        assert np.all(out["k"] == np.arange(3.0))
+    finally:
+        lgdo_io.CONSTANT_LOADERS.pop()
 
 
 def test_negative_steps_become_backward_copies():
