@@ -82,6 +82,8 @@ extern "C" const char* dsp_internal_energy_rr_kernel_name();
 extern "C" int dsp_internal_launch_rows(const RowsArgs* A, int64_t n_wf, int* err, int lds_bytes, hipStream_t stream);
 extern "C" int dsp_internal_set_rows_lds(int lds_bytes);
 extern "C" const char* dsp_internal_rows_kernel_name();
+extern "C" int dsp_internal_launch_reduce(const ReduceArgs* A, int64_t n_wf, int dtype, int vec, hipStream_t stream);
+extern "C" const char* dsp_internal_reduce_kernel_name();
 extern "C" int dsp_internal_launch_scalar(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int n_sregs, int f64, hipStream_t stream);
 extern "C" int dsp_internal_set_scalar_lds(int lds_bytes);
 extern "C" const char* dsp_internal_scalar_kernel_name();
@@ -191,6 +193,11 @@ struct dsp_chain {
     int cur_lds_bytes = 0, cio_wf = -1, cio_t0 = -1, cio_out[4] = {-1, -1, -1, -1};
     float* cur_scratch = nullptr;  // allocated at the first launch
     int cur_blocks_cap = 0;
+    // streaming reductions of rows (dsp_reduce.hip)
+    bool red_ok = false;
+    ReduceArgs red{};
+    int dio_wf = -1, dio_out[5] = {-1, -1, -1, -1, -1}, dio_pick[DSP_REDUCE_PICKS] = {-1, -1, -1, -1}, red_dtype = DSP_F32;
+    bool red_vec = false;  // rows keep 16-byte alignment and hold whole 16-byte vectors
     // the error word handed to the host by a copy that is part of the launch (dsp_chain_set_async_check): dsp_chain_check then needs no
     // transfer of its own -- one issued while a large host-to-device copy of the next buffer is in flight queues up behind it
     int* err_mirror = nullptr;  // page-locked
@@ -203,9 +210,6 @@ struct dsp_chain {
     }
 };
 
-// Does the program have the shape of the current-branch kernel (dsp_current.hip)?
-//   LOAD s0;  WINDOWER s1 <- s0 (start: constant or float32 column);  AVG_CURRENT s2 <- s1;  UPSAMPLER s3 <- s2;
-//   MOVING_WINDOW_MULTI d <- s3 (3 windows, alternating);  MIN_MAX of d;  STORE_SCALARs of its four registers
 // ip[0] of ELEMENTWISE / SCALAR_FUNC: a DSP_FN_* code; the integer loops carry their type (8, 16 or 32 bits; 32 only in the float64 chain,
 // whose values hold every 32-bit integer), the float ones nothing
 static bool fn_code_ok(int ip0, bool f64) {
@@ -215,6 +219,71 @@ static bool fn_code_ok(int ip0, bool f64) {
     return (ip0 >> 8) == 0;
 }
 
+// Does the program only read per-event values off rows (dsp_reduce.hip)?
+//   LOAD s;  then any of  MIN_MAX of s (once),  AMAX of s (once),  PICKOFF of s at a constant integral time (fixed_time_pickoff, or the plain
+//   sample wf[k]; up to DSP_REDUCE_PICKS);  then STORE_SCALARs of the registers those made, float32 columns
+static bool match_reduce_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, const int32_t* slot_len, bool f64) {
+    if (f64 || n_ops < 3 || ops[0].opcode != DSP_OP_LOAD) return false;
+    const dsp_op& ld = ops[0];
+    const dsp_io_desc& w = io[ld.io];
+    if ((w.dtype != DSP_F32 && w.dtype != DSP_I16 && w.dtype != DSP_U16) || ld.ip[0] != 0 || ld.ip[1] != 0 || w.len < 1 || slot_len[ld.dst] != w.len)
+        return false;
+    ReduceArgs& A = ch->red;
+    memset(&A, 0, sizeof A);
+    int reg_of_out[5] = {-1, -1, -1, -1, -1}, reg_of_pick[DSP_REDUCE_PICKS] = {-1, -1, -1, -1};
+    int n_pick = 0, i = 1;
+    for (; i < n_ops; ++i) {
+        const dsp_op& o = ops[i];
+        if (o.opcode == DSP_OP_MIN_MAX && o.src == ld.dst && reg_of_out[0] < 0) {
+            for (int k = 0; k < 4; ++k) reg_of_out[k] = o.dst + k;
+        } else if (o.opcode == DSP_OP_AMAX && o.src == ld.dst && reg_of_out[4] < 0) {
+            reg_of_out[4] = o.dst;
+        } else if (o.opcode == DSP_OP_PICKOFF && o.src == ld.dst && n_pick < DSP_REDUCE_PICKS && o.sp[0].kind == DSP_ARG_CONST && (o.ip[1] == 0 || o.ip[1] == 1)) {
+            const double t = (double)(float)o.sp[0].value;
+            if (!(t == std::floor(t)) || std::fabs(t) > 1e9) return false;  // (between samples: the interpolating modes stay with the program)
+            if (o.ip[1] == 1 && (t < 0 || t >= w.len)) return false;
+            reg_of_pick[n_pick] = o.dst;
+            A.pick_at[n_pick] = (t >= 0 && t <= w.len - 1) ? (int)t : -1;  // fixed_time_pickoff.py:68-74
+            A.pick_rule[n_pick] = o.ip[1] == 0;
+            ++n_pick;
+        } else {
+            break;
+        }
+    }
+    if (i == 1 || i == n_ops) return false;
+    for (int k = 0; k < 5; ++k) ch->dio_out[k] = -1;
+    for (int k = 0; k < DSP_REDUCE_PICKS; ++k) ch->dio_pick[k] = -1;
+    for (; i < n_ops; ++i) {
+        const dsp_op& o = ops[i];
+        if (o.opcode != DSP_OP_STORE_SCALAR || io[o.io].dtype != DSP_F32) return false;
+        bool placed = false;
+        for (int k = 0; k < 5 && !placed; ++k)
+            if (reg_of_out[k] == o.ip[0] && ch->dio_out[k] < 0) {
+                ch->dio_out[k] = o.io;
+                A.out_stride[k] = io[o.io].row_stride;
+                placed = true;
+            }
+        for (int k = 0; k < n_pick && !placed; ++k)
+            if (reg_of_pick[k] == o.ip[0] && ch->dio_pick[k] < 0) {
+                ch->dio_pick[k] = o.io;
+                A.pick_stride[k] = io[o.io].row_stride;
+                placed = true;
+            }
+        if (!placed) return false;  // (a register stored twice, or one nothing here made)
+    }
+    const int es = w.dtype == DSP_F32 ? 4 : 2;
+    A.wf_stride = w.row_stride;
+    A.wf_offset = w.offset;
+    A.len = w.len;
+    ch->red_dtype = w.dtype;
+    ch->red_vec = (w.row_stride * es) % 16 == 0 && (w.offset * es) % 16 == 0 && (w.len * es) % 16 == 0;
+    ch->dio_wf = ld.io;
+    return true;
+}
+
+// Does the program have the shape of the current-branch kernel (dsp_current.hip)?
+//   LOAD s0;  WINDOWER s1 <- s0 (start: constant or float32 column);  AVG_CURRENT s2 <- s1;  UPSAMPLER s3 <- s2;
+//   MOVING_WINDOW_MULTI d <- s3 (3 windows, alternating);  MIN_MAX of d;  STORE_SCALARs of its four registers
 static bool match_current_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, const int32_t* slot_len, bool f64) {
     if (f64 || n_ops < 7) return false;
     const dsp_op &ld = ops[0], &wi = ops[1], &ac = ops[2], &up = ops[3], &mw = ops[4], &mm = ops[5];
@@ -1523,6 +1592,11 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             ch->fused_on = !(env && env[0] == '1');
         }
     }
+    ch->red_ok = match_reduce_shape(ch.get(), ops, n_ops, io, slot_len, f64);
+    if (ch->red_ok) {
+        const char* env = getenv("DSPEED_HIP_NO_FUSED");
+        ch->fused_on = !(env && env[0] == '1');
+    }
     ch->cur_ok = match_current_shape(ch.get(), ops, n_ops, io, slot_len, f64);
     if (!ch->cur_ok) {
         ch->cio_wf = ch->cio_t0 = -1;
@@ -1530,6 +1604,34 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     } else {
         const char* env = getenv("DSPEED_HIP_NO_FUSED");
         ch->fused_on = !(env && env[0] == '1');
+    }
+
+    // The interpreter pays a dispatch per op and row (a lone wavefront: op fetch, decode, a few hundred cycles), and a recipe ends in
+    // dozens of one-lane stores.  Last step, after every shape matcher has read the ops: a run of STORE_SCALARs becomes one op whose lanes
+    // store one value each, and the no-ops a folded BL_SUBTRACT left are dropped.  (The row-per-lane kernel keeps its plain stores.)
+    if (!ch->scalar_ok) {
+        int w = 0;
+        for (int r = 0; r < P.n_ops;) {
+            if (P.ops[r].opcode == DSP_OP_INTERNAL_NOP) {
+                ++r;
+                continue;
+            }
+            int e = r;
+            while (e < P.n_ops && P.ops[e].opcode == DSP_OP_STORE_SCALAR && e - r < DSP_IC) ++e;
+            if (e - r >= 2) {
+                DevOp m = P.ops[r];
+                m.opcode = DSP_OP_INTERNAL_STORES;
+                m.dst = e - r;
+                for (int j = 0; j < e - r; ++j) m.ic[j] = P.ops[r + j].io | (P.ops[r + j].ip[0] << 16);
+                P.ops[w++] = m;
+                r = e;
+                continue;
+            }
+            if (w != r) P.ops[w] = P.ops[r];
+            ++w;
+            ++r;
+        }
+        P.n_ops = w;
     }
 
     HIP_TRY(hipGetDevice(&ch->device));
@@ -1654,6 +1756,16 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
     if (ch->scalar_ok && ch->fused_on) {
         hipError_t e = (hipError_t)dsp_internal_launch_scalar(ch->dev, &ptrs, n_wf, ch->host.n_sregs, ch->f64 ? 1 : 0, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "scalar kernel launch failed: %s", hipGetErrorString(e));
+        return post_err(ch, stream);
+    }
+    if (ch->red_ok && ch->fused_on) {
+        ReduceArgs A = ch->red;
+        A.wf = io_ptrs[ch->dio_wf];
+        for (int k = 0; k < 5; ++k) A.out[k] = at(ch->dio_out[k]);
+        for (int k = 0; k < DSP_REDUCE_PICKS; ++k) A.pick_out[k] = at(ch->dio_pick[k]);
+        const int vec = ch->red_vec && (reinterpret_cast<uintptr_t>(A.wf) & 15u) == 0;
+        hipError_t e = (hipError_t)dsp_internal_launch_reduce(&A, n_wf, ch->red_dtype, vec, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "reduce kernel launch failed: %s", hipGetErrorString(e));
         return post_err(ch, stream);
     }
     if (ch->cur_ok && ch->fused_on && (reinterpret_cast<uintptr_t>(io_ptrs[ch->cio_wf]) & 15u) == 0) {
@@ -1819,6 +1931,12 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
         if (blocks) *blocks = (int)((n_wf + 63) / 64);
         return DSP_OK;
     }
+    if (ch->red_ok && ch->fused_on) {
+        if (lds_bytes_per_wave) *lds_bytes_per_wave = 0;
+        if (waves_per_block) *waves_per_block = 4;
+        if (blocks) *blocks = (int)((n_wf + 3) / 4);
+        return DSP_OK;
+    }
     if (ch->cur_ok && ch->fused_on) {
         int per_cu = LDS_BYTES_PER_CU / ch->cur_lds_bytes;
         if (per_cu > 8) per_cu = 8;
@@ -1856,6 +1974,7 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
 
 const char* dsp_chain_kernel_name(dsp_chain* ch) {
     if (ch && ch->scalar_ok && ch->fused_on) return dsp_internal_scalar_kernel_name();
+    if (ch && ch->red_ok && ch->fused_on) return dsp_internal_reduce_kernel_name();
     if (ch && ch->cur_ok && ch->fused_on) return dsp_internal_current_kernel_name();
     if (ch && ch->fir_ok && ch->fused_on) return ch->fir.store ? dsp_internal_fir_store_kernel_name() : dsp_internal_fir_mfma_kernel_name();
     if (ch && ch->rows_ok && ch->fused_on) return dsp_internal_rows_kernel_name();
@@ -1882,7 +2001,7 @@ int dsp_chain_set_fused(dsp_chain* ch, int enable) {
     // 7 = classic (VM layout); anything else = default
     const int v = (enable >> 1) & 7;
     ch->variant = (v == 7 || !ch->rr_ok) ? 1 : 6;
-    return ((ch->fused_ok || ch->rr_ok || ch->rows_ok || ch->fir_ok || ch->cur_ok || ch->scalar_ok) && ch->fused_on) ? 1 : 0;
+    return ((ch->fused_ok || ch->rr_ok || ch->rows_ok || ch->fir_ok || ch->cur_ok || ch->scalar_ok || ch->red_ok) && ch->fused_on) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ single processors

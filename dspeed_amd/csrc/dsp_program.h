@@ -8,6 +8,7 @@
 #define DSP_WAVE 64
 #define DSP_FC 40 /* host-precomputed float64 constants per op */
 #define DSP_OP_INTERNAL_NOP 101  /* host-made: a BL_SUBTRACT that the LOAD in front of it does while it writes the samples (DevOp ic[0] of the LOAD) */
+#define DSP_OP_INTERNAL_STORES 102 /* host-made: a run of STORE_SCALAR ops as one op -- dst = count (<= DSP_IC), ic[j] = binding | register << 16: lane j stores */
 #define DSP_OP_INTERNAL_ZERO 100 /* host-inserted: clear slot dst's whole LDS region (guard, chunks, pads, tail) before its first use */
 #define DSP_SCRATCH_ELEMS 128
 #define DSP_IC 12 /* host-precomputed integer constants per op */
@@ -140,6 +141,21 @@ struct CurrentArgs {
     int64_t out_stride[4];
     float* scratch;          // scratch_per_wave floats per resident wavefront: the current waveform and the checkpoints of two passes
     int64_t scratch_per_wave;
+};
+
+// arguments of the streaming reductions (dsp_reduce.hip), filled by dsp_chain_execute when a program has the shape
+//   LOAD -> {MIN_MAX | AMAX | PICKOFF at a constant integral time}+ -> STORE_SCALARs
+#define DSP_REDUCE_PICKS 4
+struct ReduceArgs {
+    const void* wf;          // float32 / int16 / uint16 rows
+    int64_t wf_stride;
+    int32_t wf_offset, len;  // first sample, samples
+    void* out[5];            // t_min, t_max, a_min, a_max of MIN_MAX, the maximum of AMAX (null: not requested); float32 columns
+    int64_t out_stride[5];
+    void* pick_out[DSP_REDUCE_PICKS];
+    int64_t pick_stride[DSP_REDUCE_PICKS];
+    int32_t pick_at[DSP_REDUCE_PICKS];    // sample index, -1: outside the waveform (NaN)
+    int32_t pick_rule[DSP_REDUCE_PICKS];  // 1: fixed_time_pickoff (a NaN anywhere in the row -> NaN), 0: the plain sample
 };
 
 // arguments of the matrix-core FIR kernel (dsp_fir_mfma.hip): convolve_wf 'v' + numpy.amax of up to DSP_FIR_MAXK kernels on one waveform

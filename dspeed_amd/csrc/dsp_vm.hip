@@ -239,6 +239,26 @@ __device__ __forceinline__ void op_store_scalar(Ctx<T>& cx, const DSP_PROG DevOp
     if (lane_id() == 0) cx.template io_ptr<T>(op.io)[cx.row * io.row_stride + io.offset] = cx.sregs()[op.ip[0]];
 }
 
+// host-made (dsp_chain_create): a run of STORE_SCALARs as one op, lane j stores register ic[j] >> 16 to binding ic[j] & 0xffff
+template <typename T>
+__device__ __forceinline__ void op_store_scalars(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+    const int lane = lane_id();
+    if (lane < op.dst) {
+        int pair = op.ic[0];
+#pragma unroll
+        for (int j = 1; j < DSP_IC; ++j) pair = lane == j ? op.ic[j] : pair;  // (the op is read with scalar loads: a select per entry)
+        const int k = pair & 0xffff, reg = pair >> 16;
+        // this lane's binding: descriptor and pointer with the lane's own index (vector loads from the constant address space)
+        const DSP_PROG DevIO& io = cx.prog->io[k];
+        const int64_t at = cx.row * io.row_stride + io.offset;
+        const T v = cx.sregs()[reg];
+        if (io.dtype == DSP_BOOL)
+            cx.template io_ptr<uint8_t>(k)[at] = v != (T)0 ? 1 : 0;
+        else
+            cx.template io_ptr<T>(k)[at] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // NumPy ufuncs the recipe language adds as processors (processing_chain.py:832-947, 1266-1420): one IEEE operation per sample in the
 // loop type, truth values as 0 / 1
@@ -2255,6 +2275,7 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 3) dsp_vm_kernel(const DevProgr
                 case DSP_OP_LOAD: op_load(cx, op); break;
                 case DSP_OP_STORE: op_store(cx, op); break;
                 case DSP_OP_STORE_SCALAR: op_store_scalar(cx, op); break;
+                case DSP_OP_INTERNAL_STORES: op_store_scalars(cx, op); break;
                 case DSP_OP_BL_SUBTRACT: op_bl_subtract(cx, op); break;
                 case DSP_OP_MIN_MAX_NORM: op_min_max_norm(cx, op); break;
                 case DSP_OP_POLE_ZERO: op_pole_zero(cx, op); break;

@@ -48,7 +48,51 @@ class HipGUFunc:
         return f"<HipGUFunc {self.__name__} {self.signature}>"
 
     def __call__(self, *args, **kwargs):
-        return self._impl(self, *args, **kwargs)
+        per_row = self._per_row_integers(args)
+        if not per_row:
+            return self._impl(self, *args, **kwargs)
+        return self._by_parameter_value(per_row, args, kwargs)
+
+    def _per_row_integers(self, args):
+        """positions of integer parameters ('i' in the type string, dimension ()) given as one value per waveform -- the gufunc broadcasts them
+        like any other argument (reference processors: ``trap_filter(w_in, rise, flat, w_out)`` with rise / flat arrays)"""
+        sig = self.types[0].replace("->", "")
+        return [k for k in range(min(self.nin, len(args))) if sig[k] == "i" and self.in_dims[k] == () and not isinstance(args[k], DeviceArray)
+                and np.ndim(args[k]) >= 1 and np.size(args[k]) > 1]
+
+    def _by_parameter_value(self, per_row, args, kwargs):
+        """The kernels take an integer parameter (a filter length, a level) as a constant of the launch: rows are grouped by the values they
+        ask for, each group runs with its constants, and the results go back to the rows' places."""
+        cols = [np.asarray(args[k]).reshape(-1) for k in per_row]
+        n_rows = cols[0].size
+        if any(c.size != n_rows for c in cols):
+            raise ValueError(f"{self.__name__}: per-waveform parameters of different lengths")
+        if any(isinstance(a, DeviceArray) for a in args):
+            raise NotImplementedError(f"{self.__name__}: per-waveform integer parameters need the rows in host memory (they are grouped by value)")
+        if any(np.isnan(c.astype(np.float64)).any() for c in cols):
+            raise NotImplementedError(f"{self.__name__}: NaN integer parameter")
+        table = np.stack([c.astype(np.int64) for c in cols], axis=1)
+        values, which = np.unique(table, axis=0, return_inverse=True)
+        which = which.reshape(-1)
+        args = [np.asarray(a) if a is not None and k < self.nin else a for k, a in enumerate(args)]
+        rowwise = [isinstance(a, np.ndarray) and a.ndim >= 1 and a.shape[0] == n_rows for a in args]
+        if not rowwise[0]:
+            raise ValueError(f"{self.__name__}: {n_rows} parameter values for a waveform argument of shape {np.shape(args[0])}")
+        given = list(args[self.nin:]) + [None] * (self.nargs - len(args))
+        results = [o if isinstance(o, np.ndarray) else None for o in given]
+        for g, vals in enumerate(values):
+            rows = np.flatnonzero(which == g)
+            part = [a[rows] if rw and k < self.nin else a for k, (a, rw) in enumerate(zip(args[: self.nin], rowwise))]
+            for k, v in zip(per_row, vals):
+                part[k] = int(v)
+            got = self._impl(self, *part, **kwargs)
+            got = got if isinstance(got, tuple) else (got,)
+            for j, r in enumerate(got):
+                r = np.asarray(r)
+                if results[j] is None:
+                    results[j] = np.empty((n_rows, *r.shape[1:]), dtype=r.dtype)
+                results[j][rows] = r
+        return results[0] if len(results) == 1 else tuple(results)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -1981,7 +1981,39 @@ def _extract_stages(b: _Builder, steps, out_pars, n_rows, ft):
     # what the stages' results replaced is not computed any more: producers of staged variables, and whatever only fed them
     staged = {id(v) for v in b.vars.values() if isinstance(v, Var) and getattr(v, "ext_key", None) is not None and getattr(v, "aux_io", None) is None}
     steps = [x for x in steps if not any(r in "WS" and id(a) in staged for a, r in zip(x[1], _roles(x[0])))]
-    return _live_steps(b, steps, out_pars), stages
+    steps = _live_steps(b, steps, out_pars)
+
+    # --- per-event values read straight off rows in HBM: min_max, numpy.amax and a sample at a constant integral time of an input or of a
+    # stage's waveform.  In the program they cost a LOAD of the whole row into LDS and a pass over it, at the occupancy the longest
+    # waveform leaves (one wavefront per SIMD for 8192 samples); dsp_reduce.hip streams the row through registers once.
+    def reducible(st):
+        if st[0] in ("min_max", "amax"):
+            return True
+        if st[0] == "fixed_time_pickoff":
+            t = st[1][1]
+            return isinstance(t, (int, float, np.integer, np.floating)) and not isinstance(t, (bool, Quantity)) and float(t) == int(float(t))
+        return False
+
+    if ft == np.dtype(np.float32) and os.environ.get("DSPEED_HIP_NO_ROW_REDUCTIONS") != "1":
+        for v in [x for x in list(b.vars.values()) if row_input(x)]:
+            if np.dtype(v.dtype) not in (np.dtype(np.float32), np.dtype(np.int16), np.dtype(np.uint16)):
+                continue
+            group = [g for g in rows_steps(v) if reducible(g) and g[1][0] is v]
+            by_fn = [g[0] for g in group]
+            if not group or by_fn.count("min_max") > 1 or by_fn.count("amax") > 1 or by_fn.count("fixed_time_pickoff") > 4:
+                continue
+            rest = [x for x in steps if not any(x is g for g in group)]
+            if any(base_of(a) is v for x in rest for a, r in zip(x[1], _roles(x[0])) if r not in "WS"):
+                continue  # (the program loads these rows for something else as well: there the reduction is one more pass over LDS, no row traffic)
+            if not any(r in "wW" for x in rest for r in _roles(x[0])):
+                continue  # (the program would be left without a waveform: nothing gained by a launch of its own)
+            outs = [o for g in group for o, r in zip(g[1], _roles(g[0])) if r in "WS"]
+            build(group, outs, f"per-event values of {v.name} off its rows")
+            for o in outs:
+                o.kind = "scalar"
+            steps = rest
+
+    return steps, stages
 
 
 def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):

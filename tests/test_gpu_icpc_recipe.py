@@ -220,7 +220,8 @@ def test_index_outputs_are_bit_exact_on_the_devices_own_waveforms():
     exact(prod["tp_aoe_samp"], to_ns(tp0 + ta_x / F(16)), "tp_aoe_samp (production)")
     assert "dsp_current_kernel" in [st["chain"].kernel_name for st in chain_p._stages]
     assert [k for _what, k in chain_p.kernels()] == ["dsp_fit_rows_kernel", "dsp_vm_kernel<float>", "dsp_fir_store_kernel", "dsp_fir_store_kernel",
-                                                     "dsp_vm_kernel<float>", "dsp_rows_kernel", "dsp_current_kernel", "dsp_vm_kernel<float>", "dsp_scalar_kernel"]
+                                                     "dsp_vm_kernel<float>", "dsp_rows_kernel", "dsp_current_kernel", "dsp_reduce_kernel", "dsp_reduce_kernel",
+                                                     "dsp_vm_kernel<float>", "dsp_scalar_kernel"]
     seen.update({"tp_aoe_max": True, "A_max": True, "tp_aoe_samp": True})
     cusp_dev = g["wf_cusp"]
     assert all(seen.get(k) for k in recipes.ICPC["outputs"] if k not in ("tp_min", "tp_max", "wf_min", "wf_max", "bl_mean", "bl_slope",
@@ -366,7 +367,7 @@ def test_stage_buffers_are_bounded_and_pieces_give_the_same_results():
     wf = wf.astype(np.uint16)
     tb = {"waveform": WaveformInput(wf, 16.0, 48000.0), "baseline": bl}
     chain, _, out = build_processing_chain(recipes.ICPC, tb)
-    assert len(chain._stages) == 6
+    assert len(chain._stages) == 8
     chain.execute()
     ref = {k: np.array(v) for k, v in out.items()}
     per_row = sum(4 * (1 if ln is None else ln) for st in chain._stages for _o, _k, ln in st["outs"])

@@ -465,6 +465,32 @@ def test_reference_style_calls(P, DSPFatal):
         P.double_pole_zero(np.ones(2, dtype=np.float32), 1000, 30000, 0.98)
 
 
+def test_integer_parameters_given_per_waveform(P):
+    """trap_filter(w_in, rise, flat) with one (rise, flat) per waveform: the gufunc broadcasts integer parameters like any other argument;
+    the kernels take them as launch constants, so the rows run grouped by value and come back in their places"""
+    rng = np.random.default_rng(77)
+    n, L = 37, 1024
+    wf = (1000 + 40 * rng.standard_normal((n, L))).astype(np.float32)
+    wf[:, L // 2:] += rng.uniform(100, 3000, size=(n, 1)).astype(np.float32)
+    rise = rng.choice([8, 16, 40], n).astype(np.int32)
+    flat = rng.choice([4, 12], n).astype(np.int32)
+    got = P.trap_filter(wf, rise, flat)
+    norm = P.trap_norm(wf, rise, 8)  # one parameter per row, the other a constant
+    assert got.shape == (n, L) and got.dtype == np.float32
+    for r in range(n):
+        want, rc = oracle.trap_filter(wf[r:r + 1], int(rise[r]), int(flat[r]))
+        assert rc == 0
+        assert_rel_to_peak(got[r:r + 1], want, FILTER_TOL, f"trap_filter row {r}")
+        assert np.array_equal(got[r], P.trap_filter(wf[r], int(rise[r]), int(flat[r])))  # the same numbers as the row alone
+        want, rc = oracle.trap_norm(wf[r:r + 1], int(rise[r]), 8)
+        assert_rel_to_peak(norm[r:r + 1], want, FILTER_TOL, f"trap_norm row {r}")
+    out = np.zeros((n, L), dtype=np.float32)
+    P.trap_filter(wf, rise, flat, out)  # in-place form
+    assert np.array_equal(out, got)
+    with pytest.raises(ValueError):
+        P.trap_filter(wf, rise[:5], flat)
+
+
 def test_float64_loop_selected_by_input_dtype(P):
     """float64 / int32 / uint32 rows run the float64 loop and return float64 (reference processing_chain.py:1565-1572)"""
     rng = np.random.default_rng(21)

@@ -106,8 +106,14 @@ def test_long_filters_of_the_ge_recipe_run_ahead_of_the_program():
                     [_lib.OP_LOAD, _lib.OP_TRAP_REDUCE, _lib.OP_STORE_SCALAR],
                     # the current branch in the shape of dsp_current.hip: window at tp_0_est (a column by now) of the pole-zero rows
                     [_lib.OP_LOAD, _lib.OP_WINDOWER, _lib.OP_AVG_CURRENT, _lib.OP_UPSAMPLER, _lib.OP_MOVING_WINDOW_MULTI, _lib.OP_MIN_MAX]
-                    + [_lib.OP_STORE_SCALAR] * 4]
-    pz, t0f, cusp, t0v, atrap, current = chain._stages
+                    + [_lib.OP_STORE_SCALAR] * 4,
+                    # per-event values read straight off rows (dsp_reduce.hip): min_max of the raw waveform, maximum and one sample of the cusp's
+                    [_lib.OP_LOAD, _lib.OP_MIN_MAX] + [_lib.OP_STORE_SCALAR] * 4,
+                    [_lib.OP_LOAD, _lib.OP_AMAX, _lib.OP_PICKOFF] + [_lib.OP_STORE_SCALAR] * 2]
+    pz, t0f, cusp, t0v, atrap, current, raw_mm, cusp_values = chain._stages
+    assert raw_mm["what"] == "per-event values of waveform off its rows" and [o[1] for o in raw_mm["outs"]] == ["in:tp_min", "in:tp_max", "in:wf_min", "in:wf_max"]
+    assert cusp_values["alias"] == {"in:wf_cusp": "in:wf_cusp"} and [o[1] for o in cusp_values["outs"]] == ["in:cuspEmax", "in:cuspEftp"]
+    assert not {_lib.OP_MIN_MAX, _lib.OP_AMAX, _lib.OP_PICKOFF} & set(opcodes) and "in:wf_cusp" not in [io[0] for io in P.io] and "in:waveform" not in [io[0] for io in P.io]
     assert [o[1] for o in current["outs"]] == ["in:aoe_t_min", "in:tp_aoe_max", "in:A_min", "in:A_max"]
     assert current["alias"] == {"in:wf_pz": "in:wf_pz", "in:tp_0_est": "in:tp_0_est"}
     assert not {_lib.OP_WINDOWER, _lib.OP_UPSAMPLER, _lib.OP_MOVING_WINDOW_MULTI} & set(opcodes), "the program no longer runs the moving averages"
@@ -118,7 +124,7 @@ def test_long_filters_of_the_ge_recipe_run_ahead_of_the_program():
     assert t0f["outs"] == [("out:wf_t0_filter", "in:wf_t0_filter", 8192)] and cusp["outs"] == [("out:wf_cusp", "in:wf_cusp", 301)]
     assert cusp["program"].ops[0][4] == (0, 8192 - 6092), "bl_subtract's NaN rule covers the whole waveform: the load screens the rest"
     names = [io[0] for io in P.io]
-    assert {"in:wf_pz", "in:tp_0_est", "in:tp_0_atrap", "in:wf_cusp"} <= set(names) and chain._ext_alias["in:wf_cusp"] == "in:wf_cusp"
+    assert {"in:wf_pz", "in:tp_0_est", "in:tp_0_atrap", "in:cuspEmax", "in:tp_min"} <= set(names) and chain._ext_alias["in:cuspEmax"] == "in:cuspEmax"
     assert "in:waveform[0:6092]" in chain._in_vars, "columns only a stage reads are linked with the program's own"
     for st in chain._stages:
         _check_program_order(st["program"])

@@ -64,6 +64,7 @@ def per_op(recipe, tb, outs, rows, label):
     names = {getattr(_lib, k): k[3:] for k in dir(_lib) if k.startswith("OP_")}
     names[100] = "(clear shared LDS)"
     names[101] = "(bl_subtract, done by the load)"
+    names[102] = "(STORE_SCALAR run as one op)"
     chain, _, _ = build_processing_chain(recipe, tb, outputs=outs)
     out_cols = {}
     for k in outs:

@@ -22,11 +22,12 @@ st = Stream()
 wf, bl, _tp = synth(rows, 8192, np.int16, st, bl_lo=-3000.0, bl_hi=3000.0)
 sync()
 tb = {"waveform": WaveformInput(wf, 16.0, 48000.0), "baseline": bl}
-outs = list(recipes.ICPC["outputs"])
+drop = set(filter(None, os.environ.get("ICPC_DROP", "").split(",")))  # (outputs left out: what the rest of the recipe costs without them)
+outs = [o for o in recipes.ICPC["outputs"] if o not in drop]
 chain, _, _ = build_processing_chain(recipes.ICPC, tb, outputs=outs)
 chain.link(tb, {k: DeviceArray((rows,), np.float32) for k in outs})
 chain._ensure()
 dt = timed(chain, steps=steps, warmup=2)
-print(json.dumps({"recipe": "ICPC", "rows": rows, "steps": steps, "ms_per_pass": dt * 1e3, "waveforms_per_s": round(rows / dt),
+print(json.dumps({"recipe": "ICPC", "dropped": sorted(drop), "rows": rows, "steps": steps, "ms_per_pass": dt * 1e3, "waveforms_per_s": round(rows / dt),
                   "kernels": [s["chain"].kernel_name for s in chain._stages] + [chain._chain.kernel_name],
                   "stages": [s["what"] for s in chain._stages]}))

@@ -19,6 +19,7 @@ from dspeed_amd.processing_chain import build_processing_chain  # noqa: E402
 NAMES = {getattr(_lib, k): k[3:] for k in dir(_lib) if k.startswith("OP_")}
 NAMES[100] = "(clear shared LDS)"
 NAMES[101] = "(bl_subtract, done by the load)"
+NAMES[102] = "(STORE_SCALAR run as one op)"
 
 
 def profile(label, recipe, tb, rows):
