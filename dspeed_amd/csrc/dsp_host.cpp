@@ -197,6 +197,7 @@ struct dsp_chain {
     bool red_ok = false;
     ReduceArgs red{};
     int dio_wf = -1, dio_out[5] = {-1, -1, -1, -1, -1}, dio_pick[DSP_REDUCE_PICKS] = {-1, -1, -1, -1}, red_dtype = DSP_F32;
+    int dio_walk[DSP_REDUCE_WALKS] = {-1, -1}, dio_walk_thr[DSP_REDUCE_WALKS] = {-1, -1};
     bool red_vec = false;  // rows keep 16-byte alignment and hold whole 16-byte vectors
     // the error word handed to the host by a copy that is part of the launch (dsp_chain_set_async_check): dsp_chain_check then needs no
     // transfer of its own -- one issued while a large host-to-device copy of the next buffer is in flight queues up behind it
@@ -221,7 +222,8 @@ static bool fn_code_ok(int ip0, bool f64) {
 
 // Does the program only read per-event values off rows (dsp_reduce.hip)?
 //   LOAD s;  then any of  MIN_MAX of s (once),  AMAX of s (once),  PICKOFF of s at a constant integral time (fixed_time_pickoff, or the plain
-//   sample wf[k]; up to DSP_REDUCE_PICKS);  then STORE_SCALARs of the registers those made, float32 columns
+//   sample wf[k]; up to DSP_REDUCE_PICKS),  TIME_POINT_THRESH of s from a constant sample or from MIN_MAX's t_min / t_max (up to
+//   DSP_REDUCE_WALKS);  then STORE_SCALARs of the registers those made, float32 columns
 static bool match_reduce_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, const int32_t* slot_len, bool f64) {
     if (f64 || n_ops < 3 || ops[0].opcode != DSP_OP_LOAD) return false;
     const dsp_op& ld = ops[0];
@@ -231,7 +233,8 @@ static bool match_reduce_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, cons
     ReduceArgs& A = ch->red;
     memset(&A, 0, sizeof A);
     int reg_of_out[5] = {-1, -1, -1, -1, -1}, reg_of_pick[DSP_REDUCE_PICKS] = {-1, -1, -1, -1};
-    int n_pick = 0, i = 1;
+    int reg_of_walk[DSP_REDUCE_WALKS] = {-1, -1}, walk_thr_io[DSP_REDUCE_WALKS] = {-1, -1};
+    int n_pick = 0, n_walk = 0, i = 1;
     for (; i < n_ops; ++i) {
         const dsp_op& o = ops[i];
         if (o.opcode == DSP_OP_MIN_MAX && o.src == ld.dst && reg_of_out[0] < 0) {
@@ -246,11 +249,39 @@ static bool match_reduce_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, cons
             A.pick_at[n_pick] = (t >= 0 && t <= w.len - 1) ? (int)t : -1;  // fixed_time_pickoff.py:68-74
             A.pick_rule[n_pick] = o.ip[1] == 0;
             ++n_pick;
+        } else if (o.opcode == DSP_OP_TIME_POINT_THRESH && o.src == ld.dst && n_walk < DSP_REDUCE_WALKS && o.sp[2].kind == DSP_ARG_CONST &&
+                   (o.sp[2].value == 0.0 || o.sp[2].value == 1.0)) {
+            // threshold: a constant or a float32 column; start: a constant sample inside the waveform, or where MIN_MAX found an extreme (an
+            // integer inside the waveform by construction -- the checks of time_point_thresh.py:67-74 cannot fail)
+            if (o.sp[0].kind == DSP_ARG_INPUT && io[o.sp[0].index].dtype == DSP_F32) {
+                walk_thr_io[n_walk] = o.sp[0].index;
+                A.walk_thr_stride[n_walk] = io[o.sp[0].index].row_stride;
+            } else if (o.sp[0].kind == DSP_ARG_CONST) {
+                A.walk_thr_const[n_walk] = (float)o.sp[0].value;
+            } else {
+                return false;
+            }
+            if (o.sp[1].kind == DSP_ARG_REG && reg_of_out[0] >= 0 && (o.sp[1].index == reg_of_out[0] || o.sp[1].index == reg_of_out[1])) {
+                A.walk_from[n_walk] = o.sp[1].index == reg_of_out[0] ? 1 : 2;
+            } else if (o.sp[1].kind == DSP_ARG_CONST) {
+                const double t = (double)(float)o.sp[1].value;
+                if (!(t == std::floor(t)) || t < 0 || t >= w.len) return false;
+                A.walk_start[n_walk] = (int)t;
+            } else {
+                return false;
+            }
+            A.walk_forward[n_walk] = o.sp[2].value == 1.0;
+            reg_of_walk[n_walk] = o.dst;
+            ++n_walk;
         } else {
             break;
         }
     }
     if (i == 1 || i == n_ops) return false;
+    for (int k = 0; k < DSP_REDUCE_WALKS; ++k) {
+        ch->dio_walk[k] = -1;
+        ch->dio_walk_thr[k] = walk_thr_io[k];
+    }
     for (int k = 0; k < 5; ++k) ch->dio_out[k] = -1;
     for (int k = 0; k < DSP_REDUCE_PICKS; ++k) ch->dio_pick[k] = -1;
     for (; i < n_ops; ++i) {
@@ -269,8 +300,16 @@ static bool match_reduce_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, cons
                 A.pick_stride[k] = io[o.io].row_stride;
                 placed = true;
             }
+        for (int k = 0; k < n_walk && !placed; ++k)
+            if (reg_of_walk[k] == o.ip[0] && ch->dio_walk[k] < 0) {
+                ch->dio_walk[k] = o.io;
+                A.walk_stride[k] = io[o.io].row_stride;
+                placed = true;
+            }
         if (!placed) return false;  // (a register stored twice, or one nothing here made)
     }
+    for (int k = 0; k < n_walk; ++k)
+        if (ch->dio_walk[k] < 0) return false;  // (a walk nobody stores: the program's business)
     const int es = w.dtype == DSP_F32 ? 4 : 2;
     A.wf_stride = w.row_stride;
     A.wf_offset = w.offset;
@@ -1763,6 +1802,10 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         A.wf = io_ptrs[ch->dio_wf];
         for (int k = 0; k < 5; ++k) A.out[k] = at(ch->dio_out[k]);
         for (int k = 0; k < DSP_REDUCE_PICKS; ++k) A.pick_out[k] = at(ch->dio_pick[k]);
+        for (int k = 0; k < DSP_REDUCE_WALKS; ++k) {
+            A.walk_out[k] = at(ch->dio_walk[k]);
+            A.walk_thr[k] = (const float*)at(ch->dio_walk_thr[k]);
+        }
         const int vec = ch->red_vec && (reinterpret_cast<uintptr_t>(A.wf) & 15u) == 0;
         hipError_t e = (hipError_t)dsp_internal_launch_reduce(&A, n_wf, ch->red_dtype, vec, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "reduce kernel launch failed: %s", hipGetErrorString(e));

@@ -144,8 +144,9 @@ struct CurrentArgs {
 };
 
 // arguments of the streaming reductions (dsp_reduce.hip), filled by dsp_chain_execute when a program has the shape
-//   LOAD -> {MIN_MAX | AMAX | PICKOFF at a constant integral time}+ -> STORE_SCALARs
+//   LOAD -> {MIN_MAX | AMAX | PICKOFF at a constant integral time | TIME_POINT_THRESH from a constant sample or from the extremes}+ -> STORE_SCALARs
 #define DSP_REDUCE_PICKS 4
+#define DSP_REDUCE_WALKS 2
 struct ReduceArgs {
     const void* wf;          // float32 / int16 / uint16 rows
     int64_t wf_stride;
@@ -156,6 +157,15 @@ struct ReduceArgs {
     int64_t pick_stride[DSP_REDUCE_PICKS];
     int32_t pick_at[DSP_REDUCE_PICKS];    // sample index, -1: outside the waveform (NaN)
     int32_t pick_rule[DSP_REDUCE_PICKS];  // 1: fixed_time_pickoff (a NaN anywhere in the row -> NaN), 0: the plain sample
+    // time_point_thresh walks that start at a constant sample or at the minimum / maximum found above
+    void* walk_out[DSP_REDUCE_WALKS];
+    int64_t walk_stride[DSP_REDUCE_WALKS];
+    const float* walk_thr[DSP_REDUCE_WALKS];  // threshold column, or null: walk_thr_const
+    int64_t walk_thr_stride[DSP_REDUCE_WALKS];
+    float walk_thr_const[DSP_REDUCE_WALKS];
+    int32_t walk_from[DSP_REDUCE_WALKS];      // 0: walk_start, 1: t_min, 2: t_max
+    int32_t walk_start[DSP_REDUCE_WALKS];
+    int32_t walk_forward[DSP_REDUCE_WALKS];
 };
 
 // arguments of the matrix-core FIR kernel (dsp_fir_mfma.hip): convolve_wf 'v' + numpy.amax of up to DSP_FIR_MAXK kernels on one waveform

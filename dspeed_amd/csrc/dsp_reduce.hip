@@ -1,5 +1,6 @@
 // dsp_reduce.hip -- per-event values read straight off rows in HBM: min_max (processors/min_max.py:11-82), numpy.amax, a sample at a
-// constant index (fixed_time_pickoff at an integral time, fixed_time_pickoff.py:68-80; `wf[k]`).
+// constant index (fixed_time_pickoff at an integral time, fixed_time_pickoff.py:68-80; `wf[k]`), and time_point_thresh walks that start
+// at a constant sample or at the extremes just found (time_point_thresh.py:12-92: the t0 estimate of the Ge recipes).
 //
 // Every Ge recipe asks for tp_min / tp_max / wf_min / wf_max of the raw waveform and for the maximum and one sample of a filtered one.
 // On the waveform VM that is a LOAD of the whole row into LDS, an LDS pass and -- because the 8192-sample image leaves room for one
@@ -107,6 +108,42 @@ __global__ void __launch_bounds__(256) dsp_reduce_kernel(ReduceArgs A, int64_t n
         e.imax = tmax ? oimax : e.imax;
     }
     const bool any_nan = wave_any(e.nan);
+    // time_point_thresh (time_point_thresh.py:12-92) from a sample known by now: 64 consecutive samples per step, away from the start, until a
+    // step holds a crossing -- the row was just read, the walk finds it in the caches.  Comparisons only.
+    float walked[DSP_REDUCE_WALKS];
+#pragma unroll
+    for (int k = 0; k < DSP_REDUCE_WALKS; ++k) {
+        walked[k] = quiet_nan<float>();
+        if (!A.walk_out[k]) continue;  // (uniform)
+        const float thr = A.walk_thr[k] ? A.walk_thr[k][row * A.walk_thr_stride[k]] : A.walk_thr_const[k];
+        const int ts = A.walk_from[k] == 1 ? e.imin : (A.walk_from[k] == 2 ? e.imax : A.walk_start[k]);
+        if (any_nan || thr != thr) continue;
+        int found = -1;
+        if (A.walk_forward[k]) {  // smallest i in [ts, n - 2] with w[i] <= thr < w[i+1] or w[i] >= thr > w[i+1]
+            for (int b = ts; b <= n - 2 && found < 0; b += 64) {
+                const int i = b + lane;
+                bool hit = false;
+                if (i <= n - 2) {
+                    const float cur = (float)w[i], nxt = (float)w[i + 1];
+                    hit = (cur <= thr && thr < nxt) || (cur >= thr && thr > nxt);
+                }
+                const unsigned long long m = __ballot(hit);
+                if (m) found = b + __builtin_ctzll(m);
+            }
+        } else {  // largest i in [1, ts] with w[i-1] < thr <= w[i] or w[i-1] > thr >= w[i]
+            for (int b = ts; b >= 1 && found < 0; b -= 64) {
+                const int i = b - lane;
+                bool hit = false;
+                if (i >= 1) {
+                    const float cur = (float)w[i], prv = (float)w[i - 1];
+                    hit = (prv < thr && thr <= cur) || (prv > thr && thr >= cur);
+                }
+                const unsigned long long m = __ballot(hit);
+                if (m) found = b - __builtin_ctzll(m);
+            }
+        }
+        if (found >= 0) walked[k] = (float)found;
+    }
     if (lane == 0) {
         const float nanv = quiet_nan<float>();
         // min_max: NaN anywhere -> four NaNs (min_max.py:62-68); numpy.amax of a row with a NaN is NaN
@@ -115,6 +152,9 @@ __global__ void __launch_bounds__(256) dsp_reduce_kernel(ReduceArgs A, int64_t n
 #pragma unroll
         for (int k = 0; k < 5; ++k)
             if (A.out[k]) ((float*)A.out[k])[row * A.out_stride[k]] = v[k];
+#pragma unroll
+        for (int k = 0; k < DSP_REDUCE_WALKS; ++k)
+            if (A.walk_out[k]) ((float*)A.walk_out[k])[row * A.walk_stride[k]] = walked[k];
 #pragma unroll
         for (int k = 0; k < DSP_REDUCE_PICKS; ++k) {
             if (!A.pick_out[k]) continue;

@@ -1992,6 +1992,10 @@ def _extract_stages(b: _Builder, steps, out_pars, n_rows, ft):
         if st[0] == "fixed_time_pickoff":
             t = st[1][1]
             return isinstance(t, (int, float, np.integer, np.floating)) and not isinstance(t, (bool, Quantity)) and float(t) == int(float(t))
+        if st[0] == "time_point_thresh":  # a walk from a constant sample (from an extreme of the same rows: what the t0 chain above moves)
+            _w, thr, start, walk, _o = st[1]
+            number = lambda x: isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, (bool, Quantity))  # noqa: E731
+            return (number(thr) or plain_scalar(thr)) and number(start) and float(start) == int(float(start)) and number(walk) and float(walk) in (0.0, 1.0)
         return False
 
     if ft == np.dtype(np.float32) and os.environ.get("DSPEED_HIP_NO_ROW_REDUCTIONS") != "1":
@@ -2000,7 +2004,7 @@ def _extract_stages(b: _Builder, steps, out_pars, n_rows, ft):
                 continue
             group = [g for g in rows_steps(v) if reducible(g) and g[1][0] is v]
             by_fn = [g[0] for g in group]
-            if not group or by_fn.count("min_max") > 1 or by_fn.count("amax") > 1 or by_fn.count("fixed_time_pickoff") > 4:
+            if not group or by_fn.count("min_max") > 1 or by_fn.count("amax") > 1 or by_fn.count("fixed_time_pickoff") > 4 or by_fn.count("time_point_thresh") > 2:
                 continue
             rest = [x for x in steps if not any(x is g for g in group)]
             if any(base_of(a) is v for x in rest for a, r in zip(x[1], _roles(x[0])) if r not in "WS"):

@@ -11,7 +11,7 @@ import recipes
 pytestmark = pytest.mark.gpu
 
 
-def _program(dtype, length, offset, stride, picks, with_amax=True):
+def _program(dtype, length, offset, stride, picks, with_amax=True, walks=()):
     from dspeed_amd import _lib
     from dspeed_amd.chain import Program, Scalar
 
@@ -27,6 +27,15 @@ def _program(dtype, length, offset, stride, picks, with_amax=True):
         p.add_op(_lib.OP_PICKOFF, dst=5 + k, src=0, ip=(ord("n"), kind), sp=(Scalar.const(float(t)),))
     outs = ["t_min", "t_max", "a_min", "a_max"] + (["amax"] if with_amax else []) + [f"pick{k}" for k in range(len(picks))]
     regs = [0, 1, 2, 3] + ([4] if with_amax else []) + [5 + k for k in range(len(picks))]
+    if walks:
+        thr = p.add_io("thr", _lib.IO_SCALAR_IN, np.float32)
+        for k, (from_, forward, thr_const) in enumerate(walks):
+            r = p.n_sregs
+            p.n_sregs += 1
+            start = Scalar.reg(1) if from_ == "t_max" else (Scalar.reg(0) if from_ == "t_min" else Scalar.const(float(from_)))
+            p.add_op(_lib.OP_TIME_POINT_THRESH, dst=r, src=0, sp=(Scalar.input(thr) if thr_const is None else Scalar.const(float(thr_const)), start, Scalar.const(float(forward))))
+            outs.append(f"walk{k}")
+            regs.append(r)
     for name, r in zip(outs, regs):
         io = p.add_io(name, _lib.IO_SCALAR_OUT, np.float32, 1, r % 2, 2)  # (interleaved columns: offsets and strides on the outputs)
         p.add_op(_lib.OP_STORE_SCALAR, io=io, ip=(r,))
@@ -65,31 +74,46 @@ def test_reductions_off_rows(dtype, length, offset, stride):
         rows[8, length // 4] = -0.0             # -0.0 < 0.0 is false: sample 0 stays the minimum, with its sign
     picks = [(0, 0), (length - 1, 0), (length, 0), (-1, 0), ]
     picks = picks[:3] + [(min(2, length - 1), 1)]
-    prog, outs = _program(dtype, length, offset, stride, picks)
+    mid = 30000.0 if np.dtype(dtype) == np.uint16 else 1.0
+    walks = [("t_max", 0, None), ("t_min", 1, mid)] if length >= 64 else []
+    prog, outs = _program(dtype, length, offset, stride, picks, walks=walks)
+    thr = rng.uniform(-500, 500, n).astype(np.float32) if np.dtype(dtype) != np.uint16 else rng.uniform(20000, 40000, n).astype(np.float32)
+    thr[9] = np.nan
     got = {}
     for fused in (1, 0):
         ch = Chain(prog, "reductions", np.float32)
         assert ch.set_fused(fused) == bool(fused)
         assert ("dsp_reduce_kernel" in ch.kernel_name) == bool(fused), ch.kernel_name
-        bufs = {"wf": DeviceArray.from_numpy(w)}
+        bufs = {"wf": DeviceArray.from_numpy(w), "thr": DeviceArray.from_numpy(thr)}
         for name in outs:
             bufs[name] = DeviceArray.zeros((n, 2), np.float32)
         ch.execute(bufs, n)
         ch.check()
         got[fused] = {name: bufs[name].to_numpy() for name in outs}
+    regs_col = [r % 2 for r in range(len(outs))]  # (registers 0 .. in the order of the outputs)
     for k, name in enumerate(outs):
-        col = [0, 1, 0, 1, 0, 1, 0, 1, 0][k]
+        col = regs_col[k]
         assert np.array_equal(got[1][name][:, col], got[0][name][:, col], equal_nan=True), name
         assert np.all(got[1][name][:, 1 - col] == 0), "only the binding's own column is written"
     f = np.ascontiguousarray(rows).astype(np.float32)
     t_min, t_max, a_min, a_max, rc = oracle.min_max(f)
     assert rc == 0
-    g = {name: got[1][name][:, [0, 1, 0, 1, 0, 1, 0, 1, 0][k]] for k, name in enumerate(outs)}
+    g = {name: got[1][name][:, regs_col[k]] for k, name in enumerate(outs)}
     for name, want in (("t_min", t_min), ("t_max", t_max), ("a_min", a_min), ("a_max", a_max)):
         assert np.array_equal(g[name], want, equal_nan=True), name
         assert np.array_equal(np.signbit(g[name]), np.signbit(want)), name
     with np.errstate(invalid="ignore"):
         assert np.array_equal(g["amax"], np.max(f, axis=1), equal_nan=True)
+    for k, (from_, forward, thr_const) in enumerate(walks):
+        start = t_max if from_ == "t_max" else t_min
+        ok = ~np.isnan(start)
+        want = np.full(n, np.nan, dtype=np.float32)
+        th = thr if thr_const is None else np.full(n, thr_const, dtype=np.float32)
+        res, rc = oracle.time_point_thresh(f[ok], th[ok], start[ok], float(forward))
+        assert rc == 0
+        want[ok] = res
+        assert np.array_equal(g[f"walk{k}"], want, equal_nan=True), (k, from_, forward)
+        assert np.isnan(g["walk0"][9]) and (~np.isnan(g[f"walk{k}"])).sum() > n // 8
     for k, (t, kind) in enumerate(picks):
         if kind == 0:
             want, rc = oracle.fixed_time_pickoff(f, float(t), "n")
