@@ -135,13 +135,14 @@ def lib():
         "dsp_dwt_haar_f32": [vp, C.c_int, i64, i32, i64, i32, i32, vp, i32, i64, vp, pi64],
         "dsp_convolve_wf_f32": [vp, C.c_int, i64, i32, i64, vp, i32, i32, vp, i32, i64, vp, pi64],
         "dsp_synth_waveforms": [vp, C.c_int, i64, i32, i64, vp, vp, C.c_uint64, i64, f32, f32, f32, f32, f32, f32, f32, vp],
+        "dsp_synth_pulses": [vp, C.c_int, i64, i32, i64, vp, vp, C.c_uint64, i64, f32, f32, f32, f32, f32, f32, f32, f32, f32, vp],
         "dsp_stream_read": [vp, i64, vp, vp],
         "dsp_linear_slope_fit_rows": [vp, C.c_int, i64, i32, i64, C.c_int, vp, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double,
                                       C.POINTER(FitWindow), C.c_int, vp, vp],
     }
     f64 = C.c_double
     for name in list(sig):  # the float64 loops: same argument order, double scalars
-        if name.endswith("_f32") and name != "dsp_synth_waveforms":
+        if name.endswith("_f32") and name not in ("dsp_synth_waveforms", "dsp_synth_pulses"):
             sig[name[:-4] + "_f64"] = [f64 if t is f32 else t for t in sig[name]]
     for name, argtypes in sig.items():
         fn = getattr(L, name)
@@ -167,7 +168,7 @@ EXPORTS = [
     "dsp_double_pole_zero_f32", "dsp_pole_zero_col_f32", "dsp_double_pole_zero_col_f32", "dsp_pole_zero_col_f64", "dsp_double_pole_zero_col_f64", "dsp_trap_filter_f32", "dsp_trap_norm_f32", "dsp_asym_trap_filter_f32", "dsp_fixed_time_pickoff_f32",
     "dsp_install_abort_trace", "dsp_uninstall_abort_trace", "dsp_chain_profile", "dsp_chain_profile_read", "dsp_min_max_norm_f32", "dsp_min_max_norm_f64", "dsp_time_point_thresh_f32", "dsp_interpolated_time_point_thresh_f32", "dsp_interpolated_time_point_thresh_f64", "dsp_min_max_f32", "dsp_mean_below_threshold_f32", "dsp_mean_below_threshold_f64", "dsp_windower_f32", "dsp_windower_f64", "dsp_avg_current_f32",
     "dsp_avg_current_f64", "dsp_trap_pickoff_f32", "dsp_trap_pickoff_f64", "dsp_upsampler_f32", "dsp_upsampler_f64",
-    "dsp_moving_window_multi_f32", "dsp_moving_window_multi_f64", "dsp_linear_slope_fit_f32", "dsp_linear_slope_fit_f64", "dsp_dwt_haar_f32", "dsp_convolve_wf_f32", "dsp_synth_waveforms", "dsp_stream_read",
+    "dsp_moving_window_multi_f32", "dsp_moving_window_multi_f64", "dsp_linear_slope_fit_f32", "dsp_linear_slope_fit_f64", "dsp_dwt_haar_f32", "dsp_convolve_wf_f32", "dsp_synth_waveforms", "dsp_synth_pulses", "dsp_stream_read",
     "dsp_bl_subtract_f64", "dsp_pole_zero_f64", "dsp_double_pole_zero_f64", "dsp_trap_filter_f64", "dsp_trap_norm_f64",
     "dsp_asym_trap_filter_f64", "dsp_fixed_time_pickoff_f64", "dsp_time_point_thresh_f64", "dsp_min_max_f64", "dsp_dwt_haar_f64",
     "dsp_convolve_wf_f64", "dsp_linear_slope_fit_rows",

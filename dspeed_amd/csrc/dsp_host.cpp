@@ -38,7 +38,7 @@ extern "C" int dsp_internal_launch_stream_read(const void* src, int64_t bytes, u
 extern "C" int dsp_internal_launch_fit_rows(const FitArgs* A, int wf_dtype, int compute_dtype, hipStream_t stream);
 extern "C" int dsp_internal_launch_synth(void* wf, int out_dtype, int64_t n_wf, int wf_len, int64_t row_stride, float* baseline,
                                          float* t_pick, uint64_t seed, int64_t first_row, float tau, float sigma, float pick_offset,
-                                         float bl_lo, float bl_hi, float amp_lo, float amp_hi, hipStream_t stream);
+                                         float bl_lo, float bl_hi, float amp_lo, float amp_hi, float rise_lo, float rise_hi, hipStream_t stream);
 
 // mirror of the struct in dsp_energy.hip
 struct EnergyArgs {
@@ -2493,7 +2493,19 @@ int dsp_synth_waveforms(void* wf, int out_dtype, int64_t n_wf, int32_t wf_len, i
     if (out_dtype != DSP_F32 && out_dtype != DSP_I16) return fail(DSP_ERR_ARG, "synth output must be float32 or int16");
     if (n_wf <= 0) return DSP_OK;
     hipError_t e = (hipError_t)dsp_internal_launch_synth(wf, out_dtype, n_wf, wf_len, row_stride, baseline, t_pick, seed, first_row, tau,
-                                                         sigma, pick_offset, bl_lo, bl_hi, amp_lo, amp_hi, (hipStream_t)stream);
+                                                         sigma, pick_offset, bl_lo, bl_hi, amp_lo, amp_hi, 1.0f, 1.0f, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DSP_ERR_HIP, "synth launch failed: %s", hipGetErrorString(e));
+    return DSP_OK;
+}
+
+int dsp_synth_pulses(void* wf, int out_dtype, int64_t n_wf, int32_t wf_len, int64_t row_stride, float* baseline, float* t_pick, uint64_t seed,
+                     int64_t first_row, float tau, float sigma, float pick_offset, float bl_lo, float bl_hi, float amp_lo, float amp_hi,
+                     float rise_lo, float rise_hi, void* stream) {
+    if (out_dtype != DSP_F32 && out_dtype != DSP_I16) return fail(DSP_ERR_ARG, "synth output must be float32 or int16");
+    if (!(rise_lo >= 1.0f) || !(rise_hi >= rise_lo)) return fail(DSP_ERR_ARG, "synth: rise times are 1 <= rise_lo <= rise_hi samples");
+    if (n_wf <= 0) return DSP_OK;
+    hipError_t e = (hipError_t)dsp_internal_launch_synth(wf, out_dtype, n_wf, wf_len, row_stride, baseline, t_pick, seed, first_row, tau,
+                                                         sigma, pick_offset, bl_lo, bl_hi, amp_lo, amp_hi, rise_lo, rise_hi, (hipStream_t)stream);
     if (e != hipSuccess) return fail(DSP_ERR_HIP, "synth launch failed: %s", hipGetErrorString(e));
     return DSP_OK;
 }

@@ -2340,13 +2340,16 @@ template <typename OutT>
 __global__ void __launch_bounds__(256) dsp_synth_kernel(OutT* wf, int64_t n_wf, int wf_len, int64_t row_stride, float* baseline,
                                                         float* t_pick, uint32_t seed_lo, uint32_t seed_hi, int64_t first_row,
                                                         float inv_tau, float sigma, float pick_offset, float bl_lo, float bl_hi,
-                                                        float amp_lo, float amp_hi) {
+                                                        float amp_lo, float amp_hi, float rise_lo, float rise_hi) {
     for (int64_t r = blockIdx.x; r < n_wf; r += gridDim.x) {
         const uint64_t gr = (uint64_t)(first_row + r);
         const uint32_t k0 = mix32((uint32_t)gr ^ seed_lo), k1 = mix32((uint32_t)(gr >> 32) ^ seed_hi ^ k0);
         const float B = bl_lo + (bl_hi - bl_lo) * u01(mix32(k1 ^ 0x1234567u));
         const float A = amp_lo + (amp_hi - amp_lo) * u01(mix32(k1 ^ 0x89abcdeu));
         const float t0 = floorf((0.45f + 0.10f * u01(mix32(k1 ^ 0x5555aaau))) * (float)wf_len);
+        // charge collection: the step reaches its height over `rise` samples, linearly (rise_hi <= 1: within one sample, as dsp_synth_waveforms)
+        const float rise = rise_hi > 1.0f ? rise_lo + (rise_hi - rise_lo) * u01(mix32(k1 ^ 0x3141592u)) : 1.0f;
+        const float inv_rise = 1.0f / rise;
         if (threadIdx.x == 0) {
             if (baseline) baseline[r] = B;
             if (t_pick) t_pick[r] = t0 + pick_offset;
@@ -2358,7 +2361,7 @@ __global__ void __launch_bounds__(256) dsp_synth_kernel(OutT* wf, int64_t n_wf, 
                             1.7320508f;
             const float d = (float)i - t0;
             float v = B + sigma * n;
-            if (d >= 0.0f) v += A * __expf(-d * inv_tau);
+            if (d >= 0.0f) v += A * __expf(-d * inv_tau) * fminf((d + 1.0f) * inv_rise, 1.0f);
             if (sizeof(OutT) == 2)
                 wf[r * row_stride + i] = (OutT)__float2int_rn(v);
             else
@@ -2422,15 +2425,15 @@ extern "C" const char* dsp_internal_vm_kernel_name() { return "dsp_vm_kernel<flo
 
 extern "C" int dsp_internal_launch_synth(void* wf, int out_dtype, int64_t n_wf, int wf_len, int64_t row_stride, float* baseline,
                                          float* t_pick, uint64_t seed, int64_t first_row, float tau, float sigma, float pick_offset,
-                                         float bl_lo, float bl_hi, float amp_lo, float amp_hi, hipStream_t stream) {
+                                         float bl_lo, float bl_hi, float amp_lo, float amp_hi, float rise_lo, float rise_hi, hipStream_t stream) {
     const int blocks = (int)(n_wf < 8192 ? (n_wf > 0 ? n_wf : 1) : 8192);
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
     if (out_dtype == DSP_I16)
         hipLaunchKernelGGL(dsp_synth_kernel<int16_t>, dim3(blocks), dim3(256), 0, stream, (int16_t*)wf, n_wf, wf_len, row_stride,
-                           baseline, t_pick, lo, hi, first_row, 1.0f / tau, sigma, pick_offset, bl_lo, bl_hi, amp_lo, amp_hi);
+                           baseline, t_pick, lo, hi, first_row, 1.0f / tau, sigma, pick_offset, bl_lo, bl_hi, amp_lo, amp_hi, rise_lo, rise_hi);
     else
         hipLaunchKernelGGL(dsp_synth_kernel<float>, dim3(blocks), dim3(256), 0, stream, (float*)wf, n_wf, wf_len, row_stride, baseline,
-                           t_pick, lo, hi, first_row, 1.0f / tau, sigma, pick_offset, bl_lo, bl_hi, amp_lo, amp_hi);
+                           t_pick, lo, hi, first_row, 1.0f / tau, sigma, pick_offset, bl_lo, bl_hi, amp_lo, amp_hi, rise_lo, rise_hi);
     return (int)hipGetLastError();
 }
 

@@ -428,6 +428,13 @@ int dsp_synth_waveforms(void* wf, int out_dtype, int64_t n_wf, int32_t wf_len, i
                         uint64_t seed, int64_t first_row, float tau, float sigma, float pick_offset, float bl_lo, float bl_hi,
                         float amp_lo, float amp_hi, void* stream);
 
+/* The same rows with a charge-collection time: the step reaches its height linearly over `rise` samples, rise uniform in
+ * [rise_lo, rise_hi] per waveform (the recipe benchmarks: the rise-time walks of a Ge recipe end a few samples from their start on
+ * pulses that take tens of samples to rise, as the detectors' do, and walk the whole waveform on a one-sample step). */
+int dsp_synth_pulses(void* wf, int out_dtype, int64_t n_wf, int32_t wf_len, int64_t row_stride, float* baseline, float* t_pick, uint64_t seed,
+                     int64_t first_row, float tau, float sigma, float pick_offset, float bl_lo, float bl_hi, float amp_lo, float amp_hi,
+                     float rise_lo, float rise_hi, void* stream);
+
 /* ---- measurement helper (bench.py; SURVEY.md 8d "also report against a measured read-only streaming kernel") -----------
  * Reads `bytes` (multiple of 16) device bytes once with 16-byte loads and discards them; `sink` = any 4 writable device bytes.
  * Asynchronous on `stream`.  Replaces nothing in the reference. */

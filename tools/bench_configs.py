@@ -26,10 +26,15 @@ HBM_PEAK, FMA_PEAK = 8000.0, 157.3  # GB/s, TFLOP/s (MI355X_MICROARCH.md)
 TAU, SIGMA, SEED = 1716.28, 5.0, 0xD5BEED
 
 
-def synth(rows, wf_len, dtype, stream, bl_lo=9000.0, bl_hi=11000.0):
+def synth(rows, wf_len, dtype, stream, bl_lo=9000.0, bl_hi=11000.0, rise=None):
+    """rise=(lo, hi): pulses that take lo .. hi samples to reach their height (dsp_synth_pulses) instead of one-sample steps"""
     wf = DeviceArray((rows, wf_len), dtype)
     bl, tp = DeviceArray((rows,), np.float32), DeviceArray((rows,), np.float32)
     code = _lib.I16 if np.dtype(dtype) == np.int16 else _lib.F32
+    if rise is not None:
+        _lib.check(_lib.lib().dsp_synth_pulses(wf.ptr, code, rows, wf_len, wf_len, bl.ptr, tp.ptr, SEED, 0, TAU, SIGMA, 625 + 0.8 * 188,
+                                               bl_lo, bl_hi, 500.0, 15000.0, float(rise[0]), float(rise[1]), stream.ptr), what="synth")
+        return wf, bl, tp
     _lib.check(_lib.lib().dsp_synth_waveforms(wf.ptr, code, rows, wf_len, wf_len, bl.ptr, tp.ptr, SEED, 0, TAU, SIGMA, 625 + 0.8 * 188,
                                               bl_lo, bl_hi, 500.0, 15000.0, stream.ptr), what="synth")
     return wf, bl, tp
