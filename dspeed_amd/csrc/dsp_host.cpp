@@ -93,6 +93,12 @@ extern "C" int dsp_internal_set_current_lds(int lds_bytes);
 extern "C" const char* dsp_internal_current_kernel_name();
 extern "C" int dsp_internal_fir_mfma_lds_bytes(int kend);
 extern "C" int dsp_internal_launch_fir_mfma(const FirArgs* A, int64_t n_wf, int lds_bytes, hipStream_t stream);
+extern "C" int dsp_internal_launch_fir_f16(const FirArgs* A, const FirF16Taps* T, int64_t n_wf, int lds_bytes, hipStream_t stream);
+extern "C" int dsp_internal_fir_f16_tz(int kend);
+extern "C" size_t dsp_internal_fir_f16_taps_bytes(int kend);
+extern "C" int dsp_internal_fir_f16_lds_bytes();
+extern "C" int dsp_internal_set_fir_f16_lds(int lds_bytes);
+extern "C" const char* dsp_internal_fir_f16_kernel_name();
 extern "C" int dsp_internal_set_fir_mfma_lds(int lds_bytes);
 extern "C" const char* dsp_internal_fir_mfma_kernel_name();
 extern "C" int dsp_internal_fir_store_lds_bytes(int kend);
@@ -185,6 +191,9 @@ struct dsp_chain {
     FirArgs fir{};
     int fir_lds_bytes = 0;
     int fio_wf = -1, fio_bl = -1, fio_taps[DSP_FIR_MAXK] = {-1, -1, -1, -1}, fio_out[DSP_FIR_MAXK] = {-1, -1, -1, -1};
+    // the amax form on the float16 matrix instructions (dsp_fir_f16.hip): the default where the rows keep 16-byte alignment
+    bool fir_f16 = false;
+    FirF16Taps f16{};  // device images of the kernels' taps (rewritten by every launch: the taps are a binding)
     // a program of scalar ops only (dsp_scalar.hip: a row per lane)
     bool scalar_ok = false;
     // lane-per-waveform current-branch kernel (dsp_current.hip)
@@ -208,6 +217,8 @@ struct dsp_chain {
         if (host.prof) (void)hipFree(host.prof);
         if (err_mirror) (void)hipHostFree(err_mirror);
         if (cur_scratch) (void)hipFree(cur_scratch);
+        for (int k = 0; k < DSP_FIR_MAXK; ++k)
+            if (f16.taps16[k]) (void)hipFree(const_cast<void*>(f16.taps16[k]));
     }
 };
 
@@ -1608,6 +1619,20 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     if (ch->fir_ok) {
         const char* env = getenv("DSPEED_HIP_NO_FUSED");
         ch->fused_on = !(env && env[0] == '1');
+        // the amax form runs on the float16 matrix instructions (two-way split operands, float32-accurate: dsp_fir_f16.hip) unless asked
+        // for the float32 ones (DSPEED_HIP_FIR_F32=1: A/B and the exact float32 chain); its staging loads are 16 bytes of any row type
+        const char* f32 = getenv("DSPEED_HIP_FIR_F32");
+        const dsp_io_desc& w = io[ch->fio_wf];
+        const int es = w.dtype == DSP_F32 ? 4 : 2;
+        if (!ch->fir.store && !(f32 && f32[0] == '1') && (w.row_stride * es) % 16 == 0 && (w.offset * es) % 16 == 0) {
+            ch->fir_f16 = true;
+            ch->f16.tz = dsp_internal_fir_f16_tz(ch->fir.kend);
+            for (int k = 0; k < ch->fir.n_kernels; ++k) {
+                void* buf = nullptr;
+                HIP_TRY(hipMalloc(&buf, dsp_internal_fir_f16_taps_bytes(ch->fir.kend)));
+                ch->f16.taps16[k] = buf;
+            }
+        }
     }
     ch->rows_ok = match_rows_shape(ch.get(), ops, n_ops, io, n_io, slot_len, n_slots, dev_index, f64);
     if (!ch->rows_ok) {
@@ -1693,6 +1718,10 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     if (ch->fused_ok && classic_lds > 64 * 1024) {
         hipError_t e = (hipError_t)dsp_internal_set_energy_lds(ch->fused_trap, ch->fused_npf, classic_lds);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(energy kernel, %d): %s", classic_lds, hipGetErrorString(e));
+    }
+    if (ch->fir_f16 && dsp_internal_fir_f16_lds_bytes() > 64 * 1024) {
+        hipError_t e = (hipError_t)dsp_internal_set_fir_f16_lds(dsp_internal_fir_f16_lds_bytes());
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "hipFuncSetAttribute(float16 FIR kernel): %s", hipGetErrorString(e));
     }
     if (ch->fir_ok && ch->fir_lds_bytes > 64 * 1024) {
         hipError_t e = (hipError_t)(ch->fir.store ? dsp_internal_set_fir_store_lds(ch->fir_lds_bytes) : dsp_internal_set_fir_mfma_lds(ch->fir_lds_bytes));
@@ -1839,8 +1868,9 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
             A.taps[k] = (const float*)at(ch->fio_taps[k]);
             A.out[k] = at(ch->fio_out[k]);
         }
-        hipError_t e = (hipError_t)(A.store ? dsp_internal_launch_fir_store(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream)
-                                            : dsp_internal_launch_fir_mfma(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream));
+        hipError_t e = (hipError_t)(A.store     ? dsp_internal_launch_fir_store(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream)
+                                    : ch->fir_f16 ? dsp_internal_launch_fir_f16(&A, &ch->f16, n_wf, dsp_internal_fir_f16_lds_bytes(), (hipStream_t)stream)
+                                                  : dsp_internal_launch_fir_mfma(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream));
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "FIR kernel launch failed: %s", hipGetErrorString(e));
         return post_err(ch, stream);
     }
@@ -2019,7 +2049,8 @@ const char* dsp_chain_kernel_name(dsp_chain* ch) {
     if (ch && ch->scalar_ok && ch->fused_on) return dsp_internal_scalar_kernel_name();
     if (ch && ch->red_ok && ch->fused_on) return dsp_internal_reduce_kernel_name();
     if (ch && ch->cur_ok && ch->fused_on) return dsp_internal_current_kernel_name();
-    if (ch && ch->fir_ok && ch->fused_on) return ch->fir.store ? dsp_internal_fir_store_kernel_name() : dsp_internal_fir_mfma_kernel_name();
+    if (ch && ch->fir_ok && ch->fused_on)
+        return ch->fir.store ? dsp_internal_fir_store_kernel_name() : (ch->fir_f16 ? dsp_internal_fir_f16_kernel_name() : dsp_internal_fir_mfma_kernel_name());
     if (ch && ch->rows_ok && ch->fused_on) return dsp_internal_rows_kernel_name();
     if (ch && ch->rr_ok && ch->fused_on && ch->variant != 1) return dsp_internal_energy_rr_kernel_name();
     return (ch && ch->fused_ok && ch->fused_on) ? dsp_internal_energy_kernel_name() : dsp_internal_vm_kernel_name();

@@ -189,3 +189,10 @@ struct FirArgs {
     int32_t store;           // 1: ONE kernel whose p[0] outputs are written to out[0] as a waveform (dsp_fir_store_kernel), any mode
     int32_t dshift;          // store: output c is the sum over samples c - dshift .. c - dshift + m - 1 ('v' 0, 's' m / 2, 'f' m - 1)
 };
+
+// the float16 tap images of dsp_fir_f16.hip (one per kernel: 16 shifted / split copies of tz halfs, then the inverse scale), chain-owned
+struct FirF16Taps {
+    const void* taps16[DSP_FIR_MAXK];
+    int32_t tz;
+};
+

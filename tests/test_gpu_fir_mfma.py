@@ -23,6 +23,23 @@ def _synth(rng, n_wf, wf_len, dtype=np.float32, bl=(9000, 11000)):
     return x.astype(dtype), B[:, 0].astype(np.float32)
 
 
+@pytest.fixture(autouse=True, params=["f16", "f32"])
+def fir_kind(request, monkeypatch):
+    """every case on both forms of the 'valid' + amax kernel: the float16 matrix instructions on two-way split operands (the default,
+    dsp_fir_f16.hip) and the float32 ones (DSPEED_HIP_FIR_F32=1, dsp_fir_mfma.hip)"""
+    if request.param == "f32":
+        monkeypatch.setenv("DSPEED_HIP_FIR_F32", "1")
+    else:
+        monkeypatch.delenv("DSPEED_HIP_FIR_F32", raising=False)
+    return request.param
+
+
+def _amax_kernel():
+    import os
+
+    return "dsp_fir_mfma_kernel" if os.environ.get("DSPEED_HIP_FIR_F32") == "1" else "dsp_fir_f16_kernel"
+
+
 def _run(recipe, tb, fused=True):
     from dspeed_amd.processing_chain import build_processing_chain
 
@@ -64,7 +81,7 @@ def test_c3_geometry_against_float64_and_the_oracle():
     rng = np.random.default_rng(30)
     wf, bl = _synth(rng, 70, 8192)
     chain, out = _run(recipes.C3, {"waveform": wf, "baseline": bl})
-    assert chain._chain.kernel_name == "dsp_fir_mfma_kernel"
+    assert chain._chain.kernel_name == _amax_kernel()
     xb = oracle.bl_subtract(wf, bl)[0]
     for nm in ("cusp", "zac"):
         k = chain._consts[f"taps:{nm}_kernel"][:5792]
@@ -86,7 +103,9 @@ def test_agrees_with_the_waveform_vm():
     chain, b = _run(recipes.C3, {"waveform": wf, "baseline": bl}, fused=False)
     assert chain._chain.kernel_name.startswith("dsp_vm")
     for nm in ("cuspEmax", "zacEmax"):
-        assert np.max(np.abs(a[nm] - b[nm]) / np.abs(b[nm])) <= 2e-6  # (relative to the value itself: looser than the peak)
+        # (relative to the value itself, which for the zero-area kernel can be a hundredth of the filtered waveform's peak: far looser than the
+        # bar, which the tests above hold against float64 relative to the peak)
+        assert np.max(np.abs(a[nm] - b[nm]) / np.abs(b[nm])) <= 5e-6
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.int16, np.uint16])
@@ -97,7 +116,7 @@ def test_row_types_and_counts(dtype, n_wf):
     kernels = {"cusp": ("cusp_filter", (100, 20, 2000), 700), "zac": ("zac_filter", (100, 20, 2000), 700)}
     rec = _recipe(kernels, 0, 960)
     chain, out = _run(rec, {"waveform": wf, "baseline": bl})
-    assert chain._chain.kernel_name == "dsp_fir_mfma_kernel"
+    assert chain._chain.kernel_name == _amax_kernel()
     xb = oracle.bl_subtract(wf.astype(np.float32), bl)[0]
     for nm in kernels:
         want, peak = _want(chain, xb, nm, 700, 0, 960)
@@ -113,7 +132,7 @@ def test_one_three_and_unequal_kernels_and_offsets():
                             ({"a": ("zac_filter", (300, 40, 9000), 3800), "b": ("cusp_filter", (300, 40, 9000), 3900)}, 0, 4096)):
         rec = _recipe(kernels, lo, hi)
         chain, out = _run(rec, {"waveform": wf, "baseline": bl})
-        assert chain._chain.kernel_name == "dsp_fir_mfma_kernel", list(kernels)
+        assert chain._chain.kernel_name == _amax_kernel(), list(kernels)
         for nm, (_, _, m) in kernels.items():
             want, peak = _want(chain, xb, nm, m, lo, hi)
             assert np.max(np.abs(out[f"{nm}Emax"] - want) / peak) <= TOL, (nm, m)
@@ -131,7 +150,7 @@ def test_nan_and_infinite_samples_follow_the_reference():
     kernels = {"cusp": ("cusp_filter", (100, 20, 2000), 700), "zac": ("zac_filter", (100, 20, 2000), 700)}
     rec = _recipe(kernels, 0, 960)
     chain, out = _run(rec, {"waveform": wf, "baseline": bl})
-    assert chain._chain.kernel_name == "dsp_fir_mfma_kernel"
+    assert chain._chain.kernel_name == _amax_kernel()
     xb = oracle.bl_subtract(wf, bl)[0]
     for nm in kernels:
         k = chain._consts[f"taps:k_{nm}"][:700]
@@ -291,7 +310,7 @@ def test_staged_filters_agree_with_the_one_program_form(monkeypatch):
     chain, staged, one = _both_ways(rec, {"waveform": wf}, monkeypatch)
     kinds = sorted(st["chain"].kernel_name for st in chain._stages)
     # (the maximum of wf_b, which nothing else reads, comes straight off its rows)
-    assert kinds == ["dsp_fir_mfma_kernel", "dsp_fir_store_kernel", "dsp_fir_store_kernel", "dsp_reduce_kernel", "dsp_vm_kernel<float>"], kinds
+    assert kinds == sorted([_amax_kernel(), "dsp_fir_store_kernel", "dsp_fir_store_kernel", "dsp_reduce_kernel", "dsp_vm_kernel<float>"]), kinds
     assert np.array_equal(staged["bl_mean"], one["bl_mean"])
     peak = np.abs(one["wf_a"]).max(axis=1)
     assert np.max(np.abs(staged["wf_a"] - one["wf_a"]) / peak[:, None]) <= 2e-6
