@@ -1,22 +1,25 @@
-// dsp_fir_f16.hip -- the long FIR of the energy filters (convolve_wf 'v' + numpy.amax: dsp_fir_mfma.hip's product) on the HALF-PRECISION
-// matrix instructions, float32-accurate.
+// dsp_fir_f16.hip -- the long FIRs of dsp_fir_mfma.hip (convolve_wf 'v' + numpy.amax, and convolve_wf in any mode with its output kept) on
+// the HALF-PRECISION matrix instructions, float32-accurate.
 //
 // v_mfma_f32_16x16x4_f32 is an exact float32 chain but runs at 1/16 of the rate of v_mfma_f32_16x16x32_f16.  A float32 number is the sum
 // of two float16 numbers to 22 bits -- hi = half(x), lo = half(x - hi) -- once it is scaled into float16's range by a power of two, so
 //     x . t  =  hi_x hi_t  +  hi_x lo_t  +  lo_x hi_t  (+ lo_x lo_t, 2^-22 of the product: dropped)
-// is three float16 products, each exact in the instruction's float32 accumulator: 3/16 of the matrix time of the float32 form, and the
-// representation error (measured on the cusp / zac kernels and BASELINE's rows: 4e-9 .. 2e-7 of the filtered waveform's peak,
-// tools/fir_accuracy.py) is below what accumulating in float32 costs either way.  As in the float32 kernel the partial sums leave float32
-// every 256 samples and are added in float64.
+// is three float16 products, each exact in the instruction's float32 accumulator: 3/16 of the matrix time of the float32 form.  Measured
+// against float64 on the cusp / zac kernels and BASELINE's rows the result is as close as the float32 kernel's (1.5e-7 / 5.5e-7 of the
+// filtered waveform's peak, tools/fir_f16_accuracy.py): what limits both is the float32 accumulation, and as there the partial sums leave
+// float32 every 256 samples and are added in float64.
 //
-//   * rows: every row gets its own power-of-two scale from its largest |sample - baseline| (a first pass of the workgroup over its 64
-//     rows), so the split keeps 22 bits whatever the waveform's magnitude; the scale is undone, exactly, on the way out;
+//   * rows: dsp_fir_f16_rows_kernel streams every row once (a wavefront per row) and leaves its power-of-two scale -- the largest
+//     |sample - baseline| lands in [2^14, 2^15) -- and its flags (a NaN, an infinity); the split keeps 22 bits whatever the waveform's
+//     magnitude and the scale is undone, exactly, on the way out;
 //   * taps: dsp_fir_f16_prep_kernel scales the kernel by one power of two, splits it, reverses it and writes it with zero margins EIGHT
 //     times, shifted by 0..7 elements: the B fragment of lane (column c, k-block h) is the 8 consecutive taps kr[k + 8h - c ..], a 16-byte
 //     read that is aligned in the copy shifted by (-c) mod 8 -- the Toeplitz matrix is never materialised;
-//   * per stage of 64 samples the 64 x 64 A tile (two float16 planes) and the 384-tap window of the 16 tap copies are staged in LDS,
-//     double buffered; a wavefront owns 32 rows x 80 columns = 2 x 5 tiles and issues 30 MFMAs per 32 samples against 14 ds_read_b128;
-//   * rows holding a NaN / an infinity / a sample beyond float16's scaled range are handled as in the float32 kernel (NaN, or tap by tap).
+//   * a workgroup = 64 rows x 320 columns (one kernel's 'valid' outputs, or a column tile of a kept output); per stage of 64 samples the
+//     64 x 64 A tile (two float16 planes) and the 400-tap window of the 16 tap copies are staged in LDS, double buffered; a wavefront owns
+//     2 x 5 tiles of 16 x 16 and issues 30 MFMAs per 32 samples against 14 ds_read_b128; a column tile that meets no tap of a short kernel
+//     in a 32-sample group is skipped;
+//   * rows holding a NaN / an infinity are handled as by the float32 kernels (all NaN, or tap by tap in float32).
 #include <hip/hip_runtime.h>
 
 #include "dsp_program.h"
@@ -29,17 +32,25 @@
 namespace {
 
 constexpr int BM = 64, BN = 320, BK = 64, MT = 2, NT = 5;
-constexpr int APITCH = BK + 8;        // halfs per A row: 144 bytes, rows 16 bytes apart modulo the 128-byte bank line
-constexpr int TWIN = BN + BK;         // taps a stage's fragments can reach
-constexpr int TPITCH = TWIN + 8;      // halfs per tap copy in LDS: copies 16 bytes apart modulo the bank line
-constexpr int KFLUSH = 256;           // samples between two float64 flushes
+constexpr int APITCH = BK + 8;   // halfs per A row: 144 bytes, rows 16 bytes apart modulo the 128-byte bank line
+constexpr int TB = 336;          // zero margin below tap 0: window index TB + k - column - e - shift is never negative
+constexpr int TWIN = TB + BK;    // taps a stage's fragments can reach
+// halfs per tap copy in LDS: 848 bytes = 53 x 16, so the eight copies start in eight different 16-byte bank groups; the shifted copies
+// (1..7) sit 8 halfs further in, which cancels the 16 bytes their fragments start earlier than copy 0's: the eight lanes a read serves
+// together -- eight columns, eight copies -- then touch eight different bank groups (without it copy 0's lane met another: 42 % of the
+// LDS-active cycles were conflicts)
+constexpr int TPITCH = TWIN + 24;
+constexpr int KFLUSH = 256;      // samples between two float64 flushes ('valid' + amax over thousands of taps)
+constexpr int KFLUSH_STORE = 128;  // ... of the kept-output form: short differentiating kernels cancel, partial sums far above the output
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ float pow2_inverse(float p) { return __uint_as_float((254u << 23) - __float_as_uint(p)); }  // 1 / 2^k, exactly
+
 // ---- taps: scaled, split, reversed, zero-margined, eight shifted copies.  Layout of `dst` (halfs): [split 0..1][shift 0..7][TZ], then one float
-// (the inverse scale) at byte offset 2 * 16 * TZ.  tapz[idx] = kr[idx - BN] for 0 <= idx - BN < m, else 0;  copy_r[i] = tapz[i + r].
+// (the inverse scale) at byte offset 2 * 16 * TZ.  tapz[idx] = kr[idx - TB] for 0 <= idx - TB < m, else 0;  copy_r[i] = tapz[i + r].
 __global__ void __launch_bounds__(256) dsp_fir_f16_prep_kernel(const float* __restrict__ taps, int m, int TZ, _Float16* __restrict__ dst) {
     __shared__ float red[256];
     const int tid = (int)threadIdx.x;
@@ -56,32 +67,111 @@ __global__ void __launch_bounds__(256) dsp_fir_f16_prep_kernel(const float* __re
     }
     mx = red[0];
     int e = (int)((__float_as_uint(mx) >> 23) & 0xffu) - 127;  // floor(log2(mx)) for normal numbers
-    if (!(mx > 0.0f) || e < -100) e = 14;                        // all zeros (or denormal noise): scale 1
-    const float scale = __uint_as_float((unsigned)(127 + 14 - e) << 23);      // mx * scale in [2^14, 2^15)
-    const float inv_scale = __uint_as_float((unsigned)(127 - 14 + e) << 23);
+    if (!(mx > 0.0f) || e < -100 || e > 100) e = 14;           // all zeros (or beyond any sensible kernel): scale 1
+    const float scale = __uint_as_float((unsigned)(127 + 14 - e) << 23);  // mx * scale in [2^14, 2^15)
     for (int idx = tid; idx < 8 * TZ; idx += 256) {
         const int r = idx / TZ, i = idx - r * TZ;
-        const int t = i + r - BN;
+        const int t = i + r - TB;
         const float v = (t >= 0 && t < m) ? taps[m - 1 - t] * scale : 0.0f;
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
         dst[(size_t)r * TZ + i] = hi;
         dst[(size_t)(8 + r) * TZ + i] = lo;
     }
-    if (tid == 0) *(float*)(dst + (size_t)16 * TZ) = inv_scale;
+    if (tid == 0) *(float*)(dst + (size_t)16 * TZ) = pow2_inverse(scale);
 }
 
+// ---- rows: one wavefront per row; scale[row] = 2^(14 - floor(log2(max |x - baseline|))) over the slice, flags[row] bit 0: an infinity (or a
+// magnitude whose scale would leave float32), bit 1: a NaN in the slice or -- bl_subtract's rule, DSP_OP_LOAD ip[0..1] -- around it.
 template <int IN>
+__global__ void __launch_bounds__(256) dsp_fir_f16_rows_kernel(FirArgs A_, float* __restrict__ scale, unsigned* __restrict__ flags, int64_t n_wf) {
+    const FIR_KARG FirArgs& A = *(const FIR_KARG FirArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)A_;
+    const int lane = (int)threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (row >= n_wf) return;
+    constexpr int ESZ = IN == 0 ? 4 : 2;
+    const int n = A.n;
+    const FIR_GLOBAL char* rowp = (const FIR_GLOBAL char*)A.wf + (row * A.wf_stride + A.wf_offset) * ESZ;
+    const bool sub = A.sub_mode != 0;
+    const float bl = sub ? (A.bl ? ((const FIR_GLOBAL float*)A.bl)[row * A.bl_stride] : A.bl_const) : 0.0f;
+    auto at = [&](int i) -> float {
+        const float x = IN == 0 ? ((const FIR_GLOBAL float*)rowp)[i] : (IN == 1 ? (float)((const FIR_GLOBAL short*)rowp)[i] : (float)((const FIR_GLOBAL unsigned short*)rowp)[i]);
+        return sub ? x - bl : x;
+    };
+    float mx = 0.0f;
+    bool has_nan = false;
+    auto see = [&](float x) {
+        const float a = __builtin_fabsf(x);
+        has_nan |= (x != x);
+        mx = a > mx ? a : mx;  // (a NaN never raises it)
+    };
+    const int n8 = n & ~7;
+    for (int i0 = lane * 8; i0 < n8; i0 += 4 * 512) {  // 8 samples per lane and load, four loads in flight
+        float x[4][8];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = i0 + b * 512;
+            if (i < n8) {
+                if (IN == 0) {
+                    const f4 v0 = *(const FIR_GLOBAL f4*)(rowp + (size_t)i * 4), v1 = *(const FIR_GLOBAL f4*)(rowp + (size_t)i * 4 + 16);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        x[b][u] = v0[u];
+                        x[b][4 + u] = v1[u];
+                    }
+                } else {
+                    const u4 raw = *(const FIR_GLOBAL u4*)(rowp + (size_t)i * 2);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        x[b][2 * u] = IN == 1 ? (float)(short)(raw[u] & 0xffffu) : (float)(raw[u] & 0xffffu);
+                        x[b][2 * u + 1] = IN == 1 ? (float)(short)(raw[u] >> 16) : (float)(raw[u] >> 16);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (i0 + b * 512 < n8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) see(sub ? x[b][u] - bl : x[b][u]);
+            }
+    }
+    for (int i = n8 + lane; i < n; i += 64) see(at(i));
+    if (IN == 0 && sub) {
+        for (int i = -A.scan_before + lane; i < 0; i += 64) has_nan |= (at(i) != at(i));
+        for (int i = n + lane; i < n + A.scan_after; i += 64) has_nan |= (at(i) != at(i));
+    }
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) mx = fmaxf(mx, __shfl_xor(mx, sft));
+    has_nan = __any(has_nan);
+    int e = (int)((__float_as_uint(mx) >> 23) & 0xffu) - 127;
+    const bool bad = !(mx <= 3.4028234663852886e38f) || (mx > 0.0f && (e < -100 || e > 100));
+    if (!(mx > 0.0f) || bad) e = 14;
+    if (lane == 0) {
+        scale[row] = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+        flags[row] = (bad ? 1u : 0u) | (has_nan ? 2u : 0u);
+    }
+}
+
+// STORE: a 320-column tile of a kept output (grid.x = column tile); else kernel q's 'valid' outputs and their maximum (grid.x = q)
+template <int IN, bool STORE>
 __global__ void __launch_bounds__(512, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16Taps T_, int64_t n_wf) {
     const FIR_KARG FirArgs& A = *(const FIR_KARG FirArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     (void)A_;
     extern __shared__ __attribute__((aligned(16))) unsigned char f16_smem[];
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;  // 2 x 4 wavefronts: rows 32 wm .., columns 80 wn ..
-    const int q = (int)blockIdx.x;            // which kernel
+    const int wm = wave & 1, wn = wave >> 1;  // 2 x 4 wavefronts: rows 32 wm ..; column tiles wn, wn + 4, .. (16 columns each)
+    const int q = STORE ? 0 : (int)blockIdx.x;
     const int64_t row0 = (int64_t)blockIdx.y * BM;
-    const int n = A.n, m = A.m[q], p = A.p[q], kend = A.kend;
+    const int n = A.n, m = A.m[q], P = A.p[q];
+    // the K window of this workgroup: samples ks .. ks + kt - 1 of the rows; output column cl sums window samples cl + e .. cl + e + m - 1
+    const int c0 = STORE ? (int)blockIdx.x * BN : 0;
+    const int s0 = c0 - (STORE ? A.dshift : 0);
+    const int ks = (s0 >> 3) << 3, e = s0 - ks;  // (arithmetic shift: rounds down for the negative start of the first tiles)
+    const int cols = P - c0 < BN ? P - c0 : BN;
+    const int kt = STORE ? ((cols + m - 1 + e + BK - 1) / BK) * BK : ((A.kend + BK - 1) / BK) * BK;
     const int TZ = T_.tz;
     const FIR_GLOBAL _Float16* tg = (const FIR_GLOBAL _Float16*)T_.taps16[q];
     const float tap_inv = *(const FIR_GLOBAL float*)(tg + (size_t)16 * TZ);
@@ -90,7 +180,7 @@ __global__ void __launch_bounds__(512, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16T
     FIR_LDS _Float16* As = (FIR_LDS _Float16*)f16_smem;
     FIR_LDS _Float16* Tw = As + 2 * 2 * BM * APITCH;
     FIR_LDS float* red = (FIR_LDS float*)(Tw + 2 * 16 * TPITCH);  // [BM][4][2]
-    FIR_LDS float* rscale = red + BM * 4 * 2;                      // [BM]: 1 / the row's scale
+    FIR_LDS float* rback = red + BM * 4 * 2;                       // [BM]: what undoes the row's and the kernel's scales
 
     // ---- staging geometry: thread t carries 8 consecutive samples of row t / 8
     const int srow = tid >> 3, skc = (tid & 7) * 8;
@@ -99,81 +189,58 @@ __global__ void __launch_bounds__(512, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16T
     const FIR_GLOBAL char* rowp = (const FIR_GLOBAL char*)A.wf + (grow * A.wf_stride + A.wf_offset) * ESZ;
     const float bl = A.sub_mode ? (A.bl ? ((const FIR_GLOBAL float*)A.bl)[grow * A.bl_stride] : A.bl_const) : 0.0f;
     const bool sub = A.sub_mode != 0;
-    bool bad = false, has_nan = false;
-
-    auto load8 = [&](int k, float (&x)[8]) {  // 8 samples from sample k of the thread's row, baseline subtracted, zeros beyond the slice
-        if (IN == 0) {
-            const f4 v0 = *(const FIR_GLOBAL f4*)(rowp + (size_t)k * 4), v1 = *(const FIR_GLOBAL f4*)(rowp + (size_t)k * 4 + 16);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                x[u] = v0[u];
-                x[4 + u] = v1[u];
-            }
-        } else {
-            const u4 raw = *(const FIR_GLOBAL u4*)(rowp + (size_t)k * 2);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                x[2 * u] = IN == 1 ? (float)(short)(raw[u] & 0xffffu) : (float)(raw[u] & 0xffffu);
-                x[2 * u + 1] = IN == 1 ? (float)(short)(raw[u] >> 16) : (float)(raw[u] >> 16);
-            }
-        }
-        const int live = n - k;  // samples of this vector inside the slice (>= 8 almost always)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            float v = sub ? x[u] - bl : x[u];
-            if (live < 8 && u >= live) v = 0.0f;
-            x[u] = v;
-        }
-    };
-
-    // ---- pass 0: the row's scale.  The 8 threads of a row walk it 64 samples apart and agree on the largest magnitude.
-    float mx = 0.0f;
-    for (int k = skc; k < kend; k += 4 * BK) {  // (four loads in flight: the pass is a latency chain otherwise)
-        float x[4][8];
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-            if (k + b * BK < kend) load8(k + b * BK, x[b]);
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-            if (k + b * BK < kend) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float a = __builtin_fabsf(x[b][u]);
-                    has_nan |= (x[b][u] != x[b][u]);
-                    mx = a > mx ? a : mx;  // (a NaN never raises it)
-                }
-            }
-    }
-#pragma unroll
-    for (int sft = 1; sft < 8; sft <<= 1) mx = fmaxf(mx, __shfl_xor(mx, sft));
-    int e = (int)((__float_as_uint(mx) >> 23) & 0xffu) - 127;
-    // an infinity, or a magnitude so near float32's limits that the scale itself would leave them: the row goes the slow way (scale 1 here)
-    bad = !(mx <= 3.4028234663852886e38f) || (mx > 0.0f && (e < -100 || e > 100));
-    if (!(mx > 0.0f) || bad) e = 14;
-    const float xs = __uint_as_float((unsigned)(127 + 14 - e) << 23);
-    if ((tid & 7) == 0) rscale[srow] = __uint_as_float((unsigned)(127 - 14 + e) << 23) * tap_inv;
+    const float xs = ((const FIR_GLOBAL float*)T_.row_scale)[grow];
+    if ((tid & 7) == 0) rback[srow] = pow2_inverse(xs) * tap_inv;
 
     float stage_x[8];
-    bool stage_live = false;
-    auto fetch = [&](int k0) {
-        const int k = k0 + skc;
-        stage_live = k < kend;  // (kend is a multiple of 32, the thread's 8 samples lie on one side of it)
-        if (stage_live) load8(k, stage_x);
+    auto fetch = [&](int k0) {  // 8 samples from window sample k0 + skc of the thread's row; zeros outside the slice
+        const int i = ks + k0 + skc;
+        if (i >= 0 && i + 8 <= n) {
+            if (IN == 0) {
+                const f4 v0 = *(const FIR_GLOBAL f4*)(rowp + (size_t)i * 4), v1 = *(const FIR_GLOBAL f4*)(rowp + (size_t)i * 4 + 16);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    stage_x[u] = v0[u];
+                    stage_x[4 + u] = v1[u];
+                }
+            } else {
+                const u4 raw = *(const FIR_GLOBAL u4*)(rowp + (size_t)i * 2);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    stage_x[2 * u] = IN == 1 ? (float)(short)(raw[u] & 0xffffu) : (float)(raw[u] & 0xffffu);
+                    stage_x[2 * u + 1] = IN == 1 ? (float)(short)(raw[u] >> 16) : (float)(raw[u] >> 16);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) stage_x[u] = sub ? stage_x[u] - bl : stage_x[u];
+        } else {  // a window end: sample by sample
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int iu = i + u;
+                float x = 0.0f;
+                if (iu >= 0 && iu < n) {
+                    x = IN == 0 ? ((const FIR_GLOBAL float*)rowp)[iu]
+                                : (IN == 1 ? (float)((const FIR_GLOBAL short*)rowp)[iu] : (float)((const FIR_GLOBAL unsigned short*)rowp)[iu]);
+                    x = sub ? x - bl : x;
+                }
+                stage_x[u] = x;
+            }
+        }
     };
     auto commit = [&](int buf) {  // scaled, split, into the two planes
         h8 hi, lo;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const float v = stage_live ? stage_x[u] * xs : 0.0f;
+            const float v = stage_x[u] * xs;
             const _Float16 h = (_Float16)v;
             hi[u] = h;
             lo[u] = (_Float16)(v - (float)h);
         }
-        FIR_LDS _Float16* ap = As + (size_t)buf * 2 * BM * APITCH + srow * APITCH + skc;
+        FIR_LDS _Float16* ap = As + buf * 2 * BM * APITCH + srow * APITCH + skc;
         *(FIR_LDS h8*)ap = hi;
         *(FIR_LDS h8*)(ap + BM * APITCH) = lo;
     };
-    // the 16 tap copies' windows [k0, k0 + TWIN): 16 x 48 vectors of 8 halfs, 768 vectors over 512 threads
+    // the 16 tap copies' windows [k0, k0 + TWIN): 16 x 50 vectors of 8 halfs over 512 threads
     h8 tap_v[2];
     int tap_src[2], tap_dst[2];  // (this thread's two vectors: where they come from in the image, where they go in the window)
     bool tap_live[2];
@@ -183,7 +250,7 @@ __global__ void __launch_bounds__(512, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16T
         const int c = v / (TWIN / 8), o = (v - c * (TWIN / 8)) * 8;
         tap_live[it] = v < 16 * (TWIN / 8);
         tap_src[it] = c * TZ + o;
-        tap_dst[it] = c * TPITCH + o;
+        tap_dst[it] = c * TPITCH + o + ((c & 7) ? 8 : 0);
     }
     auto fetch_taps = [&](int k0) {
 #pragma unroll
@@ -211,34 +278,34 @@ __global__ void __launch_bounds__(512, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16T
     const int j = lane & 15, h4 = lane >> 4;
     // A fragment: row 32 wm + 16 tm + j, samples 32 g + 8 h4 .. + 7 of the stage
     const int a_off = (wm * 32 + j) * APITCH + 8 * h4;
-    // B fragment: tapz[BN + k0 + 32 g + 8 h4 - c ..], c = 80 wn + 16 tn + j: aligned in the copy shifted by r = (-j) mod 8, at window offset
-    // BN + 32 g + 8 h4 - c - r
-    const int shift = (8 - (j & 7)) & 7;
-    const int t_off = shift * TPITCH + BN + 8 * h4 - (wn * 80 + j) - shift;
+    // B fragment of column cl = 16 (wn + 4 tn) + j: tapz[TB + kk - cl - e ..] for window samples kk = k0 + 32 g + 8 h4 ..: aligned in the copy
+    // shifted by r = -(j + e) mod 8, at window offset TB + 32 g + 8 h4 - cl - e - r
+    const int shift = (8 - ((j + e) & 7)) & 7;
+    const int t_off = shift * TPITCH + (shift ? 8 : 0) + TB + 8 * h4 - (wn * 16 + j) - e - shift;
 
     fetch(0);
     fetch_taps(0);
     commit(0);
     commit_taps(0);
     __syncthreads();
-    const int n_stage = (kend + BK - 1) / BK;
+    const int n_stage = kt / BK;
     // (two loops: the float64 flush sits between runs of KFLUSH / BK stages, outside the stage loop -- inside it, as a conditional, the
     // compiler copies all 120 accumulator registers around the branch in every stage)
-    for (int st0 = 0; st0 < n_stage; st0 += KFLUSH / BK) {
-        const int st1 = st0 + KFLUSH / BK < n_stage ? st0 + KFLUSH / BK : n_stage;
+    constexpr int RUN = (STORE ? KFLUSH_STORE : KFLUSH) / BK;
+    for (int st0 = 0; st0 < n_stage; st0 += RUN) {
+        const int st1 = st0 + RUN < n_stage ? st0 + RUN : n_stage;
         for (int st = st0; st < st1; ++st) {
             const int buf = st & 1, k0 = st * BK;
-#ifndef F16_NO_FETCH
             if (st + 1 < n_stage) {
                 fetch(k0 + BK);
                 fetch_taps(k0 + BK);
             }
-#endif
             const FIR_LDS _Float16* ab = As + buf * 2 * BM * APITCH + a_off;
             const FIR_LDS _Float16* tb = Tw + buf * 16 * TPITCH + t_off;
 #pragma unroll
             for (int g = 0; g < BK / 32; ++g) {
-                h8 ah[MT], al[MT], bh[NT], blo[NT];
+                const int kb = k0 + g * 32;  // this group: window samples kb .. kb + 31
+                h8 ah[MT], al[MT];
 #pragma unroll
                 for (int tm = 0; tm < MT; ++tm) {
                     ah[tm] = *(const FIR_LDS h8*)(ab + tm * 16 * APITCH + g * 32);
@@ -246,27 +313,27 @@ __global__ void __launch_bounds__(512, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16T
                 }
 #pragma unroll
                 for (int tn = 0; tn < NT; ++tn) {
-                    bh[tn] = *(const FIR_LDS h8*)(tb + g * 32 - tn * 16);
-                    blo[tn] = *(const FIR_LDS h8*)(tb + 8 * TPITCH + g * 32 - tn * 16);
-                }
+                    // (uniform: a column tile meets a 32-sample group only where a tap lies -- window sample kk meets column cl at tap kk - cl - e)
+                    const int c_lo = 16 * (wn + 4 * tn) + e;
+                    if (!STORE || (kb + 31 >= c_lo && kb <= c_lo + 14 + m)) {
+                        const h8 bh = *(const FIR_LDS h8*)(tb + g * 32 - tn * 64);
+                        const h8 blo = *(const FIR_LDS h8*)(tb + 8 * TPITCH + g * 32 - tn * 64);
 #pragma unroll
-                for (int tm = 0; tm < MT; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < NT; ++tn) {
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], blo[tn], acc[tm][tn], 0, 0, 0);
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                        for (int tm = 0; tm < MT; ++tm) {
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tm], bh, acc[tm][tn], 0, 0, 0);
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], blo, acc[tm][tn], 0, 0, 0);
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], bh, acc[tm][tn], 0, 0, 0);
+                        }
                     }
+                }
             }
-#ifndef F16_NO_COMMIT
             if (st + 1 < n_stage) {
                 commit(buf ^ 1);
                 commit_taps(buf ^ 1);
             }
-#endif
             __syncthreads();
         }
-        // partial sums of (up to) 256 samples leave float32 here
+        // partial sums of (up to) 256 / 128 samples leave float32 here
 #pragma unroll
         for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
@@ -276,19 +343,37 @@ __global__ void __launch_bounds__(512, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16T
                 acc[tm][tn] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
             }
     }
-    // ---- numpy.amax over the valid columns of every row; C layout of the 16 x 16 tile: column = lane & 15, row = 4 (lane >> 4) + r
+    // C layout of a 16 x 16 tile: column = lane & 15, row = 4 (lane >> 4) + r
+    if (STORE) {
+        FIR_GLOBAL float* outp = (FIR_GLOBAL float*)A.out[0];
+#pragma unroll
+        for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = wm * 32 + tm * 16 + h4 * 4 + r;
+                const int64_t row = row0 + rl;
+                const double back = (double)rback[rl];  // (a power of two: exact)
+#pragma unroll
+                for (int tn = 0; tn < NT; ++tn) {
+                    const int cl = 16 * (wn + 4 * tn) + j;
+                    if (row < n_wf && cl < cols) outp[row * A.out_stride[0] + c0 + cl] = (float)(tot[tm][tn][r] * back);
+                }
+            }
+        return;  // (rows with a NaN or an infinity: dsp_fir_fixup_kernel, launched behind this one)
+    }
+    // ---- numpy.amax over the valid columns of every row
 #pragma unroll
     for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rl = wm * 32 + tm * 16 + h4 * 4 + r;
-            const double back = (double)rscale[rl];  // (a power of two: exact)
+            const double back = (double)rback[rl];
             float vmax = -__builtin_inff();
             bool vnan = false;
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn) {
-                const float v = (float)((tot[tm][tn][r] + (double)acc[tm][tn][r]) * back);
-                const bool valid = wn * 80 + tn * 16 + j < p;
+                const float v = (float)(tot[tm][tn][r] * back);
+                const bool valid = 16 * (wn + 4 * tn) + j < P;
                 vnan |= valid && (v != v);
                 vmax = (valid && v > vmax) ? v : vmax;
             }
@@ -303,25 +388,9 @@ __global__ void __launch_bounds__(512, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16T
                 red[(rl * 4 + wn) * 2 + 1] = fn;
             }
         }
-    // samples of the waveform outside the slice: bl_subtract's "NaN anywhere" covers them (DSP_OP_LOAD ip[0..1])
-    if (IN == 0 && sub) {
-#pragma unroll 1
-        for (int part = 0; part < 2; ++part) {
-            const int cnt = part == 0 ? A.scan_before : A.scan_after;
-            const FIR_GLOBAL float* sp = (const FIR_GLOBAL float*)rowp + (part == 0 ? -cnt : n);
-            for (int ee = tid & 7; ee < cnt; ee += 8) {
-                const float x = sp[ee];
-                has_nan |= (x != x);
-            }
-        }
-    }
-    // row screening: the 8 threads of a row agree
-    unsigned flags = (bad ? 1u : 0u) | (has_nan ? 2u : 0u);
-#pragma unroll
-    for (int sft = 1; sft < 8; sft <<= 1) flags |= (unsigned)__shfl_xor((int)flags, sft);
     __syncthreads();
     FIR_LDS unsigned* rowflag = (FIR_LDS unsigned*)(As);  // (the A buffers are free now)
-    if ((tid & 7) == 0) rowflag[srow] = flags;
+    if (tid < BM) rowflag[tid] = row0 + tid < n_wf ? ((const FIR_GLOBAL unsigned*)T_.row_flags)[row0 + tid] : 0u;
     __syncthreads();
     FIR_GLOBAL float* outp = (FIR_GLOBAL float*)A.out[q];
     if (tid < BM && row0 + tid < n_wf) {
@@ -346,7 +415,7 @@ __global__ void __launch_bounds__(512, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16T
         const float rbl = A.sub_mode ? (A.bl ? ((const FIR_GLOBAL float*)A.bl)[(row0 + rl) * A.bl_stride] : A.bl_const) : 0.0f;
         float vmax = -__builtin_inff();
         bool vnan = false;
-        for (int jo = tid; jo < p; jo += 512) {
+        for (int jo = tid; jo < P; jo += 512) {
             float s = 0.0f;
             for (int t = 0; t < m; ++t) {
                 float x = IN == 0 ? ((const FIR_GLOBAL float*)rp)[jo + t]
@@ -380,29 +449,46 @@ __global__ void __launch_bounds__(512, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16T
 
 }  // namespace
 
-// halfs of the tap image of one kernel: 16 copies of TZ = BN + kend rounded up to a stage + the margin the shifted copies and the last
-// window reach into, then the inverse scale (one float, kept 16-byte aligned)
-extern "C" int dsp_internal_fir_f16_tz(int kend) { return ((kend + BK - 1) / BK) * BK + TWIN + 16; }
+// halfs of the tap image of one kernel: 16 copies of TZ = the longest K window rounded up to a stage + the window the last stage reaches +
+// the margin the shifted copies reach into, then the inverse scale (one float, kept 16-byte aligned)
+extern "C" int dsp_internal_fir_f16_tz(int kend) { return ((kend + 8 + BK - 1) / BK) * BK + TWIN + 16; }
 extern "C" size_t dsp_internal_fir_f16_taps_bytes(int kend) { return (size_t)16 * dsp_internal_fir_f16_tz(kend) * 2 + 16; }
 extern "C" int dsp_internal_fir_f16_lds_bytes() { return (2 * 2 * BM * APITCH + 2 * 16 * TPITCH) * 2 + (BM * 4 * 2 + BM) * 4; }
+
+extern "C" int dsp_internal_fir_fixup(const FirArgs* A, int64_t n_wf, hipStream_t stream);  // dsp_fir_mfma.hip
+
+template <int IN>
+static void launch_f16(const FirArgs* A, const FirF16Taps* T, int64_t n_wf, int lds_bytes, hipStream_t stream) {
+    hipLaunchKernelGGL(dsp_fir_f16_rows_kernel<IN>, dim3((unsigned)((n_wf + 3) / 4)), dim3(256), 0, stream, *A, (float*)T->row_scale,
+                       (unsigned*)T->row_flags, n_wf);
+    if (A->store) {
+        const dim3 grid((unsigned)((A->p[0] + BN - 1) / BN), (unsigned)((n_wf + BM - 1) / BM));
+        hipLaunchKernelGGL((dsp_fir_f16_kernel<IN, true>), grid, dim3(512), lds_bytes, stream, *A, *T, n_wf);
+    } else {
+        const dim3 grid((unsigned)A->n_kernels, (unsigned)((n_wf + BM - 1) / BM));
+        hipLaunchKernelGGL((dsp_fir_f16_kernel<IN, false>), grid, dim3(512), lds_bytes, stream, *A, *T, n_wf);
+    }
+}
 
 extern "C" int dsp_internal_launch_fir_f16(const FirArgs* A, const FirF16Taps* T, int64_t n_wf, int lds_bytes, hipStream_t stream) {
     if (n_wf <= 0 || A->n_kernels <= 0) return 0;
     for (int q = 0; q < A->n_kernels; ++q)
         hipLaunchKernelGGL(dsp_fir_f16_prep_kernel, dim3(1), dim3(256), 0, stream, A->taps[q], A->m[q], T->tz, (_Float16*)T->taps16[q]);
-    const dim3 grid((unsigned)A->n_kernels, (unsigned)((n_wf + BM - 1) / BM));
     switch (A->in_kind) {
-        case 0: hipLaunchKernelGGL(dsp_fir_f16_kernel<0>, grid, dim3(512), lds_bytes, stream, *A, *T, n_wf); break;
-        case 1: hipLaunchKernelGGL(dsp_fir_f16_kernel<1>, grid, dim3(512), lds_bytes, stream, *A, *T, n_wf); break;
-        default: hipLaunchKernelGGL(dsp_fir_f16_kernel<2>, grid, dim3(512), lds_bytes, stream, *A, *T, n_wf); break;
+        case 0: launch_f16<0>(A, T, n_wf, lds_bytes, stream); break;
+        case 1: launch_f16<1>(A, T, n_wf, lds_bytes, stream); break;
+        default: launch_f16<2>(A, T, n_wf, lds_bytes, stream); break;
     }
-    return (int)hipGetLastError();
+    int rc = (int)hipGetLastError();
+    if (rc == 0 && A->store) rc = dsp_internal_fir_fixup(A, n_wf, stream);
+    return rc;
 }
 
 extern "C" int dsp_internal_set_fir_f16_lds(int lds_bytes) {
-    const void* k[3] = {reinterpret_cast<const void*>(&dsp_fir_f16_kernel<0>), reinterpret_cast<const void*>(&dsp_fir_f16_kernel<1>),
-                        reinterpret_cast<const void*>(&dsp_fir_f16_kernel<2>)};
-    for (int i = 0; i < 3; ++i) {
+    const void* k[6] = {reinterpret_cast<const void*>(&dsp_fir_f16_kernel<0, false>), reinterpret_cast<const void*>(&dsp_fir_f16_kernel<1, false>),
+                        reinterpret_cast<const void*>(&dsp_fir_f16_kernel<2, false>), reinterpret_cast<const void*>(&dsp_fir_f16_kernel<0, true>),
+                        reinterpret_cast<const void*>(&dsp_fir_f16_kernel<1, true>), reinterpret_cast<const void*>(&dsp_fir_f16_kernel<2, true>)};
+    for (int i = 0; i < 6; ++i) {
         const int rc = (int)hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (rc != 0) return rc;
     }

@@ -120,40 +120,44 @@ __global__ void __launch_bounds__(512, 2) dsp_fir_mfma_kernel(FirArgs A_, int64_
     commit(0, 0);
     __syncthreads();
     const int n_stage = kend / BK;
-    for (int st = 0; st < n_stage; ++st) {
-        const int buf = st & 1, k0 = st * BK;
-        if (st + 1 < n_stage) fetch(k0 + BK);
-        const FIR_LDS float* ab = As + buf * BM * APITCH + a_off;
+    // (two loops: the float64 flush sits between runs of KCHUNK / BK stages, outside the stage loop -- as a conditional inside it the compiler
+    // copies the 120 accumulator registers around the branch in every stage: a vector move per matrix instruction)
+    for (int st0 = 0; st0 < n_stage; st0 += KCHUNK / BK) {
+        const int st1 = st0 + KCHUNK / BK < n_stage ? st0 + KCHUNK / BK : n_stage;
+        for (int st = st0; st < st1; ++st) {
+            const int buf = st & 1, k0 = st * BK;
+            if (st + 1 < n_stage) fetch(k0 + BK);
+            const FIR_LDS float* ab = As + buf * BM * APITCH + a_off;
 #pragma unroll
-        for (int g = 0; g < BK / 16; ++g) {
-            f4 a[MT];
+            for (int g = 0; g < BK / 16; ++g) {
+                f4 a[MT];
 #pragma unroll
-            for (int tm = 0; tm < MT; ++tm) a[tm] = *(const FIR_LDS f4*)(ab + tm * 16 * APITCH + g * 16);
-            float b[NT][4];
-            const FIR_LDS float* tb = tapz + t_off + k0 + g * 16;
+                for (int tm = 0; tm < MT; ++tm) a[tm] = *(const FIR_LDS f4*)(ab + tm * 16 * APITCH + g * 16);
+                float b[NT][4];
+                const FIR_LDS float* tb = tapz + t_off + k0 + g * 16;
 #pragma unroll
-            for (int tn = 0; tn < NT; ++tn)
+                for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) b[tn][s] = tb[s - tn * 16];
+                    for (int s = 0; s < 4; ++s) b[tn][s] = tb[s - tn * 16];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int tm = 0; tm < MT; ++tm)
+                    for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+                        for (int tn = 0; tn < NT; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+            }
+            if (st + 1 < n_stage) commit(k0 + BK, buf ^ 1);
+            __syncthreads();
         }
-        if (st + 1 < n_stage) commit(k0 + BK, buf ^ 1);
-        if (((st + 1) * BK) % KCHUNK == 0) {  // partial sums of 128 samples leave float32 here
+        // partial sums of (up to) 128 samples leave float32 here
 #pragma unroll
-            for (int tm = 0; tm < MT; ++tm)
+        for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < NT; ++tn) {
+            for (int tn = 0; tn < NT; ++tn) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) tot[tm][tn][r] += (double)acc[tm][tn][r];
-                    acc[tm][tn] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
-                }
-        }
-        __syncthreads();
+                for (int r = 0; r < 4; ++r) tot[tm][tn][r] += (double)acc[tm][tn][r];
+                acc[tm][tn] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+            }
     }
     // ---- numpy.amax over the valid columns of every row; C layout of the 16 x 16 tile: column = lane & 15, row = 4 (lane >> 4) + r
 #pragma unroll
@@ -351,47 +355,50 @@ __global__ void __launch_bounds__(512, 2) dsp_fir_store_kernel(FirArgs A_, int64
     commit(0, 0);
     __syncthreads();
     const int n_stage = kt / BK;
-    for (int st = 0; st < n_stage; ++st) {
-        const int buf = st & 1, k0 = st * BK;
-        if (st + 1 < n_stage) fetch(k0 + BK);
-        {
-            const FIR_LDS float* ab = As + buf * BM * APITCH + a_off;
+    // (64 samples per float32 partial sum, as the waveform VM's op: short differentiating kernels cancel; the flush between runs of stages, not
+    // a conditional inside the stage loop -- see dsp_fir_mfma_kernel)
+    for (int st0 = 0; st0 < n_stage; st0 += SCHUNK / BK) {
+        const int st1 = st0 + SCHUNK / BK < n_stage ? st0 + SCHUNK / BK : n_stage;
+        for (int st = st0; st < st1; ++st) {
+            const int buf = st & 1, k0 = st * BK;
+            if (st + 1 < n_stage) fetch(k0 + BK);
+            {
+                const FIR_LDS float* ab = As + buf * BM * APITCH + a_off;
 #pragma unroll
-            for (int g = 0; g < BK / 16; ++g) {
-                const int kb = k0 + g * 16;  // this group: window samples kb .. kb + 15
-                f4 a[MT];
+                for (int g = 0; g < BK / 16; ++g) {
+                    const int kb = k0 + g * 16;  // this group: window samples kb .. kb + 15
+                    f4 a[MT];
 #pragma unroll
-                for (int tm = 0; tm < MT; ++tm) a[tm] = *(const FIR_LDS f4*)(ab + tm * 16 * APITCH + g * 16);
-                float b[NT][4];
-                const FIR_LDS float* tb = tapz + t_off + kb;
+                    for (int tm = 0; tm < MT; ++tm) a[tm] = *(const FIR_LDS f4*)(ab + tm * 16 * APITCH + g * 16);
+                    float b[NT][4];
+                    const FIR_LDS float* tb = tapz + t_off + kb;
 #pragma unroll
-                for (int tn = 0; tn < NT; ++tn)
+                    for (int tn = 0; tn < NT; ++tn)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) b[tn][s] = tb[s - tn * 64];
+                        for (int s = 0; s < 4; ++s) b[tn][s] = tb[s - tn * 64];
 #pragma unroll
-                for (int tn = 0; tn < NT; ++tn) {
-                    const int c_lo = 16 * (wn + 4 * tn) + e;  // (uniform: a scalar branch around the tile's eight matrix instructions)
-                    if (kb + 15 >= c_lo && kb <= c_lo + 14 + m) {
+                    for (int tn = 0; tn < NT; ++tn) {
+                        const int c_lo = 16 * (wn + 4 * tn) + e;  // (uniform: a scalar branch around the tile's eight matrix instructions)
+                        if (kb + 15 >= c_lo && kb <= c_lo + 14 + m) {
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
+                            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                            for (int tm = 0; tm < MT; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+                                for (int tm = 0; tm < MT; ++tm) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
+                        }
                     }
                 }
             }
+            if (st + 1 < n_stage) commit(k0 + BK, buf ^ 1);
+            __syncthreads();
         }
-        if (st + 1 < n_stage) commit(k0 + BK, buf ^ 1);
-        if (((st + 1) * BK) % SCHUNK == 0) {  // (64 samples per float32 partial sum, as the waveform VM's op: short differentiating kernels cancel)
 #pragma unroll
-            for (int tm = 0; tm < MT; ++tm)
+        for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < NT; ++tn) {
+            for (int tn = 0; tn < NT; ++tn) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) tot[tm][tn][r] += (double)acc[tm][tn][r];
-                    acc[tm][tn] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
-                }
-        }
-        __syncthreads();
+                for (int r = 0; r < 4; ++r) tot[tm][tn][r] += (double)acc[tm][tn][r];
+                acc[tm][tn] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
+            }
     }
     // ---- the tile's outputs; C layout of a 16 x 16 tile: column = lane & 15, row = 4 (lane >> 4) + r
     FIR_GLOBAL float* outp = (FIR_GLOBAL float*)A.out[0];
@@ -492,6 +499,18 @@ extern "C" int dsp_internal_launch_fir_store(const FirArgs* A, int64_t n_wf, int
             hipLaunchKernelGGL(dsp_fir_store_kernel<2>, grid, dim3(512), lds_bytes, stream, *A, n_wf);
             hipLaunchKernelGGL(dsp_fir_fixup_kernel<2>, fix, dim3(256), 0, stream, *A, n_wf);
             break;
+    }
+    return (int)hipGetLastError();
+}
+
+// the rows-with-a-NaN-or-an-infinity pass alone (behind the float16 form of the kept-output kernel, dsp_fir_f16.hip)
+extern "C" int dsp_internal_fir_fixup(const FirArgs* A, int64_t n_wf, hipStream_t stream) {
+    if (n_wf <= 0) return 0;
+    const dim3 fix((unsigned)((n_wf + 3) / 4));
+    switch (A->in_kind) {
+        case 0: hipLaunchKernelGGL(dsp_fir_fixup_kernel<0>, fix, dim3(256), 0, stream, *A, n_wf); break;
+        case 1: hipLaunchKernelGGL(dsp_fir_fixup_kernel<1>, fix, dim3(256), 0, stream, *A, n_wf); break;
+        default: hipLaunchKernelGGL(dsp_fir_fixup_kernel<2>, fix, dim3(256), 0, stream, *A, n_wf); break;
     }
     return (int)hipGetLastError();
 }

@@ -193,7 +193,8 @@ struct dsp_chain {
     int fio_wf = -1, fio_bl = -1, fio_taps[DSP_FIR_MAXK] = {-1, -1, -1, -1}, fio_out[DSP_FIR_MAXK] = {-1, -1, -1, -1};
     // the amax form on the float16 matrix instructions (dsp_fir_f16.hip): the default where the rows keep 16-byte alignment
     bool fir_f16 = false;
-    FirF16Taps f16{};  // device images of the kernels' taps (rewritten by every launch: the taps are a binding)
+    FirF16Taps f16{};  // device images of the kernels' taps (rewritten by every launch: the taps are a binding), the rows' scales and flags
+    int64_t f16_rows_cap = 0;
     // a program of scalar ops only (dsp_scalar.hip: a row per lane)
     bool scalar_ok = false;
     // lane-per-waveform current-branch kernel (dsp_current.hip)
@@ -219,6 +220,8 @@ struct dsp_chain {
         if (cur_scratch) (void)hipFree(cur_scratch);
         for (int k = 0; k < DSP_FIR_MAXK; ++k)
             if (f16.taps16[k]) (void)hipFree(const_cast<void*>(f16.taps16[k]));
+        if (f16.row_scale) (void)hipFree(const_cast<void*>(f16.row_scale));
+        if (f16.row_flags) (void)hipFree(const_cast<void*>(f16.row_flags));
     }
 };
 
@@ -1624,7 +1627,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         const char* f32 = getenv("DSPEED_HIP_FIR_F32");
         const dsp_io_desc& w = io[ch->fio_wf];
         const int es = w.dtype == DSP_F32 ? 4 : 2;
-        if (!ch->fir.store && !(f32 && f32[0] == '1') && (w.row_stride * es) % 16 == 0 && (w.offset * es) % 16 == 0) {
+        if (!(f32 && f32[0] == '1') && (w.row_stride * es) % 16 == 0 && (w.offset * es) % 16 == 0) {
             ch->fir_f16 = true;
             ch->f16.tz = dsp_internal_fir_f16_tz(ch->fir.kend);
             for (int k = 0; k < ch->fir.n_kernels; ++k) {
@@ -1868,9 +1871,21 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
             A.taps[k] = (const float*)at(ch->fio_taps[k]);
             A.out[k] = at(ch->fio_out[k]);
         }
-        hipError_t e = (hipError_t)(A.store     ? dsp_internal_launch_fir_store(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream)
-                                    : ch->fir_f16 ? dsp_internal_launch_fir_f16(&A, &ch->f16, n_wf, dsp_internal_fir_f16_lds_bytes(), (hipStream_t)stream)
-                                                  : dsp_internal_launch_fir_mfma(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream));
+        if (ch->fir_f16 && ch->f16_rows_cap < n_wf) {  // the rows' scales and flags: grown to the largest batch seen
+            if (ch->f16.row_scale) HIP_TRY(hipFree(const_cast<void*>(ch->f16.row_scale)));
+            if (ch->f16.row_flags) HIP_TRY(hipFree(const_cast<void*>(ch->f16.row_flags)));
+            ch->f16.row_scale = ch->f16.row_flags = nullptr;
+            ch->f16_rows_cap = 0;
+            void *a = nullptr, *b = nullptr;
+            HIP_TRY(hipMalloc(&a, (size_t)n_wf * sizeof(float)));
+            ch->f16.row_scale = a;
+            HIP_TRY(hipMalloc(&b, (size_t)n_wf * sizeof(unsigned)));
+            ch->f16.row_flags = b;
+            ch->f16_rows_cap = n_wf;
+        }
+        hipError_t e = (hipError_t)(ch->fir_f16 ? dsp_internal_launch_fir_f16(&A, &ch->f16, n_wf, dsp_internal_fir_f16_lds_bytes(), (hipStream_t)stream)
+                                    : A.store   ? dsp_internal_launch_fir_store(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream)
+                                                : dsp_internal_launch_fir_mfma(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream));
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "FIR kernel launch failed: %s", hipGetErrorString(e));
         return post_err(ch, stream);
     }
@@ -2050,7 +2065,7 @@ const char* dsp_chain_kernel_name(dsp_chain* ch) {
     if (ch && ch->red_ok && ch->fused_on) return dsp_internal_reduce_kernel_name();
     if (ch && ch->cur_ok && ch->fused_on) return dsp_internal_current_kernel_name();
     if (ch && ch->fir_ok && ch->fused_on)
-        return ch->fir.store ? dsp_internal_fir_store_kernel_name() : (ch->fir_f16 ? dsp_internal_fir_f16_kernel_name() : dsp_internal_fir_mfma_kernel_name());
+        return ch->fir_f16 ? dsp_internal_fir_f16_kernel_name() : (ch->fir.store ? dsp_internal_fir_store_kernel_name() : dsp_internal_fir_mfma_kernel_name());
     if (ch && ch->rows_ok && ch->fused_on) return dsp_internal_rows_kernel_name();
     if (ch && ch->rr_ok && ch->fused_on && ch->variant != 1) return dsp_internal_energy_rr_kernel_name();
     return (ch && ch->fused_ok && ch->fused_on) ? dsp_internal_energy_kernel_name() : dsp_internal_vm_kernel_name();

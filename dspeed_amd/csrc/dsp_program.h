@@ -194,5 +194,7 @@ struct FirArgs {
 struct FirF16Taps {
     const void* taps16[DSP_FIR_MAXK];
     int32_t tz;
+    const void* row_scale;  // float per row: the power of two that brings the row's largest magnitude into [2^14, 2^15)
+    const void* row_flags;  // uint32 per row: bit 0 an infinity, bit 1 a NaN
 };
 
