@@ -1627,7 +1627,9 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         const char* f32 = getenv("DSPEED_HIP_FIR_F32");
         const dsp_io_desc& w = io[ch->fio_wf];
         const int es = w.dtype == DSP_F32 ? 4 : 2;
-        if (!(f32 && f32[0] == '1') && (w.row_stride * es) % 16 == 0 && (w.offset * es) % 16 == 0) {
+        const int n_slice = ch->fir.n;  // (its 8-sample vectors are read whole: the last one must end inside the row)
+        if (!(f32 && f32[0] == '1') && (w.row_stride * es) % 16 == 0 && (w.offset * es) % 16 == 0 &&
+            ((n_slice & 7) == 0 || w.offset + ((n_slice + 7) & ~7) <= w.row_stride)) {
             ch->fir_f16 = true;
             ch->f16.tz = dsp_internal_fir_f16_tz(ch->fir.kend);
             for (int k = 0; k < ch->fir.n_kernels; ++k) {
