@@ -528,7 +528,11 @@ extern "C" int dsp_internal_launch_fir_f16(const FirArgs* A, const FirF16Taps* T
         default: launch_f16<2>(A, T, n_wf, lds_bytes, stream); break;
     }
     int rc = (int)hipGetLastError();
-    if (rc == 0 && A->store) rc = dsp_internal_fir_fixup(A, n_wf, stream);
+    if (rc == 0 && A->store) {
+        FirArgs F = *A;
+        F.row_flags = (const uint32_t*)T->row_flags;  // (the rows are screened: the pass behind reads a word per row, not the row)
+        rc = dsp_internal_fir_fixup(&F, n_wf, stream);
+    }
     return rc;
 }
 

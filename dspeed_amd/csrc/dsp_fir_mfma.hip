@@ -435,7 +435,11 @@ __global__ void __launch_bounds__(256) dsp_fir_fixup_kernel(FirArgs A_, int64_t 
         return sub ? x - bl : x;
     };
     bool has_nan = false, has_inf = false;
-    if (IN == 0) {
+    if (A.row_flags) {  // (the float16 form's first pass screened the rows: bit 0 an infinity, bit 1 a NaN)
+        const unsigned f = ((const FIR_GLOBAL unsigned*)A.row_flags)[row];
+        has_inf = (f & 1u) != 0;
+        has_nan = (f & 2u) != 0;
+    } else if (IN == 0) {
         const int n4 = n & ~3;
         for (int i = lane * 4; i < n4; i += 256) {
             const f4 v = *(const FIR_GLOBAL f4*)(rowp + (size_t)i * 4);

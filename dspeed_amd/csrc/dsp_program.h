@@ -188,6 +188,7 @@ struct FirArgs {
     int32_t scan_before, scan_after;  // samples before / after the slice that are screened for NaN (DSP_OP_LOAD ip[0..1])
     int32_t store;           // 1: ONE kernel whose p[0] outputs are written to out[0] as a waveform (dsp_fir_store_kernel), any mode
     int32_t dshift;          // store: output c is the sum over samples c - dshift .. c - dshift + m - 1 ('v' 0, 's' m / 2, 'f' m - 1)
+    const uint32_t* row_flags;  // dsp_fir_fixup_kernel: the rows' flags when something has looked at the rows already (dsp_fir_f16.hip), else null
 };
 
 // the float16 tap images of dsp_fir_f16.hip (one per kernel: 16 shifted / split copies of tz halfs, then the inverse scale), chain-owned

@@ -24,6 +24,14 @@ python3 tools/icpc_breakdown.py > "$OUT/icpc_recipe.jsonl" 2> "$OUT/icpc_recipe.
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/icpc_trace" -- python3 tools/icpc_rate.py 131072 5 > "$OUT/icpc_rate_traced.json" 2> "$OUT/icpc_trace.err"
 python3 tools/icpc_rate.py 131072 5 > "$OUT/icpc_rate.json" 2> /dev/null
 python3 tools/fir_store_rate.py 100000 1 > "$OUT/fir_store_rate.json" 2> /dev/null
+# the long FIRs on the float32 matrix instructions (the float16 form is the default) and the accuracy of both against float64
+DSPEED_HIP_FIR_F32=1 python3 tools/c3_rate.py 250000 1 > "$OUT/c3_rate_f32.json" 2>/dev/null
+DSPEED_HIP_FIR_F32=1 python3 tools/fir_store_rate.py 100000 1 > "$OUT/fir_store_rate_f32.json" 2> /dev/null
+python3 tools/fir_f16_accuracy.py > "$OUT/fir_f16_accuracy.json" 2> /dev/null
+# the recipe on pulses with a charge-collection time (the rise-time walks end where they do on detector pulses) and with the float32 FIRs
+ICPC_RISE=6,60 python3 tools/icpc_rate.py 131072 5 > "$OUT/icpc_rate_rise.json" 2> /dev/null
+DSPEED_HIP_FIR_F32=1 python3 tools/icpc_rate.py 131072 5 > "$OUT/icpc_rate_fir_f32.json" 2> /dev/null
+tools/icpc_marginal.sh > /dev/null 2>&1
 python3 tools/e2e_recipe_rate.py 400000 > "$OUT/e2e_recipe_rate.json" 2> /dev/null
 for r in 16384 32768 65536; do python3 tools/icpc_rate.py $r 10; done > "$OUT/icpc_rate_small.jsonl" 2> /dev/null
 DSPEED_HIP_NO_FUSED=1 tools/pmc_kernel.sh gpurun_out/prof_${TAG}_vm bench.py --allow-variants --no-cpu --rows 500000 --steps 5 --warmup 2 > /dev/null 2>&1
