@@ -38,6 +38,14 @@ e1.record(chain._stream)
 sync()
 dt = e0.elapsed_ms(e1) * 1e-3 / steps
 flop = 2 * 5792 * 301 * 2  # direct-form flops of the two kernels
-print(json.dumps({"config": "C3", "kernel": chain._chain.kernel_name, "rows": rows, "ms": dt * 1e3, "waveforms_per_s": rows / dt,
-                  "algorithmic_TFLOPs": rows * flop / dt / 1e12, "frac_fp32_peak": rows * flop / dt / 157.3e12,
-                  "issued_TFLOPs_mfma": rows * 2 * 6112 * 320 * 2 / dt / 1e12 if fused else None}))
+name = chain._chain.kernel_name
+rec = {"config": "C3", "kernel": name, "rows": rows, "ms": dt * 1e3, "waveforms_per_s": rows / dt, "algorithmic_TFLOPs": rows * flop / dt / 1e12}
+if "f16" in name:
+    # three float16 products per multiply-add (two-way split operands), over the 64 x 320 x 6144 padded tile of every row block and kernel
+    issued = rows * 3 * 2 * 6144 * 320 * 2 / dt
+    rec.update({"bound": "mfma-f16", "issued_TFLOPs_f16_mfma": issued / 1e12, "frac_f16_mfma_peak": issued / 2.5e15,
+                "algorithmic_over_fp32_mfma_peak": rows * flop / dt / 157.3e12,
+                "row_bytes_read_GBps": rows * 6092 * 4 * 2 / dt / 1e9})  # (the scale pass and the product, both kernels sharing the rows in L2 at best)
+elif fused:
+    rec.update({"bound": "mfma-f32", "frac_fp32_peak": rows * flop / dt / 157.3e12, "issued_TFLOPs_mfma": rows * 2 * 6112 * 320 * 2 / dt / 1e12})
+print(json.dumps(rec))
