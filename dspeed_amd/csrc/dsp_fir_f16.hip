@@ -337,16 +337,25 @@ __global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16
             h8 ah[MT], al[MT];
 #pragma unroll
             for (int tm = 0; tm < MT; ++tm) {
+#ifdef F16_DIAG_NO_LDSREAD
+                ah[tm] = h8{(_Float16)(float)kb, 0, 0, 0, 0, 0, 0, 0};
+                al[tm] = h8{(_Float16)(float)lane, 0, 0, 0, 0, 0, 0, 0};
+#else
                 ah[tm] = *(const FIR_LDS h8*)(ab + tm * 16 * APITCH + g * 32);
                 al[tm] = *(const FIR_LDS h8*)(ab + BM * APITCH + tm * 16 * APITCH + g * 32);
+#endif
             }
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn) {
                 // (uniform: a column tile meets a 32-sample group only where a tap lies -- window sample kk meets column cl at tap kk - cl - e)
                 const int c_lo = 16 * (wn + 4 * tn) + e;
                 if (!STORE || (kb + 31 >= c_lo && kb <= c_lo + 14 + m)) {
+#ifdef F16_DIAG_NO_LDSREAD
+                    const h8 bh = h8{(_Float16)(float)(kb + tn), 0, 0, 0, 0, 0, 0, 0}, blo = h8{(_Float16)(float)(lane + tn), 0, 0, 0, 0, 0, 0, 0};
+#else
                     const h8 bh = *(const FIR_LDS h8*)(tb + g * 32 - tn * 64);
                     const h8 blo = *(const FIR_LDS h8*)(tb + 8 * TPITCH + g * 32 - tn * 64);
+#endif
 #pragma unroll
                     for (int tm = 0; tm < MT; ++tm) {
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tm], bh, acc[tm][tn], 0, 0, 0);
