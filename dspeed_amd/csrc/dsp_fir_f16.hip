@@ -55,7 +55,10 @@ constexpr int TWIN = TB + BK;    // taps a stage's fragments can reach
 constexpr int TPITCH = ((TWIN + 8 + 15 * 8 + 127) / 128) * 128;
 __constant__ unsigned char tap_slot[8][8] = {{2, 5, 9, 6, 15, 12, 9, 15}, {7, 2, 8, 3, 5, 0, 15, 12}, {1, 11, 2, 13, 5, 9, 8, 6}, {8, 4, 11, 1, 4, 0, 15, 8},
                                              {7, 9, 3, 12, 15, 7, 13, 2}, {8, 11, 2, 14, 6, 9, 12, 3}, {3, 7, 6, 11, 0, 4, 15, 11}, {5, 4, 8, 9, 13, 3, 11, 1}};
-constexpr int KFLUSH = 256;      // samples between two float64 flushes ('valid' + amax over thousands of taps)
+#ifndef F16_KFLUSH
+#define F16_KFLUSH 256
+#endif
+constexpr int KFLUSH = F16_KFLUSH;      // samples between two float64 flushes ('valid' + amax over thousands of taps)
 constexpr int KFLUSH_STORE = 128;  // ... of the kept-output form: short differentiating kernels cancel, partial sums far above the output
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
