@@ -181,6 +181,36 @@ def test_nan_and_infinite_samples_follow_the_reference():
         assert np.array_equal(np.isnan(out2[f"{nm}Emax"])[no_inf], np.isnan(out[f"{nm}Emax"])[no_inf])
 
 
+def test_rows_of_any_magnitude_keep_their_accuracy():
+    """the float16 form scales every row by its own power of two before it splits it: rows of 1e-20 and of 1e+20, a row of zeros, a row with one
+    spike a million times its neighbours -- each as close to float64, relative to its own filtered peak, as ordinary rows; both forms, both shapes"""
+    rng = np.random.default_rng(44)
+    wf, bl = _synth(rng, 40, 2048)
+    x = (wf - bl[:, None]).astype(np.float32)
+    scale = np.ones(40, dtype=np.float32)
+    scale[1], scale[2], scale[3], scale[4] = 1e-20, 1e20, 1e-30, 3e30
+    x *= scale[:, None]
+    x[5] = 0.0
+    x[6, 700] = 1e6 * np.abs(x[6]).max()
+    x[7, :] = np.float32(1e-41)  # denormals: a row whose largest magnitude has no normal exponent
+    kernels = {"cusp": ("cusp_filter", (100, 20, 2000), 700)}
+    rec = _recipe(kernels, 0, 960, bl=False)
+    chain, out = _run(rec, {"waveform": x})
+    assert chain._chain.kernel_name == _amax_kernel()
+    want, peak = _want(chain, x, "cusp", 700, 0, 960)
+    ok = peak > 1e-38  # (row 5: zeros; row 7: denormal products have no seven digits in float32, they only must not turn into NaN)
+    assert np.max(np.abs(out["cuspEmax"][ok] - want[ok]) / peak[ok]) <= TOL
+    assert out["cuspEmax"][5] == 0.0 and np.isfinite(out["cuspEmax"]).all()
+    rec2, p = _store_recipe(133, "s", 2048, bl=False)
+    chain2, out2 = _run(rec2, {"waveform": x})
+    assert chain2._chain.kernel_name == _store_kernel()
+    ref = _conv64(x, chain2._consts["taps:k"][:133], "s")
+    pk = np.abs(ref).max(axis=1, keepdims=True)
+    rows_ok = pk[:, 0] > 1e-38  # (row 7: denormal outputs have no seven digits in float32)
+    assert np.max(np.abs(out2["wf_f"][rows_ok] - ref[rows_ok]) / pk[rows_ok]) <= TOL
+    assert np.all(out2["wf_f"][5] == 0.0) and np.isfinite(out2["wf_f"]).all()
+
+
 def test_shapes_outside_the_kernel_stay_on_the_vm():
     rng = np.random.default_rng(2)
     wf, bl = _synth(rng, 8, 2048)
