@@ -654,7 +654,21 @@ class ProcessingChain:
                                                      stream.ptr), what="linear_slope_fit_rows")
             for j, name in enumerate(g["names"]):
                 bufs[name] = out.ptr + j * m * isz
-        for j, st in enumerate(self._stages):  # in launch order: a stage may read what an earlier one wrote
+        # The stages, in launch order (a stage may read what an earlier one wrote) -- but not all on one stream: what a stage reads says which
+        # earlier stages it waits for, and stages that do not wait for each other (the cusp filter beside the t0 chain, the reductions off the raw
+        # rows, the lane-per-waveform kernels that leave most of a CU idle) go to side streams and run beside each other.  The program's stream
+        # waits for all of them before the program is launched.
+        plan = self._stage_plan() if self.concurrent_stages and len(self._stages) > 1 else None
+        if plan is not None:
+            side = getattr(lane, "side_streams", None)
+            if side is None:
+                side = lane.side_streams = [Stream() for _ in range(plan["n_side"])]
+                lane.stage_done = [Event() for _ in self._stages]
+                lane.pass_start = Event()
+            lane.pass_start.record(stream)  # (behind the fits, and behind everything the previous pass of this lane left on its stream)
+            for s in side:
+                s.wait_event(lane.pass_start)
+        for j, st in enumerate(self._stages):
             sb = dict(bufs)
             sb.update(st["dev"])
             for io_name, key in st["alias"].items():
@@ -665,9 +679,58 @@ class ProcessingChain:
                 if buf is None or buf.shape[0] < m:
                     buf = held[key] = DeviceArray((m,) if length is None else (m, length), self.loop_dtype)
                 sb[out_name] = bufs[key] = buf
-            lane.stage_chains[j].execute(sb, m, stream)
+            if plan is None:
+                lane.stage_chains[j].execute(sb, m, stream)
+                continue
+            k = plan["stream_of"][j]
+            s = stream if k < 0 else lane.side_streams[k]
+            for i in plan["deps"][j]:
+                if plan["stream_of"][i] != k:
+                    s.wait_event(lane.stage_done[i])
+            lane.stage_chains[j].execute(sb, m, s)
+            lane.stage_done[j].record(s)
+        if plan is not None:
+            for j in plan["sinks"]:
+                if plan["stream_of"][j] >= 0:
+                    stream.wait_event(lane.stage_done[j])
         for io_name, key in self._ext_alias.items():
             bufs[io_name] = bufs[key]
+
+    #: True (DSPEED_HIP_CONCURRENT_STAGES=1): stages that do not read each other's results run on streams of their own, beside each other.  Off
+    #: by default: measured on the Ge recipe it changes nothing (22.80 against 22.76 ms per 131 072 rows) -- the kernels that could overlap
+    #: each fill the CUs' LDS by themselves (the interpreter 4 x 35 kB, the lane-per-waveform kernels 4 x 40 kB, the float16 FIR 84 kB), so
+    #: the hardware runs them one after the other whatever stream they are on
+    concurrent_stages = os.environ.get("DSPEED_HIP_CONCURRENT_STAGES", "0") == "1"
+
+    def _stage_plan(self) -> dict:
+        """Which earlier stages every stage waits for (it reads a buffer they write: the ``alias`` of its bindings against their ``outs``), and a
+        stream for each: a stage continues the stream of the last stage it waits for when nothing else was put behind that one, else it takes
+        the program's stream (-1) or the next side stream.  ``sinks``: stages nothing later waits for on their own stream."""
+        plan = getattr(self, "_stage_plan_cache", None)
+        if plan is not None:
+            return plan
+        n = len(self._stages)
+        made = [{key for _o, key, _l in st["outs"]} for st in self._stages]
+        deps = [sorted(i for i in range(j) if made[i] & set(self._stages[j]["alias"].values())) for j in range(n)]
+        stream_of, tail_of, n_side = [0] * n, {}, 0   # tail_of: stream -> last stage put on it
+        for j in range(n):
+            k = None
+            for i in reversed(deps[j]):
+                if tail_of.get(stream_of[i]) == i:
+                    k = stream_of[i]
+                    break
+            if k is None:
+                if -1 not in tail_of:
+                    k = -1
+                else:
+                    free = [q for q in range(n_side) if q not in tail_of]
+                    k = free[0] if free else (n_side if n_side < 3 else min(range(n_side), key=lambda q: tail_of[q]))
+                    n_side = max(n_side, k + 1)
+            stream_of[j] = k
+            tail_of[k] = j
+        sinks = sorted(set(tail_of.values()))
+        plan = self._stage_plan_cache = {"deps": deps, "stream_of": stream_of, "n_side": n_side, "sinks": sinks}
+        return plan
 
     def __call__(self, tb_in, tb_out, begin: int = 0, end: int | None = None):
         """``proc_chain(tb_in, tb_out)`` of the reference (processing_chain.py:675-716).  LGDO tables (or stand-ins with their protocol,

@@ -431,3 +431,30 @@ def test_current_branch_alone_moves_its_start_ahead_too():
     assert "dsp_current_kernel" in [k for _w, k in part.kernels()]
     for k in out:
         assert np.array_equal(out[k], ref[k], equal_nan=True), k
+
+
+def test_stages_on_side_streams_give_the_same_results():
+    """stages that do not read each other's results on streams of their own (ProcessingChain.concurrent_stages): the same numbers, and the plan
+    keeps every reader behind what it reads"""
+    from dspeed_amd.processing_chain import WaveformInput, build_processing_chain
+
+    rng = np.random.default_rng(17)
+    n = 700
+    wf, bl = _synth(rng, n)
+    tb = {"waveform": WaveformInput(wf.astype(np.uint16), 16.0, 48000.0), "baseline": bl}
+    chain, _, out = build_processing_chain(recipes.ICPC, tb)
+    chain.execute()
+    ref = {k: np.array(v) for k, v in out.items()}
+    chain2, _, out2 = build_processing_chain(recipes.ICPC, tb)
+    chain2.concurrent_stages = True
+    plan = chain2._stage_plan()
+    assert plan["n_side"] >= 2 and all(i < j for j, d in enumerate(plan["deps"]) for i in d)
+    what = [st["what"] for st in chain2._stages]
+    t0f, t0v = what.index("convolve_wf wf_t0_filter"), what.index("per-event values of wf_t0_filter")
+    assert t0f in plan["deps"][t0v] and plan["stream_of"][what.index("fft_convolve_wf wf_cusp")] != plan["stream_of"][t0f]
+    for _ in range(3):  # (a lane's buffers are reused by its next pass: the side streams wait for the pass before)
+        for v in out2.values():
+            v[...] = 0
+        chain2.execute()
+        for k in ref:
+            assert np.array_equal(out2[k], ref[k], equal_nan=True), k
