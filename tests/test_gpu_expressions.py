@@ -147,6 +147,58 @@ def test_integer_loops_of_32_bits_run_in_the_float64_chain():
         build_processing_chain({"outputs": ["x"], "processors": {"x": "u + 70000"}}, tb16)
 
 
+def test_random_integer_expressions_against_numpy():
+    """seeded random expression trees over integer waveforms and per-event columns of one signedness (16-bit loops in the float32 chain; 32-bit ones in
+    the float64 chain), evaluated by NumPy's own integer ufuncs on the same arrays: same values, same dtype"""
+    rng = np.random.default_rng(2024)
+    n, L = 24, 96
+    for dt, chain_dt in ((np.uint16, np.float32), (np.int16, np.float32), (np.int32, np.float64), (np.uint32, np.float64)):
+        info = np.iinfo(dt)
+        span = 40 if dt in (np.uint16, np.int16) else 70000
+        tb = {"a": rng.integers(info.min, info.max + 1, (n, L)).astype(dt), "b": rng.integers(max(info.min, -span), span, (n, L)).astype(dt),
+              "p": rng.integers(info.min, info.max + 1, n).astype(dt), "q": rng.integers(max(info.min, -span), span, n).astype(dt)}  # ("s" would be the second)
+        tb["b"][:, ::7] = 0  # (division by zero gives 0 in NumPy's integer loops)
+
+        def tree(depth, want_wf):
+            if depth == 0 or rng.random() < 0.25:
+                if want_wf:
+                    return str(rng.choice(["a", "b"]))
+                return str(rng.choice(["p", "q", str(int(rng.integers(1, 9)))]))
+            op = rng.choice(["+", "-", "*", "//", "neg"])
+            if op == "neg":
+                return f"(-{tree(depth - 1, want_wf)})"
+            left_wf = want_wf and rng.random() < 0.7
+            l, r = tree(depth - 1, left_wf), tree(depth - 1, want_wf and (not left_wf or rng.random() < 0.5))
+            if not want_wf and l.isdigit() and r.isdigit():
+                l = "p"
+            return f"({l} {op} {r})"
+
+        procs, want = {}, {}
+        env = {"a": tb["a"], "b": tb["b"], "p": tb["p"][:, None], "q": tb["q"][:, None]}
+        k = 0
+        while k < 12:
+            is_wf = k < 8
+            e = str(tree(3, is_wf))
+            if not any(v in e for v in ("a", "b", "p", "q")):
+                e = f"(p + {e})"
+            if e.isidentifier():
+                e = f"({e} + 0)"  # (a bare name is an alias, not a ufunc)
+            try:
+                with np.errstate(all="ignore"):
+                    val = eval(e, {"__builtins__": {}}, env)
+            except OverflowError:  # (a constant that does not fit the loop's type, -3 beside uint16: NumPy refuses it, so does the builder)
+                continue
+            val = np.asarray(val)
+            if not is_wf:
+                val = val[:, 0] if val.ndim == 2 else val
+            procs[f"x{k}"], want[f"x{k}"] = e, val
+            k += 1
+        chain, out = _run(procs, list(procs), tb)
+        assert chain.loop_dtype == chain_dt
+        for k, w in want.items():
+            assert out[k].dtype == w.dtype == np.dtype(dt) and np.array_equal(out[k], w), (np.dtype(dt).name, k, procs[k])
+
+
 def u32_or(u, m):
     return u * m  # uint16 x int32 -> int32 ('ii->i')
 
