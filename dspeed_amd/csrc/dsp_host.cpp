@@ -677,6 +677,11 @@ static bool match_rows_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const 
         A.dwt_stride = d.row_stride;
         ch->rio_dwt = st_wf->io;
     }
+    // a walk backward from a known start on rows that are NaN-free or NaN from the first sample on (the LOAD's promise), and nothing else
+    // asked for: what lies behind the start cannot change the answer -- the group stops there (the t0 trapezoid of the Ge recipes: half a row)
+    bool any_mm = false;
+    for (int k = 0; k < 4; ++k) any_mm |= ch->rio_mm[k] >= 0;
+    A.stop_at_start = (A.tpt_mode == 1 && !any_mm && !dw && !has_pz && (ld.ip[2] & 1) && !A.walk_nan && !A.walk_frac && !A.trap_all_nan) ? 1 : 0;
     return true;
 }
 

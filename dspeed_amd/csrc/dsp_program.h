@@ -116,7 +116,9 @@ struct RowsArgs {
     void* dwt_out;
     int64_t dwt_stride;
     int32_t ring_entries;    // R: history samples kept per lane, a multiple of 8, >= largest lag + 16
-    int32_t pad_;
+    // 1: nothing behind the start of a backward walk matters -- the only output is a walk backward from a known start and the rows are
+    // NaN-free or NaN from the first sample on (DSP_OP_LOAD ip[2]): the group stops at the block behind its 64 rows' latest start
+    int32_t stop_at_start;
 };
 
 // arguments of the lane-per-waveform current-branch kernel (dsp_current.hip), filled by dsp_chain_execute when a program has that shape:

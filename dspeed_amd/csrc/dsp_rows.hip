@@ -48,6 +48,18 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // both wavefronts of the pair: my LDS accesses are done, then wait for the partner
 __device__ __forceinline__ void pair_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// 8-sample blocks a group walks: all of them, or (RowsArgs.stop_at_start) up to the block behind the latest start among its 64 rows -- both
+// wavefronts of the pair read the same column and agree
+template <typename ArgsRef>
+__device__ __forceinline__ int rows_blocks(const ArgsRef& A, int64_t rowc) {
+    const int all = A.len / 8;
+    if (!A.stop_at_start) return all;
+    const float ts_f = A.ts ? ((const __attribute__((address_space(1))) float*)A.ts)[rowc * A.ts_stride] : A.ts_const;
+    const bool ok = !(ts_f != ts_f) && ts_f >= 0.0f && ts_f < (float)A.len;
+    const int last = wave_max(ok ? (int)ts_f : 0) / 8 + 2;
+    return last < all ? last : all;
+}
+
 __device__ __forceinline__ void rows_report(int* err, int code, int64_t row) {
     if (atomicCAS(&err[0], 0, code) == 0) {
         err[1] = (int)(row & 0xffffffffll);
@@ -69,7 +81,8 @@ __device__ __forceinline__ void rows_produce(const ROWS_KARG RowsArgs& A, ROWS_L
     const ROWS_GLOBAL char* rowp = (const ROWS_GLOBAL char*)A.wf + (rowc * A.wf_stride + A.wf_offset) * ESZ;
     const float bl = A.sub_mode ? (A.bl ? ((const ROWS_GLOBAL float*)A.bl)[rowc * A.bl_stride] : A.bl_const) : 0.0f;
     const bool sub = A.sub_mode != 0;
-    const int nblk = A.len / RB, R = A.ring_entries;
+    const int R = A.ring_entries;
+    const int nblk = rows_blocks(A, rowc);
 
     u4 pf[4][NV];
     auto fetch = [&](u4 (&dst)[NV], int blk) {
@@ -241,7 +254,8 @@ __device__ __forceinline__ void rows_consume(const ROWS_KARG RowsArgs& A, ROWS_L
     const int64_t row = (int64_t)blockIdx.x * 64 + lane;
     const bool live = row < n_wf;
     const int64_t rowc = live ? row : n_wf - 1;
-    const int nblk = A.len / RB, R = A.ring_entries, n = A.len;
+    const int R = A.ring_entries, n = A.len;
+    const int nblk = rows_blocks(A, rowc);
     const float thr = A.thr ? ((const ROWS_GLOBAL float*)A.thr)[rowc * A.thr_stride] : A.thr_const;
     const float ts_f = A.ts ? ((const ROWS_GLOBAL float*)A.ts)[rowc * A.ts_stride] : A.ts_const;
     const bool ts_ok = (TPT == 1 || TPT == 3) && !(ts_f != ts_f) && floorf(ts_f) == ts_f && ts_f >= 0.0f && ts_f < (float)n;
