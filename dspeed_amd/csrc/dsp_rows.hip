@@ -48,12 +48,12 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // both wavefronts of the pair: my LDS accesses are done, then wait for the partner
 __device__ __forceinline__ void pair_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// 8-sample blocks a group walks: all of them, or (RowsArgs.stop_at_start) up to the block behind the latest start among its 64 rows -- both
-// wavefronts of the pair read the same column and agree
+// 8-sample blocks a group walks when RowsArgs.stop_at_start holds (the kernel's STOP build: the plain one keeps its loop bounds as they were,
+// a run-time test of the flag cost the other shapes 3.5 %): up to the block behind the latest start among its 64 rows -- both wavefronts of
+// the pair read the same column and agree
 template <typename ArgsRef>
 __device__ __forceinline__ int rows_blocks(const ArgsRef& A, int64_t rowc) {
     const int all = A.len / 8;
-    if (!A.stop_at_start) return all;
     const float ts_f = A.ts ? ((const __attribute__((address_space(1))) float*)A.ts)[rowc * A.ts_stride] : A.ts_const;
     const bool ok = !(ts_f != ts_f) && ts_f >= 0.0f && ts_f < (float)A.len;
     const int last = wave_max(ok ? (int)ts_f : 0) / 8 + 2;
@@ -71,7 +71,7 @@ __device__ __forceinline__ void rows_report(int* err, int code, int64_t row) {
 // producer: rows -> [bl_subtract] -> pole_zero / double_pole_zero -> ring, Haar tree
 // IN: 0 float32, 1 int16, 2 uint16 rows;  PZ: 1 pole_zero, 2 double_pole_zero
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int IN, int PZ>
+template <int IN, int PZ, bool STOP>
 __device__ __forceinline__ void rows_produce(const ROWS_KARG RowsArgs& A, ROWS_LDS float* ring, int64_t n_wf, int* err) {
     const int lane = lane_id();
     const int64_t row = (int64_t)blockIdx.x * 64 + lane;
@@ -82,7 +82,7 @@ __device__ __forceinline__ void rows_produce(const ROWS_KARG RowsArgs& A, ROWS_L
     const float bl = A.sub_mode ? (A.bl ? ((const ROWS_GLOBAL float*)A.bl)[rowc * A.bl_stride] : A.bl_const) : 0.0f;
     const bool sub = A.sub_mode != 0;
     const int R = A.ring_entries;
-    const int nblk = rows_blocks(A, rowc);
+    const int nblk = STOP ? rows_blocks(A, rowc) : A.len / RB;
 
     u4 pf[4][NV];
     auto fetch = [&](u4 (&dst)[NV], int blk) {
@@ -248,14 +248,14 @@ __device__ __forceinline__ double div_by_count_fx(double x, double d, double inv
     return __builtin_amdgcn_div_fixup(__builtin_fma(r, inv_d, q), d, x);
 }
 
-template <int TRAP, bool RPOW2, int TPT>
+template <int TRAP, bool RPOW2, int TPT, bool STOP>
 __device__ __forceinline__ void rows_consume(const ROWS_KARG RowsArgs& A, ROWS_LDS float* ring, int64_t n_wf, int* err) {
     const int lane = lane_id();
     const int64_t row = (int64_t)blockIdx.x * 64 + lane;
     const bool live = row < n_wf;
     const int64_t rowc = live ? row : n_wf - 1;
     const int R = A.ring_entries, n = A.len;
-    const int nblk = rows_blocks(A, rowc);
+    const int nblk = STOP ? rows_blocks(A, rowc) : A.len / RB;
     const float thr = A.thr ? ((const ROWS_GLOBAL float*)A.thr)[rowc * A.thr_stride] : A.thr_const;
     const float ts_f = A.ts ? ((const ROWS_GLOBAL float*)A.ts)[rowc * A.ts_stride] : A.ts_const;
     const bool ts_ok = (TPT == 1 || TPT == 3) && !(ts_f != ts_f) && floorf(ts_f) == ts_f && ts_f >= 0.0f && ts_f < (float)n;
@@ -405,6 +405,7 @@ __device__ __forceinline__ void rows_consume(const ROWS_KARG RowsArgs& A, ROWS_L
     }
 }
 
+template <bool STOP>
 __global__ void __launch_bounds__(128, 2) dsp_rows_kernel(RowsArgs A_, int64_t n_wf, int* err) {
     // (taking the address of the by-value argument would make the compiler copy it to scratch: read it where it lies)
     const ROWS_KARG RowsArgs& A = *(const ROWS_KARG RowsArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -416,24 +417,24 @@ __global__ void __launch_bounds__(128, 2) dsp_rows_kernel(RowsArgs A_, int64_t n
     __syncthreads();
     if (wave == 0) {
         switch (A.in_kind * 3 + A.pz_kind) {
-            case 0: rows_produce<0, 0>(A, ring, n_wf, err); break;
-            case 1: rows_produce<0, 1>(A, ring, n_wf, err); break;
-            case 2: rows_produce<0, 2>(A, ring, n_wf, err); break;
-            case 3: rows_produce<1, 0>(A, ring, n_wf, err); break;
-            case 4: rows_produce<1, 1>(A, ring, n_wf, err); break;
-            case 5: rows_produce<1, 2>(A, ring, n_wf, err); break;
-            case 6: rows_produce<2, 0>(A, ring, n_wf, err); break;
-            case 7: rows_produce<2, 1>(A, ring, n_wf, err); break;
-            default: rows_produce<2, 2>(A, ring, n_wf, err); break;
+            case 0: rows_produce<0, 0, STOP>(A, ring, n_wf, err); break;
+            case 1: rows_produce<0, 1, STOP>(A, ring, n_wf, err); break;
+            case 2: rows_produce<0, 2, STOP>(A, ring, n_wf, err); break;
+            case 3: rows_produce<1, 0, STOP>(A, ring, n_wf, err); break;
+            case 4: rows_produce<1, 1, STOP>(A, ring, n_wf, err); break;
+            case 5: rows_produce<1, 2, STOP>(A, ring, n_wf, err); break;
+            case 6: rows_produce<2, 0, STOP>(A, ring, n_wf, err); break;
+            case 7: rows_produce<2, 1, STOP>(A, ring, n_wf, err); break;
+            default: rows_produce<2, 2, STOP>(A, ring, n_wf, err); break;
         }
     } else {
 #define ROWS_C(TRAP, P2)                                                      \
     switch (A.tpt_mode) {                                                     \
-        case 0: rows_consume<TRAP, P2, 0>(A, ring, n_wf, err); break;         \
-        case 1: rows_consume<TRAP, P2, 1>(A, ring, n_wf, err); break;         \
-        case 2: rows_consume<TRAP, P2, 2>(A, ring, n_wf, err); break;         \
-        case 3: rows_consume<TRAP, P2, 3>(A, ring, n_wf, err); break;         \
-        default: rows_consume<TRAP, P2, 4>(A, ring, n_wf, err); break;        \
+        case 0: rows_consume<TRAP, P2, 0, STOP && 0 == 1>(A, ring, n_wf, err); break;         \
+        case 1: rows_consume<TRAP, P2, 1, STOP && 1 == 1>(A, ring, n_wf, err); break;         \
+        case 2: rows_consume<TRAP, P2, 2, STOP && 2 == 1>(A, ring, n_wf, err); break;         \
+        case 3: rows_consume<TRAP, P2, 3, STOP && 3 == 1>(A, ring, n_wf, err); break;         \
+        default: rows_consume<TRAP, P2, 4, STOP && 4 == 1>(A, ring, n_wf, err); break;        \
     }
         if (A.trap_kind == TRAP_FILTER) {
             ROWS_C(TRAP_FILTER, false)
@@ -451,12 +452,17 @@ __global__ void __launch_bounds__(128, 2) dsp_rows_kernel(RowsArgs A_, int64_t n
 extern "C" int dsp_internal_launch_rows(const RowsArgs* A, int64_t n_wf, int* err, int lds_bytes, hipStream_t stream) {
     if (n_wf <= 0) return 0;
     const unsigned blocks = (unsigned)((n_wf + 63) / 64);
-    hipLaunchKernelGGL(dsp_rows_kernel, dim3(blocks), dim3(128), lds_bytes, stream, *A, n_wf, err);
+    if (A->stop_at_start)
+        hipLaunchKernelGGL(dsp_rows_kernel<true>, dim3(blocks), dim3(128), lds_bytes, stream, *A, n_wf, err);
+    else
+        hipLaunchKernelGGL(dsp_rows_kernel<false>, dim3(blocks), dim3(128), lds_bytes, stream, *A, n_wf, err);
     return (int)hipGetLastError();
 }
 
 extern "C" int dsp_internal_set_rows_lds(int lds_bytes) {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dsp_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dsp_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (rc) return rc;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&dsp_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
 }
 
 extern "C" const char* dsp_internal_rows_kernel_name() { return "dsp_rows_kernel"; }
