@@ -29,7 +29,7 @@
 #include "dsp_program.h"
 
 extern "C" int dsp_internal_launch_vm_f32(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int* err, int blocks,
-                                          int threads, int lds_bytes, int with_fir, hipStream_t stream);
+                                          int threads, int lds_bytes, int with_fir, int team, hipStream_t stream);
 extern "C" int dsp_internal_launch_vm_f64(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int* err, int blocks,
                                           int threads, int lds_bytes, int with_fir, hipStream_t stream);
 extern "C" int dsp_internal_set_vm_lds(int lds_bytes);
@@ -1680,6 +1680,98 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         ch->fused_on = !(env && env[0] == '1');
     }
 
+    // ---- a team of two wavefronts per row?  A program that loads ONE waveform and then only reads it -- the trapezoid reductions, pick-offs and
+    // walks a whole recipe runs on its pole-zero rows -- whose image leaves LDS for one wavefront per SIMD: its ops fall into groups that share
+    // no scalar register, and two wavefronts can run two groups on the one image at the same time.
+    P.team = 1;
+    for (int i = 0; i < P.n_ops; ++i) P.ops[i].member = 2;
+    {
+        const char* env = getenv("DSPEED_HIP_NO_TEAMS");
+        const bool vm_runs = !(ch->fused_ok || ch->rr_ok || ch->rows_ok || ch->fir_ok || ch->cur_ok || ch->red_ok || ch->scalar_ok);
+        bool ok = vm_runs && !(env && env[0] == '1') && !f64 && !ch->has_fir && n_slots == 1 && ch->lds_bytes_per_wave > 0 &&
+                  LDS_BYTES_PER_CU / ch->lds_bytes_per_wave <= 4 && ch->waves_per_block * 2 <= 16 && n_sregs <= 128;
+        int first = 0;
+        while (first < P.n_ops && P.ops[first].opcode == DSP_OP_INTERNAL_NOP) ++first;
+        ok = ok && first < P.n_ops && P.ops[first].opcode == DSP_OP_LOAD;
+        // registers an op writes / reads (scalar registers only: after the load nothing writes the waveform)
+        auto writes = [&](const DevOp& o, int* r) {
+            int n = 0;
+            switch (o.opcode) {
+                case DSP_OP_MIN_MAX: for (int k = 0; k < 4; ++k) r[n++] = o.dst + k; break;
+                case DSP_OP_TRAP_REDUCE:
+                    if (o.dst >= 0) for (int k = 0; k < 4; ++k) r[n++] = o.dst + k;
+                    if (o.io >= 0) r[n++] = o.io;
+                    if ((((o.ip[3] >> 16) & 0x3fff) - 1) >= 0) r[n++] = ((o.ip[3] >> 16) & 0x3fff) - 1;  // (a pick-off that reads the same trapezoid)
+                    break;
+                case DSP_OP_AMAX: case DSP_OP_TRAP_PICKOFF: case DSP_OP_TIME_POINT_THRESH: case DSP_OP_PICKOFF: case DSP_OP_SCALAR_AFFINE:
+                case DSP_OP_SCALAR_DIV: case DSP_OP_SCALAR_CONVERT: case DSP_OP_SCALAR_FUNC: r[n++] = o.dst; break;
+                default: break;
+            }
+            return n;
+        };
+        auto reads = [&](const DevOp& o, int* r) {
+            int n = 0;
+            for (int k = 0; k < 4; ++k)
+                if (o.sp[k].kind == DSP_ARG_REG) r[n++] = o.sp[k].index;
+            if (o.opcode == DSP_OP_STORE_SCALAR) r[n++] = o.ip[0];
+            return n;
+        };
+        for (int i = first + 1; ok && i < P.n_ops; ++i) {
+            switch (P.ops[i].opcode) {
+                case DSP_OP_TRAP_REDUCE: case DSP_OP_TRAP_PICKOFF: case DSP_OP_TIME_POINT_THRESH: case DSP_OP_PICKOFF: case DSP_OP_MIN_MAX: case DSP_OP_AMAX:
+                case DSP_OP_SCALAR_AFFINE: case DSP_OP_SCALAR_DIV: case DSP_OP_SCALAR_CONVERT: case DSP_OP_SCALAR_FUNC: case DSP_OP_STORE_SCALAR:
+                case DSP_OP_INTERNAL_NOP: break;
+                default: ok = false;
+            }
+        }
+        if (ok) {
+            // groups: ops joined by any register one writes and the other reads or writes
+            std::vector<int> parent(P.n_ops);
+            for (int i = 0; i < P.n_ops; ++i) parent[i] = i;
+            auto find = [&](int x) { while (parent[x] != x) x = parent[x] = parent[parent[x]]; return x; };
+            std::vector<int> owner(DSP_MAX_SREGS + 8, -1);  // register -> an op that touched it
+            for (int i = first + 1; i < P.n_ops; ++i) {
+                int regs[16], n = writes(P.ops[i], regs);
+                n += reads(P.ops[i], regs + n);
+                for (int k = 0; k < n; ++k) {
+                    const int r = regs[k];
+                    if (r < 0 || r >= (int)owner.size()) { ok = false; break; }
+                    if (owner[r] < 0) owner[r] = i;
+                    else parent[find(i)] = find(owner[r]);
+                }
+            }
+            auto weight = [&](int oc) {
+                switch (oc) {
+                    case DSP_OP_TRAP_REDUCE: return 27;
+                    case DSP_OP_TRAP_PICKOFF: return 20;
+                    case DSP_OP_MIN_MAX: return 16;
+                    case DSP_OP_TIME_POINT_THRESH: case DSP_OP_AMAX: return 4;
+                    case DSP_OP_PICKOFF: return 3;
+                    case DSP_OP_STORE_SCALAR: return 1;
+                    default: return 2;
+                }
+            };
+            std::vector<int> w(P.n_ops, 0);
+            for (int i = first + 1; i < P.n_ops; ++i) w[find(i)] += weight(P.ops[i].opcode);
+            std::vector<int> roots;
+            for (int i = first + 1; i < P.n_ops; ++i)
+                if (find(i) == i) roots.push_back(i);
+            std::sort(roots.begin(), roots.end(), [&](int a, int b) { return w[a] > w[b]; });
+            int load[2] = {0, 0};
+            std::vector<int> side(P.n_ops, 0);
+            for (int r : roots) {
+                const int m = load[0] <= load[1] ? 0 : 1;
+                side[r] = m;
+                load[m] += w[r];
+            }
+            // worth a second wavefront only when it takes a real share of the work
+            if (ok && load[0] > 0 && load[1] > 0 && 5 * (load[0] < load[1] ? load[0] : load[1]) >= load[0] + load[1]) {
+                P.team = 2;
+                for (int i = first + 1; i < P.n_ops; ++i) P.ops[i].member = side[find(i)];
+            }
+        }
+    }
+
     // The interpreter pays a dispatch per op and row (a lone wavefront: op fetch, decode, a few hundred cycles), and a recipe ends in
     // dozens of one-lane stores.  Last step, after every shape matcher has read the ops: a run of STORE_SCALARs becomes one op whose lanes
     // store one value each, and the no-ops a folded BL_SUBTRACT left are dropped.  (The row-per-lane kernel keeps its plain stores.)
@@ -1691,7 +1783,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                 continue;
             }
             int e = r;
-            while (e < P.n_ops && P.ops[e].opcode == DSP_OP_STORE_SCALAR && e - r < DSP_IC) ++e;
+            while (e < P.n_ops && P.ops[e].opcode == DSP_OP_STORE_SCALAR && e - r < DSP_IC && P.ops[e].member == P.ops[r].member) ++e;
             if (e - r >= 2) {
                 DevOp m = P.ops[r];
                 m.opcode = DSP_OP_INTERNAL_STORES;
@@ -1940,8 +2032,8 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
     }
     hipError_t e = ch->f64 ? (hipError_t)dsp_internal_launch_vm_f64(ch->dev, &ptrs, n_wf, ch->dev_err, blocks, threads, lds, ch->has_fir,
                                                                     (hipStream_t)stream)
-                           : (hipError_t)dsp_internal_launch_vm_f32(ch->dev, &ptrs, n_wf, ch->dev_err, blocks, threads, lds, ch->has_fir,
-                                                                    (hipStream_t)stream);
+                           : (hipError_t)dsp_internal_launch_vm_f32(ch->dev, &ptrs, n_wf, ch->dev_err, blocks, threads * ch->host.team, lds, ch->has_fir,
+                                                                    ch->host.team, (hipStream_t)stream);
     if (e != hipSuccess) return fail(DSP_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
     return post_err(ch, stream);
 }
@@ -2061,8 +2153,8 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
         if (blocks) *blocks = b;
         return DSP_OK;
     }
-    if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->lds_bytes_per_wave;
-    if (waves_per_block) *waves_per_block = ch->waves_per_block;
+    if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->lds_bytes_per_wave / ch->host.team;  // (a team of wavefronts shares a row's image)
+    if (waves_per_block) *waves_per_block = ch->waves_per_block * ch->host.team;
     if (blocks) *blocks = vm_blocks(ch, n_wf);
     return DSP_OK;
 }

@@ -42,6 +42,8 @@ struct DevOp {
     int32_t ip[4];
     dsp_scalar_arg sp[4];
     int32_t ic[DSP_IC];
+    int32_t member;  // DevProgram.team == 2: which wavefront of a row's team runs the op (0, 1; 2 = both)
+    int32_t pad_;
     double fc[DSP_FC];
 };
 
@@ -51,6 +53,11 @@ struct DevProgram {
     int32_t sreg_off;           // element offset of the scalar register file
     int32_t waves_per_block;
     int32_t scratch_off;        // element offset of DSP_SCRATCH_ELEMS elements any op may use while it runs (16-byte aligned)
+    // 2: a TEAM of two wavefronts per row -- a program that loads one waveform and then only reads it (reductions, walks, pick-offs of long
+    // waveforms, whose image leaves LDS for one wavefront per SIMD) splits into two groups of ops that share no register; each member runs
+    // its group on the shared image (DevOp.member).  1: a wavefront per row
+    int32_t team;
+    int32_t pad_;
     // per-op cycle counters (dsp_chain_profile): n_ops + 1 device words, the last counts the waveforms sampled; null = off
     unsigned long long* prof;
     DevSlot slots[DSP_MAX_SLOTS];

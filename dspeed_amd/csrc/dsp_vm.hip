@@ -2219,18 +2219,26 @@ __device__ __forceinline__ void op_zero_region(Ctx<T>& cx, const DSP_PROG DevOp&
 // ------------------------------------------------------------------------------------------------
 // FIR: the interpreter with the long-FIR op compiled in.  That op's register needs (183 VGPRs with it, 113 without) would cap every
 // chain at 2 wavefronts per SIMD, so programs without a CONVOLVE run the lean build: 4 wavefronts per SIMD where LDS allows.
-template <typename T, bool FIR>
+template <typename T, bool FIR, int TEAM>
 // (the build without the long-FIR op: 3 wavefronts per SIMD = 168 registers.  At 4 per SIMD -- 128 registers -- the interpreter spilled in
 // every op once the per-event pole-zero forms and the recipe language's pick-off modes were in: C2 on the VM 129 -> 106 M waveforms/s; and a
 // waveform of 4096 samples leaves LDS for 9 wavefronts per CU anyway)
-__global__ void __launch_bounds__(256, FIR ? 2 : 3) dsp_vm_kernel(const DevProgram* __restrict__ prog, IoPtrs ptrs, int64_t n_wf, int* err) {
+__global__ void __launch_bounds__(256 * TEAM, TEAM > 1 ? 1 : (FIR ? 2 : 3)) dsp_vm_kernel(const DevProgram* __restrict__ prog, IoPtrs ptrs, int64_t n_wf, int* err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably wave-uniform -> rows, pointers in SGPRs
-    const int wpb = (int)(blockDim.x >> 6);
+    // TEAM == 2: wavefronts 2 s and 2 s + 1 of the workgroup share row slot s -- one LDS image, the ops of the row's program dealt out between
+    // them (DevOp.member; the LOAD is run by both, writing the same values: each member has a complete image when its own load is done).  One
+    // workgroup barrier per row keeps a member from loading the next row into an image its partner still reads.
+    const int wave_raw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably wave-uniform -> rows, pointers in SGPRs
+    const int wave = TEAM == 1 ? wave_raw : wave_raw / TEAM;
+    const int member = TEAM == 1 ? 0 : wave_raw % TEAM;
+    const int wpb = (int)(blockDim.x >> 6) / TEAM;
     auto* lds = (typename Ctx<T>::LT*)smem_raw + (size_t)wave * prog->lds_elems_per_wave;  // (C cast: generic -> LDS address space)
     // zero the whole region once: guards below each slot must read as 0 forever, pads start finite
     for (int e = lane_id(); e < prog->lds_elems_per_wave; e += 64) lds[e] = (T)0;
-    wave_sync();
+    if (TEAM == 1)
+        wave_sync();
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the partner may still be clearing what this member would load into)
 
     Ctx<T> cx;
     cx.lds = lds;
@@ -2244,9 +2252,15 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 3) dsp_vm_kernel(const DevProgr
     const int n_ops = prog->n_ops;
     // dsp_chain_profile: the first wavefront of every workgroup times each op of its waveforms with the shader clock
     unsigned long long* prof = prog->prof;
-    const bool sampled = prof != nullptr && wave == 0;
+    const bool sampled = prof != nullptr && wave_raw == 0;
     unsigned long long t_prev = 0;
-    for (int64_t row = (int64_t)blockIdx.x * wpb + wave; row < n_wf; row += total_waves) {
+    for (int64_t base = (int64_t)blockIdx.x * wpb;; base += total_waves) {
+        const int64_t row = base + wave;
+        if (TEAM == 1 ? row >= n_wf : base >= n_wf) break;  // (a team's workgroup leaves together: every wavefront meets every barrier)
+        if (TEAM > 1 && row >= n_wf) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            continue;
+        }
         cx.row = row;
         cx.nan_all = cx.nan_some = 0;
         if (sampled) t_prev = __builtin_amdgcn_s_memtime();
@@ -2257,6 +2271,10 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 3) dsp_vm_kernel(const DevProgr
         __builtin_amdgcn_s_setprio(0);
         for (int i = 0; i < n_ops; ++i) {
             const DSP_PROG DevOp& op = cx.prog->ops[i];
+            if (TEAM > 1) {
+                const int m = op.member;  // (uniform)
+                if (m != 2 && m != member) continue;
+            }
             {
                 const int lvl = (i * 4) / n_ops;
                 if (lvl != prio_level) {  // (uniform; s_setprio takes an immediate)
@@ -2320,6 +2338,7 @@ __global__ void __launch_bounds__(256, FIR ? 2 : 3) dsp_vm_kernel(const DevProgr
                 atomicAdd(prof + n_ops, 1ull);
             }
         }
+        if (TEAM > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the image is free for the next row
     }
 }
 
@@ -2394,27 +2413,30 @@ __global__ void __launch_bounds__(256) dsp_stream_read_kernel(const uint4* src, 
 // launchers (called from dsp_host.cpp)
 // ------------------------------------------------------------------------------------------------
 extern "C" int dsp_internal_launch_vm_f32(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int* err, int blocks,
-                                          int threads, int lds_bytes, int with_fir, hipStream_t stream) {
-    if (with_fir)
-        hipLaunchKernelGGL((dsp_vm_kernel<float, true>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
+                                          int threads, int lds_bytes, int with_fir, int team, hipStream_t stream) {
+    if (team == 2)
+        hipLaunchKernelGGL((dsp_vm_kernel<float, false, 2>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
+    else if (with_fir)
+        hipLaunchKernelGGL((dsp_vm_kernel<float, true, 1>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
     else
-        hipLaunchKernelGGL((dsp_vm_kernel<float, false>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
+        hipLaunchKernelGGL((dsp_vm_kernel<float, false, 1>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
     return (int)hipGetLastError();
 }
 
 extern "C" int dsp_internal_launch_vm_f64(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int* err, int blocks,
                                           int threads, int lds_bytes, int with_fir, hipStream_t stream) {
     if (with_fir)
-        hipLaunchKernelGGL((dsp_vm_kernel<double, true>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
+        hipLaunchKernelGGL((dsp_vm_kernel<double, true, 1>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
     else
-        hipLaunchKernelGGL((dsp_vm_kernel<double, false>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
+        hipLaunchKernelGGL((dsp_vm_kernel<double, false, 1>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
     return (int)hipGetLastError();
 }
 
 extern "C" int dsp_internal_set_vm_lds(int lds_bytes) {
-    const void* k[4] = {reinterpret_cast<const void*>(&dsp_vm_kernel<float, true>), reinterpret_cast<const void*>(&dsp_vm_kernel<float, false>),
-                        reinterpret_cast<const void*>(&dsp_vm_kernel<double, true>), reinterpret_cast<const void*>(&dsp_vm_kernel<double, false>)};
-    for (int i = 0; i < 4; ++i) {
+    const void* k[5] = {reinterpret_cast<const void*>(&dsp_vm_kernel<float, true, 1>), reinterpret_cast<const void*>(&dsp_vm_kernel<float, false, 1>),
+                        reinterpret_cast<const void*>(&dsp_vm_kernel<double, true, 1>), reinterpret_cast<const void*>(&dsp_vm_kernel<double, false, 1>),
+                        reinterpret_cast<const void*>(&dsp_vm_kernel<float, false, 2>)};
+    for (int i = 0; i < 5; ++i) {
         const int rc = (int)hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (rc != 0) return rc;
     }

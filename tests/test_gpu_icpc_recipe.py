@@ -458,3 +458,28 @@ def test_stages_on_side_streams_give_the_same_results():
         chain2.execute()
         for k in ref:
             assert np.array_equal(out2[k], ref[k], equal_nan=True), k
+
+
+def test_two_wavefronts_per_row_give_the_same_results(monkeypatch):
+    """the recipe's program loads the pole-zero rows and then only reads them: its ops fall into two groups that share no register, and a team of
+    two wavefronts per row runs them on the one LDS image (dsp_chain_create, DevProgram.team); DSPEED_HIP_NO_TEAMS=1 keeps a wavefront per row"""
+    from dspeed_amd.processing_chain import WaveformInput, build_processing_chain
+
+    rng = np.random.default_rng(23)
+    n = 1000  # (not a multiple of the rows a workgroup takes: the last workgroup has idle row slots that still meet its barriers)
+    wf, bl = _synth(rng, n)
+    tb = {"waveform": WaveformInput(wf.astype(np.uint16), 16.0, 48000.0), "baseline": bl}
+    chain, _, out = build_processing_chain(recipes.ICPC, tb)
+    chain.execute()
+    g = chain._chain.geometry(n)
+    assert chain._chain.kernel_name.startswith("dsp_vm") and g["waves_per_block"] == 8, g
+    monkeypatch.setenv("DSPEED_HIP_NO_TEAMS", "1")
+    single, _, ref = build_processing_chain(recipes.ICPC, tb)
+    single.execute()
+    assert single._chain.geometry(n)["waves_per_block"] == 4
+    for k in ref:
+        assert np.array_equal(np.asarray(out[k]), np.asarray(ref[k]), equal_nan=True), k
+    for _ in range(2):  # (again on the same handle: the image and the registers are reused row after row)
+        chain.execute()
+        for k in ref:
+            assert np.array_equal(np.asarray(out[k]), np.asarray(ref[k]), equal_nan=True), k
