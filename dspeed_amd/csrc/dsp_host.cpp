@@ -82,6 +82,8 @@ extern "C" const char* dsp_internal_energy_rr_kernel_name();
 extern "C" int dsp_internal_launch_rows(const RowsArgs* A, int64_t n_wf, int* err, int lds_bytes, hipStream_t stream);
 extern "C" int dsp_internal_set_rows_lds(int lds_bytes);
 extern "C" const char* dsp_internal_rows_kernel_name();
+extern "C" int dsp_internal_launch_pz_rows(const PzArgs* A, int64_t n_wf, int* err, hipStream_t stream);
+extern "C" const char* dsp_internal_pz_rows_kernel_name();
 extern "C" int dsp_internal_launch_reduce(const ReduceArgs* A, int64_t n_wf, int dtype, int vec, hipStream_t stream);
 extern "C" const char* dsp_internal_reduce_kernel_name();
 extern "C" int dsp_internal_launch_scalar(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int n_sregs, int f64, hipStream_t stream);
@@ -203,6 +205,10 @@ struct dsp_chain {
     int cur_lds_bytes = 0, cio_wf = -1, cio_t0 = -1, cio_out[4] = {-1, -1, -1, -1};
     float* cur_scratch = nullptr;  // allocated at the first launch
     int cur_blocks_cap = 0;
+    // pole-zero rows written back as rows (dsp_pz.hip)
+    bool pz_ok = false;
+    PzArgs pz{};
+    int pio_wf = -1, pio_bl = -1, pio_out = -1;
     // streaming reductions of rows (dsp_reduce.hip)
     bool red_ok = false;
     ReduceArgs red{};
@@ -232,6 +238,52 @@ static bool fn_code_ok(int ip0, bool f64) {
     if (ip0 < 0 || code > DSP_FN_LAST || (ip0 >> 17) != 0) return false;
     if (code >= DSP_FN_IADD && code <= DSP_FN_ICAST) return bits == 8 || bits == 16 || (bits == 32 && f64);
     return (ip0 >> 8) == 0;
+}
+
+// Is the program  LOAD s; [BL_SUBTRACT s <- s;]  POLE_ZERO s <- s (a constant time constant);  STORE s  on 16-byte aligned rows (dsp_pz.hip)?
+static bool match_pz_rows_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, const int32_t* slot_len, int n_slots,
+                                const std::vector<int>& dev_index, bool f64) {
+    if (f64 || n_slots != 1 || n_ops < 3 || n_ops > 4 || ops[0].opcode != DSP_OP_LOAD) return false;
+    const dsp_op& ld = ops[0];
+    const dsp_io_desc& w = io[ld.io];
+    const int len = slot_len[ld.dst];
+    if ((w.dtype != DSP_F32 && w.dtype != DSP_I16 && w.dtype != DSP_U16) || ld.ip[0] != 0 || ld.ip[1] != 0 || w.len != len || len % 8 != 0 || len < 8)
+        return false;
+    const int es = w.dtype == DSP_F32 ? 4 : 2;
+    if ((w.row_stride * es) % 16 != 0 || (w.offset * es) % 16 != 0) return false;
+    PzArgs& A = ch->pz;
+    memset(&A, 0, sizeof A);
+    ch->pio_bl = -1;
+    int i = 1;
+    if (ops[i].opcode == DSP_OP_BL_SUBTRACT) {
+        const dsp_op& bs = ops[i++];
+        if (bs.dst != ld.dst || bs.src != ld.dst || bs.ip[0] != 0) return false;
+        if (bs.sp[0].kind == DSP_ARG_INPUT && io[bs.sp[0].index].dtype == DSP_F32) {
+            ch->pio_bl = bs.sp[0].index;
+            A.bl_stride = io[ch->pio_bl].row_stride;
+        } else if (bs.sp[0].kind == DSP_ARG_CONST) {
+            A.bl_const = (float)bs.sp[0].value;
+        } else {
+            return false;
+        }
+        A.sub_mode = 1;
+    }
+    if (i + 2 != n_ops || ops[i].opcode != DSP_OP_POLE_ZERO || ops[i + 1].opcode != DSP_OP_STORE) return false;
+    const dsp_op &pz = ops[i], &st = ops[i + 1];
+    if (pz.src != ld.dst || pz.dst != ld.dst || pz.sp[0].kind != DSP_ARG_CONST || st.src != ld.dst) return false;
+    const dsp_io_desc& o = io[st.io];
+    if (o.dtype != DSP_F32 || o.len != len || o.row_stride % 4 != 0 || o.offset % 4 != 0) return false;
+    const DevOp& dpz = ch->host.ops[dev_index[i]];
+    A.c = dpz.fc[0];
+    A.tau_nan = dpz.ic[0];
+    A.wf_stride = w.row_stride;
+    A.wf_offset = w.offset;
+    A.len = len;
+    A.in_kind = w.dtype == DSP_F32 ? 0 : (w.dtype == DSP_I16 ? 1 : 2);
+    A.out_stride = o.row_stride;
+    ch->pio_wf = ld.io;
+    ch->pio_out = st.io;
+    return true;
 }
 
 // Does the program only read per-event values off rows (dsp_reduce.hip)?
@@ -1666,6 +1718,11 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             ch->fused_on = !(env && env[0] == '1');
         }
     }
+    ch->pz_ok = match_pz_rows_shape(ch.get(), ops, n_ops, io, slot_len, n_slots, dev_index, f64);
+    if (ch->pz_ok) {
+        const char* env = getenv("DSPEED_HIP_NO_FUSED");
+        ch->fused_on = !(env && env[0] == '1');
+    }
     ch->red_ok = match_reduce_shape(ch.get(), ops, n_ops, io, slot_len, f64);
     if (ch->red_ok) {
         const char* env = getenv("DSPEED_HIP_NO_FUSED");
@@ -1687,7 +1744,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
     for (int i = 0; i < P.n_ops; ++i) P.ops[i].member = 2;
     {
         const char* env = getenv("DSPEED_HIP_NO_TEAMS");
-        const bool vm_runs = !(ch->fused_ok || ch->rr_ok || ch->rows_ok || ch->fir_ok || ch->cur_ok || ch->red_ok || ch->scalar_ok);
+        const bool vm_runs = !(ch->fused_ok || ch->rr_ok || ch->rows_ok || ch->fir_ok || ch->cur_ok || ch->red_ok || ch->pz_ok || ch->scalar_ok);
         bool ok = vm_runs && !(env && env[0] == '1') && !f64 && !ch->has_fir && n_slots == 1 && ch->lds_bytes_per_wave > 0 &&
                   LDS_BYTES_PER_CU / ch->lds_bytes_per_wave <= 4 && ch->waves_per_block * 2 <= 16 && n_sregs <= 128;
         int first = 0;
@@ -1928,6 +1985,15 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "scalar kernel launch failed: %s", hipGetErrorString(e));
         return post_err(ch, stream);
     }
+    if (ch->pz_ok && ch->fused_on && (reinterpret_cast<uintptr_t>(io_ptrs[ch->pio_wf]) & 15u) == 0 && (reinterpret_cast<uintptr_t>(at(ch->pio_out)) & 15u) == 0) {
+        PzArgs A = ch->pz;
+        A.wf = io_ptrs[ch->pio_wf];
+        A.bl = (const float*)at(ch->pio_bl);
+        A.out = at(ch->pio_out);
+        hipError_t e = (hipError_t)dsp_internal_launch_pz_rows(&A, n_wf, ch->dev_err, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "pole-zero rows kernel launch failed: %s", hipGetErrorString(e));
+        return post_err(ch, stream);
+    }
     if (ch->red_ok && ch->fused_on) {
         ReduceArgs A = ch->red;
         A.wf = io_ptrs[ch->dio_wf];
@@ -2118,7 +2184,7 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
         if (blocks) *blocks = (int)((n_wf + 63) / 64);
         return DSP_OK;
     }
-    if (ch->red_ok && ch->fused_on) {
+    if ((ch->red_ok || ch->pz_ok) && ch->fused_on) {
         if (lds_bytes_per_wave) *lds_bytes_per_wave = 0;
         if (waves_per_block) *waves_per_block = 4;
         if (blocks) *blocks = (int)((n_wf + 3) / 4);
@@ -2161,6 +2227,7 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
 
 const char* dsp_chain_kernel_name(dsp_chain* ch) {
     if (ch && ch->scalar_ok && ch->fused_on) return dsp_internal_scalar_kernel_name();
+    if (ch && ch->pz_ok && ch->fused_on) return dsp_internal_pz_rows_kernel_name();
     if (ch && ch->red_ok && ch->fused_on) return dsp_internal_reduce_kernel_name();
     if (ch && ch->cur_ok && ch->fused_on) return dsp_internal_current_kernel_name();
     if (ch && ch->fir_ok && ch->fused_on)
@@ -2189,7 +2256,7 @@ int dsp_chain_set_fused(dsp_chain* ch, int enable) {
     // 7 = classic (VM layout); anything else = default
     const int v = (enable >> 1) & 7;
     ch->variant = (v == 7 || !ch->rr_ok) ? 1 : 6;
-    return ((ch->fused_ok || ch->rr_ok || ch->rows_ok || ch->fir_ok || ch->cur_ok || ch->scalar_ok || ch->red_ok) && ch->fused_on) ? 1 : 0;
+    return ((ch->fused_ok || ch->rr_ok || ch->rows_ok || ch->fir_ok || ch->cur_ok || ch->scalar_ok || ch->red_ok || ch->pz_ok) && ch->fused_on) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ single processors

@@ -152,6 +152,22 @@ struct CurrentArgs {
     int64_t scratch_per_wave;
 };
 
+// arguments of the pole-zero rows kernel (dsp_pz.hip):  LOAD -> [BL_SUBTRACT] -> POLE_ZERO (constant tau) -> STORE
+struct PzArgs {
+    const void* wf;          // float32 / int16 / uint16 rows, 16-byte aligned
+    int64_t wf_stride;
+    int32_t wf_offset, len;  // first sample, samples (a multiple of 8)
+    int32_t in_kind;         // 0 float32, 1 int16, 2 uint16
+    int32_t sub_mode;        // 1: bl_subtract first
+    const float* bl;         // per-row baseline column or null: bl_const
+    int64_t bl_stride;
+    float bl_const;
+    int32_t tau_nan;
+    double c;                // exp(-1/tau)
+    void* out;               // float32 rows
+    int64_t out_stride;
+};
+
 // arguments of the streaming reductions (dsp_reduce.hip), filled by dsp_chain_execute when a program has the shape
 //   LOAD -> {MIN_MAX | AMAX | PICKOFF at a constant integral time | TIME_POINT_THRESH from a constant sample or from the extremes}+ -> STORE_SCALARs
 #define DSP_REDUCE_PICKS 4

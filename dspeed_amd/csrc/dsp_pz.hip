@@ -1,0 +1,143 @@
+// dsp_pz.hip -- [bl_subtract ->] pole_zero of whole rows, written back as rows: what a recipe stages in HBM for the kernels that read the
+// pole-zero corrected waveform as rows (long FIRs, lane-per-waveform kernels, the program's reductions).
+//
+// pole_zero (processors/pole_zero.py:24-77) is a prefix sum: with S the inclusive prefix sum of the input, the reference's accumulator after
+// sample k is  S(k) - c S(k-1)  (c = exp(-1/tau), float64), rounded to float32 on the way out.  On the waveform VM the row goes through an
+// LDS image (lane-contiguous chunks, the recurrence inside a chunk) -- and an 8192-sample image leaves LDS for one wavefront per SIMD: 2.2 ms
+// per 131 072 rows where the bytes (16 kB in, 32 kB out) take 1.2.  Here a wavefront walks its row in the order it lies in memory -- 8 samples
+// per lane and group of 512 -- with the sums in float64 registers: a local prefix over the lane's 8 samples, one scan across the wavefront per
+// group, a carry from group to group; no LDS, eight wavefronts per SIMD, loads and stores of 16 / 32 bytes per lane.
+// The sums are the same real numbers in another order than the VM's (float64; the float32 outputs differ in a last place once in a while):
+// within the filter bar of the oracle like every scan formulation of this recurrence here.
+#include <hip/hip_runtime.h>
+
+#include "dsp_program.h"
+#include "dsp_wave.h"
+
+#define PZ_GLOBAL __attribute__((address_space(1)))
+#define PZ_KARG __attribute__((address_space(4)))
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void pz_report(int* err, int code, int64_t row) {
+    if (atomicCAS(&err[0], 0, code) == 0) {
+        err[1] = (int)(row & 0xffffffffll);
+        err[2] = (int)(row >> 32);
+    }
+}
+
+// IN: 0 float32, 1 int16, 2 uint16 rows
+template <int IN>
+__global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_wf, int* err) {
+    const PZ_KARG PzArgs& A = *(const PZ_KARG PzArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)A_;
+    const int lane = lane_id();
+    const int64_t row = (int64_t)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (row >= n_wf) return;  // (whole wavefronts: no barrier in this kernel)
+    constexpr int ESZ = IN == 0 ? 4 : 2, NV = IN == 0 ? 2 : 1;
+    const int n = A.len;
+    const PZ_GLOBAL char* rowp = (const PZ_GLOBAL char*)A.wf + (row * A.wf_stride + A.wf_offset) * ESZ;
+    PZ_GLOBAL float* outp = (PZ_GLOBAL float*)A.out + row * A.out_stride;
+    const bool sub = A.sub_mode != 0;
+    const float bl = sub ? (A.bl ? ((const PZ_GLOBAL float*)A.bl)[row * A.bl_stride] : A.bl_const) : 0.0f;
+    const double c = A.c;
+    const int n_groups = (n + 511) / 512;
+
+    u4 pf[2][NV];
+    auto fetch = [&](u4 (&dst)[NV], int g) {
+        int at = g * 512 + lane * 8;
+        at = at < n ? at : 0;  // (a lane beyond the row's end asks for something inside it and ignores it)
+        const PZ_GLOBAL u4* src = (const PZ_GLOBAL u4*)(rowp + (size_t)at * ESZ);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dst[v] = __builtin_nontemporal_load(src + v);
+    };
+    fetch(pf[0], 0);
+    if (n_groups > 1) fetch(pf[1], 1);
+
+    double carry = 0.0;  // S at the end of the previous group
+    bool in_nan = false, out_nan = false;
+    auto group = [&](const u4 (&raw)[NV], int g) {
+        const int at = g * 512 + lane * 8;
+        const bool live = at < n;  // (n is a multiple of 8: a lane's vector lies inside the row whole or not at all)
+        float x[8];
+        if (IN == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x[u] = __uint_as_float(raw[0][u]);
+                x[4 + u] = __uint_as_float(raw[NV - 1][u]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned r = raw[0][u];
+                x[2 * u] = IN == 1 ? (float)(short)(r & 0xffffu) : (float)(r & 0xffffu);
+                x[2 * u + 1] = IN == 1 ? (float)(short)(r >> 16) : (float)(r >> 16);
+            }
+        }
+        double p[8];
+        double run = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float v = live ? (sub ? x[u] - bl : x[u]) : 0.0f;  // bl_subtract.py:45, in float32
+            in_nan |= (v != v);
+            run += (double)v;
+            p[u] = run;
+        }
+        const double inc = wave_scan_add(run);
+        const double base = wave_prev(inc) + carry;  // S at the sample in front of this lane's first one
+        double before = base;
+        f4 y0, y1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double s = base + p[u];
+            const float y = (float)(s - c * before);  // pole_zero.py:69-73: the accumulator after this sample, rounded on the way out
+            out_nan |= live && (y != y);
+            if (u < 4) y0[u] = y; else y1[u - 4] = y;
+            before = s;
+        }
+        carry += readlane(inc, 63);
+        if (live) {
+            PZ_GLOBAL f4* dst = (PZ_GLOBAL f4*)(outp + at);
+            __builtin_nontemporal_store(y0, dst);
+            __builtin_nontemporal_store(y1, dst + 1);
+        }
+    };
+    for (int g = 0; g < n_groups; g += 2) {
+        u4 cur[2][NV];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) cur[k][v] = pf[k][v];
+        if (g + 2 < n_groups) fetch(pf[0], g + 2);
+        if (g + 3 < n_groups) fetch(pf[1], g + 3);
+        group(cur[0], g);
+        if (g + 1 < n_groups) group(cur[1], g + 1);
+    }
+    // ---- what the whole row decides: a NaN anywhere in the input (or a NaN baseline / time constant) makes the waveform NaN
+    // (pole_zero.py:55-58); a NaN of the recurrence's own making (inf - inf) is a DSPFatal (:76-77) -- and a NaN waveform here, like the VM's op
+    const bool bad_in = wave_any(in_nan) || A.tau_nan || (sub && bl != bl);
+    const bool bad_out = wave_any(out_nan);
+    if (bad_in || bad_out) {
+        if (!bad_in && lane == 0) pz_report(err, DSP_E_PZ_NAN, row);
+        const f4 nanv = {quiet_nan<float>(), quiet_nan<float>(), quiet_nan<float>(), quiet_nan<float>()};
+        for (int at = lane * 4; at < n; at += 256) *(PZ_GLOBAL f4*)(outp + at) = nanv;
+    }
+}
+
+}  // namespace
+
+extern "C" int dsp_internal_launch_pz_rows(const PzArgs* A, int64_t n_wf, int* err, hipStream_t stream) {
+    if (n_wf <= 0) return 0;
+    const unsigned blocks = (unsigned)((n_wf + 3) / 4);  // a wavefront per row, four to a workgroup
+    switch (A->in_kind) {
+        case 0: hipLaunchKernelGGL(dsp_pz_rows_kernel<0>, dim3(blocks), dim3(256), 0, stream, *A, n_wf, err); break;
+        case 1: hipLaunchKernelGGL(dsp_pz_rows_kernel<1>, dim3(blocks), dim3(256), 0, stream, *A, n_wf, err); break;
+        default: hipLaunchKernelGGL(dsp_pz_rows_kernel<2>, dim3(blocks), dim3(256), 0, stream, *A, n_wf, err); break;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" const char* dsp_internal_pz_rows_kernel_name() { return "dsp_pz_rows_kernel"; }

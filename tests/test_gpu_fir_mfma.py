@@ -347,7 +347,7 @@ def test_staged_filters_agree_with_the_one_program_form(monkeypatch):
     chain, staged, one = _both_ways(rec, {"waveform": wf}, monkeypatch)
     kinds = sorted(st["chain"].kernel_name for st in chain._stages)
     # (the maximum of wf_b, which nothing else reads, comes straight off its rows)
-    assert kinds == sorted([_amax_kernel(), _store_kernel(), _store_kernel(), "dsp_reduce_kernel", "dsp_vm_kernel<float>"]), kinds
+    assert kinds == sorted([_amax_kernel(), _store_kernel(), _store_kernel(), "dsp_reduce_kernel", "dsp_pz_rows_kernel"]), kinds
     assert np.array_equal(staged["bl_mean"], one["bl_mean"])
     peak = np.abs(one["wf_a"]).max(axis=1)
     assert np.max(np.abs(staged["wf_a"] - one["wf_a"]) / peak[:, None]) <= 2e-6

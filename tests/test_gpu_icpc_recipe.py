@@ -219,7 +219,7 @@ def test_index_outputs_are_bit_exact_on_the_devices_own_waveforms():
     exact(prod["A_max"], amax_x, "A_max (production)")
     exact(prod["tp_aoe_samp"], to_ns(tp0 + ta_x / F(16)), "tp_aoe_samp (production)")
     assert "dsp_current_kernel" in [st["chain"].kernel_name for st in chain_p._stages]
-    assert [k for _what, k in chain_p.kernels()] == ["dsp_fit_rows_kernel", "dsp_vm_kernel<float>", "dsp_fir_f16_kernel", "dsp_fir_f16_kernel",
+    assert [k for _what, k in chain_p.kernels()] == ["dsp_fit_rows_kernel", "dsp_pz_rows_kernel", "dsp_fir_f16_kernel", "dsp_fir_f16_kernel",
                                                      "dsp_reduce_kernel", "dsp_rows_kernel", "dsp_current_kernel", "dsp_reduce_kernel", "dsp_reduce_kernel",
                                                      "dsp_vm_kernel<float>", "dsp_scalar_kernel"]
     seen.update({"tp_aoe_max": True, "A_max": True, "tp_aoe_samp": True})

@@ -1,0 +1,77 @@
+"""[bl_subtract ->] pole_zero of whole rows written back as rows (dsp_pz.hip): the recurrence as a prefix sum in float64, walked in memory
+order by one wavefront per row.  Against the oracle (reference processors/pole_zero.py:24-77) to the filter bar, against the waveform VM's own
+scan formulation to a last place of float32, and the reference's NaN rule and DSPFatal."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+M = "dspeed.processors"
+TOL = 1e-6
+
+
+def _rows(rng, n, L, dtype):
+    i = np.arange(L)[None, :]
+    t0 = np.floor(rng.uniform(0.3, 0.6, (n, 1)) * L)
+    x = rng.uniform(800, 3000, (n, 1)) + rng.uniform(500, 15000, (n, 1)) * np.exp(-np.clip(i - t0, 0, None) / 1716.28) * (i >= t0)
+    x += 5 * rng.standard_normal((n, L))
+    return (np.rint(x) if np.dtype(dtype).kind in "iu" else x).astype(dtype)
+
+
+def _run(rec, tb, fused):
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    chain, _, out = build_processing_chain(rec, tb)
+    chain._ensure()
+    assert chain._chain.set_fused(1 if fused else 0) == bool(fused)
+    chain.execute()
+    return chain, out
+
+
+@pytest.mark.parametrize("dtype,L,use_bl", [(np.uint16, 8192, True), (np.int16, 8192, True), (np.float32, 8192, True), (np.float32, 4096, False),
+                                             (np.uint16, 1000, True), (np.float32, 8, False), (np.int16, 520, False)])
+def test_pole_zero_rows(dtype, L, use_bl):
+    rng = np.random.default_rng(L + int(use_bl))
+    n = 203
+    wf = _rows(rng, n, L, dtype)
+    bl = rng.uniform(800, 3000, n).astype(np.float32)
+    procs = {"wf_pz": f"{M}.pole_zero(wf_bl, 1716.28, wf_pz)", "wf_bl": f"{M}.bl_subtract(waveform, baseline, wf_bl)"} if use_bl else \
+        {"wf_pz": f"{M}.pole_zero(waveform, 1716.28, wf_pz)"}
+    rec = {"outputs": ["wf_pz"], "processors": procs}
+    tb = {"waveform": wf, "baseline": bl}
+    chain, out = _run(rec, tb, True)
+    assert chain._chain.kernel_name == "dsp_pz_rows_kernel"
+    x = wf.astype(np.float32)
+    if use_bl:
+        x, rc = oracle.bl_subtract(x, bl)
+        assert rc == 0
+    want, rc = oracle.pole_zero(x, 1716.28)
+    assert rc == 0
+    peak = np.abs(want).max(axis=1, keepdims=True)
+    assert out["wf_pz"].shape == want.shape and np.max(np.abs(out["wf_pz"] - want) / peak) <= TOL
+    _, vm = _run(rec, tb, False)
+    ulp = np.spacing(np.abs(vm["wf_pz"]).astype(np.float32))
+    assert np.max(np.abs(out["wf_pz"] - vm["wf_pz"]) / np.maximum(ulp, np.float32(1e-30))) <= 2  # (another order of the same float64 sums)
+    assert np.mean(out["wf_pz"] == vm["wf_pz"]) > 0.98
+
+
+def test_nan_rule_and_dspfatal():
+    from dspeed_amd.errors import DSPFatal
+
+    rng = np.random.default_rng(3)
+    wf = _rows(rng, 40, 2048, np.float32)
+    wf[3, 700] = np.nan            # a NaN anywhere: the whole waveform NaN (pole_zero.py:55-58)
+    bl = np.full(40, 1000.0, dtype=np.float32)
+    bl[5] = np.nan                 # ... also through the baseline
+    rec = {"outputs": ["wf_pz"], "processors": {"wf_bl": f"{M}.bl_subtract(waveform, baseline, wf_bl)", "wf_pz": f"{M}.pole_zero(wf_bl, 1716.28, wf_pz)"}}
+    chain, out = _run(rec, {"waveform": wf, "baseline": bl}, True)
+    assert chain._chain.kernel_name == "dsp_pz_rows_kernel"
+    assert np.isnan(out["wf_pz"][[3, 5]]).all() and not np.isnan(np.delete(out["wf_pz"], [3, 5], axis=0)).any()
+    wf2 = wf.copy()
+    wf2[3, 700] = 0.0
+    wf2[7, 100] = np.inf           # inf - inf inside the recurrence: a NaN of its own making -> DSPFatal with the row (:76-77)
+    bl[5] = 1000.0
+    with pytest.raises(DSPFatal) as e:
+        _run(rec, {"waveform": wf2, "baseline": bl}, True)
+    assert e.value.wf_range is not None and 7 in e.value.wf_range
