@@ -140,6 +140,14 @@ class Chain:
     def kernel_name(self) -> str:
         return _lib.lib().dsp_chain_kernel_name(self._h).decode()
 
+    def share_row_scales(self, consumer: "Chain") -> bool:
+        """This chain writes pole-zero corrected rows, ``consumer`` runs a float16 matrix-core FIR over them: let the rows' scales and flags
+        travel with the rows instead of being read off them again (``dsp_chain_share_row_scales``).  False: not such a pair, nothing changed."""
+        rc = _lib.lib().dsp_chain_share_row_scales(self._h, consumer._h)
+        if rc < 0:
+            _lib.check(rc, what=self.name)
+        return rc == 1
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.lib().dsp_chain_destroy(self._h)

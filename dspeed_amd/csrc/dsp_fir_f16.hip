@@ -519,8 +519,9 @@ extern "C" int dsp_internal_fir_fixup(const FirArgs* A, int64_t n_wf, hipStream_
 
 template <int IN>
 static void launch_f16(const FirArgs* A, const FirF16Taps* T, int64_t n_wf, int lds_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL(dsp_fir_f16_rows_kernel<IN>, dim3((unsigned)((n_wf + 3) / 4)), dim3(256), 0, stream, *A, (float*)T->row_scale,
-                       (unsigned*)T->row_flags, n_wf);
+    if (!T->rows_done)
+        hipLaunchKernelGGL(dsp_fir_f16_rows_kernel<IN>, dim3((unsigned)((n_wf + 3) / 4)), dim3(256), 0, stream, *A, (float*)T->row_scale,
+                           (unsigned*)T->row_flags, n_wf);
     if (A->store) {
         const dim3 grid((unsigned)((A->p[0] + BN - 1) / BN), (unsigned)((n_wf + BM - 1) / BM));
         hipLaunchKernelGGL((dsp_fir_f16_kernel<IN, true>), grid, dim3(NTHR), lds_bytes, stream, *A, *T, n_wf);

@@ -197,6 +197,13 @@ struct dsp_chain {
     bool fir_f16 = false;
     FirF16Taps f16{};  // device images of the kernels' taps (rewritten by every launch: the taps are a binding), the rows' scales and flags
     int64_t f16_rows_cap = 0;
+    // dsp_chain_share_row_scales: the pole-zero rows kernel in front writes the scales and flags of the rows it stores straight into this
+    // chain's arrays and leaves a note of which rows they describe; dsp_chain_execute checks the note against its own input
+    dsp_chain* scale_feeder = nullptr;  // (on the float16 FIR chain)
+    dsp_chain* scale_sink = nullptr;    // (on the pole-zero rows chain)
+    const void* fed_rows_ptr = nullptr;
+    int64_t fed_n_wf = -1, fed_stride = 0;
+    int32_t fed_len = 0;
     // a program of scalar ops only (dsp_scalar.hip: a row per lane)
     bool scalar_ok = false;
     // lane-per-waveform current-branch kernel (dsp_current.hip)
@@ -219,6 +226,8 @@ struct dsp_chain {
     // transfer of its own -- one issued while a large host-to-device copy of the next buffer is in flight queues up behind it
     int* err_mirror = nullptr;  // page-locked
     ~dsp_chain() {  // (also on the error paths of dsp_chain_create, which holds the chain in a unique_ptr)
+        if (scale_sink) scale_sink->scale_feeder = nullptr;
+        if (scale_feeder) scale_feeder->scale_sink = nullptr;
         if (dev) (void)hipFree(dev);
         if (dev_err) (void)hipFree(dev_err);
         if (host.prof) (void)hipFree(host.prof);
@@ -1965,6 +1974,32 @@ static int post_err(dsp_chain* ch, void* stream) {
     return DSP_OK;
 }
 
+// the rows' scales and flags of a float16 FIR chain: grown to the largest batch seen
+static int f16_rows_reserve(dsp_chain* ch, int64_t n_wf) {
+    if (ch->f16_rows_cap >= n_wf) return DSP_OK;
+    if (ch->f16.row_scale) HIP_TRY(hipFree(const_cast<void*>(ch->f16.row_scale)));
+    if (ch->f16.row_flags) HIP_TRY(hipFree(const_cast<void*>(ch->f16.row_flags)));
+    ch->f16.row_scale = ch->f16.row_flags = nullptr;
+    ch->f16_rows_cap = 0;
+    void *a = nullptr, *b = nullptr;
+    HIP_TRY(hipMalloc(&a, (size_t)n_wf * sizeof(float)));
+    ch->f16.row_scale = a;
+    HIP_TRY(hipMalloc(&b, (size_t)n_wf * sizeof(unsigned)));
+    ch->f16.row_flags = b;
+    ch->f16_rows_cap = n_wf;
+    return DSP_OK;
+}
+
+int dsp_chain_share_row_scales(dsp_chain* producer, dsp_chain* consumer) {
+    if (!producer || !consumer || producer == consumer) return fail(DSP_ERR_ARG, "dsp_chain_share_row_scales: two chains");
+    if (!producer->pz_ok || !consumer->fir_ok || !consumer->fir_f16 || consumer->fir.in_kind != 0 || consumer->fir.sub_mode != 0 ||
+        producer->device != consumer->device || producer->scale_sink || consumer->scale_feeder)
+        return 0;
+    producer->scale_sink = consumer;
+    consumer->scale_feeder = producer;
+    return 1;
+}
+
 int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* stream) {
     if (!ch || !io_ptrs) return fail(DSP_ERR_ARG, "null chain or io_ptrs");
     if (n_wf <= 0) return DSP_OK;
@@ -1990,6 +2025,18 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         A.wf = io_ptrs[ch->pio_wf];
         A.bl = (const float*)at(ch->pio_bl);
         A.out = at(ch->pio_out);
+        A.row_scale = nullptr;
+        A.row_flags = nullptr;
+        if (dsp_chain* sink = ch->scale_sink) {
+            const int rc = f16_rows_reserve(sink, n_wf);
+            if (rc != DSP_OK) return rc;
+            A.row_scale = (float*)const_cast<void*>(sink->f16.row_scale);
+            A.row_flags = (uint32_t*)const_cast<void*>(sink->f16.row_flags);
+            sink->fed_rows_ptr = A.out;
+            sink->fed_n_wf = n_wf;
+            sink->fed_stride = A.out_stride;
+            sink->fed_len = A.len;
+        }
         hipError_t e = (hipError_t)dsp_internal_launch_pz_rows(&A, n_wf, ch->dev_err, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "pole-zero rows kernel launch failed: %s", hipGetErrorString(e));
         return post_err(ch, stream);
@@ -2036,17 +2083,14 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
             A.taps[k] = (const float*)at(ch->fio_taps[k]);
             A.out[k] = at(ch->fio_out[k]);
         }
-        if (ch->fir_f16 && ch->f16_rows_cap < n_wf) {  // the rows' scales and flags: grown to the largest batch seen
-            if (ch->f16.row_scale) HIP_TRY(hipFree(const_cast<void*>(ch->f16.row_scale)));
-            if (ch->f16.row_flags) HIP_TRY(hipFree(const_cast<void*>(ch->f16.row_flags)));
-            ch->f16.row_scale = ch->f16.row_flags = nullptr;
-            ch->f16_rows_cap = 0;
-            void *a = nullptr, *b = nullptr;
-            HIP_TRY(hipMalloc(&a, (size_t)n_wf * sizeof(float)));
-            ch->f16.row_scale = a;
-            HIP_TRY(hipMalloc(&b, (size_t)n_wf * sizeof(unsigned)));
-            ch->f16.row_flags = b;
-            ch->f16_rows_cap = n_wf;
+        if (ch->fir_f16) {
+            const int rc = f16_rows_reserve(ch, n_wf);
+            if (rc != DSP_OK) return rc;
+            // scales and flags already there?  Only if the kernel in front wrote exactly the rows this one reads, and just now
+            const void* first = (const char*)A.wf + (size_t)A.wf_offset * sizeof(float);
+            ch->f16.rows_done = (ch->scale_feeder && A.in_kind == 0 && A.sub_mode == 0 && ch->fed_rows_ptr == first && ch->fed_n_wf == n_wf &&
+                                 ch->fed_stride == A.wf_stride && ch->fed_len == A.n) ? 1 : 0;
+            ch->fed_n_wf = -1;  // (a note is good for one execute)
         }
         hipError_t e = (hipError_t)(ch->fir_f16 ? dsp_internal_launch_fir_f16(&A, &ch->f16, n_wf, dsp_internal_fir_f16_lds_bytes(), (hipStream_t)stream)
                                     : A.store   ? dsp_internal_launch_fir_store(&A, n_wf, ch->fir_lds_bytes, (hipStream_t)stream)

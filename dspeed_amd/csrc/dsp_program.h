@@ -166,6 +166,8 @@ struct PzArgs {
     double c;                // exp(-1/tau)
     void* out;               // float32 rows
     int64_t out_stride;
+    float* row_scale;        // or null: what dsp_fir_f16_rows_kernel would find on the rows written here (FirF16Taps), for a float16 FIR behind
+    uint32_t* row_flags;
 };
 
 // arguments of the streaming reductions (dsp_reduce.hip), filled by dsp_chain_execute when a program has the shape
@@ -222,5 +224,7 @@ struct FirF16Taps {
     int32_t tz;
     const void* row_scale;  // float per row: the power of two that brings the row's largest magnitude into [2^14, 2^15)
     const void* row_flags;  // uint32 per row: bit 0 an infinity, bit 1 a NaN
+    int32_t rows_done;      // the kernel that wrote the rows left both already (dsp_pz.hip): no pass over the rows for them
+    int32_t pad_;
 };
 

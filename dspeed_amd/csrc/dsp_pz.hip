@@ -46,19 +46,23 @@ __global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_w
     const double c = A.c;
     const int n_groups = (n + 511) / 512;
 
-    u4 pf[2][NV];
+    // two register sets of two groups each, filled in turn: group g + 4 is asked for while g .. g + 3 are worked on, and no set is ever copied
+    // (a copy of a set would have to wait for its loads the moment it is made)
+    u4 ra[2][NV], rb[2][NV];
     auto fetch = [&](u4 (&dst)[NV], int g) {
         int at = g * 512 + lane * 8;
-        at = at < n ? at : 0;  // (a lane beyond the row's end asks for something inside it and ignores it)
+        at = at < n ? at : 0;  // (a lane beyond the row's end asks for something inside it and ignores it: no branch around a load, which
+                               //  would cost a wait for everything in flight where it joins)
         const PZ_GLOBAL u4* src = (const PZ_GLOBAL u4*)(rowp + (size_t)at * ESZ);
 #pragma unroll
         for (int v = 0; v < NV; ++v) dst[v] = __builtin_nontemporal_load(src + v);
     };
-    fetch(pf[0], 0);
-    if (n_groups > 1) fetch(pf[1], 1);
+    fetch(ra[0], 0);
+    fetch(ra[1], 1);
 
     double carry = 0.0;  // S at the end of the previous group
     bool in_nan = false, out_nan = false;
+    float mx = 0.0f;  // largest |sample written| (a NaN never raises it): the scale of a float16 FIR behind (A.row_scale)
     auto group = [&](const u4 (&raw)[NV], int g) {
         const int at = g * 512 + lane * 8;
         const bool live = at < n;  // (n is a multiple of 8: a lane's vector lies inside the row whole or not at all)
@@ -82,7 +86,7 @@ __global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_w
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const float v = live ? (sub ? x[u] - bl : x[u]) : 0.0f;  // bl_subtract.py:45, in float32
-            in_nan |= (v != v);
+            if (IN == 0) in_nan |= (v != v);                          // (integer samples: only the baseline can be a NaN, looked at below)
             run += (double)v;
             p[u] = run;
         }
@@ -94,10 +98,14 @@ __global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_w
         for (int u = 0; u < 8; ++u) {
             const double s = base + p[u];
             const float y = (float)(s - c * before);  // pole_zero.py:69-73: the accumulator after this sample, rounded on the way out
-            out_nan |= live && (y != y);
             if (u < 4) y0[u] = y; else y1[u - 4] = y;
+            const float a = __builtin_fabsf(y);
+            mx = (live && a > mx) ? a : mx;
             before = s;
         }
+        // a NaN of the recurrence stays: S is NaN or infinite from there on and every later S - c S' is NaN again -- so the last sample
+        // of every lane's eight tells (the row's last sample is one of them)
+        out_nan |= live && (y1[3] != y1[3]);
         carry += readlane(inc, 63);
         if (live) {
             PZ_GLOBAL f4* dst = (PZ_GLOBAL f4*)(outp + at);
@@ -105,16 +113,17 @@ __global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_w
             __builtin_nontemporal_store(y1, dst + 1);
         }
     };
-    for (int g = 0; g < n_groups; g += 2) {
-        u4 cur[2][NV];
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int v = 0; v < NV; ++v) cur[k][v] = pf[k][v];
-        if (g + 2 < n_groups) fetch(pf[0], g + 2);
-        if (g + 3 < n_groups) fetch(pf[1], g + 3);
-        group(cur[0], g);
-        if (g + 1 < n_groups) group(cur[1], g + 1);
+    for (int g = 0; g < n_groups; g += 4) {
+        fetch(rb[0], g + 2);
+        fetch(rb[1], g + 3);
+        group(ra[0], g);
+        group(ra[1], g + 1);  // (beyond the last group: no live lane, sums of zeros)
+        fetch(ra[0], g + 4);
+        fetch(ra[1], g + 5);
+        if (g + 2 < n_groups) {  // (uniform; no load inside)
+            group(rb[0], g + 2);
+            group(rb[1], g + 3);
+        }
     }
     // ---- what the whole row decides: a NaN anywhere in the input (or a NaN baseline / time constant) makes the waveform NaN
     // (pole_zero.py:55-58); a NaN of the recurrence's own making (inf - inf) is a DSPFatal (:76-77) -- and a NaN waveform here, like the VM's op
@@ -124,6 +133,19 @@ __global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_w
         if (!bad_in && lane == 0) pz_report(err, DSP_E_PZ_NAN, row);
         const f4 nanv = {quiet_nan<float>(), quiet_nan<float>(), quiet_nan<float>(), quiet_nan<float>()};
         for (int at = lane * 4; at < n; at += 256) *(PZ_GLOBAL f4*)(outp + at) = nanv;
+    }
+    if (A.row_scale) {  // (uniform) exactly what dsp_fir_f16_rows_kernel leaves for these rows: same samples, same rule
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) mx = fmaxf(mx, __shfl_xor(mx, sft));
+        const bool all_nan = bad_in || bad_out;
+        if (all_nan) mx = 0.0f;
+        int e = (int)((__float_as_uint(mx) >> 23) & 0xffu) - 127;
+        const bool extreme = !(mx <= 3.4028234663852886e38f) || (mx > 0.0f && (e < -100 || e > 100));
+        if (!(mx > 0.0f) || extreme) e = 14;
+        if (lane == 0) {
+            A.row_scale[row] = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+            A.row_flags[row] = (extreme ? 1u : 0u) | (all_nan ? 2u : 0u);
+        }
     }
 }
 

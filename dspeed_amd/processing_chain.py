@@ -322,6 +322,18 @@ class ProcessingChain:
             self._lanes = [SimpleNamespace(stream=self._stream, chain=self._chain, stage_chains=[st["chain"] for st in self._stages],
                                            stage_bufs=[st["bufs"] for st in self._stages], aux_bufs=self._aux_bufs, tail=self._tail_chain(0),
                                            tail_bufs={})]
+            self._pair_stages(self._lanes[0].stage_chains)
+
+    def _pair_stages(self, stage_chains) -> None:
+        """a stage that writes pole-zero rows and a float16 FIR stage that reads them: the rows' scales travel with the rows (the C side
+        takes the pair only if the two kernels are of those kinds, and checks at every execute that the rows are the same)"""
+        if os.environ.get("DSPEED_HIP_NO_SHARED_ROW_SCALES", "0") == "1":
+            return
+        for i, st in enumerate(self._stages):
+            made = {key for _o, key, _l in st["outs"]}
+            for j in range(i + 1, len(self._stages)):
+                if made & set(self._stages[j]["alias"].values()):
+                    stage_chains[i].share_row_scales(stage_chains[j])
 
     def _tail_chain(self, lane_no: int):
         if self._tail is None:
@@ -357,6 +369,7 @@ class ProcessingChain:
                 c = Chain(st["program"], f"processing_chain stage {j} ({st['what']}, lane {len(self._lanes)})", self.loop_dtype)
                 c.set_async_check(True)
                 stage_chains.append(c)
+            self._pair_stages(stage_chains)
             self._lanes.append(SimpleNamespace(stream=Stream(), chain=ch, stage_chains=stage_chains, stage_bufs=[{} for _ in self._stages],
                                                aux_bufs={}, tail=self._tail_chain(len(self._lanes)), tail_bufs={}))
         return self._lanes[k]

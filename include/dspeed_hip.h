@@ -280,6 +280,14 @@ int dsp_chain_profile_read(dsp_chain* chain, int capacity, int32_t* opcodes, int
                            uint64_t* n_waveforms);
 /* name of the device kernel the chain launches (what rocprofv3 --kernel-trace lists) */
 const char* dsp_chain_kernel_name(dsp_chain* chain);
+/* Two chains of one recipe, run one behind the other on the same rows: `producer` writes pole-zero corrected rows ([bl_subtract ->] pole_zero
+ * -> rows, the dsp_pz_rows_kernel shape), `consumer` is a float16 matrix-core FIR over float32 rows.  After this call the producer leaves,
+ * with the rows, the per-row scale and flags the FIR would otherwise read every row once more to find; dsp_chain_execute of the consumer uses
+ * them when its input is exactly what the producer's last execute wrote (address, stride, length, row count) and finds them itself otherwise.
+ * Returns 1 when the pair was linked, 0 when the chains are not of these shapes (nothing changes), < 0 on an argument error.  The link ends
+ * with either chain's dsp_chain_destroy.  No counterpart in the reference (its processors exchange nothing but their arrays,
+ * processing_chain.py:1144-1163); results are the same with and without it. */
+int dsp_chain_share_row_scales(dsp_chain* producer, dsp_chain* consumer);
 /* A chain of the shape LOAD [-> BL_SUBTRACT] -> POLE_ZERO -> TRAP_PICKOFF -> STORE_SCALAR (the Ge energy chain) runs on a
  * specialised kernel with the same per-sample arithmetic (dsp_energy.hip).  enable = 0 forces the generic interpreter (parity
  * tests); 1 = default specialised kernel (one chain per lane); 3 = 2 interleaved sub-chains per lane on a pad-free LDS image;

@@ -75,3 +75,46 @@ def test_nan_rule_and_dspfatal():
     with pytest.raises(DSPFatal) as e:
         _run(rec, {"waveform": wf2, "baseline": bl}, True)
     assert e.value.wf_range is not None and 7 in e.value.wf_range
+
+
+def test_row_scales_travel_with_the_rows(monkeypatch):
+    """a float16 FIR behind the pole-zero rows takes the rows' scales and flags from the kernel that wrote them (dsp_chain_share_row_scales):
+    bit for bit what it finds when it reads the rows itself -- ordinary rows, an all-NaN row, all-zero rows, tiny and huge ones"""
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    rng = np.random.default_rng(11)
+    n, L = 300, 4096
+    wf = _rows(rng, n, L, np.float32)
+    wf[4, 100] = np.nan
+    wf[9] = 0.0
+    wf[10] *= np.float32(1e-30)
+    wf[11] *= np.float32(1e30)
+    wf[12] *= np.float32(1e34)     # (the scale's exponent beyond +-100: the FIR's slow path)
+    bl = np.zeros(n, dtype=np.float32)
+    rec = {"outputs": ["wf_f", "f_max"], "processors": {
+        "wf_pz": f"{M}.pole_zero(waveform, 1716.28, wf_pz)",
+        "kern": {"function": "t0_filter", "module": M, "args": ["8", "125", "kern(133, 'f')"]},
+        "wf_f": {"function": "convolve_wf", "module": M, "args": ["wf_pz", "kern", "'s'", "wf_f(4096, 'f')"]},
+        "f_max": "numpy.amax(wf_f, 1, f_max)"}}
+
+    def run(shared):
+        monkeypatch.setenv("DSPEED_HIP_NO_SHARED_ROW_SCALES", "0" if shared else "1")
+        chain, _, out = build_processing_chain(rec, {"waveform": wf, "baseline": bl})
+        chain.execute()
+        kinds = [k for _w, k in chain.kernels()]
+        assert "dsp_pz_rows_kernel" in kinds and "dsp_fir_f16_kernel" in kinds, kinds
+        return {k: np.array(v) for k, v in out.items()}
+
+    a, b = run(True), run(False)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert np.isnan(a["wf_f"][4]).all() and not np.isnan(a["wf_f"][[0, 9, 10, 11]]).any()
+    import dspeed_amd.processors as P
+
+    kern = np.zeros(133, dtype=np.float32)
+    P.t0_filter(8, 125, kern)
+    want = oracle.convolve_wf(oracle.pole_zero(np.delete(wf, [4, 12], axis=0), 1716.28)[0], kern, "s", 4096)[0]
+    got = np.delete(a["wf_f"], [4, 12], axis=0)
+    peak = np.abs(want).max(axis=1, keepdims=True)
+    ok = peak[:, 0] > 1e-38
+    assert np.max(np.abs(got - want)[ok] / peak[ok]) <= 2e-6
