@@ -55,7 +55,11 @@ __global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_w
                                //  would cost a wait for everything in flight where it joins)
         const PZ_GLOBAL u4* src = (const PZ_GLOBAL u4*)(rowp + (size_t)at * ESZ);
 #pragma unroll
+#if defined(PZ_DIAG_PLAIN_LOAD)
+        for (int v = 0; v < NV; ++v) dst[v] = src[v];
+#else
         for (int v = 0; v < NV; ++v) dst[v] = __builtin_nontemporal_load(src + v);
+#endif
     };
     fetch(ra[0], 0);
     fetch(ra[1], 1);
@@ -107,10 +111,10 @@ __global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_w
         // of every lane's eight tells (the row's last sample is one of them)
         out_nan |= live && (y1[3] != y1[3]);
         carry += readlane(inc, 63);
-        if (live) {
+        if (live) {  // plain stores: measured 1.18 ms per 131 072 rows of 8192 against 1.66 with non-temporal ones (0.49 with none)
             PZ_GLOBAL f4* dst = (PZ_GLOBAL f4*)(outp + at);
-            __builtin_nontemporal_store(y0, dst);
-            __builtin_nontemporal_store(y1, dst + 1);
+            dst[0] = y0;
+            dst[1] = y1;
         }
     };
     for (int g = 0; g < n_groups; g += 4) {
