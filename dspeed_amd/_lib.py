@@ -155,6 +155,8 @@ def lib():
     L.dsp_fatal_message.argtypes = [C.c_int]
     L.dsp_chain_kernel_name.restype = C.c_char_p
     L.dsp_chain_kernel_name.argtypes = [vp]
+    L.dsp_chain_kernel_note.restype = C.c_char_p
+    L.dsp_chain_kernel_note.argtypes = [vp]
     L.dsp_chain_share_row_scales.restype = C.c_int
     L.dsp_chain_share_row_scales.argtypes = [vp, vp]
     _lib = L
@@ -166,7 +168,7 @@ EXPORTS = [
     "dsp_host_free", "dsp_memset", "dsp_h2d", "dsp_d2h", "dsp_h2d_async", "dsp_d2h_async", "dsp_stream_create", "dsp_stream_destroy",
     "dsp_stream_sync", "dsp_sync", "dsp_event_create", "dsp_event_destroy", "dsp_event_record", "dsp_event_sync",
     "dsp_event_elapsed_ms", "dsp_last_error", "dsp_fatal_message", "dsp_version", "dsp_chain_create", "dsp_chain_execute",
-    "dsp_chain_check", "dsp_chain_destroy", "dsp_chain_geometry", "dsp_chain_kernel_name", "dsp_chain_share_row_scales", "dsp_chain_set_fused", "dsp_chain_set_async_check", "dsp_bl_subtract_f32", "dsp_pole_zero_f32",
+    "dsp_chain_check", "dsp_chain_destroy", "dsp_chain_geometry", "dsp_chain_kernel_name", "dsp_chain_kernel_note", "dsp_chain_share_row_scales", "dsp_chain_set_fused", "dsp_chain_set_async_check", "dsp_bl_subtract_f32", "dsp_pole_zero_f32",
     "dsp_double_pole_zero_f32", "dsp_pole_zero_col_f32", "dsp_double_pole_zero_col_f32", "dsp_pole_zero_col_f64", "dsp_double_pole_zero_col_f64", "dsp_trap_filter_f32", "dsp_trap_norm_f32", "dsp_asym_trap_filter_f32", "dsp_fixed_time_pickoff_f32",
     "dsp_install_abort_trace", "dsp_uninstall_abort_trace", "dsp_chain_profile", "dsp_chain_profile_read", "dsp_min_max_norm_f32", "dsp_min_max_norm_f64", "dsp_time_point_thresh_f32", "dsp_interpolated_time_point_thresh_f32", "dsp_interpolated_time_point_thresh_f64", "dsp_min_max_f32", "dsp_mean_below_threshold_f32", "dsp_mean_below_threshold_f64", "dsp_windower_f32", "dsp_windower_f64", "dsp_avg_current_f32",
     "dsp_avg_current_f64", "dsp_trap_pickoff_f32", "dsp_trap_pickoff_f64", "dsp_upsampler_f32", "dsp_upsampler_f64",

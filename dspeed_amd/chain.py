@@ -140,6 +140,11 @@ class Chain:
     def kernel_name(self) -> str:
         return _lib.lib().dsp_chain_kernel_name(self._h).decode()
 
+    @property
+    def kernel_note(self) -> str:
+        """"" or why this chain runs on the generic interpreter although its ops are those of a specialised kernel"""
+        return _lib.lib().dsp_chain_kernel_note(self._h).decode()
+
     def share_row_scales(self, consumer: "Chain") -> bool:
         """This chain writes pole-zero corrected rows, ``consumer`` runs a float16 matrix-core FIR over them: let the rows' scales and flags
         travel with the rows instead of being read off them again (``dsp_chain_share_row_scales``).  False: not such a pair, nothing changed."""

@@ -199,6 +199,8 @@ struct dsp_chain {
     int64_t f16_rows_cap = 0;
     // dsp_chain_share_row_scales: the pole-zero rows kernel in front writes the scales and flags of the rows it stores straight into this
     // chain's arrays and leaves a note of which rows they describe; dsp_chain_execute checks the note against its own input
+    // why a program that all but has the shape of a specialised kernel runs on the interpreter instead (dsp_chain_kernel_note)
+    std::string note;
     dsp_chain* scale_feeder = nullptr;  // (on the float16 FIR chain)
     dsp_chain* scale_sink = nullptr;    // (on the pole-zero rows chain)
     const void* fed_rows_ptr = nullptr;
@@ -242,6 +244,16 @@ struct dsp_chain {
 
 // ip[0] of ELEMENTWISE / SCALAR_FUNC: a DSP_FN_* code; the integer loops carry their type (8, 16 or 32 bits; 32 only in the float64 chain,
 // whose values hold every 32-bit integer), the float ones nothing
+static void note(dsp_chain* ch, const char* fmt, ...) {
+    if (!ch->note.empty()) return;  // (the first reason stands)
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    ch->note = buf;
+}
+
 static bool fn_code_ok(int ip0, bool f64) {
     const int code = DSP_FN_CODE(ip0), bits = DSP_FN_INT_BITS(ip0);
     if (ip0 < 0 || code > DSP_FN_LAST || (ip0 >> 17) != 0) return false;
@@ -491,7 +503,11 @@ static bool match_fir_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const d
         const dsp_op& o = ops[i];
         if (nk == DSP_FIR_MAXK || o.src != s || o.ip[0] != 'v' || o.ip[1] != 0 || io[o.io].dtype != DSP_F32) return false;
         const int m = o.ip[3] > 0 ? o.ip[3] : io[o.io].len, p = n - m + 1;
-        if (m < 64 || p < 1 || p > 320 || o.ip[2] != p) return false;  // (a short kernel is the VM's business)
+        if (m < 64 || p < 1 || p > 320 || o.ip[2] != p) {  // (a short kernel is the VM's business)
+            if (m < 64) note(ch, "a %d-tap 'valid' convolution and its maximum: the matrix-core FIR takes kernels of 64 taps and more", m);
+            else if (p > 320) note(ch, "'valid' convolution with %d outputs and their maximum: the matrix-core FIR with a maximum takes up to 320", p);
+            return false;
+        }
         ch->fio_taps[nk] = o.io;
         A.m[nk] = m;
         A.p[nk] = p;
@@ -559,7 +575,10 @@ static bool match_fir_store_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, c
     const dsp_op& st = ops[i + 1];
     if (o.src != s || o.dst == s || o.ip[1] != 0 || io[o.io].dtype != DSP_F32 || st.src != o.dst || io[st.io].dtype != DSP_F32) return false;
     const int m = o.ip[3] > 0 ? o.ip[3] : io[o.io].len;
-    if (m < 64 || m > n) return false;
+    if (m < 64 || m > n) {
+        if (m < 64) note(ch, "a %d-tap convolution: the matrix-core FIR takes kernels of 64 taps and more", m);
+        return false;
+    }
     const int mode = o.ip[0];
     const int P = mode == 'v' ? n - m + 1 : (mode == 's' ? n : (mode == 'f' ? n + m - 1 : -1));
     if (P < 1 || slot_len[o.dst] != P || io[st.io].len != P) return false;
@@ -596,7 +615,7 @@ static bool match_rows_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const 
     const int s = ld.dst;
     const int wdt = io[ld.io].dtype, len = slot_len[s];
     if (ld.ip[0] != 0 || ld.ip[1] != 0) return false;
-    if ((wdt != DSP_F32 && wdt != DSP_I16 && wdt != DSP_U16) || !P.io[ld.io].vec_ok || len % 8 != 0 || len < 16) return false;
+    const bool row_layout = (wdt == DSP_F32 || wdt == DSP_I16 || wdt == DSP_U16) && P.io[ld.io].vec_ok && len % 8 == 0 && len >= 16;
     auto f32_or_const = [&](const dsp_scalar_arg& a) { return a.kind == DSP_ARG_CONST || (a.kind == DSP_ARG_INPUT && io[a.index].dtype == DSP_F32); };
     const dsp_op* bs = nullptr;
     if (ops[i].opcode == DSP_OP_BL_SUBTRACT) {
@@ -612,7 +631,10 @@ static bool match_rows_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const 
         ++i;
         if (pz.dst != s || pz.src != s) return false;
         for (int k = 0; k < (pz.opcode == DSP_OP_POLE_ZERO ? 1 : 3); ++k)
-            if (pz.sp[k].kind != DSP_ARG_CONST) return false;  // (per-event time constants: the VM's ops form the coefficients per row)
+            if (pz.sp[k].kind != DSP_ARG_CONST) {  // (per-event time constants: the VM's ops form the coefficients per row)
+                note(ch, "a pole-zero time constant per event: the lane-per-waveform rows kernel takes constants");
+                return false;
+            }
     }
     const dsp_op *tr = nullptr, *dw = nullptr, *st_wf = nullptr;
     int tr_at = -1;
@@ -635,6 +657,10 @@ static bool match_rows_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const 
     if (!tr || (dw != nullptr) != (st_wf != nullptr)) return false;
     if (tr->ip[3] >> 8) return false;  // (a pick-off or the amax-only form of the reduction: the VM's)
     if (dw && (st_wf->src != dw->dst || io[st_wf->io].dtype != DSP_F32)) return false;
+    if (!row_layout) {
+        note(ch, "rows of %d samples: the lane-per-waveform rows kernel takes float32 / int16 / uint16 rows of a multiple of 8 samples (16 and more) that start on 16-byte boundaries", len);
+        return false;
+    }
     const DevOp& dtr = P.ops[dev_index[tr_at]];
     RowsArgs& A = ch->rows;
     memset(&A, 0, sizeof A);
@@ -669,7 +695,10 @@ static bool match_rows_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, const 
     int maxlag = 0;
     for (int k = 0; k < 3; ++k) {
         A.lag[k] = dtr.ic[k];
-        if (A.lag[k] < 8) return false;
+        if (A.lag[k] < 8) {
+            note(ch, "a trapezoid with a rise or flat top of %d samples: the lane-per-waveform rows kernel takes 8 and more", A.lag[k]);
+            return false;
+        }
         if (A.lag[k] > maxlag) maxlag = A.lag[k];
     }
     const int R = ((maxlag + 8 + 7) / 8) * 8;  // R > largest lag + 7, a whole number of blocks
@@ -1589,6 +1618,13 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
                            pz->sp[0].kind == DSP_ARG_CONST &&
                            tp->src == 0 && tp->sp[0].kind != DSP_ARG_REG && st->ip[0] == tp->dst &&
                            (slot_len[0] == 1024 || slot_len[0] == 2048 || slot_len[0] == 4096 || slot_len[0] == 8192);
+        if (!shape && st && i == n_ops && n_slots == 1) {  // the ops of the energy chain, but not the kernels' case of it
+            if (f64) note(ch.get(), "the energy chain in a float64 loop: the fused energy kernels are float32");
+            else if (pz->sp[0].kind != DSP_ARG_CONST) note(ch.get(), "a pole-zero time constant per event: the fused energy kernels take a constant");
+            else if (!(slot_len[0] == 1024 || slot_len[0] == 2048 || slot_len[0] == 4096 || slot_len[0] == 8192))
+                note(ch.get(), "waveforms of %d samples: the fused energy kernels take 1024, 2048, 4096 or 8192", slot_len[0]);
+            else if (!P.io[ld->io].vec_ok) note(ch.get(), "rows that do not start on 16-byte boundaries: the fused energy kernels read 16 bytes per lane");
+        }
         auto f32_col = [&](const dsp_scalar_arg& a) { return a.kind != DSP_ARG_INPUT || io[a.index].dtype == DSP_F32; };
         if (shape && (!bs || f32_col(bs->sp[0])) && f32_col(tp->sp[0]) && io[st->io].dtype == DSP_F32) {  // (the kernels store a float)
             EnergyArgs& F = ch->fused;
@@ -2279,6 +2315,12 @@ const char* dsp_chain_kernel_name(dsp_chain* ch) {
     if (ch && ch->rows_ok && ch->fused_on) return dsp_internal_rows_kernel_name();
     if (ch && ch->rr_ok && ch->fused_on && ch->variant != 1) return dsp_internal_energy_rr_kernel_name();
     return (ch && ch->fused_ok && ch->fused_on) ? dsp_internal_energy_kernel_name() : dsp_internal_vm_kernel_name();
+}
+
+const char* dsp_chain_kernel_note(dsp_chain* ch) {
+    if (!ch) return "";
+    const bool specialised = ch->fused_on && (ch->scalar_ok || ch->pz_ok || ch->red_ok || ch->cur_ok || ch->fir_ok || ch->rows_ok || ch->rr_ok || ch->fused_ok);
+    return specialised ? "" : ch->note.c_str();
 }
 
 int dsp_chain_set_async_check(dsp_chain* ch, int enable) {

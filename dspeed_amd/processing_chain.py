@@ -35,6 +35,7 @@ import threading
 import time
 from collections.abc import MutableMapping
 import math
+import logging
 import os
 from copy import deepcopy
 from types import SimpleNamespace
@@ -46,6 +47,8 @@ from .chain import Chain, Program, Scalar
 from .device import DeviceArray, Event, HostPin, PinnedArray, Stream, dtype_code, set_device
 from .errors import DSPFatal, ProcessingChainError
 from .recipe import LANGUAGE_CALLS as _CALLS, Recipe
+
+log = logging.getLogger("dspeed")  # (the reference's logger name: processing_chain.py:33)
 
 _UNITS_NS = {"ns": 1.0, "us": 1e3, "ms": 1e6, "s": 1e9}
 
@@ -295,6 +298,14 @@ class ProcessingChain:
             rep.append(("scalar tail of the program", self._lanes[0].tail.kernel_name))
         return rep
 
+    def kernel_notes(self) -> list:
+        """[(what, reason)] for every stage / program that runs on the generic interpreter although its ops are those of a specialised kernel
+        (``dsp_chain_kernel_note``): a time constant per event, a length or alignment the kernel does not take, a kernel of fewer than 64 taps.
+        Logged as a warning when the chain is first set up -- such a chain is correct and 2 - 4 x slower than its neighbour."""
+        self._ensure()
+        chains = [(st["what"], st["chain"]) for st in self._stages] + [("program", self._chain)]
+        return [(what, ch.kernel_note) for what, ch in chains if ch.kernel_note]
+
     def __str__(self):
         return "Input variables: " + str(list(self._in_vars)) + "\nProcessors:\n  " + "\n  ".join(self.proc_strings)
 
@@ -323,6 +334,9 @@ class ProcessingChain:
                                            stage_bufs=[st["bufs"] for st in self._stages], aux_bufs=self._aux_bufs, tail=self._tail_chain(0),
                                            tail_bufs={})]
             self._pair_stages(self._lanes[0].stage_chains)
+            for what, ch in [(st["what"], st["chain"]) for st in self._stages] + [("program", self._chain)]:
+                if ch.kernel_note:
+                    log.warning("%s runs on the generic interpreter (%s): %s", what, ch.kernel_name, ch.kernel_note)
 
     def _pair_stages(self, stage_chains) -> None:
         """a stage that writes pole-zero rows and a float16 FIR stage that reads them: the rows' scales travel with the rows (the C side

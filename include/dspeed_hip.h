@@ -280,6 +280,10 @@ int dsp_chain_profile_read(dsp_chain* chain, int capacity, int32_t* opcodes, int
                            uint64_t* n_waveforms);
 /* name of the device kernel the chain launches (what rocprofv3 --kernel-trace lists) */
 const char* dsp_chain_kernel_name(dsp_chain* chain);
+/* "" or, for a chain that runs on the generic interpreter although its ops are those of a specialised kernel, the reason in a sentence (a time
+ * constant per event, a length or an alignment the kernel does not take, a kernel of fewer than 64 taps ...): what a recipe's author needs to
+ * see to know why a chain is 2 - 4 x slower than its neighbour.  The string lives as long as the chain. */
+const char* dsp_chain_kernel_note(dsp_chain* chain);
 /* Two chains of one recipe, run one behind the other on the same rows: `producer` writes pole-zero corrected rows ([bl_subtract ->] pole_zero
  * -> rows, the dsp_pz_rows_kernel shape), `consumer` is a float16 matrix-core FIR over float32 rows.  After this call the producer leaves,
  * with the rows, the per-row scale and flags the FIR would otherwise read every row once more to find; dsp_chain_execute of the consumer uses

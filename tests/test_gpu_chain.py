@@ -1,4 +1,6 @@
 """GPU parity of the fused chains (one launch, intermediates in LDS) against the golden chain fixtures and the oracle."""
+import json
+
 import numpy as np
 import pytest
 
@@ -196,3 +198,44 @@ def test_data_dependent_fatal_reports_row():
             _run_energy(wf, bl, tp, 100.0, 16, 8, "i", fused=fused)
         assert ei.value.wf_range == range(6, 7)
         assert "integer t_in" in str(ei.value)
+
+
+def test_a_chain_that_misses_a_specialised_kernel_says_why(caplog):
+    """dsp_chain_kernel_note: the energy chain with a time constant per event, on 3000-sample rows, with a short trapezoid; a 40-tap FIR -- each
+    runs on the interpreter (same results as ever) and the chain says why, in the log of the recipe's author"""
+    import logging
+
+    import recipes
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    rng = np.random.default_rng(5)
+    n = 64
+    M = "dspeed.processors"
+
+    def notes(rec, tb):
+        with caplog.at_level(logging.WARNING, logger="dspeed"):
+            caplog.clear()
+            chain, _, out = build_processing_chain(rec, tb)
+            chain.execute()
+        return chain, [r.getMessage() for r in caplog.records]
+
+    wf = (1000 + 50 * rng.standard_normal((n, 4096))).astype(np.float32)
+    tb = {"waveform": wf, "baseline": np.full(n, 1000, np.float32), "t_pick": np.full(n, 3000, np.float32)}
+    chain, msgs = notes(recipes.C2, tb)
+    assert chain.kernel_notes() == [] and msgs == [] and chain._chain.kernel_name == "dsp_energy_rr_kernel"
+    # a time constant per event
+    rec_tau = json.loads(json.dumps(recipes.C2))
+    rec_tau["processors"]["wf_pz"] = "dspeed.processors.pole_zero(wf_blsub, tau, wf_pz)"
+    chain, msgs = notes(rec_tau, dict(tb, tau=np.full(n, 1716.28, np.float32)))
+    assert chain._chain.kernel_name.startswith("dsp_vm_kernel")
+    assert len(chain.kernel_notes()) == 1 and "time constant per event" in chain.kernel_notes()[0][1] and any("time constant per event" in m for m in msgs)
+    # 3000-sample rows
+    tb3 = {"waveform": wf[:, :3000].copy(), "baseline": tb["baseline"], "t_pick": np.full(n, 2000, np.float32)}
+    chain, msgs = notes(recipes.C2, tb3)
+    assert chain._chain.kernel_name.startswith("dsp_vm_kernel") and "3000 samples" in chain.kernel_notes()[0][1] and len(msgs) == 1
+    # a 40-tap FIR kept as a waveform
+    rec_f = {"outputs": ["wf_f"], "processors": {
+             "kern": {"function": "t0_filter", "module": M, "args": [8, 32, "kern(40, 'f')"]},
+             "wf_f": {"function": "convolve_wf", "module": M, "args": ["waveform", "kern", "'s'", "wf_f(4096, 'f')"]}}}
+    chain, msgs = notes(rec_f, {"waveform": wf})
+    assert any("40-tap" in note for _w, note in chain.kernel_notes()), (chain.kernels(), chain.kernel_notes())
