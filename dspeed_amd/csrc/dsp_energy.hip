@@ -44,6 +44,8 @@ struct EnergyArgs {
     int32_t q[3], rho[3];  // lag = q*C + rho
     int32_t lds_elems_per_wave;
     int32_t slot_off;      // element offset of the slot inside the wave's region (2*pitch guard below it)
+    const float* tau;      // or null: the pole-zero time constant per event (a column) instead of c / tau_nan -- the TAU builds of the register-resident kernel
+    int64_t tau_stride;
     int32_t ablate;        // diagnostic build only (-DDSPEED_HIP_DIAG, libdspeed_hip_diag.so): bit 0/1/2 = skip pass 1/2/3 (results are then
                            // wrong), bit 3 = per-phase cycle stamps.  The product library ignores the field: ABLATE below is a constant 0.
 };
@@ -378,7 +380,11 @@ struct EnergyPlan {
 // ------------------------------------------------------------------------------------------------
 // IN: waveform element type in HBM: 0 float32, 1 int16, 2 uint16 (digitiser samples; widened to float32 while staging, exactly
 // like the reference's ufunc casting picks the float32 loop for them, processing_chain.py:1565-1572)
-template <int NPF, int KIND, int S, int IN>
+// exp(-1 / tau) in float64 for a time constant that varies per event, as the interpreter's op forms it (dsp_vm.hip pz_decay; pole_zero.py:60):
+// out of line, the device's exp is 200 instructions
+__device__ __attribute__((noinline)) double rr_decay(double tau) { return exp(-1.0 / tau); }
+
+template <int NPF, int KIND, int S, int IN, bool TAU = false>
 __global__ void __launch_bounds__(256, NPF >= 32 ? 1 : 2) dsp_energy_rr_kernel(EnergyArgs A, EnergyPlan PL, int64_t n_wf, int* err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int C = 4 * NPF + 1, len = 256 * NPF, NG = (C - 1) / 8, CS = (C - 1) / S, NGS = CS / 8;
@@ -491,7 +497,13 @@ __global__ void __launch_bounds__(256, NPF >= 32 ? 1 : 2) dsp_energy_rr_kernel(E
             Xp[t & 3] += (double)xr[t];
         }
         const double X = (Xp[0] + Xp[1]) + (Xp[2] + Xp[3]);
+        double c_row = A.c;
         bool in_nan = A.tau_nan != 0;
+        if constexpr (TAU) {  // (a build of its own: the constant-tau kernels keep their code)
+            const float tau = A.tau[row * A.tau_stride];
+            in_nan = tau != tau;
+            c_row = rr_decay((double)tau);
+        }
         if (wave_any(!(fabs(X) <= 1.7976931348623157e308))) {
             bool n = false;
 #pragma unroll
@@ -506,7 +518,7 @@ __global__ void __launch_bounds__(256, NPF >= 32 ? 1 : 2) dsp_energy_rr_kernel(E
         if (!in_nan) {
             const double E = wave_exscan_add(X);
             // ---- pass 2 (straight line): pole-zero recurrence in the reference's operation order, in place
-            const double c = A.c;
+            const double c = c_row;
             double xp = (double)xprev, acc = E - c * (E - xp);
             float run = 0.0f;
 #pragma unroll
@@ -725,16 +737,16 @@ __global__ void __launch_bounds__(256, NPF >= 32 ? 1 : 2) dsp_energy_rr_kernel(E
     }
 }
 
-template <int KIND, int S, int IN>
+template <int KIND, int S, int IN, bool TAU = false>
 int launch_rr_kind(const EnergyArgs& A, const EnergyPlan& PL, int npf, int64_t n_wf, int* err, int blocks, int threads, int lds_bytes,
                    hipStream_t st) {
     switch (npf) {
-        case 4: hipLaunchKernelGGL((dsp_energy_rr_kernel<4, KIND, S, IN>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
-        case 8: hipLaunchKernelGGL((dsp_energy_rr_kernel<8, KIND, S, IN>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
-        case 16: hipLaunchKernelGGL((dsp_energy_rr_kernel<16, KIND, S, IN>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 4: hipLaunchKernelGGL((dsp_energy_rr_kernel<4, KIND, S, IN, TAU>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 8: hipLaunchKernelGGL((dsp_energy_rr_kernel<8, KIND, S, IN, TAU>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
+        case 16: hipLaunchKernelGGL((dsp_energy_rr_kernel<16, KIND, S, IN, TAU>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err); break;
         case 32:  // 8192 samples (production LEGEND rows): 129 samples per lane, one wavefront per SIMD (512-register budget, 36 KB of LDS)
             if (S != 1) return (int)hipErrorInvalidValue;
-            hipLaunchKernelGGL((dsp_energy_rr_kernel<32, KIND, 1, IN>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err);
+            hipLaunchKernelGGL((dsp_energy_rr_kernel<32, KIND, 1, IN, TAU>), dim3(blocks), dim3(threads), lds_bytes, st, A, PL, n_wf, err);
             break;
         default: return (int)hipErrorInvalidValue;
     }
@@ -781,6 +793,9 @@ extern "C" int dsp_internal_set_energy_lds(int trap_opcode, int npf, int lds_byt
 extern "C" int dsp_internal_launch_energy_rr(const EnergyArgs* A, const EnergyPlan* PL, int trap_opcode, int npf, int S, int wf_dtype,
                                              int64_t n_wf, int* err, int blocks, int threads, int lds_bytes, hipStream_t stream) {
 #define GO_(KIND)                                                                                                          \
+    if (A->tau && wf_dtype == DSP_I16) return launch_rr_kind<KIND, 1, 1, true>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream); \
+    if (A->tau && wf_dtype == DSP_U16) return launch_rr_kind<KIND, 1, 2, true>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream); \
+    if (A->tau) return launch_rr_kind<KIND, 1, 0, true>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream);       \
     if (wf_dtype == DSP_I16) return launch_rr_kind<KIND, 1, 1>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream); \
     if (wf_dtype == DSP_U16) return launch_rr_kind<KIND, 1, 2>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream); \
     return S == 2 ? launch_rr_kind<KIND, 2, 0>(*A, *PL, npf, n_wf, err, blocks, threads, lds_bytes, stream)                \

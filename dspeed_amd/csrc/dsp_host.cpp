@@ -65,6 +65,8 @@ struct EnergyArgs {
     int32_t q[3], rho[3];
     int32_t lds_elems_per_wave;
     int32_t slot_off;
+    const float* tau;
+    int64_t tau_stride;
     int32_t ablate;
 };
 extern "C" int dsp_internal_launch_energy(const EnergyArgs* A, int trap_opcode, int npf, int64_t n_wf, int* err, int blocks,
@@ -181,7 +183,7 @@ struct dsp_chain {
     EnergyArgs rr{};
     EnergyPlan plan[2]{};  // [S - 1]
     int rr_lds_bytes = 0;
-    int io_wf = -1, io_bl = -1, io_tp = -1, io_out = -1;
+    int io_wf = -1, io_bl = -1, io_tp = -1, io_out = -1, io_tau = -1;
     // lane-per-waveform kernel (dsp_rows.hip): [bl_subtract ->] pole_zero | double_pole_zero -> short trapezoid -> min_max /
     // time_point_thresh, + Haar DWT of the pole-zero corrected waveform
     bool rows_ok = false;
@@ -1613,14 +1615,17 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         const dsp_op* tp = (pz && n_ops > i && ops[i].opcode == DSP_OP_TRAP_PICKOFF) ? &ops[i++] : nullptr;
         const dsp_op* st = (tp && n_ops > i && ops[i].opcode == DSP_OP_STORE_SCALAR) ? &ops[i++] : nullptr;
         const int wdt = ld ? io[ld->io].dtype : -1;
+        // (a time constant per event, a float32 column: the register-resident kernel's TAU builds form exp(-1/tau) per row like the interpreter's op)
+        const bool tau_col = pz && pz->sp[0].kind == DSP_ARG_INPUT && io[pz->sp[0].index].dtype == DSP_F32;
         const bool shape = !f64 && st && i == n_ops && n_slots == 1 && ld->ip[0] == 0 && ld->ip[1] == 0 && (wdt == DSP_F32 || wdt == DSP_I16 || wdt == DSP_U16) && P.io[ld->io].vec_ok &&
                            (!bs || (bs->dst == 0 && bs->src == 0 && bs->sp[0].kind != DSP_ARG_REG)) && pz->dst == 0 && pz->src == 0 &&
-                           pz->sp[0].kind == DSP_ARG_CONST &&
+                           (pz->sp[0].kind == DSP_ARG_CONST || tau_col) &&
                            tp->src == 0 && tp->sp[0].kind != DSP_ARG_REG && st->ip[0] == tp->dst &&
                            (slot_len[0] == 1024 || slot_len[0] == 2048 || slot_len[0] == 4096 || slot_len[0] == 8192);
         if (!shape && st && i == n_ops && n_slots == 1) {  // the ops of the energy chain, but not the kernels' case of it
             if (f64) note(ch.get(), "the energy chain in a float64 loop: the fused energy kernels are float32");
-            else if (pz->sp[0].kind != DSP_ARG_CONST) note(ch.get(), "a pole-zero time constant per event: the fused energy kernels take a constant");
+            else if (pz->sp[0].kind != DSP_ARG_CONST && !tau_col)
+                note(ch.get(), "a pole-zero time constant per event that is not a float32 column: the fused energy kernels take a constant or such a column");
             else if (!(slot_len[0] == 1024 || slot_len[0] == 2048 || slot_len[0] == 4096 || slot_len[0] == 8192))
                 note(ch.get(), "waveforms of %d samples: the fused energy kernels take 1024, 2048, 4096 or 8192", slot_len[0]);
             else if (!P.io[ld->io].vec_ok) note(ch.get(), "rows that do not start on 16-byte boundaries: the fused energy kernels read 16 bytes per lane");
@@ -1671,7 +1676,11 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             ch->io_out = st->io;
             ch->fused_trap = tp->ip[3];
             ch->fused_npf = slot_len[0] / 256;          // one wavefront per waveform: len == 256 * npf, npf in {4, 8, 16}
-            ch->fused_ok = slot_len[0] <= 4096 && wdt == DSP_F32;  // the classic kernel reads float32 rows only
+            ch->fused_ok = slot_len[0] <= 4096 && wdt == DSP_F32 && !tau_col;  // the classic kernel reads float32 rows only, one time constant
+            if (tau_col) {
+                ch->io_tau = pz->sp[0].index;
+                F.tau_stride = io[ch->io_tau].row_stride;
+            }
             ch->wf_dtype = wdt;
             const char* env = getenv("DSPEED_HIP_NO_FUSED");
             ch->fused_on = !(env && env[0] == '1');
@@ -2155,6 +2164,7 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         F.wf = io_ptrs[ch->io_wf];
         F.bl = (const float*)at(ch->io_bl);
         F.tp = (const float*)at(ch->io_tp);
+        F.tau = (const float*)at(ch->io_tau);
         F.out = (float*)at(ch->io_out);
         const int S = (ch->variant == 8 && ch->wf_dtype == DSP_F32) ? 2 : 1;
         int rwpb, rblocks;

@@ -223,12 +223,11 @@ def test_a_chain_that_misses_a_specialised_kernel_says_why(caplog):
     tb = {"waveform": wf, "baseline": np.full(n, 1000, np.float32), "t_pick": np.full(n, 3000, np.float32)}
     chain, msgs = notes(recipes.C2, tb)
     assert chain.kernel_notes() == [] and msgs == [] and chain._chain.kernel_name == "dsp_energy_rr_kernel"
-    # a time constant per event
+    # a time constant per event: the register-resident kernel's own build since round 3 -- nothing to say
     rec_tau = json.loads(json.dumps(recipes.C2))
     rec_tau["processors"]["wf_pz"] = "dspeed.processors.pole_zero(wf_blsub, tau, wf_pz)"
     chain, msgs = notes(rec_tau, dict(tb, tau=np.full(n, 1716.28, np.float32)))
-    assert chain._chain.kernel_name.startswith("dsp_vm_kernel")
-    assert len(chain.kernel_notes()) == 1 and "time constant per event" in chain.kernel_notes()[0][1] and any("time constant per event" in m for m in msgs)
+    assert chain._chain.kernel_name == "dsp_energy_rr_kernel" and chain.kernel_notes() == [] and msgs == []
     # 3000-sample rows
     tb3 = {"waveform": wf[:, :3000].copy(), "baseline": tb["baseline"], "t_pick": np.full(n, 2000, np.float32)}
     chain, msgs = notes(recipes.C2, tb3)
@@ -239,3 +238,53 @@ def test_a_chain_that_misses_a_specialised_kernel_says_why(caplog):
              "wf_f": {"function": "convolve_wf", "module": M, "args": ["waveform", "kern", "'s'", "wf_f(4096, 'f')"]}}}
     chain, msgs = notes(rec_f, {"waveform": wf})
     assert any("40-tap" in note for _w, note in chain.kernel_notes()), (chain.kernels(), chain.kernel_notes())
+
+
+@pytest.mark.parametrize("dtype,L", [(np.float32, 4096), (np.int16, 8192), (np.uint16, 2048), (np.float32, 1024)])
+@pytest.mark.parametrize("trap", ["trap_filter", "trap_norm", "asym_trap_filter"])
+def test_energy_chain_with_a_time_constant_per_event(dtype, L, trap):
+    """pole_zero's tau as a per-event column (pole_zero.py:24-30, the gufunc's "()" slot): the register-resident kernel's TAU build forms
+    exp(-1/tau) per row as the interpreter's op does -- the oracle's and the interpreter's energies to 1e-6 relative (as with a constant), a
+    NaN time constant -> a NaN energy"""
+    import recipes
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    rng = np.random.default_rng(L + len(trap))
+    n = 150
+    i = np.arange(L)[None, :]
+    t0 = np.floor(0.4 * L)
+    tau = rng.uniform(800, 2500, n).astype(np.float32)
+    x = 1000 + rng.uniform(500, 15000, (n, 1)) * np.exp(-np.clip(i - t0, 0, None) / tau[:, None].astype(np.float64)) * (i >= t0) + 5 * rng.standard_normal((n, L))
+    wf = (np.rint(x) if np.dtype(dtype).kind in "iu" else x).astype(dtype)
+    tau[7] = np.nan
+    bl = np.full(n, 1000, np.float32)
+    rise, flat = L // 16, L // 32
+    tp = np.full(n, t0 + rise + flat // 2, np.float32)
+    args = ["wf_pz", str(rise), str(flat), "wf_trap"] if trap != "asym_trap_filter" else ["wf_pz", str(rise), str(flat), str(rise // 2), "wf_trap"]
+    rec = {"outputs": ["trapEftp"], "processors": {
+        "wf_blsub": "dspeed.processors.bl_subtract(waveform, baseline, wf_blsub)",
+        "wf_pz": "dspeed.processors.pole_zero(wf_blsub, tau, wf_pz)",
+        "wf_trap": {"function": trap, "module": "dspeed.processors", "args": args},
+        "trapEftp": {"function": "fixed_time_pickoff", "module": "dspeed.processors", "args": ["wf_trap", "t_pick", "'l'", "trapEftp"]}}}
+    tb = {"waveform": wf, "baseline": bl, "t_pick": tp, "tau": tau}
+    got = {}
+    for fused in (1, 0):
+        chain, _, out = build_processing_chain(rec, tb)
+        chain._ensure()
+        chain._chain.set_fused(fused)
+        assert chain._chain.kernel_name == ("dsp_energy_rr_kernel" if fused else "dsp_vm_kernel<float>")
+        chain.execute()
+        got[fused] = np.array(out["trapEftp"])
+    assert np.isnan(got[1][7]) and not np.isnan(np.delete(got[1], 7)).any()
+    # (the kernel walks the recurrence in the reference's order, the interpreter sums prefix sums: last places)
+    assert np.isnan(got[0][7]) and np.max(np.abs(np.delete(got[1], 7) - np.delete(got[0], 7)) / np.abs(np.delete(got[0], 7))) <= 1e-6
+    xs = wf.astype(np.float32) - bl[:, None]
+    want = np.empty(n, np.float32)
+    for r in range(n):
+        if r == 7:
+            continue
+        pz = oracle.pole_zero(xs[r:r + 1], float(tau[r]))[0]
+        tr = getattr(oracle, trap)(pz, *[int(a) for a in args[1:-1]])[0]
+        want[r] = oracle.fixed_time_pickoff(tr, tp[r:r + 1], "l")[0][0]
+    ok = np.arange(n) != 7
+    assert np.max(np.abs(got[1][ok] - want[ok]) / np.abs(want[ok])) <= 1e-6

@@ -70,6 +70,18 @@ def main():
         gbps = rows * 16396 / dt / 1e9
         out.append({"config": label, "kernel": chain._chain.kernel_name, "rows": rows, "waveforms_per_s": rows / dt, "bound": "hbm",
                     "achieved_GBps": gbps, "frac": gbps / HBM_PEAK})
+    # ---- C2 with the pole-zero time constant as a per-event column (the register-resident kernel's TAU build; the interpreter before)
+    import copy
+    rec_tau = copy.deepcopy(recipes.C2)
+    rec_tau["processors"]["wf_pz"] = "dspeed.processors.pole_zero(wf_blsub, tau, wf_pz)"
+    tau = DeviceArray.from_numpy(np.full(rows, TAU, dtype=np.float32))
+    tb = {"waveform": wf, "baseline": bl, "t_pick": tp, "tau": tau}
+    chain, _, _ = build_processing_chain(rec_tau, tb)
+    chain.link(tb, {"trapEftp": DeviceArray((rows,), np.float32)})
+    dt = timed(chain)
+    gbps = rows * 16400 / dt / 1e9
+    out.append({"config": "C2-tau-per-event", "kernel": chain._chain.kernel_name, "rows": rows, "waveforms_per_s": rows / dt, "bound": "hbm",
+                "bytes_per_waveform": 16400, "achieved_GBps": gbps, "frac": gbps / HBM_PEAK})
     del wf
     # ---- C2 on 16-bit rows (what the digitisers write): 8 kB per waveform instead of 16
     wf, bl, tp = synth(rows, 4096, np.int16, st, bl_lo=-3000.0, bl_hi=3000.0)
