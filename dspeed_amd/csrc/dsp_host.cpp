@@ -219,7 +219,7 @@ struct dsp_chain {
     // pole-zero rows written back as rows (dsp_pz.hip)
     bool pz_ok = false;
     PzArgs pz{};
-    int pio_wf = -1, pio_bl = -1, pio_out = -1;
+    int pio_wf = -1, pio_bl = -1, pio_out = -1, pio_tau = -1;
     // streaming reductions of rows (dsp_reduce.hip)
     bool red_ok = false;
     ReduceArgs red{};
@@ -293,7 +293,10 @@ static bool match_pz_rows_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, con
     }
     if (i + 2 != n_ops || ops[i].opcode != DSP_OP_POLE_ZERO || ops[i + 1].opcode != DSP_OP_STORE) return false;
     const dsp_op &pz = ops[i], &st = ops[i + 1];
-    if (pz.src != ld.dst || pz.dst != ld.dst || pz.sp[0].kind != DSP_ARG_CONST || st.src != ld.dst) return false;
+    const bool tau_col = pz.sp[0].kind == DSP_ARG_INPUT && io[pz.sp[0].index].dtype == DSP_F32;
+    if (pz.src != ld.dst || pz.dst != ld.dst || (pz.sp[0].kind != DSP_ARG_CONST && !tau_col) || st.src != ld.dst) return false;
+    ch->pio_tau = tau_col ? pz.sp[0].index : -1;
+    if (tau_col) A.tau_stride = io[ch->pio_tau].row_stride;
     const dsp_io_desc& o = io[st.io];
     if (o.dtype != DSP_F32 || o.len != len || o.row_stride % 4 != 0 || o.offset % 4 != 0) return false;
     const DevOp& dpz = ch->host.ops[dev_index[i]];
@@ -2070,6 +2073,7 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         A.wf = io_ptrs[ch->pio_wf];
         A.bl = (const float*)at(ch->pio_bl);
         A.out = at(ch->pio_out);
+        A.tau = (const float*)at(ch->pio_tau);
         A.row_scale = nullptr;
         A.row_flags = nullptr;
         if (dsp_chain* sink = ch->scale_sink) {

@@ -166,6 +166,8 @@ struct PzArgs {
     double c;                // exp(-1/tau)
     void* out;               // float32 rows
     int64_t out_stride;
+    const float* tau;        // or null: the time constant per event (a float32 column) instead of c / tau_nan
+    int64_t tau_stride;
     float* row_scale;        // or null: what dsp_fir_f16_rows_kernel would find on the rows written here (FirF16Taps), for a float16 FIR behind
     uint32_t* row_flags;
 };

@@ -43,7 +43,11 @@ __global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_w
     PZ_GLOBAL float* outp = (PZ_GLOBAL float*)A.out + row * A.out_stride;
     const bool sub = A.sub_mode != 0;
     const float bl = sub ? (A.bl ? ((const PZ_GLOBAL float*)A.bl)[row * A.bl_stride] : A.bl_const) : 0.0f;
-    const double c = A.c;
+    // a time constant per event (pole_zero.py:24-30, the "()" slot filled by a variable): the constant of pole_zero.py:60 formed here in
+    // float64, as the interpreter's op forms it
+    const float tau_row = A.tau ? ((const PZ_GLOBAL float*)A.tau)[row * A.tau_stride] : 0.0f;
+    const double c = A.tau ? exp(-1.0 / (double)tau_row) : A.c;
+    const bool tau_nan = A.tau ? (tau_row != tau_row) : (A.tau_nan != 0);
     const int n_groups = (n + 511) / 512;
 
     // two register sets of two groups each, filled in turn: group g + 4 is asked for while g .. g + 3 are worked on, and no set is ever copied
@@ -131,7 +135,7 @@ __global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_w
     }
     // ---- what the whole row decides: a NaN anywhere in the input (or a NaN baseline / time constant) makes the waveform NaN
     // (pole_zero.py:55-58); a NaN of the recurrence's own making (inf - inf) is a DSPFatal (:76-77) -- and a NaN waveform here, like the VM's op
-    const bool bad_in = wave_any(in_nan) || A.tau_nan || (sub && bl != bl);
+    const bool bad_in = wave_any(in_nan) || tau_nan || (sub && bl != bl);
     const bool bad_out = wave_any(out_nan);
     if (bad_in || bad_out) {
         if (!bad_in && lane == 0) pz_report(err, DSP_E_PZ_NAN, row);

@@ -118,3 +118,23 @@ def test_row_scales_travel_with_the_rows(monkeypatch):
     peak = np.abs(want).max(axis=1, keepdims=True)
     ok = peak[:, 0] > 1e-38
     assert np.max(np.abs(got - want)[ok] / peak[ok]) <= 2e-6
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.float32])
+def test_time_constant_per_event(dtype):
+    """tau as a per-event column: exp(-1/tau) per row in float64 on the device (pole_zero.py:60), a NaN time constant -> a NaN waveform"""
+    rng = np.random.default_rng(17)
+    n, L = 90, 2048
+    wf = _rows(rng, n, L, dtype)
+    tau = rng.uniform(500, 3000, n).astype(np.float32)
+    tau[11] = np.nan
+    rec = {"outputs": ["wf_pz"], "processors": {"wf_pz": f"{M}.pole_zero(waveform, tau, wf_pz)"}}
+    chain, out = _run(rec, {"waveform": wf, "tau": tau}, True)
+    assert chain._chain.kernel_name == "dsp_pz_rows_kernel"
+    assert np.isnan(out["wf_pz"][11]).all()
+    x = wf.astype(np.float32)
+    for r in range(n):
+        if r == 11:
+            continue
+        want = oracle.pole_zero(x[r:r + 1], float(tau[r]))[0][0]
+        assert np.max(np.abs(out["wf_pz"][r] - want)) / np.abs(want).max() <= TOL, r
