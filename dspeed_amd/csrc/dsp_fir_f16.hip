@@ -25,6 +25,7 @@
 #include "dsp_program.h"
 #include "dsp_wave.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 #define FIR_LDS __attribute__((address_space(3)))
@@ -173,8 +174,14 @@ __global__ void __launch_bounds__(256) dsp_fir_f16_rows_kernel(FirArgs A_, float
 }
 
 // STORE: a 320-column tile of a kept output (grid.x = column tile); else kernel q's 'valid' outputs and their maximum (grid.x = q)
-template <int IN, bool STORE>
+// RES (kept output, short kernels): the tap copies a tile can reach -- kt + TB taps each -- fit the room of the two window buffers, so they are
+// staged once, before the first stage, and no stage fetches or writes taps (dsp_internal_fir_f16_resident says when)
+constexpr int RES_HALFS = 2 * 16 * TPITCH;  // halfs of the tap region
+__host__ __device__ constexpr int res_pitch(int kt) { return ((kt + TB + 8 + 15 * 8 + 127) / 128) * 128; }
+
+template <int IN, bool STORE, bool RES = false>
 __global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16Taps T_, int64_t n_wf) {
+    static_assert(!RES || STORE, "resident taps: the kept-output form");
     const FIR_KARG FirArgs& A = *(const FIR_KARG FirArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     (void)A_;
     extern __shared__ __attribute__((aligned(16))) unsigned char f16_smem[];
@@ -282,6 +289,27 @@ __global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16
         tap_src[it] = c * TZ + o;
         tap_dst[it] = c * TPITCH + o + 8 * tap_slot[e][c & 7];
     }
+    const int rpitch = res_pitch(kt);
+    if constexpr (RES) {  // all of it, once: 16 copies x (kt + TB) taps
+        const int per = (kt + TB) / 8, total = 16 * per;
+        for (int v0 = tid; v0 < total; v0 += 4 * NTHR) {
+            h8 tv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int v = v0 + u * NTHR < total ? v0 + u * NTHR : total - 1;
+                const int c = v / per, o = (v - c * per) * 8;
+                tv[u] = *(const FIR_GLOBAL h8*)(tg + c * TZ + o);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int v = v0 + u * NTHR;
+                if (v < total) {
+                    const int c = v / per, o = (v - c * per) * 8;
+                    *(FIR_LDS h8*)(Tw + c * rpitch + o + 8 * tap_slot[e][c & 7]) = tv[u];
+                }
+            }
+        }
+    }
     auto fetch_taps = [&](int k0, h8 (&tap_v)[TAPV]) {
 #pragma unroll
         for (int it = 0; it < TAPV; ++it) tap_v[it] = *(const FIR_GLOBAL h8*)(tg + tap_src[it] + k0);
@@ -310,17 +338,18 @@ __global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16
     // B fragment of column cl = 16 (wn + 4 tn) + j: tapz[TB + kk - cl - e ..] for window samples kk = k0 + 32 g + 8 h4 ..: aligned in the copy
     // shifted by r = -(j + e) mod 8, at window offset TB + 32 g + 8 h4 - cl - e - r
     const int shift = (8 - ((j + e) & 7)) & 7;
-    const int t_off = shift * TPITCH + 8 * tap_slot[e][shift] + TB + 8 * h4 - (wn * 16 + j) - e - shift;
+    const int t_pitch = RES ? rpitch : TPITCH;
+    const int t_off = shift * t_pitch + 8 * tap_slot[e][shift] + TB + 8 * h4 - (wn * 16 + j) - e - shift;
 
     const int n_stage = kt / BK;
     fetch(0, stage_xx[0]);
-    fetch_taps(0, tap_vv[0]);
+    if constexpr (!RES) fetch_taps(0, tap_vv[0]);
     if (n_stage > 1) {
         fetch(BK, stage_xx[1]);
-        fetch_taps(BK, tap_vv[1]);
+        if constexpr (!RES) fetch_taps(BK, tap_vv[1]);
     }
     commit(0, 0, stage_xx[0]);
-    commit_taps(0, tap_vv[0]);
+    if constexpr (!RES) commit_taps(0, tap_vv[0]);
     __syncthreads();
     // stage st (parity PAR): its operands are in LDS buffer PAR; register set 1 - PAR holds stage st + 1, register set PAR is free for st + 2
     auto stage = [&](auto par, int st) {
@@ -329,11 +358,11 @@ __global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16
 #ifndef F16_DIAG_NO_FETCH
         if (st + 2 < n_stage) {
             fetch(k0 + 2 * BK, stage_xx[PAR]);
-            fetch_taps(k0 + 2 * BK, tap_vv[PAR]);
+            if constexpr (!RES) fetch_taps(k0 + 2 * BK, tap_vv[PAR]);
         }
 #endif
         const FIR_LDS _Float16* ab = As + PAR * 2 * BM * APITCH + a_off;
-        const FIR_LDS _Float16* tb = Tw + PAR * 16 * TPITCH + t_off;
+        const FIR_LDS _Float16* tb = RES ? Tw + t_off + k0 : Tw + PAR * 16 * TPITCH + t_off;
 #pragma unroll
         for (int g = 0; g < BK / 32; ++g) {
             const int kb = k0 + g * 32;  // this group: window samples kb .. kb + 31
@@ -357,7 +386,7 @@ __global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16
                     const h8 bh = h8{(_Float16)(float)(kb + tn), 0, 0, 0, 0, 0, 0, 0}, blo = h8{(_Float16)(float)(lane + tn), 0, 0, 0, 0, 0, 0, 0};
 #else
                     const h8 bh = *(const FIR_LDS h8*)(tb + g * 32 - tn * 64);
-                    const h8 blo = *(const FIR_LDS h8*)(tb + 8 * TPITCH + g * 32 - tn * 64);
+                    const h8 blo = *(const FIR_LDS h8*)(tb + 8 * t_pitch + g * 32 - tn * 64);
 #endif
 #pragma unroll
                     for (int tm = 0; tm < MT; ++tm) {
@@ -371,7 +400,7 @@ __global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16
 #ifndef F16_DIAG_NO_COMMIT
         if (st + 1 < n_stage) {
             commit(1 - PAR, k0 + BK, stage_xx[1 - PAR]);
-            commit_taps(1 - PAR, tap_vv[1 - PAR]);
+            if constexpr (!RES) commit_taps(1 - PAR, tap_vv[1 - PAR]);
         }
 #endif
 #ifndef F16_DIAG_NO_BARRIER
@@ -527,7 +556,13 @@ static void launch_f16(const FirArgs* A, const FirF16Taps* T, int64_t n_wf, int 
                            (unsigned*)T->row_flags, n_wf);
     if (A->store) {
         const dim3 grid((unsigned)((A->p[0] + BN - 1) / BN), (unsigned)((n_wf + BM - 1) / BM));
-        hipLaunchKernelGGL((dsp_fir_f16_kernel<IN, true>), grid, dim3(NTHR), lds_bytes, stream, *A, *T, n_wf);
+        // the longest window of a tile: its columns, the kernel, the alignment of its first sample (e <= 7), in whole stages
+        const int cols = A->p[0] < BN ? A->p[0] : BN, kt_max = ((cols + A->m[0] - 1 + 7 + BK - 1) / BK) * BK;
+        static const bool no_res = getenv("DSPEED_HIP_FIR_NO_RESIDENT_TAPS") && getenv("DSPEED_HIP_FIR_NO_RESIDENT_TAPS")[0] == '1';
+        if (!no_res && 16 * res_pitch(kt_max) <= RES_HALFS)
+            hipLaunchKernelGGL((dsp_fir_f16_kernel<IN, true, true>), grid, dim3(NTHR), lds_bytes, stream, *A, *T, n_wf);
+        else
+            hipLaunchKernelGGL((dsp_fir_f16_kernel<IN, true>), grid, dim3(NTHR), lds_bytes, stream, *A, *T, n_wf);
     } else {
         const dim3 grid((unsigned)A->n_kernels, (unsigned)((n_wf + BM - 1) / BM));
         hipLaunchKernelGGL((dsp_fir_f16_kernel<IN, false>), grid, dim3(NTHR), lds_bytes, stream, *A, *T, n_wf);
@@ -553,10 +588,12 @@ extern "C" int dsp_internal_launch_fir_f16(const FirArgs* A, const FirF16Taps* T
 }
 
 extern "C" int dsp_internal_set_fir_f16_lds(int lds_bytes) {
-    const void* k[6] = {reinterpret_cast<const void*>(&dsp_fir_f16_kernel<0, false>), reinterpret_cast<const void*>(&dsp_fir_f16_kernel<1, false>),
+    const void* k[9] = {reinterpret_cast<const void*>(&dsp_fir_f16_kernel<0, false>), reinterpret_cast<const void*>(&dsp_fir_f16_kernel<1, false>),
                         reinterpret_cast<const void*>(&dsp_fir_f16_kernel<2, false>), reinterpret_cast<const void*>(&dsp_fir_f16_kernel<0, true>),
-                        reinterpret_cast<const void*>(&dsp_fir_f16_kernel<1, true>), reinterpret_cast<const void*>(&dsp_fir_f16_kernel<2, true>)};
-    for (int i = 0; i < 6; ++i) {
+                        reinterpret_cast<const void*>(&dsp_fir_f16_kernel<1, true>), reinterpret_cast<const void*>(&dsp_fir_f16_kernel<2, true>),
+                        reinterpret_cast<const void*>(&dsp_fir_f16_kernel<0, true, true>), reinterpret_cast<const void*>(&dsp_fir_f16_kernel<1, true, true>),
+                        reinterpret_cast<const void*>(&dsp_fir_f16_kernel<2, true, true>)};
+    for (int i = 0; i < 9; ++i) {
         const int rc = (int)hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (rc != 0) return rc;
     }

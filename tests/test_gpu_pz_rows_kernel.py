@@ -138,3 +138,37 @@ def test_time_constant_per_event(dtype):
             continue
         want = oracle.pole_zero(x[r:r + 1], float(tau[r]))[0][0]
         assert np.max(np.abs(out["wf_pz"][r] - want)) / np.abs(want).max() <= TOL, r
+
+
+def test_row_scales_follow_the_batch(monkeypatch):
+    """the same chain on a second, larger batch (the scale arrays grow, the rows live elsewhere) and on a batch handed over in pieces
+    (execute(begin, end): every piece is an execute of its own, the producer's note is good for exactly one): as without the link"""
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    rng = np.random.default_rng(23)
+    L = 2048
+    rec = {"outputs": ["wf_f"], "processors": {
+        "wf_pz": f"{M}.pole_zero(waveform, 1716.28, wf_pz)",
+        "kern": {"function": "t0_filter", "module": M, "args": ["8", "125", "kern(133, 'f')"]},
+        "wf_f": {"function": "convolve_wf", "module": M, "args": ["wf_pz", "kern", "'s'", f"wf_f({L}, 'f')"]}}}
+    batches = [_rows(rng, 100, L, np.int16), _rows(rng, 700, L, np.int16), _rows(rng, 64, L, np.int16)]
+
+    def run(shared):
+        monkeypatch.setenv("DSPEED_HIP_NO_SHARED_ROW_SCALES", "0" if shared else "1")
+        chain, _, _ = build_processing_chain(rec, {"waveform": batches[0]})
+        res = []
+        for wf in batches:
+            out = {"wf_f": np.full((len(wf), L), -1.0, dtype=np.float32)}
+            chain.link({"waveform": wf}, out)
+            chain.execute()
+            res.append(out["wf_f"].copy())
+            out2 = {"wf_f": np.full((len(wf), L), -1.0, dtype=np.float32)}
+            chain.link({"waveform": wf}, out2)
+            half = len(wf) // 2
+            chain.execute(0, half)
+            chain.execute(half, len(wf))
+            assert np.array_equal(out2["wf_f"], out["wf_f"])
+        return res
+
+    for a, b in zip(run(True), run(False)):
+        assert np.array_equal(a, b) and not np.isnan(a).any() and np.abs(a).max() > 0
