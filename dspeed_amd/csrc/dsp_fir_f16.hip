@@ -56,6 +56,14 @@ constexpr int TWIN = TB + BK;    // taps a stage's fragments can reach
 constexpr int TPITCH = ((TWIN + 8 + 15 * 8 + 127) / 128) * 128;
 __constant__ unsigned char tap_slot[8][8] = {{2, 5, 9, 6, 15, 12, 9, 15}, {7, 2, 8, 3, 5, 0, 15, 12}, {1, 11, 2, 13, 5, 9, 8, 6}, {8, 4, 11, 1, 4, 0, 15, 8},
                                              {7, 9, 3, 12, 15, 7, 13, 2}, {8, 11, 2, 14, 6, 9, 12, 3}, {3, 7, 6, 11, 0, 4, 15, 11}, {5, 4, 8, 9, 13, 3, 11, 1}};
+// F16_PIPE 0: the stages of the amax form as those of the kept-output form (A/B: C3 34.0 M waveforms/s; 35.2 M with one vector instruction dealt
+// out per matrix instruction, 35.8 M with two)
+#ifndef F16_PIPE
+#define F16_PIPE 1
+#endif
+#ifndef F16_PIPE_VALU
+#define F16_PIPE_VALU 2
+#endif
 #ifndef F16_KFLUSH
 #define F16_KFLUSH 256
 #endif
@@ -237,7 +245,13 @@ __global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16
             if (IN == 0) raw[v].w[IN == 0 ? 1 : 0] = src[1];
         }
     };
-    auto commit = [&](int buf, int k0, const Raw (&raw)[SV]) {  // zeros outside the slice, baseline, scale, split, into the two planes
+    // zeros outside the slice, baseline, scale, split, into the two planes.  MASK: the stage reaches outside the slice (its first or last one, a
+    // scalar test for the whole workgroup); every other stage skips the per-sample selects, 24 of its 60 vector instructions per 8 samples
+    struct Split {
+        h8 hi, lo;
+    };
+    auto convert_as = [&](auto mask, int k0, const Raw (&raw)[SV], Split (&out)[SV]) {
+        constexpr bool MASK = decltype(mask)::value;
 #pragma unroll
         for (int v = 0; v < SV; ++v) {
             const int i = ks + k0 + 64 * v + skc;
@@ -260,7 +274,7 @@ __global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 x[u] = sub ? x[u] - bl : x[u];
-                x[u] = u < live ? x[u] : 0.0f;
+                if (MASK) x[u] = u < live ? x[u] : 0.0f;
             }
             h8 hi, lo;
 #pragma unroll
@@ -270,10 +284,28 @@ __global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16
                 hi[u] = h;
                 lo[u] = (_Float16)(y - (float)h);
             }
-            FIR_LDS _Float16* ap = As + buf * 2 * BM * APITCH + srow * APITCH + 64 * v + skc;
-            *(FIR_LDS h8*)ap = hi;
-            *(FIR_LDS h8*)(ap + BM * APITCH) = lo;
+            out[v].hi = hi;
+            out[v].lo = lo;
         }
+    };
+    auto put = [&](int buf, const Split (&sp)[SV]) {
+#pragma unroll
+        for (int v = 0; v < SV; ++v) {
+            FIR_LDS _Float16* ap = As + buf * 2 * BM * APITCH + srow * APITCH + 64 * v + skc;
+            *(FIR_LDS h8*)ap = sp[v].hi;
+            *(FIR_LDS h8*)(ap + BM * APITCH) = sp[v].lo;
+        }
+    };
+    auto commit_as = [&](auto mask, int buf, int k0, const Raw (&raw)[SV]) {
+        Split sp[SV];
+        convert_as(mask, k0, raw, sp);
+        put(buf, sp);
+    };
+    auto commit = [&](int buf, int k0, const Raw (&raw)[SV]) {
+        if (ks + k0 >= 0 && ks + k0 + BK <= n)  // (uniform)
+            commit_as(std::false_type(), buf, k0, raw);
+        else
+            commit_as(std::true_type(), buf, k0, raw);
     };
     // the 16 tap copies' windows [k0, k0 + TWIN): 16 x 50 vectors of 8 halfs over the workgroup's threads (a thread beyond the last vector
     // requests the last one again and does not store it)
@@ -352,11 +384,21 @@ __global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16
     if constexpr (!RES) commit_taps(0, tap_vv[0]);
     __syncthreads();
     // stage st (parity PAR): its operands are in LDS buffer PAR; register set 1 - PAR holds stage st + 1, register set PAR is free for st + 2
-    auto stage = [&](auto par, int st) {
+    // PIPE (a stage well inside the rows and the run of stages: nothing conditional in it): the operands of the next stage are converted and written
+    // BEFORE this stage's matrix instructions in program order and the scheduler is told to deal the two out alternately -- a wavefront issues its
+    // conversions in the shadow of its own matrix instructions instead of everybody converting while the matrix pipe idles
+    auto stage = [&](auto par, auto pipe, int st) {
         constexpr int PAR = decltype(par)::value;
+        constexpr bool PIPE = decltype(pipe)::value;
         const int k0 = st * BK;
+        Split piped[SV];
+        if constexpr (PIPE) {
+            fetch(k0 + 2 * BK, stage_xx[PAR]);
+            if constexpr (!RES) fetch_taps(k0 + 2 * BK, tap_vv[PAR]);
+            convert_as(std::false_type(), k0 + BK, stage_xx[1 - PAR], piped);
+        }
 #ifndef F16_DIAG_NO_FETCH
-        if (st + 2 < n_stage) {
+        if (!PIPE && st + 2 < n_stage) {
             fetch(k0 + 2 * BK, stage_xx[PAR]);
             if constexpr (!RES) fetch_taps(k0 + 2 * BK, tap_vv[PAR]);
         }
@@ -397,8 +439,17 @@ __global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16
                 }
             }
         }
+        if constexpr (PIPE) {
+            put(1 - PAR, piped);
+            if constexpr (!RES) commit_taps(1 - PAR, tap_vv[1 - PAR]);
+#pragma unroll
+            for (int i = 0; i < (BK / 32) * NT * MT * 3; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one matrix instruction
+                __builtin_amdgcn_sched_group_barrier(0x002, F16_PIPE_VALU, 0);  // vector instructions of the conversion behind it
+            }
+        }
 #ifndef F16_DIAG_NO_COMMIT
-        if (st + 1 < n_stage) {
+        if (!PIPE && st + 1 < n_stage) {
             commit(1 - PAR, k0 + BK, stage_xx[1 - PAR]);
             if constexpr (!RES) commit_taps(1 - PAR, tap_vv[1 - PAR]);
         }
@@ -415,17 +466,7 @@ __global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16
     // (a kept output of a short kernel flushed once at the end instead -- a column's sum spans m samples only: 3.76 -> 3.56 ms for the
     // recipe's 133-tap filter, errors 5.5e-7 -> 6.4e-7 of the peak and 4.6e-7 -> 9.5e-7 for 250 taps, tools/fir_f16_store_accuracy.py: left)
     constexpr int run = RUN;
-    for (int st0 = 0; st0 < n_stage; st0 += run) {
-        const int st1 = st0 + run < n_stage ? st0 + run : n_stage;
-        if (RUN == 1) {
-            if (st0 & 1) stage(std::integral_constant<int, 1>(), st0); else stage(std::integral_constant<int, 0>(), st0);
-        } else {
-            for (int st = st0; st < st1; st += 2) {
-                stage(std::integral_constant<int, 0>(), st);
-                if (st + 1 < st1) stage(std::integral_constant<int, 1>(), st + 1);
-            }
-        }
-        // partial sums of (up to) 256 / 128 samples leave float32 here
+    auto flush = [&]() {  // partial sums of (up to) 256 / 128 samples leave float32 here
 #pragma unroll
         for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
@@ -434,6 +475,35 @@ __global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16
                 for (int r = 0; r < 4; ++r) tot[tm][tn][r] += (double)acc[tm][tn][r];
                 acc[tm][tn] = acc_t{0.0f, 0.0f, 0.0f, 0.0f};
             }
+    };
+    // stages 0 .. n_pipe - 1: whole runs whose every stage has two more behind it and converts samples inside the rows only
+    int n_pipe = 0;
+#if F16_PIPE
+    if (!STORE && RUN > 1) {
+        int last = n_stage - 3;                        // st + 2 < n_stage
+        const int inside = (n - ks) / BK - 2;          // ks + (st + 2) BK <= n
+        last = last < inside ? last : inside;
+        n_pipe = ks >= 0 && last >= 0 ? ((last + 1) / RUN) * RUN : 0;
+    }
+#endif
+    for (int st0 = 0; st0 < n_pipe; st0 += RUN) {
+        for (int st = st0; st < st0 + RUN; st += 2) {
+            stage(std::integral_constant<int, 0>(), std::true_type(), st);
+            stage(std::integral_constant<int, 1>(), std::true_type(), st + 1);
+        }
+        flush();
+    }
+    for (int st0 = n_pipe; st0 < n_stage; st0 += run) {
+        const int st1 = st0 + run < n_stage ? st0 + run : n_stage;
+        if (RUN == 1) {
+            if (st0 & 1) stage(std::integral_constant<int, 1>(), std::false_type(), st0); else stage(std::integral_constant<int, 0>(), std::false_type(), st0);
+        } else {
+            for (int st = st0; st < st1; st += 2) {
+                stage(std::integral_constant<int, 0>(), std::false_type(), st);
+                if (st + 1 < st1) stage(std::integral_constant<int, 1>(), std::false_type(), st + 1);
+            }
+        }
+        flush();
     }
     // C layout of a 16 x 16 tile: column = lane & 15, row = 4 (lane >> 4) + r
     if (STORE) {
