@@ -96,7 +96,9 @@ __global__ void __launch_bounds__(256) dsp_fir_f16_prep_kernel(const float* __re
     int e = (int)((__float_as_uint(mx) >> 23) & 0xffu) - 127;  // floor(log2(mx)) for normal numbers
     if (!(mx > 0.0f) || e < -100 || e > 100) e = 14;           // all zeros (or beyond any sensible kernel): scale 1
     const float scale = __uint_as_float((unsigned)(127 + 14 - e) << 23);  // mx * scale in [2^14, 2^15)
-    for (int idx = tid; idx < 8 * TZ; idx += 256) {
+    // (every workgroup finds the scale for itself -- m reads -- and writes its share of the copies: one workgroup alone took 67 us for a
+    // 5792-tap kernel, a fifth of a percent of C3 per launch and two launches per pass)
+    for (int idx = (int)blockIdx.x * 256 + tid; idx < 8 * TZ; idx += (int)gridDim.x * 256) {
         const int r = idx / TZ, i = idx - r * TZ;
         const int t = i + r - TB;
         const float v = (t >= 0 && t < m) ? taps[m - 1 - t] * scale : 0.0f;
@@ -105,7 +107,7 @@ __global__ void __launch_bounds__(256) dsp_fir_f16_prep_kernel(const float* __re
         dst[(size_t)r * TZ + i] = hi;
         dst[(size_t)(8 + r) * TZ + i] = lo;
     }
-    if (tid == 0) *(float*)(dst + (size_t)16 * TZ) = pow2_inverse(scale);
+    if (tid == 0 && blockIdx.x == 0) *(float*)(dst + (size_t)16 * TZ) = pow2_inverse(scale);
 }
 
 // ---- rows: one wavefront per row; scale[row] = 2^(14 - floor(log2(max |x - baseline|))) over the slice, flags[row] bit 0: an infinity (or a
@@ -141,14 +143,23 @@ __global__ void __launch_bounds__(256) dsp_fir_f16_rows_kernel(FirArgs A_, float
             const int i = i0 + b * 512;
             if (i < n8) {
                 if (IN == 0) {
+#ifdef F16_ROWS_PLAIN_LOADS
                     const f4 v0 = *(const FIR_GLOBAL f4*)(rowp + (size_t)i * 4), v1 = *(const FIR_GLOBAL f4*)(rowp + (size_t)i * 4 + 16);
+#else
+                    const f4 v0 = __builtin_nontemporal_load((const FIR_GLOBAL f4*)(rowp + (size_t)i * 4));
+                    const f4 v1 = __builtin_nontemporal_load((const FIR_GLOBAL f4*)(rowp + (size_t)i * 4 + 16));
+#endif
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         x[b][u] = v0[u];
                         x[b][4 + u] = v1[u];
                     }
                 } else {
+#ifdef F16_ROWS_PLAIN_LOADS
                     const u4 raw = *(const FIR_GLOBAL u4*)(rowp + (size_t)i * 2);
+#else
+                    const u4 raw = __builtin_nontemporal_load((const FIR_GLOBAL u4*)(rowp + (size_t)i * 2));
+#endif
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         x[b][2 * u] = IN == 1 ? (float)(short)(raw[u] & 0xffffu) : (float)(raw[u] & 0xffffu);
@@ -642,7 +653,7 @@ static void launch_f16(const FirArgs* A, const FirF16Taps* T, int64_t n_wf, int 
 extern "C" int dsp_internal_launch_fir_f16(const FirArgs* A, const FirF16Taps* T, int64_t n_wf, int lds_bytes, hipStream_t stream) {
     if (n_wf <= 0 || A->n_kernels <= 0) return 0;
     for (int q = 0; q < A->n_kernels; ++q)
-        hipLaunchKernelGGL(dsp_fir_f16_prep_kernel, dim3(1), dim3(256), 0, stream, A->taps[q], A->m[q], T->tz, (_Float16*)T->taps16[q]);
+        hipLaunchKernelGGL(dsp_fir_f16_prep_kernel, dim3(32), dim3(256), 0, stream, A->taps[q], A->m[q], T->tz, (_Float16*)T->taps16[q]);
     switch (A->in_kind) {
         case 0: launch_f16<0>(A, T, n_wf, lds_bytes, stream); break;
         case 1: launch_f16<1>(A, T, n_wf, lds_bytes, stream); break;
