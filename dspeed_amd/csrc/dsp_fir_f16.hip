@@ -199,7 +199,7 @@ constexpr int RES_HALFS = 2 * 16 * TPITCH;  // halfs of the tap region
 __host__ __device__ constexpr int res_pitch(int kt) { return ((kt + TB + 8 + 15 * 8 + 127) / 128) * 128; }
 
 template <int IN, bool STORE, bool RES = false>
-__global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16Taps T_, int64_t n_wf) {
+__global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16Taps T_, int64_t n_wf, int parts) {
     static_assert(!RES || STORE, "resident taps: the kept-output form");
     const FIR_KARG FirArgs& A = *(const FIR_KARG FirArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     (void)A_;
@@ -207,11 +207,25 @@ __global__ void __launch_bounds__(NTHR, 1) dsp_fir_f16_kernel(FirArgs A_, FirF16
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = BM == 64 ? (wave & 1) : 0, wn = BM == 64 ? (wave >> 1) : wave;  // rows 32 wm ..; column tiles wn, wn + 4, .. (16 columns each)
-    const int q = STORE ? 0 : (int)blockIdx.x;
-    const int64_t row0 = (int64_t)blockIdx.y * BM;
+    // Which (kernel or column tile, block of 64 rows) this workgroup is.  Workgroup ids go round the 8 XCDs, each with an L2 of its own: every
+    // workgroup that reads one block of rows -- the kernels of the amax form, the column tiles of a kept output, whose windows overlap -- gets
+    // ids 8 apart, i.e. the same XCD one after the other, and all but the first find the rows in that L2 (id = 8 * slot + xcd; slot = (block
+    // group, part), row block = 8 * group + xcd).  F16_PLAIN_GRID: id = part + parts * row block, as before, for the A/B.
+    // (parts: kernels / column tiles)
+#ifdef F16_PLAIN_GRID
+    const int part = (int)(blockIdx.x % (unsigned)parts);
+    const int64_t rblock = blockIdx.x / (unsigned)parts;
+#else
+    const int xcd = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3);
+    const int part = slot % parts;
+    const int64_t rblock = (int64_t)(slot / parts) * 8 + xcd;
+#endif
+    if (rblock * BM >= n_wf) return;  // (the grid is padded to whole groups of 8 row blocks; whole workgroups leave, before any barrier)
+    const int q = STORE ? 0 : part;
+    const int64_t row0 = rblock * BM;
     const int n = A.n, m = A.m[q], P = A.p[q];
     // the K window of this workgroup: samples ks .. ks + kt - 1 of the rows; output column cl sums window samples cl + e .. cl + e + m - 1
-    const int c0 = STORE ? (int)blockIdx.x * BN : 0;
+    const int c0 = STORE ? part * BN : 0;
     const int s0 = c0 - (STORE ? A.dshift : 0);
     const int ks = (s0 >> 3) << 3, e = s0 - ks;  // (arithmetic shift: rounds down for the negative start of the first tiles)
     const int cols = P - c0 < BN ? P - c0 : BN;
@@ -635,18 +649,22 @@ static void launch_f16(const FirArgs* A, const FirF16Taps* T, int64_t n_wf, int 
     if (!T->rows_done)
         hipLaunchKernelGGL(dsp_fir_f16_rows_kernel<IN>, dim3((unsigned)((n_wf + 3) / 4)), dim3(256), 0, stream, *A, (float*)T->row_scale,
                            (unsigned*)T->row_flags, n_wf);
+    int parts;
+    const int64_t rblocks = (n_wf + BM - 1) / BM, rgroups = (rblocks + 7) / 8;
     if (A->store) {
-        const dim3 grid((unsigned)((A->p[0] + BN - 1) / BN), (unsigned)((n_wf + BM - 1) / BM));
+        parts = (A->p[0] + BN - 1) / BN;
+        const dim3 grid((unsigned)(8 * rgroups * parts));
         // the longest window of a tile: its columns, the kernel, the alignment of its first sample (e <= 7), in whole stages
         const int cols = A->p[0] < BN ? A->p[0] : BN, kt_max = ((cols + A->m[0] - 1 + 7 + BK - 1) / BK) * BK;
         static const bool no_res = getenv("DSPEED_HIP_FIR_NO_RESIDENT_TAPS") && getenv("DSPEED_HIP_FIR_NO_RESIDENT_TAPS")[0] == '1';
         if (!no_res && 16 * res_pitch(kt_max) <= RES_HALFS)
-            hipLaunchKernelGGL((dsp_fir_f16_kernel<IN, true, true>), grid, dim3(NTHR), lds_bytes, stream, *A, *T, n_wf);
+            hipLaunchKernelGGL((dsp_fir_f16_kernel<IN, true, true>), grid, dim3(NTHR), lds_bytes, stream, *A, *T, n_wf, parts);
         else
-            hipLaunchKernelGGL((dsp_fir_f16_kernel<IN, true>), grid, dim3(NTHR), lds_bytes, stream, *A, *T, n_wf);
+            hipLaunchKernelGGL((dsp_fir_f16_kernel<IN, true>), grid, dim3(NTHR), lds_bytes, stream, *A, *T, n_wf, parts);
     } else {
-        const dim3 grid((unsigned)A->n_kernels, (unsigned)((n_wf + BM - 1) / BM));
-        hipLaunchKernelGGL((dsp_fir_f16_kernel<IN, false>), grid, dim3(NTHR), lds_bytes, stream, *A, *T, n_wf);
+        parts = A->n_kernels;
+        const dim3 grid((unsigned)(8 * rgroups * parts));
+        hipLaunchKernelGGL((dsp_fir_f16_kernel<IN, false>), grid, dim3(NTHR), lds_bytes, stream, *A, *T, n_wf, parts);
     }
 }
 
