@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256) dsp_fir_f16_rows_kernel(FirArgs A_, float
 
 // STORE: a 320-column tile of a kept output; else kernel q's 'valid' outputs and their maximum (which tile / kernel and which block of rows: from the workgroup id, below)
 // RES (kept output, short kernels): the tap copies a tile can reach -- kt + TB taps each -- fit the room of the two window buffers, so they are
-// staged once, before the first stage, and no stage fetches or writes taps (dsp_internal_fir_f16_resident says when)
+// staged once, before the first stage, and no stage fetches or writes taps (launch_f16 decides: the longest window of a tile must fit)
 constexpr int RES_HALFS = 2 * 16 * TPITCH;  // halfs of the tap region
 __host__ __device__ constexpr int res_pitch(int kt) { return ((kt + TB + 8 + 15 * 8 + 127) / 128) * 128; }
 
