@@ -172,3 +172,22 @@ def test_row_scales_follow_the_batch(monkeypatch):
 
     for a, b in zip(run(True), run(False)):
         assert np.array_equal(a, b) and not np.isnan(a).any() and np.abs(a).max() > 0
+
+
+def test_many_rows_scale_exactly():
+    """32 768 rows of 8192 int16 samples (a production piece): pole_zero(2 x) == 2 pole_zero(x) bit for bit (a power of two commutes with every
+    sum, product and rounding of the recurrence), and every 1024th row against the oracle"""
+    rng = np.random.default_rng(29)
+    n, L = 32768, 8192
+    wf = _rows(rng, 64, L, np.int16)
+    wf = np.clip(np.tile(wf, (n // 64, 1)) + rng.integers(-40, 40, (n, 1), dtype=np.int16), -16000, 16000).astype(np.int16)
+    bl = rng.uniform(800, 3000, n).astype(np.float32)
+    rec = {"outputs": ["wf_pz"], "processors": {"wf_bl": f"{M}.bl_subtract(waveform, baseline, wf_bl)", "wf_pz": f"{M}.pole_zero(wf_bl, 1716.28, wf_pz)"}}
+    chain, a = _run(rec, {"waveform": wf, "baseline": bl}, True)
+    assert chain._chain.kernel_name == "dsp_pz_rows_kernel"
+    a = np.array(a["wf_pz"])
+    _, b = _run(rec, {"waveform": (2 * wf).astype(np.int16), "baseline": (2 * bl).astype(np.float32)}, True)
+    assert np.array_equal(np.array(b["wf_pz"]), 2 * a)
+    pick = np.arange(0, n, 1024)
+    want = oracle.pole_zero(oracle.bl_subtract(wf[pick].astype(np.float32), bl[pick])[0], 1716.28)[0]
+    assert np.max(np.abs(a[pick] - want) / np.abs(want).max(axis=1, keepdims=True)) <= TOL
