@@ -454,15 +454,28 @@ static bool match_current_shape(dsp_chain* ch, const dsp_op* ops, int n_ops, con
     int shift = -1;
     for (int k = 0; k <= 4; ++k)
         if (upf == (float)(1 << k)) shift = k;
-    if (shift < 0) return false;
+    if (shift < 0) {
+        note(ch, "the current branch with an upsampling factor of %g: the lane-per-waveform kernel takes 1, 2, 4, 8 or 16", (double)upf);
+        return false;
+    }
     A.up_shift = shift;
     A.up_half = (1 << shift) / 2;
     A.n_up = slot_len[up.dst];
-    if (A.n_up < 32 || A.n_up % 16 != 0 || ((A.n_up - 1 + A.up_half) >> shift) >= A.n_c) return false;
+    if (A.n_up < 32 || A.n_up % 16 != 0 || ((A.n_up - 1 + A.up_half) >> shift) >= A.n_c) {
+        if (A.n_up % 16 != 0) note(ch, "the current branch with %d upsampled samples: the lane-per-waveform kernel takes a multiple of 16", A.n_up);
+        return false;
+    }
     // moving_window_multi: three alternating windows whose length is a multiple of 16 samples
-    if (mw.sp[0].kind != DSP_ARG_CONST || mw.ip[0] != 0 || mw.ip[1] != 3 || slot_len[mw.dst] != A.n_up) return false;
+    if (mw.sp[0].kind != DSP_ARG_CONST || mw.ip[0] != 0 || mw.ip[1] != 3 || slot_len[mw.dst] != A.n_up) {
+        if (mw.sp[0].kind == DSP_ARG_CONST && (mw.ip[0] != 0 || mw.ip[1] != 3))
+            note(ch, "the current branch with %d moving windows of type %d: the lane-per-waveform kernel takes three alternating ones", mw.ip[1], mw.ip[0]);
+        return false;
+    }
     const float mal = (float)mw.sp[0].value;
-    if (!(mal >= 16.0f) || std::floor(mal) != mal || mal > 112.0f || ((int)mal % 16) != 0 || (int)mal >= A.n_up) return false;
+    if (!(mal >= 16.0f) || std::floor(mal) != mal || mal > 112.0f || ((int)mal % 16) != 0 || (int)mal >= A.n_up) {
+        note(ch, "the current branch with moving windows of %g samples: the lane-per-waveform kernel takes multiples of 16 up to 112", (double)mal);
+        return false;
+    }
     A.ma_len = (int)mal;
     A.ma_length = mal;
     for (int i = 6; i < n_ops; ++i) {

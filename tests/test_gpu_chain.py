@@ -288,3 +288,31 @@ def test_energy_chain_with_a_time_constant_per_event(dtype, L, trap):
         want[r] = oracle.fixed_time_pickoff(tr, tp[r:r + 1], "l")[0][0]
     ok = np.arange(n) != 7
     assert np.max(np.abs(got[1][ok] - want[ok]) / np.abs(want[ok])) <= 1e-6
+
+
+def test_current_branch_outside_its_kernel_says_why():
+    """the current branch with 40-sample moving windows (not a multiple of 16): on the interpreter, and the stage says so"""
+    from dspeed_amd.processing_chain import build_processing_chain
+
+    rng = np.random.default_rng(8)
+    n, L = 40, 2048
+    M = "dspeed.processors"
+    wf = np.cumsum(rng.standard_normal((n, L)), axis=1).astype(np.float32)
+    t0 = np.full(n, 700.0, np.float32)
+    for ma, kernel, word in ((48, "dsp_current_kernel", None), (40, "dsp_vm_kernel<float>", "40 samples")):
+        rec = {"outputs": ["A_max"], "processors": {
+            "wf_le": {"function": "windower", "module": M, "args": ["waveform", "t0", "wf_le(301, 'f')"]},
+            "curr": {"function": "avg_current", "module": M, "args": ["wf_le", 1, "curr(300, 'f')"]},
+            "curr_up": {"function": "upsampler", "module": M, "args": ["curr", "16", "curr_up(4784, 'f')"]},
+            "curr_av": {"function": "moving_window_multi", "module": M, "args": ["curr_up", str(ma), 3, 0, "curr_av"]},
+            "t_min, t_max, A_min, A_max": f"{M}.min_max(curr_av, t_min, t_max, A_min, A_max)"}}
+        chain, _, out = build_processing_chain(rec, {"waveform": wf, "t0": t0})
+        chain.execute()
+        names = [k for _w, k in chain.kernels()]
+        assert kernel in names, names
+        notes = [t for _w, t in chain.kernel_notes()]
+        assert (notes == []) if word is None else any(word in t for t in notes), notes
+        up = oracle.upsampler(oracle.avg_current(oracle.windower(wf, t0, 301)[0], 1)[0], 16, 4784)[0]
+        av = oracle.moving_window_multi(up, ma, 3, 0)[0]
+        want = oracle.min_max(av)[3]
+        assert np.max(np.abs(out["A_max"] - want) / np.abs(want)) <= 1e-6
