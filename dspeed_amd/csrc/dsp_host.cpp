@@ -2132,7 +2132,10 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         for (int k = 0; k < 4; ++k) A.out[k] = at(ch->cio_out[k]);
         A.scratch = ch->cur_scratch;
         const int64_t groups = (n_wf + 63) / 64;
-        const int blocks = (int)(groups < ch->cur_blocks_cap ? groups : ch->cur_blocks_cap);
+        // as many wavefronts as make every one walk the same number of groups (2 048 groups on 1 280 wavefronts are two rounds, the second
+        // three fifths empty; on 1 024 they are two full ones with a wavefront less per CU in each other's way)
+        const int64_t rounds = (groups + ch->cur_blocks_cap - 1) / ch->cur_blocks_cap;
+        const int blocks = (int)((groups + rounds - 1) / rounds);
         hipError_t e = (hipError_t)dsp_internal_launch_current(&A, n_wf, blocks, ch->cur_lds_bytes, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "current kernel launch failed: %s", hipGetErrorString(e));
         return post_err(ch, stream);
