@@ -1895,6 +1895,11 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
             if (ok && load[0] > 0 && load[1] > 0 && 5 * (load[0] < load[1] ? load[0] : load[1]) >= load[0] + load[1]) {
                 P.team = 2;
                 for (int i = first + 1; i < P.n_ops; ++i) P.ops[i].member = side[find(i)];
+                // a workgroup per team: the barrier at the end of a row then holds the two members of one row, not four rows' worth of
+                // wavefronts whose walks take different times (DSPEED_HIP_TEAM_WPB: the teams per workgroup, for the A/B)
+                int twpb = 1;
+                if (const char* tw = getenv("DSPEED_HIP_TEAM_WPB")) twpb = atoi(tw);
+                if (twpb >= 1 && twpb < ch->waves_per_block) ch->waves_per_block = P.waves_per_block = twpb;
             }
         }
     }

@@ -472,7 +472,14 @@ def test_two_wavefronts_per_row_give_the_same_results(monkeypatch):
     chain, _, out = build_processing_chain(recipes.ICPC, tb)
     chain.execute()
     g = chain._chain.geometry(n)
-    assert chain._chain.kernel_name.startswith("dsp_vm") and g["waves_per_block"] == 8, g
+    assert chain._chain.kernel_name.startswith("dsp_vm") and g["waves_per_block"] == 2, g   # (a workgroup per team)
+    monkeypatch.setenv("DSPEED_HIP_TEAM_WPB", "4")  # four teams to a workgroup: the last one has idle row slots that still meet its barriers
+    four, _, out4 = build_processing_chain(recipes.ICPC, tb)
+    four.execute()
+    assert four._chain.geometry(n)["waves_per_block"] == 8
+    for k in out4:
+        assert np.array_equal(np.asarray(out[k]), np.asarray(out4[k]), equal_nan=True), k
+    monkeypatch.delenv("DSPEED_HIP_TEAM_WPB")
     monkeypatch.setenv("DSPEED_HIP_NO_TEAMS", "1")
     single, _, ref = build_processing_chain(recipes.ICPC, tb)
     single.execute()
