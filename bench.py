@@ -66,8 +66,8 @@ KERNEL_SOURCES = ("dsp_energy.hip", "dsp_wave.h", "dsp_program.h")
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=10)  # (the first ~6 launches after start-up run 5-20 % slower: clocks, first touch)
+    ap.add_argument("--steps", type=int, default=400)  # (3 ms each: a timed region of more than a second, long enough for the driver's own GPU-activity samples)
+    ap.add_argument("--warmup", type=int, default=20)  # (the first ~6 launches after start-up run 5-20 % slower: clocks, first touch)
     ap.add_argument("--rows", type=int, default=0, help="rows per rank (default: 1 000 000 at N=1, 1 250 000 at N>1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the single-thread CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (profiling runs)")
@@ -78,6 +78,20 @@ def parse(argv=None):
     ap.add_argument("--fail-rank", type=int, default=-1, help="(dry run) this rank exits non-zero: tests the launcher's error path")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="launcher: seconds before the ranks are given up")
     return ap.parse_args(argv)
+
+
+def energy_recipe(tau: float, rise: int, flat: int) -> dict:
+    """BASELINE.json configs[1] / [3] in dspeed's recipe syntax: what an existing LEGEND configuration holds"""
+    return {
+        "outputs": ["trapEftp"],
+        "processors": {
+            "wf_blsub": "dspeed.processors.bl_subtract(waveform, baseline, wf_blsub)",
+            "wf_pz": {"function": "pole_zero", "module": "dspeed.processors", "args": ["wf_blsub", "db.pz.tau", "wf_pz"],
+                      "defaults": {"db.pz.tau": repr(float(tau))}},
+            "wf_trap": {"function": "trap_filter", "module": "dspeed.processors", "args": ["wf_pz", str(int(rise)), str(int(flat)), "wf_trap"]},
+            "trapEftp": {"function": "fixed_time_pickoff", "module": "dspeed.processors", "args": ["wf_trap", "t_pick", "'l'", "trapEftp"]},
+        },
+    }
 
 
 def kernel_source_hash() -> str:
@@ -233,21 +247,34 @@ def worker(args) -> int:
     device = local_rank % ndev
     set_device(device)
 
-    stream = Stream()
+    synth_stream = Stream()
     wf = DeviceArray((rows, WF_LEN), np.float32)
     bl = DeviceArray((rows,), np.float32)
     tp = DeviceArray((rows,), np.float32)
     out = DeviceArray((rows,), np.float32)
     _lib.check(L.dsp_synth_waveforms(wf.ptr, _lib.F32, rows, WF_LEN, WF_LEN, bl.ptr, tp.ptr, SEED, first_row, TAU, SIGMA,
-                                     RISE + 0.8 * FLAT, 9000.0, 11000.0, 500.0, 15000.0, stream.ptr), what="synth")
-    stream.sync()
+                                     RISE + 0.8 * FLAT, 9000.0, 11000.0, 500.0, 15000.0, synth_stream.ptr), what="synth")
+    synth_stream.sync()
 
-    chain = Chain(energy_chain_program(WF_LEN, TAU, RISE, FLAT, "l"), "energy_chain")
-    bufs = {"waveform": wf, "baseline": bl, "t_pick": tp, "trapEftp": out}
+    # The boundary a dspeed user crosses: the recipe as the reference writes it (module string "dspeed.processors",
+    # the pole-zero constant looked up as db.pz.tau with its default) through build_processing_chain (reference processing_chain.py:2363-2369);
+    # the table's columns are device-resident, so a pass is the chain's launch and nothing else.
+    from dspeed_amd import build_processing_chain
+
+    recipe = energy_recipe(TAU, RISE, FLAT)
+    tb_in = {"waveform": wf, "baseline": bl, "t_pick": tp}
+    chain, _mask, tb_out = build_processing_chain(recipe, tb_in, db_dict={})
+    tb_out["trapEftp"] = out
+    chain.link(tb_in, tb_out)
+    stream = chain.stream
+    kernel_name = dict(chain.kernels())["program"]
+    if WF_LEN in (1024, 2048, 4096, 8192) and kernel_name != "dsp_energy_rr_kernel":
+        print(f"bench.py: the recipe was given to {kernel_name}, not to the energy kernel: {chain.kernel_notes()}", file=sys.stderr)
+        return 6
 
     for _ in range(args.warmup):
-        chain.execute(bufs, rows, stream)
-    chain.check(stream)
+        chain.execute(0, rows, wait=False)
+    chain.wait()
 
     starts = [Event() for _ in range(args.steps)]
     stops = [Event() for _ in range(args.steps)]
@@ -256,12 +283,16 @@ def worker(args) -> int:
     t0 = time.perf_counter()
     for k in range(args.steps):
         starts[k].record(stream)
-        chain.execute(bufs, rows, stream)
+        chain.execute(0, rows, wait=False)
         stops[k].record(stream)
     sync()
     barrier()
     t1 = time.perf_counter()
-    chain.check(stream, row_offset=first_row)
+    try:
+        chain.wait()
+    except Exception as exc:  # a DSPFatal of the timed passes: rows of this rank's shard
+        print(f"bench.py: rank {rank} (rows from {first_row}): {exc}", file=sys.stderr)
+        return 3
     elapsed = max(gather_floats(t1 - t0))
     kernel_ms = [starts[k].elapsed_ms(stops[k]) for k in range(args.steps)]
     avg_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
@@ -296,6 +327,26 @@ def worker(args) -> int:
     achieved = rows * BYTES_PER_WF / avg_kernel_s / 1e9
     geo = chain.geometry(rows)
 
+    # the same program handed to dsp_chain_create directly (no recipe, no ProcessingChain): the number the boundary must not cost
+    raw = None
+    try:
+        raw_chain = Chain(energy_chain_program(WF_LEN, TAU, RISE, FLAT, "l"), "energy_chain")
+        raw_bufs = {"waveform": wf, "baseline": bl, "t_pick": tp, "trapEftp": out}
+        r0, r1 = Event(), Event()
+        n_raw = max(5, min(args.steps, 40))
+        for k in range(3 + n_raw):
+            if k == 3:
+                r0.record(stream)
+            raw_chain.execute(raw_bufs, rows, stream)
+        r1.record(stream)
+        sync()
+        raw_chain.check(stream, row_offset=first_row)
+        raw_ms = r0.elapsed_ms(r1) / n_raw
+        raw = {"entry": "dsp_chain_create (Chain(energy_chain_program))", "kernel": raw_chain.kernel_name, "kernel_ms_avg": raw_ms,
+               "frac": rows * BYTES_PER_WF / (raw_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "launches": n_raw}
+    except Exception as exc:  # a measurement extra: never fails the bench line
+        print(f"[bench] raw-chain measurement skipped: {exc}", file=sys.stderr)
+
     cpu = None
     if not args.no_cpu:  # rank 0, for every N: the other ranks have left, the timed region is over
         t = time.perf_counter()
@@ -328,7 +379,7 @@ def worker(args) -> int:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
-            if (t.get("rows") == rows and t.get("wf_len") == WF_LEN and t.get("kernel") == chain.kernel_name
+            if (t.get("rows") == rows and t.get("wf_len") == WF_LEN and t.get("kernel") == kernel_name
                     and t.get("kernel_source_hash") == src_hash and t.get("geometry") == geo):
                 traffic, traffic_src = t["hbm_bytes_per_launch"], f"recorded: profiles/{name} ({t.get('source')})"
                 break
@@ -367,7 +418,7 @@ def worker(args) -> int:
         "config": {"workload": (f"{rows} x {WF_LEN} float32 rows per GPU, fused bl_subtract->pole_zero(tau={TAU})->trap_filter({RISE},{FLAT})"
                                 "->fixed_time_pickoff('l'); " + ("BASELINE configs[1]" if n_gpus == 1 else "BASELINE configs[3] shard")),
                    "rows_per_gpu": rows, "wf_len": WF_LEN, "sharding": "event axis, no collectives", "device": info["name"],
-                   "kernel": chain.kernel_name, "lds_bytes_per_wave": geo["lds_bytes_per_wave"], "waves_per_block": geo["waves_per_block"],
+                   "entry": "build_processing_chain", "kernel": kernel_name, "lds_bytes_per_wave": geo["lds_bytes_per_wave"], "waves_per_block": geo["waves_per_block"],
                    "blocks": geo["blocks"], "ranks_seen": ranks_seen, "devices_seen": devices_seen, "env": env_switches,
                    "kernel_source_hash": src_hash},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -375,7 +426,7 @@ def worker(args) -> int:
                      "bytes_per_waveform": BYTES_PER_WF, "kernel_ms_avg": 1e3 * avg_kernel_s,
                      "kernel_ms_min": float(np.min(kernel_ms)), "kernel_ms_avg_per_rank_min": float(np.min(rank_kernel_ms)),
                      "kernel_ms_avg_per_rank_max": float(np.max(rank_kernel_ms)), "measured_stream_read_GBps": stream_gbps,
-                     "frac_of_measured_stream_read": (achieved / stream_gbps) if stream_gbps else None},
+                     "frac_of_measured_stream_read": (achieved / stream_gbps) if stream_gbps else None, "raw_chain": raw},
         "cpu_baseline": cpu,
         "parity_max_rel_vs_oracle": parity,
         "parity_bar": PARITY_BAR,

@@ -224,11 +224,14 @@ def shard_bounds(n_rows: int, n_shards: int) -> list[tuple[int, int]]:
 
 
 class DeviceTeam:
-    """One worker thread per entry of ``devices`` (an ordinal may appear twice: two handles and two streams on one GPU).  A worker makes
-    its device current once and keeps everything it creates -- chain handle, streams, staging buffers -- for its lifetime."""
+    """One worker thread per entry of ``devices`` (an ordinal may appear twice: two handles and two streams on one GPU).  A worker is started
+    when the team first runs something, makes its device current once and lives until ``close()``: what it creates -- chain handles, streams,
+    the page-locked bounce buffer of its synchronous copies (thread-local, ``device._Bounce``) -- is created once per ``build_dsp`` call, and a
+    chain is served by the thread that built it."""
 
     def __init__(self, devices: list[int]):
         self.devices = list(devices)
+        self._workers = []  # (thread, queue of (callable(device), slot list, index, done semaphore) or None)
 
     def __len__(self):
         return max(1, len(self.devices))
@@ -237,30 +240,67 @@ class DeviceTeam:
     def parallel(self) -> bool:
         return len(self.devices) > 1
 
+    def _start(self):
+        def serve(dev, jobs):
+            try:
+                set_device(dev)
+                failed = None
+            except BaseException as e:  # noqa: BLE001 -- every job of this worker reports it
+                failed = e
+            while True:
+                item = jobs.get()
+                if item is None:
+                    return
+                job, results, errors, k, done = item
+                try:
+                    if failed is not None:
+                        raise failed
+                    results[k] = job(dev)
+                except BaseException as e:  # noqa: BLE001 -- handed to the caller of run()
+                    errors[k] = e
+                finally:
+                    done.release()
+
+        for k, dev in enumerate(self.devices):
+            q: queue.Queue = queue.Queue()
+            t = threading.Thread(target=serve, args=(dev, q), name=f"dspeed-dev{dev}-{k}", daemon=True)
+            t.start()
+            self._workers.append((t, q))
+
+    def submit(self, k: int, job, results: list, errors: list, index: int, done: threading.Semaphore) -> None:
+        """queue ``job(device)`` on worker k; results[index] / errors[index] receive what it returns / raises, ``done`` is released after it"""
+        if not self._workers:
+            self._start()
+        self._workers[k % len(self._workers)][1].put((job, results, errors, index, done))
+
     def run(self, jobs: list):
         """jobs[k] = callable(device) run on worker k; returns their results in order; the error of the lowest-numbered failed job is raised
         after every worker has finished (a DSPFatal of an earlier shard is the one the serial loop would have met first)"""
         if not self.devices:
             return [job(None) for job in jobs]
         results, errors = [None] * len(jobs), [None] * len(jobs)
-
-        def work(k):
-            try:
-                dev = self.devices[k % len(self.devices)]
-                set_device(dev)
-                results[k] = jobs[k](dev)
-            except BaseException as e:  # noqa: BLE001 -- handed to the caller below
-                errors[k] = e
-
-        threads = [threading.Thread(target=work, args=(k,), name=f"dspeed-dev{self.devices[k % len(self.devices)]}-{k}") for k in range(len(jobs))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        done = threading.Semaphore(0)
+        for k, job in enumerate(jobs):
+            self.submit(k, job, results, errors, k, done)
+        for _ in jobs:
+            done.acquire()
         for e in errors:
             if e is not None:
                 raise e
         return results
+
+    def close(self):
+        workers, self._workers = self._workers, []
+        for _t, q in workers:
+            q.put(None)
+        for t, _q in workers:
+            t.join()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ----------------------------------------------------------------------------------------------------------------------------------
@@ -369,31 +409,26 @@ def _run_chunks(source, recipe, db_block, outputs, rows: RowSelection, buffer_le
     done = 0
     try:
         if not team.parallel:
-            for i_entry, n, cols in chunks:
-                if team.devices:
-                    set_device(team.devices[0])
-                deliver(i_entry, n, *workers[0].process(i_entry, n, cols))
+            for i_entry, n, cols in chunks:  # (one device: its worker thread, which built the chain, also serves it)
+                deliver(i_entry, n, *team.run([lambda _dev, a=(i_entry, n, cols): workers[0].process(*a)])[0])
                 done += n
             return done
-        # one thread per device takes chunks from its own queue; results come back through one queue and are delivered in file order
-        todo = [queue.Queue(maxsize=2) for _ in workers]
+        # the team's worker of a device (the thread that built its chain) takes that device's chunks one after the other; results come back
+        # through one queue and are delivered in file order.  At most two chunks wait per device (read-ahead without holding the whole file).
         finished: queue.Queue = queue.Queue()
+        room = [threading.Semaphore(2) for _ in workers]
+        sink_r, sink_e, sink_done = [None], [None], threading.Semaphore(0)  # (the jobs report through `finished`)
 
-        def serve(k):
-            set_device(team.devices[k])
-            while True:
-                item = todo[k].get()
-                if item is None:
-                    return
-                seq, i_entry, n, cols = item
+        def job_of(k, seq, i_entry, n, cols):
+            def job(_dev):
                 try:
                     finished.put((seq, i_entry, n, workers[k].process(i_entry, n, cols), None))
                 except BaseException as e:  # noqa: BLE001
                     finished.put((seq, i_entry, n, None, e))
+                finally:
+                    room[k].release()
+            return job
 
-        threads = [threading.Thread(target=serve, args=(k,), name=f"dspeed-dev{team.devices[k]}-{k}") for k in range(len(workers))]
-        for t in threads:
-            t.start()
         waiting, next_seq, sent, failure = {}, 0, 0, None
 
         def drain(block):
@@ -410,25 +445,27 @@ def _run_chunks(source, recipe, db_block, outputs, rows: RowSelection, buffer_le
                 if err is not None:
                     failure = failure or err
                 elif failure is None:
-                    deliver(i_entry, n, *result)
-                    done += n
+                    try:  # (a failing delivery -- a write error -- ends the table like a failing chunk: later chunks are collected, not written)
+                        deliver(i_entry, n, *result)
+                        done += n
+                    except BaseException as e:  # noqa: BLE001
+                        failure = e
 
         try:
             for item in chunks:
                 if failure is not None:
                     break
-                todo[sent % len(workers)].put((sent, *item))
+                k = sent % len(workers)
+                while not room[k].acquire(timeout=0.05):
+                    drain(block=False)
+                team.submit(k, job_of(k, sent, *item), sink_r, sink_e, 0, sink_done)
                 sent += 1
                 while not finished.empty():
                     seq, i_entry, n, result, err = finished.get()
                     waiting[seq] = (i_entry, n, result, err)
                 drain(block=False)
         finally:
-            for q in todo:
-                q.put(None)
             drain(block=True)
-            for t in threads:
-                t.join()
         if failure is not None:
             raise failure
     finally:
@@ -641,20 +678,23 @@ def build_dsp(raw_in, dsp_out: str | None = None, dsp_config=None, lh5_tables=No
     else:
         sink = _Lh5Sink(dsp_out, write_mode, rows.i_start)
 
-    for name in source.names:
-        recipe = book.recipe_for(name)
-        if recipe is None:  # (dsp_config may be None with chan_config: channels without a match are skipped)
-            continue
-        db_block = book.database_for(name)
-        friends = friends_of(recipe, db_block)
-        dsp_name = name.replace("raw", "dsp")
-        if chunked:
-            deliver, close = sink.chunk_writer(dsp_name)
-            _run_chunks(source.open(name, friends), recipe, db_block, outputs, rows, buffer_len, team, deliver)
-            close()
-        else:
-            table = source.with_friends(name, friends) if friends else source.tables[name]
-            sink.table_done(dsp_name, _run_array_table(table, recipe, db_block, outputs, rows, buffer_len, team))
+    try:
+        for name in source.names:
+            recipe = book.recipe_for(name)
+            if recipe is None:  # (dsp_config may be None with chan_config: channels without a match are skipped)
+                continue
+            db_block = book.database_for(name)
+            friends = friends_of(recipe, db_block)
+            dsp_name = name.replace("raw", "dsp")
+            if chunked:
+                deliver, close = sink.chunk_writer(dsp_name)
+                _run_chunks(source.open(name, friends), recipe, db_block, outputs, rows, buffer_len, team, deliver)
+                close()
+            else:
+                table = source.with_friends(name, friends) if friends else source.tables[name]
+                sink.table_done(dsp_name, _run_array_table(table, recipe, db_block, outputs, rows, buffer_len, team))
+    finally:
+        team.close()
 
     if isinstance(sink, _Lh5Sink):
         return None

@@ -206,6 +206,7 @@ struct dsp_chain {
     dsp_chain* scale_feeder = nullptr;  // (on the float16 FIR chain)
     dsp_chain* scale_sink = nullptr;    // (on the pole-zero rows chain)
     const void* fed_rows_ptr = nullptr;
+    void* fed_stream = nullptr;  // the stream of the producer's launch: its scales and flags are ordered ahead of a consumer on that stream only
     int64_t fed_n_wf = -1, fed_stride = 0;
     int32_t fed_len = 0;
     // a program of scalar ops only (dsp_scalar.hip: a row per lane)
@@ -2019,6 +2020,21 @@ static void rr_geometry(const dsp_chain* ch, int64_t n_wf, int* wpb_out, int* bl
     *blocks_out = (int)(want < cap ? want : cap);
 }
 
+// launch geometry of the current-branch kernel (dsp_current.hip): persistent wavefronts, as many as a CU's LDS takes (at most 8 per CU) ...
+static int current_blocks_cap(const dsp_chain* ch) {
+    int per_cu = LDS_BYTES_PER_CU / ch->cur_lds_bytes;
+    if (per_cu > 8) per_cu = 8;
+    return ch->num_cu * (per_cu < 1 ? 1 : per_cu);
+}
+// ... and of those as many as make every one walk the same number of 64-row groups (2 048 groups on 1 280 wavefronts are two rounds, the
+// second three fifths empty; on 1 024 they are two full ones with a wavefront less per CU in each other's way).  One helper for the launch
+// and for dsp_chain_geometry.
+static int current_blocks(const dsp_chain* ch, int64_t n_wf) {
+    const int64_t groups = (n_wf + 63) / 64, cap = current_blocks_cap(ch);
+    const int64_t rounds = (groups + cap - 1) / cap;
+    return (int)((groups + rounds - 1) / (rounds < 1 ? 1 : rounds));
+}
+
 // makes `device` current for the calling thread and puts the previous one back when it goes out of scope
 struct DeviceScope {
     int prev = -1;
@@ -2100,6 +2116,7 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
             A.row_scale = (float*)const_cast<void*>(sink->f16.row_scale);
             A.row_flags = (uint32_t*)const_cast<void*>(sink->f16.row_flags);
             sink->fed_rows_ptr = A.out;
+            sink->fed_stream = stream;
             sink->fed_n_wf = n_wf;
             sink->fed_stride = A.out_stride;
             sink->fed_len = A.len;
@@ -2124,9 +2141,7 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
     }
     if (ch->cur_ok && ch->fused_on && (reinterpret_cast<uintptr_t>(io_ptrs[ch->cio_wf]) & 15u) == 0) {
         // persistent wavefronts, as many as a CU's LDS takes (at most 8 per CU): each keeps its scratch area for the groups of rows it walks
-        int per_cu = LDS_BYTES_PER_CU / ch->cur_lds_bytes;
-        if (per_cu > 8) per_cu = 8;
-        const int cap = ch->num_cu * (per_cu < 1 ? 1 : per_cu);
+        const int cap = current_blocks_cap(ch);
         if (!ch->cur_scratch) {
             HIP_TRY(hipMalloc((void**)&ch->cur_scratch, (size_t)cap * (size_t)ch->cur.scratch_per_wave * sizeof(float)));
             ch->cur_blocks_cap = cap;
@@ -2136,11 +2151,7 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         A.t0 = (const float*)at(ch->cio_t0);
         for (int k = 0; k < 4; ++k) A.out[k] = at(ch->cio_out[k]);
         A.scratch = ch->cur_scratch;
-        const int64_t groups = (n_wf + 63) / 64;
-        // as many wavefronts as make every one walk the same number of groups (2 048 groups on 1 280 wavefronts are two rounds, the second
-        // three fifths empty; on 1 024 they are two full ones with a wavefront less per CU in each other's way)
-        const int64_t rounds = (groups + ch->cur_blocks_cap - 1) / ch->cur_blocks_cap;
-        const int blocks = (int)((groups + rounds - 1) / rounds);
+        const int blocks = current_blocks(ch, n_wf);
         hipError_t e = (hipError_t)dsp_internal_launch_current(&A, n_wf, blocks, ch->cur_lds_bytes, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "current kernel launch failed: %s", hipGetErrorString(e));
         return post_err(ch, stream);
@@ -2158,7 +2169,8 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
             if (rc != DSP_OK) return rc;
             // scales and flags already there?  Only if the kernel in front wrote exactly the rows this one reads, and just now
             const void* first = (const char*)A.wf + (size_t)A.wf_offset * sizeof(float);
-            ch->f16.rows_done = (ch->scale_feeder && A.in_kind == 0 && A.sub_mode == 0 && ch->fed_rows_ptr == first && ch->fed_n_wf == n_wf &&
+            // -- and on this stream: scales and flags are written by the producer's launch, so only stream order puts them ahead of this one
+            ch->f16.rows_done = (ch->scale_feeder && A.in_kind == 0 && A.sub_mode == 0 && ch->fed_rows_ptr == first && ch->fed_n_wf == n_wf && ch->fed_stream == stream &&
                                  ch->fed_stride == A.wf_stride && ch->fed_len == A.n) ? 1 : 0;
             ch->fed_n_wf = -1;  // (a note is good for one execute)
         }
@@ -2306,12 +2318,9 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
         return DSP_OK;
     }
     if (ch->cur_ok && ch->fused_on) {
-        int per_cu = LDS_BYTES_PER_CU / ch->cur_lds_bytes;
-        if (per_cu > 8) per_cu = 8;
-        const int64_t groups = (n_wf + 63) / 64, cap = (int64_t)ch->num_cu * (per_cu < 1 ? 1 : per_cu);
         if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->cur_lds_bytes;
         if (waves_per_block) *waves_per_block = 1;
-        if (blocks) *blocks = (int)(groups < cap ? groups : cap);
+        if (blocks) *blocks = current_blocks(ch, n_wf);
         return DSP_OK;
     }
     if (ch->fir_ok && ch->fused_on) {  // 8 wavefronts per 64 waveforms and kernel

@@ -2252,8 +2252,11 @@ __global__ void __launch_bounds__(256 * TEAM, TEAM > 1 ? 1 : (FIR ? 2 : 3)) dsp_
     const int n_ops = prog->n_ops;
     // dsp_chain_profile: the first wavefront of every workgroup times each op of its waveforms with the shader clock
     unsigned long long* prof = prog->prof;
-    const bool sampled = prof != nullptr && wave_raw == 0;
+    // (of a team both members of the workgroup's first row slot are sampled: each closes an interval into the op IT ran last, so the cycles of
+    // an op land on that op whichever member ran it; an op both run -- the LOAD -- collects both members' cycles)
+    const bool sampled = prof != nullptr && wave_raw < TEAM;
     unsigned long long t_prev = 0;
+    int prof_last = -1;
     for (int64_t base = (int64_t)blockIdx.x * wpb;; base += total_waves) {
         const int64_t row = base + wave;
         if (TEAM == 1 ? row >= n_wf : base >= n_wf) break;  // (a team's workgroup leaves together: every wavefront meets every barrier)
@@ -2263,7 +2266,10 @@ __global__ void __launch_bounds__(256 * TEAM, TEAM > 1 ? 1 : (FIR ? 2 : 3)) dsp_
         }
         cx.row = row;
         cx.nan_all = cx.nan_some = 0;
-        if (sampled) t_prev = __builtin_amdgcn_s_memtime();
+        if (sampled) {
+            t_prev = __builtin_amdgcn_s_memtime();
+            prof_last = -1;
+        }
         // wave priority rises with the progress through the row's program (levels 0..3 over the op list): of the wavefronts that share a
         // SIMD the one closest to finishing its row issues first, the others' loads and stores fill its gaps -- the arbitration that took the
         // specialised energy kernel from 63 % to 69 % of the HBM peak (dsp_energy.hip); C2 on this interpreter 137 -> 148 M waveforms/s
@@ -2284,10 +2290,11 @@ __global__ void __launch_bounds__(256 * TEAM, TEAM > 1 ? 1 : (FIR ? 2 : 3)) dsp_
                     else __builtin_amdgcn_s_setprio(3);
                 }
             }
-            if (prof && i > 0 && sampled) {  // close the previous op's interval (one s_memtime per op when profiling, none otherwise)
+            if (sampled) {  // close the interval of the op this wavefront ran last (one s_memtime per op when profiling, none otherwise)
                 const unsigned long long now = __builtin_amdgcn_s_memtime();
-                if (lane_id() == 0) atomicAdd(prof + (i - 1), now - t_prev);
+                if (prof_last >= 0 && lane_id() == 0) atomicAdd(prof + prof_last, now - t_prev);
                 t_prev = now;
+                prof_last = i;
             }
             switch (op.opcode) {
                 case DSP_OP_LOAD: op_load(cx, op); break;
@@ -2334,8 +2341,8 @@ __global__ void __launch_bounds__(256 * TEAM, TEAM > 1 ? 1 : (FIR ? 2 : 3)) dsp_
         if (sampled) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             if (lane_id() == 0) {
-                atomicAdd(prof + (n_ops - 1), now - t_prev);
-                atomicAdd(prof + n_ops, 1ull);
+                if (prof_last >= 0) atomicAdd(prof + prof_last, now - t_prev);
+                if (member == 0) atomicAdd(prof + n_ops, 1ull);
             }
         }
         if (TEAM > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the image is free for the next row

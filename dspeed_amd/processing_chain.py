@@ -264,6 +264,7 @@ class ProcessingChain:
         self._chain = None
         self._stream = None
         self._lanes = []          # [0] = the chain itself; further lanes for pieces of a batch that run at the same time (_lane)
+        self._pending = None      # (start, stop, lane) of a pass queued with execute(wait=False)
         self._dev = {}
         self._tb_in = None
         self._tb_out = None
@@ -297,6 +298,11 @@ class ProcessingChain:
         if self._lanes and self._lanes[0].tail is not None:
             rep.append(("scalar tail of the program", self._lanes[0].tail.kernel_name))
         return rep
+
+    def geometry(self, n_rows: int) -> dict:
+        """launch geometry of the program's kernel for a pass over ``n_rows`` rows (``dsp_chain_geometry``)"""
+        self._ensure()
+        return self._chain.geometry(n_rows)
 
     def kernel_notes(self) -> list:
         """[(what, reason)] for every stage / program that runs on the generic interpreter although its ops are those of a specialised kernel
@@ -438,7 +444,31 @@ class ProcessingChain:
                 self._pins[key] = None
         return self._pins[key] is not None
 
-    def execute(self, start: int = 0, stop: int | None = None) -> None:
+    @property
+    def stream(self) -> Stream:
+        """the stream the chain's kernels are launched on (lane 0: what a pass over device-resident columns uses) -- for HIP events around a pass"""
+        self._ensure()
+        return self._stream
+
+    def wait(self) -> None:
+        """Finish a pass started with ``execute(..., wait=False)``: wait for its kernels and raise the DSPFatal a row met, as ``execute`` itself
+        does otherwise."""
+        pending, self._pending = self._pending, None
+        if pending is None:
+            return
+        a, b, lane = pending
+        try:
+            for ch in lane.stage_chains:
+                ch.check(lane.stream, row_offset=a)
+            lane.chain.check(lane.stream, row_offset=a)
+        except DSPFatal as e:  # the reference annotates and re-raises (processing_chain.py:1154-1159)
+            if e.wf_range is None:
+                e.wf_range = range(a, b)
+            raise
+
+    def execute(self, start: int = 0, stop: int | None = None, wait: bool = True) -> None:
+        """``wait=False`` (columns resident on the device only): the pass is queued on ``stream`` and the call returns; ``wait()`` -- or the next
+        ``execute`` -- finishes it.  The device's error word keeps the first DSPFatal of the passes queued since the last check."""
         if stop is None:
             stop = self._buffer_len
         n = stop - start
@@ -499,6 +529,30 @@ class ProcessingChain:
         else:
             sizes = [piece] * (n // piece) + ([n % piece] if n % piece else [])
         n_pieces = len(sizes)
+        if row_bytes == 0 and n_pieces == 1:
+            # every column lives on the device and the stages' rows fit: the launches of one pass on the chain's own stream, no staging, no
+            # feeder thread (a 3 ms pass of the energy chain does not pay for either)
+            lane = self._lane(0)
+            if self._pending is not None and self._pending[:2] != (start, stop):
+                self.wait()  # (a DSPFatal's row is counted from the first row of its pass: queued passes must cover the same rows)
+            bufs = dict(self._dev)
+            for name, col in dev_in.items():
+                bufs[name] = col.view_rows(start, stop)
+            for name, col in dev_out.items():
+                bufs[name] = col.view_rows(start, stop)
+            t = time.perf_counter()
+            self._run_aux(bufs, n, lane.stream, lane)
+            self._handover_bufs(bufs, n, lane)
+            lane.chain.execute(bufs, n, lane.stream)
+            self._run_tail(bufs, n, lane.stream, lane)
+            self._pending = (start, stop, lane)
+            if wait:
+                self.wait()
+                self._timing["kernel"] += time.perf_counter() - t
+            return
+        if not wait:
+            raise ValueError("execute(wait=False) needs every linked column on the device (host columns are streamed in pieces and finished in order)")
+        self.wait()
         n_lanes = min(self.pieces_in_flight, n_pieces)  # pieces whose kernels are on the device at the same time
         n_slots = min(n_lanes + 2, n_pieces)            # ... + the one on the link + the one being copied
         # piece buffers live as long as the chain (the reference pre-allocates its ProcChainVar buffers the same way,

@@ -287,7 +287,10 @@ const char* dsp_chain_kernel_note(dsp_chain* chain);
 /* Two chains of one recipe, run one behind the other on the same rows: `producer` writes pole-zero corrected rows ([bl_subtract ->] pole_zero
  * -> rows, the dsp_pz_rows_kernel shape), `consumer` is a float16 matrix-core FIR over float32 rows.  After this call the producer leaves,
  * with the rows, the per-row scale and flags the FIR would otherwise read every row once more to find; dsp_chain_execute of the consumer uses
- * them when its input is exactly what the producer's last execute wrote (address, stride, length, row count) and finds them itself otherwise.
+ * them when its input is exactly what the producer's last execute wrote (address, stride, length, row count) AND it is executed on the stream
+ * that execute was queued on (only stream order puts the scales ahead of the FIR), and finds them itself otherwise.  The caller's part of the
+ * contract: nothing rewrites those rows between the producer's execute and the consumer's (the library cannot see a write to caller memory);
+ * the note is good for one execute of the consumer.
  * Returns 1 when the pair was linked, 0 when the chains are not of these shapes (nothing changes), < 0 on an argument error.  The link ends
  * with either chain's dsp_chain_destroy.  No counterpart in the reference (its processors exchange nothing but their arrays,
  * processing_chain.py:1144-1163); results are the same with and without it. */
