@@ -59,6 +59,14 @@ class Op(C.Structure):
                 ("sp", ScalarArg * 4)]
 
 
+class PlanInfo(C.Structure):  # dsp_plan_info
+    _fields_ = [("kernel", C.c_char * 64), ("note", C.c_char * 256), ("lds_bytes_per_wave", C.c_int32), ("waves_per_block", C.c_int32),
+                ("team", C.c_int32), ("n_device_ops", C.c_int32), ("lds_elems_per_wave", C.c_int32), ("sreg_off", C.c_int32),
+                ("scratch_off", C.c_int32), ("n_slots", C.c_int32), ("slot_base", C.c_int32 * MAX_SLOTS), ("slot_elems", C.c_int32 * MAX_SLOTS),
+                ("slot_first_op", C.c_int32 * MAX_SLOTS), ("slot_last_op", C.c_int32 * MAX_SLOTS), ("slot_off", C.c_int32 * MAX_SLOTS),
+                ("slot_pitch", C.c_int32 * MAX_SLOTS), ("slot_chunk", C.c_int32 * MAX_SLOTS)]
+
+
 _lib = None
 
 
@@ -101,6 +109,7 @@ def lib():
         "dsp_event_elapsed_ms": [vp, vp, C.POINTER(C.c_float)],
         "dsp_chain_create": [C.POINTER(Op), C.c_int, C.POINTER(IoDesc), C.c_int, C.POINTER(i32), C.c_int, C.c_int, C.c_int,
                              C.POINTER(vp)],
+        "dsp_chain_plan": [C.POINTER(Op), C.c_int, C.POINTER(IoDesc), C.c_int, C.POINTER(i32), C.c_int, C.c_int, C.c_int, C.POINTER(PlanInfo)],
         "dsp_chain_execute": [vp, C.POINTER(vp), i64, vp],
         "dsp_chain_check": [vp, vp, pi64],
         "dsp_chain_destroy": [vp],
@@ -167,7 +176,7 @@ EXPORTS = [
     "dsp_device_count", "dsp_set_device", "dsp_get_device", "dsp_device_info", "dsp_malloc", "dsp_free", "dsp_host_alloc", "dsp_host_register", "dsp_host_unregister", "dsp_stream_wait_event",
     "dsp_host_free", "dsp_memset", "dsp_h2d", "dsp_d2h", "dsp_h2d_async", "dsp_d2h_async", "dsp_stream_create", "dsp_stream_destroy",
     "dsp_stream_sync", "dsp_sync", "dsp_event_create", "dsp_event_destroy", "dsp_event_record", "dsp_event_sync",
-    "dsp_event_elapsed_ms", "dsp_last_error", "dsp_fatal_message", "dsp_version", "dsp_chain_create", "dsp_chain_execute",
+    "dsp_event_elapsed_ms", "dsp_last_error", "dsp_fatal_message", "dsp_version", "dsp_chain_create", "dsp_chain_plan", "dsp_chain_execute",
     "dsp_chain_check", "dsp_chain_destroy", "dsp_chain_geometry", "dsp_chain_kernel_name", "dsp_chain_kernel_note", "dsp_chain_share_row_scales", "dsp_chain_set_fused", "dsp_chain_set_async_check", "dsp_bl_subtract_f32", "dsp_pole_zero_f32",
     "dsp_double_pole_zero_f32", "dsp_pole_zero_col_f32", "dsp_double_pole_zero_col_f32", "dsp_pole_zero_col_f64", "dsp_double_pole_zero_col_f64", "dsp_trap_filter_f32", "dsp_trap_norm_f32", "dsp_asym_trap_filter_f32", "dsp_fixed_time_pickoff_f32",
     "dsp_install_abort_trace", "dsp_uninstall_abort_trace", "dsp_chain_profile", "dsp_chain_profile_read", "dsp_min_max_norm_f32", "dsp_min_max_norm_f64", "dsp_time_point_thresh_f32", "dsp_interpolated_time_point_thresh_f32", "dsp_interpolated_time_point_thresh_f64", "dsp_min_max_f32", "dsp_mean_below_threshold_f32", "dsp_mean_below_threshold_f64", "dsp_windower_f32", "dsp_windower_f64", "dsp_avg_current_f32",

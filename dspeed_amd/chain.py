@@ -63,6 +63,38 @@ class Program:
         return len(self.ops) - 1
 
 
+def _c_program(program: Program):
+    """the program as the C structs of dsp_chain_create / dsp_chain_plan"""
+    n_ops, n_io = len(program.ops), len(program.io)
+    ops = (_lib.Op * max(n_ops, 1))()
+    for i, (opcode, dst, src, io, ip, sp) in enumerate(program.ops):
+        o = ops[i]
+        o.opcode, o.dst, o.src, o.io = opcode, dst, src, io
+        for k, v in enumerate(ip):
+            o.ip[k] = v
+        for k, s in enumerate(sp):
+            o.sp[k].kind, o.sp[k].index, o.sp[k].value = s.kind, s.index, s.value
+    ios = (_lib.IoDesc * max(n_io, 1))()
+    for i, (_, kind, code, length, offset, stride) in enumerate(program.io):
+        d = ios[i]
+        d.kind, d.dtype, d.len, d.offset, d.row_stride = kind, code, length, offset, stride
+    slots = (C.c_int32 * max(len(program.slots), 1))(*program.slots)
+    return ops, n_ops, ios, n_io, slots, len(program.slots)
+
+
+def plan(program: Program, compute_dtype=np.float32, name: str = "chain") -> dict:
+    """What ``Chain(program)`` would be given -- kernel, note, LDS layout -- without a device (``dsp_chain_plan``): the same validation and the
+    same errors as creating the chain, on a machine with or without a GPU."""
+    info = _lib.PlanInfo()
+    rc = _lib.lib().dsp_chain_plan(*_c_program(program), program.n_sregs, dtype_code(np.dtype(compute_dtype)), C.byref(info))
+    _lib.check(rc, what=name)
+    n = info.n_slots
+    out = {k: getattr(info, k) for k in ("lds_bytes_per_wave", "waves_per_block", "team", "n_device_ops", "lds_elems_per_wave", "sreg_off", "scratch_off")}
+    out.update(kernel=info.kernel.decode(), note=info.note.decode(),
+               slots=[{k: getattr(info, "slot_" + k)[s] for k in ("base", "elems", "first_op", "last_op", "off", "pitch", "chunk")} for s in range(n)])
+    return out
+
+
 class Chain:
     """A compiled chain bound to the current device."""
 
@@ -71,22 +103,8 @@ class Chain:
         self.name = name
         self.compute_dtype = np.dtype(compute_dtype)
         L = _lib.lib()
-        n_ops, n_io = len(program.ops), len(program.io)
-        ops = (_lib.Op * max(n_ops, 1))()
-        for i, (opcode, dst, src, io, ip, sp) in enumerate(program.ops):
-            o = ops[i]
-            o.opcode, o.dst, o.src, o.io = opcode, dst, src, io
-            for k, v in enumerate(ip):
-                o.ip[k] = v
-            for k, s in enumerate(sp):
-                o.sp[k].kind, o.sp[k].index, o.sp[k].value = s.kind, s.index, s.value
-        ios = (_lib.IoDesc * max(n_io, 1))()
-        for i, (_, kind, code, length, offset, stride) in enumerate(program.io):
-            d = ios[i]
-            d.kind, d.dtype, d.len, d.offset, d.row_stride = kind, code, length, offset, stride
-        slots = (C.c_int32 * max(len(program.slots), 1))(*program.slots)
         handle = C.c_void_p()
-        rc = L.dsp_chain_create(ops, n_ops, ios, n_io, slots, len(program.slots), program.n_sregs, dtype_code(self.compute_dtype), C.byref(handle))
+        rc = L.dsp_chain_create(*_c_program(program), program.n_sregs, dtype_code(self.compute_dtype), C.byref(handle))
         _lib.check(rc, what=name)
         self._h = handle
         self.io_names = [io[0] for io in program.io]

@@ -1236,7 +1236,9 @@ class _Builder:
                 raise ProcessingChainError(f"slice bound with time units in '{src}' on a waveform without a sampling period")
             v = float(v) / base.period
         if isinstance(v, (Var, SExpr, tuple, Grid)):
-            raise NotImplementedError(f"slice bounds must be constants: '{src}'")
+            # the reference refuses a variable as a slice bound with exactly this (:1016-1022); a window that starts at a per-event time is
+            # the `windower` processor's job there (icpc-dsp-config.json: wf_le)
+            raise ProcessingChainError(f"Slice values must be constants: '{src}'")
         return int(round(float(v)))
 
     def _round(self, f, a, src):
@@ -1479,8 +1481,6 @@ class _Builder:
             out = SExpr(None, (), name, v.unit, v.is_coord, None)
         if declared is not None:  # numpy.add(a, b, out) written as a processor: `out` is a declared variable with its own unit
             out = SExpr(None, (), declared.name, declared.unit, declared.is_coord, declared.grid)
-        if sym in "*/" and (isinstance(a, Quantity) or isinstance(b, Quantity)):
-            raise NotImplementedError(f"'{src}': multiplying / dividing a per-event variable by a time is not supported")
         a0, b0 = a, b
         _, (a, b, _o) = _resolve(self, "ssS", [a, b, out], expression=True)
         if int_dt is not None and all(x is x0 for x, x0 in ((a, a0), (b, b0)) if _is_scalar(x0)):  # (a converted coordinate is a float)

@@ -261,6 +261,25 @@ typedef struct dsp_chain dsp_chain; /* opaque */
  * Validates the program and every constant-only DSPFatal condition; on failure returns the code and *out = NULL. */
 int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_io, const int32_t* slot_len, int n_slots,
                      int n_sregs, int compute_dtype, dsp_chain** out);
+/* What dsp_chain_create would decide about the program -- validation (every constant-only DSPFatal included), LDS packing, the kernel it
+ * would run on -- WITHOUT a device: no HIP call is made, so it also works on a machine that has none (the build container, a sanitizer
+ * build of the planner: tests/test_planner_fuzz.py).  Same return codes and dsp_last_error() texts as dsp_chain_create.  The reference has
+ * no counterpart (ProcessorManager.__init__ validates while it allocates, processing_chain.py:1527-1775). */
+typedef struct dsp_plan_info {
+    char kernel[64];             /* dsp_chain_kernel_name of the chain that would be created */
+    char note[256];              /* dsp_chain_kernel_note */
+    int32_t lds_bytes_per_wave;  /* of the generic interpreter's layout (what dsp_chain_geometry reports for it) */
+    int32_t waves_per_block;
+    int32_t team;                /* wavefronts per row on the interpreter: 1 or 2 */
+    int32_t n_device_ops;        /* ops of the device program: the caller's, plus region-clearing ops, minus folded ones */
+    int32_t lds_elems_per_wave, sreg_off, scratch_off; /* layout of a wavefront's LDS in elements of the compute type */
+    int32_t n_slots;
+    int32_t slot_base[DSP_MAX_SLOTS], slot_elems[DSP_MAX_SLOTS];   /* region of slot s: [base, base + elems) incl. guard and tail */
+    int32_t slot_first_op[DSP_MAX_SLOTS], slot_last_op[DSP_MAX_SLOTS]; /* lifetime in ops of the caller's program */
+    int32_t slot_off[DSP_MAX_SLOTS], slot_pitch[DSP_MAX_SLOTS], slot_chunk[DSP_MAX_SLOTS]; /* sample 0, lane pitch, samples per lane */
+} dsp_plan_info;
+int dsp_chain_plan(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_io, const int32_t* slot_len, int n_slots, int n_sregs,
+                   int compute_dtype, dsp_plan_info* info);
 /* Enqueue one pass over n_wf rows on `stream` (asynchronous).  io_ptrs[k] = device pointer for binding k. */
 int dsp_chain_execute(dsp_chain* chain, void* const* io_ptrs, int64_t n_wf, void* stream);
 /* Wait for the chain's stream work and return 0 or the first data-dependent DSPFatal (code > 0) with the
