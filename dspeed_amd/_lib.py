@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("DSPEED_HIP_LIB") or os.path.join(_HERE, "libdspeed_hi
 # ---- constants of include/dspeed_hip.h
 OK, ERR_HIP, ERR_ARG, ERR_UNSUPPORTED, ERR_TOO_LONG = 0, -1, -2, -3, -4
 E_ZERODIV = 17
-F32, F64, I16, U16, I32, U32, BOOL = range(7)
+F32, F64, I16, U16, I32, U32, BOOL, I64, U64 = range(9)
 IO_WF_IN, IO_WF_OUT, IO_SCALAR_IN, IO_SCALAR_OUT, IO_TAPS = range(5)
 ARG_CONST, ARG_INPUT, ARG_REG = range(3)
 (OP_LOAD, OP_STORE, OP_STORE_SCALAR, OP_BL_SUBTRACT, OP_POLE_ZERO, OP_DOUBLE_POLE_ZERO, OP_TRAP_FILTER, OP_TRAP_NORM,
@@ -25,7 +25,7 @@ ARG_CONST, ARG_INPUT, ARG_REG = range(3)
  OP_SCALAR_AFFINE, OP_MEAN_BELOW, OP_CONVOLVE_AMAX, OP_WINDOWER, OP_AVG_CURRENT, OP_TRAP_WINDOW_PICKOFF, OP_TRAP_REDUCE, OP_UPSAMPLER, OP_MOVING_WINDOW_MULTI, OP_LINEAR_SLOPE_FIT,
  OP_SCALAR_CONVERT, OP_SCALAR_DIV, OP_INTERP_TIME_POINT_THRESH, OP_MIN_MAX_NORM, OP_ELEMENTWISE, OP_SCALAR_FUNC) = range(1, 34)
 (FN_ADD, FN_SUB, FN_MUL, FN_DIV, FN_LT, FN_LE, FN_GT, FN_GE, FN_EQ, FN_NE, FN_WHERE, FN_ISNAN, FN_ISFINITE, FN_NEG, FN_COPY, FN_FLOORDIV,
- FN_IADD, FN_ISUB, FN_IMUL, FN_IFLOORDIV, FN_ICAST) = range(21)
+ FN_IADD, FN_ISUB, FN_IMUL, FN_IFLOORDIV, FN_ICAST, FN_LOR, FN_LAND) = range(23)
 
 
 def fn_int(code, dtype):

@@ -54,7 +54,7 @@ extern "C" int dsp_internal_launch_pz_rows(const PzArgs* A, int64_t n_wf, int* e
 extern "C" const char* dsp_internal_pz_rows_kernel_name();
 extern "C" int dsp_internal_launch_reduce(const ReduceArgs* A, int64_t n_wf, int dtype, int vec, hipStream_t stream);
 extern "C" const char* dsp_internal_reduce_kernel_name();
-extern "C" int dsp_internal_launch_scalar(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int n_sregs, int f64, hipStream_t stream);
+extern "C" int dsp_internal_launch_scalar(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int n_sregs, int type, hipStream_t stream);  // type: 0 float32, 1 float64, 2 int64 registers
 extern "C" int dsp_internal_set_scalar_lds(int lds_bytes);
 extern "C" const char* dsp_internal_scalar_kernel_name();
 extern "C" int dsp_internal_current_lds_bytes(int ma_len);
@@ -364,7 +364,7 @@ int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_
         if (rc != DSP_OK) return rc;
     }
     const DevProgram& P = ch->host;
-    const int esz = ch->f64 ? 8 : 4;
+    const int esz = (ch->f64 || ch->i64) ? 8 : 4;
     if (ch->fir_f16)  // device images of the float16 FIR's taps (rewritten by every launch: the taps are a binding)
         for (int k = 0; k < ch->fir.n_kernels; ++k) {
             void* buf = nullptr;
@@ -536,7 +536,7 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         return k < 0 ? nullptr : (void*)((char*)io_ptrs[k] + (int64_t)ch->host.io[k].offset * elem_size(ch->host.io[k].dtype));
     };
     if (ch->scalar_ok && ch->fused_on) {
-        hipError_t e = (hipError_t)dsp_internal_launch_scalar(ch->dev, &ptrs, n_wf, ch->host.n_sregs, ch->f64 ? 1 : 0, (hipStream_t)stream);
+        hipError_t e = (hipError_t)dsp_internal_launch_scalar(ch->dev, &ptrs, n_wf, ch->host.n_sregs, ch->i64 ? 2 : (ch->f64 ? 1 : 0), (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "scalar kernel launch failed: %s", hipGetErrorString(e));
         return post_err(ch, stream);
     }
@@ -744,7 +744,7 @@ int dsp_chain_destroy(dsp_chain* ch) {
 int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int* waves_per_block, int* blocks) {
     if (!ch) return fail(DSP_ERR_ARG, "null chain");
     if (ch->scalar_ok && ch->fused_on) {
-        if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->host.n_sregs * 64 * (ch->f64 ? 8 : 4);
+        if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->host.n_sregs * 64 * ((ch->f64 || ch->i64) ? 8 : 4);
         if (waves_per_block) *waves_per_block = 1;
         if (blocks) *blocks = (int)((n_wf + 63) / 64);
         return DSP_OK;

@@ -34,7 +34,7 @@ const char* dsp_plan_last_error() { return g_last_error.c_str(); }
 int dsp_elem_size(int dtype) {
     switch (dtype) {
         case DSP_F32: case DSP_I32: case DSP_U32: return 4;
-        case DSP_F64: return 8;
+        case DSP_F64: case DSP_I64: case DSP_U64: return 8;
         case DSP_I16: case DSP_U16: return 2;
         case DSP_BOOL: return 1;
         default: return 0;
@@ -87,10 +87,14 @@ static void note(ChainPlan* ch, const char* fmt, ...) {
     ch->note = buf;
 }
 
-static bool fn_code_ok(int ip0, bool f64) {
+static bool fn_code_ok(int ip0, bool f64, bool i64 = false) {
     const int code = DSP_FN_CODE(ip0), bits = DSP_FN_INT_BITS(ip0);
     if (ip0 < 0 || code > DSP_FN_LAST || (ip0 >> 17) != 0) return false;
-    if (code >= DSP_FN_IADD && code <= DSP_FN_ICAST) return bits == 8 || bits == 16 || (bits == 32 && f64);
+    if (code >= DSP_FN_IADD && code <= DSP_FN_ICAST) return bits == 8 || bits == 16 || (bits == 32 && (f64 || i64)) || (bits == 64 && i64);
+    if (i64) {  // an integer program: no float arithmetic; a comparison may name its loop's type (uint64: unsigned)
+        if (code <= DSP_FN_DIV || code == DSP_FN_NEG || code == DSP_FN_FLOORDIV) return false;
+        return (ip0 >> 8) == 0 || bits == 8 || bits == 16 || bits == 32 || bits == 64;
+    }
     return (ip0 >> 8) == 0;
 }
 
@@ -720,9 +724,17 @@ int dsp_plan_build(ChainPlan* ch, const dsp_op* ops, int n_ops, const dsp_io_des
     if (n_io < 0 || n_io > DSP_MAX_IO) return fail(DSP_ERR_ARG, "n_io=%d out of range", n_io);
     if (n_slots < 0 || n_slots > DSP_MAX_SLOTS) return fail(DSP_ERR_ARG, "n_slots=%d out of range", n_slots);
     if (n_sregs < 0 || n_sregs > DSP_MAX_SREGS) return fail(DSP_ERR_ARG, "n_sregs=%d out of range", n_sregs);
-    if (compute_dtype != DSP_F32 && compute_dtype != DSP_F64) return fail(DSP_ERR_ARG, "compute_dtype must be DSP_F32 or DSP_F64");
-    const int esz = compute_dtype == DSP_F64 ? 8 : 4;
+    if (compute_dtype != DSP_F32 && compute_dtype != DSP_F64 && compute_dtype != DSP_I64)
+        return fail(DSP_ERR_ARG, "compute_dtype must be DSP_F32, DSP_F64 or DSP_I64");
+    const bool i64 = compute_dtype == DSP_I64;  // an integer program of per-event values (dspeed_hip.h): 64-bit integer registers
+    const int esz = compute_dtype == DSP_F32 ? 4 : 8;
     const bool f64 = compute_dtype == DSP_F64;
+    if (i64) {
+        if (n_slots != 0) return fail(DSP_ERR_ARG, "an integer program (DSP_I64) has no waveform slots");
+        for (int i = 0; i < n_ops; ++i)
+            if (ops[i].opcode != DSP_OP_SCALAR_FUNC && ops[i].opcode != DSP_OP_STORE_SCALAR)
+                return fail(DSP_ERR_ARG, "op %d: an integer program (DSP_I64) holds SCALAR_FUNC and STORE_SCALAR ops only", i);
+    }
 
     DevProgram& P = ch->host;
     P.n_ops = n_ops;
@@ -730,6 +742,7 @@ int dsp_plan_build(ChainPlan* ch, const dsp_op* ops, int n_ops, const dsp_io_des
     P.n_io = n_io;
     P.n_sregs = n_sregs;
     ch->f64 = f64;
+    ch->i64 = i64;
 
     // ---- LDS layout: [guard 2*pitch][slot 64*pitch][tail 8] per slot, then the scalar registers
     // FIR inputs are laid out linearly (no chunk pad): a slot qualifies when a CONVOLVE reads it and everything else that touches
@@ -880,9 +893,14 @@ int dsp_plan_build(ChainPlan* ch, const dsp_op* ops, int n_ops, const dsp_io_des
         if (a.kind == DSP_IO_WF_IN && !f64 && (a.dtype == DSP_I32 || a.dtype == DSP_U32 || a.dtype == DSP_F64))
             return fail(DSP_ERR_ARG, "io %d: int32/uint32/float64 rows select the float64 loop (compute_dtype DSP_F64)", k);
         const bool is_out = a.kind == DSP_IO_WF_OUT || a.kind == DSP_IO_SCALAR_OUT;
-        if ((is_out || a.kind == DSP_IO_TAPS) && a.dtype != compute_dtype && !(is_out && a.dtype == DSP_BOOL))
+        if ((is_out || a.kind == DSP_IO_TAPS) && a.dtype != compute_dtype && !(is_out && a.dtype == DSP_BOOL) && !(i64 && a.kind == DSP_IO_SCALAR_OUT))
             return fail(DSP_ERR_ARG, "io %d: outputs have the chain's compute type or DSP_BOOL, taps the compute type", k);
-        if (a.dtype == DSP_BOOL && !is_out) return fail(DSP_ERR_ARG, "io %d: DSP_BOOL is an output type", k);
+        if ((a.dtype == DSP_BOOL || a.dtype == DSP_I64 || a.dtype == DSP_U64) && a.kind != DSP_IO_SCALAR_IN && a.kind != DSP_IO_SCALAR_OUT && !(a.dtype == DSP_BOOL && is_out))
+            return fail(DSP_ERR_ARG, "io %d: DSP_BOOL / DSP_I64 / DSP_U64 are types of per-event columns (DSP_BOOL also of waveform outputs)", k);
+        if (i64 && a.kind == DSP_IO_SCALAR_IN && (a.dtype == DSP_F32 || a.dtype == DSP_F64))
+            return fail(DSP_ERR_ARG, "io %d: an integer program (DSP_I64) reads integer and DSP_BOOL columns", k);
+        if (!i64 && is_out && (a.dtype == DSP_I64 || a.dtype == DSP_U64))
+            return fail(DSP_ERR_ARG, "io %d: 64-bit integer outputs are written by integer programs (compute_dtype DSP_I64)", k);
         d.kind = a.kind;
         d.dtype = a.dtype;
         d.len = a.len;
@@ -1154,7 +1172,7 @@ int dsp_plan_build(ChainPlan* ch, const dsp_op* ops, int n_ops, const dsp_io_des
                 break;
             }
             case DSP_OP_SCALAR_FUNC:
-                if (o.dst < 0 || o.dst >= n_sregs || !fn_code_ok(o.ip[0], f64)) return fail(DSP_ERR_ARG, "op %d: bad SCALAR_FUNC", i);
+                if (o.dst < 0 || o.dst >= n_sregs || !fn_code_ok(o.ip[0], f64, i64)) return fail(DSP_ERR_ARG, "op %d: bad SCALAR_FUNC", i);
                 break;
             case DSP_OP_CONVOLVE:
             case DSP_OP_CONVOLVE_AMAX: {

@@ -85,6 +85,7 @@ struct ChainPlan {
     int classic_wpb = 0;       // classic energy kernel launch (built for 2 wavefronts per SIMD)
     bool has_fir = false;      // the program holds a CONVOLVE: the VM build with the FIR op (2 wavefronts per SIMD instead of 4)
     bool f64 = false;  // the float64 gufunc loop (LDS elements are 8 bytes)
+    bool i64 = false;  // an integer program of per-event values (compute_dtype DSP_I64): the row-per-lane kernel with 64-bit integer registers
     // specialised energy-chain kernel (dsp_energy.hip), selected when the program has exactly that shape
     bool fused_ok = false, fused_on = true;
     EnergyArgs fused{};

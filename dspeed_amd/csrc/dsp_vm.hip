@@ -93,6 +93,9 @@ struct Ctx {
         if (io.dtype == DSP_I32) return (T)io_ptr<const int32_t>(a.index)[at];
         if (io.dtype == DSP_I16) return (T)io_ptr<const int16_t>(a.index)[at];
         if (io.dtype == DSP_U16) return (T)io_ptr<const uint16_t>(a.index)[at];
+        if (io.dtype == DSP_BOOL) return (T)(io_ptr<const uint8_t>(a.index)[at] != 0);
+        if (io.dtype == DSP_I64) return (T)io_ptr<const int64_t>(a.index)[at];  // (the value converted, as NumPy's cast into a float loop does)
+        if (io.dtype == DSP_U64) return (T)io_ptr<const uint64_t>(a.index)[at];
         return (T)io_ptr<const uint32_t>(a.index)[at];
     }
 };
@@ -281,6 +284,8 @@ __device__ __forceinline__ T ew_apply(T a, T b, T c, int meta) {
     else if constexpr (FN == DSP_FN_ISFINITE) return (T)((a - a) == (T)0);
     else if constexpr (FN == DSP_FN_NEG) return -a;
     else if constexpr (FN == DSP_FN_FLOORDIV) return floor(a / b);
+    else if constexpr (FN == DSP_FN_LOR) return (T)(a != (T)0 || b != (T)0);
+    else if constexpr (FN == DSP_FN_LAND) return (T)(a != (T)0 && b != (T)0);
     else return a;
 }
 
@@ -307,6 +312,8 @@ __device__ __forceinline__ void ew_dispatch(int fn, F&& f) {
         case DSP_FN_ISFINITE: f(std::integral_constant<int, DSP_FN_ISFINITE>()); break;
         case DSP_FN_NEG: f(std::integral_constant<int, DSP_FN_NEG>()); break;
         case DSP_FN_FLOORDIV: f(std::integral_constant<int, DSP_FN_FLOORDIV>()); break;
+        case DSP_FN_LOR: f(std::integral_constant<int, DSP_FN_LOR>()); break;
+        case DSP_FN_LAND: f(std::integral_constant<int, DSP_FN_LAND>()); break;
         default: f(std::integral_constant<int, DSP_FN_COPY>()); break;
     }
 }

@@ -15,7 +15,7 @@ from . import _lib
 
 _DTYPES = {np.dtype(np.float32): _lib.F32, np.dtype(np.float64): _lib.F64, np.dtype(np.int16): _lib.I16,
            np.dtype(np.uint16): _lib.U16, np.dtype(np.int32): _lib.I32, np.dtype(np.uint32): _lib.U32,
-           np.dtype(np.bool_): _lib.BOOL}
+           np.dtype(np.bool_): _lib.BOOL, np.dtype(np.int64): _lib.I64, np.dtype(np.uint64): _lib.U64}
 
 
 def dtype_code(dt) -> int:

@@ -160,6 +160,7 @@ class SExpr:
         self.op, self.args, self.name = op, tuple(args), name   # 'affine' (x, mul, add) | 'div' (a, b) | 'convert' (x, off_in, off_out, ratio) | 'func' (FN_*, a, b, c)
         self.unit, self.is_coord, self.grid, self.mode = unit, is_coord, grid, mode
         self.sreg = None
+        self.io = None     # (op 'ext': the binding through which a program reads the column an integer program wrote)
         self.dtype = None  # np.bool_ for truth values ('func' results of comparisons, isnan, isfinite)
 
     def __repr__(self):
@@ -210,28 +211,43 @@ def _is_int_dtype(a) -> bool:
 _INT_LOOPS = "bBhHiIlLqQ"  # the integer signatures of numpy.add / subtract / multiply / floor_divide / negative, in the order of ufunc.types
 
 
-def _int_loop_of(variables, src):
+def _all_bool(variables) -> bool:
+    return bool(variables) and all(np.dtype((v[1] if isinstance(v, tuple) else v).dtype) == np.dtype(np.bool_) for v in variables)
+
+
+def _int_loop_of(variables, src, loops=_INT_LOOPS):
     """The integer ufunc loop the reference picks for these variables: the first signature every variable can be cast to
     (np.can_cast per parameter, reference :1565-1572; the first one left, :1654-1664).  Constants do not take part: they are converted to
-    the loop's type afterwards (:1765-1768)."""
+    the loop's type afterwards (:1765-1768).  ``loops``: the integer signatures of the ufunc in the order of its ``types`` (numpy.add's
+    and its relatives' by default; ``where`` has its own, processors/where.py:11-20).  Truth values alone select NumPy's '??' loops where the
+    ufunc has one (add, multiply: the callers' business) and the int8 loop otherwise (floor_divide)."""
     dts = [np.dtype((v[1] if isinstance(v, tuple) else v).dtype) for v in variables]
-    if all(d == np.dtype(np.bool_) for d in dts):
-        raise NotImplementedError(f"'{src}' is arithmetic between truth values (NumPy's '??' loops: logical or / and); not available on the device path")
-    c = next((c for c in _INT_LOOPS if all(np.can_cast(d, c) for d in dts)), None)
-    if c is None or np.dtype(c).itemsize > 4:
-        raise NotImplementedError(f"'{src}' selects a 64-bit integer loop in the reference ({', '.join(d.name for d in dts)}); the device path holds "
-                                  "integers of up to 32 bits -- make one operand a float (astype)")
+    c = next((c for c in loops if all(np.can_cast(d, c) for d in dts)), None)
+    if c is None:  # int64 beside uint64: no integer signature takes both, NumPy goes on to the float64 one
+        raise NotImplementedError(f"'{src}' mixes {' and '.join(sorted({d.name for d in dts}))}: NumPy's loop for them is the float64 one, which cannot "
+                                  "hold them; cast one side (astype)")
     return np.dtype(c)
 
 
-def _int_loop_const(c, dt, src):
-    """a constant beside integer variables: the reference converts it to the loop's type, dtype.type(np.round(c))  (:1765-1768)"""
+def _int_loop_const(c, dt, src, period=None):
+    """a constant beside integer variables: the reference converts it to the loop's type, dtype.type(np.round(c)) (:1765-1768) -- a value
+    outside the type wraps around (NumPy's conversion between its own integer scalars); a time counts periods of the processor's grid first
+    (:1747-1764)"""
     if isinstance(c, Quantity):
-        raise NotImplementedError(f"'{src}': a time beside integer variables")
+        if period is None:
+            raise ProcessingChainError(f"could not find valid conversion for {c!r} in '{src}'; CoordinateGrid is None")
+        c = float(c) / period
+    if dt == np.dtype(np.bool_):  # (not an integer type: dtype.type(c), the truth of the number)
+        return float(bool(c))
     r = int(np.round(float(c)))
-    if not np.iinfo(dt).min <= r <= np.iinfo(dt).max:
-        raise NotImplementedError(f"'{src}': {c} does not fit the {dt.name} loop the integer operands select (the reference wraps it around)")
-    return float(r)
+    if abs(r) > 2 ** 53:
+        raise NotImplementedError(f"'{src}': the constant {c} beside integer variables is beyond 2^53")
+    return float(int(np.array(r, dtype=np.int64).astype(dt)))
+
+
+_BOOL_MINUS = ("numpy boolean subtract, the `-` operator, is not supported, use the bitwise_xor, the `^` operator, or the logical_xor "
+               "function instead.")  # (what numpy.subtract / numpy.negative raise for truth values when the reference's processor first runs)
+_WHERE_LOOPS = "BHILbhiq"  # processors/where.py:11-20: u1 u2 u4 u8 i1 i2 i4 i8 (then f4, f8)
 
 
 _GENERATORS = ("cusp_filter", "zac_filter", "t0_filter", "moving_slope")
@@ -333,7 +349,7 @@ class ProcessingChain:
             for name, arr in self._consts.items():
                 self._dev[name] = DeviceArray.from_numpy(arr)
             for k, st in enumerate(self._stages):
-                st["chain"] = Chain(st["program"], f"processing_chain stage {k} ({st['what']})", self.loop_dtype)
+                st["chain"] = Chain(st["program"], f"processing_chain stage {k} ({st['what']})", st.get("compute", self.loop_dtype))
                 st["chain"].set_async_check(True)
                 st["dev"] = {name: DeviceArray.from_numpy(arr) for name, arr in st["consts"].items()}
             self._lanes = [SimpleNamespace(stream=self._stream, chain=self._chain, stage_chains=[st["chain"] for st in self._stages],
@@ -386,7 +402,7 @@ class ProcessingChain:
             ch.set_async_check(True)
             stage_chains = []
             for j, st in enumerate(self._stages):
-                c = Chain(st["program"], f"processing_chain stage {j} ({st['what']}, lane {len(self._lanes)})", self.loop_dtype)
+                c = Chain(st["program"], f"processing_chain stage {j} ({st['what']}, lane {len(self._lanes)})", st.get("compute", self.loop_dtype))
                 c.set_async_check(True)
                 stage_chains.append(c)
             self._pair_stages(stage_chains)
@@ -758,7 +774,7 @@ class ProcessingChain:
             for out_name, key, length in st["outs"]:
                 buf = held.get(key)
                 if buf is None or buf.shape[0] < m:
-                    buf = held[key] = DeviceArray((m,) if length is None else (m, length), self.loop_dtype)
+                    buf = held[key] = DeviceArray((m,) if length is None else (m, length), st.get("out_dtypes", {}).get(key, self.loop_dtype))
                 sb[out_name] = bufs[key] = buf
             if plan is None:
                 lane.stage_chains[j].execute(sb, m, stream)
@@ -839,6 +855,78 @@ class ProcessingChain:
         return tb_out
 
 
+class GroupedProcessingChain(ProcessingChain):
+    """A recipe in which an INTEGER parameter of a processor is a per-event column -- ``trap_filter(wf, rise_col, flat_col, out)`` --, which
+    the reference serves by broadcasting the column into the gufunc's "()" slot (processing_chain.py:1702-1745).  Device programs hold
+    such parameters as constants (they size loops and the LDS layout), so a pass groups the rows by the values of those columns, runs each
+    group through a chain built for its values (built once per distinct combination and kept) and puts the results back at the rows'
+    places -- the scheme of the single-processor entry points (``gufunc.py``).  Results are those of the reference row by row; a DSPFatal
+    names the first row, in table order, that met one.  Everything else -- bindings, outputs, attributes -- is the chain of the first
+    combination's (``proto``)."""
+
+    def __init__(self, proto: ProcessingChain, build, columns):
+        self.__dict__.update(proto.__dict__)
+        self._proto, self._build_group, self.group_columns, self._group_chains = proto, build, list(columns), {}
+
+    def kernels(self) -> list:
+        return self._proto.kernels()
+
+    def kernel_notes(self) -> list:
+        return self._proto.kernel_notes()
+
+    @staticmethod
+    def _take(col, idx):
+        if isinstance(col, WaveformInput):
+            t0 = col.t0 if isinstance(col.t0, float) else np.asarray(col.t0)[idx]
+            return WaveformInput(GroupedProcessingChain._take(col.values, idx), col.dt, t0)
+        if isinstance(col, DeviceArray):
+            raise NotImplementedError("per-event integer parameters of processors: the rows are grouped by value on the host -- link host arrays")
+        return np.ascontiguousarray(np.asarray(col)[idx])
+
+    def execute(self, start: int = 0, stop: int | None = None, wait: bool = True) -> None:
+        if stop is None:
+            stop = self._buffer_len
+        if stop <= start:
+            return
+        if not wait:
+            raise ValueError("execute(wait=False) is for chains over device-resident columns; this one groups host rows by value")
+        keys = np.stack([np.asarray(_column(self._tb_in, c))[start:stop].astype(np.int64) for c in self.group_columns], axis=1)
+        uniq, first, inverse = np.unique(keys, axis=0, return_index=True, return_inverse=True)
+        inverse = np.asarray(inverse).reshape(-1)
+        failures = []
+        for g in np.argsort(first):  # (groups in the order their first rows stand in the table)
+            idx = np.flatnonzero(inverse == g) + start
+            combo = tuple(int(v) for v in uniq[g])
+            part = {name: self._take(col, idx) for name, col in self._tb_in.items()}
+            chain = self._group_chains.get(combo)
+            try:
+                if chain is None:
+                    chain = self._group_chains[combo] = self._build_group(dict(zip(self.group_columns, combo)), part)
+                    chain.device = self.device
+                out = {name: np.empty((len(idx), *np.shape(col)[1:]), dtype=np.asarray(col).dtype) for name, col in self._tb_out.items()
+                       if name not in self._copy_pars}
+                chain.link(part, out)
+                chain.execute(0, len(idx))
+            except DSPFatal as e:  # (a constant-only condition of this group's values, or a row of it: the reference meets it at the group's first such row)
+                row = idx[e.wf_range.start] if isinstance(e.wf_range, range) and len(e.wf_range) else idx[0]
+                e.wf_range = range(int(row), int(row) + 1)
+                failures.append((int(row), e))
+                continue
+            for name, col in out.items():
+                self._tb_out[name][idx] = col
+            for k in self._timing:
+                self._timing[k] += chain.get_timing()[k]
+        if failures:
+            raise min(failures, key=lambda f: f[0])[1]
+
+    def __call__(self, tb_in, tb_out, begin: int = 0, end: int | None = None):
+        from . import lgdo_io
+
+        if lgdo_io.is_lgdo_table(tb_in):  # (the grouping columns are read on the host: they are part of what the table must give)
+            tb_in = lgdo_io.table_columns(tb_in, set(v.source.split(".")[0] for v in self._in_vars.values()) | set(self._copy_pars) | set(self.group_columns))
+        return super().__call__(tb_in, tb_out, begin, end)
+
+
 def _column(tb, name):
     if name not in tb and name.endswith(".t0"):  # the per-row t0 of a WaveformInput
         return tb[name[:-3]].t0
@@ -878,6 +966,7 @@ class _Builder:
         self.cur_key = None   # recipe entry being added (the expression steps it creates carry its name)
         self._anon = 0        # counter behind the names of expression results
         self._conversions = {}  # (id(value), target grid key, rounding) -> SExpr: one conversion per variable and grid (reference :303-313)
+        self.group_values = {}  # input column -> the integer it holds in the rows this chain is built for (GroupedProcessingChain)
         for name, col in self.tb_in.items():
             if isinstance(col, WaveformInput) and self.default_period is None:
                 self.default_period = col.dt
@@ -975,6 +1064,8 @@ class _Builder:
                 if isinstance(n.op, ast.UAdd):
                     return v
                 if _is_int_dtype(v):  # numpy.negative's integer loops: 0 - v in the variable's type
+                    if _all_bool([v]):
+                        raise ProcessingChainError(f"'{src}': {_BOOL_MINUS.replace('subtract', 'negative')}")
                     dt = _int_loop_of([v], src)
                     return self._scalar_func(_lib.fn_int(_lib.FN_ISUB, dt), [0.0, v], f"(-{v.name})", v.unit, v.is_coord, v.grid, dt)
                 return SExpr("affine", (v, -1.0, -0.0), f"(-{v.name})", v.unit, v.is_coord, v.grid)
@@ -982,7 +1073,9 @@ class _Builder:
                 if isinstance(n.op, ast.UAdd):
                     return v
                 if _is_int_dtype(v):
-                    dt = _int_loop_of([v], src)
+                    if _all_bool([v]):
+                        raise ProcessingChainError(f"'{src}': {_BOOL_MINUS.replace('subtract', 'negative')}")
+                    dt = self._wide_wf_loop(_int_loop_of([v], src), _lib.FN_ISUB, [0.0, v], src)
                     return self._elementwise(_lib.fn_int(_lib.FN_ISUB, dt), [0.0, v], f"(-{self._nm(v)})", src, self._unit_of(v), dt)
                 return self._elementwise(_lib.FN_NEG, [v], f"(-{self._nm(v)})", src, self._unit_of(v))
             if isinstance(v, (Var, tuple)):
@@ -1003,6 +1096,13 @@ class _Builder:
             name = f"({self._nm(a)}{sym}{self._nm(b2)})"
             if _is_wf(a) or _is_wf(b2):
                 return self._elementwise(fn, [a, b2], name, src, None, np.bool_)
+            variables = [x for x in (a, b2) if _is_scalar(x)]
+            if all(_is_int_dtype(x) for x in variables) and any(np.dtype(x.dtype).itemsize == 8 for x in variables):
+                # 64-bit integers are compared as integers (NumPy's 'qq->?' / 'QQ->?' loops; a constant is converted to the loop's type,
+                # :1765-1768): the comparison joins the integer program that holds them (_int_island)
+                dt = _int_loop_of(variables, src)
+                a, b2 = (x if _is_scalar(x) else _int_loop_const(x, dt, src) for x in (a, b2))
+                return self._scalar_func(_lib.fn_int(fn, dt), [a, b2], name, None, False, None, np.bool_)
             return self._scalar_func(fn, [a, b2], name, None, False, None, np.bool_)
         if isinstance(n, ast.IfExp):  # a if condition else b  (reference :1073-1078)
             return self._where(self._eval(n.test, src, new), self._eval(n.body, src, new), self._eval(n.orelse, src, new), src)
@@ -1141,7 +1241,9 @@ class _Builder:
                     x, d = a[0], np.dtype(a[1][1] if isinstance(a[1], tuple) else a[1])
                     if not (_is_wf(x) or _is_scalar(x)):
                         raise ProcessingChainError(f"cannot call astype() on {x!r}")
-                    if d.kind in "iu" and d.itemsize <= 4:  # numpy.copyto(casting="unsafe"): truncation, then the wrap to the type
+                    if d.kind in "iu" and (d.itemsize <= 4 or (_is_scalar(x) and _is_int_dtype(x))):
+                        # numpy.copyto(casting="unsafe"): truncation, then the wrap to the type (a per-event integer to a 64-bit type: in the
+                        # integer program, _int_island)
                         fn, nm = _lib.fn_int(_lib.FN_ICAST, d), f"{self._nm(x)}.astype(`{d.char}`)"
                         if _is_wf(x):
                             return self._elementwise(fn, [x], nm, src, self._unit_of(x), d)
@@ -1152,7 +1254,8 @@ class _Builder:
                             return self._elementwise(_lib.FN_NE, [x, 0.0], nm, src, self._unit_of(x), np.bool_)
                         return self._scalar_func(_lib.FN_NE, [x, 0.0], nm, x.unit, x.is_coord, x.grid, np.bool_)
                     if d.kind != "f" or d.itemsize < 4:
-                        raise NotImplementedError(f"astype to {d} is not available on the device path (float32 / float64 loops, integers of up to 32 bits): '{src}'")
+                        raise NotImplementedError(f"astype to {d} is not available on the device path (float32 / float64 loops; 64-bit integers from "
+                                                  f"per-event integers only): '{src}'")
                     if _is_wf(x):
                         out = self._elementwise(_lib.FN_COPY, [x], f"{self._nm(x)}.astype(`{d.char}`)", src, self._unit_of(x))
                     elif _is_scalar(x):
@@ -1350,6 +1453,8 @@ class _Builder:
         grid = next((g for g in (_grid_of(a) for a in ops3 if _is_wf(a)) if g is not None), None)
         self._anon += 1
         out = Var(f"{name}#{self._anon}", "wf", n, dtype, grid=grid, unit=unit, is_coord=False)
+        if getattr(self, "_wide_bound", None) is not None:
+            out.int_bits, self._wide_bound = self._wide_bound, None
         roles = "".join("w" if _is_wf(a) else ("c" if a is None else "s") for a in ops3)
         self._step("ew:" + roles, [int(fn), *ops3, out], "c" + roles + "W")
         return out
@@ -1362,6 +1467,34 @@ class _Builder:
         out.args = (int(fn), *res[:-1])
         return out
 
+    def _int_bits(self, x) -> int:
+        """bits of magnitude an integer operand can hold: of a column / waveform its type's, of a constant its value's, of a result what its
+        operands' bounds give (kept on the variable by _wide_wf_loop)"""
+        if not (_is_wf(x) or _is_scalar(x)):
+            return max(1, int(abs(float(x))).bit_length())
+        v = x[1] if isinstance(x, tuple) else x
+        known = getattr(v, "int_bits", None)
+        if known is not None:
+            return known
+        dt = np.dtype(v.dtype)
+        return 1 if dt.kind == "b" else dt.itemsize * 8 - (1 if dt.kind == "i" else 0) + (1 if dt.kind == "i" else 0)
+
+    def _wide_wf_loop(self, dtype, code, opnds, src):
+        """A 64-bit integer loop on WAVEFORMS (int32 beside uint32 samples: NumPy's 'll->l'): the waveform VM holds samples in the chain's
+        float type, and a float64 holds every integer below 2^53.  The loop is taken when the operands' types bound the result below that --
+        then nothing wraps either, so the float64 chain's exact integer arithmetic IS the int64 loop -- and refused by name otherwise.
+        (Per-event 64-bit integers are exact in any case: they run in an integer program of their own, _int_island.)"""
+        dtype = np.dtype(dtype)
+        if dtype.itemsize < 8:
+            return dtype
+        ba, bb = (self._int_bits(x) for x in opnds)
+        bound = {_lib.FN_IADD: max(ba, bb) + 1, _lib.FN_ISUB: max(ba, bb) + 1, _lib.FN_IMUL: ba + bb, _lib.FN_IFLOORDIV: ba}[code]
+        if bound > 53:
+            raise NotImplementedError(f"'{src}' is a 64-bit integer loop on waveforms whose result can exceed 2^53 ({bound} bits): the waveform "
+                                      "kernels hold samples in float64 at most; cast an operand to a float (astype)")
+        self._wide_bound = bound  # (picked up by _elementwise for the variable it makes)
+        return dtype
+
     def _wf_binop(self, op, a, b, src):
         fn, sym = {ast.Add: (_lib.FN_ADD, "+"), ast.Sub: (_lib.FN_SUB, "-"), ast.Mult: (_lib.FN_MUL, "*"), ast.Div: (_lib.FN_DIV, "/"),
                    ast.FloorDiv: (_lib.FN_FLOORDIV, "//")}.get(type(op), (None, None))
@@ -1370,11 +1503,20 @@ class _Builder:
         if fn is None or (fn == _lib.FN_FLOORDIV and not int_loop):
             raise NotImplementedError(f"operator in '{src}' is not available on waveforms on the device path")
         dtype = np.float32
-        if int_loop:
+        if int_loop and _all_bool(variables) and fn != _lib.FN_FLOORDIV:
+            # truth values alone: numpy.add and numpy.multiply have '??->?' loops -- logical or, logical and --, numpy.subtract refuses
+            if fn == _lib.FN_SUB:
+                raise ProcessingChainError(f"'{src}': {_BOOL_MINUS}")
+            dtype, fn = np.dtype(np.bool_), (_lib.FN_LOR if fn == _lib.FN_ADD else _lib.FN_LAND)
+            a, b = (x if (_is_wf(x) or _is_scalar(x)) else _int_loop_const(x, dtype, src) for x in (a, b))
+        elif int_loop:
             # every variable is an integer: the reference's first matching ufunc loop is an integer one (:1565-1572), with its wrap-around
             dtype = _int_loop_of(variables, src)
-            fn = _lib.fn_int({_lib.FN_ADD: _lib.FN_IADD, _lib.FN_SUB: _lib.FN_ISUB, _lib.FN_MUL: _lib.FN_IMUL, _lib.FN_FLOORDIV: _lib.FN_IFLOORDIV}[fn], dtype)
-            a, b = (x if (_is_wf(x) or _is_scalar(x)) else _int_loop_const(x, dtype, src) for x in (a, b))
+            code = {_lib.FN_ADD: _lib.FN_IADD, _lib.FN_SUB: _lib.FN_ISUB, _lib.FN_MUL: _lib.FN_IMUL, _lib.FN_FLOORDIV: _lib.FN_IFLOORDIV}[fn]
+            per = next((g.period for g in (_grid_of(x) for x in (a, b) if _is_wf(x)) if g is not None), self.default_period)
+            a, b = (x if (_is_wf(x) or _is_scalar(x)) else _int_loop_const(x, dtype, src, per) for x in (a, b))
+            dtype = self._wide_wf_loop(dtype, code, [a, b], src)
+            fn = _lib.fn_int(code, dtype)
         va, vb = _is_wf(a) or _is_scalar(a), _is_wf(b) or _is_scalar(b)
         ua, ub = (self._unit_of(a) if va else None), (self._unit_of(b) if vb else None)
         if va and vb:  # reference :848-862
@@ -1435,12 +1577,22 @@ class _Builder:
                 a, b = (float(a) / _UNITS_NS[unit] if qa else a), (float(b) / _UNITS_NS[unit] if qb else b)
         both_bool = all(getattr(x, "dtype", None) == np.dtype(np.bool_) if is_var(x) else isinstance(x, bool) for x in (a, b))
         dtype = np.bool_ if both_bool else np.float32
+        variables = [x for x in (a, b) if is_var(x)]
+        wide = False
+        if variables and not both_bool and all(_is_int_dtype(x) for x in variables) and not any(_is_wf(x) for x in variables):
+            # integer columns select an integer signature of the reference's where (processors/where.py:11-20), the constant beside one is
+            # converted to it (:1765-1768).  The value is the chosen operand's, whatever the type: only its label -- and 64-bit integers,
+            # which no float register holds -- matter here
+            int_dt = _int_loop_of(variables, src, _WHERE_LOOPS)
+            if int_dt.itemsize == 8:
+                wide, dtype = True, int_dt
+                a, b = (x if is_var(x) else _int_loop_const(x, int_dt, src) for x in (a, b))
         if any(_is_wf(x) for x in (cond, a, b)):
             out = self._elementwise(_lib.FN_WHERE, [cond, a, b], name, src, unit, dtype)
             if grid is not None:
                 out.grid = grid
             return out
-        return self._scalar_func(_lib.FN_WHERE, [cond, a, b], name, unit, is_coord, grid, dtype if both_bool else None)
+        return self._scalar_func(_lib.FN_WHERE, [cond, a, b], name, unit, is_coord, grid, dtype if (both_bool or wide) else None)
 
     def _scalar_binop(self, op, a, b, src, declared=None):
         """A binary operator with a per-event variable on at least one side: the reference adds the NumPy ufunc as a processor
@@ -1449,7 +1601,15 @@ class _Builder:
         # every variable an integer column: the reference's first matching ufunc loop is an integer one (:1565-1572), with its wrap-around
         int_dt = None
         if type(op) in (ast.Add, ast.Sub, ast.Mult, ast.FloorDiv) and all(_is_int_dtype(x) for x in (a, b) if _is_scalar(x)):
-            int_dt = _int_loop_of([x for x in (a, b) if _is_scalar(x)], src)
+            variables = [x for x in (a, b) if _is_scalar(x)]
+            if _all_bool(variables) and not isinstance(op, ast.FloorDiv):
+                # truth values alone: numpy.add / numpy.multiply run their '??->?' loops (logical or / and), numpy.subtract refuses
+                if isinstance(op, ast.Sub):
+                    raise ProcessingChainError(f"'{src}': {_BOOL_MINUS}")
+                a, b = (x if _is_scalar(x) else _int_loop_const(x, np.dtype(np.bool_), src) for x in (a, b))
+                return self._scalar_func(_lib.FN_LOR if isinstance(op, ast.Add) else _lib.FN_LAND, [a, b],
+                                         f"({self._nm(a)}{'+' if isinstance(op, ast.Add) else '*'}{self._nm(b)})", None, False, None, np.bool_)
+            int_dt = _int_loop_of(variables, src)
         if isinstance(op, ast.FloorDiv):  # numpy.floor_divide as a processor: len(v)//2 and the like (reference :832-847)
             for x in (a, b):
                 if isinstance(x, (tuple, Grid, Quantity)) or (isinstance(x, Var) and x.kind != "scalar"):
@@ -1571,6 +1731,36 @@ def _resolve(b: _Builder, roles, args, same_dim_out=False, expression=False):
 
 
 def build_processing_chain(processors, tb_in=None, db_dict=None, outputs=None, block_width: int = 16, device: int | None = None):
+    """``_build_chain`` -- or, where a processor's integer parameter is a column of the input table, a chain per value of that column
+    (GroupedProcessingChain); documented at ``_build_chain``."""
+    columns, values = [], {}
+    while True:
+        try:
+            chain, mask, tb_out = _build_chain(processors, tb_in, db_dict, outputs, block_width, device, values)
+            break
+        except _PerEventInteger as e:
+            col = _column(tb_in, e.column)
+            if isinstance(col, DeviceArray):
+                raise NotImplementedError(f"'{e.column}' is an integer parameter of a processor, given per event: the rows are grouped by its value "
+                                          "on the host -- give the table's columns as host arrays") from None
+            col = np.asarray(col)
+            if len(col) == 0:
+                raise ProcessingChainError(f"'{e.column}' is an integer parameter of a processor and the table has no rows to take its values from") from None
+            columns.append(e.column)
+            values[e.column] = int(col[0])
+    if not columns:
+        return chain, mask, tb_out
+    recipe = _load(processors)
+
+    def build(group_values, part):
+        return _build_chain(recipe, part, db_dict, outputs, block_width, device, group_values)[0]
+
+    grouped = GroupedProcessingChain(chain, build, columns)
+    grouped.link(tb_in, tb_out)
+    return grouped, mask, tb_out
+
+
+def _build_chain(processors, tb_in, db_dict, outputs, block_width, device, group_values):
     """Translate a dspeed recipe into a device chain.
 
     Returns ``(proc_chain, field_mask, tb_out)`` like the reference (processing_chain.py:2363-2369): ``tb_in`` is a
@@ -1597,6 +1787,7 @@ def build_processing_chain(processors, tb_in=None, db_dict=None, outputs=None, b
     order, leafs, out_pars, copy_pars = book.plan(outputs)
 
     b = _Builder(tb_in, db_dict)
+    b.group_values = dict(group_values)
     for leaf in leafs:
         if tb_in is None or leaf not in tb_in:
             raise ProcessingChainError(f"'{leaf}' not found in input table or recipe")
@@ -1606,7 +1797,7 @@ def build_processing_chain(processors, tb_in=None, db_dict=None, outputs=None, b
     for entry in order:
         try:
             _add_step(b, entry.key, entry, list(entry.targets), proc_strings)
-        except (ProcessingChainError, NotImplementedError, DSPFatal):
+        except (ProcessingChainError, NotImplementedError, DSPFatal, _PerEventInteger):
             raise
         except Exception as e:
             raise ProcessingChainError("Exception raised while attempting to add processor:\n" + json.dumps(entry.as_dict(), indent=2, default=str)) from e
@@ -1722,9 +1913,36 @@ def _add_step(b: _Builder, key, node, new_vars, proc_strings):
             a.dtype = np.dtype(np.float32)
             a.is_coord = False
     args = [_as_taps(b, a, function) if r == "t" else a for a, r in zip(args, roles)]
+    args = [_group_constant(b, a, function, key) if r == "i" and isinstance(a, (Var, SExpr)) else a for a, r in zip(args, roles)]
     _, args = _resolve(b, roles, args, same_dim_out=function in _SAME_DIM)
     b.steps.append((function, args, key))
     proc_strings.append(f"{function}({', '.join(str(a.name if isinstance(a, (Var, SExpr)) else a) for a in args)})")
+
+
+class _PerEventInteger(Exception):
+    """an integer parameter of a processor is a column of the input table: the chain is built per value of it (GroupedProcessingChain)"""
+
+    def __init__(self, column):
+        super().__init__(column)
+        self.column = column
+
+
+def _group_constant(b: _Builder, a, function, key):
+    """An INTEGER parameter of a processor (the rise and flat times of a trapezoid, a wavelet level, the number of moving windows) given as
+    a per-event variable.  The reference broadcasts the variable's buffer into the gufunc's "()" slot, if its type can be cast to the
+    signature's (:1565-1572, 1702-1745).  The device program holds such parameters as constants -- they size loops and LDS --, so the rows
+    are grouped by the column's value and each group runs a chain built for it: here the column is replaced by the value of the group this
+    chain is for, or reported to ``build_processing_chain``, which then returns a GroupedProcessingChain."""
+    if isinstance(a, Var) and a.kind == "const":
+        return a.const
+    if not (isinstance(a, Var) and a.kind == "scalar" and a.is_input and a.source is not None and getattr(a, "ext_key", None) is None):
+        raise NotImplementedError(f"{function} ({key}): the integer parameter '{a.name}' is computed per event inside the recipe; the device "
+                                  "programs take integer parameters as constants or as columns of the input table (rows grouped by value)")
+    if not np.can_cast(a.dtype, np.int32):  # ("fii->f" and the like: the column must cast to the signature's 'i', reference :1565-1572)
+        raise ProcessingChainError(f"could not find a type signature matching the types of the variables given for {function} ({a.name} is {a.dtype})")
+    if a.source not in b.group_values:
+        raise _PerEventInteger(a.source)
+    return int(b.group_values[a.source])
 
 
 def _as_taps(b: _Builder, a, function):
@@ -2164,6 +2382,145 @@ def _extract_stages(b: _Builder, steps, out_pars, n_rows, ft):
     return steps, stages
 
 
+def _column_dtype(dt):
+    """type of the column an integer value travels in (the 8-bit integer types have no column type of their own: 16 bits hold them)"""
+    dt = np.dtype(dt)
+    return {np.dtype(np.int8): np.dtype(np.int16), np.dtype(np.uint8): np.dtype(np.uint16)}.get(dt, dt)
+
+
+def _int_island(b: _Builder, steps, out_pars, ft):
+    """Per-event INTEGER arithmetic that no float register holds -- NumPy's 64-bit loops ('ll->l', 'QQ->Q': int64 / uint64 columns, int32
+    beside uint32; reference :1565-1572), comparisons, ``where`` and casts of their results, and in a float32 chain the 32-bit loops too -- leaves
+    the programs: it becomes an *integer program* (``dsp_chain_create(..., DSP_I64)``: 64-bit integer registers, NumPy's wrap-around bit
+    for bit, dsp_scalar.hip) that runs ahead of everything else on the input table's integer columns.  What the recipe's outputs or the
+    other programs read of it arrives as a column of the value's own type (``SExpr.op == 'ext'``).  Operands must be columns of the input
+    table, constants or such arithmetic itself: a 64-bit loop on a value a processor computes is refused by name (a 32-bit one then stays
+    where it was: the float operation, exact below 2^24).  Returns the stage's description (None: nothing to do) and {output: dtype} of the
+    recipe outputs it writes itself."""
+    nodes, seen = [], set()
+
+    def visit(x):
+        if isinstance(x, SExpr) and id(x) not in seen:
+            seen.add(id(x))
+            for y in x.args:
+                visit(y)
+            nodes.append(x)  # (operands first)
+
+    for _fn, args, _key in steps:
+        for a in args:
+            visit(a)
+    for o in out_pars:
+        visit(b.vars.get(o))
+
+    def int_dt(x):
+        dt = getattr(x, "dtype", None)
+        if isinstance(x, SExpr):
+            return np.dtype(dt) if x.op == "func" and dt is not None and np.dtype(dt).kind in "iub" else None
+        if isinstance(x, Var) and x.kind == "scalar":
+            return np.dtype(dt) if dt is not None and np.dtype(dt).kind in "iub" else None
+        return None
+
+    def is_leaf(x):  # a column of the input table: in HBM before any program runs
+        return isinstance(x, Var) and x.kind == "scalar" and x.is_input and x.source is not None and x.sreg is None and getattr(x, "ext_key", None) is None
+
+    wide = lambda dt: dt is not None and dt.itemsize == 8 and dt.kind in "iu"  # noqa: E731
+    eligible = {}
+
+    def ok(x):  # computable ahead of the programs, in integers
+        if isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, Quantity):
+            return True
+        if is_leaf(x):
+            return int_dt(x) is not None
+        if isinstance(x, SExpr):
+            if id(x) not in eligible:
+                eligible[id(x)] = x.op == "func" and int_dt(x) is not None and all(ok(y) for y in x.args[1:])
+            return eligible[id(x)]
+        return False
+
+    need = []
+    for n in nodes:
+        if n.op != "func":
+            continue
+        opn = [x for x in n.args[1:] if isinstance(x, (Var, SExpr))]
+        is_wide = wide(int_dt(n)) or any(wide(int_dt(x)) for x in opn)
+        narrow32 = ((int(n.args[0]) >> 8) & 0xff) == 32 and ft != np.dtype(np.float64) and int_dt(n) is not None
+        if is_wide:
+            if int_dt(n) is None or not ok(n):
+                raise NotImplementedError(f"'{n.name}': 64-bit integers reach the device as columns of the input table and arithmetic between them; "
+                                          "here they meet a value a processor computes, or leave as a float (astype of a 64-bit integer)")
+            need.append(n)
+        elif narrow32 and ok(n):
+            need.append(n)
+    if not need:
+        return None, {}
+    island = {}
+
+    def take(x):
+        if isinstance(x, SExpr) and id(x) not in island:
+            for y in x.args[1:]:
+                take(y)
+            island[id(x)] = x
+
+    for n in need:
+        take(n)
+    members = [n for n in nodes if id(n) in island]  # (operands first)
+
+    # who reads a member from outside: a processor, an expression that stays behind, an output of the recipe
+    outside = set()
+    for _fn, args, _key in steps:
+        outside.update(id(a) for a in args if isinstance(a, SExpr) and id(a) in island)
+    for n in nodes:
+        if id(n) not in island:
+            outside.update(id(y) for y in n.args if isinstance(y, SExpr) and id(y) in island)
+    direct = {}
+    for o in out_pars:
+        v = b.vars.get(o)
+        if isinstance(v, SExpr) and id(v) in island and not (v.is_coord is True and _time_unit_ns(v.unit) is not None):
+            direct.setdefault(id(v), []).append(o)
+        elif isinstance(v, SExpr) and id(v) in island:
+            outside.add(id(v))
+
+    t = Program()
+    in_vars, leaf_io = {}, {}
+
+    def opnd(x):
+        if isinstance(x, SExpr):
+            return Scalar.reg(x.sreg)
+        if isinstance(x, Var):
+            if id(x) not in leaf_io:
+                name = f"in:{x.name}"
+                leaf_io[id(x)] = t.add_io(name, _lib.IO_SCALAR_IN, np.dtype(x.dtype))
+                in_vars[name] = x
+            return Scalar.input(leaf_io[id(x)])
+        return Scalar.const(float(x))
+
+    outs, out_dtypes, direct_out = [], {}, {}
+    for k, n in enumerate(members):
+        n.sreg = t.add_sregs(1)
+        sp = [opnd(x) for x in n.args[1:]]
+        t.add_op(_lib.OP_SCALAR_FUNC, dst=n.sreg, ip=(int(n.args[0]),), sp=tuple(sp + [Scalar.const(0.0)] * (3 - len(sp))))
+    for k, n in enumerate(members):
+        nat = int_dt(n)
+        is_u64 = int(nat == np.dtype(np.uint64))
+        for o in direct.get(id(n), ()):
+            t.add_op(_lib.OP_STORE_SCALAR, io=t.add_io(f"out:{o}", _lib.IO_SCALAR_OUT, _column_dtype(nat)), ip=(n.sreg, is_u64))
+            direct_out[o] = (nat, _column_dtype(nat))
+        if id(n) in outside:
+            key = f"in:isl{k}"
+            t.add_op(_lib.OP_STORE_SCALAR, io=t.add_io(f"out:isl{k}", _lib.IO_SCALAR_OUT, _column_dtype(nat)), ip=(n.sreg, is_u64))
+            outs.append((f"out:isl{k}", key, None))
+            out_dtypes[key] = _column_dtype(nat)
+            n.ext_key = key
+    for n in members:  # from here on a member is a column in HBM to everybody else
+        n.op, n.args, n.sreg = "ext", (), None
+        n.ext_dtype = _column_dtype(int_dt(n))
+    if len(t.ops) > _lib.MAX_OPS or len(t.io) > _lib.MAX_IO or t.n_sregs > _lib.MAX_SREGS:
+        raise NotImplementedError("the recipe's integer arithmetic is too large for one device program (ops/bindings/registers limit)")
+    stage = {"what": "integer arithmetic between per-event columns (64-bit registers)", "program": t, "consts": {}, "in_vars": in_vars, "alias": {},
+             "outs": outs, "out_dtypes": out_dtypes, "compute": np.dtype(np.int64), "chain": None, "bufs": {}}
+    return stage, direct_out
+
+
 def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
     """``stage_mode``: the program of a stage that runs ahead of the main program (_extract_stages): fits and other stages are not taken
     out of it again; their results arrive as bindings (``Var.ext_key``)."""
@@ -2173,6 +2530,7 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
     ext_alias = {}  # binding name -> name of the buffer a fit / stage ahead of the program filled (a slice of it has a name of its own)
     vector_lens = {}
     steps = b.steps
+    island, island_out = (None, {}) if stage_mode else _int_island(b, steps, out_pars, ft)
     # --- linear_slope_fit on the rows of the batch (dsp_linear_slope_fit_rows: one waveform per lane) instead of inside the program,
     # where its sequential float32 recurrences cost a third of a LEGEND recipe: a fit whose waveform is an input, the input minus a
     # per-event input / constant (bl_subtract or numpy.subtract), or the pole_zero of that (constant tau), read whole or through a
@@ -2274,6 +2632,8 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
     if not stage_mode and ft == np.dtype(np.float32) and os.environ.get("DSPEED_HIP_NO_STAGES", "0") != "1":
         steps, stages = _extract_stages(b, steps, out_pars, n_rows, ft)
 
+    if island is not None:
+        stages = [island] + stages
     steps = b.steps = _schedule(steps)
     out_names = set(out_pars)  # names of the variables that are outputs (a variable may have another name than the output: alias, named slice)
     for o in out_pars:
@@ -2417,6 +2777,13 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
 
     def scalar_operand(a, args, integer=False, what=""):
         """Scalar argument -> Scalar (const / input column / register)."""
+        if isinstance(a, SExpr) and a.op == "ext":  # a column the integer program ahead of this one wrote (_int_island)
+            if getattr(a, "ext_key", None) is None:
+                raise ProcessingChainError(f"{what}: '{a.name}' is written by the integer program as an output only")
+            if a.io is None:
+                a.io = p.add_io(a.ext_key, _lib.IO_SCALAR_IN, a.ext_dtype)
+                ext_alias[a.ext_key] = a.ext_key
+            return Scalar.input(a.io)
         if isinstance(a, SExpr):
             if a.sreg is None:  # first reader: emit the op (its operands were computed by earlier processors)
                 def opnd(x):
@@ -2787,6 +3154,11 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
     tb_out = {}
     for o in out_pars:
         v = b.vars.get(o)
+        if o in island_out:  # written by the integer program, in its own type
+            nat, col_dt = island_out[o]
+            out_bind[f"out:{o}"] = (SimpleNamespace(name=o, dtype=col_dt), None)
+            tb_out[o] = np.empty(n_rows, dtype=nat)
+            continue
         if _is_wf(v) and isinstance(v, tuple):  # a named slice: of an input it is read straight from the rows, else copied out of its waveform
             v = ensure_loaded(v, len(steps))
         if v is None or v.kind in (None,):
@@ -2853,6 +3225,8 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
                          "stride": col.shape[1], "sub": sub_bind, "sub_dtype": sub_code, "sub_const": sub_const, "mode": g["mode"],
                          "tau": g["tau"], "fits": list(g["fits"]), "names": [f"aux:{gi}:{j}" for j in range(4 * len(g["fits"]))]})
     p.slots = slot_len
+    if not p.ops:  # (every output is written by the integer program or handed through: the program is a placeholder)
+        p.add_op(_lib.OP_SCALAR_AFFINE, dst=p.add_sregs(1), sp=(Scalar.const(0.0), Scalar.const(0.0), Scalar.const(0.0)))
     if len(p.ops) > _lib.MAX_OPS or len(p.slots) > _lib.MAX_SLOTS or len(p.io) > _lib.MAX_IO or p.n_sregs > _lib.MAX_SREGS:
         raise NotImplementedError("recipe is too large for one device chain (ops/slots/bindings limit)")
     for st in stages:  # columns of the input table that only a stage reads are linked like the program's own

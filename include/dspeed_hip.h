@@ -74,7 +74,9 @@ extern "C" {
 #define DSP_U16 3
 #define DSP_I32 4
 #define DSP_U32 5
-#define DSP_BOOL 6 /* one byte per element, 0 / 1: chain outputs only (results of comparisons, isnan, isfinite) */
+#define DSP_BOOL 6 /* one byte per element, 0 / 1: outputs (results of comparisons, isnan, isfinite) and per-event input columns */
+#define DSP_I64 7  /* per-event columns, and the compute type of integer programs (below) */
+#define DSP_U64 8  /* per-event columns */
 
 /* ---- device, memory, streams (thin, so a host needs nothing but this library) --------------------- */
 int dsp_device_count(int* count);
@@ -131,7 +133,7 @@ const char* dsp_version(void);
 
 typedef struct dsp_io_desc {
     int32_t kind;       /* DSP_IO_* */
-    int32_t dtype;      /* DSP_F32 ... ; outputs have the chain's compute type, or DSP_BOOL (nonzero -> 1) */
+    int32_t dtype;      /* DSP_F32 ... ; outputs have the chain's compute type, or DSP_BOOL (nonzero -> 1); any type in an integer program */
     int32_t len;        /* samples per row used by the chain (1 for scalars) */
     int32_t offset;     /* first sample within the row: a constant slice wf[offset:offset+len] costs nothing */
     int64_t row_stride; /* elements between consecutive rows (>= offset+len; 1 for scalars; 0 = same value for all rows) */
@@ -239,7 +241,17 @@ typedef struct dsp_scalar_arg {
 #define DSP_FN_IFLOORDIV 19 /* floor division, 0 where B == 0 (numpy.floor_divide's integer loops) */
 #define DSP_FN_ICAST 20     /* astype to an integer type (:1268-1300, numpy.copyto(casting="unsafe")): truncation towards zero, then the wrap; a value the
                              * C conversion does not define (NaN, beyond the 32-bit / 64-bit range it goes through) gives what x86-64's cvtt* gives */
-#define DSP_FN_LAST 20
+#define DSP_FN_LOR 21       /* A != 0 || B != 0: numpy.add's '??->?' loop, what the language's + is between truth values (processing_chain.py:832-891) */
+#define DSP_FN_LAND 22      /* A != 0 && B != 0: numpy.multiply's '??->?' loop */
+#define DSP_FN_LAST 22
+/* INTEGER PROGRAMS (compute_dtype DSP_I64): arithmetic between per-event INTEGER values whose NumPy loop is a 64-bit one ('ll->l', 'QQ->Q':
+ * int64 / uint64 columns, int32 beside uint32) cannot be held in a float loop type.  A program of SCALAR_FUNC and STORE_SCALAR ops only may
+ * be created with compute_dtype DSP_I64: its registers are 64-bit integers, input columns are integer or DSP_BOOL columns read exactly,
+ * DSP_FN_IADD ... DSP_FN_ICAST take bits 8 / 16 / 32 / 64 and wrap to that type as NumPy's loops do (two's complement; floor division by 0
+ * gives 0), comparisons / WHERE / LOR / LAND / COPY work on the integers -- a comparison or floor division of uint64 values carries
+ * DSP_FN_INT(64, 0) and is done unsigned --, and a STORE_SCALAR writes the binding's own type: DSP_I64 / DSP_U64 as they are, narrower integers
+ * truncated, DSP_BOOL as != 0, DSP_F32 / DSP_F64 converted (ip[1] = 1: the register holds a uint64).  dspeed_amd's recipe builder runs such a
+ * program ahead of the main one and hands its columns on. */
 #define DSP_FN_INT(bits, is_signed) (((bits) << 8) | ((is_signed) ? 1 << 16 : 0))
 #define DSP_FN_CODE(ip0) ((ip0) & 0xff)
 #define DSP_FN_INT_BITS(ip0) (((ip0) >> 8) & 0xff)
@@ -256,7 +268,8 @@ typedef struct dsp_op {
 
 typedef struct dsp_chain dsp_chain; /* opaque */
 
-/* compute_dtype: DSP_F32 (the loop int16/uint16/float32 inputs select) or DSP_F64 (float64/int32/uint32 inputs).
+/* compute_dtype: DSP_F32 (the loop int16/uint16/float32 inputs select), DSP_F64 (float64/int32/uint32 inputs) or DSP_I64 (an integer program of
+ * per-event values, above).
  * slot_len[s] = number of samples held by waveform slot s (static per chain, like ProcChainVar shapes).
  * Validates the program and every constant-only DSPFatal condition; on failure returns the code and *out = NULL. */
 int dsp_chain_create(const dsp_op* ops, int n_ops, const dsp_io_desc* io, int n_io, const int32_t* slot_len, int n_slots,

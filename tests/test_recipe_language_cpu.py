@@ -243,12 +243,16 @@ def test_integer_columns_select_numpys_integer_loops():
                       (("uint16", "int32"), "int32"), (("uint32",), "uint32")):
         assert _int_loop_of([v(d) for d in dts], "x") == np.dtype(want), dts
         assert np.dtype(want).char == next(t[0] for t in np.add.types if all(np.can_cast(d, t[0]) for d in dts) and t[0] != "?")
-    for dts in (("int32", "uint32"), ("int64",), ("bool", "bool")):
-        with pytest.raises(NotImplementedError):
-            _int_loop_of([v(d) for d in dts], "x")
+    # 64-bit loops (round 4: per-event values in an integer program, waveforms range-tracked in the float64 chain); truth values alone take the
+    # int8 loop where the ufunc has no '??' one (floor_divide); int64 beside uint64 is NumPy's float64 loop, refused by name
+    for dts, want in ((("int32", "uint32"), "int64"), (("int64",), "int64"), (("uint64", "uint16"), "uint64"), (("bool", "bool"), "int8")):
+        assert _int_loop_of([v(d) for d in dts], "x") == np.dtype(want), dts
+    with pytest.raises(NotImplementedError, match="float64"):
+        _int_loop_of([v("int64"), v("uint64")], "x")
     assert _int_loop_const(2.5, np.dtype("uint16"), "x") == 2.0 and _int_loop_const(3.5, np.dtype("uint16"), "x") == 4.0  # np.round: half to even
-    with pytest.raises(NotImplementedError, match="does not fit"):
-        _int_loop_const(-1, np.dtype("uint16"), "x")
+    # a constant outside the loop's type wraps around, as NumPy's conversion between its integer scalars does (reference :1765-1768)
+    assert _int_loop_const(-1, np.dtype("uint16"), "x") == 65535.0 == float(np.uint16(np.int64(-1)))
+    assert _int_loop_const(40000, np.dtype("int16"), "x") == float(np.int16(np.int64(40000)))
     tb = {"u": np.zeros((4, 64), np.uint16), "h": np.zeros((4, 64), np.int16), "ev": np.zeros(4, np.uint16), "n32": np.zeros(4, np.int32)}
     procs = {"a": "u * 2.5", "b": "-h", "c": "ev // 3", "d": "astype(h, 'uint16') + u", "e": "n32 // 2", "f": "u / 2"}
     chain, _, out = build_processing_chain({"outputs": list(procs), "processors": procs}, tb)
@@ -257,8 +261,10 @@ def test_integer_columns_select_numpys_integer_loops():
     assert ew == {_lib.fn_int(_lib.FN_IMUL, np.uint16), _lib.fn_int(_lib.FN_ISUB, np.int16), _lib.fn_int(_lib.FN_ICAST, np.uint16),
                   _lib.fn_int(_lib.FN_IADD, np.uint16), _lib.FN_DIV}
     sf = {o[4][0] for o in chain.program.ops if o[0] == _lib.OP_SCALAR_FUNC}
-    # (a 32-bit loop between per-event values of a float32 chain is the float operation: exact below 2**24)
-    assert sf == {_lib.fn_int(_lib.FN_IFLOORDIV, np.uint16), _lib.FN_FLOORDIV}
+    assert sf == {_lib.fn_int(_lib.FN_IFLOORDIV, np.uint16)}
+    # (a 32-bit loop between per-event columns of a float32 chain: no float32 holds every int32 -- it runs in the integer program ahead of the chain)
+    isl = chain._stages[0]
+    assert isl["compute"] == np.int64 and [o[4][0] for o in isl["program"].ops if o[0] == _lib.OP_SCALAR_FUNC] == [_lib.fn_int(_lib.FN_IFLOORDIV, np.int32)]
     mul = next(o for o in chain.program.ops if o[0] == _lib.OP_ELEMENTWISE and o[4][0] == _lib.fn_int(_lib.FN_IMUL, np.uint16))
     assert mul[5][1].value == 2.0
 
