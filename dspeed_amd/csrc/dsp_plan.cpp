@@ -90,7 +90,8 @@ static void note(ChainPlan* ch, const char* fmt, ...) {
 static bool fn_code_ok(int ip0, bool f64, bool i64 = false) {
     const int code = DSP_FN_CODE(ip0), bits = DSP_FN_INT_BITS(ip0);
     if (ip0 < 0 || code > DSP_FN_LAST || (ip0 >> 17) != 0) return false;
-    if (code >= DSP_FN_IADD && code <= DSP_FN_ICAST) return bits == 8 || bits == 16 || (bits == 32 && (f64 || i64)) || (bits == 64 && i64);
+    // (64 bits outside an integer program: the float64 chain's waveform loops, exact while results stay below 2^53 -- the caller's promise)
+    if (code >= DSP_FN_IADD && code <= DSP_FN_ICAST) return bits == 8 || bits == 16 || (bits == 32 && (f64 || i64)) || (bits == 64 && (i64 || (f64 && code != DSP_FN_ICAST)));
     if (i64) {  // an integer program: no float arithmetic; a comparison may name its loop's type (uint64: unsigned)
         if (code <= DSP_FN_DIV || code == DSP_FN_NEG || code == DSP_FN_FLOORDIV) return false;
         return (ip0 >> 8) == 0 || bits == 8 || bits == 16 || bits == 32 || bits == 64;

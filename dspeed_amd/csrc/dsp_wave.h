@@ -187,7 +187,8 @@ __device__ __forceinline__ int64_t int_loop_value(double a) {
 }
 
 __device__ __forceinline__ double int_loop_wrap(int64_t r, int meta) {
-    const int bits = DSP_FN_INT_BITS(meta);  // 8, 16, 32
+    const int bits = DSP_FN_INT_BITS(meta);  // 8, 16, 32; 64 (the float64 chain, waveforms: the host admits the loop only where the operands' types
+    if (bits >= 64) return (double)r;        // bound the result below 2^53 -- nothing wraps and every value is a float64, processing_chain.py _wide_wf_loop)
     const uint64_t m = (uint64_t)r & ((1ull << bits) - 1ull);
     int64_t v = (int64_t)m;
     if (DSP_FN_INT_SIGNED(meta) && ((m >> (bits - 1)) & 1ull)) v -= (int64_t)1 << bits;

@@ -2512,8 +2512,8 @@ def _int_island(b: _Builder, steps, out_pars, ft):
             out_dtypes[key] = _column_dtype(nat)
             n.ext_key = key
     for n in members:  # from here on a member is a column in HBM to everybody else
-        n.op, n.args, n.sreg = "ext", (), None
         n.ext_dtype = _column_dtype(int_dt(n))
+        n.op, n.args, n.sreg = "ext", (), None
     if len(t.ops) > _lib.MAX_OPS or len(t.io) > _lib.MAX_IO or t.n_sregs > _lib.MAX_SREGS:
         raise NotImplementedError("the recipe's integer arithmetic is too large for one device program (ops/bindings/registers limit)")
     stage = {"what": "integer arithmetic between per-event columns (64-bit registers)", "program": t, "consts": {}, "in_vars": in_vars, "alias": {},

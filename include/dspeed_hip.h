@@ -234,7 +234,9 @@ typedef struct dsp_scalar_arg {
 /* NumPy's INTEGER ufunc loops (the first signature every operand can be cast to is an integer one when all operands are integer columns,
  * processing_chain.py:1565-1572, 1654-1664): the operands hold integers exactly in the loop type, the operation is done on 64-bit integers
  * and the result wrapped to the loop's integer type, the way 'hh->h', 'HH->H', 'ii->i' ... do.  ip[0] = DSP_FN_I* | DSP_FN_INT(bits, signed)
- * with bits 8, 16 or 32 (32 needs the float64 chain: a float32 does not hold every int32). */
+ * with bits 8, 16 or 32 (32 needs the float64 chain: a float32 does not hold every int32), or 64 in the float64 chain for IADD / ISUB / IMUL /
+ * IFLOORDIV when the caller knows that operands and result stay below 2^53 in magnitude (int32 beside uint32 samples: nothing wraps there and
+ * every value is a float64; 64-bit loops between per-event values run exactly in an integer program, below). */
 #define DSP_FN_IADD 16
 #define DSP_FN_ISUB 17
 #define DSP_FN_IMUL 18

@@ -146,12 +146,12 @@ def test_wide_loops_on_waveforms_are_exact_in_the_float64_chain():
     b = rng.integers(0, 2 ** 32, (n, 96), dtype=np.uint32)
     a[0, :4] = [-2 ** 31, 2 ** 31 - 1, -1, 0]
     b[0, :4] = [2 ** 32 - 1, 2 ** 32 - 1, 0, 1]
-    tb = {"a": a, "b": b, "s": rng.integers(0, 2 ** 32, n, dtype=np.uint32), "h": rng.integers(1, 1000, (n, 96)).astype(np.int16)}
-    procs = {"x": "a + b", "y": "a - b", "z": "b - a", "q": "a // b", "t": "a + s", "m": "(a + b) * h", "u": "(a + b) // h", "neg": "-(a + b)"}
+    tb = {"a": a, "b": b, "sc": rng.integers(0, 2 ** 32, n, dtype=np.uint32), "h": rng.integers(1, 1000, (n, 96)).astype(np.int16)}
+    procs = {"x": "a + b", "y": "a - b", "z": "b - a", "q": "a // b", "t": "a + sc", "m": "(a + b) * h", "u": "(a + b) // h", "neg": "-(a + b)"}
     chain, out = _run(procs, list(procs), tb)
     assert chain.loop_dtype == np.float64
     with np.errstate(all="ignore"):
-        want = {"x": a + b, "y": a - b, "z": b - a, "q": a // b, "t": a + tb["s"][:, None], "m": (a + b) * tb["h"], "u": (a + b) // tb["h"], "neg": -(a + b)}
+        want = {"x": a + b, "y": a - b, "z": b - a, "q": a // b, "t": a + tb["sc"][:, None], "m": (a + b) * tb["h"], "u": (a + b) // tb["h"], "neg": -(a + b)}
     for k, w in want.items():
         assert w.dtype == np.int64 and out[k].dtype == np.int64 and np.array_equal(out[k], w), k
     with pytest.raises(NotImplementedError, match="2\\^53"):  # 32 + 32 bits: the product can exceed what a float64 holds
