@@ -25,7 +25,7 @@ ARG_CONST, ARG_INPUT, ARG_REG = range(3)
  OP_SCALAR_AFFINE, OP_MEAN_BELOW, OP_CONVOLVE_AMAX, OP_WINDOWER, OP_AVG_CURRENT, OP_TRAP_WINDOW_PICKOFF, OP_TRAP_REDUCE, OP_UPSAMPLER, OP_MOVING_WINDOW_MULTI, OP_LINEAR_SLOPE_FIT,
  OP_SCALAR_CONVERT, OP_SCALAR_DIV, OP_INTERP_TIME_POINT_THRESH, OP_MIN_MAX_NORM, OP_ELEMENTWISE, OP_SCALAR_FUNC) = range(1, 34)
 (FN_ADD, FN_SUB, FN_MUL, FN_DIV, FN_LT, FN_LE, FN_GT, FN_GE, FN_EQ, FN_NE, FN_WHERE, FN_ISNAN, FN_ISFINITE, FN_NEG, FN_COPY, FN_FLOORDIV,
- FN_IADD, FN_ISUB, FN_IMUL, FN_IFLOORDIV, FN_ICAST, FN_LOR, FN_LAND) = range(23)
+ FN_IADD, FN_ISUB, FN_IMUL, FN_IFLOORDIV, FN_ICAST, FN_LOR, FN_LAND, FN_RINT, FN_FLOOR, FN_CEIL, FN_TRUNC) = range(27)
 
 
 def fn_int(code, dtype):

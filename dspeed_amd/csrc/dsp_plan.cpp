@@ -93,7 +93,7 @@ static bool fn_code_ok(int ip0, bool f64, bool i64 = false) {
     // (64 bits outside an integer program: the float64 chain's waveform loops, exact while results stay below 2^53 -- the caller's promise)
     if (code >= DSP_FN_IADD && code <= DSP_FN_ICAST) return bits == 8 || bits == 16 || (bits == 32 && (f64 || i64)) || (bits == 64 && (i64 || (f64 && code != DSP_FN_ICAST)));
     if (i64) {  // an integer program: no float arithmetic; a comparison may name its loop's type (uint64: unsigned)
-        if (code <= DSP_FN_DIV || code == DSP_FN_NEG || code == DSP_FN_FLOORDIV) return false;
+        if (code <= DSP_FN_DIV || code == DSP_FN_NEG || code == DSP_FN_FLOORDIV || code >= DSP_FN_RINT) return false;
         return (ip0 >> 8) == 0 || bits == 8 || bits == 16 || bits == 32 || bits == 64;
     }
     return (ip0 >> 8) == 0;

@@ -37,7 +37,11 @@ __device__ __forceinline__ T sc_apply(int ip0, T a, T b, T c) {
         case DSP_FN_ISNAN: return (T)(a != a);
         case DSP_FN_ISFINITE: return (T)((a - a) == (T)0);
         case DSP_FN_NEG: return -a;
-        case DSP_FN_FLOORDIV: return floor(a / b);
+        case DSP_FN_FLOORDIV: return np_floor_divide<T>(a, b);
+        case DSP_FN_RINT: return rint(a);
+        case DSP_FN_FLOOR: return floor(a);
+        case DSP_FN_CEIL: return ceil(a);
+        case DSP_FN_TRUNC: return trunc(a);
         case DSP_FN_LOR: return (T)(a != (T)0 || b != (T)0);
         case DSP_FN_LAND: return (T)(a != (T)0 && b != (T)0);
         default: return a;

@@ -283,7 +283,11 @@ __device__ __forceinline__ T ew_apply(T a, T b, T c, int meta) {
     else if constexpr (FN == DSP_FN_ISNAN) return (T)(a != a);
     else if constexpr (FN == DSP_FN_ISFINITE) return (T)((a - a) == (T)0);
     else if constexpr (FN == DSP_FN_NEG) return -a;
-    else if constexpr (FN == DSP_FN_FLOORDIV) return floor(a / b);
+    else if constexpr (FN == DSP_FN_FLOORDIV) return np_floor_divide<T>(a, b);
+    else if constexpr (FN == DSP_FN_RINT) return rint(a);
+    else if constexpr (FN == DSP_FN_FLOOR) return floor(a);
+    else if constexpr (FN == DSP_FN_CEIL) return ceil(a);
+    else if constexpr (FN == DSP_FN_TRUNC) return trunc(a);
     else if constexpr (FN == DSP_FN_LOR) return (T)(a != (T)0 || b != (T)0);
     else if constexpr (FN == DSP_FN_LAND) return (T)(a != (T)0 && b != (T)0);
     else return a;
@@ -314,6 +318,10 @@ __device__ __forceinline__ void ew_dispatch(int fn, F&& f) {
         case DSP_FN_FLOORDIV: f(std::integral_constant<int, DSP_FN_FLOORDIV>()); break;
         case DSP_FN_LOR: f(std::integral_constant<int, DSP_FN_LOR>()); break;
         case DSP_FN_LAND: f(std::integral_constant<int, DSP_FN_LAND>()); break;
+        case DSP_FN_RINT: f(std::integral_constant<int, DSP_FN_RINT>()); break;
+        case DSP_FN_FLOOR: f(std::integral_constant<int, DSP_FN_FLOOR>()); break;
+        case DSP_FN_CEIL: f(std::integral_constant<int, DSP_FN_CEIL>()); break;
+        case DSP_FN_TRUNC: f(std::integral_constant<int, DSP_FN_TRUNC>()); break;
         default: f(std::integral_constant<int, DSP_FN_COPY>()); break;
     }
 }

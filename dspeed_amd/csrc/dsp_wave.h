@@ -177,6 +177,22 @@ __device__ __forceinline__ bool pickoff_in_range(T t_in, int n) {
     return !(t_in != t_in) && !(t_in < (T)0) && !(t_in > (T)(n - 1));
 }
 
+// numpy.floor_divide's float loops (numpy/_core/src/npymath: npy_divmod): the quotient is formed from fmod's exact remainder, so it is the
+// floor of the TRUE quotient where floor(a / b) can land one above it (a / b rounding up to an integer)
+template <typename T>
+__device__ __forceinline__ T np_floor_divide(T a, T b) {
+    if (b == (T)0) return a / b;  // (inf or NaN, as the division gives it)
+    T mod = sizeof(T) == 8 ? (T)fmod((double)a, (double)b) : (T)fmodf((float)a, (float)b);
+    T div = (a - mod) / b;
+    if (mod != (T)0 && ((b < (T)0) != (mod < (T)0))) div -= (T)1;
+    if (div != (T)0) {
+        T fl = floor(div);
+        if (div - fl > (T)0.5) fl += (T)1;
+        return fl;
+    }
+    return copysign((T)0, a / b);
+}
+
 // ------------------------------------------------------------------------------------------------
 // NumPy's integer ufunc loops on values held in the float loop type (DSP_FN_IADD ... DSP_FN_ICAST, dspeed_hip.h): exact 64-bit integer
 // arithmetic, then the wrap to the loop's integer type

@@ -1357,8 +1357,18 @@ class _Builder:
             if isinstance(val, Quantity):
                 return Quantity(r)
             return int(r) if float(r).is_integer() and not isinstance(to, float) else r
+        if _is_wf(val):
+            # a waveform: the reference's round_to_nearest / floor_to_nearest / ... ufunc sample by sample (processors/round_to_nearest.py):
+            # to_nearest * f(val / to_nearest), each operation in the loop's type; a NaN sample stays NaN
+            if isinstance(to, (Grid, Quantity)):
+                raise ProcessingChainError(f"could not find valid conversion for {to!r} in '{src}': a waveform's samples are not times")
+            fn = {"round": _lib.FN_RINT, "floor": _lib.FN_FLOOR, "ceil": _lib.FN_CEIL, "trunc": _lib.FN_TRUNC}[f]
+            unit, nm = self._unit_of(val), self._nm(val)
+            q = val if float(to) == 1.0 else self._elementwise(_lib.FN_DIV, [val, float(to)], f"({nm}/{to})", src, unit)
+            r = self._elementwise(fn, [q], f"{f}({nm}, {to})", src, unit)
+            return r if float(to) == 1.0 else self._elementwise(_lib.FN_MUL, [r, float(to)], f"{f}({nm}, {to})", src, unit)
         if not _is_scalar(val):
-            raise NotImplementedError(f"{f}() of waveforms is not supported on the device: '{src}'")
+            raise ProcessingChainError(f"cannot round {val!r} in '{src}'")
         mode = _ROUND_MODES[f]
         if val.is_coord is True:
             if val.grid is None:
@@ -1370,8 +1380,8 @@ class _Builder:
             else:
                 grid = Grid(val.grid.period * float(to), val.grid.offset, val.grid.offset_var)
             return self.converted(val, grid, mode)
-        if isinstance(to, (Grid, Quantity)):
-            raise NotImplementedError(f"'{src}': rounding a per-event variable that is not a time coordinate to a time")
+        if isinstance(to, (Grid, Quantity)):  # (the reference hands the time to the rounding ufunc, whose manager finds no grid to count it in, :1752-1756)
+            raise ProcessingChainError(f"could not find valid conversion for {to!r} in '{src}'; '{val.name}' is not a time coordinate")
         q = val if float(to) == 1.0 else SExpr("div", (val, float(to)), f"({val.name}/{to})", val.unit, False, None)
         r = SExpr("convert", (q, 0.0, 0.0, 1.0), f"{f}({val.name}, {to})", val.unit, False, None, mode)
         return r if float(to) == 1.0 else SExpr("affine", (r, float(to), -0.0), f"{f}({val.name}, {to})", val.unit, False, None)
@@ -1500,8 +1510,8 @@ class _Builder:
                    ast.FloorDiv: (_lib.FN_FLOORDIV, "//")}.get(type(op), (None, None))
         variables = [x for x in (a, b) if _is_wf(x) or _is_scalar(x)]
         int_loop = fn not in (None, _lib.FN_DIV) and all(_is_int_dtype(x) for x in variables)
-        if fn is None or (fn == _lib.FN_FLOORDIV and not int_loop):
-            raise NotImplementedError(f"operator in '{src}' is not available on waveforms on the device path")
+        if fn is None:  # (%, **, @ ...: not in the reference's operator table either, :46-59)
+            raise ProcessingChainError(f"Could not parse expression:\n  {src}")
         dtype = np.float32
         if int_loop and _all_bool(variables) and fn != _lib.FN_FLOORDIV:
             # truth values alone: numpy.add and numpy.multiply have '??->?' loops -- logical or, logical and --, numpy.subtract refuses
@@ -1610,20 +1620,18 @@ class _Builder:
                 return self._scalar_func(_lib.FN_LOR if isinstance(op, ast.Add) else _lib.FN_LAND, [a, b],
                                          f"({self._nm(a)}{'+' if isinstance(op, ast.Add) else '*'}{self._nm(b)})", None, False, None, np.bool_)
             int_dt = _int_loop_of(variables, src)
-        if isinstance(op, ast.FloorDiv):  # numpy.floor_divide as a processor: len(v)//2 and the like (reference :832-847)
-            for x in (a, b):
-                if isinstance(x, (tuple, Grid, Quantity)) or (isinstance(x, Var) and x.kind != "scalar"):
-                    raise NotImplementedError(f"'//' in '{src}' takes per-event variables and plain numbers")
-            v = a if _is_scalar(a) else b
-            if int_dt is not None:
-                a, b = (x if _is_scalar(x) else _int_loop_const(x, int_dt, src) for x in (a, b))
-                return self._scalar_func(_lib.fn_int(_lib.FN_IFLOORDIV, int_dt), [a, b], f"({self._nm(a)}//{self._nm(b)})", v.unit, False, None, int_dt)
-            return self._scalar_func(_lib.FN_FLOORDIV, [a, b], f"({self._nm(a)}//{self._nm(b)})", v.unit, False, None, None)
-        if sym is None:
-            raise NotImplementedError(f"operator in '{src}' is not supported between per-event variables")
+        if sym is None and not isinstance(op, ast.FloorDiv):  # (%, **, @ ...: not in the reference's operator table either, :46-59)
+            raise ProcessingChainError(f"Could not parse expression:\n  {src}")
         for x in (a, b):
             if isinstance(x, (tuple, Grid)) or (isinstance(x, Var) and x.kind != "scalar"):
-                raise NotImplementedError(f"expressions on waveforms are not supported on the device: '{src}'")
+                raise ProcessingChainError(f"operands {a!r} and {b!r} of '{src}' are not numbers or per-event variables")
+        if isinstance(op, ast.FloorDiv):  # numpy.floor_divide as a processor: len(v)//2 and the like (reference :832-847)
+            v = a if _is_scalar(a) else b
+            if int_dt is not None:
+                a, b = (x if _is_scalar(x) else _int_loop_const(x, int_dt, src, self.default_period) for x in (a, b))
+                return self._scalar_func(_lib.fn_int(_lib.FN_IFLOORDIV, int_dt), [a, b], f"({self._nm(a)}//{self._nm(b)})", v.unit, False, None, int_dt)
+            _, (a, b) = _resolve(self, "ss", [a, b], expression=True)  # (a time beside the variable counts periods of its grid)
+            return self._scalar_func(_lib.FN_FLOORDIV, [a, b], f"({self._nm(a)}//{self._nm(b)})", v.unit, False, None, None)
         sa, sb = _is_scalar(a), _is_scalar(b)
         name = f"({a.name if sa else a}{sym}{b.name if sb else b})"
         if sa and sb:  # reference :848-872
@@ -1884,7 +1892,15 @@ def _add_step(b: _Builder, key, node, new_vars, proc_strings):
         if is_wf(x) and not is_wf(y) and function in ("subtract", "add"):
             function = "numpy_subtract" if function == "subtract" else "numpy_add"
         elif is_wf(x) or is_wf(y):
-            raise NotImplementedError(f"numpy.{function} on these waveform operands is not available on the device path ({key})")
+            # the ufunc on waveforms, as the operator of the language makes it (one NumPy loop per sample); the declared output names the result
+            val = b._wf_binop(_NUMPY_BINARY[function](), x, y, f"numpy.{function}({', '.join(map(str, node['args']))})")
+            if out.length is not None and out.length != val.length:
+                raise ProcessingChainError(f"failed to broadcast array dimensions for {function}: '{out.name}' holds {out.length} samples, the operands {val.length}")
+            val.name = out.name
+            val.unit = out.unit if out.unit is not None else val.unit
+            val.grid = out.grid if out.grid is not None else val.grid
+            b.vars[new_vars[0]] = val
+            return
         else:
             b.vars[new_vars[0]] = b._scalar_binop(_NUMPY_BINARY[function](), x, y, str(node["args"]), declared=out)
             return

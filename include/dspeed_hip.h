@@ -230,7 +230,7 @@ typedef struct dsp_scalar_arg {
 #define DSP_FN_ISFINITE 12
 #define DSP_FN_NEG 13
 #define DSP_FN_COPY 14     /* astype to the loop type */
-#define DSP_FN_FLOORDIV 15 /* floor(A / B): numpy.floor_divide between per-event values that hold integers (len(v) // 2) */
+#define DSP_FN_FLOORDIV 15 /* numpy.floor_divide's float loops (npy_divmod: the quotient from fmod, so that it never lies above A / B's true floor) */
 /* NumPy's INTEGER ufunc loops (the first signature every operand can be cast to is an integer one when all operands are integer columns,
  * processing_chain.py:1565-1572, 1654-1664): the operands hold integers exactly in the loop type, the operation is done on 64-bit integers
  * and the result wrapped to the loop's integer type, the way 'hh->h', 'HH->H', 'ii->i' ... do.  ip[0] = DSP_FN_I* | DSP_FN_INT(bits, signed)
@@ -245,7 +245,11 @@ typedef struct dsp_scalar_arg {
                              * C conversion does not define (NaN, beyond the 32-bit / 64-bit range it goes through) gives what x86-64's cvtt* gives */
 #define DSP_FN_LOR 21       /* A != 0 || B != 0: numpy.add's '??->?' loop, what the language's + is between truth values (processing_chain.py:832-891) */
 #define DSP_FN_LAND 22      /* A != 0 && B != 0: numpy.multiply's '??->?' loop */
-#define DSP_FN_LAST 22
+#define DSP_FN_RINT 23      /* round / floor / ceil / trunc of every sample (processors/round_to_nearest.py: the language's round(wf, to_nearest) is */
+#define DSP_FN_FLOOR 24     /* A / to_nearest, one of these, times to_nearest) */
+#define DSP_FN_CEIL 25
+#define DSP_FN_TRUNC 26
+#define DSP_FN_LAST 26
 /* INTEGER PROGRAMS (compute_dtype DSP_I64): arithmetic between per-event INTEGER values whose NumPy loop is a 64-bit one ('ll->l', 'QQ->Q':
  * int64 / uint64 columns, int32 beside uint32) cannot be held in a float loop type.  A program of SCALAR_FUNC and STORE_SCALAR ops only may
  * be created with compute_dtype DSP_I64: its registers are 64-bit integers, input columns are integer or DSP_BOOL columns read exactly,

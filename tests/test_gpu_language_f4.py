@@ -227,3 +227,36 @@ def test_a_variable_slice_bound_is_the_references_error():
     for expr in ("waveform[k:k+10]", "waveform[:k]", "waveform[0:50:k]"):
         with pytest.raises(ProcessingChainError, match="Slice values must be constants"):
             build_processing_chain({"outputs": ["x"], "processors": {"x": expr}}, tb)
+
+
+def test_rounding_floor_division_and_numpy_ufuncs_on_waveforms():
+    """round / floor / ceil / trunc(wf, to_nearest) are the reference's rounding ufuncs sample by sample (processors/round_to_nearest.py:
+    to_nearest * f(val / to_nearest) in the loop's type); ``//`` between floats is numpy.floor_divide's float loop (its quotient comes from
+    fmod, not from floor(a / b)); numpy.multiply / numpy.divide with waveform operands written as processors are the operators"""
+    rng = np.random.default_rng(31)
+    n = 40
+    wf = rng.normal(0, 50, (n, 300)).astype(np.float32)
+    wf[0, :6] = [2.5, 3.5, -2.5, -0.5, 0.5, np.nan]
+    tb = {"waveform": wf, "g": rng.uniform(0.5, 4.0, n).astype(np.float32), "d": rng.choice([0.1, 0.3, 7.0, -2.5], n).astype(np.float32)}
+    procs = {"r1": "round(waveform)", "r5": "round(waveform, 5)", "f2": "floor(waveform, 2)", "c3": "ceil(waveform, 0.5)", "t4": "trunc(waveform, 4)",
+             "fd": "waveform // d", "fd3": "waveform // 0.3", "gd": "g // d", "g01": "g // 0.1",
+             "scaled": {"function": "multiply", "module": "numpy", "args": ["waveform", "g", "scaled"]},
+             "ratio": {"function": "divide", "module": "numpy", "args": ["waveform", "scaled", "ratio"]},
+             "back": f"{M}.bl_subtract(scaled, g, back)"}
+    _, out = _run(procs, list(procs), tb)
+    f = np.float32
+    with np.errstate(all="ignore"):
+        want = {"r1": np.rint(wf), "r5": f(5) * np.rint(wf / f(5)), "f2": f(2) * np.floor(wf / f(2)), "c3": f(0.5) * np.ceil(wf / f(0.5)),
+                "t4": f(4) * np.trunc(wf / f(4)), "fd": np.floor_divide(wf, tb["d"][:, None]), "fd3": np.floor_divide(wf, f(0.3)),
+                "gd": np.floor_divide(tb["g"], tb["d"]), "g01": np.floor_divide(tb["g"], f(0.1)), "scaled": wf * tb["g"][:, None]}
+        want["ratio"] = wf / want["scaled"]
+        want["back"] = want["scaled"] - tb["g"][:, None]
+        want["back"][np.isnan(want["scaled"]).any(axis=1)] = np.nan  # (bl_subtract's NaN rule)
+    for k, w in want.items():
+        assert out[k].dtype == np.float32 and np.array_equal(out[k], w.astype(np.float32), equal_nan=True), k
+    # floor(a / b) and numpy.floor_divide do differ on these inputs (0.3 and 0.1 are not float32 numbers: quotients round up to integers)
+    with np.errstate(all="ignore"):
+        assert (np.floor(wf / f(0.3)) != want["fd3"])[~np.isnan(wf)].any() or (np.floor(tb["g"] / f(0.1)) != want["g01"]).any()
+    for bad in ("waveform % 2", "waveform ** 2", "g % 2"):  # not in the reference's operator table (processing_chain.py:46-59)
+        with pytest.raises(ProcessingChainError):
+            build_processing_chain({"outputs": ["x"], "processors": {"x": bad}}, tb)
