@@ -238,6 +238,7 @@ def test_rounding_floor_division_and_numpy_ufuncs_on_waveforms():
     wf = rng.normal(0, 50, (n, 300)).astype(np.float32)
     wf[0, :6] = [2.5, 3.5, -2.5, -0.5, 0.5, np.nan]
     tb = {"waveform": wf, "g": rng.uniform(0.5, 4.0, n).astype(np.float32), "d": rng.choice([0.1, 0.3, 7.0, -2.5], n).astype(np.float32)}
+    tb["g"][:5] = [0.5, 0.7, 1.0, 1.4, 1.5]  # (multiples of float32(0.1), which lies above 0.1: the true quotients are just below 5, 7, 10 ...)
     procs = {"r1": "round(waveform)", "r5": "round(waveform, 5)", "f2": "floor(waveform, 2)", "c3": "ceil(waveform, 0.5)", "t4": "trunc(waveform, 4)",
              "fd": "waveform // d", "fd3": "waveform // 0.3", "gd": "g // d", "g01": "g // 0.1",
              "scaled": {"function": "multiply", "module": "numpy", "args": ["waveform", "g", "scaled"]},
@@ -254,9 +255,8 @@ def test_rounding_floor_division_and_numpy_ufuncs_on_waveforms():
         want["back"][np.isnan(want["scaled"]).any(axis=1)] = np.nan  # (bl_subtract's NaN rule)
     for k, w in want.items():
         assert out[k].dtype == np.float32 and np.array_equal(out[k], w.astype(np.float32), equal_nan=True), k
-    # floor(a / b) and numpy.floor_divide do differ on these inputs (0.3 and 0.1 are not float32 numbers: quotients round up to integers)
-    with np.errstate(all="ignore"):
-        assert (np.floor(wf / f(0.3)) != want["fd3"])[~np.isnan(wf)].any() or (np.floor(tb["g"] / f(0.1)) != want["g01"]).any()
+    # floor(a / b) and numpy.floor_divide do differ on such inputs: the quotient rounds up to an integer the true one never reaches
+    assert np.array_equal(want["g01"][:5], [4, 6, 9, 13, 14]) and np.array_equal(np.floor(tb["g"][:5] / f(0.1)), [5, 7, 10, 14, 15])
     for bad in ("waveform % 2", "waveform ** 2", "g % 2"):  # not in the reference's operator table (processing_chain.py:46-59)
         with pytest.raises(ProcessingChainError):
             build_processing_chain({"outputs": ["x"], "processors": {"x": bad}}, tb)
