@@ -72,3 +72,13 @@ def assert_rel_to_peak(got, want, tol, what=""):
     err = np.max(np.abs(g - w) / peak)
     assert err <= tol, f"{what}: max |diff|/peak = {err:.3e} > {tol:g}"
     return err
+
+
+def recipe_kernel(which):
+    """The kernels the Ge recipes generate once (t0 filter 8 + 125 samples; cusp / zero-area cusp with sigma 1250, flat top 188, decay 28 125
+    samples, 5792 taps), as the REFERENCE's own generator bodies made them (oracle/gen_golden.py: kernels.npz f32_t00, energy_kernels.npz
+    f32_*_geo1) -- so that a whole-recipe test does not build its expectation with the product's generators."""
+    book, case = {"t0": ("kernels", "f32_t00"), "cusp": ("energy_kernels", "f32_cusp_filter_geo1"), "zac": ("energy_kernels", "f32_zac_filter_geo1")}[which]
+    c = next(c for c in load(book) if c.name == case)
+    assert not c.fatal
+    return np.ascontiguousarray(c["kernel"], dtype=np.float32)

@@ -142,3 +142,47 @@ ICPC = {
         "tp_aoe_samp": {"function": "add", "module": "numpy", "args": ["tp_0_est", "tp_aoe_max/16", "tp_aoe_samp"], "unit": "ns"},
     },
 }
+
+
+def icpc_with_reference_values():
+    """ICPC above with the parameter VALUES and the full output list of the reference's own Ge test configuration
+    (tests/configs/icpc-dsp-config.json: 43 processors, 34 outputs): the fit windows, the unit-less pole-zero constant (27 460.5 *samples*, as
+    that file's default stands), the 10 us / 3.008 us energy trapezoid picked at rise + 0.8 x 3 us, the zero-area cusp beside the cusp, and the
+    whole rise-time ladder 100 / 99 / 95 / 90 / 80 / 50 / 20 / 10 / 1 %.  Written as edits of ICPC so that what differs is in one place;
+    tests/test_recipe_language_cpu.py checks (where the reference checkout is mounted) that this recipe and the reference's file translate into
+    the same device programs op for op."""
+    import copy
+
+    r = copy.deepcopy(ICPC)
+    p = r["processors"]
+    p["bl_mean , bl_std, bl_slope, bl_intercept"]["args"][0] = "wf_blsub[0:750]"
+    p["wf_pz"]["defaults"] = {"db.pz.tau": "27460.5"}
+    p["pz_mean , pz_std, pz_slope, pz_intercept"]["args"][0] = "wf_pz[1500:]"
+    p["wf_etrap"]["defaults"] = {"db.etrap.rise": "10*us", "db.etrap.flat": "3.008*us"}
+    p["trapEftp"]["defaults"] = {"db.etrap.rise": "10*us", "db.etrap.flat": "3*us", "db.etrap.sample": "0.8"}
+    cusp = p["cusp_kernel"]
+    p["zac_kernel"] = {"function": "zac_filter", "module": _M, "unit": "ADC",
+                       "args": [a.replace("db.cusp.", "db.zac.").replace("cusp_kernel", "zac_kernel") for a in cusp["args"]],
+                       "defaults": {"db.zac.sigma": "20*us", "db.zac.flat": "3*us", "db.pz.tau": "450*us"}}
+    p["wf_zac"] = {"function": "fft_convolve_wf", "module": _M, "unit": "ADC",
+                   "args": [p["wf_cusp"]["args"][0], "zac_kernel", "'v'", p["wf_cusp"]["args"][3].replace("wf_cusp", "wf_zac")]}
+    p["zacEmax"] = {"function": "numpy.amax(wf_zac, 1, zacEmax)", "kwargs": {"signature": "(n),()->()", "types": ["fi->f"]}, "unit": "ADC"}
+    p["zacEftp"] = {"function": "fixed_time_pickoff", "module": _M, "args": ["wf_zac", "db.zac.sample", "'i'", "zacEftp"], "unit": "ADC",
+                    "defaults": {"db.zac.sample": "50"}}
+    ladder = [("tp_95", "0.95", "tp_99"), ("tp_90", "0.9", "tp_95"), ("tp_80", "0.8", "tp_90"), ("tp_50", "0.5", "tp_80"), ("tp_20", "0.2", "tp_50"),
+              ("tp_10", "0.1", "tp_20"), ("tp_01", "0.01", "tp_10")]
+    for name, frac, start in ladder:
+        p[name] = {"function": "time_point_thresh", "module": _M, "args": ["wf_pz", f"trapTmax*{frac}", start, 0, name], "unit": "ns"}
+    r["outputs"] = ["tp_min", "tp_max", "wf_min", "wf_max", "bl_mean", "bl_std", "bl_slope", "bl_intercept", "pz_slope", "pz_std", "pz_mean", "trapTmax",
+                    "tp_0_est", "tp_0_atrap", "tp_10", "tp_20", "tp_50", "tp_80", "tp_90", "tp_99", "tp_100", "tp_01", "tp_95", "A_max", "QDrift", "dt_eff",
+                    "tp_aoe_max", "tp_aoe_samp", "trapEmax", "trapEftp", "cuspEmax", "zacEmax", "zacEftp", "cuspEftp"]
+    return r
+
+
+ICPC_REF = icpc_with_reference_values()
+# what the oracle-side restatement of a whole pass needs to know about a recipe (tests/test_gpu_icpc_recipe.py::_expected)
+ICPC_PARAMS = {"bl_window": 700, "tau_samples": 27460.0 / 16.0, "pz_from": 1600, "etrap": (500, 125), "pick_ns": (8000.0, 2000.0 * 0.8), "zac": False,
+               "ladder": [("tp_90", 0.9, "tp_99"), ("tp_50", 0.5, "tp_90"), ("tp_10", 0.1, "tp_50")]}
+ICPC_REF_PARAMS = {"bl_window": 750, "tau_samples": 27460.5, "pz_from": 1500, "etrap": (625, 188), "pick_ns": (10000.0, 3000.0 * 0.8), "zac": True,
+                   "ladder": [("tp_95", 0.95, "tp_99"), ("tp_90", 0.9, "tp_95"), ("tp_80", 0.8, "tp_90"), ("tp_50", 0.5, "tp_80"), ("tp_20", 0.2, "tp_50"),
+                              ("tp_10", 0.1, "tp_20"), ("tp_01", 0.01, "tp_10")]}

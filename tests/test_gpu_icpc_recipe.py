@@ -5,6 +5,7 @@ processor by processor with the reference's unit handling restated in NumPy (pro
 import numpy as np
 import pytest
 
+import golden_util
 import oracle
 import recipes
 
@@ -30,8 +31,9 @@ def _convert(x, off_in, off_out, ratio, rounding=None):
     return r.astype(x.dtype)
 
 
-def _expected(wf, bl, t0_ns, F=np.float32, dt=16.0):
-    P = __import__("dspeed_amd.processors", fromlist=["x"])
+def _expected(wf, bl, t0_ns, F=np.float32, dt=16.0, par=recipes.ICPC_PARAMS):
+    """the oracle's processors composed as the recipe says, with the reference's unit handling restated; ``par``: the recipe's parameter values
+    (recipes.ICPC_PARAMS / ICPC_REF_PARAMS).  The kernels are the reference generators' own (fixtures: golden_util.recipe_kernel)."""
     e = {}
     w = wf.astype(F)
     bl, t0_ns = bl.astype(F), t0_ns.astype(F)
@@ -41,11 +43,10 @@ def _expected(wf, bl, t0_ns, F=np.float32, dt=16.0):
     tmin, tmax, e["wf_min"], e["wf_max"], _ = oracle.min_max(w)
     e["tp_min"], e["tp_max"] = to_ns(tmin), to_ns(tmax)
     blsub = oracle.bl_subtract(w, bl)[0]
-    e["bl_mean"], e["bl_std"], e["bl_slope"], e["bl_intercept"], _ = oracle.linear_slope_fit(blsub[:, :700])
-    pz = oracle.pole_zero(blsub, F(27460.0 / dt))[0]
-    e["pz_mean"], e["pz_std"], _, _, _ = oracle.linear_slope_fit(np.ascontiguousarray(pz[:, 1600:]))
-    k0 = np.zeros(133, dtype=np.float32)  # (declared 'f': float32 taps in either loop)
-    P.t0_filter(128.0 / dt, 2000.0 / dt, k0)
+    e["bl_mean"], e["bl_std"], e["bl_slope"], e["bl_intercept"], _ = oracle.linear_slope_fit(np.ascontiguousarray(blsub[:, :par["bl_window"]]))
+    pz = oracle.pole_zero(blsub, F(par["tau_samples"]))[0]
+    e["pz_mean"], e["pz_std"], e["pz_slope"], _, _ = oracle.linear_slope_fit(np.ascontiguousarray(pz[:, par["pz_from"]:]))
+    k0 = golden_util.recipe_kernel("t0")  # (declared 'f': float32 taps in either loop)
     wt0 = oracle.convolve_wf(pz, k0, "s", 8192)[0]
     _, tp_start, _, _, _ = oracle.min_max(wt0)
     atrap = oracle.asym_trap_filter(pz, 8, 4, 125)[0]
@@ -54,23 +55,23 @@ def _expected(wf, bl, t0_ns, F=np.float32, dt=16.0):
     e["tp_0_atrap"], e["tp_0_est"] = to_ns(tp_atrap), to_ns(tp0)
     trap = oracle.trap_norm(pz, 625, 188)[0]
     e["trapTmax"] = np.max(trap, axis=1)
-    etrap = oracle.trap_norm(pz, 500, 125)[0]
+    etrap = oracle.trap_norm(pz, *par["etrap"])[0]
     e["trapEmax"] = np.max(etrap, axis=1)
-    # round(tp_0_est + 8*us + 2*us*0.8, wf_etrap.grid): two float32 additions, then rint on the same grid
-    t_pick = _convert((tp0 + F(8000.0 / dt)) + F(2000.0 * 0.8 / dt), off.astype(np.float64), off.astype(np.float64), 1.0, np.rint)
+    # round(tp_0_est + rise + flat*0.8, wf_etrap.grid): two float32 additions, then rint on the same grid
+    t_pick = _convert((tp0 + F(par["pick_ns"][0] / dt)) + F(par["pick_ns"][1] / dt), off.astype(np.float64), off.astype(np.float64), 1.0, np.rint)
     e["trapEftp"] = oracle.fixed_time_pickoff(etrap, t_pick, "l")[0]
-    kc = np.zeros(8192 - 2100 - 300, dtype=np.float32)
-    P.cusp_filter(20000.0 / dt, float(np.rint(3000.0 / dt)), 450000.0 / dt, kc)
-    cusp = oracle.convolve_wf(blsub, kc, "v", 301, in_len=8192 - 2100)[0]
+    cusp = oracle.convolve_wf(blsub, golden_util.recipe_kernel("cusp"), "v", 301, in_len=8192 - 2100)[0]
     e["cuspEmax"] = np.max(cusp, axis=1)
     e["cuspEftp"] = oracle.fixed_time_pickoff(cusp, F(50), "i")[0]
+    if par["zac"]:
+        zac = oracle.convolve_wf(blsub, golden_util.recipe_kernel("zac"), "v", 301, in_len=8192 - 2100)[0]
+        e["zacEmax"] = np.max(zac, axis=1)
+        e["zacEftp"] = oracle.fixed_time_pickoff(zac, F(50), "i")[0]
     tmx = e["trapTmax"]
-    t100 = oracle.time_point_thresh(pz, tmx, tp0, 1)[0]
-    t99 = oracle.time_point_thresh(pz, F(0.99) * tmx, tp0, 1)[0]
-    t90 = oracle.time_point_thresh(pz, tmx * F(0.9), t99, 0)[0]
-    t50 = oracle.time_point_thresh(pz, tmx * F(0.5), t90, 0)[0]
-    t10 = oracle.time_point_thresh(pz, tmx * F(0.1), t50, 0)[0]
-    for k, v in (("tp_100", t100), ("tp_99", t99), ("tp_90", t90), ("tp_50", t50), ("tp_10", t10)):
+    walks = {"tp_100": oracle.time_point_thresh(pz, tmx, tp0, 1)[0], "tp_99": oracle.time_point_thresh(pz, F(0.99) * tmx, tp0, 1)[0]}
+    for name, frac, start in par["ladder"]:  # each rung walks backward from the one above it
+        walks[name] = oracle.time_point_thresh(pz, tmx * F(frac), walks[start], 0)[0]
+    for k, v in walks.items():
         e[k] = to_ns(v)
     trap2 = oracle.trap_norm(pz, 250, 6)[0]
     q = oracle.fixed_time_pickoff(trap2, tp0 + F(8096.0 / dt), "l")[0]
@@ -123,6 +124,37 @@ def test_whole_ge_recipe_is_one_device_program(t0_kind, rows_dtype):
         assert err <= bound, f"{k}: {err:.3g}"
     # the times are in ns with the waveform's t0 in them: the rise sits ~ t0 + 0.5 * 8192 * 16 ns
     assert np.all(np.abs(out["tp_0_est"] - (t0_ns + 0.5 * 8192 * 16)) < 0.08 * 8192 * 16)
+
+
+def test_the_references_parameter_values_all_34_outputs():
+    """The recipe with the parameter values and the full output list of the reference's own Ge test configuration
+    (tests/configs/icpc-dsp-config.json:1-347; recipes.ICPC_REF, shown op for op equal to that file's translation by
+    tests/test_recipe_language_cpu.py) on the device against the all-oracle run: 34 outputs."""
+    from dspeed_amd.processing_chain import WaveformInput, build_processing_chain
+
+    rng = np.random.default_rng(2031)
+    n = 64
+    wf, bl = _synth(rng, n)
+    t0_ns = (rng.integers(2900, 3100, n) * 16).astype(F)
+    tb = {"waveform": WaveformInput(wf, 16.0, t0_ns), "baseline": bl}
+    chain, mask, out = build_processing_chain(recipes.ICPC_REF, tb)
+    assert len(out) == 34 and set(out) == set(recipes.ICPC_REF["outputs"])
+    chain.execute()
+    want, _tp0 = _expected(wf, bl, t0_ns, np.float32, 16.0, recipes.ICPC_REF_PARAMS)
+    # index / time / fit / current-branch outputs: the oracle's bit for bit wherever the filtered samples a walk compares do not differ
+    # (measured: all rows of this batch); energies to the filter bar
+    exact = ["tp_min", "tp_max", "wf_min", "wf_max", "tp_0_est", "tp_0_atrap", "tp_01", "tp_10", "tp_20", "tp_50", "tp_80", "tp_90", "tp_95", "tp_99",
+             "tp_100", "tp_aoe_max", "tp_aoe_samp", "bl_mean", "bl_std", "bl_slope", "bl_intercept", "pz_mean", "pz_std", "pz_slope", "A_max"]
+    rel = ["trapTmax", "trapEmax", "trapEftp", "cuspEmax", "cuspEftp", "zacEmax", "zacEftp", "QDrift", "dt_eff"]
+    assert sorted(exact + rel) == sorted(recipes.ICPC_REF["outputs"])
+    for k in exact:
+        assert np.array_equal(out[k], want[k], equal_nan=True), (k, int(np.sum(out[k] != want[k])))
+    for k in rel:
+        scale = np.maximum(np.abs(want[k]), 1e-3 * np.max(np.abs(want[k])))
+        assert not np.isnan(out[k]).any(), k
+        err = np.max(np.abs(out[k] - want[k]) / scale)
+        assert err <= 1e-6, f"{k}: {err:.3g}"
+    assert (out["tp_01"] <= out["tp_10"]).all() and (out["tp_80"] <= out["tp_95"]).all() and not np.isnan(out["tp_01"]).any()
 
 
 def test_index_outputs_are_bit_exact_on_the_devices_own_waveforms():
@@ -230,11 +262,7 @@ def test_index_outputs_are_bit_exact_on_the_devices_own_waveforms():
     w = wf.astype(F)
     o_bl = oracle.bl_subtract(w, bl)[0]
     o_pz = oracle.pole_zero(o_bl, F(27460.0 / dt))[0]
-    P = __import__("dspeed_amd.processors", fromlist=["x"])
-    k0 = np.zeros(133, dtype=np.float32)
-    P.t0_filter(128.0 / dt, 2000.0 / dt, k0)
-    kc = np.zeros(8192 - 2100 - 300, dtype=np.float32)
-    P.cusp_filter(20000.0 / dt, float(np.rint(3000.0 / dt)), 450000.0 / dt, kc)
+    k0, kc = golden_util.recipe_kernel("t0"), golden_util.recipe_kernel("cusp")  # (the reference generators' own output: fixtures)
     pairs = {"wf_pz": (pz_dev, o_pz), "wf_t0_filter": (wt0_dev, oracle.convolve_wf(o_pz, k0, "s", 8192)[0]),
              "wf_atrap": (atrap_dev, oracle.asym_trap_filter(o_pz, 8, 4, 125)[0]), "wf_trap": (trap_dev, oracle.trap_norm(o_pz, 625, 188)[0]),
              "wf_etrap": (etrap_dev, oracle.trap_norm(o_pz, 500, 125)[0]), "wf_trap2": (trap2_dev, oracle.trap_norm(o_pz, 250, 6)[0]),

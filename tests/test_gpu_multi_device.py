@@ -261,3 +261,39 @@ def test_waveform_table_of_variable_length_waveforms():
     chain, _, out = build_processing_chain(rec, tb)
     chain.execute()
     assert np.array_equal(out["first"], np.array([r[0] for r in rows])) and np.array_equal(out["n"], lens)
+
+
+def test_two_different_gpus_when_the_box_has_them():
+    """The first box with more than one GPU exercises what ``devices=[0, 0]`` cannot: hipSetDevice(1) on a worker thread, chain handles,
+    streams, staging and stage buffers of a second device, ``dsp_chain_execute`` putting the caller's device back.  Skipped on the one-GPU
+    boxes of the test pool."""
+    from lgdo_standins import Array, LH5Iterator, Table, WaveformTable
+
+    from dspeed_amd import build_dsp, build_processing_chain
+    from dspeed_amd.device import device_count, set_device
+
+    if device_count() < 2:
+        pytest.skip("one GPU visible: devices=[0, 1] needs two")
+    rng = np.random.default_rng(23)
+    t1, x1 = _table(rng, 1203)
+    one = build_dsp({"raw/ch1": t1}, dsp_config=recipes.C2, buffer_len=200)
+    two = build_dsp({"raw/ch1": t1}, dsp_config=recipes.C2, buffer_len=200, devices=[0, 1])
+    rev = build_dsp({"raw/ch1": t1}, dsp_config=recipes.C2, devices=[1, 0])
+    for k in one["dsp/ch1"]:
+        assert np.array_equal(two["dsp/ch1"][k], one["dsp/ch1"][k]) and np.array_equal(rev["dsp/ch1"][k], one["dsp/ch1"][k]), k
+    # a chain bound to device 1, driven from a thread whose current device is 0: results equal, and the caller's device comes back
+    chain, _, out = build_processing_chain(recipes.C2, t1, device=1)
+    set_device(0)
+    chain.execute()
+    from dspeed_amd import _lib
+    import ctypes
+
+    cur = ctypes.c_int(-1)
+    _lib.check(_lib.lib().dsp_get_device(ctypes.byref(cur)))
+    assert np.array_equal(out["trapEftp"], one["dsp/ch1"]["trapEftp"])
+    # chunks of an iterator dealt to the two devices arrive in file order
+    n = 1000
+    lg = Table(waveform=WaveformTable(np.rint(x1[:n]).astype(np.uint16), 16.0, np.zeros(n)), baseline=Array(t1["baseline"][:n]), t_pick=Array(t1["t_pick"][:n]))
+    ref = np.asarray(build_dsp(lg, dsp_config=recipes.C2)["trapEftp"])
+    got = np.asarray(build_dsp(LH5Iterator(lg, buffer_len=130), dsp_config=recipes.C2, devices=[0, 1])["trapEftp"])
+    assert np.array_equal(got, ref)

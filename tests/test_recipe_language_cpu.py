@@ -417,3 +417,35 @@ def test_the_scalar_tail_of_a_program_becomes_a_program_of_its_own(monkeypatch):
             written.add(o[1])
     small, _, _ = build_processing_chain(recipes.C2, _tb(wf_len=4096) | {"t_pick": np.zeros(4, dtype=np.float32)})
     assert small._tail is None
+
+
+def _programs(chain):
+    """everything the device is given for a recipe: the main program, the stages ahead of it, the scalar tail behind it, the fits on the rows"""
+    def prog(p):
+        return {"ops": [(o[0], o[1], o[2], o[3], o[4], tuple((a.kind, a.index, a.value if a.value == a.value else "nan") for a in o[5])) for o in p.ops],
+                "io": list(p.io), "slots": list(p.slots), "n_sregs": p.n_sregs}
+
+    out = {"main": prog(chain.program), "stages": [(st["what"], prog(st["program"]), {k: v.tobytes() for k, v in st["consts"].items()}) for st in chain._stages],
+           "tail": prog(chain._tail["program"]) if chain._tail else None, "fits": [{k: v for k, v in g.items()} for g in chain._aux],
+           "consts": {k: v.tobytes() for k, v in chain._consts.items()}}
+    return out
+
+
+def test_the_recipe_with_the_references_values_is_the_references_file_op_for_op():
+    """recipes.ICPC_REF -- ICPC with the reference's parameter values and its 34 outputs, which the GPU tests run against the oracle -- and the
+    reference's own file (tests/configs/icpc-dsp-config.json) translate into the same device programs: ops, bindings, slots, registers, kernels'
+    taps, stage by stage.  Only where the reference checkout is mounted; nothing of the file is copied."""
+    import os
+
+    path = "/root/reference/tests/configs/icpc-dsp-config.json"
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not mounted")
+    tb = _tb(t0=np.zeros(4, dtype=np.float32))
+    theirs, mask_t, out_t = build_processing_chain(path, tb)
+    ours, mask_o, out_o = build_processing_chain(recipes.ICPC_REF, tb)
+    assert sorted(mask_t) == sorted(mask_o) and list(out_t) == list(out_o) and len(out_o) == 34
+    a, b = _programs(theirs), _programs(ours)
+    assert a["main"] == b["main"] and a["tail"] == b["tail"] and a["fits"] == b["fits"] and a["consts"] == b["consts"]
+    assert len(a["stages"]) == len(b["stages"])
+    for sa, sb in zip(a["stages"], b["stages"]):
+        assert sa == sb, sa[0]
