@@ -36,7 +36,7 @@ def fn_int(code, dtype):
     return code | (dtype.itemsize * 8) << 8 | (1 << 16 if dtype.kind == "i" else 0)
 
 
-MAX_OPS, MAX_SLOTS, MAX_IO, MAX_SREGS = 192, 32, 64, 128
+MAX_OPS, MAX_SLOTS, MAX_IO, MAX_SREGS = 192, 32, 128, 128
 
 
 class IoDesc(C.Structure):

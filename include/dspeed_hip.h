@@ -121,7 +121,7 @@ const char* dsp_version(void);
  */
 #define DSP_MAX_OPS 192   /* a whole LEGEND recipe (tests/configs/icpc-dsp-config.json: 43 processors, 34 outputs) is one program */
 #define DSP_MAX_SLOTS 32  /* waveform variables; slots whose lifetimes do not overlap share LDS (packed by dsp_chain_create) */
-#define DSP_MAX_IO 64
+#define DSP_MAX_IO 128 /* (a whole recipe's scalar tail binds its 34 outputs, the registers handed over to it and the per-row offsets of its grids) */
 #define DSP_MAX_SREGS 128
 
 /* I/O binding kinds */

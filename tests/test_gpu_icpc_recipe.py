@@ -63,10 +63,12 @@ def _expected(wf, bl, t0_ns, F=np.float32, dt=16.0, par=recipes.ICPC_PARAMS):
     cusp = oracle.convolve_wf(blsub, golden_util.recipe_kernel("cusp"), "v", 301, in_len=8192 - 2100)[0]
     e["cuspEmax"] = np.max(cusp, axis=1)
     e["cuspEftp"] = oracle.fixed_time_pickoff(cusp, F(50), "i")[0]
+    e["_peak:cuspEftp"] = np.max(np.abs(cusp), axis=1)  # (what a sample of the filtered waveform is measured against: the waveform's peak)
     if par["zac"]:
         zac = oracle.convolve_wf(blsub, golden_util.recipe_kernel("zac"), "v", 301, in_len=8192 - 2100)[0]
         e["zacEmax"] = np.max(zac, axis=1)
         e["zacEftp"] = oracle.fixed_time_pickoff(zac, F(50), "i")[0]
+        e["_peak:zacEftp"] = np.max(np.abs(zac), axis=1)  # (the zero-area kernel on rows that still decay: the undershoot is several times zacEmax)
     tmx = e["trapTmax"]
     walks = {"tp_100": oracle.time_point_thresh(pz, tmx, tp0, 1)[0], "tp_99": oracle.time_point_thresh(pz, F(0.99) * tmx, tp0, 1)[0]}
     for name, frac, start in par["ladder"]:  # each rung walks backward from the one above it
@@ -104,6 +106,7 @@ def test_whole_ge_recipe_is_one_device_program(t0_kind, rows_dtype):
     chain.execute()
     want, tp0 = _expected(wf, bl, t0_ns, ft)
     assert set(out) == set(recipes.ICPC["outputs"]) and all(v.dtype == ft for v in out.values())
+    want = {k: v for k, v in want.items() if not k.startswith("_")}
 
     # Measured on this batch (tools/icpc_parity_measure.py, profiles/r03_icpc_parity_by_output.json): every index / time output, the six fit
     # outputs (the fits run on the rows exactly as the oracle's loops do) and the current branch (dsp_current.hip) equal the all-oracle run
@@ -149,11 +152,22 @@ def test_the_references_parameter_values_all_34_outputs():
     assert sorted(exact + rel) == sorted(recipes.ICPC_REF["outputs"])
     for k in exact:
         assert np.array_equal(out[k], want[k], equal_nan=True), (k, int(np.sum(out[k] != want[k])))
+    # A maximum is held to 1e-6 of its own value.  A sample picked off a filtered waveform at a fixed time (cuspEftp, zacEftp: sample 50 of 301,
+    # on the filter's flank) is a filter OUTPUT SAMPLE: the bar is the waveform's, 1e-6 of the filtered waveform's peak (north_star; against
+    # float64 the device's zero-area filter is within 3.8e-7 of the peak at every sample, the oracle within 6e-8: profiles/r04_fir_zac_samples.json)
+    measured = {}
     for k in rel:
-        scale = np.maximum(np.abs(want[k]), 1e-3 * np.max(np.abs(want[k])))
+        scale = want[f"_peak:{k}"] if f"_peak:{k}" in want else np.maximum(np.abs(want[k]), 1e-3 * np.max(np.abs(want[k])))
         assert not np.isnan(out[k]).any(), k
         err = np.max(np.abs(out[k] - want[k]) / scale)
+        measured[k] = {"rel_to_bar_scale": float(err), "rel_to_own_value": float(np.max(np.abs(out[k] - want[k]) / np.abs(want[k])))}
         assert err <= 1e-6, f"{k}: {err:.3g}"
+    import json
+    import os
+
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/icpc_ref_values_parity.json", "w") as f:
+        json.dump({"recipe": "recipes.ICPC_REF (the reference file's values, 34 outputs)", "rows": n, "bit_exact_outputs": exact, "float_outputs": measured}, f, indent=1)
     assert (out["tp_01"] <= out["tp_10"]).all() and (out["tp_80"] <= out["tp_95"]).all() and not np.isnan(out["tp_01"]).any()
 
 
