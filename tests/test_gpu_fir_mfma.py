@@ -1,6 +1,8 @@
 """The matrix-core FIR (dsp_fir_mfma.hip): convolve_wf 'v' + numpy.amax of the energy kernels as a float32 product with the Toeplitz
 matrix of the taps (BASELINE.json configs[2]; reference convolutions.py:14-72, energy_kernels.py:12-157).  Float arithmetic in another
 summation order than NumPy's: the bar is 1e-6 of the filtered waveform's peak (north_star), measured here against float64 sums too."""
+import os
+
 import numpy as np
 import pytest
 
@@ -373,3 +375,59 @@ def one_taps(chain, name):
         if f"taps:{name}" in st["consts"]:
             return st["consts"][f"taps:{name}"][:133]
     raise KeyError(name)
+
+
+def test_zero_area_kernel_on_rows_with_their_pedestal_is_as_accurate_as_the_references_own_arithmetic():
+    """Round-3 review: no test covered a zero-area kernel on rows whose pedestal (10 000 ADC) was not subtracted -- the filter removes the pedestal
+    itself, the filtered waveform's peak is 0.4 % of the products that make it, and the float16 split (22 bits per operand) has the least margin
+    there.  Measured (tools/fir_pedestal_accuracy.py, profiles/r04_fir_pedestal_accuracy.json): against float64 the float16 form errs by
+    4.4e-5 of the peak, the float32 matrix form by 4.1e-5, NumPy's own float32 ``np.convolve`` -- the reference's arithmetic, convolutions.py:72
+    -- by 0.8e-5 and SciPy's float32 ``fftconvolve`` (convolutions.py:118) by 2.2e-5: in this regime the reference itself is not a 1e-6
+    quantity (only the float64-accumulating oracle is, 6e-8).  What is asserted: the two device forms agree with each other, neither is worse
+    than a small multiple of the reference's own float32 error, and on the same rows with the baseline subtracted first -- what every LEGEND
+    recipe does before its long filters, icpc-dsp-config.json:160-239 -- the 1e-6 bar holds."""
+    import golden_util
+    from scipy.signal import fftconvolve
+
+    from dspeed_amd import build_processing_chain
+
+    rng = np.random.default_rng(77)
+    n, L = 48, 8192
+    i = np.arange(L)[None, :]
+    B = rng.uniform(9000, 11000, (n, 1))
+    A = rng.uniform(500, 15000, (n, 1))
+    A[:8], B[:8] = 500.0, 11000.0
+    t0 = np.floor(rng.uniform(0.45, 0.55, (n, 1)) * L)
+    wf = np.rint(B + A * np.exp(-(i - t0) / 1716.28) * (i >= t0) + 5.0 * rng.standard_normal((n, L))).astype(np.uint16)
+    k = golden_util.recipe_kernel("zac")
+    x64 = wf.astype(np.float64)[:, :6092]
+    ref = np.lib.stride_tricks.sliding_window_view(x64, 5792, axis=1) @ np.asarray(k, np.float64)[::-1]
+    peak = np.abs(ref).max(axis=1, keepdims=True)
+    x32 = wf.astype(np.float32)[:, :6092]
+    numpy_err = max(np.abs(np.convolve(x32[r], k, "valid") - ref[r]).max() / peak[r, 0] for r in range(n))
+    scipy_err = max(np.abs(fftconvolve(x32[r], k, "valid") - ref[r]).max() / peak[r, 0] for r in range(n))
+    procs = {"kern": {"function": "zac_filter", "module": "dspeed.processors", "args": ["1250", "188", "28125", "kern(5792, 'f')"]},
+             "wf_f": {"function": "convolve_wf", "module": "dspeed.processors", "args": ["waveform[:6092]", "kern", "'v'", "wf_f(301, 'f')"]}}
+    got = {}
+    for form in ("f16", "f32"):
+        if form == "f32":
+            os.environ["DSPEED_HIP_FIR_F32"] = "1"
+        try:
+            chain, _, out = build_processing_chain({"outputs": ["wf_f"], "processors": procs}, {"waveform": wf})
+            chain.execute()
+        finally:
+            os.environ.pop("DSPEED_HIP_FIR_F32", None)
+        got[form] = out["wf_f"]
+        err = (np.abs(out["wf_f"] - ref) / peak).max()
+        assert err <= 8 * max(numpy_err, scipy_err), (form, err, numpy_err, scipy_err)
+    assert (np.abs(got["f16"] - got["f32"]) / peak).max() <= 8 * max(numpy_err, scipy_err)
+    assert numpy_err > 2e-6  # (the premise: the reference's own float32 arithmetic is not at the bar here)
+    # ... and with the baseline subtracted while staging, as the recipes do: the bar
+    procs_bl = dict(procs, wf_blsub="dspeed.processors.bl_subtract(waveform, baseline, wf_blsub)")
+    procs_bl["wf_f"] = dict(procs["wf_f"], args=["wf_blsub[:6092]", "kern", "'v'", "wf_f(301, 'f')"])
+    bl = B[:, 0].astype(np.float32)
+    chain, _, out = build_processing_chain({"outputs": ["wf_f"], "processors": procs_bl}, {"waveform": wf, "baseline": bl})
+    chain.execute()
+    xb = (wf.astype(np.float32) - bl[:, None]).astype(np.float64)[:, :6092]
+    refb = np.lib.stride_tricks.sliding_window_view(xb, 5792, axis=1) @ np.asarray(k, np.float64)[::-1]
+    assert (np.abs(out["wf_f"] - refb) / np.abs(refb).max(axis=1, keepdims=True)).max() <= 1e-6
