@@ -419,7 +419,7 @@ class ProcessingChain:
     #: How host-resident columns reach the device.  False (default): through page-locked staging buffers the chain owns
     #: (hipHostMalloc), filled / emptied by host threads -- the device only exchanges data with memory the runtime allocated itself.
     #: True: the linked NumPy columns are page-locked in place (hipHostRegister) and copied from directly: the full PCIe rate
-    #: without a host copy, for buffers that live as long as the chain (build_dsp-style refilled tables); DESIGN.md section 5 on why it
+    #: without a host copy, for buffers that live as long as the chain (build_dsp-style refilled tables); profiles/design_diary_r01_r03.md, "Host memory and the runtime", on why it
     #: is not the default.  Environment DSPEED_HIP_PIN_IN_PLACE=1 switches it on globally.
     pin_in_place = os.environ.get("DSPEED_HIP_PIN_IN_PLACE", "0") == "1"
     #: host threads that move rows between NumPy columns and the staging buffers (tools/host_copy_rate.py: 8 threads move 79 GB/s in 32 MiB
