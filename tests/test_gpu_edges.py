@@ -140,7 +140,7 @@ def test_fir_edges_same_and_full_modes(wf_len, m):
 
 
 @pytest.mark.skipif(os.environ.get("DSPEED_TEST_PIN_IN_PLACE", "0") != "1",
-                    reason="in-place page-locking of NumPy memory is opt-in (profiles/design_diary_r01_r03.md, "Host memory and the runtime"); set DSPEED_TEST_PIN_IN_PLACE=1")
+                    reason="in-place page-locking of NumPy memory is opt-in (profiles/design_diary_r01_r03.md: Host memory and the runtime); set DSPEED_TEST_PIN_IN_PLACE=1")
 def test_page_locked_ranges_never_overlap():
     """HostPin: one record per range at the runtime -- the same array twice shares it, a range that shares pages with a live one is
     refused (the chain then copies it unpinned), and everything can be locked again once released."""
@@ -169,7 +169,7 @@ def test_page_locked_ranges_never_overlap():
 
 
 @pytest.mark.skipif(os.environ.get("DSPEED_TEST_PIN_IN_PLACE", "0") != "1",
-                    reason="in-place page-locking of NumPy memory is opt-in (profiles/design_diary_r01_r03.md, "Host memory and the runtime"); set DSPEED_TEST_PIN_IN_PLACE=1")
+                    reason="in-place page-locking of NumPy memory is opt-in (profiles/design_diary_r01_r03.md: Host memory and the runtime); set DSPEED_TEST_PIN_IN_PLACE=1")
 def test_columns_page_locked_in_place_give_the_same_results():
     import recipes
     from dspeed_amd.processing_chain import build_processing_chain
