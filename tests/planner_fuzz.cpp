@@ -472,7 +472,44 @@ Prog current_shape() {
 }
 
 // arithmetic between per-event values and stores only: the row-per-lane kernel's programs (the tail of a recipe)
+// an integer program (compute type DSP_I64, dspeed_hip.h): SCALAR_FUNC and STORE_SCALAR ops only, integer / bool input columns, outputs of any type
+Prog integer_shape() {
+    Prog p;
+    p.dtype = DSP_I64;
+    auto in_col = [&]() {
+        dsp_scalar_arg a{};
+        a.kind = DSP_ARG_INPUT;
+        a.index = add_io(p, DSP_IO_SCALAR_IN, chance(0.02) ? DSP_F32 : pick({DSP_I64, DSP_U64, DSP_I32, DSP_U32, DSP_I16, DSP_U16, DSP_BOOL, DSP_I64}), 1, 0, pick({1, 1, 0, 2}));
+        return a;
+    };
+    auto opnd = [&]() {
+        if (p.n_sregs && chance(0.4)) return dsp_scalar_arg{DSP_ARG_REG, rnd(0, p.n_sregs - 1), 0.0};
+        if (chance(0.5)) return in_col();
+        return cst((double)pick({0, 1, -1, 7, 65535, 1 << 30, rnd(-1000, 1000)}));
+    };
+    for (int k = rnd(1, 30); k > 0 && p.n_sregs < DSP_MAX_SREGS - 4 && (int)p.io.size() < DSP_MAX_IO - 6; --k) {
+        dsp_op o{};
+        if (p.n_sregs && chance(0.3)) {
+            o = op0(DSP_OP_STORE_SCALAR);
+            o.io = add_io(p, DSP_IO_SCALAR_OUT, pick({DSP_I64, DSP_U64, DSP_I32, DSP_U32, DSP_I16, DSP_U16, DSP_BOOL, DSP_F32, DSP_F64}), 1, 0, 1);
+            o.ip[0] = rnd(0, p.n_sregs - 1), o.ip[1] = chance(0.2);
+        } else {
+            int fn = pick({DSP_FN_IADD, DSP_FN_ISUB, DSP_FN_IMUL, DSP_FN_IFLOORDIV, DSP_FN_ICAST, DSP_FN_LT, DSP_FN_GE, DSP_FN_EQ, DSP_FN_WHERE, DSP_FN_LOR, DSP_FN_LAND, DSP_FN_COPY});
+            if (chance(0.02)) fn = pick({DSP_FN_ADD, DSP_FN_RINT, DSP_FN_DIV});  // (float functions: refused in an integer program)
+            if (fn >= DSP_FN_IADD && fn <= DSP_FN_ICAST) fn |= DSP_FN_INT(chance(0.02) ? 24 : pick({8, 16, 32, 64, 64}), chance(0.5));
+            else if (chance(0.3)) fn |= DSP_FN_INT(64, chance(0.5));
+            o = op0(chance(0.97) ? DSP_OP_SCALAR_FUNC : DSP_OP_SCALAR_AFFINE), o.ip[0] = fn;
+            for (int q = 0; q < 3; ++q) o.sp[q] = opnd();
+            o.dst = new_sregs(p, 1);
+        }
+        p.ops.push_back(o);
+    }
+    if (p.ops.empty()) p.ops.push_back(op0(DSP_OP_SCALAR_FUNC)), p.n_sregs = 1;
+    return p;
+}
+
 Prog scalar_shape() {
+    if (chance(0.3)) return integer_shape();
     Prog p;
     p.dtype = chance(0.3) ? DSP_F64 : DSP_F32;
     for (int k = rnd(1, 40); k > 0 && p.n_sregs < DSP_MAX_SREGS - 4 && (int)p.io.size() < DSP_MAX_IO - 6; --k) {
@@ -539,7 +576,7 @@ void mutate(Prog& p) {
 bool check(const Prog& p, const ChainPlan& c) {
     const DevProgram& P = c.host;
     const int ns = (int)p.slots.size();
-    const int esz = c.f64 ? 8 : 4;
+    const int esz = (c.f64 || c.i64) ? 8 : 4;
     REQUIRE(c.lds_bytes_per_wave == P.lds_elems_per_wave * esz && c.lds_bytes_per_wave <= LDS_BYTES_PER_CU, "LDS %d bytes", c.lds_bytes_per_wave);
     REQUIRE(P.sreg_off + p.n_sregs <= P.scratch_off && P.scratch_off + DSP_SCRATCH_ELEMS <= P.lds_elems_per_wave, "register file / scratch: %d + %d, %d, %d", P.sreg_off,
             p.n_sregs, P.scratch_off, P.lds_elems_per_wave);
@@ -558,6 +595,15 @@ bool check(const Prog& p, const ChainPlan& c) {
                     c.slot_last_op[t]);
             if (overlap) REQUIRE(c.slot_shares[s] && c.slot_shares[t], "slots %d and %d share LDS without the clearing op", s, t);
         }
+    }
+    if (c.i64) {  // an integer program: the row-per-lane kernel, 8-byte registers, nothing but functions of per-event values and stores
+        REQUIRE(c.scalar_ok && ns == 0 && esz == 8, "integer program on %s", dsp_plan_kernel_name(&c));
+        for (size_t i = 0; i < p.ops.size(); ++i) REQUIRE(p.ops[i].opcode == DSP_OP_SCALAR_FUNC || p.ops[i].opcode == DSP_OP_STORE_SCALAR, "integer program holds opcode %d", p.ops[i].opcode);
+        for (size_t k = 0; k < p.io.size(); ++k)
+            if (p.io[k].kind == DSP_IO_SCALAR_IN) REQUIRE(p.io[k].dtype != DSP_F32 && p.io[k].dtype != DSP_F64, "integer program reads a float column");
+    } else {
+        for (size_t k = 0; k < p.io.size(); ++k)
+            if (p.io[k].kind == DSP_IO_SCALAR_OUT || p.io[k].kind == DSP_IO_WF_OUT) REQUIRE(p.io[k].dtype == p.dtype || p.io[k].dtype == DSP_BOOL, "output %zu of type %d in a chain of type %d", k, p.io[k].dtype, p.dtype);
     }
     REQUIRE(P.n_ops >= 1 && P.n_ops <= DSP_MAX_OPS + DSP_MAX_SLOTS, "device ops %d", P.n_ops);
     REQUIRE(P.team == 1 || P.team == 2, "team %d", P.team);
@@ -636,7 +682,7 @@ int main(int argc, char** argv) {
     const long n_programs = argc > 1 ? atol(argv[1]) : 10000;
     const unsigned long long seed = argc > 2 ? strtoull(argv[2], nullptr, 0) : 0xD5BEEDull;
     rng.seed(seed);
-    long accepted = 0, by_kind[8] = {0};
+    long accepted = 0, by_kind[8] = {0}, n_integer = 0;
     long kernels[10] = {0};
     for (long it = 0; it < n_programs; ++it) {
         Prog p;
@@ -666,6 +712,7 @@ int main(int argc, char** argv) {
         }
         ++accepted;
         ++by_kind[kind <= 6 ? kind : 7];
+        n_integer += plan->i64 ? 1 : 0;
         kernels[plan->scalar_ok ? 0 : plan->pz_ok ? 1 : plan->red_ok ? 2 : plan->cur_ok ? 3 : plan->fir_ok ? 4 : plan->rows_ok ? 5 : plan->rr_ok ? 6 : plan->fused_ok ? 7 : plan->host.team == 2 ? 8 : 9]++;
         if (!check(p, *plan)) {
             fprintf(stderr, "program %ld (seed %llu, kind %d, kernel %s)\n", it, seed, kind, dsp_plan_kernel_name(plan.get()));
@@ -674,8 +721,8 @@ int main(int argc, char** argv) {
         }
     }
     printf("{\"programs\": %ld, \"accepted\": %ld, \"accepted_by_generator\": {\"energy\": %ld, \"rows\": %ld, \"fir\": %ld, \"pz\": %ld, \"reduce\": %ld, \"current\": %ld, \"scalar\": %ld, \"random\": %ld}, "
-           "\"kernels\": {\"scalar\": %ld, \"pz_rows\": %ld, \"reduce\": %ld, \"current\": %ld, \"fir\": %ld, \"rows\": %ld, \"energy_rr\": %ld, \"energy\": %ld, \"vm_team\": %ld, \"vm\": %ld}}\n",
+           "\"kernels\": {\"scalar\": %ld, \"pz_rows\": %ld, \"reduce\": %ld, \"current\": %ld, \"fir\": %ld, \"rows\": %ld, \"energy_rr\": %ld, \"energy\": %ld, \"vm_team\": %ld, \"vm\": %ld}, \"integer_programs\": %ld}\n",
            n_programs, accepted, by_kind[0], by_kind[1], by_kind[2], by_kind[3], by_kind[4], by_kind[5], by_kind[6], by_kind[7], kernels[0], kernels[1], kernels[2], kernels[3], kernels[4], kernels[5],
-           kernels[6], kernels[7], kernels[8], kernels[9]);
+           kernels[6], kernels[7], kernels[8], kernels[9], n_integer);
     return 0;
 }

@@ -49,6 +49,7 @@ def test_ten_thousand_random_programs_plan_clean_under_asan_and_ubsan(fuzzer):
     # every specialised kernel's shape was reached (and its argument block checked), as were the interpreter and its two-wavefront teams
     for kernel in ("scalar", "pz_rows", "reduce", "current", "fir", "rows", "energy_rr", "vm_team", "vm"):
         assert rep["kernels"][kernel] > 0, (kernel, rep)
+    assert rep["integer_programs"] > 50  # (compute type DSP_I64: the integer programs of round 4)
 
 
 @pytest.mark.parametrize("seed", [1, 2])
