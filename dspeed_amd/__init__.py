@@ -18,7 +18,7 @@ __version__ = "0.1.0"
 
 
 def __getattr__(name):
-    if name in ("build_processing_chain", "ProcessingChain"):
+    if name in ("build_processing_chain", "ProcessingChain", "GroupedProcessingChain", "WaveformInput"):
         from . import processing_chain
 
         return getattr(processing_chain, name)
