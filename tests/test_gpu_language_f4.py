@@ -260,3 +260,47 @@ def test_rounding_floor_division_and_numpy_ufuncs_on_waveforms():
     for bad in ("waveform % 2", "waveform ** 2", "g % 2"):  # not in the reference's operator table (processing_chain.py:46-59)
         with pytest.raises(ProcessingChainError):
             build_processing_chain({"outputs": ["x"], "processors": {"x": bad}}, tb)
+
+
+def test_the_round_4_additions_through_the_table_loop_and_the_containers():
+    """integer programs, grouped chains and the device-resident fast path behind the entry points a dspeed user calls: build_dsp over arrays, an LGDO
+    table in memory and a chunk iterator; ProcessingChain.execute(wait=False) on device-resident columns"""
+    from lgdo_standins import Array, LH5Iterator, Table, WaveformTable
+
+    from dspeed_amd.device import DeviceArray
+
+    rng = np.random.default_rng(41)
+    n = 700
+    wf = np.cumsum(rng.normal(0, 3, (n, 256)), axis=1).astype(np.float32)
+    ev = (np.arange(n, dtype=np.int64) * 7 + 2 ** 45)
+    rise = rng.choice([4, 8, 16], n).astype(np.int32)
+    recipe = {"outputs": ["ev2", "odd", "e", "hi"], "processors": {
+        "ev2": "eventnumber * 3 + 1", "odd": "(eventnumber // 7) - (eventnumber // 14) * 2 == 1", "hi": "astype(eventnumber // 1024, 'uint32')",
+        "wf_trap": {"function": "trap_norm", "module": M, "args": ["waveform", "rise", "2", "wf_trap"]},
+        "e": {"function": "fixed_time_pickoff", "module": M, "args": ["wf_trap", "200", "'i'", "e"]}}}
+    want_e = np.array([oracle.trap_norm(wf[r:r + 1], int(rise[r]), 2)[0][0, 200] for r in range(n)], np.float32)
+
+    def check(out):
+        assert np.asarray(out["ev2"]).dtype == np.int64 and np.array_equal(out["ev2"], ev * 3 + 1)
+        assert np.array_equal(out["odd"], (ev // 7) - (ev // 14) * 2 == 1) and np.array_equal(out["hi"], (ev // 1024).astype(np.uint32))
+        assert np.asarray(out["hi"]).dtype == np.uint32 and np.asarray(out["odd"]).dtype == np.bool_
+        peak = np.abs(want_e).max()
+        assert np.abs(np.asarray(out["e"]) - want_e).max() <= 1e-6 * peak
+
+    check(build_dsp({"waveform": wf, "eventnumber": ev, "rise": rise}, dsp_config=recipe, buffer_len=256))
+    lg = Table(waveform=WaveformTable(wf, 16.0, np.zeros(n)), eventnumber=Array(ev), rise=Array(rise))
+    check(build_dsp(lg, dsp_config=recipe))
+    check(build_dsp(LH5Iterator(lg, buffer_len=150), dsp_config=recipe))
+    # columns resident on the device: a pass is queued and finished later; the integer program writes its int64 column in place
+    rec2 = {"outputs": ["ev2", "m"], "processors": {"ev2": "eventnumber * 3 + 1", "a, b, lo, m": {"function": "min_max", "module": M, "args": ["waveform", "a", "b", "lo", "m"]}}}
+    tb = {"waveform": DeviceArray.from_numpy(wf), "eventnumber": DeviceArray.from_numpy(ev)}
+    chain, _, _ = build_processing_chain(rec2, tb)
+    outs = {"ev2": DeviceArray((n,), np.int64), "m": DeviceArray((n,), np.float32)}
+    chain.link(tb, outs)
+    for _ in range(3):
+        chain.execute(0, n, wait=False)
+    chain.wait()
+    assert np.array_equal(outs["ev2"].to_numpy(), ev * 3 + 1) and np.array_equal(outs["m"].to_numpy(), wf.max(axis=1))
+    with pytest.raises(ValueError, match="wait=False"):
+        chain2, _, _ = build_processing_chain(rec2, {"waveform": wf, "eventnumber": ev})
+        chain2.execute(0, n, wait=False)
