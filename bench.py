@@ -3,8 +3,11 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A *step* is one pass of the fused hot path (bl_subtract -> pole_zero -> trap_filter -> fixed_time_pickoff,
-one launch of the waveform VM) over one synthetic batch that is already resident in HBM:
+A *step* is one pass of the hot path (bl_subtract -> pole_zero -> trap_filter -> fixed_time_pickoff) over one synthetic batch that is
+already resident in HBM.  The chain is built the way a dspeed user builds it -- build_processing_chain(<the recipe as a LEGEND configuration
+writes it: module string "dspeed.processors", db.pz.tau with its default>, table of device-resident columns) -- and a pass is
+ProcessingChain.execute: one launch of the energy kernel (the bench refuses to print a line if the recipe was given to another kernel).  The
+same program handed to dsp_chain_create directly is timed beside it (roofline.raw_chain):
 
     N = 1   1 000 000 x 4096 float32 rows                      (BASELINE.json configs[1])
     N > 1   1 250 000 x 4096 rows per rank, batch-sharded,     (configs[3]: 10 M rows over 8 GPUs)

@@ -704,6 +704,8 @@ class GroupedProcessingChain(ProcessingChain):
                 failures.append((int(row), e))
                 continue
             for name, col in out.items():
+                if isinstance(self._tb_out[name], DeviceArray):
+                    raise NotImplementedError("per-event integer parameters of processors: the groups' results are put back on the host -- link host arrays as outputs")
                 self._tb_out[name][idx] = col
             for k in self._timing:
                 self._timing[k] += chain.get_timing()[k]
