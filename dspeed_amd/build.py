@@ -21,8 +21,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdspeed_hip.so")
 LIB_DIAG = os.path.join(HERE, "libdspeed_hip_diag.so")
-SOURCES = ["dsp_vm.hip", "dsp_energy.hip", "dsp_fit.hip", "dsp_rows.hip", "dsp_current.hip", "dsp_scalar.hip", "dsp_reduce.hip", "dsp_pz.hip", "dsp_fir_mfma.hip", "dsp_fir_f16.hip", "dsp_plan.cpp", "dsp_host.cpp"]
-DEPS = SOURCES + ["dsp_program.h", "dsp_plan.h", "dsp_wave.h", os.path.join("..", "..", "include", "dspeed_hip.h")]
+SOURCES = ["dsp_vm.hip", "dsp_energy.hip", "dsp_fit.hip", "dsp_rows.hip", "dsp_current.hip", "dsp_scalar.hip", "dsp_reduce.hip", "dsp_pz.hip", "dsp_fir_mfma.hip", "dsp_fir_f16.hip", "dsp_fir_runs.hip", "dsp_plan.cpp", "dsp_host.cpp"]
+DEPS = SOURCES + ["dsp_program.h", "dsp_plan.h", "dsp_wave.h", "dsp_reduce_tail.h", os.path.join("..", "..", "include", "dspeed_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-Wall",
          "-Wno-unused-function"]
 

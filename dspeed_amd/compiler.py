@@ -297,6 +297,20 @@ def _live_steps(b: _Builder, steps, out_pars):
 STAGE_MIN_TAPS = 64
 
 
+#: what the run-length FIR kernel takes (DSP_FIR_RUNS_MAX / DSP_FIR_RUNS_MAX_TAPS of csrc/dsp_program.h)
+FIR_RUNS_MAX, FIR_RUNS_MAX_TAPS = 24, 512
+
+
+def _piecewise_constant(taps) -> bool:
+    """Is the kernel a few runs of equal taps (``t0_filter``: a ramp of 8 and a plateau of 125; moving averages)?  Then convolve_wf is a
+    handful of differences of prefix sums per output instead of a multiply-add per tap (csrc/dsp_fir_runs.hip)."""
+    k = np.asarray(taps, dtype=np.float32)
+    if k.ndim != 1 or not 1 <= k.size <= FIR_RUNS_MAX_TAPS or not np.isfinite(k).all():
+        return False
+    edges = np.concatenate([[np.float32(0)], k, [np.float32(0)]])
+    return int(np.count_nonzero(edges[1:] != edges[:-1])) <= FIR_RUNS_MAX + 1
+
+
 def _extract_stages(b: _Builder, steps, out_pars, n_rows, ft):
     """Long FIRs leave the program: each ``convolve_wf`` with a constant kernel of STAGE_MIN_TAPS or more taps becomes a launch of the
     matrix-core FIR kernels ahead of the program (one waveform per wavefront is the wrong shape for 133 x 8192 or 5792 x 301
@@ -377,6 +391,42 @@ def _extract_stages(b: _Builder, steps, out_pars, n_rows, ft):
             if o.kind == "wf":
                 o.ext_len, o.offset, o.dtype = o.length, 0, np.dtype(np.float32)
 
+    def rows_steps(v):
+        """steps that read only the rows v and per-event values already in HBM and make per-event values only; in order, closed under
+        their own results"""
+        made, picked = set(), []
+        for st in steps:
+            roles = _roles(st[0])
+            ins = [(a, r) for a, r in zip(st[1], roles) if r not in "WS"]
+            outs = [a for a, r in zip(st[1], roles) if r in "WS"]
+            if not outs or any(r == "W" for r in roles) or st[0] in ("alias",) or not any(base_of(a) is v and isinstance(a, Var) for a, r in ins):
+                continue
+            ok = True
+            for a, r in ins:
+                if base_of(a) is v and isinstance(a, Var):
+                    continue
+                if isinstance(a, (Var, SExpr, tuple)) and not (isinstance(a, tuple) and a and a[0] == "char"):
+                    ok = ok and isinstance(a, Var) and (plain_scalar(a) or id(a) in made)
+            if ok and all(isinstance(o, Var) and o.name not in out_names for o in outs[:0]) and all(isinstance(o, Var) for o in outs):
+                picked.append(st)
+                made.update(id(o) for o in outs)
+        return picked
+
+    def fusable(g, group):
+        """what the run-length FIR kernel reads off the waveform it has just filtered (the reductions of dsp_reduce.hip): min_max, numpy.amax,
+        a sample at a constant integral time, time_point_thresh from a constant sample or from min_max's t_min / t_max"""
+        number = lambda x: isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, (bool, Quantity))  # noqa: E731
+        if g[0] in ("min_max", "amax"):
+            return True
+        if g[0] == "fixed_time_pickoff":
+            return number(g[1][1]) and float(g[1][1]) == int(float(g[1][1]))
+        if g[0] == "time_point_thresh":
+            _w, thr, start, walk, _o = g[1]
+            extremes = [o for x in group if x[0] == "min_max" for o in x[1][1:3]]
+            return ((number(thr) or plain_scalar(thr)) and number(walk) and float(walk) in (0.0, 1.0)
+                    and ((number(start) and float(start) == int(float(start))) or any(start is o for o in extremes)))
+        return False
+
     for st in list(steps):
         fn, args, key = st
         if fn not in ("convolve_wf", "fft_convolve_wf") or not any(st is x for x in steps):
@@ -413,8 +463,28 @@ def _extract_stages(b: _Builder, steps, out_pars, n_rows, ft):
             users[0][1][2].kind = "scalar"
             gone = [st, users[0]]
         else:
-            build(pre + [st], [out], f"{fn} {key}")
-            gone = [st]
+            # a piecewise-constant kernel (the t0 filter) on float32 rows: prefix sums instead of products, and what the recipe reads off
+            # the filtered waveform -- min_max, the threshold walk of the t0 estimate -- in the same pass; a filtered waveform that nothing
+            # else reads then never reaches HBM (csrc/dsp_fir_runs.hip)
+            group = []
+            if (ft == np.dtype(np.float32) and not pre and isinstance(args[0], Var) and row_input(args[0]) and np.dtype(args[0].dtype) == np.dtype(np.float32)
+                    and n_in % 8 == 0 and _piecewise_constant(taps.const) and os.environ.get("DSPEED_HIP_NO_FIR_RUNS") != "1"):
+                for g in rows_steps(out):
+                    if g[1][0] is out and fusable(g, group):
+                        group.append(g)
+                by_fn = [g[0] for g in group]
+                if by_fn.count("min_max") > 1 or by_fn.count("amax") > 1 or by_fn.count("fixed_time_pickoff") > 4 or by_fn.count("time_point_thresh") > 2:
+                    group = []
+            if group:
+                made = [o for g in group for o, r in zip(g[1], _roles(g[0])) if r in "WS"]
+                keep = out.name in out_names or any(not any(x is g for g in group) for x in users)
+                build([st] + group, made + ([out] if keep else []), f"{fn} {key} on prefix sums + per-event values of {out.name}")
+                for o in made:
+                    o.kind = "scalar"
+                gone = [st] + group
+            else:
+                build(pre + [st], [out], f"{fn} {key}")
+                gone = [st]
         steps = [x for x in steps if not any(x is g for g in gone)]
     if not stages:
         return steps, stages
@@ -424,27 +494,6 @@ def _extract_stages(b: _Builder, steps, out_pars, n_rows, ft):
     # Ge recipes, asym_trap_filter -> time_point_thresh: a fifth of the program).  The kernel reads rows, so the trapezoid's input must
     # be rows (an input or what a stage above wrote) and every per-event operand a column in HBM: what such an operand depends on --
     # min_max of the t0-filtered waveform -- moves ahead of the program as well, as a small program of its own on the same rows.
-    def rows_steps(v):
-        """steps that read only the rows v and per-event values already in HBM and make per-event values only; in order, closed under
-        their own results"""
-        made, picked = set(), []
-        for st in steps:
-            roles = _roles(st[0])
-            ins = [(a, r) for a, r in zip(st[1], roles) if r not in "WS"]
-            outs = [a for a, r in zip(st[1], roles) if r in "WS"]
-            if not outs or any(r == "W" for r in roles) or st[0] in ("alias",) or not any(base_of(a) is v and isinstance(a, Var) for a, r in ins):
-                continue
-            ok = True
-            for a, r in ins:
-                if base_of(a) is v and isinstance(a, Var):
-                    continue
-                if isinstance(a, (Var, SExpr, tuple)) and not (isinstance(a, tuple) and a and a[0] == "char"):
-                    ok = ok and isinstance(a, Var) and (plain_scalar(a) or id(a) in made)
-            if ok and all(isinstance(o, Var) and o.name not in out_names for o in outs[:0]) and all(isinstance(o, Var) for o in outs):
-                picked.append(st)
-                made.update(id(o) for o in outs)
-        return picked
-
     trap_fns = ("trap_filter", "trap_norm", "asym_trap_filter")
     for st in list(steps):
         fn, args, key = st
@@ -1345,7 +1394,8 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
                 release(src, si)
                 continue
             dst.slot = new_slot(dst.length)
-            p.add_op(_lib.OP_CONVOLVE, dst=dst.slot, src=src.slot, io=taps.io, ip=(char_of(args[2]), has_nan, 0, int(taps.length)))
+            p.add_op(_lib.OP_CONVOLVE, dst=dst.slot, src=src.slot, io=taps.io,
+                     ip=(char_of(args[2]), has_nan, int(_piecewise_constant(taps.const)), int(taps.length)))
             release(src, si)
         else:
             raise NotImplementedError(f"processor '{fn}' is not implemented on the device path")

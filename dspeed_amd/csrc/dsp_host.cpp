@@ -58,6 +58,7 @@ extern "C" int dsp_internal_launch_scalar(const DevProgram* dev_prog, const IoPt
 extern "C" int dsp_internal_set_scalar_lds(int lds_bytes);
 extern "C" const char* dsp_internal_scalar_kernel_name();
 extern "C" int dsp_internal_current_lds_bytes(int ma_len);
+extern "C" int dsp_internal_launch_fir_runs(const FirRunsArgs* A, FirRunsTable* table, int64_t n_wf, int blocks, hipStream_t stream);
 extern "C" int dsp_internal_launch_current(const CurrentArgs* A, int64_t n_wf, int blocks, int lds_bytes, hipStream_t stream);
 extern "C" int dsp_internal_set_current_lds(int lds_bytes);
 extern "C" const char* dsp_internal_current_kernel_name();
@@ -117,6 +118,8 @@ struct dsp_chain : ChainPlan {
     int32_t fed_len = 0;
     float* cur_scratch = nullptr;  // (current-branch kernel) allocated at the first launch
     int cur_blocks_cap = 0;
+    FirRunsTable* runs_table = nullptr;  // (run-length FIR) the kernel's breakpoints, rewritten by every launch; allocated at the first
+    float* runs_scratch = nullptr;       // a row per resident wavefront for a filtered waveform that nothing keeps
     // the error word handed to the host by a copy that is part of the launch (dsp_chain_set_async_check): dsp_chain_check then needs no
     // transfer of its own -- one issued while a large host-to-device copy of the next buffer is in flight queues up behind it
     int* err_mirror = nullptr;  // page-locked
@@ -128,6 +131,8 @@ struct dsp_chain : ChainPlan {
         if (host.prof) (void)hipFree(host.prof);
         if (err_mirror) (void)hipHostFree(err_mirror);
         if (cur_scratch) (void)hipFree(cur_scratch);
+        if (runs_table) (void)hipFree(runs_table);
+        if (runs_scratch) (void)hipFree(runs_scratch);
         for (int k = 0; k < DSP_FIR_MAXK; ++k)
             if (f16.taps16[k]) (void)hipFree(const_cast<void*>(f16.taps16[k]));
         if (f16.row_scale) (void)hipFree(const_cast<void*>(f16.row_scale));
@@ -473,6 +478,19 @@ static int current_blocks(const dsp_chain* ch, int64_t n_wf) {
     return (int)((groups + rounds - 1) / (rounds < 1 ? 1 : rounds));
 }
 
+// launch geometry of the run-length FIR (dsp_fir_runs.hip): persistent workgroups of four wavefronts, a row per wavefront and round; four
+// workgroups per CU where LDS allows (the kernel's registers leave room for five wavefronts per SIMD), every one the same number of rounds
+static int runs_blocks_cap(const dsp_chain* ch) {
+    int per_cu = LDS_BYTES_PER_CU / dsp_internal_fir_runs_lds_bytes(ch->runs.m);
+    if (per_cu > 4) per_cu = 4;
+    return ch->num_cu * (per_cu < 1 ? 1 : per_cu);
+}
+static int runs_blocks(const dsp_chain* ch, int64_t n_wf) {
+    const int64_t groups = (n_wf + 3) / 4, cap = runs_blocks_cap(ch);
+    const int64_t rounds = (groups + cap - 1) / cap;
+    return (int)((groups + rounds - 1) / (rounds < 1 ? 1 : rounds));
+}
+
 // makes `device` current for the calling thread and puts the previous one back when it goes out of scope
 struct DeviceScope {
     int prev = -1;
@@ -575,6 +593,25 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         const int vec = ch->red_vec && (reinterpret_cast<uintptr_t>(A.wf) & 15u) == 0;
         hipError_t e = (hipError_t)dsp_internal_launch_reduce(&A, n_wf, ch->red_dtype, vec, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "reduce kernel launch failed: %s", hipGetErrorString(e));
+        return post_err(ch, stream);
+    }
+    if (ch->runs_ok && ch->fused_on && (reinterpret_cast<uintptr_t>(io_ptrs[ch->uio_wf]) & 15u) == 0) {
+        if (!ch->runs_table) HIP_TRY(hipMalloc((void**)&ch->runs_table, sizeof(FirRunsTable)));
+        FirRunsArgs A = ch->runs;
+        if (!A.keep && !ch->runs_scratch)
+            HIP_TRY(hipMalloc((void**)&ch->runs_scratch, (size_t)runs_blocks_cap(ch) * 4 * (size_t)A.out_stride * sizeof(float)));
+        A.wf = (const float*)io_ptrs[ch->uio_wf];
+        A.taps = (const float*)at(ch->uio_taps);
+        A.out = A.keep ? (float*)at(ch->uio_out) : ch->runs_scratch;
+        A.table = ch->runs_table;
+        for (int k = 0; k < 5; ++k) A.red.out[k] = at(ch->dio_out[k]);
+        for (int k = 0; k < DSP_REDUCE_PICKS; ++k) A.red.pick_out[k] = at(ch->dio_pick[k]);
+        for (int k = 0; k < DSP_REDUCE_WALKS; ++k) {
+            A.red.walk_out[k] = at(ch->dio_walk[k]);
+            A.red.walk_thr[k] = (const float*)at(ch->dio_walk_thr[k]);
+        }
+        hipError_t e = (hipError_t)dsp_internal_launch_fir_runs(&A, ch->runs_table, n_wf, runs_blocks(ch, n_wf), (hipStream_t)stream);
+        if (e != hipSuccess) return fail(DSP_ERR_HIP, "run-length FIR kernel launch failed: %s", hipGetErrorString(e));
         return post_err(ch, stream);
     }
     if (ch->cur_ok && ch->fused_on && (reinterpret_cast<uintptr_t>(io_ptrs[ch->cio_wf]) & 15u) == 0) {
@@ -755,6 +792,12 @@ int dsp_chain_geometry(dsp_chain* ch, int64_t n_wf, int* lds_bytes_per_wave, int
         if (blocks) *blocks = (int)((n_wf + 3) / 4);
         return DSP_OK;
     }
+    if (ch->runs_ok && ch->fused_on) {
+        if (lds_bytes_per_wave) *lds_bytes_per_wave = dsp_internal_fir_runs_lds_bytes(ch->runs.m) / 4;
+        if (waves_per_block) *waves_per_block = 4;
+        if (blocks) *blocks = runs_blocks(ch, n_wf);
+        return DSP_OK;
+    }
     if (ch->cur_ok && ch->fused_on) {
         if (lds_bytes_per_wave) *lds_bytes_per_wave = ch->cur_lds_bytes;
         if (waves_per_block) *waves_per_block = 1;
@@ -791,7 +834,7 @@ const char* dsp_chain_kernel_name(dsp_chain* ch) { return dsp_plan_kernel_name(c
 
 const char* dsp_chain_kernel_note(dsp_chain* ch) {
     if (!ch) return "";
-    const bool specialised = ch->fused_on && (ch->scalar_ok || ch->pz_ok || ch->red_ok || ch->cur_ok || ch->fir_ok || ch->rows_ok || ch->rr_ok || ch->fused_ok);
+    const bool specialised = ch->fused_on && (ch->scalar_ok || ch->pz_ok || ch->red_ok || ch->runs_ok || ch->cur_ok || ch->fir_ok || ch->rows_ok || ch->rr_ok || ch->fused_ok);
     return specialised ? "" : ch->note.c_str();
 }
 
@@ -814,7 +857,7 @@ int dsp_chain_set_fused(dsp_chain* ch, int enable) {
     // 7 = classic (VM layout); anything else = default
     const int v = (enable >> 1) & 7;
     ch->variant = (v == 7 || !ch->rr_ok) ? 1 : 6;
-    return ((ch->fused_ok || ch->rr_ok || ch->rows_ok || ch->fir_ok || ch->cur_ok || ch->scalar_ok || ch->red_ok || ch->pz_ok) && ch->fused_on) ? 1 : 0;
+    return ((ch->fused_ok || ch->rr_ok || ch->rows_ok || ch->fir_ok || ch->cur_ok || ch->scalar_ok || ch->red_ok || ch->runs_ok || ch->pz_ok) && ch->fused_on) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ single processors

@@ -152,32 +152,28 @@ static bool match_pz_rows_shape(ChainPlan* ch, const dsp_op* ops, int n_ops, con
 //   LOAD s;  then any of  MIN_MAX of s (once),  AMAX of s (once),  PICKOFF of s at a constant integral time (fixed_time_pickoff, or the plain
 //   sample wf[k]; up to DSP_REDUCE_PICKS),  TIME_POINT_THRESH of s from a constant sample or from MIN_MAX's t_min / t_max (up to
 //   DSP_REDUCE_WALKS);  then STORE_SCALARs of the registers those made, float32 columns
-static bool match_reduce_shape(ChainPlan* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, const int32_t* slot_len, bool f64) {
-    if (f64 || n_ops < 3 || ops[0].opcode != DSP_OP_LOAD) return false;
-    const dsp_op& ld = ops[0];
-    const dsp_io_desc& w = io[ld.io];
-    if ((w.dtype != DSP_F32 && w.dtype != DSP_I16 && w.dtype != DSP_U16) || ld.ip[0] != 0 || ld.ip[1] != 0 || w.len < 1 || slot_len[ld.dst] != w.len)
-        return false;
-    ReduceArgs& A = ch->red;
+// The reductions themselves: ops[first ..] on waveform slot `slot` of `len` samples, then the stores; fills A and ch->dio_* (dsp_fir_runs.hip
+// runs the same on the waveform it has just filtered)
+static bool match_reduce_ops(ChainPlan* ch, const dsp_op* ops, int first, int n_ops, int slot, int len, const dsp_io_desc* io, ReduceArgs& A) {
     memset(&A, 0, sizeof A);
     int reg_of_out[5] = {-1, -1, -1, -1, -1}, reg_of_pick[DSP_REDUCE_PICKS] = {-1, -1, -1, -1};
     int reg_of_walk[DSP_REDUCE_WALKS] = {-1, -1}, walk_thr_io[DSP_REDUCE_WALKS] = {-1, -1};
-    int n_pick = 0, n_walk = 0, i = 1;
+    int n_pick = 0, n_walk = 0, i = first;
     for (; i < n_ops; ++i) {
         const dsp_op& o = ops[i];
-        if (o.opcode == DSP_OP_MIN_MAX && o.src == ld.dst && reg_of_out[0] < 0) {
+        if (o.opcode == DSP_OP_MIN_MAX && o.src == slot && reg_of_out[0] < 0) {
             for (int k = 0; k < 4; ++k) reg_of_out[k] = o.dst + k;
-        } else if (o.opcode == DSP_OP_AMAX && o.src == ld.dst && reg_of_out[4] < 0) {
+        } else if (o.opcode == DSP_OP_AMAX && o.src == slot && reg_of_out[4] < 0) {
             reg_of_out[4] = o.dst;
-        } else if (o.opcode == DSP_OP_PICKOFF && o.src == ld.dst && n_pick < DSP_REDUCE_PICKS && o.sp[0].kind == DSP_ARG_CONST && (o.ip[1] == 0 || o.ip[1] == 1)) {
+        } else if (o.opcode == DSP_OP_PICKOFF && o.src == slot && n_pick < DSP_REDUCE_PICKS && o.sp[0].kind == DSP_ARG_CONST && (o.ip[1] == 0 || o.ip[1] == 1)) {
             const double t = (double)(float)o.sp[0].value;
             if (!(t == std::floor(t)) || std::fabs(t) > 1e9) return false;  // (between samples: the interpolating modes stay with the program)
-            if (o.ip[1] == 1 && (t < 0 || t >= w.len)) return false;
+            if (o.ip[1] == 1 && (t < 0 || t >= len)) return false;
             reg_of_pick[n_pick] = o.dst;
-            A.pick_at[n_pick] = (t >= 0 && t <= w.len - 1) ? (int)t : -1;  // fixed_time_pickoff.py:68-74
+            A.pick_at[n_pick] = (t >= 0 && t <= len - 1) ? (int)t : -1;  // fixed_time_pickoff.py:68-74
             A.pick_rule[n_pick] = o.ip[1] == 0;
             ++n_pick;
-        } else if (o.opcode == DSP_OP_TIME_POINT_THRESH && o.src == ld.dst && n_walk < DSP_REDUCE_WALKS && o.sp[2].kind == DSP_ARG_CONST &&
+        } else if (o.opcode == DSP_OP_TIME_POINT_THRESH && o.src == slot && n_walk < DSP_REDUCE_WALKS && o.sp[2].kind == DSP_ARG_CONST &&
                    (o.sp[2].value == 0.0 || o.sp[2].value == 1.0)) {
             // threshold: a constant or a float32 column; start: a constant sample inside the waveform, or where MIN_MAX found an extreme (an
             // integer inside the waveform by construction -- the checks of time_point_thresh.py:67-74 cannot fail)
@@ -193,7 +189,7 @@ static bool match_reduce_shape(ChainPlan* ch, const dsp_op* ops, int n_ops, cons
                 A.walk_from[n_walk] = o.sp[1].index == reg_of_out[0] ? 1 : 2;
             } else if (o.sp[1].kind == DSP_ARG_CONST) {
                 const double t = (double)(float)o.sp[1].value;
-                if (!(t == std::floor(t)) || t < 0 || t >= w.len) return false;
+                if (!(t == std::floor(t)) || t < 0 || t >= len) return false;
                 A.walk_start[n_walk] = (int)t;
             } else {
                 return false;
@@ -205,7 +201,7 @@ static bool match_reduce_shape(ChainPlan* ch, const dsp_op* ops, int n_ops, cons
             break;
         }
     }
-    if (i == 1 || i == n_ops) return false;
+    if (i == first || i == n_ops) return false;
     for (int k = 0; k < DSP_REDUCE_WALKS; ++k) {
         ch->dio_walk[k] = -1;
         ch->dio_walk_thr[k] = walk_thr_io[k];
@@ -238,10 +234,21 @@ static bool match_reduce_shape(ChainPlan* ch, const dsp_op* ops, int n_ops, cons
     }
     for (int k = 0; k < n_walk; ++k)
         if (ch->dio_walk[k] < 0) return false;  // (a walk nobody stores: the program's business)
+    A.len = len;
+    return true;
+}
+
+static bool match_reduce_shape(ChainPlan* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, const int32_t* slot_len, bool f64) {
+    if (f64 || n_ops < 3 || ops[0].opcode != DSP_OP_LOAD) return false;
+    const dsp_op& ld = ops[0];
+    const dsp_io_desc& w = io[ld.io];
+    if ((w.dtype != DSP_F32 && w.dtype != DSP_I16 && w.dtype != DSP_U16) || ld.ip[0] != 0 || ld.ip[1] != 0 || w.len < 1 || slot_len[ld.dst] != w.len)
+        return false;
+    ReduceArgs& A = ch->red;
+    if (!match_reduce_ops(ch, ops, 1, n_ops, ld.dst, w.len, io, A)) return false;
     const int es = w.dtype == DSP_F32 ? 4 : 2;
     A.wf_stride = w.row_stride;
     A.wf_offset = w.offset;
-    A.len = w.len;
     ch->red_dtype = w.dtype;
     ch->red_vec = (w.row_stride * es) % 16 == 0 && (w.offset * es) % 16 == 0 && (w.len * es) % 16 == 0;
     ch->dio_wf = ld.io;
@@ -427,7 +434,7 @@ static bool match_fir_store_shape(ChainPlan* ch, const dsp_op* ops, int n_ops, c
     if (i + 2 != n_ops || ops[i].opcode != DSP_OP_CONVOLVE || ops[i + 1].opcode != DSP_OP_STORE) return false;
     const dsp_op& o = ops[i];
     const dsp_op& st = ops[i + 1];
-    if (o.src != s || o.dst == s || o.ip[1] != 0 || io[o.io].dtype != DSP_F32 || st.src != o.dst || io[st.io].dtype != DSP_F32) return false;
+    if (o.src != s || o.dst == s || (o.ip[1] & 3) != 0 || io[o.io].dtype != DSP_F32 || st.src != o.dst || io[st.io].dtype != DSP_F32) return false;
     const int m = o.ip[3] > 0 ? o.ip[3] : io[o.io].len;
     if (m < 64 || m > n) {
         if (m < 64) note(ch, "a %d-tap convolution: the matrix-core FIR takes kernels of 64 taps and more", m);
@@ -454,6 +461,61 @@ static bool match_fir_store_shape(ChainPlan* ch, const dsp_op* ops, int n_ops, c
     ch->fio_out[0] = st.io;
     ch->fir_lds_bytes = dsp_internal_fir_store_lds_bytes(A.kend);
     return ch->fir_lds_bytes <= 80 * 1024;
+}
+
+// The run-length FIR (dsp_fir_runs.hip):  LOAD s (float32 rows);  CONVOLVE d <- s with ip[2] = 1 (the caller found the kernel piecewise constant:
+// at most DSP_FIR_RUNS_MAX runs) and at most DSP_FIR_RUNS_MAX_TAPS finite taps, any mode;  [STORE d];  [the reductions of match_reduce_ops on d].
+// At least one of the two: a filtered waveform nobody keeps and nobody reads is no program.
+static bool match_fir_runs_shape(ChainPlan* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, const int32_t* slot_len, int n_slots, bool f64) {
+    if (f64 || n_ops < 3 || n_slots != 2 || ops[0].opcode != DSP_OP_LOAD || ops[1].opcode != DSP_OP_CONVOLVE) return false;
+    const dsp_op &ld = ops[0], &o = ops[1];
+    const dsp_io_desc& w = io[ld.io];
+    const int s = ld.dst, n = slot_len[s];
+    if (o.ip[2] != 1 || (o.ip[1] & 3) != 0 || o.src != s || o.dst == s || io[o.io].dtype != DSP_F32) return false;
+    if (w.dtype != DSP_F32 || ld.ip[0] != 0 || ld.ip[1] != 0 || w.len != n || n % 8 != 0 || n < 8 || w.row_stride % 4 != 0 || w.offset % 4 != 0) {
+        note(ch, "a piecewise-constant kernel on rows that are not float32, 16-byte aligned and a multiple of 8 samples long: the run-length FIR kernel takes those");
+        return false;
+    }
+    const int m = o.ip[3] > 0 ? o.ip[3] : io[o.io].len;
+    if (m < 1 || m > n || m > DSP_FIR_RUNS_MAX_TAPS) return false;
+    const int mode = o.ip[0];
+    const int P = mode == 'v' ? n - m + 1 : (mode == 's' ? n : (mode == 'f' ? n + m - 1 : -1));
+    if (P < 1 || slot_len[o.dst] != P) return false;
+    FirRunsArgs& A = ch->runs;
+    memset(&A, 0, sizeof A);
+    // the STORE of the filtered waveform, wherever it stands behind the CONVOLVE; everything else must be the reductions and their stores
+    ch->uio_out = -1;
+    std::vector<dsp_op> rest;
+    for (int i = 2; i < n_ops; ++i) {
+        if (ops[i].opcode == DSP_OP_STORE) {
+            const dsp_op& st = ops[i];
+            if (A.keep || st.src != o.dst || io[st.io].dtype != DSP_F32 || io[st.io].len != P) return false;
+            ch->uio_out = st.io;
+            A.keep = 1;
+            A.out_stride = io[st.io].row_stride;
+        } else {
+            rest.push_back(ops[i]);
+        }
+    }
+    for (int k = 0; k < 5; ++k) ch->dio_out[k] = -1;
+    for (int k = 0; k < DSP_REDUCE_PICKS; ++k) ch->dio_pick[k] = -1;
+    for (int k = 0; k < DSP_REDUCE_WALKS; ++k) ch->dio_walk[k] = ch->dio_walk_thr[k] = -1;
+    if (!rest.empty()) {
+        if (!match_reduce_ops(ch, rest.data(), 0, (int)rest.size(), o.dst, P, io, A.red)) return false;
+        A.has_red = 1;
+    } else if (!A.keep) {
+        return false;
+    }
+    A.wf_stride = w.row_stride;
+    A.wf_offset = w.offset;
+    A.n = n;
+    A.m = m;
+    A.p = P;
+    A.start = mode == 'v' ? m - 1 : (mode == 's' ? (m - 1) / 2 : 0);
+    if (!A.keep) A.out_stride = (P + 63) & ~63;  // the pitch of the wavefronts' scratch rows
+    ch->uio_wf = ld.io;
+    ch->uio_taps = o.io;
+    return true;
 }
 
 // Does the program have the shape of the lane-per-waveform kernel?  Fills ch->rows / ch->rio_* and returns true if so.
@@ -1404,6 +1466,15 @@ int dsp_plan_build(ChainPlan* ch, const dsp_op* ops, int n_ops, const dsp_io_des
         const char* env = getenv("DSPEED_HIP_NO_FUSED");
         ch->fused_on = !(env && env[0] == '1');
     }
+    {
+        const char* off = getenv("DSPEED_HIP_NO_FIR_RUNS");  // A/B runs: the matrix-core FIR for piecewise-constant kernels too
+        if (!ch->red_ok && !(off && off[0] == '1')) ch->runs_ok = match_fir_runs_shape(ch, ops, n_ops, io, slot_len, n_slots, f64);
+        if (ch->runs_ok) {
+            const char* env = getenv("DSPEED_HIP_NO_FUSED");
+            ch->fused_on = !(env && env[0] == '1');
+            ch->fir_ok = ch->fir_f16 = false;  // (LOAD, CONVOLVE, STORE has the matrix-core kernel's shape as well)
+        }
+    }
     ch->cur_ok = match_current_shape(ch, ops, n_ops, io, slot_len, f64);
     if (!ch->cur_ok) {
         ch->cio_wf = ch->cio_t0 = -1;
@@ -1552,6 +1623,7 @@ const char* dsp_plan_kernel_name(const ChainPlan* ch) {
     if (ch && ch->scalar_ok && ch->fused_on) return dsp_internal_scalar_kernel_name();
     if (ch && ch->pz_ok && ch->fused_on) return dsp_internal_pz_rows_kernel_name();
     if (ch && ch->red_ok && ch->fused_on) return dsp_internal_reduce_kernel_name();
+    if (ch && ch->runs_ok && ch->fused_on) return dsp_internal_fir_runs_kernel_name();
     if (ch && ch->cur_ok && ch->fused_on) return dsp_internal_current_kernel_name();
     if (ch && ch->fir_ok && ch->fused_on)
         return ch->fir_f16 ? dsp_internal_fir_f16_kernel_name() : (ch->fir.store ? dsp_internal_fir_store_kernel_name() : dsp_internal_fir_mfma_kernel_name());
@@ -1568,7 +1640,7 @@ extern "C" int dsp_chain_plan(const dsp_op* ops, int n_ops, const dsp_io_desc* i
     const int rc = dsp_plan_build(ch.get(), ops, n_ops, io, n_io, slot_len, n_slots, n_sregs, compute_dtype);
     if (rc != DSP_OK) return rc;
     snprintf(info->kernel, sizeof info->kernel, "%s", dsp_plan_kernel_name(ch.get()));
-    const bool specialised = ch->fused_on && (ch->scalar_ok || ch->pz_ok || ch->red_ok || ch->cur_ok || ch->fir_ok || ch->rows_ok || ch->rr_ok || ch->fused_ok);
+    const bool specialised = ch->fused_on && (ch->scalar_ok || ch->pz_ok || ch->red_ok || ch->runs_ok || ch->cur_ok || ch->fir_ok || ch->rows_ok || ch->rr_ok || ch->fused_ok);
     snprintf(info->note, sizeof info->note, "%s", specialised ? "" : ch->note.c_str());
     const DevProgram& P = ch->host;
     info->lds_bytes_per_wave = ch->lds_bytes_per_wave;

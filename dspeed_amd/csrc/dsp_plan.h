@@ -69,6 +69,8 @@ extern "C" const char* dsp_internal_current_kernel_name();
 extern "C" const char* dsp_internal_fir_f16_kernel_name();
 extern "C" const char* dsp_internal_fir_mfma_kernel_name();
 extern "C" const char* dsp_internal_fir_store_kernel_name();
+extern "C" const char* dsp_internal_fir_runs_kernel_name();
+extern "C" int dsp_internal_fir_runs_lds_bytes(int m);
 
 // thread-local text behind dsp_last_error(); dsp_fail formats it and hands `code` back
 int dsp_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -131,6 +133,10 @@ struct ChainPlan {
     int dio_wf = -1, dio_out[5] = {-1, -1, -1, -1, -1}, dio_pick[DSP_REDUCE_PICKS] = {-1, -1, -1, -1}, red_dtype = DSP_F32;
     int dio_walk[DSP_REDUCE_WALKS] = {-1, -1}, dio_walk_thr[DSP_REDUCE_WALKS] = {-1, -1};
     bool red_vec = false;  // rows keep 16-byte alignment and hold whole 16-byte vectors
+    // run-length FIR with the reductions of its output (dsp_fir_runs.hip); the reductions' bindings are dio_* above
+    bool runs_ok = false;
+    FirRunsArgs runs{};
+    int uio_wf = -1, uio_taps = -1, uio_out = -1;
     // LDS packing as decided (for dsp_chain_plan and the fuzzer's invariants): region of slot s = [slot_base[s], slot_base[s] + slot_foot[s])
     // elements of the compute type, alive from op slot_first_op[s] to slot_last_op[s] of the caller's program
     int32_t slot_base[DSP_MAX_SLOTS] = {0}, slot_foot[DSP_MAX_SLOTS] = {0}, slot_first_op[DSP_MAX_SLOTS] = {0}, slot_last_op[DSP_MAX_SLOTS] = {0};

@@ -230,3 +230,31 @@ struct FirF16Taps {
     int32_t pad_;
 };
 
+
+// the run-length FIR of dsp_fir_runs.hip: a kernel that is piecewise constant (the t0 filter of the Ge recipes: a ramp of 8 taps and a
+// plateau of 125) written as  sum_b weight[b] * P[c + start + 1 - t[b]]  over its breakpoints t[0] = 0 < t[1] < .. < t[n_break - 1] = m,
+// P the float64 prefix sums of the row.  Written by dsp_fir_runs_prep_kernel from the taps binding ahead of every launch.
+#define DSP_FIR_RUNS_MAX 24      /* runs a kernel may have (breakpoints: one more) */
+#define DSP_FIR_RUNS_MAX_TAPS 512
+struct FirRunsTable {
+    int32_t n_break;   // 0: the taps are not of this form after all (more runs, a NaN or an infinity among them): every row tap by tap
+    int32_t taps_nan;  // a NaN among the taps: every output NaN (convolutions.py:45-46)
+    int32_t t[DSP_FIR_RUNS_MAX + 2];
+    double weight[DSP_FIR_RUNS_MAX + 2];
+};
+
+// arguments of dsp_fir_runs_kernel:  LOAD -> CONVOLVE (any mode, ip[2] = 1) -> [STORE] -> the reductions of ReduceArgs on the filtered waveform
+struct FirRunsArgs {
+    const float* wf;         // float32 rows, 16-byte aligned
+    int64_t wf_stride;
+    int32_t wf_offset, n;    // first sample, samples (a multiple of 8)
+    const float* taps;       // the kernel as the recipe holds it
+    int32_t m, p;            // taps, outputs
+    int32_t start;           // output c is np.convolve's full output c + start ('f' 0, 's' (m - 1) / 2, 'v' m - 1)
+    int32_t keep;            // 1: the filtered waveform is an output (out), 0: it lives in the wavefront's scratch row until the reductions are done
+    float* out;              // float32 rows (keep) or the scratch area: p_pitch floats per resident wavefront
+    int64_t out_stride;      // keep: elements between rows; else p_pitch
+    const FirRunsTable* table;
+    int32_t has_red, pad_;
+    ReduceArgs red;          // (wf / wf_stride / wf_offset unused: the reductions read the filtered row)
+};

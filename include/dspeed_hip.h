@@ -173,7 +173,10 @@ typedef struct dsp_scalar_arg {
 #define DSP_OP_CONVOLVE 14     /* convolutions.py:14-72,75-119  dst <- src (*) io taps; ip[0] = mode char f|v|s, ip[1] = what the caller
                                   * found among the taps: bit 0 a NaN (output NaN), bit 1 an infinity; ip[3] > 0: the kernel has ip[3]
                                   * taps and the binding (longer, ideally a multiple of 16) holds zeros after them -- lets the blocked tap
-                                  * loop cover every tap */
+                                  * loop cover every tap; ip[2] = 1: the caller found the kernel piecewise constant (kernels.py t0_filter,
+                                  * moving averages: a few runs of equal taps) -- a hint only, the kernel in use looks at the taps of
+                                  * every launch itself: LOAD, CONVOLVE, [STORE], [per-event reductions of the filtered waveform] then
+                                  * runs on prefix sums (dsp_fir_runs_kernel) */
 #define DSP_OP_COPY 15         /* dst[k] <- src[ip[0] + k * step], step = ip[1] (0 stands for 1; negative: backwards)  (constant slice of an intermediate: processing_chain.py:1009-1071) */
 #define DSP_OP_TRAP_PICKOFF 16 /* fusion of TRAP_FILTER|TRAP_NORM|ASYM_TRAP (ip[3] = which opcode) with PICKOFF: the trap output is
                                   never materialised; sreg[dst] <- trap(src) at sp[0]; ip[0..2] = rise, flat, fall; mode in `io` */

@@ -41,6 +41,8 @@ NAME(dsp_internal_current_kernel_name, "dsp_current_kernel")
 NAME(dsp_internal_fir_f16_kernel_name, "dsp_fir_f16_kernel")
 NAME(dsp_internal_fir_mfma_kernel_name, "dsp_fir_mfma_kernel")
 NAME(dsp_internal_fir_store_kernel_name, "dsp_fir_store_kernel")
+NAME(dsp_internal_fir_runs_kernel_name, "dsp_fir_runs_kernel")
+extern "C" int dsp_internal_fir_runs_lds_bytes(int m) { return 4 * (((m + 63) & ~63) + 512) * 8; }
 
 namespace {
 
@@ -382,6 +384,51 @@ Prog fir_shape() {
     return p;
 }
 
+// LOAD, CONVOLVE with the piecewise-constant hint, [STORE], [reductions of the filtered waveform] (dsp_fir_runs.hip)
+Prog fir_runs_shape() {
+    Prog p;
+    const int len = pick({8192, 4096, 1000, 512, 8}), off = pick({0, 0, 8, 4, 1}), stride = off + len + pick({0, 8, 3});
+    const int s = new_slot(p, len);
+    dsp_op ld = op0(DSP_OP_LOAD);
+    ld.dst = s, ld.io = add_io(p, DSP_IO_WF_IN, pick({DSP_F32, DSP_F32, DSP_F32, DSP_I16}), len, off, stride);
+    if (chance(0.1)) ld.ip[0] = off;
+    p.ops.push_back(ld);
+    const int m = pick({133, 16, 1, 512, 513, 64, len}), mode = pick({'v', 's', 'f', 'x'});
+    const int outlen = mode == 'v' ? len - m + 1 : mode == 's' ? len : len + m - 1;
+    dsp_op c = op0(DSP_OP_CONVOLVE);
+    c.src = s, c.dst = new_slot(p, outlen > 0 ? outlen : 1), c.io = add_io(p, DSP_IO_TAPS, DSP_F32, ((m + 15) / 16) * 16, 0, 0);
+    c.ip[0] = mode, c.ip[1] = chance(0.1) ? rnd(1, 3) : 0, c.ip[2] = chance(0.9) ? 1 : rnd(0, 2), c.ip[3] = m;
+    p.ops.push_back(c);
+    const bool keep = chance(0.5), store_first = chance(0.5);
+    dsp_op st = op0(DSP_OP_STORE);
+    st.src = c.dst, st.io = add_io(p, DSP_IO_WF_OUT, DSP_F32, p.slots[c.dst], pick({0, 0, 4}), p.slots[c.dst] + 8);
+    if (keep && store_first) p.ops.push_back(st);
+    int mm = -1;
+    std::vector<int> regs;
+    for (int k = rnd(keep ? 0 : 1, 5); k > 0; --k) {
+        dsp_op o{};
+        switch (rnd(0, 3)) {
+            case 0: o = op0(DSP_OP_MIN_MAX), o.src = c.dst, o.dst = mm = new_sregs(p, 4); for (int q = 0; q < 4; ++q) regs.push_back(mm + q); break;
+            case 1: o = op0(DSP_OP_AMAX), o.src = c.dst, o.dst = new_sregs(p, 1), regs.push_back(o.dst); break;
+            case 2: o = op0(DSP_OP_PICKOFF), o.src = c.dst, o.dst = new_sregs(p, 1), o.ip[0] = pick({'i', 'l', 'n'}), o.ip[1] = pick({0, 1}), o.sp[0] = cst(pick({0.0, 50.0, 50.5, (double)outlen, -1.0})), regs.push_back(o.dst); break;
+            default:
+                o = op0(DSP_OP_TIME_POINT_THRESH), o.src = c.dst, o.dst = new_sregs(p, 1), o.sp[0] = shape_arg(p);
+                o.sp[1] = (mm >= 0 && chance(0.5)) ? dsp_scalar_arg{DSP_ARG_REG, mm + rnd(0, 1), 0.0} : cst(pick({0.0, 100.0, 100.5, -1.0}));
+                o.sp[2] = cst(pick({0.0, 1.0, 0.5}));
+                regs.push_back(o.dst);
+        }
+        p.ops.push_back(o);
+    }
+    for (int r : regs)
+        if (chance(0.9)) {
+            dsp_op sc = op0(DSP_OP_STORE_SCALAR);
+            sc.io = f32_out(p), sc.ip[0] = r;
+            p.ops.push_back(sc);
+        }
+    if (keep && !store_first) p.ops.push_back(st);
+    return p;
+}
+
 Prog pz_shape() {
     Prog p;
     const int len = pick({8192, 4096, 1000, 8}), off = pick({0, 0, 8, 4, 1}), stride = off + len + pick({0, 8, 3});
@@ -654,6 +701,24 @@ bool check(const Prog& p, const ChainPlan& c) {
         for (int k = 0; k < DSP_REDUCE_WALKS; ++k)
             if (c.dio_walk[k] >= 0 && c.red.walk_from[k] == 0) REQUIRE(c.red.walk_start[k] >= 0 && c.red.walk_start[k] < c.red.len, "reduce kernel: walk from %d of %d", c.red.walk_start[k], c.red.len);
     }
+    if (c.runs_ok) {
+        REQUIRE(!c.red_ok && !c.fir_ok, "run-length FIR beside another kernel of the same program");
+        REQUIRE(io_ok(c.uio_wf, DSP_IO_WF_IN) && p.io[c.uio_wf].dtype == DSP_F32 && io_ok(c.uio_taps, DSP_IO_TAPS), "run-length FIR: bindings");
+        const FirRunsArgs& R = c.runs;
+        REQUIRE(R.wf_offset == p.io[c.uio_wf].offset && R.wf_stride == p.io[c.uio_wf].row_stride && R.n == p.io[c.uio_wf].len, "run-length FIR: the row binding's offset / stride / length");
+        REQUIRE(R.n % 8 == 0 && R.wf_offset % 4 == 0 && R.wf_stride % 4 == 0 && R.wf_offset + R.n <= R.wf_stride, "run-length FIR: rows of %d samples at %d of %lld", R.n, R.wf_offset, (long long)R.wf_stride);
+        REQUIRE(R.m >= 1 && R.m <= DSP_FIR_RUNS_MAX_TAPS && R.m <= R.n && R.m <= p.io[c.uio_taps].len, "run-length FIR: %d taps", R.m);
+        REQUIRE(R.start >= 0 && R.start <= R.m - 1 && R.p >= 1 && R.p + R.start <= R.n + R.m - 1 + R.start && R.p <= R.n + R.m - 1, "run-length FIR: %d outputs from %d", R.p, R.start);
+        REQUIRE(R.keep ? (io_ok(c.uio_out, DSP_IO_WF_OUT) && p.io[c.uio_out].len == R.p && R.out_stride == p.io[c.uio_out].row_stride) : (R.has_red && R.out_stride >= R.p),
+                "run-length FIR: where the filtered waveform goes");
+        if (R.has_red) {
+            REQUIRE(R.red.len == R.p, "run-length FIR: reductions over %d of %d outputs", R.red.len, R.p);
+            for (int k = 0; k < DSP_REDUCE_PICKS; ++k)
+                if (c.dio_pick[k] >= 0) REQUIRE(R.red.pick_at[k] >= -1 && R.red.pick_at[k] < R.p, "run-length FIR: pick-off at %d of %d", R.red.pick_at[k], R.p);
+            for (int k = 0; k < DSP_REDUCE_WALKS; ++k)
+                if (c.dio_walk[k] >= 0 && R.red.walk_from[k] == 0) REQUIRE(R.red.walk_start[k] >= 0 && R.red.walk_start[k] < R.p, "run-length FIR: walk from %d of %d", R.red.walk_start[k], R.p);
+        }
+    }
     if (c.cur_ok) {
         REQUIRE(io_ok(c.cio_wf, DSP_IO_WF_IN), "current kernel: row binding");
         REQUIRE(c.cur.wf_offset == p.io[c.cio_wf].offset && c.cur.wf_stride == p.io[c.cio_wf].row_stride && c.cur.n_in == p.io[c.cio_wf].len, "current kernel: the row binding's offset / stride / length");
@@ -682,11 +747,11 @@ int main(int argc, char** argv) {
     const long n_programs = argc > 1 ? atol(argv[1]) : 10000;
     const unsigned long long seed = argc > 2 ? strtoull(argv[2], nullptr, 0) : 0xD5BEEDull;
     rng.seed(seed);
-    long accepted = 0, by_kind[8] = {0}, n_integer = 0;
-    long kernels[10] = {0};
+    long accepted = 0, by_kind[9] = {0}, n_integer = 0;
+    long kernels[11] = {0};
     for (long it = 0; it < n_programs; ++it) {
         Prog p;
-        const int kind = rnd(0, 13);
+        const int kind = rnd(0, 14);
         switch (kind) {
             case 0: p = energy_shape(); break;
             case 1: p = rows_shape(); break;
@@ -695,10 +760,11 @@ int main(int argc, char** argv) {
             case 4: p = reduce_shape(); break;
             case 5: p = current_shape(); break;
             case 6: p = scalar_shape(); break;
+            case 7: p = fir_runs_shape(); break;
             default: p = random_program();
         }
-        if (kind <= 6 && chance(0.3)) mutate(p);
-        if (kind > 6 && chance(0.05)) mutate(p);
+        if (kind <= 7 && chance(0.3)) mutate(p);
+        if (kind > 7 && chance(0.05)) mutate(p);
         if (p.slots.size() > DSP_MAX_SLOTS && chance(0.9)) p.slots.resize(DSP_MAX_SLOTS);
         std::unique_ptr<ChainPlan> plan(new ChainPlan());
         const int rc = dsp_plan_build(plan.get(), p.ops.data(), (int)p.ops.size(), p.io.data(), (int)p.io.size(), p.slots.data(), (int)p.slots.size(), p.n_sregs, p.dtype);
@@ -711,18 +777,18 @@ int main(int argc, char** argv) {
             continue;
         }
         ++accepted;
-        ++by_kind[kind <= 6 ? kind : 7];
+        ++by_kind[kind <= 7 ? kind : 8];
         n_integer += plan->i64 ? 1 : 0;
-        kernels[plan->scalar_ok ? 0 : plan->pz_ok ? 1 : plan->red_ok ? 2 : plan->cur_ok ? 3 : plan->fir_ok ? 4 : plan->rows_ok ? 5 : plan->rr_ok ? 6 : plan->fused_ok ? 7 : plan->host.team == 2 ? 8 : 9]++;
+        kernels[plan->scalar_ok ? 0 : plan->pz_ok ? 1 : plan->red_ok ? 2 : plan->runs_ok ? 10 : plan->cur_ok ? 3 : plan->fir_ok ? 4 : plan->rows_ok ? 5 : plan->rr_ok ? 6 : plan->fused_ok ? 7 : plan->host.team == 2 ? 8 : 9]++;
         if (!check(p, *plan)) {
             fprintf(stderr, "program %ld (seed %llu, kind %d, kernel %s)\n", it, seed, kind, dsp_plan_kernel_name(plan.get()));
             dump(p);
             return 1;
         }
     }
-    printf("{\"programs\": %ld, \"accepted\": %ld, \"accepted_by_generator\": {\"energy\": %ld, \"rows\": %ld, \"fir\": %ld, \"pz\": %ld, \"reduce\": %ld, \"current\": %ld, \"scalar\": %ld, \"random\": %ld}, "
-           "\"kernels\": {\"scalar\": %ld, \"pz_rows\": %ld, \"reduce\": %ld, \"current\": %ld, \"fir\": %ld, \"rows\": %ld, \"energy_rr\": %ld, \"energy\": %ld, \"vm_team\": %ld, \"vm\": %ld}, \"integer_programs\": %ld}\n",
-           n_programs, accepted, by_kind[0], by_kind[1], by_kind[2], by_kind[3], by_kind[4], by_kind[5], by_kind[6], by_kind[7], kernels[0], kernels[1], kernels[2], kernels[3], kernels[4], kernels[5],
-           kernels[6], kernels[7], kernels[8], kernels[9], n_integer);
+    printf("{\"programs\": %ld, \"accepted\": %ld, \"accepted_by_generator\": {\"energy\": %ld, \"rows\": %ld, \"fir\": %ld, \"pz\": %ld, \"reduce\": %ld, \"current\": %ld, \"scalar\": %ld, \"fir_runs\": %ld, \"random\": %ld}, "
+           "\"kernels\": {\"scalar\": %ld, \"pz_rows\": %ld, \"reduce\": %ld, \"current\": %ld, \"fir\": %ld, \"rows\": %ld, \"energy_rr\": %ld, \"energy\": %ld, \"vm_team\": %ld, \"vm\": %ld, \"fir_runs\": %ld}, \"integer_programs\": %ld}\n",
+           n_programs, accepted, by_kind[0], by_kind[1], by_kind[2], by_kind[3], by_kind[4], by_kind[5], by_kind[6], by_kind[7], by_kind[8], kernels[0], kernels[1], kernels[2], kernels[3], kernels[4], kernels[5],
+           kernels[6], kernels[7], kernels[8], kernels[9], kernels[10], n_integer);
     return 0;
 }

@@ -47,7 +47,7 @@ def test_ten_thousand_random_programs_plan_clean_under_asan_and_ubsan(fuzzer):
     rep = _run(fuzzer, 12000, 0xD5BEED)
     assert rep["programs"] == 12000 and rep["accepted"] >= 3000
     # every specialised kernel's shape was reached (and its argument block checked), as were the interpreter and its two-wavefront teams
-    for kernel in ("scalar", "pz_rows", "reduce", "current", "fir", "rows", "energy_rr", "vm_team", "vm"):
+    for kernel in ("scalar", "pz_rows", "reduce", "current", "fir", "rows", "energy_rr", "vm_team", "vm", "fir_runs"):
         assert rep["kernels"][kernel] > 0, (kernel, rep)
     assert rep["integer_programs"] > 50  # (compute type DSP_I64: the integer programs of round 4)
 

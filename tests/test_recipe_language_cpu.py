@@ -6,6 +6,7 @@ import pytest
 
 import recipes
 from dspeed_amd import _lib
+from dspeed_amd.chain import plan
 from dspeed_amd.errors import ProcessingChainError
 from dspeed_amd.processing_chain import Grid, Quantity, WaveformInput, _Builder, build_processing_chain
 
@@ -97,12 +98,12 @@ def test_long_filters_of_the_ge_recipe_run_ahead_of_the_program():
     assert _lib.OP_CONVOLVE not in opcodes and _lib.OP_CONVOLVE_AMAX not in opcodes and _lib.OP_POLE_ZERO not in opcodes
     what = [[o[0] for o in st["program"].ops] for st in chain._stages]
     assert what == [[_lib.OP_LOAD, _lib.OP_BL_SUBTRACT, _lib.OP_POLE_ZERO, _lib.OP_STORE],
-                    [_lib.OP_LOAD, _lib.OP_CONVOLVE, _lib.OP_STORE],
+                    # the t0 filter is piecewise constant (a ramp of 8 taps, a plateau of 125): the run-length FIR kernel (dsp_fir_runs.hip),
+                    # and with it what the recipe reads off the filtered waveform -- min_max, and tp_0_est's walk from the maximum; nothing
+                    # else reads wf_t0_filter, so it is not stored.  Sample indices are handed on (no unit conversion before the stores)
+                    [_lib.OP_LOAD, _lib.OP_CONVOLVE, _lib.OP_MIN_MAX, _lib.OP_TIME_POINT_THRESH] + [_lib.OP_STORE_SCALAR] * 5,
                     [_lib.OP_LOAD, _lib.OP_BL_SUBTRACT, _lib.OP_CONVOLVE, _lib.OP_STORE],
-                    # the t0 chain: what the walk on the asymmetric trapezoid starts from (min_max of the t0-filtered waveform; tp_0_est
-                    # reads the same rows and goes along), then the short trapezoid -> threshold walk in the shape of the rows kernel;
-                    # both hand on sample indices (no unit conversion before the stores)
-                    [_lib.OP_LOAD, _lib.OP_MIN_MAX, _lib.OP_TIME_POINT_THRESH] + [_lib.OP_STORE_SCALAR] * 5,
+                    # the short trapezoid -> threshold walk in the shape of the rows kernel
                     [_lib.OP_LOAD, _lib.OP_TRAP_REDUCE, _lib.OP_STORE_SCALAR],
                     # the current branch in the shape of dsp_current.hip: window at tp_0_est (a column by now) of the pole-zero rows
                     [_lib.OP_LOAD, _lib.OP_WINDOWER, _lib.OP_AVG_CURRENT, _lib.OP_UPSAMPLER, _lib.OP_MOVING_WINDOW_MULTI, _lib.OP_MIN_MAX]
@@ -110,18 +111,20 @@ def test_long_filters_of_the_ge_recipe_run_ahead_of_the_program():
                     # per-event values read straight off rows (dsp_reduce.hip): min_max of the raw waveform, maximum and one sample of the cusp's
                     [_lib.OP_LOAD, _lib.OP_MIN_MAX] + [_lib.OP_STORE_SCALAR] * 4,
                     [_lib.OP_LOAD, _lib.OP_AMAX, _lib.OP_PICKOFF] + [_lib.OP_STORE_SCALAR] * 2]
-    pz, t0f, cusp, t0v, atrap, current, raw_mm, cusp_values = chain._stages
+    pz, t0f, cusp, atrap, current, raw_mm, cusp_values = chain._stages
     assert raw_mm["what"] == "per-event values of waveform off its rows" and [o[1] for o in raw_mm["outs"]] == ["in:tp_min", "in:tp_max", "in:wf_min", "in:wf_max"]
     assert cusp_values["alias"] == {"in:wf_cusp": "in:wf_cusp"} and [o[1] for o in cusp_values["outs"]] == ["in:cuspEmax", "in:cuspEftp"]
     assert not {_lib.OP_MIN_MAX, _lib.OP_AMAX, _lib.OP_PICKOFF} & set(opcodes) and "in:wf_cusp" not in [io[0] for io in P.io] and "in:waveform" not in [io[0] for io in P.io]
     assert [o[1] for o in current["outs"]] == ["in:aoe_t_min", "in:tp_aoe_max", "in:A_min", "in:A_max"]
     assert current["alias"] == {"in:wf_pz": "in:wf_pz", "in:tp_0_est": "in:tp_0_est"}
     assert not {_lib.OP_WINDOWER, _lib.OP_UPSAMPLER, _lib.OP_MOVING_WINDOW_MULTI} & set(opcodes), "the program no longer runs the moving averages"
-    assert [o[1] for o in t0v["outs"]] == ["in:conv_tmin", "in:tp_start", "in:conv_min", "in:conv_max", "in:tp_0_est"]
+    assert [o[1] for o in t0f["outs"]] == ["in:conv_tmin", "in:tp_start", "in:conv_min", "in:conv_max", "in:tp_0_est"]
+    assert t0f["program"].ops[1][4][2] == 1, "CONVOLVE ip[2]: the caller found the kernel piecewise constant"
+    assert plan(t0f["program"])["kernel"] == "dsp_fir_runs_kernel"
     assert atrap["alias"] == {"in:wf_pz": "in:wf_pz", "in:bl_std": "aux:0:1", "in:tp_start": "in:tp_start"} and atrap["outs"] == [("out:tp_0_atrap", "in:tp_0_atrap", None)]
     assert _lib.OP_TRAP_REDUCE in opcodes and "in:wf_t0_filter" not in [io[0] for io in P.io], "the program no longer touches the t0-filtered waveform"
-    assert pz["outs"] == [("out:wf_pz", "in:wf_pz", 8192)] and t0f["alias"] == {"in:wf_pz": "in:wf_pz"}
-    assert t0f["outs"] == [("out:wf_t0_filter", "in:wf_t0_filter", 8192)] and cusp["outs"] == [("out:wf_cusp", "in:wf_cusp", 301)]
+    assert pz["outs"] == [("out:wf_pz", "in:wf_pz", 8192)] and t0f["alias"] == {"in:wf_pz": "in:wf_pz", "in:bl_std": "aux:0:1"}
+    assert cusp["outs"] == [("out:wf_cusp", "in:wf_cusp", 301)]
     assert cusp["program"].ops[0][4] == (0, 8192 - 6092), "bl_subtract's NaN rule covers the whole waveform: the load screens the rest"
     names = [io[0] for io in P.io]
     assert {"in:wf_pz", "in:tp_0_est", "in:tp_0_atrap", "in:cuspEmax", "in:tp_min"} <= set(names) and chain._ext_alias["in:cuspEmax"] == "in:cuspEmax"
