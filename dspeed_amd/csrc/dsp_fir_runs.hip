@@ -11,12 +11,15 @@
 //
 // -- B + 1 = 10 terms per output instead of 133, in float64 (P of 8192 float32 samples is exact or within 2^-53 of it; the float32
 // np.convolve of the reference carries 133 roundings: this form sits closer to the oracle's float64 sums than any float32 product).
-// A wavefront walks its row in memory order, 512 samples a step: prefix sums as in dsp_pz.hip (local prefix of 8 samples per lane,
-// one scan across the wavefront, a carry from step to step), the sums of the last m + 512 samples in LDS, every lane 8 outputs per step
-// (lane + 64 u: consecutive lanes read consecutive sums -- no bank conflict), first-occurrence extremes as the outputs appear, and at
-// the end of the row the walks / pick-offs of dsp_reduce_tail.h on what was just written.  When nothing else reads the filtered waveform
-// it never reaches HBM: the wavefront keeps it in a scratch row of its own that stays in the caches.  HBM-bound by the bytes of the rows
-// read (and written, when kept).
+// A wavefront walks its row in memory order, 512 samples a step: prefix sums as in dsp_pz.hip (local prefix of 8 samples per lane, one
+// scan across the wavefront, a carry from step to step), the sums of the last m + 512 samples in LDS, every lane 8 CONSECUTIVE outputs per
+// step.  Consecutive outputs at consecutive breakpoints (the ramp: a breakpoint at every tap) read overlapping sums: a group of G
+// breakpoints needs 8 + G - 1 sums per lane, read once into registers, instead of 8 G -- LDS bandwidth is what bounds this kernel (a sum
+// per output and breakpoint: 82 % LDS-busy, 2.3 ms per 131 072 rows of 8192; with the groups 16 + 8 reads per lane and step instead of
+// 80).  Lanes 64 bytes apart would meet on the same banks, so sum i lives at element i + i / 8 (72 bytes from lane to lane: every bank
+// once per half wavefront).  First-occurrence extremes as the outputs appear, and at the end of the row the walks / pick-offs of
+// dsp_reduce_tail.h on what was just written.  When nothing else reads the filtered waveform it never reaches HBM: the wavefront keeps it
+// in a scratch row of its own that stays in the caches.
 //
 // Rows with a NaN become NaN (convolutions.py:40-43); rows with an infinity (the prefix sums are useless from there on) and kernels that
 // are not piecewise constant after all (the taps are a binding: dsp_fir_runs_prep_kernel looks at them ahead of every launch) are done
@@ -58,9 +61,40 @@ __global__ void __launch_bounds__(64) dsp_fir_runs_prep_kernel(const float* taps
     }
     bad = wave_any(bad);
     nan = wave_any(nan);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // lane 0 reads what the others wrote
     if (lane == 0) {
-        tab->n_break = (bad || n_break > DSP_FIR_RUNS_MAX + 1) ? 0 : n_break;
+        const bool ok = !(bad || n_break > DSP_FIR_RUNS_MAX + 1);
+        tab->n_break = ok ? n_break : 0;
         tab->taps_nan = nan ? 1 : 0;
+        int n_groups = 0;
+        for (int b = 0; ok && b < n_break;) {  // breakpoints at consecutive taps go together
+            int cnt = 1;
+            while (b + cnt < n_break && cnt < DSP_FIR_RUNS_GROUP && tab->t[b + cnt] == tab->t[b] + cnt) ++cnt;
+            tab->first[n_groups] = b;
+            tab->count[n_groups] = cnt;
+            ++n_groups;
+            b += cnt;
+        }
+        tab->n_groups = n_groups;
+    }
+}
+
+// A group of G breakpoints at the taps t, t + 1, .. t + G - 1 (weights w[0 .. G-1]) on the lane's 8 consecutive outputs: output r and
+// breakpoint k read window element 8 lane + r + mp - t - k -- 8 + G - 1 different ones, win[r + G - 1 - k].  `row9`: the window + 9 lane
+// elements (the padded position of element 8 lane), s = mp - t - (G - 1) >= 0 the first one needed, relative to that (uniform).
+template <int G>
+__device__ __forceinline__ void group_of(double (&acc)[8], const FR_LDS double* row9, int s, double tab_w, int bi) {
+    double win[8 + G - 1];
+#pragma unroll
+    for (int j = 0; j < 8 + G - 1; ++j) {
+        const int q = s + j;
+        win[j] = row9[q + (q >> 3)];
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        const double w = readlane(tab_w, bi + k);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = __builtin_fma(w, win[r + (G - 1) - k], acc[r]);
     }
 }
 
@@ -72,18 +106,26 @@ __global__ void __launch_bounds__(256) dsp_fir_runs_kernel(FirRunsArgs A_, int64
     const int wib = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int n = A.n, m = A.m, p = A.p, start = A.start;
     const bool has_red = A.has_red != 0;
-    const int mp = (m + 63) & ~63;  // the sums carried from step to step: positions [0, mp); the step's own: [mp, mp + 512)
-    FR_LDS double* buf = (FR_LDS double*)fr_smem + wib * (mp + STEP);
+    const int mp = (m + 63) & ~63;  // the sums carried from step to step: window elements [0, mp); the step's own: [mp, mp + 512)
+    constexpr int PSTEP = STEP + STEP / 8;
+    const int pmp = mp + mp / 8;    // (element i at position i + i / 8)
+    FR_LDS double* buf = (FR_LDS double*)fr_smem + wib * (pmp + PSTEP);
+    const FR_LDS double* row9 = buf + 9 * lane;
     // the kernel's breakpoints: entry b in lane b's registers, read out with v_readlane where the loop over them needs it (a load per
     // breakpoint and step -- scalar or LDS -- would sit in front of the step's LDS reads and wait out its latency every time)
     const FR_KARG FirRunsTable& T = *(const FR_KARG FirRunsTable*)(unsigned long long)A.table;
     const int n_break = T.n_break;
-    int tab_t = 0;
-    double tab_w = 0.0;  // (lanes from n_break on: weight 0 at a position inside the window -- the loop takes the breakpoints two at a time)
+    const int n_groups = T.n_groups;
+    int tab_t = 0, tab_first = 0, tab_count = 1;
+    double tab_w = 0.0;
     if (lane < n_break) {
         const FR_GLOBAL FirRunsTable* tg = (const FR_GLOBAL FirRunsTable*)A.table;
         tab_t = tg->t[lane];
         tab_w = tg->weight[lane];
+        if (lane < n_groups) {
+            tab_first = tg->first[lane];
+            tab_count = tg->count[lane];
+        }
     }
     const int64_t wave = (int64_t)blockIdx.x * 4 + wib, n_waves = (int64_t)gridDim.x * 4;
     const int n_steps = (p + start + STEP - 1) / STEP;  // output c of step g, position j: c = 512 g - start + j
@@ -98,7 +140,7 @@ __global__ void __launch_bounds__(256) dsp_fir_runs_kernel(FirRunsArgs A_, int64
         e.nan = false;
         double carry = 0.0;
         if (n_break > 0) {
-            for (int q = lane; q < mp; q += 64) buf[q] = 0.0;  // P of the samples in front of the row
+            for (int q = lane; q < pmp; q += 64) buf[q] = 0.0;  // P of the samples in front of the row
             auto fetch = [&](f4 (&dst)[2], int g) {
                 int at = g * STEP + lane * 8;
                 at = at < n ? at : 0;  // (a lane beyond the row's end asks for something inside it and ignores it)
@@ -106,88 +148,119 @@ __global__ void __launch_bounds__(256) dsp_fir_runs_kernel(FirRunsArgs A_, int64
                 dst[0] = __builtin_nontemporal_load(src);
                 dst[1] = __builtin_nontemporal_load(src + 1);
             };
-            f4 cur[2], nxt[2];
-            fetch(cur, 0);
-            for (int g = 0; g < n_steps; ++g) {
-                fetch(nxt, g + 1);
+            // three sets of registers for the samples, filled in turn: the samples of step g + 2 are asked for when step g begins -- with one
+            // step of lead the loop waited for memory (16 wavefronts a CU x 2 kB in flight carry about 2 TB/s at HBM's latency under load:
+            // every form of this kernel took the same 2.1 ms per 131 072 rows, whatever its arithmetic)
+            auto step = [&](int g, const f4 (&cur)[2]) __attribute__((always_inline)) {
                 // ---- the step's prefix sums: P[512 g + 8 lane + u + 1] at position mp + 8 lane + u
-                const bool live = g * STEP + lane * 8 < n;  // (n is a multiple of 8)
                 double pl[8], run = 0.0;
+                if (g * STEP + STEP <= n) {  // (uniform) every lane's eight samples lie inside the row
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float v = live ? (u < 4 ? cur[0][u] : cur[1][u - 4]) : 0.0f;
-                    run += (double)v;
-                    pl[u] = run;
+                    for (int u = 0; u < 8; ++u) {
+                        run += (double)(u < 4 ? cur[0][u] : cur[1][u - 4]);
+                        pl[u] = run;
+                    }
+                } else {
+                    const bool live = g * STEP + lane * 8 < n;  // (n is a multiple of 8)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float v = live ? (u < 4 ? cur[0][u] : cur[1][u - 4]) : 0.0f;
+                        run += (double)v;
+                        pl[u] = run;
+                    }
                 }
                 const double inc = wave_scan_add(run);
                 const double base = wave_prev(inc) + carry;
-                typedef double d2 __attribute__((ext_vector_type(2)));
-                FR_LDS d2* dst = (FR_LDS d2*)(buf + mp + lane * 8);
+                FR_LDS double* dst = buf + pmp + lane * 9;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    d2 v;
-                    v[0] = base + pl[2 * u];
-                    v[1] = base + pl[2 * u + 1];
-                    dst[u] = v;
-                }
+                for (int u = 0; u < 8; ++u) dst[u] = base + pl[u];
                 carry += readlane(inc, 63);
                 wave_sync();
-                // ---- 8 outputs per lane: c = 512 g - start + lane + 64 u reads P[c + start + 1 - t] = position lane + 64 u + mp - t
+                // ---- 8 consecutive outputs per lane: c = 512 g - start + 8 lane + r reads P[c + start + 1 - t] = window element 8 lane + r + mp - t
                 double acc[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u] = 0.0;
-                for (int b = 0; b < n_break; b += 2) {
-                    const double w0 = readlane(tab_w, b), w1 = readlane(tab_w, b + 1);
-                    const FR_LDS double* s0 = buf + (lane + mp - __builtin_amdgcn_readlane(tab_t, b));
-                    const FR_LDS double* s1 = buf + (lane + mp - __builtin_amdgcn_readlane(tab_t, b + 1));
-                    double p0[8], p1[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        p0[u] = s0[64 * u];
-                        p1[u] = s1[64 * u];
+                for (int r = 0; r < 8; ++r) acc[r] = 0.0;
+                for (int gi = 0; gi < n_groups; ++gi) {
+                    const int bi = __builtin_amdgcn_readlane(tab_first, gi), G = __builtin_amdgcn_readlane(tab_count, gi);
+                    const int s = mp - __builtin_amdgcn_readlane(tab_t, bi) - (G - 1);
+                    switch (G) {
+                        case 1: group_of<1>(acc, row9, s, tab_w, bi); break;
+                        case 2: group_of<2>(acc, row9, s, tab_w, bi); break;
+                        case 3: group_of<3>(acc, row9, s, tab_w, bi); break;
+                        case 4: group_of<4>(acc, row9, s, tab_w, bi); break;
+                        case 5: group_of<5>(acc, row9, s, tab_w, bi); break;
+                        case 6: group_of<6>(acc, row9, s, tab_w, bi); break;
+                        case 7: group_of<7>(acc, row9, s, tab_w, bi); break;
+                        default: group_of<8>(acc, row9, s, tab_w, bi); break;
                     }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) acc[u] = __builtin_fma(w1, p1[u], __builtin_fma(w0, p0[u], acc[u]));
                 }
-                const int c0 = g * STEP - start + lane;
+                const int c0 = g * STEP - start + 8 * lane;
                 float y[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) y[u] = (float)acc[u];
+                for (int r = 0; r < 8; ++r) y[r] = (float)acc[r];
                 if (g * STEP - start >= 0 && g * STEP - start + STEP <= p) {  // (uniform) a step inside the output: no bounds to look at
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) outp[c0 + 64 * u] = y[u];
+                    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));  // (rows of outputs start wherever `start` puts them)
+                    f4u lo = {y[0], y[1], y[2], y[3]}, hi = {y[4], y[5], y[6], y[7]};
+                    *(FR_GLOBAL f4u*)(outp + c0) = lo;
+                    *(FR_GLOBAL f4u*)(outp + c0 + 4) = hi;
                     if (has_red) {
-                        // (finite samples give finite sums: no NaN to look for here -- rows with a NaN or an infinity are redone below)
+                        // (finite samples give finite sums: no NaN to look for here -- rows with a NaN or an infinity are redone below.)
+                        // Most steps change no lane's extremes (the filtered pulse has one rise): the largest and smallest of the lane's
+                        // eight first, the indices only in a step where some lane has a new extreme
+                        const float hi8 = fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7])));
+                        const float lo8 = fminf(fminf(fminf(y[0], y[1]), fminf(y[2], y[3])), fminf(fminf(y[4], y[5]), fminf(y[6], y[7])));
+                        if (__any(hi8 > e.vmax)) {
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const bool lt = y[u] < e.vmin, gt = y[u] > e.vmax;
-                            e.vmin = lt ? y[u] : e.vmin;
-                            e.imin = lt ? c0 + 64 * u : e.imin;
-                            e.vmax = gt ? y[u] : e.vmax;
-                            e.imax = gt ? c0 + 64 * u : e.imax;
+                            for (int r = 0; r < 8; ++r) {
+                                const bool gt = y[r] > e.vmax;
+                                e.vmax = gt ? y[r] : e.vmax;
+                                e.imax = gt ? c0 + r : e.imax;
+                            }
+                        }
+                        if (__any(lo8 < e.vmin)) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                const bool lt = y[r] < e.vmin;
+                                e.vmin = lt ? y[r] : e.vmin;
+                                e.imin = lt ? c0 + r : e.imin;
+                            }
                         }
                     }
                 } else {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int c = c0 + 64 * u;
+                    for (int r = 0; r < 8; ++r) {
+                        const int c = c0 + r;
                         const bool valid = c >= 0 && c < p;
-                        if (valid) outp[c] = y[u];
-                        if (has_red) take(e, y[u], c, valid);
+                        if (valid) outp[c] = y[r];
+                        if (has_red) take(e, y[r], c, valid);
                     }
                 }
                 // ---- the last mp sums move to the front
-                double keep[DSP_FIR_RUNS_MAX_TAPS / 64];
+                constexpr int NK = (DSP_FIR_RUNS_MAX_TAPS + DSP_FIR_RUNS_MAX_TAPS / 8) / 64;
+                double keep[NK];
 #pragma unroll
-                for (int k = 0; k < DSP_FIR_RUNS_MAX_TAPS / 64; ++k)
-                    if (k * 64 < mp) keep[k] = buf[STEP + k * 64 + lane];
+                for (int k = 0; k < NK; ++k)
+                    if (k * 64 < pmp) keep[k] = buf[PSTEP + k * 64 + lane];  // (the last lanes of the last round read past the window: the block's LDS runs that far, and the value is dropped)
                 wave_sync();
 #pragma unroll
-                for (int k = 0; k < DSP_FIR_RUNS_MAX_TAPS / 64; ++k)
-                    if (k * 64 < mp) buf[k * 64 + lane] = keep[k];
+                for (int k = 0; k < NK; ++k)
+                    if (k * 64 + lane < pmp) buf[k * 64 + lane] = keep[k];
                 wave_sync();
-                cur[0] = nxt[0];
-                cur[1] = nxt[1];
+            };
+            f4 b0[2], b1[2], b2[2];
+            fetch(b0, 0);
+            fetch(b1, 1);
+            for (int g = 0; g < n_steps; g += 3) {
+                fetch(b2, g + 2);
+                step(g, b0);
+                if (g + 1 < n_steps) {  // (uniform)
+                    fetch(b0, g + 3);
+                    step(g + 1, b1);
+                }
+                if (g + 2 < n_steps) {
+                    fetch(b1, g + 4);
+                    step(g + 2, b2);
+                }
             }
         }
         // ---- the rows the sums cannot do: a NaN or an infinity among the samples (the row's total tells: once a sum is not finite it stays so)
@@ -224,7 +297,10 @@ __global__ void __launch_bounds__(256) dsp_fir_runs_kernel(FirRunsArgs A_, int64
 
 }  // namespace
 
-extern "C" int dsp_internal_fir_runs_lds_bytes(int m) { return 4 * (((m + 63) & ~63) + STEP) * (int)sizeof(double); }
+extern "C" int dsp_internal_fir_runs_lds_bytes(int m) {
+    const int mp = (m + 63) & ~63;
+    return (4 * (mp + mp / 8 + STEP + STEP / 8) + 64) * (int)sizeof(double);  // (+ the round of the window's copy that reads past the last window)
+}
 
 extern "C" int dsp_internal_launch_fir_runs(const FirRunsArgs* A, FirRunsTable* table, int64_t n_wf, int blocks, hipStream_t stream) {
     if (n_wf <= 0 || A->p <= 0) return 0;

@@ -236,11 +236,15 @@ struct FirF16Taps {
 // P the float64 prefix sums of the row.  Written by dsp_fir_runs_prep_kernel from the taps binding ahead of every launch.
 #define DSP_FIR_RUNS_MAX 24      /* runs a kernel may have (breakpoints: one more) */
 #define DSP_FIR_RUNS_MAX_TAPS 512
+#define DSP_FIR_RUNS_GROUP 8     /* breakpoints at consecutive taps are taken together, up to this many */
 struct FirRunsTable {
     int32_t n_break;   // 0: the taps are not of this form after all (more runs, a NaN or an infinity among them): every row tap by tap
     int32_t taps_nan;  // a NaN among the taps: every output NaN (convolutions.py:45-46)
     int32_t t[DSP_FIR_RUNS_MAX + 2];
     double weight[DSP_FIR_RUNS_MAX + 2];
+    // breakpoints at consecutive taps (a ramp: every tap differs from the one before) as groups: first[k] .. first[k] + count[k] - 1
+    int32_t n_groups, pad_;
+    int32_t first[DSP_FIR_RUNS_MAX + 2], count[DSP_FIR_RUNS_MAX + 2];
 };
 
 // arguments of dsp_fir_runs_kernel:  LOAD -> CONVOLVE (any mode, ip[2] = 1) -> [STORE] -> the reductions of ReduceArgs on the filtered waveform

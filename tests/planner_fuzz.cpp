@@ -42,7 +42,7 @@ NAME(dsp_internal_fir_f16_kernel_name, "dsp_fir_f16_kernel")
 NAME(dsp_internal_fir_mfma_kernel_name, "dsp_fir_mfma_kernel")
 NAME(dsp_internal_fir_store_kernel_name, "dsp_fir_store_kernel")
 NAME(dsp_internal_fir_runs_kernel_name, "dsp_fir_runs_kernel")
-extern "C" int dsp_internal_fir_runs_lds_bytes(int m) { return 4 * (((m + 63) & ~63) + 512) * 8; }
+extern "C" int dsp_internal_fir_runs_lds_bytes(int m) { return (4 * ((((m + 63) & ~63) + 512) * 9 / 8) + 64) * 8; }
 
 namespace {
 

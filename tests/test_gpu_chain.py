@@ -232,10 +232,14 @@ def test_a_chain_that_misses_a_specialised_kernel_says_why(caplog):
     tb3 = {"waveform": wf[:, :3000].copy(), "baseline": tb["baseline"], "t_pick": np.full(n, 2000, np.float32)}
     chain, msgs = notes(recipes.C2, tb3)
     assert chain._chain.kernel_name.startswith("dsp_vm_kernel") and "3000 samples" in chain.kernel_notes()[0][1] and len(msgs) == 1
-    # a 40-tap FIR kept as a waveform
+    # a 40-tap FIR kept as a waveform: a piecewise-constant kernel (t0_filter) has the run-length FIR kernel whatever its length ...
     rec_f = {"outputs": ["wf_f"], "processors": {
              "kern": {"function": "t0_filter", "module": M, "args": [8, 32, "kern(40, 'f')"]},
              "wf_f": {"function": "convolve_wf", "module": M, "args": ["waveform", "kern", "'s'", "wf_f(4096, 'f')"]}}}
+    chain, msgs = notes(rec_f, {"waveform": wf})
+    assert chain.kernels() == [("program", "dsp_fir_runs_kernel")] and chain.kernel_notes() == [] and msgs == []
+    # ... any other one of fewer than 64 taps stays with the interpreter, and the chain says so
+    rec_f["processors"]["kern"] = {"function": "moving_slope", "module": M, "args": ["kern(40, 'f')"]}
     chain, msgs = notes(rec_f, {"waveform": wf})
     assert any("40-tap" in note for _w, note in chain.kernel_notes()), (chain.kernels(), chain.kernel_notes())
 

@@ -348,8 +348,9 @@ def test_staged_filters_agree_with_the_one_program_form(monkeypatch):
         "t_lo, t_a, v_lo, v_hi": f"{M}.min_max(wf_a, t_lo, t_a, v_lo, v_hi)"}}
     chain, staged, one = _both_ways(rec, {"waveform": wf}, monkeypatch)
     kinds = sorted(st["chain"].kernel_name for st in chain._stages)
-    # (the maximum of wf_b, which nothing else reads, comes straight off its rows)
-    assert kinds == sorted([_amax_kernel(), _store_kernel(), _store_kernel(), "dsp_reduce_kernel", "dsp_pz_rows_kernel"]), kinds
+    # (the maximum of wf_b, which nothing else reads, comes straight off its rows; ka -- a ramp of 8 taps and a plateau -- is piecewise constant:
+    # the run-length FIR kernel, with a_max and min_max of wf_a in the same pass; kb's ramp of 30 taps is more runs than that kernel takes)
+    assert kinds == sorted([_amax_kernel(), _store_kernel(), "dsp_fir_runs_kernel", "dsp_reduce_kernel", "dsp_pz_rows_kernel"]), kinds
     assert np.array_equal(staged["bl_mean"], one["bl_mean"])
     peak = np.abs(one["wf_a"]).max(axis=1)
     assert np.max(np.abs(staged["wf_a"] - one["wf_a"]) / peak[:, None]) <= 2e-6

@@ -97,6 +97,8 @@ def test_row_scales_travel_with_the_rows(monkeypatch):
         "wf_f": {"function": "convolve_wf", "module": M, "args": ["wf_pz", "kern", "'s'", "wf_f(4096, 'f')"]},
         "f_max": "numpy.amax(wf_f, 1, f_max)"}}
 
+    monkeypatch.setenv("DSPEED_HIP_NO_FIR_RUNS", "1")  # (this kernel is piecewise constant: by default the run-length FIR, which needs no scales)
+
     def run(shared):
         monkeypatch.setenv("DSPEED_HIP_NO_SHARED_ROW_SCALES", "0" if shared else "1")
         chain, _, out = build_processing_chain(rec, {"waveform": wf, "baseline": bl})
@@ -152,6 +154,8 @@ def test_row_scales_follow_the_batch(monkeypatch):
         "kern": {"function": "t0_filter", "module": M, "args": ["8", "125", "kern(133, 'f')"]},
         "wf_f": {"function": "convolve_wf", "module": M, "args": ["wf_pz", "kern", "'s'", f"wf_f({L}, 'f')"]}}}
     batches = [_rows(rng, 100, L, np.int16), _rows(rng, 700, L, np.int16), _rows(rng, 64, L, np.int16)]
+
+    monkeypatch.setenv("DSPEED_HIP_NO_FIR_RUNS", "1")  # (this kernel is piecewise constant: by default the run-length FIR, which needs no scales)
 
     def run(shared):
         monkeypatch.setenv("DSPEED_HIP_NO_SHARED_ROW_SCALES", "0" if shared else "1")
