@@ -18,6 +18,9 @@ cp $S/icpc_rate_small.jsonl profiles/${TAG}_icpc_rate_small.jsonl
 cp $S/icpc_pmc.json profiles/${TAG}_icpc_pmc.json
 cp $S/fir_store_rate.json profiles/${TAG}_fir_store_rate.json
 cp $S/fir_store_rate_f32.json profiles/${TAG}_fir_store_rate_f32.json
+cp $S/fir_runs_rate.jsonl profiles/${TAG}_fir_runs_rate.jsonl
+cp $S/fir_runs_rate_mfma.jsonl profiles/${TAG}_fir_runs_rate_mfma.jsonl
+cp $S/fir_runs_pmc.json profiles/${TAG}_fir_runs_pmc.json
 cp $S/fir_f16_accuracy.json profiles/${TAG}_fir_f16_accuracy.json
 cp $S/e2e_recipe_rate.json profiles/${TAG}_e2e_recipe_rate.json
 cp $S/vm_pmc.json profiles/${TAG}_vm_pmc.json

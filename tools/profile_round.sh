@@ -24,6 +24,11 @@ python3 tools/icpc_breakdown.py > "$OUT/icpc_recipe.jsonl" 2> "$OUT/icpc_recipe.
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/icpc_trace" -- python3 tools/icpc_rate.py 131072 5 > "$OUT/icpc_rate_traced.json" 2> "$OUT/icpc_trace.err"
 python3 tools/icpc_rate.py 131072 5 > "$OUT/icpc_rate.json" 2> /dev/null
 python3 tools/fir_store_rate.py 100000 1 > "$OUT/fir_store_rate.json" 2> /dev/null
+# the run-length FIR (piecewise-constant kernels: the t0 filter) in its three forms, the matrix-core FIR on the same rows, its counters
+python3 tools/fir_runs_rate.py 131072 8192 5 > "$OUT/fir_runs_rate.jsonl" 2> /dev/null
+DSPEED_HIP_NO_FIR_RUNS=1 python3 tools/fir_runs_rate.py 131072 8192 2 > "$OUT/fir_runs_rate_mfma.jsonl" 2> /dev/null
+tools/pmc_kernel.sh gpurun_out/prof_${TAG}_runs tools/fir_runs_rate.py 65536 8192 2 > /dev/null 2>&1
+python3 tools/pmc_table.py gpurun_out/prof_${TAG}_runs "dsp_fir_runs_kernel" "$OUT/fir_runs_pmc.json" > /dev/null
 # the long FIRs on the float32 matrix instructions (the float16 form is the default) and the accuracy of both against float64
 DSPEED_HIP_FIR_F32=1 python3 tools/c3_rate.py 250000 1 > "$OUT/c3_rate_f32.json" 2>/dev/null
 DSPEED_HIP_FIR_F32=1 python3 tools/fir_store_rate.py 100000 1 > "$OUT/fir_store_rate_f32.json" 2> /dev/null

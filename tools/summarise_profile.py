@@ -149,6 +149,17 @@ if os.path.exists(e2e) and os.path.getsize(e2e):
 fsr = f"{src}/fir_store_rate.json"
 if os.path.exists(fsr) and os.path.getsize(fsr):
     shutil.copy(fsr, f"profiles/{tag}_fir_store_rate.json")
+frr = f"{src}/fir_runs_rate.jsonl"
+if os.path.exists(frr) and os.path.getsize(frr):
+    shutil.copy(frr, f"profiles/{tag}_fir_runs_rate.jsonl")
+    rs = [json.loads(line) for line in open(frr) if line.strip().startswith("{")]
+    summary += ["", f"The run-length FIR (`dsp_fir_runs_kernel`, the 133-tap t0 filter on {rs[0]['rows']} float32 rows of {rs[0]['samples']}; `tools/fir_runs_rate.py`): " +
+                "; ".join(f"{r['form']}: {r['ms']:.2f} ms = {r['algorithmic_GBps'] / 1e3:.2f} TB/s of the rows it must move" for r in rs) + "."]
+    other = f"{src}/fir_runs_rate_mfma.jsonl"
+    if os.path.exists(other) and os.path.getsize(other):
+        shutil.copy(other, f"profiles/{tag}_fir_runs_rate_mfma.jsonl")
+        ro = [json.loads(line) for line in open(other) if line.strip().startswith("{")]
+        summary += ["The same programs with `DSPEED_HIP_NO_FIR_RUNS=1`: " + "; ".join(f"{r['form']}: {r['kernel']} {r['ms']:.2f} ms" for r in ro) + "."]
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(summary) + "\n")
 shutil.copy(f"{src}/bench_default.json", f"profiles/{tag}_bench.json")
 print("\n".join(summary))
