@@ -1484,6 +1484,10 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
     tail = None
     if not stage_mode and os.environ.get("DSPEED_HIP_NO_SCALAR_TAIL", "0") != "1":
         tail = _split_scalar_tail(p, ft)
+    if not stage_mode and os.environ.get("DSPEED_HIP_NO_SCALAR_HEAD", "0") != "1":  # (behind the tail's cut: what is only stored is the tail's)
+        head = _split_scalar_head(p, ft, ext_alias)
+        if head is not None:
+            stages.append(head)
     from .processing_chain import ProcessingChain  # (the runtime imports this module)
 
     chain = ProcessingChain(p, in_bind, out_bind, consts, n_rows, proc_strings, ft, aux_desc, stages=stages, ext_alias=ext_alias, tail=tail)
@@ -1494,6 +1498,108 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
 _SCALAR_OPS = (_lib.OP_SCALAR_AFFINE, _lib.OP_SCALAR_DIV, _lib.OP_SCALAR_CONVERT, _lib.OP_SCALAR_FUNC, _lib.OP_STORE_SCALAR)
 #: a tail is cut off when it has at least this many ops (a launch and a column per handed-over register have to pay for themselves)
 SCALAR_TAIL_MIN_OPS = 8
+
+
+#: a head is split off when it takes at least this many ops out of the program
+SCALAR_HEAD_MIN_OPS = 2
+
+
+def _split_scalar_head(p: Program, ft, ext_alias: dict):
+    """The counterpart of the scalar tail at the other end: arithmetic between per-event values that needs nothing the program computes --
+    pick-off times from the t0 estimate a stage left in HBM, thresholds from fit results -- leaves the program and runs ahead of it with a row
+    per lane (dsp_scalar.hip), as one more stage; the program reads the results as columns.  On the interpreter an op costs a row's wavefront
+    about 1 700 cycles whatever it computes (a lone wavefront issues its ~ 150 dispatch instructions one per ~ 12 cycles: measured 45 us per
+    op and 65 536 rows), and a program of 8192-sample rows holds one row per SIMD.  ``p`` is changed in place; returns the stage's description or
+    None.  Registers may be reused along the program: what an op reads is tracked by position."""
+    if not p.slots:
+        return None  # (no waveform: the program is a row-per-lane program already)
+    from_head = {}          # register -> (column name, index into `made`) while the register's current value comes from a head op
+    head_ops, made = [], []  # made: [column name, register, read by the program?]
+    new_ops = []
+
+    def reads_of(opcode, ip, sp):
+        r = [a.index for a in sp if a.kind == _lib.ARG_REG]
+        if opcode == _lib.OP_STORE_SCALAR:
+            r.append(ip[0])
+        return r
+
+    def writes_of(opcode, dst, io, ip):
+        if opcode == _lib.OP_STORE_SCALAR or opcode in (_lib.OP_LOAD, _lib.OP_STORE):
+            return []
+        if opcode in (_lib.OP_MIN_MAX,):
+            return [dst + k for k in range(4)]
+        if opcode == _lib.OP_TRAP_REDUCE:  # (its extremes, the maximum alone, a pick-off of the same trapezoid: include/dspeed_hip.h)
+            w = [dst + k for k in range(4)] if dst >= 0 else []
+            if io >= 0:
+                w.append(io)
+            if ((ip[3] >> 16) & 0x3fff) - 1 >= 0:
+                w.append(((ip[3] >> 16) & 0x3fff) - 1)
+            return w
+        return [dst]
+
+    waveform_ops = {_lib.OP_LOAD, _lib.OP_STORE}
+    for k, (opcode, dst, src, io, ip, sp) in enumerate(p.ops):
+        is_head = (opcode in _SCALAR_OPS and opcode != _lib.OP_STORE_SCALAR
+                   and all(a.kind in (_lib.ARG_CONST, _lib.ARG_INPUT) or (a.kind == _lib.ARG_REG and a.index in from_head) for a in sp))
+        if is_head:
+            head_ops.append((opcode, dst, src, io, ip, sp))
+            made.append([f"head:r{dst}.{len(made)}", dst, False])
+            from_head[dst] = len(made) - 1
+            continue
+        # an op that stays: what it reads of the head's results arrives as a column
+        sp2 = []
+        for a in sp:
+            if a.kind == _lib.ARG_REG and a.index in from_head:
+                made[from_head[a.index]][2] = True
+                sp2.append(("head", from_head[a.index]))
+            else:
+                sp2.append(a)
+        if opcode == _lib.OP_STORE_SCALAR and ip[0] in from_head:  # a stored value needs its register: a copy of the column
+            made[from_head[ip[0]]][2] = True
+            new_ops.append(("copy", ip[0], from_head[ip[0]]))
+            del from_head[ip[0]]
+        new_ops.append((opcode, dst, src, io, ip, tuple(sp2)))
+        for r in writes_of(opcode, dst, io, ip):
+            from_head.pop(r, None)
+    if len(head_ops) < SCALAR_HEAD_MIN_OPS or not any(m[2] for m in made):
+        return None
+    h = Program()
+    h.n_sregs = p.n_sregs
+    io_map = {}
+
+    def head_io(idx):
+        if idx not in io_map:
+            name, kind, code, length, offset, stride = p.io[idx]
+            io_map[idx] = h.add_io(name, kind, code, length, offset, stride)
+        return io_map[idx]
+
+    for opcode, dst, src, io, ip, sp in head_ops:
+        h.add_op(opcode, dst=dst, src=src, io=io, ip=ip, sp=tuple(Scalar.input(head_io(a.index)) if a.kind == _lib.ARG_INPUT else a for a in sp))
+        # (a register written twice by the head: the column is stored right behind the op that made this version)
+        name, r, used = made[len(h.ops) - 1 - sum(1 for o in h.ops[:-1] if o[0] == _lib.OP_STORE_SCALAR)]
+        if used:
+            h.add_op(_lib.OP_STORE_SCALAR, io=h.add_io("out:" + name, _lib.IO_SCALAR_OUT, ft), ip=(r,))
+    col_io = {}
+
+    def column(j):
+        if j not in col_io:
+            col_io[j] = p.add_io("in:" + made[j][0], _lib.IO_SCALAR_IN, ft)
+            ext_alias["in:" + made[j][0]] = "in:" + made[j][0]
+        return col_io[j]
+
+    del p.ops[:]
+    for entry in new_ops:
+        if entry[0] == "copy":
+            _c, r, j = entry
+            p.add_op(_lib.OP_SCALAR_FUNC, dst=r, ip=(_lib.FN_COPY,), sp=(Scalar.input(column(j)), Scalar.const(0.0), Scalar.const(0.0)))
+            continue
+        opcode, dst, src, io, ip, sp = entry
+        p.add_op(opcode, dst=dst, src=src, io=io, ip=ip, sp=tuple(Scalar.input(column(a[1])) if isinstance(a, tuple) else a for a in sp))
+    if len(p.io) > _lib.MAX_IO or len(h.io) > _lib.MAX_IO:
+        raise NotImplementedError("recipe is too large for one device chain (ops/slots/bindings limit)")
+    names = [io[0] for io in h.io if io[1] == _lib.IO_SCALAR_IN]
+    return {"what": "per-event arithmetic ahead of the program", "program": h, "consts": {}, "in_vars": {}, "alias": {n: ext_alias.get(n, n) for n in names},
+            "outs": [("out:" + name, "in:" + name, None) for name, _r, used in made if used], "chain": None, "bufs": {}}
 
 
 def _split_scalar_tail(p: Program, ft):

@@ -1487,6 +1487,60 @@ int dsp_plan_build(ChainPlan* ch, const dsp_op* ops, int n_ops, const dsp_io_des
     // ---- a team of two wavefronts per row?  A program that loads ONE waveform and then only reads it -- the trapezoid reductions, pick-offs and
     // walks a whole recipe runs on its pole-zero rows -- whose image leaves LDS for one wavefront per SIMD: its ops fall into groups that share
     // no scalar register, and two wavefronts can run two groups on the one image at the same time.
+    // ---- a threshold that is a fraction of a per-event value (the rise-time walks of the Ge recipes: time_point_thresh at 0.99 / 0.9 / 0.5 /
+    // 0.1 of the trapezoid's maximum) costs the interpreter an op of its own -- ~ 1 700 cycles of a row's lone wavefront, whatever the op
+    // computes -- for one multiplication.  SCALAR_AFFINE d <- x * const + 0 whose result only TIME_POINT_THRESH ops read as their threshold
+    // is folded into them: they multiply (the same float multiplication: x * b + (+-0) is x * b) and the op becomes a no-op.
+    {
+        auto writes_reg = [&](const DevOp& o, int r) {
+            switch (o.opcode) {
+                case DSP_OP_MIN_MAX: return r >= o.dst && r < o.dst + 4;
+                case DSP_OP_TRAP_REDUCE:
+                    return (o.dst >= 0 && r >= o.dst && r < o.dst + 4) || (o.io >= 0 && r == o.io) || r == ((o.ip[3] >> 16) & 0x3fff) - 1;
+                case DSP_OP_LOAD: case DSP_OP_STORE: case DSP_OP_STORE_SCALAR: case DSP_OP_INTERNAL_NOP: case DSP_OP_INTERNAL_ZERO: return false;
+                default: return o.dst == r;  // (waveform ops name a slot there: a spurious match only ends a window early)
+            }
+        };
+        for (int i = 0; i < P.n_ops; ++i) {
+            DevOp& a = P.ops[i];
+            if (a.opcode != DSP_OP_SCALAR_AFFINE || a.sp[0].kind != DSP_ARG_REG || a.sp[1].kind != DSP_ARG_CONST || a.sp[2].kind != DSP_ARG_CONST ||
+                a.sp[2].value != 0.0 || a.sp[0].index == a.dst)
+                continue;
+            const int r = a.dst, x = a.sp[0].index;
+            std::vector<int> users;
+            bool fine = true;
+            for (int j = i + 1; j < P.n_ops && fine; ++j) {
+                const DevOp& o = P.ops[j];
+                bool reads_r = false;
+                for (int k = 0; k < 4; ++k)
+                    if (o.sp[k].kind == DSP_ARG_REG && o.sp[k].index == r) {
+                        reads_r = true;
+                        if (!(o.opcode == DSP_OP_TIME_POINT_THRESH && k == 0 && o.ic[0] == 0)) fine = false;
+                    }
+                if (o.opcode == DSP_OP_STORE_SCALAR && o.ip[0] == r) fine = false;
+                if (reads_r && fine) users.push_back(j);
+                if (writes_reg(o, r)) break;                        // the register starts another life: what follows reads that
+                if (writes_reg(o, x) && fine) {                     // the value the walks would multiply changes here: nothing may read r after it
+                    for (int j2 = j + 1; j2 < P.n_ops; ++j2) {
+                        const DevOp& o2 = P.ops[j2];
+                        for (int k = 0; k < 4; ++k)
+                            if (o2.sp[k].kind == DSP_ARG_REG && o2.sp[k].index == r) fine = false;
+                        if (o2.opcode == DSP_OP_STORE_SCALAR && o2.ip[0] == r) fine = false;
+                        if (writes_reg(o2, r)) break;
+                    }
+                    break;
+                }
+            }
+            if (!fine || users.empty()) continue;
+            for (int j : users) {
+                P.ops[j].sp[0] = a.sp[0];
+                P.ops[j].ic[0] = 1;
+                P.ops[j].fc[0] = a.sp[1].value;
+            }
+            a.opcode = DSP_OP_INTERNAL_NOP;
+        }
+    }
+
     P.team = 1;
     for (int i = 0; i < P.n_ops; ++i) P.ops[i].member = 2;
     {
@@ -1609,6 +1663,7 @@ int dsp_plan_build(ChainPlan* ch, const dsp_op* ops, int n_ops, const dsp_io_des
         P.n_ops = w;
     }
 
+    for (int i = 0; i < P.n_ops; ++i) P.ops[i].prio = (i * 4) / P.n_ops;
     for (int s = 0; s < n_slots; ++s) {
         ch->slot_base[s] = base[s];
         ch->slot_foot[s] = foot[s];

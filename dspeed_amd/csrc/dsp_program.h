@@ -43,7 +43,7 @@ struct DevOp {
     dsp_scalar_arg sp[4];
     int32_t ic[DSP_IC];
     int32_t member;  // DevProgram.team == 2: which wavefront of a row's team runs the op (0, 1; 2 = both)
-    int32_t pad_;
+    int32_t prio;    // the wave priority the interpreter runs the op at: 0 .. 3 over the op list (the planner's division, not one per op and row)
     double fc[DSP_FC];
 };
 

@@ -103,9 +103,11 @@ struct Ctx {
 // ------------------------------------------------------------------------------------------------
 // LOAD / STORE: coalesced 16-byte global accesses <-> chunked LDS layout
 // ------------------------------------------------------------------------------------------------
-template <typename T, typename InT>
+// TEAM == 2: the two wavefronts of a row's team load alternate batches (`member` 0 / 1) -- half the loads and half the LDS writes each; the
+// caller's barrier makes the image whole for both
+template <typename T, typename InT, int TEAM = 1>
 __device__ __forceinline__ bool load_slot(Ctx<T>& cx, const DSP_PROG DevSlot& s, const DSP_GLOBAL InT* __restrict__ g, int len, bool vec_ok, bool sub,
-                                          T bsub) {
+                                          T bsub, int member = 0) {
     constexpr int V = 16 / (int)sizeof(InT);
     typedef InT vec_t __attribute__((ext_vector_type(V)));
     const int total = 64 * s.C;
@@ -125,7 +127,7 @@ __device__ __forceinline__ bool load_slot(Ctx<T>& cx, const DSP_PROG DevSlot& s,
                 cx.lds[a + m] = x;
             }
         };
-        for (int base = 0; base < total; base += 64 * V * B) {
+        for (int base = (TEAM > 1 ? member : 0) * 64 * V * B; base < total; base += TEAM * 64 * V * B) {
             vec_t v[B];
             const int e0 = base + lane_id() * V;
             if (base + 64 * V * B <= len) {
@@ -152,7 +154,7 @@ __device__ __forceinline__ bool load_slot(Ctx<T>& cx, const DSP_PROG DevSlot& s,
             }
         }
     } else {
-        for (int e = lane_id(); e < total; e += 64) {
+        for (int e = lane_id() + (TEAM > 1 ? member : 0) * 64; e < total; e += TEAM * 64) {
             T x = (e < len) ? (T)g[e] : (T)0;
             x = (sub && e < len) ? x - bsub : x;
             nan |= (x != x);
@@ -162,8 +164,8 @@ __device__ __forceinline__ bool load_slot(Ctx<T>& cx, const DSP_PROG DevSlot& s,
     return nan;
 }
 
-template <typename T>
-__device__ __forceinline__ void op_load(Ctx<T>& cx, const DSP_PROG DevOp& op) {
+template <typename T, int TEAM = 1>
+__device__ __forceinline__ void op_load(Ctx<T>& cx, const DSP_PROG DevOp& op, int member = 0) {
     const DSP_PROG DevSlot& s = cx.prog->slots[op.dst];
     const DSP_PROG DevIO& io = cx.prog->io[op.io];
     const int64_t at = cx.row * io.row_stride + io.offset;
@@ -172,12 +174,12 @@ __device__ __forceinline__ void op_load(Ctx<T>& cx, const DSP_PROG DevOp& op) {
     const T bsub = sub ? cx.scalar(op.sp[0]) : (T)0;
     bool nan;
     switch (io.dtype) {
-        case DSP_F32: nan = load_slot<T, float>(cx, s, cx.template io_ptr<const float>(op.io) + at, io.len, vec_ok, sub, bsub); break;
-        case DSP_I16: nan = load_slot<T, int16_t>(cx, s, cx.template io_ptr<const int16_t>(op.io) + at, io.len, vec_ok, sub, bsub); break;
-        case DSP_U16: nan = load_slot<T, uint16_t>(cx, s, cx.template io_ptr<const uint16_t>(op.io) + at, io.len, vec_ok, sub, bsub); break;
-        case DSP_I32: nan = load_slot<T, int32_t>(cx, s, cx.template io_ptr<const int32_t>(op.io) + at, io.len, vec_ok, sub, bsub); break;
-        case DSP_U32: nan = load_slot<T, uint32_t>(cx, s, cx.template io_ptr<const uint32_t>(op.io) + at, io.len, vec_ok, sub, bsub); break;
-        default: nan = load_slot<T, double>(cx, s, cx.template io_ptr<const double>(op.io) + at, io.len, vec_ok, sub, bsub); break;
+        case DSP_F32: nan = load_slot<T, float, TEAM>(cx, s, cx.template io_ptr<const float>(op.io) + at, io.len, vec_ok, sub, bsub, member); break;
+        case DSP_I16: nan = load_slot<T, int16_t, TEAM>(cx, s, cx.template io_ptr<const int16_t>(op.io) + at, io.len, vec_ok, sub, bsub, member); break;
+        case DSP_U16: nan = load_slot<T, uint16_t, TEAM>(cx, s, cx.template io_ptr<const uint16_t>(op.io) + at, io.len, vec_ok, sub, bsub, member); break;
+        case DSP_I32: nan = load_slot<T, int32_t, TEAM>(cx, s, cx.template io_ptr<const int32_t>(op.io) + at, io.len, vec_ok, sub, bsub, member); break;
+        case DSP_U32: nan = load_slot<T, uint32_t, TEAM>(cx, s, cx.template io_ptr<const uint32_t>(op.io) + at, io.len, vec_ok, sub, bsub, member); break;
+        default: nan = load_slot<T, double, TEAM>(cx, s, cx.template io_ptr<const double>(op.io) + at, io.len, vec_ok, sub, bsub, member); break;
     }
     if (op.ip[0] > 0 || op.ip[1] > 0) {  // the slice of a longer waveform, first read by a processor whose NaN rule covers all of it
         for (int part = 0; part < 2; ++part) {
@@ -192,9 +194,19 @@ __device__ __forceinline__ void op_load(Ctx<T>& cx, const DSP_PROG DevOp& op) {
             }
         }
     }
+    bool any_nan = wave_any(nan);
+    if (TEAM > 1) {
+        // each member saw half of the row: what they found meets in two words of the op scratch area, between two barriers -- the first also
+        // makes the image whole for both, the second keeps the words until both have read them
+        auto* sc = cx.lds + cx.prog->scratch_off;
+        if (lane_id() == 0) sc[member] = any_nan ? (T)1 : (T)0;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        any_nan = (sc[0] != (T)0) || (sc[1] != (T)0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     if (sub)  // bl_subtract.py:41-44: a NaN anywhere (or a NaN baseline, which made every sample NaN) is a NaN waveform
-        cx.set_nan(op.dst, wave_any(nan));
-    else if (wave_any(nan))  // (the samples are all there: what reads the slot as a whole sees a NaN waveform, a store writes it as it is)
+        cx.set_nan(op.dst, any_nan);
+    else if (any_nan)  // (the samples are all there: what reads the slot as a whole sees a NaN waveform, a store writes it as it is)
         cx.set_some_nan(op.dst);
     else
         cx.set_nan(op.dst, false);
@@ -1722,7 +1734,9 @@ __device__ __forceinline__ int find_crossing(Ctx<T>& cx, const SlotRef& ss, T th
 template <typename T>
 __device__ __forceinline__ void op_time_point_thresh(Ctx<T>& cx, const DSP_PROG DevOp& op) {
     const DSP_PROG DevSlot& ss = cx.prog->slots[op.src];
-    const T thr = cx.scalar(op.sp[0]), ts_f = cx.scalar(op.sp[1]), walk_f = cx.scalar(op.sp[2]);
+    T thr = cx.scalar(op.sp[0]);
+    if (op.ic[0]) thr = thr * (T)op.fc[0];  // (the planner folded `threshold = value * constant` into the walk: dsp_plan.cpp)
+    const T ts_f = cx.scalar(op.sp[1]), walk_f = cx.scalar(op.sp[2]);
     T out = quiet_nan<T>();
     const int n = ss.len, lane = lane_id();
     if (!(cx.slot_nan(op.src) || thr != thr || ts_f != ts_f || walk_f != walk_f)) {
@@ -2241,7 +2255,7 @@ template <typename T, bool FIR, int TEAM>
 __global__ void __launch_bounds__(256 * TEAM, TEAM > 1 ? 1 : (FIR ? 2 : 3)) dsp_vm_kernel(const DevProgram* __restrict__ prog, IoPtrs ptrs, int64_t n_wf, int* err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // TEAM == 2: wavefronts 2 s and 2 s + 1 of the workgroup share row slot s -- one LDS image, the ops of the row's program dealt out between
-    // them (DevOp.member; the LOAD is run by both, writing the same values: each member has a complete image when its own load is done).  One
+    // them (DevOp.member; the LOAD is shared: each member loads every other batch, a barrier makes the image whole).  One more
     // workgroup barrier per row keeps a member from loading the next row into an image its partner still reads.
     const int wave_raw = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably wave-uniform -> rows, pointers in SGPRs
     const int wave = TEAM == 1 ? wave_raw : wave_raw / TEAM;
@@ -2275,8 +2289,10 @@ __global__ void __launch_bounds__(256 * TEAM, TEAM > 1 ? 1 : (FIR ? 2 : 3)) dsp_
     for (int64_t base = (int64_t)blockIdx.x * wpb;; base += total_waves) {
         const int64_t row = base + wave;
         if (TEAM == 1 ? row >= n_wf : base >= n_wf) break;  // (a team's workgroup leaves together: every wavefront meets every barrier)
-        if (TEAM > 1 && row >= n_wf) {
+        if (TEAM > 1 && row >= n_wf) {  // (an idle row slot of the last round meets the barriers of a row: the one at its end and the load's two)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
             continue;
         }
         cx.row = row;
@@ -2297,7 +2313,7 @@ __global__ void __launch_bounds__(256 * TEAM, TEAM > 1 ? 1 : (FIR ? 2 : 3)) dsp_
                 if (m != 2 && m != member) continue;
             }
             {
-                const int lvl = (i * 4) / n_ops;
+                const int lvl = op.prio;
                 if (lvl != prio_level) {  // (uniform; s_setprio takes an immediate)
                     prio_level = lvl;
                     if (lvl == 1) __builtin_amdgcn_s_setprio(1);
@@ -2312,7 +2328,7 @@ __global__ void __launch_bounds__(256 * TEAM, TEAM > 1 ? 1 : (FIR ? 2 : 3)) dsp_
                 prof_last = i;
             }
             switch (op.opcode) {
-                case DSP_OP_LOAD: op_load(cx, op); break;
+                case DSP_OP_LOAD: op_load<T, TEAM>(cx, op, member); break;
                 case DSP_OP_STORE: op_store(cx, op); break;
                 case DSP_OP_STORE_SCALAR: op_store_scalar(cx, op); break;
                 case DSP_OP_INTERNAL_STORES: op_store_scalars(cx, op); break;

@@ -268,7 +268,7 @@ def test_index_outputs_are_bit_exact_on_the_devices_own_waveforms():
     # (the t0 filter -- piecewise constant -- with min_max and tp_0_est's walk on the run-length FIR kernel: wf_t0_filter is not stored)
     assert [k for _what, k in chain_p.kernels()] == ["dsp_fit_rows_kernel", "dsp_pz_rows_kernel", "dsp_fir_runs_kernel", "dsp_fir_f16_kernel",
                                                      "dsp_rows_kernel", "dsp_current_kernel", "dsp_reduce_kernel", "dsp_reduce_kernel",
-                                                     "dsp_vm_kernel<float>", "dsp_scalar_kernel"]
+                                                     "dsp_scalar_kernel", "dsp_vm_kernel<float>", "dsp_scalar_kernel"]  # (scalar head, program, scalar tail)
     seen.update({"tp_aoe_max": True, "A_max": True, "tp_aoe_samp": True})
     cusp_dev = g["wf_cusp"]
     assert all(seen.get(k) for k in recipes.ICPC["outputs"] if k not in ("tp_min", "tp_max", "wf_min", "wf_max", "bl_mean", "bl_slope",
@@ -410,7 +410,7 @@ def test_stage_buffers_are_bounded_and_pieces_give_the_same_results():
     wf = wf.astype(np.uint16)
     tb = {"waveform": WaveformInput(wf, 16.0, 48000.0), "baseline": bl}
     chain, _, out = build_processing_chain(recipes.ICPC, tb)
-    assert len(chain._stages) == 7
+    assert len(chain._stages) == 8
     chain.execute()
     ref = {k: np.array(v) for k, v in out.items()}
     per_row = sum(4 * (1 if ln is None else ln) for st in chain._stages for _o, _k, ln in st["outs"])

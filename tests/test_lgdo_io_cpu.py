@@ -106,7 +106,7 @@ def test_variable_index_into_a_variable_length_array_translates():
     rec = {"outputs": ["vals", "v_end"], "processors": {"vals": "vov_in(shape=50)[len(vov_in)//2]", "v_end": "vov_in(shape=50)[-1]",
                                                         "var_slice": "vov_in[indices:20]"}}
     chain, mask, out = build_processing_chain(rec, Table(vov_in=vov))
-    ops = chain.program.ops
+    ops = chain.program.ops + [o for st in chain._stages for o in st["program"].ops]  # (len(vov_in) // 2 needs no waveform: the scalar head's)
     picks = [o for o in ops if o[0] == _lib.OP_PICKOFF]
     assert len(picks) == 2 and all(o[4][1] == 2 for o in picks)  # get_default with a per-event index
     # len(vov_in) // 2: the lengths are uint32, so NumPy's 'II->I' loop (the float64 rows make this the float64 chain, which holds them)

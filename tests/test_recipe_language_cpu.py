@@ -20,6 +20,7 @@ def _programs_whole(monkeypatch):
     """these tests read the arithmetic between per-event values where the builder generated it: the all-scalar tail stays in the program
     (the test of the split itself takes the switch off again)"""
     monkeypatch.setenv("DSPEED_HIP_NO_SCALAR_TAIL", "1")
+    monkeypatch.setenv("DSPEED_HIP_NO_SCALAR_HEAD", "1")
 
 
 def _tb(n=4, wf_len=8192, t0=0.0, dtype=np.uint16):
@@ -391,6 +392,35 @@ def test_negative_steps_become_backward_copies():
     for expr in ("waveform[10:100:-1]", "waveform[::0]"):
         with pytest.raises(ProcessingChainError):
             build_processing_chain({"outputs": ["x"], "processors": {"x": expr}}, tb)
+
+
+def test_arithmetic_that_needs_nothing_of_the_program_runs_ahead_of_it(monkeypatch):
+    """the scalar head (_split_scalar_head): the pick-off times of the two energy trapezoids -- arithmetic on the t0 estimate that a stage left in
+    HBM -- leave the program, are computed with a row per lane as one more stage, and the program reads them as columns; what is left between
+    its waveform ops are the four thresholds of the rise-time walks, fractions of the trapezoid's maximum, which the planner folds into the
+    walks.  On the interpreter an op costs a row's wavefront ~ 1 700 cycles whatever it computes."""
+    monkeypatch.delenv("DSPEED_HIP_NO_SCALAR_TAIL")
+    monkeypatch.delenv("DSPEED_HIP_NO_SCALAR_HEAD")
+    chain, _, _ = build_processing_chain(recipes.ICPC, _tb())
+    P, head = chain.program, chain._stages[-1]
+    assert head["what"] == "per-event arithmetic ahead of the program" and len(chain._stages) == 8
+    assert [o[0] for o in head["program"].ops] == [_lib.OP_SCALAR_AFFINE, _lib.OP_STORE_SCALAR, _lib.OP_SCALAR_AFFINE, _lib.OP_SCALAR_AFFINE,
+                                                   _lib.OP_SCALAR_CONVERT, _lib.OP_STORE_SCALAR]
+    assert head["alias"] == {"in:tp_0_est": "in:tp_0_est"} and [k for _o, k, _l in head["outs"]] == ["in:head:r13.0", "in:head:r19.3"]
+    assert plan(head["program"])["kernel"] == "dsp_scalar_kernel"
+    _check_program_order(head["program"])
+    _check_program_order(P)
+    arithmetic = [o for o in P.ops if o[0] in (_lib.OP_SCALAR_AFFINE, _lib.OP_SCALAR_CONVERT, _lib.OP_SCALAR_FUNC, _lib.OP_SCALAR_DIV)]
+    assert len(arithmetic) == 4 and all(o[0] == _lib.OP_SCALAR_AFFINE and o[5][0].kind == _lib.ARG_REG for o in arithmetic)
+    picks = [o for o in P.ops if o[0] in (_lib.OP_TRAP_PICKOFF, _lib.OP_TRAP_REDUCE) and any(a.kind == _lib.ARG_INPUT for a in o[5])]
+    assert len(picks) == 2 and {P.io[a.index][0] for o in picks for a in o[5] if a.kind == _lib.ARG_INPUT} == {"in:head:r13.0", "in:head:r19.3"}
+    # the device program of the interpreter: thresholds folded into the walks, each team member's stores one op -- 26 ops of the recipe's program are 11
+    info = plan(P)
+    assert info["kernel"].startswith("dsp_vm_kernel") and info["team"] == 2 and info["n_device_ops"] == 11, info["n_device_ops"]
+    # a register that is reused along the program: only what an op reads at its place in the program counts
+    monkeypatch.setenv("DSPEED_HIP_NO_SCALAR_HEAD", "1")
+    whole, _, _ = build_processing_chain(recipes.ICPC, _tb())
+    assert len(whole.program.ops) == len(P.ops) + 4 and len(whole._stages) == 7
 
 
 def test_the_scalar_tail_of_a_program_becomes_a_program_of_its_own(monkeypatch):
