@@ -2327,6 +2327,26 @@ __global__ void __launch_bounds__(256 * TEAM, TEAM > 1 ? 1 : (FIR ? 2 : 3)) dsp_
                 t_prev = now;
                 prof_last = i;
             }
+            if constexpr (TEAM > 1) {
+                // a team's program holds nothing but these (dsp_plan.cpp: what makes a program eligible): the build is a fifth of the full
+                // interpreter's 280 kB -- the instruction cache (64 kB per two CUs) sees eight wavefronts of a CU in different ops
+                switch (op.opcode) {
+                    case DSP_OP_LOAD: op_load<T, TEAM>(cx, op, member); break;
+                    case DSP_OP_STORE_SCALAR: op_store_scalar(cx, op); break;
+                    case DSP_OP_INTERNAL_STORES: op_store_scalars(cx, op); break;
+                    case DSP_OP_PICKOFF: op_pickoff(cx, op); break;
+                    case DSP_OP_TRAP_PICKOFF: op_trap_pickoff(cx, op); break;
+                    case DSP_OP_TRAP_REDUCE: op_trap_reduce(cx, op); break;
+                    case DSP_OP_TIME_POINT_THRESH: op_time_point_thresh(cx, op); break;
+                    case DSP_OP_MIN_MAX: op_min_max(cx, op, false); break;
+                    case DSP_OP_AMAX: op_min_max(cx, op, true); break;
+                    case DSP_OP_SCALAR_AFFINE: op_scalar_affine(cx, op); break;
+                    case DSP_OP_SCALAR_DIV: op_scalar_div(cx, op); break;
+                    case DSP_OP_SCALAR_FUNC: op_scalar_func(cx, op); break;
+                    case DSP_OP_SCALAR_CONVERT: op_scalar_convert(cx, op); break;
+                    default: break;
+                }
+            } else
             switch (op.opcode) {
                 case DSP_OP_LOAD: op_load<T, TEAM>(cx, op, member); break;
                 case DSP_OP_STORE: op_store(cx, op); break;
