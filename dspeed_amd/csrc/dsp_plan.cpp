@@ -1542,7 +1542,7 @@ int dsp_plan_build(ChainPlan* ch, const dsp_op* ops, int n_ops, const dsp_io_des
     }
 
     P.team = 1;
-    for (int i = 0; i < P.n_ops; ++i) P.ops[i].member = 2;
+    for (int i = 0; i < P.n_ops; ++i) P.ops[i].member = DSP_MEMBER_ALL;
     {
         const char* env = getenv("DSPEED_HIP_NO_TEAMS");
         const bool vm_runs = !(ch->fused_ok || ch->rr_ok || ch->rows_ok || ch->fir_ok || ch->cur_ok || ch->red_ok || ch->pz_ok || ch->scalar_ok);
@@ -1615,16 +1615,35 @@ int dsp_plan_build(ChainPlan* ch, const dsp_op* ops, int n_ops, const dsp_io_des
             for (int i = first + 1; i < P.n_ops; ++i)
                 if (find(i) == i) roots.push_back(i);
             std::sort(roots.begin(), roots.end(), [&](int a, int b) { return w[a] > w[b]; });
-            int load[2] = {0, 0};
+            // groups dealt out to two or three members, heaviest first, each to the member with the least so far (three: when the third
+            // member still gets a real share -- the Ge recipe's program is a trapezoid with its five walks, a trapezoid with a pick-off and
+            // a pick-off of a third: the recurrences are latency-bound, a third wavefront on the image fills a SIMD's idle issue slots)
+            int load[3] = {0, 0, 0}, n_team = 2;
             std::vector<int> side(P.n_ops, 0);
-            for (int r : roots) {
-                const int m = load[0] <= load[1] ? 0 : 1;
-                side[r] = m;
-                load[m] += w[r];
+            auto deal = [&](int members) {
+                load[0] = load[1] = load[2] = 0;
+                for (int r : roots) {
+                    int m = 0;
+                    for (int k = 1; k < members; ++k)
+                        if (load[k] < load[m]) m = k;
+                    side[r] = m;
+                    load[m] += w[r];
+                }
+            };
+            const char* t3 = getenv("DSPEED_HIP_TEAM_MAX");  // (A/B runs: 2 keeps teams of two)
+            deal(3);
+            {
+                const int total = load[0] + load[1] + load[2];
+                int least = load[0] < load[1] ? load[0] : load[1];
+                least = load[2] < least ? load[2] : least;
+                if ((int)roots.size() >= 3 && 6 * least >= total && !(t3 && atoi(t3) < 3) && ch->waves_per_block * 3 <= 16)
+                    n_team = 3;
+                else
+                    deal(2);
             }
-            // worth a second wavefront only when it takes a real share of the work
-            if (ok && load[0] > 0 && load[1] > 0 && 5 * (load[0] < load[1] ? load[0] : load[1]) >= load[0] + load[1]) {
-                P.team = 2;
+            // worth more wavefronts only when each takes a real share of the work
+            if (ok && load[0] > 0 && load[1] > 0 && (n_team == 3 || 5 * (load[0] < load[1] ? load[0] : load[1]) >= load[0] + load[1])) {
+                P.team = n_team;
                 for (int i = first + 1; i < P.n_ops; ++i) P.ops[i].member = side[find(i)];
                 // a workgroup per team: the barrier at the end of a row then holds the two members of one row, not four rows' worth of
                 // wavefronts whose walks take different times (DSPEED_HIP_TEAM_WPB: the teams per workgroup, for the A/B)

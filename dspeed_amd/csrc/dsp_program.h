@@ -37,12 +37,13 @@ struct DevIO {
     int32_t pad_;
 };
 
+#define DSP_MEMBER_ALL 15
 struct DevOp {
     int32_t opcode, dst, src, io;
     int32_t ip[4];
     dsp_scalar_arg sp[4];
     int32_t ic[DSP_IC];
-    int32_t member;  // DevProgram.team == 2: which wavefront of a row's team runs the op (0, 1; 2 = both)
+    int32_t member;  // DevProgram.team > 1: which wavefront of a row's team runs the op (0 .. team - 1; DSP_MEMBER_ALL: every member)
     int32_t prio;    // the wave priority the interpreter runs the op at: 0 .. 3 over the op list (the planner's division, not one per op and row)
     double fc[DSP_FC];
 };
@@ -53,9 +54,9 @@ struct DevProgram {
     int32_t sreg_off;           // element offset of the scalar register file
     int32_t waves_per_block;
     int32_t scratch_off;        // element offset of DSP_SCRATCH_ELEMS elements any op may use while it runs (16-byte aligned)
-    // 2: a TEAM of two wavefronts per row -- a program that loads one waveform and then only reads it (reductions, walks, pick-offs of long
-    // waveforms, whose image leaves LDS for one wavefront per SIMD) splits into two groups of ops that share no register; each member runs
-    // its group on the shared image (DevOp.member).  1: a wavefront per row
+    // 2, 3: a TEAM of wavefronts per row -- a program that loads one waveform and then only reads it (reductions, walks, pick-offs of long
+    // waveforms, whose image leaves LDS for one wavefront per SIMD) splits into groups of ops that share no register; each member runs
+    // its groups on the shared image (DevOp.member).  1: a wavefront per row
     int32_t team;
     int32_t pad_;
     // per-op cycle counters (dsp_chain_profile): n_ops + 1 device words, the last counts the waveforms sampled; null = off

@@ -201,7 +201,9 @@ __device__ __forceinline__ void op_load(Ctx<T>& cx, const DSP_PROG DevOp& op, in
         auto* sc = cx.lds + cx.prog->scratch_off;
         if (lane_id() == 0) sc[member] = any_nan ? (T)1 : (T)0;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        any_nan = (sc[0] != (T)0) || (sc[1] != (T)0);
+        any_nan = false;
+#pragma unroll
+        for (int m = 0; m < TEAM; ++m) any_nan |= sc[m] != (T)0;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (sub)  // bl_subtract.py:41-44: a NaN anywhere (or a NaN baseline, which made every sample NaN) is a NaN waveform
@@ -2310,7 +2312,7 @@ __global__ void __launch_bounds__(256 * TEAM, TEAM > 1 ? 1 : (FIR ? 2 : 3)) dsp_
             const DSP_PROG DevOp& op = cx.prog->ops[i];
             if (TEAM > 1) {
                 const int m = op.member;  // (uniform)
-                if (m != 2 && m != member) continue;
+                if (m != DSP_MEMBER_ALL && m != member) continue;
             }
             {
                 const int lvl = op.prio;
@@ -2472,7 +2474,9 @@ __global__ void __launch_bounds__(256) dsp_stream_read_kernel(const uint4* src, 
 // ------------------------------------------------------------------------------------------------
 extern "C" int dsp_internal_launch_vm_f32(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int* err, int blocks,
                                           int threads, int lds_bytes, int with_fir, int team, hipStream_t stream) {
-    if (team == 2)
+    if (team == 3)
+        hipLaunchKernelGGL((dsp_vm_kernel<float, false, 3>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
+    else if (team == 2)
         hipLaunchKernelGGL((dsp_vm_kernel<float, false, 2>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
     else if (with_fir)
         hipLaunchKernelGGL((dsp_vm_kernel<float, true, 1>), dim3(blocks), dim3(threads), lds_bytes, stream, dev_prog, *ptrs, n_wf, err);
@@ -2491,10 +2495,10 @@ extern "C" int dsp_internal_launch_vm_f64(const DevProgram* dev_prog, const IoPt
 }
 
 extern "C" int dsp_internal_set_vm_lds(int lds_bytes) {
-    const void* k[5] = {reinterpret_cast<const void*>(&dsp_vm_kernel<float, true, 1>), reinterpret_cast<const void*>(&dsp_vm_kernel<float, false, 1>),
+    const void* k[6] = {reinterpret_cast<const void*>(&dsp_vm_kernel<float, true, 1>), reinterpret_cast<const void*>(&dsp_vm_kernel<float, false, 1>),
                         reinterpret_cast<const void*>(&dsp_vm_kernel<double, true, 1>), reinterpret_cast<const void*>(&dsp_vm_kernel<double, false, 1>),
-                        reinterpret_cast<const void*>(&dsp_vm_kernel<float, false, 2>)};
-    for (int i = 0; i < 5; ++i) {
+                        reinterpret_cast<const void*>(&dsp_vm_kernel<float, false, 2>), reinterpret_cast<const void*>(&dsp_vm_kernel<float, false, 3>)};
+    for (int i = 0; i < 6; ++i) {
         const int rc = (int)hipFuncSetAttribute(k[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (rc != 0) return rc;
     }

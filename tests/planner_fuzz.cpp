@@ -653,8 +653,8 @@ bool check(const Prog& p, const ChainPlan& c) {
             if (p.io[k].kind == DSP_IO_SCALAR_OUT || p.io[k].kind == DSP_IO_WF_OUT) REQUIRE(p.io[k].dtype == p.dtype || p.io[k].dtype == DSP_BOOL, "output %zu of type %d in a chain of type %d", k, p.io[k].dtype, p.dtype);
     }
     REQUIRE(P.n_ops >= 1 && P.n_ops <= DSP_MAX_OPS + DSP_MAX_SLOTS, "device ops %d", P.n_ops);
-    REQUIRE(P.team == 1 || P.team == 2, "team %d", P.team);
-    for (int i = 0; i < P.n_ops; ++i) REQUIRE(P.ops[i].member >= 0 && P.ops[i].member <= 2, "op %d member %d", i, P.ops[i].member);
+    REQUIRE(P.team >= 1 && P.team <= 3, "team %d", P.team);
+    for (int i = 0; i < P.n_ops; ++i) REQUIRE((P.ops[i].member >= 0 && P.ops[i].member < P.team) || P.ops[i].member == DSP_MEMBER_ALL, "op %d member %d", i, P.ops[i].member);
     REQUIRE(c.waves_per_block >= 1 && c.waves_per_block <= 4 && P.waves_per_block == c.waves_per_block, "waves per block %d", c.waves_per_block);
     auto io_ok = [&](int k, int kind) { return k >= 0 && k < (int)p.io.size() && p.io[k].kind == kind; };
     if (c.rr_ok || c.fused_ok) {
@@ -779,7 +779,7 @@ int main(int argc, char** argv) {
         ++accepted;
         ++by_kind[kind <= 7 ? kind : 8];
         n_integer += plan->i64 ? 1 : 0;
-        kernels[plan->scalar_ok ? 0 : plan->pz_ok ? 1 : plan->red_ok ? 2 : plan->runs_ok ? 10 : plan->cur_ok ? 3 : plan->fir_ok ? 4 : plan->rows_ok ? 5 : plan->rr_ok ? 6 : plan->fused_ok ? 7 : plan->host.team == 2 ? 8 : 9]++;
+        kernels[plan->scalar_ok ? 0 : plan->pz_ok ? 1 : plan->red_ok ? 2 : plan->runs_ok ? 10 : plan->cur_ok ? 3 : plan->fir_ok ? 4 : plan->rows_ok ? 5 : plan->rr_ok ? 6 : plan->fused_ok ? 7 : plan->host.team >= 2 ? 8 : 9]++;
         if (!check(p, *plan)) {
             fprintf(stderr, "program %ld (seed %llu, kind %d, kernel %s)\n", it, seed, kind, dsp_plan_kernel_name(plan.get()));
             dump(p);

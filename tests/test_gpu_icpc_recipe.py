@@ -505,9 +505,11 @@ def test_stages_on_side_streams_give_the_same_results():
             assert np.array_equal(out2[k], ref[k], equal_nan=True), k
 
 
-def test_two_wavefronts_per_row_give_the_same_results(monkeypatch):
-    """the recipe's program loads the pole-zero rows and then only reads them: its ops fall into two groups that share no register, and a team of
-    two wavefronts per row runs them on the one LDS image (dsp_chain_create, DevProgram.team); DSPEED_HIP_NO_TEAMS=1 keeps a wavefront per row"""
+def test_a_team_of_wavefronts_per_row_gives_the_same_results(monkeypatch):
+    """the recipe's program loads the pole-zero rows and then only reads them: its ops fall into three groups that share no register (a trapezoid
+    with its five walks, a trapezoid with a pick-off, a pick-off of a third), and a team of three wavefronts per row runs them on the one LDS image,
+    each loading a third of the row (dsp_chain_create, DevProgram.team); DSPEED_HIP_TEAM_MAX=2 makes it a team of two, DSPEED_HIP_NO_TEAMS=1 keeps
+    a wavefront per row"""
     from dspeed_amd.processing_chain import WaveformInput, build_processing_chain
 
     rng = np.random.default_rng(23)
@@ -517,14 +519,21 @@ def test_two_wavefronts_per_row_give_the_same_results(monkeypatch):
     chain, _, out = build_processing_chain(recipes.ICPC, tb)
     chain.execute()
     g = chain._chain.geometry(n)
-    assert chain._chain.kernel_name.startswith("dsp_vm") and g["waves_per_block"] == 2, g   # (a workgroup per team)
+    assert chain._chain.kernel_name.startswith("dsp_vm") and g["waves_per_block"] == 3, g   # (a workgroup per team)
     monkeypatch.setenv("DSPEED_HIP_TEAM_WPB", "4")  # four teams to a workgroup: the last one has idle row slots that still meet its barriers
     four, _, out4 = build_processing_chain(recipes.ICPC, tb)
     four.execute()
-    assert four._chain.geometry(n)["waves_per_block"] == 8
+    assert four._chain.geometry(n)["waves_per_block"] == 12
     for k in out4:
         assert np.array_equal(np.asarray(out[k]), np.asarray(out4[k]), equal_nan=True), k
     monkeypatch.delenv("DSPEED_HIP_TEAM_WPB")
+    monkeypatch.setenv("DSPEED_HIP_TEAM_MAX", "2")
+    two, _, out2 = build_processing_chain(recipes.ICPC, tb)
+    two.execute()
+    assert two._chain.geometry(n)["waves_per_block"] == 2
+    for k in out2:
+        assert np.array_equal(np.asarray(out[k]), np.asarray(out2[k]), equal_nan=True), k
+    monkeypatch.delenv("DSPEED_HIP_TEAM_MAX")
     monkeypatch.setenv("DSPEED_HIP_NO_TEAMS", "1")
     single, _, ref = build_processing_chain(recipes.ICPC, tb)
     single.execute()
