@@ -1491,7 +1491,7 @@ int dsp_plan_build(ChainPlan* ch, const dsp_op* ops, int n_ops, const dsp_io_des
     // 0.1 of the trapezoid's maximum) costs the interpreter an op of its own -- ~ 1 700 cycles of a row's lone wavefront, whatever the op
     // computes -- for one multiplication.  SCALAR_AFFINE d <- x * const + 0 whose result only TIME_POINT_THRESH ops read as their threshold
     // is folded into them: they multiply (the same float multiplication: x * b + (+-0) is x * b) and the op becomes a no-op.
-    {
+    if (const char* nf = getenv("DSPEED_HIP_NO_THRESHOLD_FOLD"); !(nf && nf[0] == '1')) {  // (A/B runs and the bit-identity test)
         auto writes_reg = [&](const DevOp& o, int r) {
             switch (o.opcode) {
                 case DSP_OP_MIN_MAX: return r >= o.dst && r < o.dst + 4;

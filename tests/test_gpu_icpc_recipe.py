@@ -505,6 +505,31 @@ def test_stages_on_side_streams_give_the_same_results():
             assert np.array_equal(out2[k], ref[k], equal_nan=True), k
 
 
+def test_programs_that_shed_ops_give_the_same_bits(monkeypatch):
+    """the scalar head (arithmetic that needs nothing of the program, run ahead of it with a row per lane) and the thresholds folded into the walks
+    (`time_point_thresh(wf, 0.9 * trapTmax, ...)`: the planner drops the multiplication's op and the walk multiplies) change where an operation
+    runs, not the operation: every output bit-identical with either switched off"""
+    from dspeed_amd.processing_chain import WaveformInput, build_processing_chain
+
+    rng = np.random.default_rng(29)
+    n = 600
+    wf, bl = _synth(rng, n)
+    tb = {"waveform": WaveformInput(wf.astype(np.uint16), 16.0, 48000.0), "baseline": bl}
+    chain, _, out = build_processing_chain(recipes.ICPC_REF, tb)
+    chain.execute()
+    assert "per-event arithmetic ahead of the program" in [st["what"] for st in chain._stages]
+    ref = {k: np.array(v) for k, v in out.items()}
+    for switch in ("DSPEED_HIP_NO_SCALAR_HEAD", "DSPEED_HIP_NO_THRESHOLD_FOLD", "DSPEED_HIP_NO_SCALAR_TAIL"):
+        monkeypatch.setenv(switch, "1")
+        other, _, out2 = build_processing_chain(recipes.ICPC_REF, tb)
+        other.execute()
+        monkeypatch.delenv(switch)
+        if switch == "DSPEED_HIP_NO_SCALAR_HEAD":
+            assert "per-event arithmetic ahead of the program" not in [st["what"] for st in other._stages]
+        for k in ref:
+            assert np.array_equal(np.asarray(out2[k]), ref[k], equal_nan=True), (switch, k)
+
+
 def test_a_team_of_wavefronts_per_row_gives_the_same_results(monkeypatch):
     """the recipe's program loads the pole-zero rows and then only reads them: its ops fall into three groups that share no register (a trapezoid
     with its five walks, a trapezoid with a pick-off, a pick-off of a third), and a team of three wavefronts per row runs them on the one LDS image,
