@@ -454,7 +454,19 @@ def _extract_stages(b: _Builder, steps, out_pars, n_rows, ft):
                 anc = ancestors(base)
                 if not anc or any(a[0] in ("convolve_wf", "fft_convolve_wf") for a in anc):
                     continue
-                build(anc, [base], f"{base.name} -> HBM")
+                # min_max of the raw rows goes along: the pole-zero rows kernel streams them anyway (dsp_pz.hip), a launch of the
+                # reductions kernel would read them once more
+                extra, made = [], []
+                raw = base_of(anc[0][1][0]) if anc and anc[0][0] in ("bl_subtract", "pole_zero") else None
+                if (ft == np.dtype(np.float32) and isinstance(raw, Var) and row_input(raw) and [a[0] for a in anc] in (["bl_subtract", "pole_zero"], ["pole_zero"])
+                        and os.environ.get("DSPEED_HIP_NO_ROW_REDUCTIONS") != "1"):
+                    mm = [g for g in rows_steps(raw) if g[0] == "min_max" and g[1][0] is raw]
+                    if len(mm) == 1:
+                        extra, made = mm, [o for o in mm[0][1][1:5]]
+                build(extra + anc, made + [base], f"{base.name} -> HBM" + (f" + min_max of {raw.name}" if extra else ""))
+                for o in made:
+                    o.kind = "scalar"
+                steps = [x for x in steps if not any(x is g for g in extra)]
         # --- the filter itself; numpy.amax goes along when it is the only reader
         users = [x for x in steps if x is not st and any(base_of(a) is out for a, r in zip(x[1], _roles(x[0])) if r not in "WS")]
         if (len(users) == 1 and users[0][0] == "amax" and users[0][1][0] is out and out.name not in out_names and isinstance(users[0][1][2], Var)

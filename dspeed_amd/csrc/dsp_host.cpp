@@ -564,6 +564,7 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         A.bl = (const float*)at(ch->pio_bl);
         A.out = at(ch->pio_out);
         A.tau = (const float*)at(ch->pio_tau);
+        for (int k = 0; k < 4; ++k) A.mm_out[k] = at(ch->pio_mm[k]);
         A.row_scale = nullptr;
         A.row_flags = nullptr;
         if (dsp_chain* sink = ch->scale_sink) {

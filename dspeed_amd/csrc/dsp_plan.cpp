@@ -99,10 +99,11 @@ static bool fn_code_ok(int ip0, bool f64, bool i64 = false) {
     return (ip0 >> 8) == 0;
 }
 
-// Is the program  LOAD s; [BL_SUBTRACT s <- s;]  POLE_ZERO s <- s (a constant time constant);  STORE s  on 16-byte aligned rows (dsp_pz.hip)?
+// Is the program  LOAD s; [MIN_MAX of s;] [BL_SUBTRACT s <- s;]  POLE_ZERO s <- s;  STORE s  [+ STORE_SCALARs of MIN_MAX's values]  on 16-byte aligned rows
+// (dsp_pz.hip)?  The MIN_MAX is that of the rows as they are read: every Ge recipe asks for tp_min / tp_max / wf_min / wf_max of the raw waveform.
 static bool match_pz_rows_shape(ChainPlan* ch, const dsp_op* ops, int n_ops, const dsp_io_desc* io, const int32_t* slot_len, int n_slots,
                                 const std::vector<int>& dev_index, bool f64) {
-    if (f64 || n_slots != 1 || n_ops < 3 || n_ops > 4 || ops[0].opcode != DSP_OP_LOAD) return false;
+    if (f64 || n_slots != 1 || n_ops < 3 || n_ops > 9 || ops[0].opcode != DSP_OP_LOAD) return false;
     const dsp_op& ld = ops[0];
     const dsp_io_desc& w = io[ld.io];
     const int len = slot_len[ld.dst];
@@ -113,7 +114,31 @@ static bool match_pz_rows_shape(ChainPlan* ch, const dsp_op* ops, int n_ops, con
     PzArgs& A = ch->pz;
     memset(&A, 0, sizeof A);
     ch->pio_bl = -1;
-    int i = 1;
+    for (int k = 0; k < 4; ++k) ch->pio_mm[k] = -1;
+    int i = 1, mm_reg = -1;
+    if (ops[i].opcode == DSP_OP_MIN_MAX) {  // min_max of the rows as they are read: the kernel streams them anyway
+        if (ops[i].src != ld.dst) return false;
+        mm_reg = ops[i++].dst;
+        A.mm_on = 1;
+    }
+    // the stores of its four values, wherever they stand behind it
+    std::vector<dsp_op> rest(ops, ops + i);
+    int pz_at = -1;  // (the pole-zero op's place in the caller's program: its device op holds the constants)
+    for (int k = i; k < n_ops; ++k) {
+        const dsp_op& o = ops[k];
+        if (o.opcode == DSP_OP_POLE_ZERO && pz_at < 0) pz_at = k;
+        if (o.opcode != DSP_OP_STORE_SCALAR) {
+            rest.push_back(o);
+            continue;
+        }
+        const int which = o.ip[0] - mm_reg;
+        if (mm_reg < 0 || which < 0 || which > 3 || ch->pio_mm[which] >= 0 || io[o.io].dtype != DSP_F32) return false;
+        ch->pio_mm[which] = o.io;
+        A.mm_stride[which] = io[o.io].row_stride;
+    }
+    if (pz_at < 0 || (int)rest.size() < i + 2) return false;
+    ops = rest.data();  // (the program without those stores)
+    n_ops = (int)rest.size();
     if (ops[i].opcode == DSP_OP_BL_SUBTRACT) {
         const dsp_op& bs = ops[i++];
         if (bs.dst != ld.dst || bs.src != ld.dst || bs.ip[0] != 0) return false;
@@ -135,7 +160,7 @@ static bool match_pz_rows_shape(ChainPlan* ch, const dsp_op* ops, int n_ops, con
     if (tau_col) A.tau_stride = io[ch->pio_tau].row_stride;
     const dsp_io_desc& o = io[st.io];
     if (o.dtype != DSP_F32 || o.len != len || o.row_stride % 4 != 0 || o.offset % 4 != 0) return false;
-    const DevOp& dpz = ch->host.ops[dev_index[i]];
+    const DevOp& dpz = ch->host.ops[dev_index[pz_at]];
     A.c = dpz.fc[0];
     A.tau_nan = dpz.ic[0];
     A.wf_stride = w.row_stride;

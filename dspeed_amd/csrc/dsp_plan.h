@@ -126,7 +126,7 @@ struct ChainPlan {
     // pole-zero rows written back as rows (dsp_pz.hip)
     bool pz_ok = false;
     PzArgs pz{};
-    int pio_wf = -1, pio_bl = -1, pio_out = -1, pio_tau = -1;
+    int pio_wf = -1, pio_bl = -1, pio_out = -1, pio_tau = -1, pio_mm[4] = {-1, -1, -1, -1};
     // streaming reductions of rows (dsp_reduce.hip)
     bool red_ok = false;
     ReduceArgs red{};

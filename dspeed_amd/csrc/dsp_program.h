@@ -171,6 +171,9 @@ struct PzArgs {
     int64_t tau_stride;
     float* row_scale;        // or null: what dsp_fir_f16_rows_kernel would find on the rows written here (FirF16Taps), for a float16 FIR behind
     uint32_t* row_flags;
+    void* mm_out[4];         // or null each: min_max (min_max.py:11-82) of the rows as they are READ (t_min, t_max, a_min, a_max; float32 columns)
+    int64_t mm_stride[4];
+    int32_t mm_on, pad_;
 };
 
 // arguments of the streaming reductions (dsp_reduce.hip), filled by dsp_chain_execute when a program has the shape

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dsp_program.h"
+#include "dsp_reduce_tail.h"
 #include "dsp_wave.h"
 
 #define PZ_GLOBAL __attribute__((address_space(1)))
@@ -70,6 +71,14 @@ __global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_w
 
     double carry = 0.0;  // S at the end of the previous group
     bool in_nan = false, out_nan = false;
+    // min_max of the rows as they are read (A.mm_on: every Ge recipe asks for it of the raw waveform; a kernel of its own read the rows once
+    // more): first-occurrence extremes per lane, in index order, one exchange across the wavefront at the end
+    const bool mm_on = A.mm_on != 0;
+    Extremes e;
+    e.vmin = __builtin_inff();
+    e.vmax = -__builtin_inff();
+    e.imin = e.imax = 0;
+    e.nan = false;
     float mx = 0.0f;  // largest |sample written| (a NaN never raises it): the scale of a float16 FIR behind (A.row_scale)
     auto group = [&](const u4 (&raw)[NV], int g) {
         const int at = g * 512 + lane * 8;
@@ -87,6 +96,24 @@ __global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_w
                 const unsigned r = raw[0][u];
                 x[2 * u] = IN == 1 ? (float)(short)(r & 0xffffu) : (float)(r & 0xffffu);
                 x[2 * u + 1] = IN == 1 ? (float)(short)(r >> 16) : (float)(r >> 16);
+            }
+        }
+        if (mm_on && live) {  // (uniform flag; most groups change no lane's extremes: the largest and smallest of the eight first)
+            const float hi8 = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
+            const float lo8 = fminf(fminf(fminf(x[0], x[1]), fminf(x[2], x[3])), fminf(fminf(x[4], x[5]), fminf(x[6], x[7])));
+            if (hi8 > e.vmax || lo8 < e.vmin) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool lt = x[u] < e.vmin, gt = x[u] > e.vmax;
+                    e.vmin = lt ? x[u] : e.vmin;
+                    e.imin = lt ? at + u : e.imin;
+                    e.vmax = gt ? x[u] : e.vmax;
+                    e.imax = gt ? at + u : e.imax;
+                }
+            }
+            if (IN == 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e.nan |= x[u] != x[u];  // (fmaxf / fminf skip a NaN: looked for by itself)
             }
         }
         double p[8];
@@ -141,6 +168,27 @@ __global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_w
         if (!bad_in && lane == 0) pz_report(err, DSP_E_PZ_NAN, row);
         const f4 nanv = {quiet_nan<float>(), quiet_nan<float>(), quiet_nan<float>(), quiet_nan<float>()};
         for (int at = lane * 4; at < n; at += 256) *(PZ_GLOBAL f4*)(outp + at) = nanv;
+    }
+    if (mm_on) {  // min_max.py:62-77: four NaNs for a row with a NaN, else the first occurrence of each extreme
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const float ovmin = __shfl_xor(e.vmin, sft), ovmax = __shfl_xor(e.vmax, sft);
+            const int oimin = __shfl_xor(e.imin, sft), oimax = __shfl_xor(e.imax, sft);
+            const bool tmin = ovmin < e.vmin || (ovmin == e.vmin && oimin < e.imin);
+            const bool tmax = ovmax > e.vmax || (ovmax == e.vmax && oimax < e.imax);
+            e.vmin = tmin ? ovmin : e.vmin;
+            e.imin = tmin ? oimin : e.imin;
+            e.vmax = tmax ? ovmax : e.vmax;
+            e.imax = tmax ? oimax : e.imax;
+        }
+        const bool any = wave_any(e.nan);
+        if (lane == 0) {
+            const float nanv = quiet_nan<float>();
+            const float v[4] = {any ? nanv : (float)e.imin, any ? nanv : (float)e.imax, any ? nanv : e.vmin, any ? nanv : e.vmax};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (A.mm_out[k]) ((PZ_GLOBAL float*)A.mm_out[k])[row * A.mm_stride[k]] = v[k];
+        }
     }
     if (A.row_scale) {  // (uniform) exactly what dsp_fir_f16_rows_kernel leaves for these rows: same samples, same rule
 #pragma unroll

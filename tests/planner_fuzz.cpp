@@ -436,6 +436,12 @@ Prog pz_shape() {
     dsp_op ld = op0(DSP_OP_LOAD);
     ld.dst = s, ld.io = add_io(p, DSP_IO_WF_IN, pick({DSP_F32, DSP_I16, DSP_U16}), len, off, stride);
     p.ops.push_back(ld);
+    int mm = -1;
+    if (chance(0.4)) {  // min_max of the rows as they are read
+        dsp_op m = op0(DSP_OP_MIN_MAX);
+        m.src = s, m.dst = mm = new_sregs(p, 4);
+        p.ops.push_back(m);
+    }
     if (chance(0.6)) {
         dsp_op b = op0(DSP_OP_BL_SUBTRACT);
         b.dst = b.src = s, b.sp[0] = shape_arg(p);
@@ -444,10 +450,21 @@ Prog pz_shape() {
     dsp_op pz = op0(DSP_OP_POLE_ZERO);
     pz.dst = pz.src = s, pz.sp[0] = chance(0.7) ? cst(pick({1716.28, 1716.28, 0.0, (double)NAN})) : shape_arg(p);
     p.ops.push_back(pz);
+    const bool stores_first = chance(0.5);
+    auto stores = [&]() {
+        for (int k = 0; mm >= 0 && k < 4; ++k)
+            if (chance(0.85)) {
+                dsp_op sc = op0(DSP_OP_STORE_SCALAR);
+                sc.io = f32_out(p), sc.ip[0] = mm + k;
+                p.ops.push_back(sc);
+            }
+    };
+    if (stores_first) stores();
     dsp_op st = op0(DSP_OP_STORE);
     const int ooff = pick({0, 0, 4, 1});
     st.src = s, st.io = add_io(p, DSP_IO_WF_OUT, DSP_F32, len, ooff, ooff + len + pick({0, 4}));
     p.ops.push_back(st);
+    if (!stores_first) stores();
     return p;
 }
 
@@ -692,6 +709,8 @@ bool check(const Prog& p, const ChainPlan& c) {
         REQUIRE(c.pz.wf_offset == p.io[c.pio_wf].offset && c.pz.wf_stride == p.io[c.pio_wf].row_stride && c.pz.len == p.io[c.pio_wf].len && c.pz.out_stride == p.io[c.pio_out].row_stride,
                 "pole-zero rows: the bindings' offset / stride / length");
         REQUIRE(c.pz.len % 8 == 0, "pole-zero rows: length %d", c.pz.len);
+        for (int k = 0; k < 4; ++k)
+            if (c.pio_mm[k] >= 0) REQUIRE(c.pz.mm_on && io_ok(c.pio_mm[k], DSP_IO_SCALAR_OUT) && c.pz.mm_stride[k] == p.io[c.pio_mm[k]].row_stride, "pole-zero rows: min_max output %d", k);
     }
     if (c.red_ok) {
         REQUIRE(io_ok(c.dio_wf, DSP_IO_WF_IN), "reduce kernel: row binding");

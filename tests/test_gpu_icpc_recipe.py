@@ -267,7 +267,7 @@ def test_index_outputs_are_bit_exact_on_the_devices_own_waveforms():
     assert "dsp_current_kernel" in [st["chain"].kernel_name for st in chain_p._stages]
     # (the t0 filter -- piecewise constant -- with min_max and tp_0_est's walk on the run-length FIR kernel: wf_t0_filter is not stored)
     assert [k for _what, k in chain_p.kernels()] == ["dsp_fit_rows_kernel", "dsp_pz_rows_kernel", "dsp_fir_runs_kernel", "dsp_fir_f16_kernel",
-                                                     "dsp_rows_kernel", "dsp_current_kernel", "dsp_reduce_kernel", "dsp_reduce_kernel",
+                                                     "dsp_rows_kernel", "dsp_current_kernel", "dsp_reduce_kernel",
                                                      "dsp_scalar_kernel", "dsp_vm_kernel<float>", "dsp_scalar_kernel"]  # (scalar head, program, scalar tail)
     seen.update({"tp_aoe_max": True, "A_max": True, "tp_aoe_samp": True})
     cusp_dev = g["wf_cusp"]
@@ -410,7 +410,7 @@ def test_stage_buffers_are_bounded_and_pieces_give_the_same_results():
     wf = wf.astype(np.uint16)
     tb = {"waveform": WaveformInput(wf, 16.0, 48000.0), "baseline": bl}
     chain, _, out = build_processing_chain(recipes.ICPC, tb)
-    assert len(chain._stages) == 8
+    assert len(chain._stages) == 7
     chain.execute()
     ref = {k: np.array(v) for k, v in out.items()}
     per_row = sum(4 * (1 if ln is None else ln) for st in chain._stages for _o, _k, ln in st["outs"])
@@ -494,7 +494,7 @@ def test_stages_on_side_streams_give_the_same_results():
     plan = chain2._stage_plan()
     assert plan["n_side"] >= 2 and all(i < j for j, d in enumerate(plan["deps"]) for i in d)
     what = [st["what"] for st in chain2._stages]
-    pzs, t0f = what.index("wf_pz -> HBM"), what.index("convolve_wf wf_t0_filter on prefix sums + per-event values of wf_t0_filter")
+    pzs, t0f = what.index("wf_pz -> HBM + min_max of waveform"), what.index("convolve_wf wf_t0_filter on prefix sums + per-event values of wf_t0_filter")
     assert pzs in plan["deps"][t0f] and t0f in plan["deps"][what.index("asym_trap_filter wf_atrap on rows")]
     assert plan["stream_of"][what.index("fft_convolve_wf wf_cusp")] != plan["stream_of"][t0f]
     for _ in range(3):  # (a lane's buffers are reused by its next pass: the side streams wait for the pass before)

@@ -56,6 +56,43 @@ def test_pole_zero_rows(dtype, L, use_bl):
     assert np.mean(out["wf_pz"] == vm["wf_pz"]) > 0.98
 
 
+@pytest.mark.parametrize("dtype,L,use_bl", [(np.uint16, 8192, True), (np.int16, 4096, True), (np.float32, 8192, True), (np.float32, 520, False)])
+def test_min_max_of_the_raw_rows_goes_along(dtype, L, use_bl):
+    """every Ge recipe asks for tp_min / tp_max / wf_min / wf_max of the raw waveform (min_max.py:11-82): the kernel that writes the pole-zero
+    rows streams the raw rows anyway and keeps their first-occurrence extremes -- comparisons only: the oracle's values bit for bit (ties,
+    constant rows, a NaN -> four NaNs, infinities, -0.0), and the interpreter's on the same program"""
+    rng = np.random.default_rng(L + 7)
+    n = 333
+    wf = _rows(rng, n, L, dtype)
+    wf[1, :] = wf[1, 0]                                   # a constant row: both extremes at sample 0
+    wf[2, [L // 3, L - 1]] = wf[2].max()                  # the maximum twice: the first one counts
+    wf[3, [0, L // 2]] = wf[3].min()
+    wf[4, 9:] = wf[4, 9]                                  # an extreme inside one lane's eight samples, then nothing new
+    if np.dtype(dtype) == np.float32:
+        wf[5, L // 2] = np.nan                            # -> four NaNs (and a NaN waveform)
+        if L % 1024 == 0:
+            wf[6, L - 1] = np.inf                         # (the last sample: the recurrence ends on an infinity, not on inf - inf)
+        wf[8, :] = 0.0
+        wf[8, L // 4] = -0.0                              # -0.0 < 0.0 is false: sample 0 stays the minimum
+    bl = rng.uniform(800, 3000, n).astype(np.float32)
+    procs = {"wf_bl": f"{M}.bl_subtract(waveform, baseline, wf_bl)", "wf_pz": f"{M}.pole_zero(wf_bl, 1716.28, wf_pz)"} if use_bl else \
+        {"wf_pz": f"{M}.pole_zero(waveform, 1716.28, wf_pz)"}
+    procs["t_lo, t_hi, v_lo, v_hi"] = f"{M}.min_max(waveform, t_lo, t_hi, v_lo, v_hi)"
+    rec = {"outputs": ["wf_pz", "t_lo", "t_hi", "v_lo", "v_hi"], "processors": procs}
+    tb = {"waveform": wf, "baseline": bl}
+    chain, out = _run(rec, tb, True)
+    assert [k for _w, k in chain.kernels()] == ["dsp_pz_rows_kernel"]  # (the whole program: one launch)
+    want = oracle.min_max(np.ascontiguousarray(wf, dtype=np.float32))
+    for k, w in zip(("t_lo", "t_hi", "v_lo", "v_hi"), want[:4]):
+        np.testing.assert_array_equal(out[k], w, err_msg=k)
+    _, vm = _run(rec, tb, False)
+    for k in ("t_lo", "t_hi", "v_lo", "v_hi"):
+        np.testing.assert_array_equal(out[k], vm[k], err_msg=k)
+    ok = ~np.isnan(vm["wf_pz"]).any(axis=1) & np.isfinite(vm["wf_pz"]).all(axis=1)
+    ulp = np.spacing(np.abs(vm["wf_pz"][ok]).astype(np.float32))
+    assert np.max(np.abs(out["wf_pz"][ok] - vm["wf_pz"][ok]) / np.maximum(ulp, np.float32(1e-30))) <= 2
+
+
 def test_nan_rule_and_dspfatal():
     from dspeed_amd.errors import DSPFatal
 

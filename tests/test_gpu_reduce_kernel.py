@@ -145,10 +145,11 @@ def test_ge_recipe_reads_them_off_the_rows(monkeypatch):
     chain, _, out = build_processing_chain(recipes.ICPC, tb)
     chain.execute()
     ks = dict(chain.kernels())
-    assert ks["per-event values of waveform off its rows"] == "dsp_reduce_kernel" and ks["per-event values of wf_cusp off its rows"] == "dsp_reduce_kernel"
+    # (min_max of the raw waveform goes along with the kernel that writes the pole-zero rows: it streams the raw rows anyway)
+    assert ks["wf_pz -> HBM + min_max of waveform"] == "dsp_pz_rows_kernel" and ks["per-event values of wf_cusp off its rows"] == "dsp_reduce_kernel"
     monkeypatch.setenv("DSPEED_HIP_NO_ROW_REDUCTIONS", "1")
     whole, _, ref = build_processing_chain(recipes.ICPC, tb)
-    assert not any("off its rows" in w for w, _k in whole.kernels())
+    assert not any("off its rows" in w or "min_max of" in w for w, _k in whole.kernels())
     whole.execute()
     for k in ref:
         assert np.array_equal(np.asarray(out[k]), np.asarray(ref[k]), equal_nan=True), k

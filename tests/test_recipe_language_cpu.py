@@ -98,7 +98,8 @@ def test_long_filters_of_the_ge_recipe_run_ahead_of_the_program():
     opcodes = [o[0] for o in P.ops]
     assert _lib.OP_CONVOLVE not in opcodes and _lib.OP_CONVOLVE_AMAX not in opcodes and _lib.OP_POLE_ZERO not in opcodes
     what = [[o[0] for o in st["program"].ops] for st in chain._stages]
-    assert what == [[_lib.OP_LOAD, _lib.OP_BL_SUBTRACT, _lib.OP_POLE_ZERO, _lib.OP_STORE],
+    # (min_max of the raw waveform goes along with the pole-zero rows: the kernel that writes them streams the raw rows anyway)
+    assert what == [[_lib.OP_LOAD, _lib.OP_MIN_MAX, _lib.OP_BL_SUBTRACT, _lib.OP_POLE_ZERO] + [_lib.OP_STORE_SCALAR] * 4 + [_lib.OP_STORE],
                     # the t0 filter is piecewise constant (a ramp of 8 taps, a plateau of 125): the run-length FIR kernel (dsp_fir_runs.hip),
                     # and with it what the recipe reads off the filtered waveform -- min_max, and tp_0_est's walk from the maximum; nothing
                     # else reads wf_t0_filter, so it is not stored.  Sample indices are handed on (no unit conversion before the stores)
@@ -109,11 +110,11 @@ def test_long_filters_of_the_ge_recipe_run_ahead_of_the_program():
                     # the current branch in the shape of dsp_current.hip: window at tp_0_est (a column by now) of the pole-zero rows
                     [_lib.OP_LOAD, _lib.OP_WINDOWER, _lib.OP_AVG_CURRENT, _lib.OP_UPSAMPLER, _lib.OP_MOVING_WINDOW_MULTI, _lib.OP_MIN_MAX]
                     + [_lib.OP_STORE_SCALAR] * 4,
-                    # per-event values read straight off rows (dsp_reduce.hip): min_max of the raw waveform, maximum and one sample of the cusp's
-                    [_lib.OP_LOAD, _lib.OP_MIN_MAX] + [_lib.OP_STORE_SCALAR] * 4,
+                    # per-event values read straight off rows (dsp_reduce.hip): maximum and one sample of the cusp's
                     [_lib.OP_LOAD, _lib.OP_AMAX, _lib.OP_PICKOFF] + [_lib.OP_STORE_SCALAR] * 2]
-    pz, t0f, cusp, atrap, current, raw_mm, cusp_values = chain._stages
-    assert raw_mm["what"] == "per-event values of waveform off its rows" and [o[1] for o in raw_mm["outs"]] == ["in:tp_min", "in:tp_max", "in:wf_min", "in:wf_max"]
+    pz, t0f, cusp, atrap, current, cusp_values = chain._stages
+    assert pz["what"] == "wf_pz -> HBM + min_max of waveform" and [o[1] for o in pz["outs"]] == ["in:tp_min", "in:tp_max", "in:wf_min", "in:wf_max", "in:wf_pz"]
+    assert plan(pz["program"])["kernel"] == "dsp_pz_rows_kernel"
     assert cusp_values["alias"] == {"in:wf_cusp": "in:wf_cusp"} and [o[1] for o in cusp_values["outs"]] == ["in:cuspEmax", "in:cuspEftp"]
     assert not {_lib.OP_MIN_MAX, _lib.OP_AMAX, _lib.OP_PICKOFF} & set(opcodes) and "in:wf_cusp" not in [io[0] for io in P.io] and "in:waveform" not in [io[0] for io in P.io]
     assert [o[1] for o in current["outs"]] == ["in:aoe_t_min", "in:tp_aoe_max", "in:A_min", "in:A_max"]
@@ -124,7 +125,7 @@ def test_long_filters_of_the_ge_recipe_run_ahead_of_the_program():
     assert plan(t0f["program"])["kernel"] == "dsp_fir_runs_kernel"
     assert atrap["alias"] == {"in:wf_pz": "in:wf_pz", "in:bl_std": "aux:0:1", "in:tp_start": "in:tp_start"} and atrap["outs"] == [("out:tp_0_atrap", "in:tp_0_atrap", None)]
     assert _lib.OP_TRAP_REDUCE in opcodes and "in:wf_t0_filter" not in [io[0] for io in P.io], "the program no longer touches the t0-filtered waveform"
-    assert pz["outs"] == [("out:wf_pz", "in:wf_pz", 8192)] and t0f["alias"] == {"in:wf_pz": "in:wf_pz", "in:bl_std": "aux:0:1"}
+    assert pz["outs"][-1] == ("out:wf_pz", "in:wf_pz", 8192) and t0f["alias"] == {"in:wf_pz": "in:wf_pz", "in:bl_std": "aux:0:1"}
     assert cusp["outs"] == [("out:wf_cusp", "in:wf_cusp", 301)]
     assert cusp["program"].ops[0][4] == (0, 8192 - 6092), "bl_subtract's NaN rule covers the whole waveform: the load screens the rest"
     names = [io[0] for io in P.io]
@@ -403,7 +404,7 @@ def test_arithmetic_that_needs_nothing_of_the_program_runs_ahead_of_it(monkeypat
     monkeypatch.delenv("DSPEED_HIP_NO_SCALAR_HEAD")
     chain, _, _ = build_processing_chain(recipes.ICPC, _tb())
     P, head = chain.program, chain._stages[-1]
-    assert head["what"] == "per-event arithmetic ahead of the program" and len(chain._stages) == 8
+    assert head["what"] == "per-event arithmetic ahead of the program" and len(chain._stages) == 7
     assert [o[0] for o in head["program"].ops] == [_lib.OP_SCALAR_AFFINE, _lib.OP_STORE_SCALAR, _lib.OP_SCALAR_AFFINE, _lib.OP_SCALAR_AFFINE,
                                                    _lib.OP_SCALAR_CONVERT, _lib.OP_STORE_SCALAR]
     assert head["alias"] == {"in:tp_0_est": "in:tp_0_est"} and [k for _o, k, _l in head["outs"]] == ["in:head:r13.0", "in:head:r19.3"]
@@ -420,7 +421,7 @@ def test_arithmetic_that_needs_nothing_of_the_program_runs_ahead_of_it(monkeypat
     # a register that is reused along the program: only what an op reads at its place in the program counts
     monkeypatch.setenv("DSPEED_HIP_NO_SCALAR_HEAD", "1")
     whole, _, _ = build_processing_chain(recipes.ICPC, _tb())
-    assert len(whole.program.ops) == len(P.ops) + 4 and len(whole._stages) == 7
+    assert len(whole.program.ops) == len(P.ops) + 4 and len(whole._stages) == 6
 
 
 def test_the_scalar_tail_of_a_program_becomes_a_program_of_its_own(monkeypatch):
