@@ -483,3 +483,23 @@ def test_the_recipe_with_the_references_values_is_the_references_file_op_for_op(
     assert len(a["stages"]) == len(b["stages"])
     for sa, sb in zip(a["stages"], b["stages"]):
         assert sa == sb, sa[0]
+
+
+def test_the_compilers_idea_of_a_piecewise_constant_kernel_is_the_kernels():
+    """compiler._piecewise_constant sets CONVOLVE's hint with the limits of csrc/dsp_fir_runs.hip (DSP_FIR_RUNS_MAX runs, DSP_FIR_RUNS_MAX_TAPS taps):
+    the two files must agree, and the kernels of the Ge recipes fall where they should"""
+    import os
+    import re
+
+    from dspeed_amd import compiler
+
+    src = open(os.path.join(os.path.dirname(compiler.__file__), "csrc", "dsp_program.h")).read()
+    limits = {k: int(v) for k, v in re.findall(r"#define (DSP_FIR_RUNS_MAX(?:_TAPS)?) +(\d+)", src)}
+    assert limits == {"DSP_FIR_RUNS_MAX": compiler.FIR_RUNS_MAX, "DSP_FIR_RUNS_MAX_TAPS": compiler.FIR_RUNS_MAX_TAPS}
+    import golden_util
+
+    assert compiler._piecewise_constant(golden_util.recipe_kernel("t0"))                 # a ramp of 8 taps, a plateau of 125
+    assert not compiler._piecewise_constant(golden_util.recipe_kernel("cusp"))           # 5792 taps, all different
+    assert compiler._piecewise_constant(np.full(512, 0.25, np.float32)) and not compiler._piecewise_constant(np.full(513, 0.25, np.float32))
+    ramp = np.arange(30, dtype=np.float32)
+    assert not compiler._piecewise_constant(ramp) and compiler._piecewise_constant(ramp[:24]) and not compiler._piecewise_constant(np.array([1.0, np.inf], np.float32))
