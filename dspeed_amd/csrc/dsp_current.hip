@@ -13,8 +13,8 @@
 // 2 x 299 floats per waveform, in a scratch area that stays in L2) and the samples between two checkpoints are recomputed, in registers,
 // when the next pass needs them -- a recurrence restarted from its own intermediate value reproduces its values bit for bit:
 //   sweep A (blocks 0 .. nb-1):  pass 1 values, checkpoint P0[b] = value before block b
-//   sweep B (blocks nb-1 .. 0):  pass 1 block b again from P0[b]; pass 2 steps on it (the lagged operand: block b + L/16, kept in an LDS
-//                                ring of L/16 + 1 blocks); checkpoint P1[b] = pass 2 value before block b in walking order
+//   sweep B (blocks nb-1 .. 0):  pass 1 block b again from P0[b]; pass 2 steps on it (the lagged operand: block b + L/16, again from its
+//                                checkpoint); checkpoint P1[b] = pass 2 value before block b in walking order
 //   sweep C (blocks 0 .. nb-1):  pass 1 block b + L/16 from P0, pass 2 block b from P1, pass 3 steps on it + the running min / max
 // 48 divisions per 16 samples instead of 32 (pass 1 adds one of n_c precomputed increments per sample: the upsampled waveform repeats each
 // current sample cnt times), no sample array anywhere; the checkpoints and increments of the next block are loaded while a block is computed.
@@ -58,8 +58,10 @@ __global__ void __launch_bounds__(64, 1) dsp_current_kernel(CurrentArgs A_, int6
     constexpr int NR = (CB >> SH) + (SH > 0 ? 1 : 0);  // runs of equal upsampled samples that a block of 16 touches
     const int lane = lane_id();
     const int q = A.ma_len / CB, nring = q + 1;
-    CUR_LDS float* ring0 = (CUR_LDS float*)cur_smem;            // pass-1 blocks: [nring][CB][64]
-    CUR_LDS float* ring1 = ring0 + nring * CB * 64;             // pass-2 blocks
+    // pass-2 blocks: [nring][CB][64].  (The pass-1 blocks a pass-2 step lags behind had a ring of their own until round 4: 32 kB per wavefront,
+    // four or five wavefronts per CU -- one per SIMD, and a lone wavefront waits out every dependent instruction.  A pass-1 block is 16
+    // additions from its checkpoint: it is recomputed where it is needed, and eight wavefronts fit a CU.)
+    CUR_LDS float* ring1 = (CUR_LDS float*)cur_smem;
     const int n_c = A.n_c, nb = A.n_up / CB, ql = A.ma_len >> SH;  // u[i] = c[(i + HALF) >> SH];  u[i - L] = c[((i + HALF) >> SH) - ql]
     const double len_d = (double)A.ma_length, inv_len = 1.0 / len_d;
     const double acl_d = (double)A.ac_length, inv_acl = 1.0 / acl_d;
@@ -178,58 +180,44 @@ __global__ void __launch_bounds__(64, 1) dsp_current_kernel(CurrentArgs A_, int6
         // ---- sweep B: pass 2 over recomputed pass-1 blocks, checkpoints
         float acc1 = 0.0f;
         {
-            float d[NR], dn[NR];
+            float d[NR], dn[NR], dq[NR], dqn[NR];
             load_d(d, nb - 1);
-            float cp = load_cp(P0, nb - 1);
+            load_d(dq, nb - 1 + q);
+            float cp = load_cp(P0, nb - 1), cpq = load_cp(P0, nb - 1 + q);
             for (int b = nb - 1; b >= 0; --b) {
                 float o0[CB], lag[CB], o1[CB];
                 load_d(dn, b - 1);
-                const float cpn = load_cp(P0, b - 1);
+                load_d(dqn, b - 1 + q);
+                const float cpn = load_cp(P0, b - 1), cpqn = load_cp(P0, b - 1 + q);
                 pass1_block(b, cp, d, o0);
-                CUR_LDS float* w0 = ring0 + (b % nring) * CB * 64 + lane;
-#pragma unroll
-                for (int j = 0; j < CB; ++j) w0[j * 64] = o0[j];
-                const CUR_LDS float* r0 = ring0 + ((b + q) % nring) * CB * 64 + lane;  // (block b + q: written q iterations ago; unused in the tail)
-#pragma unroll
-                for (int j = 0; j < CB; ++j) lag[j] = r0[j * 64];
+                pass1_block(b + q, cpq, dq, lag);  // (the lagged block, again from its checkpoint; past the end in the tail, where nobody reads it)
                 P1[(int64_t)b * 64] = acc1;
                 acc1 = pass2_block(b, acc1, o0, lag, first1, o1);
 #pragma unroll
-                for (int r = 0; r < NR; ++r) d[r] = dn[r];
+                for (int r = 0; r < NR; ++r) {
+                    d[r] = dn[r];
+                    dq[r] = dqn[r];
+                }
                 cp = cpn;
+                cpq = cpqn;
             }
         }
         const float first2 = acc1;  // out1[0] = out2[0]
         // ---- sweep C: pass 3 over recomputed pass-2 blocks, running extremes
-        for (int bb = 0; bb < q && bb < nb; ++bb) {
-            float o0[CB], d[NR];
-            load_d(d, bb);
-            pass1_block(bb, load_cp(P0, bb), d, o0);
-            CUR_LDS float* w0 = ring0 + (bb % nring) * CB * 64 + lane;
-#pragma unroll
-            for (int j = 0; j < CB; ++j) w0[j * 64] = o0[j];
-        }
         float acc2 = 0.0f, vmin = __builtin_inff(), vmax = -__builtin_inff();
         int imin = 0, imax = 0;
         {
-            float d[NR], dn[NR];
+            float d[NR], dn[NR], db[NR], dbn[NR];
             load_d(d, q);
-            float cp0 = load_cp(P0, q), cp1 = load_cp(P1, 0);
+            load_d(db, 0);
+            float cp0 = load_cp(P0, q), cpb = load_cp(P0, 0), cp1 = load_cp(P1, 0);
             for (int b = 0; b < nb; ++b) {
                 float o0[CB], lag0[CB], o1[CB], lag1[CB];
                 load_d(dn, b + q + 1);
-                const float cp0n = load_cp(P0, b + q + 1), cp1n = load_cp(P1, b + 1);
+                load_d(dbn, b + 1);
+                const float cp0n = load_cp(P0, b + q + 1), cpbn = load_cp(P0, b + 1), cp1n = load_cp(P1, b + 1);
                 pass1_block(b + q, cp0, d, lag0);  // (past the end: values nobody uses -- the tail subtracts first1)
-                if (b + q < nb) {
-                    CUR_LDS float* w0 = ring0 + ((b + q) % nring) * CB * 64 + lane;
-#pragma unroll
-                    for (int j = 0; j < CB; ++j) w0[j * 64] = lag0[j];
-                }
-                {
-                    const CUR_LDS float* r0 = ring0 + (b % nring) * CB * 64 + lane;
-#pragma unroll
-                    for (int j = 0; j < CB; ++j) o0[j] = r0[j * 64];
-                }
+                pass1_block(b, cpb, db, o0);       // (both pass-1 blocks from their checkpoints: 16 additions each, no ring)
                 pass2_block(b, cp1, o0, lag0, first1, o1);
                 CUR_LDS float* w1 = ring1 + (b % nring) * CB * 64 + lane;
 #pragma unroll
@@ -253,8 +241,12 @@ __global__ void __launch_bounds__(64, 1) dsp_current_kernel(CurrentArgs A_, int6
                     imax = gt ? i : imax;
                 }
 #pragma unroll
-                for (int r = 0; r < NR; ++r) d[r] = dn[r];
+                for (int r = 0; r < NR; ++r) {
+                    d[r] = dn[r];
+                    db[r] = dbn[r];
+                }
                 cp0 = cp0n;
+                cpb = cpbn;
                 cp1 = cp1n;
             }
         }
@@ -291,7 +283,7 @@ int set_lds_sh(int lds_bytes) {
 
 }  // namespace
 
-extern "C" int dsp_internal_current_lds_bytes(int ma_len) { return 2 * (ma_len / CB + 1) * CB * 64 * 4; }
+extern "C" int dsp_internal_current_lds_bytes(int ma_len) { return (ma_len / CB + 1) * CB * 64 * 4; }
 
 extern "C" int dsp_internal_launch_current(const CurrentArgs* A, int64_t n_wf, int blocks, int lds_bytes, hipStream_t stream) {
     if (n_wf <= 0) return 0;

@@ -463,10 +463,10 @@ static void rr_geometry(const dsp_chain* ch, int64_t n_wf, int* wpb_out, int* bl
     *blocks_out = (int)(want < cap ? want : cap);
 }
 
-// launch geometry of the current-branch kernel (dsp_current.hip): persistent wavefronts, as many as a CU's LDS takes (at most 8 per CU) ...
+// launch geometry of the current-branch kernel (dsp_current.hip): persistent wavefronts, as many as a CU's LDS takes (at most 12 per CU) ...
 static int current_blocks_cap(const dsp_chain* ch) {
     int per_cu = LDS_BYTES_PER_CU / ch->cur_lds_bytes;
-    if (per_cu > 8) per_cu = 8;
+    if (per_cu > 12) per_cu = 12;  // (three wavefronts per SIMD: the kernel's 109 - 163 registers allow them)
     return ch->num_cu * (per_cu < 1 ? 1 : per_cu);
 }
 // ... and of those as many as make every one walk the same number of 64-row groups (2 048 groups on 1 280 wavefronts are two rounds, the
@@ -616,7 +616,7 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         return post_err(ch, stream);
     }
     if (ch->cur_ok && ch->fused_on && (reinterpret_cast<uintptr_t>(io_ptrs[ch->cio_wf]) & 15u) == 0) {
-        // persistent wavefronts, as many as a CU's LDS takes (at most 8 per CU): each keeps its scratch area for the groups of rows it walks
+        // persistent wavefronts, as many as a CU's LDS takes (at most 12 per CU): each keeps its scratch area for the groups of rows it walks
         const int cap = current_blocks_cap(ch);
         if (!ch->cur_scratch) {
             HIP_TRY(hipMalloc((void**)&ch->cur_scratch, (size_t)cap * (size_t)ch->cur.scratch_per_wave * sizeof(float)));

@@ -23,7 +23,7 @@
 #include "../dspeed_amd/csrc/dsp_plan.h"
 
 // ---- the kernels' side of the planner's interface: tile geometry and names (the library links the .hip files' own; these follow them)
-extern "C" int dsp_internal_current_lds_bytes(int ma_len) { return 2 * (ma_len / 16 + 1) * 16 * 64 * 4; }
+extern "C" int dsp_internal_current_lds_bytes(int ma_len) { return (ma_len / 16 + 1) * 16 * 64 * 4; }
 extern "C" int dsp_internal_fir_mfma_lds_bytes(int kend) { return (((320 + kend + 3) & ~3) + 2 * 64 * 36 + 64 * 4 * 2) * 4; }
 extern "C" int dsp_internal_fir_store_lds_bytes(int kend) { return (((320 + kend + 3) & ~3) + 2 * 64 * 36) * 4; }
 extern "C" int dsp_internal_fir_f16_tz(int kend) { return ((kend + 8 + 63) / 64) * 64 + 400 + 16; }
