@@ -112,6 +112,11 @@ struct dsp_chain : ChainPlan {
     // chain's arrays and leaves a note of which rows they describe; dsp_chain_execute checks the note against its own input
     dsp_chain* scale_feeder = nullptr;  // (on the float16 FIR chain)
     dsp_chain* scale_sink = nullptr;    // (on the pole-zero rows chain)
+    // the same for a float16 FIR that reads a slice of the rows the pole-zero kernel READS, minus the same baseline column: the kernel sees
+    // x - baseline of every sample anyway
+    dsp_chain* scale_sink_in = nullptr;  // (on the pole-zero rows chain)
+    bool fed_in_side = false;            // (on the FIR chain: the note below describes its rows as the producer's input, fed_bl its baseline)
+    const void* fed_bl = nullptr;
     const void* fed_rows_ptr = nullptr;
     void* fed_stream = nullptr;  // the stream of the producer's launch: its scales and flags are ordered ahead of a consumer on that stream only
     int64_t fed_n_wf = -1, fed_stride = 0;
@@ -125,7 +130,11 @@ struct dsp_chain : ChainPlan {
     int* err_mirror = nullptr;  // page-locked
     ~dsp_chain() {  // (also on the error paths of dsp_chain_create, which holds the chain in a unique_ptr)
         if (scale_sink) scale_sink->scale_feeder = nullptr;
-        if (scale_feeder) scale_feeder->scale_sink = nullptr;
+        if (scale_sink_in) scale_sink_in->scale_feeder = nullptr;
+        if (scale_feeder) {
+            if (scale_feeder->scale_sink == this) scale_feeder->scale_sink = nullptr;
+            if (scale_feeder->scale_sink_in == this) scale_feeder->scale_sink_in = nullptr;
+        }
         if (dev) (void)hipFree(dev);
         if (dev_err) (void)hipFree(dev_err);
         if (host.prof) (void)hipFree(host.prof);
@@ -530,12 +539,26 @@ static int f16_rows_reserve(dsp_chain* ch, int64_t n_wf) {
 
 int dsp_chain_share_row_scales(dsp_chain* producer, dsp_chain* consumer) {
     if (!producer || !consumer || producer == consumer) return fail(DSP_ERR_ARG, "dsp_chain_share_row_scales: two chains");
-    if (!producer->pz_ok || !consumer->fir_ok || !consumer->fir_f16 || consumer->fir.in_kind != 0 || consumer->fir.sub_mode != 0 ||
-        producer->device != consumer->device || producer->scale_sink || consumer->scale_feeder)
-        return 0;
-    producer->scale_sink = consumer;
-    consumer->scale_feeder = producer;
-    return 1;
+    if (!producer->pz_ok || !consumer->fir_ok || !consumer->fir_f16 || producer->device != consumer->device || consumer->scale_feeder) return 0;
+    if (consumer->fir.in_kind == 0 && consumer->fir.sub_mode == 0 && !producer->scale_sink) {  // the FIR reads the rows the kernel writes
+        producer->scale_sink = consumer;
+        consumer->scale_feeder = producer;
+        consumer->fed_in_side = false;
+        return 1;
+    }
+    // the FIR reads a slice of the rows the kernel reads, minus the same baseline column: integer rows only (a float32 row's NaN rule looks at the
+    // samples around the slice as well); that the two are bound to the same buffers is checked at every execute
+    const PzArgs& P = producer->pz;
+    const FirArgs& F = consumer->fir;
+    if (F.in_kind != 0 && F.in_kind == P.in_kind && F.sub_mode == 1 && P.sub_mode == 1 && consumer->fio_bl >= 0 && producer->pio_bl >= 0 &&
+        F.wf_stride == P.wf_stride && F.bl_stride == P.bl_stride && F.wf_offset >= P.wf_offset && F.wf_offset + F.n <= P.wf_offset + P.len &&
+        !producer->scale_sink_in) {
+        producer->scale_sink_in = consumer;
+        consumer->scale_feeder = producer;
+        consumer->fed_in_side = true;
+        return 1;
+    }
+    return 0;
 }
 
 int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* stream) {
@@ -577,6 +600,23 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
             sink->fed_n_wf = n_wf;
             sink->fed_stride = A.out_stride;
             sink->fed_len = A.len;
+        }
+        A.in_scale = nullptr;
+        A.in_flags = nullptr;
+        if (dsp_chain* sink = ch->scale_sink_in) {
+            const int rc = f16_rows_reserve(sink, n_wf);
+            if (rc != DSP_OK) return rc;
+            const int es = A.in_kind == 0 ? 4 : 2;
+            A.in_scale = (float*)const_cast<void*>(sink->f16.row_scale);
+            A.in_flags = (uint32_t*)const_cast<void*>(sink->f16.row_flags);
+            A.in_lo = sink->fir.wf_offset - A.wf_offset;
+            A.in_hi = A.in_lo + sink->fir.n;
+            sink->fed_rows_ptr = (const char*)A.wf + (size_t)sink->fir.wf_offset * es;  // the consumer's first sample, if it is bound to these rows
+            sink->fed_bl = A.bl;
+            sink->fed_stream = stream;
+            sink->fed_n_wf = n_wf;
+            sink->fed_stride = A.wf_stride;
+            sink->fed_len = sink->fir.n;
         }
         hipError_t e = (hipError_t)dsp_internal_launch_pz_rows(&A, n_wf, ch->dev_err, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "pole-zero rows kernel launch failed: %s", hipGetErrorString(e));
@@ -644,10 +684,12 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
             const int rc = f16_rows_reserve(ch, n_wf);
             if (rc != DSP_OK) return rc;
             // scales and flags already there?  Only if the kernel in front wrote exactly the rows this one reads, and just now
-            const void* first = (const char*)A.wf + (size_t)A.wf_offset * sizeof(float);
+            const void* first = (const char*)A.wf + (size_t)A.wf_offset * (A.in_kind == 0 ? sizeof(float) : sizeof(int16_t));
             // -- and on this stream: scales and flags are written by the producer's launch, so only stream order puts them ahead of this one
-            ch->f16.rows_done = (ch->scale_feeder && A.in_kind == 0 && A.sub_mode == 0 && ch->fed_rows_ptr == first && ch->fed_n_wf == n_wf && ch->fed_stream == stream &&
-                                 ch->fed_stride == A.wf_stride && ch->fed_len == A.n) ? 1 : 0;
+            const bool same_batch = ch->scale_feeder && ch->fed_rows_ptr == first && ch->fed_n_wf == n_wf && ch->fed_stream == stream &&
+                                    ch->fed_stride == A.wf_stride && ch->fed_len == A.n;
+            ch->f16.rows_done = (same_batch && (ch->fed_in_side ? (A.in_kind != 0 && A.sub_mode == 1 && ch->fed_bl == (const void*)A.bl && A.bl != nullptr)
+                                                                : (A.in_kind == 0 && A.sub_mode == 0))) ? 1 : 0;
             ch->fed_n_wf = -1;  // (a note is good for one execute)
         }
         hipError_t e = (hipError_t)(ch->fir_f16 ? dsp_internal_launch_fir_f16(&A, &ch->f16, n_wf, dsp_internal_fir_f16_lds_bytes(), (hipStream_t)stream)

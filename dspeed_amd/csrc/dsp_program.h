@@ -174,6 +174,11 @@ struct PzArgs {
     void* mm_out[4];         // or null each: min_max (min_max.py:11-82) of the rows as they are READ (t_min, t_max, a_min, a_max; float32 columns)
     int64_t mm_stride[4];
     int32_t mm_on, pad_;
+    // or null: what dsp_fir_f16_rows_kernel would find on samples [in_lo, in_hi) of the rows READ here, minus the baseline -- for a float16 FIR
+    // that filters that slice of the same rows with the same baseline (the cusp filter of the Ge recipes: waveform[0:6092] - baseline)
+    float* in_scale;
+    uint32_t* in_flags;
+    int32_t in_lo, in_hi;
 };
 
 // arguments of the streaming reductions (dsp_reduce.hip), filled by dsp_chain_execute when a program has the shape

@@ -80,6 +80,11 @@ __global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_w
     e.imin = e.imax = 0;
     e.nan = false;
     float mx = 0.0f;  // largest |sample written| (a NaN never raises it): the scale of a float16 FIR behind (A.row_scale)
+    // the same of the samples [in_lo, in_hi) as they are READ, minus the baseline: the scale of a float16 FIR that filters that slice of
+    // these rows (A.in_scale; integer rows)
+    const bool in_on = A.in_scale != nullptr;
+    const int in_lo = A.in_lo, in_hi = A.in_hi;
+    float mx_in = 0.0f;
     auto group = [&](const u4 (&raw)[NV], int g) {
         const int at = g * 512 + lane * 8;
         const bool live = at < n;  // (n is a multiple of 8: a lane's vector lies inside the row whole or not at all)
@@ -122,6 +127,10 @@ __global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_w
         for (int u = 0; u < 8; ++u) {
             const float v = live ? (sub ? x[u] - bl : x[u]) : 0.0f;  // bl_subtract.py:45, in float32
             if (IN == 0) in_nan |= (v != v);                          // (integer samples: only the baseline can be a NaN, looked at below)
+            if (in_on && at + u >= in_lo && at + u < in_hi) {          // (x - baseline in float32: what dsp_fir_f16_rows_kernel looks at)
+                const float a = __builtin_fabsf(v);
+                mx_in = (live && a > mx_in) ? a : mx_in;
+            }
             run += (double)v;
             p[u] = run;
         }
@@ -168,6 +177,17 @@ __global__ void __launch_bounds__(256) dsp_pz_rows_kernel(PzArgs A_, int64_t n_w
         if (!bad_in && lane == 0) pz_report(err, DSP_E_PZ_NAN, row);
         const f4 nanv = {quiet_nan<float>(), quiet_nan<float>(), quiet_nan<float>(), quiet_nan<float>()};
         for (int at = lane * 4; at < n; at += 256) *(PZ_GLOBAL f4*)(outp + at) = nanv;
+    }
+    if (in_on) {  // (uniform) exactly what dsp_fir_f16_rows_kernel leaves for the slice: same samples, same rule
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) mx_in = fmaxf(mx_in, __shfl_xor(mx_in, sft));
+        int e2 = (int)((__float_as_uint(mx_in) >> 23) & 0xffu) - 127;
+        const bool bad = !(mx_in <= 3.4028234663852886e38f) || (mx_in > 0.0f && (e2 < -100 || e2 > 100));
+        if (!(mx_in > 0.0f) || bad) e2 = 14;
+        if (lane == 0) {
+            A.in_scale[row] = __uint_as_float((unsigned)(127 + 14 - e2) << 23);
+            A.in_flags[row] = (bad ? 1u : 0u) | ((sub && bl != bl) ? 2u : 0u);  // (integer rows: a NaN can only come in through the baseline)
+        }
     }
     if (mm_on) {  // min_max.py:62-77: four NaNs for a row with a NaN, else the first occurrence of each extreme
 #pragma unroll

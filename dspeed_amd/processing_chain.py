@@ -158,8 +158,12 @@ class ProcessingChain:
             return
         for i, st in enumerate(self._stages):
             made = {key for _o, key, _l in st["outs"]}
+            reads = {nm.split("[")[0] for nm in st["in_vars"]}
             for j in range(i + 1, len(self._stages)):
-                if made & set(self._stages[j]["alias"].values()):
+                # ... or one that filters a slice of the rows the pole-zero kernel reads, minus the same baseline (the cusp filter on
+                # waveform[0:6092] - baseline): the kernel sees those samples anyway
+                same_input = reads & {nm.split("[")[0] for nm in self._stages[j]["in_vars"]}
+                if made & set(self._stages[j]["alias"].values()) or same_input:
                     stage_chains[i].share_row_scales(stage_chains[j])
 
     def _tail_chain(self, lane_no: int):

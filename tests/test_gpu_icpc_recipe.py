@@ -505,6 +505,40 @@ def test_stages_on_side_streams_give_the_same_results():
             assert np.array_equal(out2[k], ref[k], equal_nan=True), k
 
 
+def test_row_scales_from_the_kernel_that_reads_the_same_rows(monkeypatch):
+    """the cusp filter runs on the float16 matrix instructions and needs every row's scale (a power of two from max |waveform[0:6092] - baseline|)
+    and flags; the kernel that writes the pole-zero rows reads the same rows and subtracts the same baseline, so it leaves them
+    (dsp_chain_share_row_scales, input side) and the filter skips its own pass over the rows: bit for bit what it computes itself -- ordinary
+    rows, rows equal to their baseline, a NaN baseline, a huge one"""
+    from dspeed_amd.processing_chain import WaveformInput, build_processing_chain
+
+    rng = np.random.default_rng(41)
+    n = 500
+    wf, bl = _synth(rng, n)
+    wf = wf.astype(np.int16)
+    bl = bl.copy()
+    wf[3] = 1200
+    bl[3] = 1200.0          # x - baseline = 0 everywhere: the scale of a zero row
+    bl[4] = np.nan          # -> flags: a NaN row
+    bl[5] = 3e38            # a magnitude whose scale would leave float32: the filter's slow path
+    bl[6] = -2.5e-3
+    tb = {"waveform": WaveformInput(wf, 16.0, 48000.0), "baseline": bl}
+    outs = ["cuspEmax", "cuspEftp", "tp_0_est", "trapEmax", "wf_max", "tp_max"]
+
+    def run(shared):
+        monkeypatch.setenv("DSPEED_HIP_NO_SHARED_ROW_SCALES", "0" if shared else "1")
+        chain, _, out = build_processing_chain(recipes.ICPC, tb, outputs=outs)
+        chain.execute()
+        ks = [k for _w, k in chain.kernels()]
+        assert "dsp_pz_rows_kernel" in ks and "dsp_fir_f16_kernel" in ks, ks
+        return {k: np.array(v) for k, v in out.items()}
+
+    a, b = run(True), run(False)
+    for k in outs:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert np.isnan(a["cuspEmax"][4]) and np.isfinite(a["cuspEmax"][[0, 1, 2, 6]]).all() and a["cuspEmax"][3] == 0.0
+
+
 def test_programs_that_shed_ops_give_the_same_bits(monkeypatch):
     """the scalar head (arithmetic that needs nothing of the program, run ahead of it with a row per lane) and the thresholds folded into the walks
     (`time_point_thresh(wf, 0.9 * trapTmax, ...)`: the planner drops the multiplication's op and the walk multiplies) change where an operation
