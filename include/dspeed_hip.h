@@ -332,6 +332,11 @@ const char* dsp_chain_kernel_note(dsp_chain* chain);
  * that execute was queued on (only stream order puts the scales ahead of the FIR), and finds them itself otherwise.  The caller's part of the
  * contract: nothing rewrites those rows between the producer's execute and the consumer's (the library cannot see a write to caller memory);
  * the note is good for one execute of the consumer.
+ * A second form of the pair: `consumer` is a float16 FIR over a slice of the INTEGER rows the producer READS, minus the same per-event baseline
+ * column (the cusp filter of the Ge recipes on waveform[0:6092] - baseline beside bl_subtract -> pole_zero of the whole waveform): the producer
+ * sees waveform - baseline of every sample anyway and leaves the slice's scale and flags; the consumer uses them when its rows and its baseline
+ * are the buffers of the producer's last execute (addresses, stride, row count, stream), and finds them itself otherwise.  A producer takes one
+ * consumer of each form, a consumer one producer.
  * Returns 1 when the pair was linked, 0 when the chains are not of these shapes (nothing changes), < 0 on an argument error.  The link ends
  * with either chain's dsp_chain_destroy.  No counterpart in the reference (its processors exchange nothing but their arrays,
  * processing_chain.py:1144-1163); results are the same with and without it. */
