@@ -531,6 +531,17 @@ class ProcessingChain:
         lib = _lib.lib()
         lane = lane if lane is not None else self._lane(0)
         ft_code, isz = dtype_code(self.loop_dtype), self.loop_dtype.itemsize
+        # The fits beside the first stages: one waveform per lane is eight wavefronts a CU whose recurrences wait out every instruction, the
+        # kernel that writes the pole-zero rows is bound by HBM and uses no LDS -- the two share the CUs.  The fits go to a stream of their
+        # own behind everything the lane's stream holds so far; the first stage that reads a fit's column (and the program) waits for them.
+        beside = self.fits_beside_stages and bool(self._aux) and bool(self._stages)
+        main_stream = stream
+        if beside:
+            if getattr(lane, "fit_stream", None) is None:
+                lane.fit_stream, lane.fit_start, lane.fit_done = Stream(), Event(), Event()
+            lane.fit_start.record(main_stream)
+            lane.fit_stream.wait_event(lane.fit_start)
+            stream = lane.fit_stream
         for gi, g in enumerate(self._aux):
             n_cols = len(g["names"])
             out = lane.aux_bufs.get(gi)
@@ -546,12 +557,19 @@ class ProcessingChain:
                                                      stream.ptr), what="linear_slope_fit_rows")
             for j, name in enumerate(g["names"]):
                 bufs[name] = out.ptr + j * m * isz
+        fits_pending = False
+        if beside:
+            lane.fit_done.record(stream)
+            stream, fits_pending = main_stream, True
         # The stages, in launch order (a stage may read what an earlier one wrote) -- but not all on one stream: what a stage reads says which
         # earlier stages it waits for, and stages that do not wait for each other (the cusp filter beside the t0 chain, the reductions off the raw
         # rows, the lane-per-waveform kernels that leave most of a CU idle) go to side streams and run beside each other.  The program's stream
         # waits for all of them before the program is launched.
         plan = self._stage_plan() if self.concurrent_stages and len(self._stages) > 1 else None
         if plan is not None:
+            if fits_pending:  # (stages on side streams of their own: they start behind the fits, as before)
+                stream.wait_event(lane.fit_done)
+                fits_pending = False
             side = getattr(lane, "side_streams", None)
             if side is None:
                 side = lane.side_streams = [Stream() for _ in range(plan["n_side"])]
@@ -561,6 +579,9 @@ class ProcessingChain:
             for s in side:
                 s.wait_event(lane.pass_start)
         for j, st in enumerate(self._stages):
+            if fits_pending and any(str(key).startswith("aux:") for key in st["alias"].values()):
+                stream.wait_event(lane.fit_done)
+                fits_pending = False
             sb = dict(bufs)
             sb.update(st["dev"])
             for io_name, key in st["alias"].items():
@@ -585,8 +606,14 @@ class ProcessingChain:
             for j in plan["sinks"]:
                 if plan["stream_of"][j] >= 0:
                     stream.wait_event(lane.stage_done[j])
+        if fits_pending:
+            stream.wait_event(lane.fit_done)
         for io_name, key in self._ext_alias.items():
             bufs[io_name] = bufs[key]
+
+    #: True (default; DSPEED_HIP_FITS_BESIDE=0 switches it off): the fits on the rows run on a stream of their own beside the stages that do not read
+    #: their results -- in the Ge recipe the kernel that writes the pole-zero rows
+    fits_beside_stages = os.environ.get("DSPEED_HIP_FITS_BESIDE", "1") != "0"
 
     #: True (DSPEED_HIP_CONCURRENT_STAGES=1): stages that do not read each other's results run on streams of their own, beside each other.  Off
     #: by default: measured on the Ge recipe it changes nothing (22.80 against 22.76 ms per 131 072 rows) -- the kernels that could overlap
