@@ -553,10 +553,17 @@ def test_programs_that_shed_ops_give_the_same_bits(monkeypatch):
     chain.execute()
     assert "per-event arithmetic ahead of the program" in [st["what"] for st in chain._stages]
     ref = {k: np.array(v) for k, v in out.items()}
-    for switch in ("DSPEED_HIP_NO_SCALAR_HEAD", "DSPEED_HIP_NO_THRESHOLD_FOLD", "DSPEED_HIP_NO_SCALAR_TAIL"):
-        monkeypatch.setenv(switch, "1")
+    # (and the fits on a stream of their own beside the first stages, or on the lane's stream: DSPEED_HIP_FITS_BESIDE)
+    for switch, value in (("DSPEED_HIP_NO_SCALAR_HEAD", "1"), ("DSPEED_HIP_NO_THRESHOLD_FOLD", "1"), ("DSPEED_HIP_NO_SCALAR_TAIL", "1"),
+                          ("DSPEED_HIP_FITS_BESIDE", "0")):
+        monkeypatch.setenv(switch, value)
+        if switch == "DSPEED_HIP_FITS_BESIDE":
+            from dspeed_amd.processing_chain import ProcessingChain
+
+            monkeypatch.setattr(ProcessingChain, "fits_beside_stages", False)  # (the class attribute was read from the environment at import)
         other, _, out2 = build_processing_chain(recipes.ICPC_REF, tb)
-        other.execute()
+        for _ in range(2):  # (twice: the second pass's fits start behind the first pass's readers of their columns)
+            other.execute()
         monkeypatch.delenv(switch)
         if switch == "DSPEED_HIP_NO_SCALAR_HEAD":
             assert "per-event arithmetic ahead of the program" not in [st["what"] for st in other._stages]
