@@ -1585,11 +1585,9 @@ def _split_scalar_head(p: Program, ft, ext_alias: dict):
             io_map[idx] = h.add_io(name, kind, code, length, offset, stride)
         return io_map[idx]
 
-    for opcode, dst, src, io, ip, sp in head_ops:
+    for (opcode, dst, src, io, ip, sp), (name, r, used) in zip(head_ops, made):
         h.add_op(opcode, dst=dst, src=src, io=io, ip=ip, sp=tuple(Scalar.input(head_io(a.index)) if a.kind == _lib.ARG_INPUT else a for a in sp))
-        # (a register written twice by the head: the column is stored right behind the op that made this version)
-        name, r, used = made[len(h.ops) - 1 - sum(1 for o in h.ops[:-1] if o[0] == _lib.OP_STORE_SCALAR)]
-        if used:
+        if used:  # (stored right behind the op that made it: the head may write the register again)
             h.add_op(_lib.OP_STORE_SCALAR, io=h.add_io("out:" + name, _lib.IO_SCALAR_OUT, ft), ip=(r,))
     col_io = {}
 
