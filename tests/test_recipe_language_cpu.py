@@ -503,3 +503,40 @@ def test_the_compilers_idea_of_a_piecewise_constant_kernel_is_the_kernels():
     assert compiler._piecewise_constant(np.full(512, 0.25, np.float32)) and not compiler._piecewise_constant(np.full(513, 0.25, np.float32))
     ramp = np.arange(30, dtype=np.float32)
     assert not compiler._piecewise_constant(ramp) and compiler._piecewise_constant(ramp[:24]) and not compiler._piecewise_constant(np.array([1.0, np.inf], np.float32))
+
+
+def test_the_scalar_head_follows_registers_by_position():
+    """_split_scalar_head on a hand-made program: a register the head wrote and a waveform op overwrites later, a head result that is only
+    stored (a copy of its column), an op that reads the overwritten register (stays)"""
+    from dspeed_amd import compiler
+    from dspeed_amd.chain import Program, Scalar
+
+    p = Program()
+    p.slots = [256]
+    p.n_sregs = 8
+    wf = p.add_io("in:wf", _lib.IO_WF_IN, np.float32, 256, 0, 256)
+    a = p.add_io("in:a", _lib.IO_SCALAR_IN, np.float32)
+    outs = [p.add_io(f"out:{k}", _lib.IO_SCALAR_OUT, np.float32) for k in range(3)]
+    p.add_op(_lib.OP_LOAD, dst=0, io=wf)
+    p.add_op(_lib.OP_SCALAR_AFFINE, dst=1, sp=(Scalar.input(a), Scalar.const(2.0), Scalar.const(0.0)))      # head
+    p.add_op(_lib.OP_PICKOFF, dst=2, src=0, ip=(ord("n"), 0), sp=(Scalar.reg(1),))                          # reads the head's r1
+    p.add_op(_lib.OP_MIN_MAX, dst=1, src=0)                                                                 # r1 .. r4 start another life
+    p.add_op(_lib.OP_SCALAR_AFFINE, dst=5, sp=(Scalar.reg(1), Scalar.const(1.0), Scalar.const(1.0)))        # reads MIN_MAX's r1: stays
+    p.add_op(_lib.OP_SCALAR_AFFINE, dst=6, sp=(Scalar.input(a), Scalar.const(3.0), Scalar.const(0.0)))      # head, only stored
+    p.add_op(_lib.OP_STORE_SCALAR, io=outs[0], ip=(6,))
+    p.add_op(_lib.OP_STORE_SCALAR, io=outs[1], ip=(5,))
+    p.add_op(_lib.OP_STORE_SCALAR, io=outs[2], ip=(2,))
+    ext = {}
+    head = compiler._split_scalar_head(p, np.dtype(np.float32), ext)
+    assert [o[0] for o in head["program"].ops] == [_lib.OP_SCALAR_AFFINE, _lib.OP_STORE_SCALAR, _lib.OP_SCALAR_AFFINE, _lib.OP_STORE_SCALAR]
+    assert [k for _o, k, _l in head["outs"]] == ["in:head:r1.0", "in:head:r6.1"] and set(ext) == {"in:head:r1.0", "in:head:r6.1"}
+    ops = p.ops
+    assert [o[0] for o in ops] == [_lib.OP_LOAD, _lib.OP_PICKOFF, _lib.OP_MIN_MAX, _lib.OP_SCALAR_AFFINE, _lib.OP_SCALAR_FUNC, _lib.OP_STORE_SCALAR,
+                                   _lib.OP_STORE_SCALAR, _lib.OP_STORE_SCALAR]
+    pick, keep, copy = ops[1], ops[3], ops[4]
+    assert pick[5][0].kind == _lib.ARG_INPUT and p.io[pick[5][0].index][0] == "in:head:r1.0"
+    assert keep[5][0].kind == _lib.ARG_REG and keep[5][0].index == 1, "the register MIN_MAX wrote, not the head's"
+    assert copy[1] == 6 and copy[4][0] == _lib.FN_COPY and p.io[copy[5][0].index][0] == "in:head:r6.1"
+    _check_program_order(p)
+    plan(p)  # (the planner takes it)
+    plan(head["program"])
