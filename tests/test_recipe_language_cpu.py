@@ -540,3 +540,32 @@ def test_the_scalar_head_follows_registers_by_position():
     _check_program_order(p)
     plan(p)  # (the planner takes it)
     plan(head["program"])
+
+
+def test_the_planner_folds_a_thresholds_factor_into_the_walk():
+    """dsp_plan.cpp: SCALAR_AFFINE d <- x * const + 0 whose result only TIME_POINT_THRESH ops read as their threshold becomes a no-op (the walk
+    multiplies); anything else that reads d, an offset, or x changing in between keeps the op"""
+    from dspeed_amd.chain import Program, Scalar
+
+    def program(offset=0.0, store_thr=False, rewrite_x=False):
+        p = Program()
+        p.slots = [512]
+        p.n_sregs = 8
+        wf = p.add_io("wf", _lib.IO_WF_IN, np.float32, 512, 0, 512)
+        p.add_op(_lib.OP_LOAD, dst=0, io=wf)
+        p.add_op(_lib.OP_MIN_MAX, dst=0, src=0)
+        p.add_op(_lib.OP_SCALAR_AFFINE, dst=4, sp=(Scalar.reg(3), Scalar.const(0.5), Scalar.const(offset)))
+        if rewrite_x:
+            p.add_op(_lib.OP_AMAX, dst=3, src=0)
+        p.add_op(_lib.OP_TIME_POINT_THRESH, dst=5, src=0, sp=(Scalar.reg(4), Scalar.reg(1), Scalar.const(0.0)))
+        p.add_op(_lib.OP_TIME_POINT_THRESH, dst=6, src=0, sp=(Scalar.reg(4), Scalar.reg(5), Scalar.const(0.0)))
+        for r in (5, 6) + ((4,) if store_thr else ()):
+            p.add_op(_lib.OP_STORE_SCALAR, io=p.add_io(f"o{r}", _lib.IO_SCALAR_OUT, np.float32), ip=(r,))
+        return p
+
+    # LOAD, MIN_MAX, two walks, the stores as one op
+    assert plan(program())["n_device_ops"] == 5
+    assert plan(program(offset=-0.0))["n_device_ops"] == 5
+    assert plan(program(offset=1.0))["n_device_ops"] == 6          # an offset: the op stays
+    assert plan(program(store_thr=True))["n_device_ops"] == 6      # the threshold itself is an output
+    assert plan(program(rewrite_x=True))["n_device_ops"] == 7      # the value the walks would multiply changes before they run
