@@ -98,7 +98,7 @@ __device__ __forceinline__ void group_of(double (&acc)[8], const FR_LDS double* 
     }
 }
 
-__global__ void __launch_bounds__(256) dsp_fir_runs_kernel(FirRunsArgs A_, int64_t n_wf) {
+__global__ void __launch_bounds__(256) dsp_fir_runs_kernel(FirRunsArgs A_, int64_t n_wf, int* err) {
     const FR_KARG FirRunsArgs& A = *(const FR_KARG FirRunsArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     (void)A_;
     extern __shared__ __attribute__((aligned(16))) double fr_smem[];
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256) dsp_fir_runs_kernel(FirRunsArgs A_, int64
         }
         if (has_red) {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the walks read what other lanes of this wavefront just wrote (same CU, same L1: no write-back, no invalidate)
-            reduce_finish<float>(A.red, row, e, (const float*)outp, p, lane);  // (its loads are back before the next row's stores are issued)
+            reduce_finish<float>(A.red, row, e, (const float*)outp, p, lane, err);  // (its loads are back before the next row's stores are issued)
         }
     }
 }
@@ -302,10 +302,10 @@ extern "C" int dsp_internal_fir_runs_lds_bytes(int m) {
     return (4 * (mp + mp / 8 + STEP + STEP / 8) + 64) * (int)sizeof(double);  // (+ the round of the window's copy that reads past the last window)
 }
 
-extern "C" int dsp_internal_launch_fir_runs(const FirRunsArgs* A, FirRunsTable* table, int64_t n_wf, int blocks, hipStream_t stream) {
+extern "C" int dsp_internal_launch_fir_runs(const FirRunsArgs* A, FirRunsTable* table, int64_t n_wf, int blocks, int* err, hipStream_t stream) {
     if (n_wf <= 0 || A->p <= 0) return 0;
     hipLaunchKernelGGL(dsp_fir_runs_prep_kernel, dim3(1), dim3(64), 0, stream, A->taps, A->m, table);
-    hipLaunchKernelGGL(dsp_fir_runs_kernel, dim3((unsigned)blocks), dim3(256), (size_t)dsp_internal_fir_runs_lds_bytes(A->m), stream, *A, n_wf);
+    hipLaunchKernelGGL(dsp_fir_runs_kernel, dim3((unsigned)blocks), dim3(256), (size_t)dsp_internal_fir_runs_lds_bytes(A->m), stream, *A, n_wf, err);
     return (int)hipGetLastError();
 }
 

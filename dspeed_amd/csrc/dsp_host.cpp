@@ -52,13 +52,13 @@ extern "C" int dsp_internal_set_rows_lds(int lds_bytes);
 extern "C" const char* dsp_internal_rows_kernel_name();
 extern "C" int dsp_internal_launch_pz_rows(const PzArgs* A, int64_t n_wf, int* err, hipStream_t stream);
 extern "C" const char* dsp_internal_pz_rows_kernel_name();
-extern "C" int dsp_internal_launch_reduce(const ReduceArgs* A, int64_t n_wf, int dtype, int vec, hipStream_t stream);
+extern "C" int dsp_internal_launch_reduce(const ReduceArgs* A, int64_t n_wf, int dtype, int vec, int* err, hipStream_t stream);
 extern "C" const char* dsp_internal_reduce_kernel_name();
 extern "C" int dsp_internal_launch_scalar(const DevProgram* dev_prog, const IoPtrs* ptrs, int64_t n_wf, int n_sregs, int type, hipStream_t stream);  // type: 0 float32, 1 float64, 2 int64 registers
 extern "C" int dsp_internal_set_scalar_lds(int lds_bytes);
 extern "C" const char* dsp_internal_scalar_kernel_name();
 extern "C" int dsp_internal_current_lds_bytes(int ma_len);
-extern "C" int dsp_internal_launch_fir_runs(const FirRunsArgs* A, FirRunsTable* table, int64_t n_wf, int blocks, hipStream_t stream);
+extern "C" int dsp_internal_launch_fir_runs(const FirRunsArgs* A, FirRunsTable* table, int64_t n_wf, int blocks, int* err, hipStream_t stream);
 extern "C" int dsp_internal_launch_current(const CurrentArgs* A, int64_t n_wf, int blocks, int lds_bytes, hipStream_t stream);
 extern "C" int dsp_internal_set_current_lds(int lds_bytes);
 extern "C" const char* dsp_internal_current_kernel_name();
@@ -630,9 +630,10 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         for (int k = 0; k < DSP_REDUCE_WALKS; ++k) {
             A.walk_out[k] = at(ch->dio_walk[k]);
             A.walk_thr[k] = (const float*)at(ch->dio_walk_thr[k]);
+            A.walk_ts[k] = (const float*)at(ch->dio_walk_ts[k]);
         }
         const int vec = ch->red_vec && (reinterpret_cast<uintptr_t>(A.wf) & 15u) == 0;
-        hipError_t e = (hipError_t)dsp_internal_launch_reduce(&A, n_wf, ch->red_dtype, vec, (hipStream_t)stream);
+        hipError_t e = (hipError_t)dsp_internal_launch_reduce(&A, n_wf, ch->red_dtype, vec, ch->dev_err, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "reduce kernel launch failed: %s", hipGetErrorString(e));
         return post_err(ch, stream);
     }
@@ -650,8 +651,9 @@ int dsp_chain_execute(dsp_chain* ch, void* const* io_ptrs, int64_t n_wf, void* s
         for (int k = 0; k < DSP_REDUCE_WALKS; ++k) {
             A.red.walk_out[k] = at(ch->dio_walk[k]);
             A.red.walk_thr[k] = (const float*)at(ch->dio_walk_thr[k]);
+            A.red.walk_ts[k] = (const float*)at(ch->dio_walk_ts[k]);
         }
-        hipError_t e = (hipError_t)dsp_internal_launch_fir_runs(&A, ch->runs_table, n_wf, runs_blocks(ch, n_wf), (hipStream_t)stream);
+        hipError_t e = (hipError_t)dsp_internal_launch_fir_runs(&A, ch->runs_table, n_wf, runs_blocks(ch, n_wf), ch->dev_err, (hipStream_t)stream);
         if (e != hipSuccess) return fail(DSP_ERR_HIP, "run-length FIR kernel launch failed: %s", hipGetErrorString(e));
         return post_err(ch, stream);
     }

@@ -182,7 +182,11 @@ static bool match_pz_rows_shape(ChainPlan* ch, const dsp_op* ops, int n_ops, con
 static bool match_reduce_ops(ChainPlan* ch, const dsp_op* ops, int first, int n_ops, int slot, int len, const dsp_io_desc* io, ReduceArgs& A) {
     memset(&A, 0, sizeof A);
     int reg_of_out[5] = {-1, -1, -1, -1, -1}, reg_of_pick[DSP_REDUCE_PICKS] = {-1, -1, -1, -1};
-    int reg_of_walk[DSP_REDUCE_WALKS] = {-1, -1}, walk_thr_io[DSP_REDUCE_WALKS] = {-1, -1};
+    int reg_of_walk[DSP_REDUCE_WALKS], walk_thr_io[DSP_REDUCE_WALKS], walk_ts_io[DSP_REDUCE_WALKS];
+    for (int k = 0; k < DSP_REDUCE_WALKS; ++k) reg_of_walk[k] = walk_thr_io[k] = walk_ts_io[k] = -1;
+    // thresholds that are a fraction of a per-event column: SCALAR_AFFINE d <- column * constant + 0 in front of the walk that reads d
+    struct Scaled { int reg, io; float factor; };
+    std::vector<Scaled> scaled;
     int n_pick = 0, n_walk = 0, i = first;
     for (; i < n_ops; ++i) {
         const dsp_op& o = ops[i];
@@ -198,24 +202,46 @@ static bool match_reduce_ops(ChainPlan* ch, const dsp_op* ops, int first, int n_
             A.pick_at[n_pick] = (t >= 0 && t <= len - 1) ? (int)t : -1;  // fixed_time_pickoff.py:68-74
             A.pick_rule[n_pick] = o.ip[1] == 0;
             ++n_pick;
+        } else if (o.opcode == DSP_OP_SCALAR_AFFINE && o.sp[0].kind == DSP_ARG_INPUT && io[o.sp[0].index].dtype == DSP_F32 && o.sp[1].kind == DSP_ARG_CONST &&
+                   o.sp[2].kind == DSP_ARG_CONST && o.sp[2].value == 0.0) {
+            scaled.push_back({o.dst, o.sp[0].index, (float)o.sp[1].value});
         } else if (o.opcode == DSP_OP_TIME_POINT_THRESH && o.src == slot && n_walk < DSP_REDUCE_WALKS && o.sp[2].kind == DSP_ARG_CONST &&
                    (o.sp[2].value == 0.0 || o.sp[2].value == 1.0)) {
-            // threshold: a constant or a float32 column; start: a constant sample inside the waveform, or where MIN_MAX found an extreme (an
-            // integer inside the waveform by construction -- the checks of time_point_thresh.py:67-74 cannot fail)
+            // threshold: a constant, a float32 column or a fraction of one; start: a constant sample inside the waveform, where MIN_MAX found an
+            // extreme (an integer inside the waveform by construction -- the checks of time_point_thresh.py:67-74 cannot fail), a float32
+            // column or where an earlier walk of this program ended (checked per event, as the processor does)
             if (o.sp[0].kind == DSP_ARG_INPUT && io[o.sp[0].index].dtype == DSP_F32) {
                 walk_thr_io[n_walk] = o.sp[0].index;
                 A.walk_thr_stride[n_walk] = io[o.sp[0].index].row_stride;
             } else if (o.sp[0].kind == DSP_ARG_CONST) {
                 A.walk_thr_const[n_walk] = (float)o.sp[0].value;
+            } else if (o.sp[0].kind == DSP_ARG_REG) {
+                const Scaled* sc = nullptr;
+                for (const Scaled& c : scaled)
+                    if (c.reg == o.sp[0].index) sc = &c;  // (the latest value of the register)
+                if (!sc) return false;
+                walk_thr_io[n_walk] = sc->io;
+                A.walk_thr_stride[n_walk] = io[sc->io].row_stride;
+                A.walk_thr_factor[n_walk] = sc->factor;
+                A.walk_thr_scaled[n_walk] = 1;
             } else {
                 return false;
             }
+            int from_walk = -1;
+            for (int k = 0; k < n_walk; ++k)
+                if (o.sp[1].kind == DSP_ARG_REG && reg_of_walk[k] == o.sp[1].index) from_walk = k;
             if (o.sp[1].kind == DSP_ARG_REG && reg_of_out[0] >= 0 && (o.sp[1].index == reg_of_out[0] || o.sp[1].index == reg_of_out[1])) {
                 A.walk_from[n_walk] = o.sp[1].index == reg_of_out[0] ? 1 : 2;
             } else if (o.sp[1].kind == DSP_ARG_CONST) {
                 const double t = (double)(float)o.sp[1].value;
                 if (!(t == std::floor(t)) || t < 0 || t >= len) return false;
                 A.walk_start[n_walk] = (int)t;
+            } else if (o.sp[1].kind == DSP_ARG_INPUT && io[o.sp[1].index].dtype == DSP_F32) {
+                A.walk_from[n_walk] = 3;
+                walk_ts_io[n_walk] = o.sp[1].index;
+                A.walk_ts_stride[n_walk] = io[o.sp[1].index].row_stride;
+            } else if (from_walk >= 0) {
+                A.walk_from[n_walk] = 4 + from_walk;
             } else {
                 return false;
             }
@@ -230,7 +256,12 @@ static bool match_reduce_ops(ChainPlan* ch, const dsp_op* ops, int first, int n_
     for (int k = 0; k < DSP_REDUCE_WALKS; ++k) {
         ch->dio_walk[k] = -1;
         ch->dio_walk_thr[k] = walk_thr_io[k];
+        ch->dio_walk_ts[k] = walk_ts_io[k];
     }
+    A.n_walks = n_walk;
+    for (const Scaled& c : scaled)  // (a fraction that something other than a walk reads -- a store -- is the program's business)
+        for (int j = i; j < n_ops; ++j)
+            if (ops[j].opcode == DSP_OP_STORE_SCALAR && ops[j].ip[0] == c.reg) return false;
     for (int k = 0; k < 5; ++k) ch->dio_out[k] = -1;
     for (int k = 0; k < DSP_REDUCE_PICKS; ++k) ch->dio_pick[k] = -1;
     for (; i < n_ops; ++i) {
@@ -257,9 +288,15 @@ static bool match_reduce_ops(ChainPlan* ch, const dsp_op* ops, int first, int n_
             }
         if (!placed) return false;  // (a register stored twice, or one nothing here made)
     }
-    for (int k = 0; k < n_walk; ++k)
-        if (ch->dio_walk[k] < 0) return false;  // (a walk nobody stores: the program's business)
+    for (int k = 0; k < n_walk; ++k) {
+        bool feeds = false;
+        for (int j = k + 1; j < n_walk; ++j) feeds |= A.walk_from[j] == 4 + k;
+        if (ch->dio_walk[k] < 0 && !feeds) return false;  // (a walk nobody stores or starts from: the program's business)
+    }
     A.len = len;
+    // does anything need the whole row?  The extremes, a pick-off's NaN rule -- or the walks' own NaN rule unless the caller says a row is NaN
+    // from its first sample on or not at all (the caller of match_reduce_ops sets need_stream = 1 where it has no such promise)
+    A.need_stream = (reg_of_out[0] >= 0 || reg_of_out[4] >= 0 || n_pick > 0) ? 1 : 0;
     return true;
 }
 
@@ -271,6 +308,7 @@ static bool match_reduce_shape(ChainPlan* ch, const dsp_op* ops, int n_ops, cons
         return false;
     ReduceArgs& A = ch->red;
     if (!match_reduce_ops(ch, ops, 1, n_ops, ld.dst, w.len, io, A)) return false;
+    if (!(ld.ip[2] & 1) && w.dtype == DSP_F32) A.need_stream = 1;  // (float rows without the promise of LOAD ip[2]: a NaN may sit anywhere)
     const int es = w.dtype == DSP_F32 ? 4 : 2;
     A.wf_stride = w.row_stride;
     A.wf_offset = w.offset;
@@ -524,9 +562,10 @@ static bool match_fir_runs_shape(ChainPlan* ch, const dsp_op* ops, int n_ops, co
     }
     for (int k = 0; k < 5; ++k) ch->dio_out[k] = -1;
     for (int k = 0; k < DSP_REDUCE_PICKS; ++k) ch->dio_pick[k] = -1;
-    for (int k = 0; k < DSP_REDUCE_WALKS; ++k) ch->dio_walk[k] = ch->dio_walk_thr[k] = -1;
+    for (int k = 0; k < DSP_REDUCE_WALKS; ++k) ch->dio_walk[k] = ch->dio_walk_thr[k] = ch->dio_walk_ts[k] = -1;
     if (!rest.empty()) {
         if (!match_reduce_ops(ch, rest.data(), 0, (int)rest.size(), o.dst, P, io, A.red)) return false;
+        A.red.need_stream = 1;
         A.has_red = 1;
     } else if (!A.keep) {
         return false;

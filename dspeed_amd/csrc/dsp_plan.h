@@ -131,7 +131,8 @@ struct ChainPlan {
     bool red_ok = false;
     ReduceArgs red{};
     int dio_wf = -1, dio_out[5] = {-1, -1, -1, -1, -1}, dio_pick[DSP_REDUCE_PICKS] = {-1, -1, -1, -1}, red_dtype = DSP_F32;
-    int dio_walk[DSP_REDUCE_WALKS] = {-1, -1}, dio_walk_thr[DSP_REDUCE_WALKS] = {-1, -1};
+    int dio_walk[DSP_REDUCE_WALKS] = {-1, -1, -1, -1, -1, -1}, dio_walk_thr[DSP_REDUCE_WALKS] = {-1, -1, -1, -1, -1, -1},
+        dio_walk_ts[DSP_REDUCE_WALKS] = {-1, -1, -1, -1, -1, -1};
     bool red_vec = false;  // rows keep 16-byte alignment and hold whole 16-byte vectors
     // run-length FIR with the reductions of its output (dsp_fir_runs.hip); the reductions' bindings are dio_* above
     bool runs_ok = false;

@@ -184,7 +184,7 @@ struct PzArgs {
 // arguments of the streaming reductions (dsp_reduce.hip), filled by dsp_chain_execute when a program has the shape
 //   LOAD -> {MIN_MAX | AMAX | PICKOFF at a constant integral time | TIME_POINT_THRESH from a constant sample or from the extremes}+ -> STORE_SCALARs
 #define DSP_REDUCE_PICKS 4
-#define DSP_REDUCE_WALKS 2
+#define DSP_REDUCE_WALKS 6
 struct ReduceArgs {
     const void* wf;          // float32 / int16 / uint16 rows
     int64_t wf_stride;
@@ -201,9 +201,18 @@ struct ReduceArgs {
     const float* walk_thr[DSP_REDUCE_WALKS];  // threshold column, or null: walk_thr_const
     int64_t walk_thr_stride[DSP_REDUCE_WALKS];
     float walk_thr_const[DSP_REDUCE_WALKS];
-    int32_t walk_from[DSP_REDUCE_WALKS];      // 0: walk_start, 1: t_min, 2: t_max
+    int32_t walk_from[DSP_REDUCE_WALKS];      // 0: walk_start, 1: t_min, 2: t_max, 3: the column walk_ts, 4 + j: where walk j (an earlier one) ended
     int32_t walk_start[DSP_REDUCE_WALKS];
     int32_t walk_forward[DSP_REDUCE_WALKS];
+    // round 4: the rise-time walks of a recipe as a launch of their own behind its program (thousands of rows in flight instead of four a CU) --
+    // thresholds that are a fraction of a per-event value (the column times walk_thr_factor: one float multiplication, as SCALAR_AFFINE makes it),
+    // starts that are a column or where an earlier walk ended (checked like the processor's: DSPFatal for a fractional or outside start)
+    float walk_thr_factor[DSP_REDUCE_WALKS];
+    int32_t walk_thr_scaled[DSP_REDUCE_WALKS];
+    const float* walk_ts[DSP_REDUCE_WALKS];
+    int64_t walk_ts_stride[DSP_REDUCE_WALKS];
+    int32_t n_walks;
+    int32_t need_stream;  // 0: nothing asks for the whole row (walks only, on rows that are NaN from the first sample on or NaN-free: LOAD ip[2])
 };
 
 // arguments of the matrix-core FIR kernel (dsp_fir_mfma.hip): convolve_wf 'v' + numpy.amax of up to DSP_FIR_MAXK kernels on one waveform

@@ -35,7 +35,7 @@ struct RowVec<uint16_t> {
 
 // VEC: row starts, stride and length are whole 16-byte vectors (every Ge waveform is); otherwise a sample per lane and load
 template <typename IN, bool VEC>
-__global__ void __launch_bounds__(256) dsp_reduce_kernel(ReduceArgs A, int64_t n_wf) {
+__global__ void __launch_bounds__(256) dsp_reduce_kernel(ReduceArgs A, int64_t n_wf, int* err) {
     constexpr int N = VEC ? RowVec<IN>::N : 1;
     typedef typename RowVec<IN>::vec vec;
     const int lane = lane_id();
@@ -49,7 +49,10 @@ __global__ void __launch_bounds__(256) dsp_reduce_kernel(ReduceArgs A, int64_t n
     e.nan = false;
     // samples [g * 64 * N + lane * N, + N) of group g; four groups requested before the first is looked at
     const int per_group = 64 * N, n_groups = (n + per_group - 1) / per_group;
-    if constexpr (VEC) {
+    if (!A.need_stream) {
+        // walks only, on rows that are NaN from the first sample on or NaN-free (what pole_zero writes): nothing reads the whole row
+        e.nan = (float)w[0] != (float)w[0];
+    } else if constexpr (VEC) {
         const vec* wv = (const vec*)w;
         for (int g0 = 0; g0 < n_groups; g0 += 4) {
             vec x[4];
@@ -80,28 +83,28 @@ __global__ void __launch_bounds__(256) dsp_reduce_kernel(ReduceArgs A, int64_t n
             }
         }
     }
-    reduce_finish<IN>(A, row, e, w, n, lane);
+    reduce_finish<IN>(A, row, e, w, n, lane, err);
 }
 
 }  // namespace
 
 template <typename IN>
-static void launch_reduce(const ReduceArgs* A, int64_t n_wf, int vec, hipStream_t stream) {
+static void launch_reduce(const ReduceArgs* A, int64_t n_wf, int vec, int* err, hipStream_t stream) {
     const unsigned blocks = (unsigned)((n_wf + 3) / 4);  // a wavefront per row, four to a workgroup
     if (vec)
-        hipLaunchKernelGGL((dsp_reduce_kernel<IN, true>), dim3(blocks), dim3(256), 0, stream, *A, n_wf);
+        hipLaunchKernelGGL((dsp_reduce_kernel<IN, true>), dim3(blocks), dim3(256), 0, stream, *A, n_wf, err);
     else
-        hipLaunchKernelGGL((dsp_reduce_kernel<IN, false>), dim3(blocks), dim3(256), 0, stream, *A, n_wf);
+        hipLaunchKernelGGL((dsp_reduce_kernel<IN, false>), dim3(blocks), dim3(256), 0, stream, *A, n_wf, err);
 }
 
-extern "C" int dsp_internal_launch_reduce(const ReduceArgs* A, int64_t n_wf, int dtype, int vec, hipStream_t stream) {
+extern "C" int dsp_internal_launch_reduce(const ReduceArgs* A, int64_t n_wf, int dtype, int vec, int* err, hipStream_t stream) {
     if (n_wf <= 0) return 0;
     if (dtype == DSP_F32)
-        launch_reduce<float>(A, n_wf, vec, stream);
+        launch_reduce<float>(A, n_wf, vec, err, stream);
     else if (dtype == DSP_I16)
-        launch_reduce<int16_t>(A, n_wf, vec, stream);
+        launch_reduce<int16_t>(A, n_wf, vec, err, stream);
     else
-        launch_reduce<uint16_t>(A, n_wf, vec, stream);
+        launch_reduce<uint16_t>(A, n_wf, vec, err, stream);
     return (int)hipGetLastError();
 }
 

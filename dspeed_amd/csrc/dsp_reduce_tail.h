@@ -29,7 +29,7 @@ __device__ __forceinline__ void take(Extremes& e, float v, int i, bool live) {
 // every lane holds the extremes of the samples it saw; `w`: the row (readable by every lane: in HBM or the caches), n samples
 // (ARGS: ReduceArgs wherever the kernel holds it -- a by-value argument or the kernel-argument segment)
 template <typename IN, typename ARGS>
-__device__ __forceinline__ void reduce_finish(ARGS& A, int64_t row, Extremes e, const IN* w, int n, int lane) {
+__device__ __forceinline__ void reduce_finish(ARGS& A, int64_t row, Extremes e, const IN* w, int n, int lane, int* err = nullptr) {
     // across the wavefront: smaller value, then smaller index
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -49,13 +49,35 @@ __device__ __forceinline__ void reduce_finish(ARGS& A, int64_t row, Extremes e, 
 #pragma unroll
     for (int k = 0; k < DSP_REDUCE_WALKS; ++k) {
         walked[k] = quiet_nan<float>();
-        if (!A.walk_out[k]) continue;  // (uniform)
-        const float thr = A.walk_thr[k] ? A.walk_thr[k][row * A.walk_thr_stride[k]] : A.walk_thr_const[k];
-        const int ts = A.walk_from[k] == 1 ? e.imin : (A.walk_from[k] == 2 ? e.imax : A.walk_start[k]);
+        if (k >= A.n_walks) continue;  // (uniform)
+        float thr = A.walk_thr[k] ? A.walk_thr[k][row * A.walk_thr_stride[k]] : A.walk_thr_const[k];
+        if (A.walk_thr_scaled[k]) thr = thr * A.walk_thr_factor[k];
+        const int from = A.walk_from[k];
+        int ts = from == 1 ? e.imin : (from == 2 ? e.imax : A.walk_start[k]);
+        if (from >= 3) {  // a start that is a per-event value: the processor's own checks (time_point_thresh.py:60-74)
+            float ts_f = from == 3 ? A.walk_ts[k][row * A.walk_ts_stride[k]] : quiet_nan<float>();
+#pragma unroll
+            for (int j = 0; j < k; ++j)
+                if (from == 4 + j) ts_f = walked[j];
+            if (any_nan || thr != thr || ts_f != ts_f) continue;
+            int code = 0;
+            if (floorf(ts_f) != ts_f) code = DSP_E_TPT_START_INT;
+            else if (ts_f < 0.0f || ts_f >= (float)n) code = DSP_E_TPT_RANGE;
+            if (code) {
+                if (err && lane == 0 && atomicCAS(&err[0], 0, code) == 0) {
+                    err[1] = (int)(row & 0xffffffffll);
+                    err[2] = (int)(row >> 32);
+                }
+                continue;
+            }
+            ts = (int)ts_f;
+        }
         if (any_nan || thr != thr) continue;
         int found = -1;
+        // the first two steps one at a time (where the walks of real pulses end), then four steps a round with their eight loads in flight
         if (A.walk_forward[k]) {  // smallest i in [ts, n - 2] with w[i] <= thr < w[i+1] or w[i] >= thr > w[i+1]
-            for (int b = ts; b <= n - 2 && found < 0; b += 64) {
+            int b = ts;
+            for (int s = 0; s < 2 && b <= n - 2 && found < 0; ++s, b += 64) {
                 const int i = b + lane;
                 bool hit = false;
                 if (i <= n - 2) {
@@ -65,8 +87,25 @@ __device__ __forceinline__ void reduce_finish(ARGS& A, int64_t row, Extremes e, 
                 const unsigned long long m = __ballot(hit);
                 if (m) found = b + __builtin_ctzll(m);
             }
+            for (; b <= n - 2 && found < 0; b += 256) {
+                float cur[4], nxt[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = b + 64 * q + lane, ic = i <= n - 2 ? i : n - 2;
+                    cur[q] = (float)w[ic];
+                    nxt[q] = (float)w[ic + 1];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = b + 64 * q + lane;
+                    const bool hit = i <= n - 2 && ((cur[q] <= thr && thr < nxt[q]) || (cur[q] >= thr && thr > nxt[q]));
+                    const unsigned long long m = __ballot(hit);
+                    if (m && found < 0) found = b + 64 * q + __builtin_ctzll(m);
+                }
+            }
         } else {  // largest i in [1, ts] with w[i-1] < thr <= w[i] or w[i-1] > thr >= w[i]
-            for (int b = ts; b >= 1 && found < 0; b -= 64) {
+            int b = ts;
+            for (int s = 0; s < 2 && b >= 1 && found < 0; ++s, b -= 64) {
                 const int i = b - lane;
                 bool hit = false;
                 if (i >= 1) {
@@ -75,6 +114,22 @@ __device__ __forceinline__ void reduce_finish(ARGS& A, int64_t row, Extremes e, 
                 }
                 const unsigned long long m = __ballot(hit);
                 if (m) found = b - __builtin_ctzll(m);
+            }
+            for (; b >= 1 && found < 0; b -= 256) {
+                float cur[4], prv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = b - 64 * q - lane, ic = i >= 1 ? i : 1;
+                    cur[q] = (float)w[ic];
+                    prv[q] = (float)w[ic - 1];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = b - 64 * q - lane;
+                    const bool hit = i >= 1 && ((prv[q] < thr && thr <= cur[q]) || (prv[q] > thr && thr >= cur[q]));
+                    const unsigned long long m = __ballot(hit);
+                    if (m && found < 0) found = b - 64 * q - __builtin_ctzll(m);
+                }
             }
         }
         if (found >= 0) walked[k] = (float)found;

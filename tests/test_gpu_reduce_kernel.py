@@ -155,3 +155,79 @@ def test_ge_recipe_reads_them_off_the_rows(monkeypatch):
         assert np.array_equal(np.asarray(out[k]), np.asarray(ref[k]), equal_nan=True), k
     t_min, t_max, a_min, a_max, rc = oracle.min_max(wf.astype(np.float32))
     assert np.array_equal(out["wf_min"], a_min) and np.array_equal(out["wf_max"], a_max)
+
+
+@pytest.mark.parametrize("promise", [1, 0])
+def test_walks_from_per_event_starts_with_fractions_of_a_column_as_thresholds(promise):
+    """the rise-time walks of a recipe as a launch of their own: time_point_thresh (time_point_thresh.py:12-92) whose threshold is a fraction of a
+    per-event column (SCALAR_AFFINE in front of it) and whose start is a column or where an earlier walk ended -- a chain of four and one beside
+    it, as the Ge recipes have them.  Comparisons and one float multiplication: the interpreter's bits, and the oracle's walk by walk; a
+    fractional or outside start is the processor's DSPFatal, a NaN operand a NaN."""
+    from dspeed_amd import _lib
+    from dspeed_amd.chain import Chain, Program, Scalar
+    from dspeed_amd.device import DeviceArray
+    from dspeed_amd.errors import DSPFatal
+
+    rng = np.random.default_rng(77 + promise)
+    n, L = 1500, 8192
+    i = np.arange(L)[None, :]
+    t0 = np.floor(rng.uniform(0.3, 0.6, (n, 1)) * L)
+    rise = rng.uniform(1, 60, (n, 1))
+    amp = rng.uniform(500, 15000, (n, 1))
+    w = (amp * np.clip((i - t0) / rise, 0, 1) * np.exp(-np.clip(i - t0 - rise, 0, None) / 30000.0) + 4.0 * rng.standard_normal((n, L))).astype(np.float32)
+    peak = w.max(axis=1).astype(np.float32)
+    ts = (t0[:, 0] - 40).astype(np.float32)
+    w[3] = np.nan             # a NaN waveform
+    peak[4] = np.nan          # a NaN threshold
+    ts[5] = np.nan            # a NaN start
+    w[6] = 0.0                # nothing to cross: the first walk finds nothing, the walks that start from it are NaN
+    p = Program()
+    p.slots = [L]
+    p.n_sregs = 12
+    wf = p.add_io("wf", _lib.IO_WF_IN, np.float32, L, 0, L)
+    pk = p.add_io("peak", _lib.IO_SCALAR_IN, np.float32)
+    st = p.add_io("ts", _lib.IO_SCALAR_IN, np.float32)
+    p.add_op(_lib.OP_LOAD, dst=0, io=wf, ip=(0, 0, promise))
+    p.add_op(_lib.OP_SCALAR_AFFINE, dst=8, sp=(Scalar.input(pk), Scalar.const(0.99), Scalar.const(-0.0)))
+    p.add_op(_lib.OP_TIME_POINT_THRESH, dst=0, src=0, sp=(Scalar.reg(8), Scalar.input(st), Scalar.const(1.0)))   # forward from the column
+    for k, frac in enumerate((0.9, 0.5, 0.1)):                                                                    # backward, each from the one before
+        p.add_op(_lib.OP_SCALAR_AFFINE, dst=9 + k, sp=(Scalar.input(pk), Scalar.const(frac), Scalar.const(0.0)))
+        p.add_op(_lib.OP_TIME_POINT_THRESH, dst=1 + k, src=0, sp=(Scalar.reg(9 + k), Scalar.reg(k), Scalar.const(0.0)))
+    p.add_op(_lib.OP_TIME_POINT_THRESH, dst=4, src=0, sp=(Scalar.input(pk), Scalar.input(st), Scalar.const(1.0)))  # the peak itself, forward
+    outs = [f"walk{k}" for k in range(5)]
+    for k, name in enumerate(outs):
+        p.add_op(_lib.OP_STORE_SCALAR, io=p.add_io(name, _lib.IO_SCALAR_OUT, np.float32), ip=(k,))
+    got = {}
+    for fused in (1, 0):
+        ch = Chain(p, "walks", np.float32)
+        assert ch.set_fused(fused) == bool(fused) and ("dsp_reduce_kernel" in ch.kernel_name) == bool(fused), ch.kernel_name
+        bufs = {"wf": DeviceArray.from_numpy(w), "peak": DeviceArray.from_numpy(peak), "ts": DeviceArray.from_numpy(ts)}
+        bufs.update({name: DeviceArray.zeros((n,), np.float32) for name in outs})
+        ch.execute(bufs, n)
+        ch.check()
+        got[fused] = {name: bufs[name].to_numpy() for name in outs}
+    for name in outs:
+        np.testing.assert_array_equal(got[1][name], got[0][name], err_msg=name)
+    # the oracle, walk by walk (its inputs: the float32 thresholds the device formed)
+    g = got[1]
+    starts = [ts, g["walk0"], g["walk1"], g["walk2"], ts]
+    thrs = [np.float32(0.99) * peak, np.float32(0.9) * peak, np.float32(0.5) * peak, np.float32(0.1) * peak, peak]
+    for k in range(5):
+        ok = ~(np.isnan(starts[k]) | np.isnan(thrs[k]) | np.isnan(w).any(axis=1))
+        want = np.full(n, np.nan, np.float32)
+        res, rc = oracle.time_point_thresh(w[ok], thrs[k][ok], starts[k][ok], 1.0 if k in (0, 4) else 0.0)
+        assert rc == 0
+        want[ok] = res
+        np.testing.assert_array_equal(g[f"walk{k}"], want, err_msg=f"walk{k}")
+    assert np.isnan(g["walk0"][[3, 4, 5, 6]]).all() and np.isnan(g["walk3"][6]) and (~np.isnan(g["walk3"])).sum() > n // 2
+    # the processor's DSPFatal for a start between two samples / outside the waveform, with its row
+    for bad, row in ((1234.5, 17), (float(L), 18), (-1.0, 19)):
+        ts2 = ts.copy()
+        ts2[row] = bad
+        ch = Chain(p, "walks", np.float32)
+        bufs = {"wf": DeviceArray.from_numpy(w), "peak": DeviceArray.from_numpy(peak), "ts": DeviceArray.from_numpy(ts2)}
+        bufs.update({name: DeviceArray.zeros((n,), np.float32) for name in outs})
+        ch.execute(bufs, n)
+        with pytest.raises(DSPFatal) as e:
+            ch.check()
+        assert e.value.wf_range is not None and row in e.value.wf_range, (bad, e.value.wf_range)
