@@ -1500,9 +1500,12 @@ def _compile(b: _Builder, out_pars, n_rows, proc_strings, stage_mode=False):
         head = _split_scalar_head(p, ft, ext_alias)
         if head is not None:
             stages.append(head)
+    walks = None
+    if not stage_mode and os.environ.get("DSPEED_HIP_NO_WALKS_BEHIND", "0") != "1":
+        walks = _split_walks(p, ft)
     from .processing_chain import ProcessingChain  # (the runtime imports this module)
 
-    chain = ProcessingChain(p, in_bind, out_bind, consts, n_rows, proc_strings, ft, aux_desc, stages=stages, ext_alias=ext_alias, tail=tail)
+    chain = ProcessingChain(p, in_bind, out_bind, consts, n_rows, proc_strings, ft, aux_desc, stages=stages, ext_alias=ext_alias, tail=tail, walks=walks)
     chain.vector_lens = vector_lens  # variable-length outputs -> the input column that holds their per-event lengths
     return chain, tb_out
 
@@ -1610,6 +1613,142 @@ def _split_scalar_head(p: Program, ft, ext_alias: dict):
     names = [io[0] for io in h.io if io[1] == _lib.IO_SCALAR_IN]
     return {"what": "per-event arithmetic ahead of the program", "program": h, "consts": {}, "in_vars": {}, "alias": {n: ext_alias.get(n, n) for n in names},
             "outs": [("out:" + name, "in:" + name, None) for name, _r, used in made if used], "chain": None, "bufs": {}}
+
+
+#: the rise-time walks leave a program whose waveform has at least this many samples (LDS then holds a handful of rows per CU)
+WALKS_BEHIND_MIN_SAMPLES = 4096
+#: walks the reductions kernel takes in one program (DSP_REDUCE_WALKS of csrc/dsp_program.h)
+WALKS_BEHIND_MAX = 6
+
+
+def _split_walks(p: Program, ft):
+    """The threshold walks of a program that only reads its one long waveform -- the rise times of the Ge recipes: time_point_thresh at 0.99 /
+    0.9 / 0.5 / 0.1 of the trapezoid's maximum, each from where the one before ended -- run behind the program as a launch of their own
+    (dsp_reduce.hip: a wavefront per row straight off HBM, thousands of rows in flight) instead of in it, where LDS holds four 8192-sample
+    rows per CU and the row's wavefronts wait for the chain *trapezoid -> maximum -> walks* (2.1 of 14.2 ms of the Ge recipe's pass on the
+    synthetic rows, whose tp_100 walk runs to the end of the waveform; 0.6 - 0.9 on pulses with a rise time).  The per-event values the walks
+    start from or scale (the maximum) are handed over as columns (``walk:r<k>``); the stores of the walks' results move along.  ``p`` is
+    changed in place; returns {"program", "handover"} or None."""
+    from .chain import plan
+
+    ops = p.ops
+    if len(p.slots) != 1 or not ops or ops[0][0] != _lib.OP_LOAD or p.slots[0] < WALKS_BEHIND_MIN_SAMPLES:
+        return None
+    slot = ops[0][1]
+    TPT, AFF, STS = _lib.OP_TIME_POINT_THRESH, _lib.OP_SCALAR_AFFINE, _lib.OP_STORE_SCALAR
+
+    def writes_of(op):
+        opcode, dst, _src, io, ip, _sp = op
+        if opcode in (STS, _lib.OP_LOAD, _lib.OP_STORE):
+            return []
+        if opcode == _lib.OP_MIN_MAX:
+            return [dst + k for k in range(4)]
+        if opcode == _lib.OP_TRAP_REDUCE:
+            w = [dst + k for k in range(4)] if dst >= 0 else []
+            if io >= 0:
+                w.append(io)
+            if ((ip[3] >> 16) & 0x3fff) - 1 >= 0:
+                w.append(((ip[3] >> 16) & 0x3fff) - 1)
+            return w
+        return [dst]
+
+    n_writes = {}
+    for op in ops:
+        for r in writes_of(op):
+            n_writes[r] = n_writes.get(r, 0) + 1
+    writer = {r: k for k, op in enumerate(ops) for r in writes_of(op)}
+
+    def readers(r):
+        return [(k, j) for k, op in enumerate(ops) for j, a in enumerate(op[5]) if a.kind == _lib.ARG_REG and a.index == r] + \
+               [(k, -1) for k, op in enumerate(ops) if op[0] == STS and op[4][0] == r]
+
+    number = lambda a: a.kind == _lib.ARG_CONST  # noqa: E731
+    walks = [k for k, op in enumerate(ops) if op[0] == TPT and op[2] == slot and number(op[5][2]) and op[5][2].value in (0.0, 1.0)]
+    scales = set()
+    changed = True
+    while changed:  # a walk stays if its result is read by anything but a store or a moving walk's start; a fraction if anything else reads it
+        changed = False
+        for k in list(walks):
+            d = ops[k][1]
+            fine = n_writes.get(d, 0) == 1 and all(j == -1 or (kk in walks and j == 1) for kk, j in readers(d))
+            for j in (0, 1):  # threshold, start
+                a = ops[k][5][j]
+                if a.kind != _lib.ARG_REG:
+                    continue
+                src = writer.get(a.index)
+                if src is None or n_writes.get(a.index, 0) != 1 or src > k:
+                    fine = False
+                elif ops[src][0] == TPT and src in walks:
+                    fine = fine and j == 1
+                elif (j == 0 and ops[src][0] == AFF and number(ops[src][5][1]) and number(ops[src][5][2]) and ops[src][5][2].value == 0.0
+                      and ops[src][5][0].kind in (_lib.ARG_REG, _lib.ARG_INPUT) and all(kk in walks and jj == 0 for kk, jj in readers(a.index))):
+                    x = ops[src][5][0]
+                    if x.kind == _lib.ARG_REG and (n_writes.get(x.index, 0) != 1 or writer[x.index] > src or ops[writer[x.index]][0] in (TPT, AFF)):
+                        fine = False
+                elif ops[src][0] in (TPT, AFF):
+                    fine = False  # (a walk that stays, or arithmetic of another form: the program's)
+            if not fine:
+                walks.remove(k)
+                changed = True
+    if not 2 <= len(walks) <= WALKS_BEHIND_MAX:
+        return None
+    for k in walks:
+        a = ops[k][5][0]
+        if a.kind == _lib.ARG_REG and ops[writer[a.index]][0] == AFF:
+            scales.add(writer[a.index])
+    moved = set(walks) | scales
+    walk_regs = {ops[k][1] for k in walks}
+    stores = [k for k, op in enumerate(ops) if op[0] == STS and op[4][0] in walk_regs]
+    # what the walks read of the program: registers made by ops that stay -> columns
+    handed = []
+    for k in sorted(moved):
+        for a in ops[k][5][:2] if ops[k][0] == TPT else ops[k][5][:1]:
+            if a.kind == _lib.ARG_REG and writer[a.index] not in moved and a.index not in handed:
+                handed.append(a.index)
+    w = Program()
+    w.n_sregs = p.n_sregs
+    w.slots = list(p.slots)
+    io_map = {}
+
+    def w_io(idx):
+        if idx not in io_map:
+            name, kind, code, length, offset, stride = p.io[idx]
+            io_map[idx] = w.add_io(name, kind, code, length, offset, stride)
+        return io_map[idx]
+
+    col = {r: w.add_io(f"walk:r{r}", _lib.IO_SCALAR_IN, ft) for r in handed}
+
+    def operand(a):
+        if a.kind == _lib.ARG_INPUT:
+            return Scalar.input(w_io(a.index))
+        if a.kind == _lib.ARG_REG and a.index in col:
+            return Scalar.input(col[a.index])
+        return a
+
+    ld = ops[0]
+    w.add_op(_lib.OP_LOAD, dst=ld[1], src=ld[2], io=w_io(ld[3]), ip=ld[4], sp=ld[5])
+    for k in sorted(moved):
+        opcode, dst, src, io, ip, sp = ops[k]
+        w.add_op(opcode, dst=dst, src=src, io=io, ip=ip, sp=tuple(operand(a) for a in sp))
+    for k in stores:
+        opcode, dst, src, io, ip, sp = ops[k]
+        w.add_op(opcode, dst=dst, src=src, io=w_io(io), ip=ip, sp=sp)
+    try:
+        if "dsp_reduce_kernel" not in plan(w, ft)["kernel"]:
+            return None
+    except Exception:  # noqa: BLE001  (a form the planner refuses: the walks stay where they were)
+        return None
+    gone = moved | set(stores)
+    kept = [op for k, op in enumerate(ops) if k not in gone]
+    del ops[:]
+    ops.extend(kept)
+    handover = []
+    for r in handed:
+        handover.append(f"walk:r{r}")
+        p.add_op(STS, io=p.add_io(f"walk:r{r}", _lib.IO_SCALAR_OUT, ft), ip=(r,))
+    if len(p.io) > _lib.MAX_IO or len(w.io) > _lib.MAX_IO:
+        raise NotImplementedError("recipe is too large for one device chain (ops/slots/bindings limit)")
+    return {"program": w, "handover": handover}
 
 
 def _split_scalar_tail(p: Program, ft):

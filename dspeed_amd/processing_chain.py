@@ -56,9 +56,10 @@ class ProcessingChain:
     (processing_chain.py:665-673); ``__call__(tb_in, tb_out)`` relinks I/O like :675-716."""
 
     def __init__(self, program: Program, inputs: dict, outputs: dict, consts: dict, buffer_len: int, proc_strings: list[str],
-                 loop_dtype=np.float32, aux=(), stages=(), ext_alias=None, tail=None):
+                 loop_dtype=np.float32, aux=(), stages=(), ext_alias=None, tail=None, walks=None):
         self._program = program
         self._tail = tail         # the program's all-scalar tail as a program of its own, run behind it with a row per lane (_split_scalar_tail)
+        self._walks = walks       # the program's threshold walks as a program of their own, run behind it off the rows in HBM (_split_walks)
         self.loop_dtype = np.dtype(loop_dtype)  # float32 or float64 gufunc loop of the whole chain
         self._in_vars = inputs      # binding name -> Var (source column)
         self._out_vars = outputs    # binding name -> (Var, length or None)
@@ -102,6 +103,8 @@ class ProcessingChain:
         rep = [(f"linear_slope_fit x {len(g['fits'])} on the rows of {g['wf']}", "dsp_fit_rows_kernel") for g in self._aux]
         rep += [(st["what"], st["chain"].kernel_name) for st in self._stages]
         rep.append(("program", self._chain.kernel_name))
+        if self._lanes and self._lanes[0].walks is not None:
+            rep.append(("threshold walks behind the program", self._lanes[0].walks.kernel_name))
         if self._lanes and self._lanes[0].tail is not None:
             rep.append(("scalar tail of the program", self._lanes[0].tail.kernel_name))
         return rep
@@ -145,7 +148,7 @@ class ProcessingChain:
                 st["dev"] = {name: DeviceArray.from_numpy(arr) for name, arr in st["consts"].items()}
             self._lanes = [SimpleNamespace(stream=self._stream, chain=self._chain, stage_chains=[st["chain"] for st in self._stages],
                                            stage_bufs=[st["bufs"] for st in self._stages], aux_bufs=self._aux_bufs, tail=self._tail_chain(0),
-                                           tail_bufs={})]
+                                           tail_bufs={}, walks=self._walks_chain(0))]
             self._pair_stages(self._lanes[0].stage_chains)
             for what, ch in [(st["what"], st["chain"]) for st in self._stages] + [("program", self._chain)]:
                 if ch.kernel_note:
@@ -166,6 +169,13 @@ class ProcessingChain:
                 if made & set(self._stages[j]["alias"].values()) or same_input:
                     stage_chains[i].share_row_scales(stage_chains[j])
 
+    def _walks_chain(self, lane_no: int):
+        if self._walks is None:
+            return None
+        ch = Chain(self._walks["program"], f"processing_chain threshold walks (lane {lane_no})", self.loop_dtype)
+        ch.set_async_check(True)
+        return ch
+
     def _tail_chain(self, lane_no: int):
         if self._tail is None:
             return None
@@ -180,9 +190,8 @@ class ProcessingChain:
         lane.tail.execute(bufs, m, stream)
 
     def _handover_bufs(self, bufs: dict, m: int, lane) -> None:
-        if self._tail is None:
-            return
-        for name in self._tail["handover"]:
+        names = (self._tail["handover"] if self._tail is not None else []) + (self._walks["handover"] if self._walks is not None else [])
+        for name in names:
             buf = lane.tail_bufs.get(name)
             if buf is None or buf.shape[0] < m:
                 buf = lane.tail_bufs[name] = DeviceArray((m,), self.loop_dtype)
@@ -202,7 +211,7 @@ class ProcessingChain:
                 stage_chains.append(c)
             self._pair_stages(stage_chains)
             self._lanes.append(SimpleNamespace(stream=Stream(), chain=ch, stage_chains=stage_chains, stage_bufs=[{} for _ in self._stages],
-                                               aux_bufs={}, tail=self._tail_chain(len(self._lanes)), tail_bufs={}))
+                                               aux_bufs={}, tail=self._tail_chain(len(self._lanes)), tail_bufs={}, walks=self._walks_chain(len(self._lanes))))
         return self._lanes[k]
 
     #: bytes of host-resident I/O per pipelined piece, two pieces in flight.  Tens of MB are enough for the PCIe transfers; the size is set
@@ -272,6 +281,8 @@ class ProcessingChain:
             for ch in lane.stage_chains:
                 ch.check(lane.stream, row_offset=a)
             lane.chain.check(lane.stream, row_offset=a)
+            if lane.walks is not None:
+                lane.walks.check(lane.stream, row_offset=a)
         except DSPFatal as e:  # the reference annotates and re-raises (processing_chain.py:1154-1159)
             if e.wf_range is None:
                 e.wf_range = range(a, b)
@@ -355,6 +366,8 @@ class ProcessingChain:
             self._run_aux(bufs, n, lane.stream, lane)
             self._handover_bufs(bufs, n, lane)
             lane.chain.execute(bufs, n, lane.stream)
+            if lane.walks is not None:
+                lane.walks.execute(bufs, n, lane.stream)
             self._run_tail(bufs, n, lane.stream, lane)
             self._pending = (start, stop, lane)
             if wait:
@@ -409,6 +422,8 @@ class ProcessingChain:
                 for ch in lane.stage_chains:
                     ch.check(lane.stream, row_offset=a)
                 lane.chain.check(lane.stream, row_offset=a)
+                if lane.walks is not None:
+                    lane.walks.check(lane.stream, row_offset=a)
             except DSPFatal as e:  # the reference annotates and re-raises (processing_chain.py:1154-1159)
                 if e.wf_range is None:
                     e.wf_range = range(a, b)
@@ -497,6 +512,8 @@ class ProcessingChain:
                 self._run_aux(bufs, m, s_c, lane)
                 self._handover_bufs(bufs, m, lane)
                 lane.chain.execute(bufs, m, s_c)
+                if lane.walks is not None:
+                    lane.walks.execute(bufs, m, s_c)
                 self._run_tail(bufs, m, s_c, lane)
                 for name, (col, length, direct) in host_out.items():
                     d = bufs[name]
@@ -519,7 +536,7 @@ class ProcessingChain:
                 s_in.sync()
                 for ln in lanes:
                     ln.stream.sync()
-                    for ch in (*ln.stage_chains, ln.chain):  # their error words belong to the abandoned pieces
+                    for ch in (*ln.stage_chains, ln.chain, *([ln.walks] if ln.walks is not None else [])):  # their error words belong to the abandoned pieces
                         try:
                             ch.check(ln.stream)
                         except DSPFatal:

@@ -268,7 +268,7 @@ def test_index_outputs_are_bit_exact_on_the_devices_own_waveforms():
     # (the t0 filter -- piecewise constant -- with min_max and tp_0_est's walk on the run-length FIR kernel: wf_t0_filter is not stored)
     assert [k for _what, k in chain_p.kernels()] == ["dsp_fit_rows_kernel", "dsp_pz_rows_kernel", "dsp_fir_runs_kernel", "dsp_fir_f16_kernel",
                                                      "dsp_rows_kernel", "dsp_current_kernel", "dsp_reduce_kernel",
-                                                     "dsp_scalar_kernel", "dsp_vm_kernel<float>", "dsp_scalar_kernel"]  # (scalar head, program, scalar tail)
+                                                     "dsp_scalar_kernel", "dsp_vm_kernel<float>", "dsp_reduce_kernel", "dsp_scalar_kernel"]  # (scalar head, program, walks, tail)
     seen.update({"tp_aoe_max": True, "A_max": True, "tp_aoe_samp": True})
     cusp_dev = g["wf_cusp"]
     assert all(seen.get(k) for k in recipes.ICPC["outputs"] if k not in ("tp_min", "tp_max", "wf_min", "wf_max", "bl_mean", "bl_slope",
@@ -540,9 +540,10 @@ def test_row_scales_from_the_kernel_that_reads_the_same_rows(monkeypatch):
 
 
 def test_programs_that_shed_ops_give_the_same_bits(monkeypatch):
-    """the scalar head (arithmetic that needs nothing of the program, run ahead of it with a row per lane) and the thresholds folded into the walks
-    (`time_point_thresh(wf, 0.9 * trapTmax, ...)`: the planner drops the multiplication's op and the walk multiplies) change where an operation
-    runs, not the operation: every output bit-identical with either switched off"""
+    """the scalar head (arithmetic that needs nothing of the program, run ahead of it with a row per lane), the thresholds folded into the walks
+    (`time_point_thresh(wf, 0.9 * trapTmax, ...)`: the planner drops the multiplication's op and the walk multiplies) and the rise-time walks as
+    a launch of their own behind the program change where an operation runs, not the operation: every output bit-identical with either switched
+    off"""
     from dspeed_amd.processing_chain import WaveformInput, build_processing_chain
 
     rng = np.random.default_rng(29)
@@ -555,7 +556,7 @@ def test_programs_that_shed_ops_give_the_same_bits(monkeypatch):
     ref = {k: np.array(v) for k, v in out.items()}
     # (and the fits on a stream of their own beside the first stages, or on the lane's stream: DSPEED_HIP_FITS_BESIDE)
     for switch, value in (("DSPEED_HIP_NO_SCALAR_HEAD", "1"), ("DSPEED_HIP_NO_THRESHOLD_FOLD", "1"), ("DSPEED_HIP_NO_SCALAR_TAIL", "1"),
-                          ("DSPEED_HIP_FITS_BESIDE", "0")):
+                          ("DSPEED_HIP_NO_WALKS_BEHIND", "1"), ("DSPEED_HIP_FITS_BESIDE", "0")):
         monkeypatch.setenv(switch, value)
         if switch == "DSPEED_HIP_FITS_BESIDE":
             from dspeed_amd.processing_chain import ProcessingChain

@@ -21,6 +21,7 @@ def _programs_whole(monkeypatch):
     (the test of the split itself takes the switch off again)"""
     monkeypatch.setenv("DSPEED_HIP_NO_SCALAR_TAIL", "1")
     monkeypatch.setenv("DSPEED_HIP_NO_SCALAR_HEAD", "1")
+    monkeypatch.setenv("DSPEED_HIP_NO_WALKS_BEHIND", "1")
 
 
 def _tb(n=4, wf_len=8192, t0=0.0, dtype=np.uint16):
@@ -569,3 +570,26 @@ def test_the_planner_folds_a_thresholds_factor_into_the_walk():
     assert plan(program(offset=1.0))["n_device_ops"] == 6          # an offset: the op stays
     assert plan(program(store_thr=True))["n_device_ops"] == 6      # the threshold itself is an output
     assert plan(program(rewrite_x=True))["n_device_ops"] == 7      # the value the walks would multiply changes before they run
+
+
+def test_the_rise_time_walks_run_behind_the_program(monkeypatch):
+    """_split_walks: the five threshold walks of the Ge recipe's program (0.99 / 0.9 / 0.5 / 0.1 of the trapezoid's maximum, each from where the one
+    before ended, and the maximum itself) leave it for a launch of their own on the reductions kernel, which reads the pole-zero rows straight
+    off HBM with thousands of rows in flight; the maximum is handed over as a column, the walks' stores move along"""
+    for k in ("DSPEED_HIP_NO_SCALAR_TAIL", "DSPEED_HIP_NO_SCALAR_HEAD", "DSPEED_HIP_NO_WALKS_BEHIND"):
+        monkeypatch.delenv(k)
+    chain, _, _ = build_processing_chain(recipes.ICPC, _tb())
+    P, W = chain.program, chain._walks["program"]
+    assert chain._walks["handover"] == ["walk:r3"]
+    assert [o[0] for o in P.ops] == [_lib.OP_LOAD, _lib.OP_TRAP_REDUCE, _lib.OP_TRAP_PICKOFF, _lib.OP_TRAP_REDUCE] + [_lib.OP_STORE_SCALAR] * 5
+    assert [P.io[o[3]][0] for o in P.ops[4:]] == ["tail:r3", "tail:r14", "tail:r18", "tail:r22", "walk:r3"]
+    kinds = [o[0] for o in W.ops]
+    assert kinds == [_lib.OP_LOAD] + [_lib.OP_SCALAR_AFFINE, _lib.OP_TIME_POINT_THRESH] * 4 + [_lib.OP_TIME_POINT_THRESH] + [_lib.OP_STORE_SCALAR] * 5
+    assert W.io[W.ops[0][3]][0] == "in:wf_pz" and W.ops[0][4] == P.ops[0][4], "the same rows, with the load's promise about their NaNs"
+    assert all(W.io[o[5][0].index][0] == "walk:r3" for o in W.ops if o[0] == _lib.OP_SCALAR_AFFINE)
+    assert sorted(W.io[o[3]][0] for o in W.ops if o[0] == _lib.OP_STORE_SCALAR) == sorted(f"tail:r{r}" for r in (5, 7, 9, 11, 12))
+    _check_program_order(P)
+    _check_program_order(W)
+    assert plan(W)["kernel"] == "dsp_reduce_kernel"
+    info = plan(P)
+    assert info["kernel"].startswith("dsp_vm_kernel") and info["team"] == 3 and info["n_device_ops"] == 8  # (LOAD, three trapezoid ops, the members' stores)
