@@ -475,19 +475,35 @@ Prog reduce_shape() {
     dsp_op ld = op0(DSP_OP_LOAD);
     ld.dst = s, ld.io = add_io(p, DSP_IO_WF_IN, pick({DSP_F32, DSP_I16, DSP_U16}), len, off, stride);
     p.ops.push_back(ld);
-    int mm = -1;
+    int mm = -1, last_walk = -1;
     std::vector<int> regs;
-    for (int k = rnd(1, 6); k > 0; --k) {
+    ld.ip[2] = chance(0.5);  // (the promise about the rows' NaNs: walks alone then need no pass over the row)
+    p.ops[0] = ld;
+    for (int k = rnd(1, 8); k > 0; --k) {
         dsp_op o{};
         switch (rnd(0, 3)) {
             case 0: o = op0(DSP_OP_MIN_MAX), o.src = s, o.dst = mm = new_sregs(p, 4); for (int q = 0; q < 4; ++q) regs.push_back(mm + q); break;
             case 1: o = op0(DSP_OP_AMAX), o.src = s, o.dst = new_sregs(p, 1), regs.push_back(o.dst); break;
             case 2: o = op0(DSP_OP_PICKOFF), o.src = s, o.dst = new_sregs(p, 1), o.ip[0] = pick({'i', 'l', 'n'}), o.ip[1] = pick({0, 1}), o.sp[0] = cst(pick({0.0, 50.0, 50.5, (double)len, -1.0})), regs.push_back(o.dst); break;
-            default:
-                o = op0(DSP_OP_TIME_POINT_THRESH), o.src = s, o.dst = new_sregs(p, 1), o.sp[0] = shape_arg(p);
-                o.sp[1] = (mm >= 0 && chance(0.5)) ? dsp_scalar_arg{DSP_ARG_REG, mm + rnd(0, 1), 0.0} : cst(pick({0.0, 100.0, 100.5, -1.0}));
+            default: {
+                // a threshold: a constant, a column, a fraction of a column (SCALAR_AFFINE in front); a start: a constant, an extreme, a column,
+                // where an earlier walk ended
+                dsp_scalar_arg thr = shape_arg(p);
+                if (chance(0.3)) {
+                    dsp_op a = op0(DSP_OP_SCALAR_AFFINE);
+                    a.dst = new_sregs(p, 1), a.sp[0] = shape_arg(p), a.sp[1] = cst(pick({0.9, 0.5, 1.0})), a.sp[2] = cst(pick({0.0, 0.0, -0.0, 1.0}));
+                    p.ops.push_back(a);
+                    thr = dsp_scalar_arg{DSP_ARG_REG, a.dst, 0.0};
+                }
+                o = op0(DSP_OP_TIME_POINT_THRESH), o.src = s, o.dst = new_sregs(p, 1), o.sp[0] = thr;
+                if (mm >= 0 && chance(0.3)) o.sp[1] = dsp_scalar_arg{DSP_ARG_REG, mm + rnd(0, 1), 0.0};
+                else if (last_walk >= 0 && chance(0.4)) o.sp[1] = dsp_scalar_arg{DSP_ARG_REG, last_walk, 0.0};
+                else if (chance(0.3)) o.sp[1] = shape_arg(p);
+                else o.sp[1] = cst(pick({0.0, 100.0, 100.5, -1.0}));
                 o.sp[2] = cst(pick({0.0, 1.0, 0.5}));
                 regs.push_back(o.dst);
+                last_walk = o.dst;
+            }
         }
         p.ops.push_back(o);
     }
@@ -719,6 +735,14 @@ bool check(const Prog& p, const ChainPlan& c) {
             if (c.dio_pick[k] >= 0) REQUIRE(c.red.pick_at[k] >= -1 && c.red.pick_at[k] < c.red.len, "reduce kernel: pick-off at %d of %d", c.red.pick_at[k], c.red.len);
         for (int k = 0; k < DSP_REDUCE_WALKS; ++k)
             if (c.dio_walk[k] >= 0 && c.red.walk_from[k] == 0) REQUIRE(c.red.walk_start[k] >= 0 && c.red.walk_start[k] < c.red.len, "reduce kernel: walk from %d of %d", c.red.walk_start[k], c.red.len);
+        REQUIRE(c.red.n_walks >= 0 && c.red.n_walks <= DSP_REDUCE_WALKS, "reduce kernel: %d walks", c.red.n_walks);
+        for (int k = 0; k < c.red.n_walks; ++k) {
+            const int from = c.red.walk_from[k];
+            REQUIRE(from >= 0 && from < 4 + k, "reduce kernel: walk %d starts from %d", k, from);
+            if (from == 3) REQUIRE(io_ok(c.dio_walk_ts[k], DSP_IO_SCALAR_IN) && p.io[c.dio_walk_ts[k]].dtype == DSP_F32 && c.red.walk_ts_stride[k] == p.io[c.dio_walk_ts[k]].row_stride, "reduce kernel: walk %d's start column", k);
+            if (c.red.walk_thr_scaled[k]) REQUIRE(io_ok(c.dio_walk_thr[k], DSP_IO_SCALAR_IN), "reduce kernel: walk %d scales no column", k);
+        }
+        if (!c.red.need_stream) REQUIRE(c.dio_out[0] < 0 && c.dio_out[4] < 0 && (p.io[c.dio_wf].dtype != DSP_F32 || (p.ops[0].ip[2] & 1)), "reduce kernel: no pass over rows that need one");
     }
     if (c.runs_ok) {
         REQUIRE(!c.red_ok && !c.fir_ok, "run-length FIR beside another kernel of the same program");
