@@ -45,6 +45,7 @@ __device__ __forceinline__ void reduce_finish(ARGS& A, int64_t row, Extremes e, 
     const bool any_nan = wave_any(e.nan);
     // time_point_thresh (time_point_thresh.py:12-92) from a sample known by now: 64 consecutive samples per step, away from the start, until a
     // step holds a crossing -- the row was just read, the walk finds it in the caches.  Comparisons only.
+    constexpr int WR = 8;  // steps per round of a long walk
     float walked[DSP_REDUCE_WALKS];
 #pragma unroll
     for (int k = 0; k < DSP_REDUCE_WALKS; ++k) {
@@ -74,7 +75,7 @@ __device__ __forceinline__ void reduce_finish(ARGS& A, int64_t row, Extremes e, 
         }
         if (any_nan || thr != thr) continue;
         int found = -1;
-        // the first two steps one at a time (where the walks of real pulses end), then four steps a round with their eight loads in flight
+        // the first two steps one at a time (where the walks of real pulses end), then eight steps a round with their sixteen loads in flight
         if (A.walk_forward[k]) {  // smallest i in [ts, n - 2] with w[i] <= thr < w[i+1] or w[i] >= thr > w[i+1]
             int b = ts;
             for (int s = 0; s < 2 && b <= n - 2 && found < 0; ++s, b += 64) {
@@ -87,16 +88,16 @@ __device__ __forceinline__ void reduce_finish(ARGS& A, int64_t row, Extremes e, 
                 const unsigned long long m = __ballot(hit);
                 if (m) found = b + __builtin_ctzll(m);
             }
-            for (; b <= n - 2 && found < 0; b += 256) {
-                float cur[4], nxt[4];
+            for (; b <= n - 2 && found < 0; b += 64 * WR) {
+                float cur[WR], nxt[WR];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < WR; ++q) {
                     const int i = b + 64 * q + lane, ic = i <= n - 2 ? i : n - 2;
                     cur[q] = (float)w[ic];
                     nxt[q] = (float)w[ic + 1];
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < WR; ++q) {
                     const int i = b + 64 * q + lane;
                     const bool hit = i <= n - 2 && ((cur[q] <= thr && thr < nxt[q]) || (cur[q] >= thr && thr > nxt[q]));
                     const unsigned long long m = __ballot(hit);
@@ -115,16 +116,16 @@ __device__ __forceinline__ void reduce_finish(ARGS& A, int64_t row, Extremes e, 
                 const unsigned long long m = __ballot(hit);
                 if (m) found = b - __builtin_ctzll(m);
             }
-            for (; b >= 1 && found < 0; b -= 256) {
-                float cur[4], prv[4];
+            for (; b >= 1 && found < 0; b -= 64 * WR) {
+                float cur[WR], prv[WR];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < WR; ++q) {
                     const int i = b - 64 * q - lane, ic = i >= 1 ? i : 1;
                     cur[q] = (float)w[ic];
                     prv[q] = (float)w[ic - 1];
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < WR; ++q) {
                     const int i = b - 64 * q - lane;
                     const bool hit = i >= 1 && ((prv[q] < thr && thr <= cur[q]) || (prv[q] > thr && thr >= cur[q]));
                     const unsigned long long m = __ballot(hit);
