@@ -1740,6 +1740,8 @@ def _split_walks(p: Program, ft):
         return None
     gone = moved | set(stores)
     kept = [op for k, op in enumerate(ops) if k not in gone]
+    if not any(op[0] not in (_lib.OP_LOAD, STS) for op in kept):
+        return None  # (nothing but the walks read the waveform: the program is theirs)
     del ops[:]
     ops.extend(kept)
     handover = []
