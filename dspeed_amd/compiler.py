@@ -1552,7 +1552,6 @@ def _split_scalar_head(p: Program, ft, ext_alias: dict):
             return w
         return [dst]
 
-    waveform_ops = {_lib.OP_LOAD, _lib.OP_STORE}
     for k, (opcode, dst, src, io, ip, sp) in enumerate(p.ops):
         is_head = (opcode in _SCALAR_OPS and opcode != _lib.OP_STORE_SCALAR
                    and all(a.kind in (_lib.ARG_CONST, _lib.ARG_INPUT) or (a.kind == _lib.ARG_REG and a.index in from_head) for a in sp))
