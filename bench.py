@@ -19,7 +19,8 @@ the ALGORITHMIC bytes of SURVEY.md 8(d): 16 396 B per waveform (4096x4 read + ba
 + energy written) against the 8 TB/s HBM3E peak, from per-launch HIP-event durations on the launch stream.
 `cpu_baseline` times the CPU oracle (C restatement of the reference's numba loops, run the way dspeed's
 ProcessingChain runs them: 16-row blocks, one processor call per block) on a bounded sample of the same batch, on rank 0,
-after the timed region, for every N.
+after the timed region, for every N.  `ge_recipe` (N = 1 only, after the timed region, not part of `value`) is the whole Ge recipe of
+tests/recipes.py (ICPC: 27 outputs, eleven launches a pass) on 131 072 device-resident int16 rows of 8192 samples: ms per pass and waveforms/s.
 
 Multi-process rendezvous uses torch.distributed with the gloo backend only for the barrier and the
 max-over-ranks of the timing: the path has no exchange step, so no RCCL traffic exists to measure.
@@ -73,7 +74,8 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=20)  # (the first ~6 launches after start-up run 5-20 % slower: clocks, first touch)
     ap.add_argument("--rows", type=int, default=0, help="rows per rank (default: 1 000 000 at N=1, 1 250 000 at N>1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the single-thread CPU baseline sample")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg (profiling runs)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the legs beside the timed region: cpu_baseline and the Ge recipe (profiling runs)")
+    ap.add_argument("--no-recipe", action="store_true", help="skip the whole-Ge-recipe leg beside the headline")
     ap.add_argument("--wf-len", type=int, default=0, help="experiment only: other waveform length (trap geometry scaled)")
     ap.add_argument("--dry-run", action="store_true", help="workers skip the device: launcher / rendezvous / bookkeeping only (CPU tests)")
     ap.add_argument("--allow-variants", action="store_true", help="A/B experiments: run although DSPEED_HIP_* kernel switches are set")
@@ -350,6 +352,40 @@ def worker(args) -> int:
     except Exception as exc:  # a measurement extra: never fails the bench line
         print(f"[bench] raw-chain measurement skipped: {exc}", file=sys.stderr)
 
+    # beside the headline, SURVEY 8(f)'s widest row: the whole Ge recipe (tests/recipes.py ICPC, 27 outputs, eleven launches a pass) on
+    # 131 072 device-resident int16 rows of 8192 samples -- the figure DESIGN section 5 quotes, measured here so that the driver's own run holds it.
+    # N=1, rank 0, after the timed region; an extra that never fails the bench line.
+    ge = None
+    if n_gpus == 1 and not (args.no_recipe or args.no_cpu or args.wf_len or args.rows):
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import recipes
+            from dspeed_amd.processing_chain import WaveformInput
+
+            n_ge, len_ge = 131072, 8192
+            wf_g = DeviceArray((n_ge, len_ge), np.int16)
+            bl_g, tp_g = DeviceArray((n_ge,), np.float32), DeviceArray((n_ge,), np.float32)
+            _lib.check(L.dsp_synth_waveforms(wf_g.ptr, _lib.I16, n_ge, len_ge, len_ge, bl_g.ptr, tp_g.ptr, SEED, 0, TAU, SIGMA, 625 + 0.8 * 188,
+                                             -3000.0, 3000.0, 500.0, 15000.0, synth_stream.ptr), what="synth")
+            synth_stream.sync()
+            tb_g = {"waveform": WaveformInput(wf_g, 16.0, 48000.0), "baseline": bl_g}
+            chain_g, _, _ = build_processing_chain(recipes.ICPC, tb_g)
+            chain_g.link(tb_g, {k: DeviceArray((n_ge,), np.float32) for k in recipes.ICPC["outputs"]})
+            g0, g1 = Event(), Event()
+            n_pass = 10
+            for k in range(3 + n_pass):
+                if k == 3:
+                    g0.record(chain_g.stream)
+                chain_g.execute()
+            g1.record(chain_g.stream)
+            sync()
+            ms_g = g0.elapsed_ms(g1) / n_pass
+            ge = {"workload": f"tests/recipes.py ICPC ({len(recipes.ICPC['outputs'])} outputs) on {n_ge} x {len_ge} int16 rows, device-resident, through build_processing_chain",
+                  "ms_per_pass": ms_g, "waveforms_per_s": n_ge / (ms_g * 1e-3), "passes": n_pass, "kernels": [k for _what, k in chain_g.kernels()]}
+            del chain_g, wf_g
+        except Exception as exc:
+            print(f"[bench] Ge-recipe measurement skipped: {exc}", file=sys.stderr)
+
     cpu = None
     if not args.no_cpu:  # rank 0, for every N: the other ranks have left, the timed region is over
         t = time.perf_counter()
@@ -431,6 +467,7 @@ def worker(args) -> int:
                      "kernel_ms_avg_per_rank_max": float(np.max(rank_kernel_ms)), "measured_stream_read_GBps": stream_gbps,
                      "frac_of_measured_stream_read": (achieved / stream_gbps) if stream_gbps else None, "raw_chain": raw},
         "cpu_baseline": cpu,
+        "ge_recipe": ge,
         "parity_max_rel_vs_oracle": parity,
         "parity_bar": PARITY_BAR,
     }

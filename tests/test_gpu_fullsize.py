@@ -194,3 +194,42 @@ def test_c5_one_million_int16_rows():
     assert rc == 0 and np.array_equal(o1["tp_0"].to_numpy()[idx], tp0, equal_nan=True) and np.isfinite(tp0).mean() > 0.2
     dwt = oracle.dwt_haar(dpz, 5, "a", 256)[0]
     assert np.array_equal(_rows(o1["dwt_haar"], idx), dwt)
+
+
+def test_ge_recipe_on_the_measured_batch():
+    """the whole Ge recipe on the batch its rate is quoted on (131 072 int16 rows of 8192 samples, device-resident): every kernel of the pass
+    walks the batch in rounds of persistent workgroups whose count follows from the batch, so the same rows are run (a) in one launch, (b) in
+    two uneven pieces, (c) a sample of them -- first, last, the rows either side of the pieces' seam, a stride through the rest -- as a batch of
+    their own; all outputs bit for bit the same.  What the outputs ARE is checked against the oracle on small batches
+    (test_gpu_icpc_recipe.py); this ties the full batch to those."""
+    from dspeed_amd.device import DeviceArray
+    from dspeed_amd.processing_chain import WaveformInput, build_processing_chain
+
+    n, cut = 131_072, 70_001
+    wf, bl, _ = _synth(n, 8192, dtype=np.int16, bl=(-3000.0, 3000.0))
+    tb = {"waveform": WaveformInput(wf, 16.0, 48000.0), "baseline": bl}
+    names = list(recipes.ICPC["outputs"])
+    chain, _, _ = build_processing_chain(recipes.ICPC, tb)
+    o1 = {k: DeviceArray((n,), np.float32) for k in names}
+    chain.link(tb, o1)
+    chain.execute()
+    one = {k: o1[k].to_numpy() for k in names}
+    o2 = {k: DeviceArray((n,), np.float32) for k in names}
+    chain.link(tb, o2)
+    chain.execute(0, cut)
+    chain.execute(cut, n)
+    for k in names:
+        assert np.array_equal(one[k], o2[k].to_numpy(), equal_nan=True), k
+    idx = np.array(sorted({0, 1, 3, 4, 63, 64, cut - 1, cut, n - 2, n - 1} | set(range(17, n, 1021))))
+    small = {"waveform": WaveformInput(DeviceArray.from_numpy(_rows(wf, idx)), 16.0, 48000.0), "baseline": DeviceArray.from_numpy(bl.to_numpy()[idx])}
+    chain_s, _, _ = build_processing_chain(recipes.ICPC, small)
+    o3 = {k: DeviceArray((len(idx),), np.float32) for k in names}
+    chain_s.link(small, o3)
+    chain_s.execute()
+    for k in names:
+        assert np.array_equal(one[k][idx], o3[k].to_numpy(), equal_nan=True), k
+    # the batch is pulses (one-sample steps: most rise-time walks find no crossing and say NaN): the energies are there, and where two
+    # rise-time points exist they are ordered
+    assert np.isfinite(one["trapEmax"]).all() and (one["trapEmax"] > 100.0).mean() > 0.9
+    ok = np.isfinite(one["tp_10"]) & np.isfinite(one["tp_90"])
+    assert (one["tp_10"][ok] <= one["tp_90"][ok]).all()
