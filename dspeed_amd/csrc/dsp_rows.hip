@@ -240,14 +240,6 @@ __device__ __forceinline__ void rows_produce(const ROWS_KARG RowsArgs& A, ROWS_L
 // TPT: 0 none, 1 walk backward from a known start, 2 backward from the running arg-extremum, 3 forward from a known start,
 //      4 forward from the running arg-extremum
 // ------------------------------------------------------------------------------------------------------------------------------
-// x / d for a positive integer-valued d: div_by_count's three operations, with the special cases (an infinite or NaN x) restored by the
-// hardware's own division fix-up instead of a compare and two selects
-__device__ __forceinline__ double div_by_count_fx(double x, double d, double inv_d) {
-    const double q = x * inv_d;
-    const double r = __builtin_fma(-q, d, x);
-    return __builtin_amdgcn_div_fixup(__builtin_fma(r, inv_d, q), d, x);
-}
-
 template <int TRAP, bool RPOW2, int TPT, bool STOP>
 __device__ __forceinline__ void rows_consume(const ROWS_KARG RowsArgs& A, ROWS_LDS float* ring, int64_t n_wf, int* err) {
     const int lane = lane_id();

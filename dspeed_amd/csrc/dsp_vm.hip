@@ -660,7 +660,12 @@ __device__ __forceinline__ void op_double_pole_zero(Ctx<T>& cx, const DSP_PROG D
 //        ASYM         L1 = rise, L2 = rise+flat, L3 = rise+flat+fall
 // ic: 0..2 lags, 3..5 q_k = L_k / C, 6..8 rho_k = L_k % C;  fc: 0 rise, 1 fall
 // ------------------------------------------------------------------------------------------------
+#ifndef VM_FULL_AMAX
+#define VM_FULL_AMAX 1  // (0: A/B builds without the maximum-only replay of full rows)
+#endif
 constexpr int TRAP_NCAP = 4;
+__device__ __forceinline__ float keep_larger(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double keep_larger(double a, double b) { return __builtin_fmax(a, b); }
 
 // Runs the trap emulation over slot `ss`.  If STORE, writes the filtered waveform into slot `sd` (must differ from ss).
 // cap_idx[c] (uniform, -1 = unused): sample indices whose filtered value is wanted; returned in cap_val[c] (uniform).
@@ -669,6 +674,8 @@ constexpr int TRAP_NCAP = 4;
 // corrected values is the corrected extreme), the threshold walk is a second replay comparing consecutive corrected samples.
 // RED = 2: only the maximum is wanted (numpy.amax of the trapezoid): one compare per sample instead of two extremes with their indices.
 // RED = 3: only the threshold walk is wanted (no min_max registers): the first replay tracks nothing, it just yields the carries.
+// RED = 4: as 2 on rows that fill their chunks (len = 64 C: every index is a sample): one v_max per sample -- a NaN never replaces the
+// running maximum in either form; the two differ in the sign of a maximum that is zero.
 template <typename T, int KIND, bool STORE, int RED = 0>
 __device__ __forceinline__ void trap_core(Ctx<T>& cx, const DSP_PROG DevOp& op, const DSP_PROG DevSlot& ss, const DSP_PROG DevSlot& sd, const int* cap_idx, T* cap_val) {
     const int C = ss.C, lane = lane_id();
@@ -762,7 +769,9 @@ __device__ __forceinline__ void trap_core(Ctx<T>& cx, const DSP_PROG DevOp& op, 
             for (int u = t; u < nb; ++u) {
                 y = trap_step_r<T, KIND>(y, ps[u], l0[u], l1[u], l2[u], rr, ll, inv_rr, inv_ll);
                 if (STORE) pd[u] = y;
-                if (RED == 2) {
+                if (RED == 4) {
+                    vmax = keep_larger(vmax, y);
+                } else if (RED == 2) {
                     vmax = (i_first + u < n_valid && y > vmax) ? y : vmax;
                 } else if (RED == 1) {  // (selects, no branches: strict comparisons keep the first occurrence)
                     const int idx = i_first + u;
@@ -794,7 +803,7 @@ __device__ __forceinline__ void trap_core(Ctx<T>& cx, const DSP_PROG DevOp& op, 
         const T v = (T)((double)capv[c] + delta);
         cap_val[c] = cap_lane[c] >= 0 ? readlane(v, cap_lane[c]) : (T)0;
     }
-    if constexpr (RED == 2) {
+    if constexpr (RED == 2 || RED == 4) {
         T cmax = vmax != -__builtin_huge_val() ? (T)((double)vmax + delta) : vmax;
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) {
@@ -925,7 +934,12 @@ __device__ __forceinline__ void op_trap_reduce(Ctx<T>& cx, const DSP_PROG DevOp&
             }
         }
     }
-    if (amax_only && kind == DSP_OP_TRAP_FILTER)
+    const bool full = VM_FULL_AMAX && ss.len == 64 * ss.C;  // (every Ge recipe's rows: 8192 = 64 x 128)
+    if (amax_only && kind == DSP_OP_TRAP_FILTER && full)
+        trap_core<T, TRAP_FILTER, false, 4>(cx, op, ss, ss, idx, w4);
+    else if (amax_only && kind == DSP_OP_TRAP_NORM && full)
+        trap_core<T, TRAP_NORM, false, 4>(cx, op, ss, ss, idx, w4);
+    else if (amax_only && kind == DSP_OP_TRAP_FILTER)
         trap_core<T, TRAP_FILTER, false, 2>(cx, op, ss, ss, idx, w4);
     else if (amax_only && kind == DSP_OP_TRAP_NORM)
         trap_core<T, TRAP_NORM, false, 2>(cx, op, ss, ss, idx, w4);

@@ -111,6 +111,13 @@ __device__ __forceinline__ double div_by_count(double x, double d, double inv_d)
     const double c = __builtin_fma(r, inv_d, q);
     return (__builtin_fabs(q) <= 1.7976931348623157e308) ? c : q;  // +-inf / NaN: the residual is NaN, x * (1/d) already has the result
 }
+// the same with the special cases (an infinite or NaN x, whose residual is NaN; the sign of a zero) restored by the hardware's own division
+// fix-up instead of a compare and two selects: one instruction for three in the trapezoids' per-sample step
+__device__ __forceinline__ double div_by_count_fx(double x, double d, double inv_d) {
+    const double q = x * inv_d;
+    const double r = __builtin_fma(-q, d, x);
+    return __builtin_amdgcn_div_fixup(__builtin_fma(r, inv_d, q), d, x);
+}
 
 template <typename T, int KIND>
 __device__ __forceinline__ T trap_step(T y, T a, T b1, T b2, T b3, double rr, double ll) {
@@ -132,13 +139,13 @@ __device__ __forceinline__ T trap_step_r(T y, T a, T b1, T b2, T b3, double rr, 
         return (((y + a) - b1) - b2) + b3;
     } else if (KIND == TRAP_NORM) {
         const T e = ((a - b1) - b2) + b3;
-        return (T)((double)y + div_by_count((double)e, rr, inv_rr));
+        return (T)((double)y + div_by_count_fx((double)e, rr, inv_rr));
     } else if (KIND == TRAP_ASYM_P2) {  // rise is a power of two (the usual 128 ns at 16 ns): e1 * (1 / rise) IS the correctly rounded quotient
         const T e1 = a - b1, e2 = b2 - b3;
-        return (T)(((double)y + (double)e1 * inv_rr) - div_by_count((double)e2, ll, inv_ll));
+        return (T)(((double)y + (double)e1 * inv_rr) - div_by_count_fx((double)e2, ll, inv_ll));
     } else {
         const T e1 = a - b1, e2 = b2 - b3;
-        return (T)(((double)y + div_by_count((double)e1, rr, inv_rr)) - div_by_count((double)e2, ll, inv_ll));
+        return (T)(((double)y + div_by_count_fx((double)e1, rr, inv_rr)) - div_by_count_fx((double)e2, ll, inv_ll));
     }
 }
 
