@@ -372,9 +372,9 @@ def worker(args) -> int:
             chain_g, _, _ = build_processing_chain(recipes.ICPC, tb_g)
             chain_g.link(tb_g, {k: DeviceArray((n_ge,), np.float32) for k in recipes.ICPC["outputs"]})
             g0, g1 = Event(), Event()
-            n_pass = 10
-            for k in range(3 + n_pass):
-                if k == 3:
+            n_pass = 20
+            for k in range(5 + n_pass):
+                if k == 5:
                     g0.record(chain_g.stream)
                 chain_g.execute()
             g1.record(chain_g.stream)
