@@ -20,9 +20,11 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// lanes without a source get 0: with all rows written the hardware's own zero fill (bound_ctrl) -- no register to clear first --, with a
+// row mask the "old" value 0 of the rows that are not written
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ int dpp0(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
 }
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float dpp0(float v) {
